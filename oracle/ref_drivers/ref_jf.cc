@@ -1,0 +1,314 @@
+// oracle/ref_drivers/ref_jf.cc -- TEST INFRASTRUCTURE, not product code.
+//
+// A thin driver around the *reference's own classes* (headers + lib/*.cc compiled
+// in place from /root/reference by oracle/Makefile; nothing is copied).  It
+// exists because the reference CLI cannot be built here: every sub-command
+// includes a yaggo-generated *_cmdline.hpp and yaggo is absent.  The driver
+// wires the classes together the same way the reference mains do:
+//   count : sub_commands/count_main.cc:142-184,275-284,331-355
+//   dump  : sub_commands/dump_main.cc:36-88
+//   histo : sub_commands/histo_main.cc:34-90
+//   stats : sub_commands/stats_main.cc:33-79
+//   query : sub_commands/query_main.cc:44-123
+// so its outputs ARE the reference's outputs for the hot path.  Only tests/,
+// __graft_entry__.smoke() and bench.py's cpu_baseline leg may execute it.
+#include <config.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <chrono>
+#include <fstream>
+#include <iostream>
+#include <limits>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include <jellyfish/err.hpp>
+#include <jellyfish/thread_exec.hpp>
+#include <jellyfish/hash_counter.hpp>
+#include <jellyfish/stream_manager.hpp>
+#include <jellyfish/mer_overlap_sequence_parser.hpp>
+#include <jellyfish/mer_iterator.hpp>
+#include <jellyfish/mapped_file.hpp>
+#include <jellyfish/jellyfish.hpp>
+
+using jellyfish::mer_dna;
+typedef std::vector<const char*>                                         file_vector;
+typedef jellyfish::stream_manager<file_vector::const_iterator>           stream_manager_type;
+typedef jellyfish::mer_overlap_sequence_parser<stream_manager_type>      sequence_parser;
+typedef jellyfish::mer_iterator<sequence_parser, mer_dna>                mer_iterator_type;
+
+static double now_s() {
+  using namespace std::chrono;
+  return duration_cast<duration<double>>(steady_clock::now().time_since_epoch()).count();
+}
+
+// Same loop body as mer_counter_base::start (COUNT op, default filter).
+class ref_counter : public jellyfish::thread_exec {
+  mer_hash&       ary_;
+  sequence_parser parser_;
+  bool            canonical_;
+public:
+  std::vector<size_t> counts_;
+  ref_counter(int nb_threads, mer_hash& ary, stream_manager_type& streams, bool canonical)
+    : ary_(ary), parser_(mer_dna::k(), streams.nb_streams(), 3 * nb_threads, 4096, streams),
+      canonical_(canonical), counts_(nb_threads, 0) { ary_.reset_done(); }
+  virtual void start(int thid) {
+    size_t count = 0;
+    for(mer_iterator_type mers(parser_, canonical_); mers; ++mers) {
+      ary_.add(*mers, 1);
+      ++count;
+    }
+    counts_[thid] = count;
+    ary_.done();
+  }
+};
+
+static uint64_t parse_size(const char* s) {  // yaggo "suffix": k/M/G/T = powers of 1000
+  char* end;
+  double v = strtod(s, &end);
+  switch(*end) {
+  case 'k': v *= 1e3; break;  case 'M': v *= 1e6; break;
+  case 'G': v *= 1e9; break;  case 'T': v *= 1e12; break;
+  default: break;
+  }
+  return (uint64_t)v;
+}
+
+static int do_count(int argc, char* argv[]) {
+  unsigned    k = 0, threads = 1, counter_len = 7, reprobes = 126, out_counter_len = 4, Files = 1;
+  uint64_t    size = 0, lower = 0, upper = std::numeric_limits<uint64_t>::max();
+  bool        canonical = false, text = false, no_write = false, lower_given = false, upper_given = false;
+  const char* output = "mer_counts.jf";
+  const char* timing = 0;
+  file_vector files;
+  for(int i = 1; i < argc; ++i) {
+    std::string a(argv[i]);
+    auto next = [&]() -> const char* { if(i + 1 >= argc) { std::cerr << "missing value for " << a << "\n"; exit(1); } return argv[++i]; };
+    if(a == "-m") k = atoi(next());
+    else if(a == "-s") size = parse_size(next());
+    else if(a == "-t") threads = atoi(next());
+    else if(a == "-c") counter_len = atoi(next());
+    else if(a == "-p") reprobes = atoi(next());
+    else if(a == "-F") Files = atoi(next());
+    else if(a == "--out-counter-len") out_counter_len = atoi(next());
+    else if(a == "-o") output = next();
+    else if(a == "-L") { lower = strtoull(next(), 0, 10); lower_given = true; }
+    else if(a == "-U") { upper = strtoull(next(), 0, 10); upper_given = true; }
+    else if(a == "-C") canonical = true;
+    else if(a == "--text") text = true;
+    else if(a == "--no-write") no_write = true;
+    else if(a == "--timing") timing = next();
+    else files.push_back(argv[i]);
+  }
+  if(!k || !size || files.empty()) {
+    std::cerr << "usage: ref_jf count -m K -s SIZE [-t T] [-C] [-c bits] [-p reprobes] [--out-counter-len B] [-o out] [-L l] [-U u] [--text] [--timing f] [--no-write] files...\n";
+    return 1;
+  }
+  double t0 = now_s();
+  jellyfish::file_header header;
+  header.fill_standard();
+  header.set_cmdline(argc, argv);
+  mer_dna::k(k);
+  header.canonical(canonical);
+  mer_hash ary(size, k * 2, counter_len, threads, reprobes);
+  std::unique_ptr<jellyfish::dumper_t<mer_array> > dumper;
+  if(text) dumper.reset(new text_dumper(threads, output, &header));
+  else     dumper.reset(new binary_dumper(out_counter_len, ary.key_len(), threads, output, &header));
+  ary.dumper(dumper.get());
+  double t1 = now_s();
+
+  stream_manager_type streams(Files);
+  streams.paths(files.begin(), files.end());
+  ref_counter counter(threads, ary, streams, canonical);
+  counter.exec_join(threads);
+  double t2 = now_s();
+  size_t total = 0;
+  for(size_t c : counter.counts_) total += c;
+
+  if(!no_write) {
+    dumper->one_file(true);
+    if(lower_given) dumper->min(lower);
+    if(upper_given) dumper->max(upper);
+    dumper->dump(ary.ary());
+  }
+  double t3 = now_s();
+  if(timing) {
+    std::ofstream tf(timing);
+    tf << "Init     " << (t1 - t0) << "\n"
+       << "Counting " << (t2 - t1) << "\n"
+       << "Writing  " << (t3 - t2) << "\n"
+       << "Mers     " << total << "\n";
+  }
+  return 0;
+}
+
+static bool open_db(const char* path, std::ifstream& is, jellyfish::file_header& header) {
+  is.open(path);
+  if(!is.good()) { std::cerr << "Failed to open '" << path << "'\n"; return false; }
+  if(!header.read(is)) { std::cerr << "Failed to parse header of '" << path << "'\n"; return false; }
+  mer_dna::k(header.key_len() / 2);
+  return true;
+}
+
+template<typename Reader>
+static void dump_loop(Reader& r, bool column, char spacer, uint64_t lower, uint64_t upper) {
+  while(r.next()) {
+    if(r.val() < lower || r.val() > upper) continue;
+    if(column) std::cout << r.key() << spacer << r.val() << "\n";
+    else       std::cout << ">" << r.val() << "\n" << r.key() << "\n";
+  }
+}
+
+// dump [-c] [-t] [-L l] [-U u] db   (dump_main.cc:36-52)
+static int do_dump(int argc, char* argv[]) {
+  bool column = false, tab = false, check_order = false;
+  uint64_t lower = 0, upper = std::numeric_limits<uint64_t>::max();
+  const char* db = 0;
+  for(int i = 1; i < argc; ++i) {
+    std::string a(argv[i]);
+    if(a == "-c") column = true; else if(a == "-t") tab = true;
+    else if(a == "--check-order") check_order = true;
+    else if(a == "-L") lower = strtoull(argv[++i], 0, 10);
+    else if(a == "-U") upper = strtoull(argv[++i], 0, 10);
+    else db = argv[i];
+  }
+  if(!db) return 1;
+  std::ios::sync_with_stdio(false);
+  if(check_order) {
+    // Structural validity as the reference's own readers need it: strictly
+    // ascending (pos, key) under the header's matrix (mer_heap.hpp:26-30).
+    std::ifstream is; jellyfish::file_header header;
+    if(!open_db(db, is, header)) return 1;
+    binary_reader reader(is, &header);
+    bool first = true; uint64_t ppos = 0; mer_dna pkey; uint64_t n = 0;
+    while(reader.next()) {
+      uint64_t pos = reader.pos();
+      if(!first && (pos < ppos || (pos == ppos && !(pkey < reader.key())))) {
+        std::cout << "ORDER VIOLATION at record " << n << "\n"; return 2;
+      }
+      ppos = pos; pkey = reader.key(); first = false; ++n;
+    }
+    std::cout << "ORDER OK " << n << "\n";
+    return 0;
+  }
+  char spacer = tab ? '\t' : ' ';
+  std::ifstream is; jellyfish::file_header header;
+  if(!open_db(db, is, header)) return 1;
+  if(header.format() == binary_dumper::format)    { binary_reader r(is, &header); dump_loop(r, column, spacer, lower, upper); }
+  else if(header.format() == text_dumper::format) { text_reader r(is, &header);   dump_loop(r, column, spacer, lower, upper); }
+  else { std::cerr << "Unknown format '" << header.format() << "'\n"; return 1; }
+  return 0;
+}
+
+template<typename Reader>
+static void histo_loop(Reader& reader, uint64_t base, uint64_t ceil, uint64_t inc, std::vector<uint64_t>& histo) {
+  while(reader.next()) {
+    if(reader.val() < base)      ++histo[0];
+    else if(reader.val() > ceil) ++histo[histo.size() - 1];
+    else                         ++histo[(reader.val() - base) / inc];
+  }
+}
+
+// histo [-l low] [-h high] [-i inc] [-f] db   (histo_main.cc:47-90)
+static int do_histo(int argc, char* argv[]) {
+  uint64_t low = 1, high = 10000, incr = 1; bool full = false; const char* db = 0;
+  for(int i = 1; i < argc; ++i) {
+    std::string a(argv[i]);
+    if(a == "-l") low = strtoull(argv[++i], 0, 10);
+    else if(a == "-h") high = strtoull(argv[++i], 0, 10);
+    else if(a == "-i") incr = strtoull(argv[++i], 0, 10);
+    else if(a == "-f") full = true;
+    else db = argv[i];
+  }
+  if(!db) return 1;
+  std::ifstream is; jellyfish::file_header header;
+  if(!open_db(db, is, header)) return 1;
+  const uint64_t base = incr >= low ? 0 : low - incr;
+  const uint64_t ceil = high + incr;
+  const uint64_t nb_buckets = (ceil + incr - base) / incr;
+  std::vector<uint64_t> histo(nb_buckets, 0);
+  if(header.format() == binary_dumper::format) { binary_reader r(is, &header); histo_loop(r, base, ceil, incr, histo); }
+  else                                         { text_reader r(is, &header);   histo_loop(r, base, ceil, incr, histo); }
+  uint64_t col = base;
+  for(uint64_t i = 0; i < nb_buckets; ++i, col += incr)
+    if(histo[i] > 0 || full) std::cout << col << " " << histo[i] << "\n";
+  return 0;
+}
+
+// stats db   (stats_main.cc:33-79)
+static int do_stats(int argc, char* argv[]) {
+  uint64_t low = 0, high = std::numeric_limits<uint64_t>::max(); const char* db = 0;
+  for(int i = 1; i < argc; ++i) {
+    std::string a(argv[i]);
+    if(a == "-L") low = strtoull(argv[++i], 0, 10);
+    else if(a == "-U") high = strtoull(argv[++i], 0, 10);
+    else db = argv[i];
+  }
+  if(!db) return 1;
+  std::ifstream is; jellyfish::file_header header;
+  if(!open_db(db, is, header)) return 1;
+  uint64_t uniq = 0, distinct = 0, total = 0, max = 0;
+  binary_reader reader(is, &header);
+  while(reader.next()) {
+    if(reader.val() < low || reader.val() > high) continue;
+    uniq += reader.val() == 1; total += reader.val();
+    max = std::max(max, reader.val()); ++distinct;
+  }
+  std::cout << "Unique:    " << uniq << "\n" << "Distinct:  " << distinct << "\n"
+            << "Total:     " << total << "\n" << "Max_count: " << max << "\n";
+  return 0;
+}
+
+// query db mer...   (query_main.cc:56-70,104-115) -- random access through the
+// reference's binary_query (interpolation search on the header's matrix).
+static int do_query(int argc, char* argv[]) {
+  if(argc < 2) return 1;
+  const char* db = argv[1];
+  std::ifstream in(db, std::ios::in | std::ios::binary);
+  jellyfish::file_header header(in);
+  if(!in.good()) { std::cerr << "Failed to parse header\n"; return 1; }
+  mer_dna::k(header.key_len() / 2);
+  jellyfish::mapped_file binary_map(db);
+  binary_query bq(binary_map.base() + header.offset(), header.key_len(), header.counter_len(), header.matrix(),
+                  header.size() - 1, binary_map.length() - header.offset());
+  mer_dna m;
+  auto one = [&](const std::string& s) {
+    try {
+      m = s;
+      if(header.canonical()) m.canonicalize();
+      std::cout << m << " " << bq.check(m) << "\n";
+    } catch(std::length_error& e) { std::cerr << "Invalid mer '" << s << "'\n"; }
+  };
+  if(argc == 2) { std::string line; while(std::getline(std::cin, line)) one(line); }
+  for(int i = 2; i < argc; ++i) one(argv[i]);
+  return 0;
+}
+
+// header db : print the JSON header (info_main.cc --json equivalent)
+static int do_header(int argc, char* argv[]) {
+  if(argc < 2) return 1;
+  std::ifstream is; jellyfish::file_header header;
+  if(!open_db(argv[1], is, header)) return 1;
+  std::cout << header.root().toStyledString();
+  return 0;
+}
+
+int main(int argc, char* argv[]) {
+  if(argc < 2) { std::cerr << "usage: ref_jf <count|dump|histo|stats|query|header> ...\n"; return 1; }
+  std::string cmd(argv[1]);
+  try {
+    if(cmd == "count")  return do_count(argc - 1, argv + 1);
+    if(cmd == "dump")   return do_dump(argc - 1, argv + 1);
+    if(cmd == "histo")  return do_histo(argc - 1, argv + 1);
+    if(cmd == "stats")  return do_stats(argc - 1, argv + 1);
+    if(cmd == "query")  return do_query(argc - 1, argv + 1);
+    if(cmd == "header") return do_header(argc - 1, argv + 1);
+  } catch(std::exception& e) {
+    std::cerr << "ref_jf: " << e.what() << "\n";
+    return 1;
+  }
+  std::cerr << "unknown command " << cmd << "\n";
+  return 1;
+}
