@@ -1,0 +1,186 @@
+/* include/jfgpu.h -- C ABI of the MI355X-native k-mer counting engine (libjfgpu.so).
+ *
+ * This is the drop-in boundary for the `jellyfish count` hot path.  The
+ * reference (gmarcais/Jellyfish, /root/reference) has no FFI: its seam is the C++
+ * template API `jellyfish::cooperative::hash_counter<mer_dna>` plus the
+ * binary/sorted file format.  Each entry point below names the reference
+ * interface (file:line relative to /root/reference) it stands in for; the C++
+ * facade in jellyfish_amd/include/jellyfish_amd/ and the `jellyfish-amd` CLI sit
+ * on top of exactly these functions.
+ *
+ * Conventions
+ *  - plain C: opaque handle, pointers + sizes, int return codes (0 = ok), no
+ *    exceptions cross the boundary; jfgpu_last_error() gives the message the
+ *    reference would have thrown (e.g. "Hash full", hash_counter.hpp:194-195).
+ *  - k-mers are arrays of ceil(k/32) little-endian uint64 words, word 0 least
+ *    significant, base i of the string (0 = leftmost) at bits 2(k-1-i), A=0 C=1
+ *    G=2 T=3 -- the in-memory layout of mer_dna (mer_dna.hpp:143-155,526-542),
+ *    i.e. what mer_dna::data() returns and binary_writer writes.
+ *  - buffers are host pointers unless the function name ends in _dev (then the
+ *    pointer is device memory on the table's GPU, e.g. a torch tensor's
+ *    data_ptr()).  All work is enqueued on the table's HIP stream; functions that
+ *    return results to the host synchronise that stream.
+ *  - the engine needs a gfx950 GPU.  There is no CPU fallback: every call fails
+ *    with JFGPU_E_NO_DEVICE when no HIP device is usable.
+ */
+#ifndef JFGPU_H
+#define JFGPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JFGPU_ABI_VERSION 1
+
+enum {
+  JFGPU_OK = 0,
+  JFGPU_E_INVALID = 1,    /* bad argument (std::length_error / out_of_range in the reference) */
+  JFGPU_E_NO_DEVICE = 2,  /* no usable HIP device / kernel image */
+  JFGPU_E_ALLOC = 3,      /* large_hash::array::ErrorAllocation, large_hash_array.hpp:55,169-172 */
+  JFGPU_E_FULL = 4,       /* std::runtime_error("Hash full"), hash_counter.hpp:194-195 */
+  JFGPU_E_HIP = 5,        /* HIP runtime error */
+  JFGPU_E_UNSUPPORTED = 6 /* feature not built yet (e.g. k > 32) */
+};
+
+typedef struct jfgpu_table jfgpu_table; /* opaque: one hash shard resident in one GPU's HBM */
+
+/* Parameters of a table.  Mirrors the ctor of hash_counter / large_hash::array
+ * (hash_counter.hpp:56-64, large_hash_array.hpp:992-1001) minus the CPU-only knobs
+ * (nb_threads, reprobe schedule: the in-memory probing is never serialised). */
+typedef struct jfgpu_params {
+  uint32_t k;            /* mer length; key_len = 2k bits.  1..32 today */
+  uint32_t canonical;    /* count_main.cc -C: count min(mer, revcomp) */
+  uint64_t size;         /* requested GLOBAL number of slots (hint: rounded up to a power of
+                            two, capped at 4^k, raised to the engine minimum for large k) */
+  int32_t  device;       /* HIP device ordinal, -1 = current device */
+  uint32_t shard_bits;   /* log2(number of shards).  Shard s owns global positions whose top
+                            shard_bits bits equal s; 0 = single GPU */
+  uint32_t shard_id;     /* which shard this table is */
+  uint64_t matrix_seed;  /* seed of the random GF(2) hash matrix; 0 = engine default.
+                            All shards of one job must use the same seed */
+  const uint64_t* matrix_columns; /* optional explicit matrix: 2k columns in file-header order
+                            (file_header.hpp:35-64), r = log2(global size) rows; its low r x r
+                            block must be invertible.  NULL = random from matrix_seed */
+  uint32_t out_counter_len; /* bytes per count in dumps (binary_dumper ctor val_len,
+                            count_main_cmdline.yaggo --out-counter-len); 0 = 4 */
+  uint32_t reserved;
+} jfgpu_params;
+
+/* Geometry + matrix actually used, for file_header::update_from_ary (file_header.hpp:25-33). */
+typedef struct jfgpu_info {
+  uint32_t k, key_len;       /* key_len = 2k */
+  uint32_t canonical;
+  uint32_t lsize;            /* log2(global size) = rows of the matrix */
+  uint64_t size;             /* global number of slots (power of two) -> header "size" */
+  uint64_t local_size;       /* slots held by this shard */
+  uint32_t shard_bits, shard_id;
+  uint32_t val_len;          /* bits of the in-slot count field -> header "val_len" */
+  uint32_t slot_bytes;       /* 8 */
+  uint32_t tile_slots;       /* probe domain (slots) */
+  uint32_t matrix_identity;  /* 1 when size == 4^k (large_hash_array.hpp:997-1000) */
+  uint32_t out_counter_len;
+  uint32_t max_reprobe;      /* informational header fields (merge_files.cc:128,145-146) */
+  uint64_t table_bytes;
+} jfgpu_info;
+
+typedef struct jfgpu_stats {
+  uint64_t unique;     /* k-mers with count 1            (stats_main.cc:41) */
+  uint64_t distinct;   /* number of different k-mers     (:44) */
+  uint64_t total;      /* sum of counts                  (:42) */
+  uint64_t max_count;  /*                                (:43) */
+  uint64_t occupied;   /* slots in use (== distinct) */
+  uint64_t mers_fed;   /* k-mer occurrences accepted by jfgpu_count_* so far */
+} jfgpu_stats;
+
+const char* jfgpu_last_error(void);       /* thread-local message of the last failing call */
+int  jfgpu_abi_version(void);
+int  jfgpu_device_count(void);            /* usable HIP devices (0 => nothing will work) */
+
+/* hash_counter ctor / dtor (hash_counter.hpp:56-68). */
+int  jfgpu_create(const jfgpu_params* params, jfgpu_table** out);
+void jfgpu_destroy(jfgpu_table* t);
+int  jfgpu_get_info(const jfgpu_table* t, jfgpu_info* out);
+/* matrix() (large_hash_array.hpp:211): 2k columns, file-header order. */
+int  jfgpu_get_matrix(const jfgpu_table* t, uint64_t* columns /* [2k] */);
+/* array::clear() (large_hash_array.hpp:224-226). */
+int  jfgpu_clear(jfgpu_table* t);
+/* Block until everything enqueued so far has retired; reports a deferred
+ * "Hash full" (the device cannot throw mid-kernel). == every thread called
+ * hash_counter::done() (hash_counter.hpp:169-172). */
+int  jfgpu_sync(jfgpu_table* t);
+
+/* ---- the hot path ------------------------------------------------------ */
+/* mer_counter_base::start COUNT loop (sub_commands/count_main.cc:152-163) over one
+ * parser-contract buffer (mer_overlap_sequence_parser.hpp:161-185: sequence
+ * characters, any byte outside [ACGTacgt] resets the window, k-mers do not span
+ * calls): encode (mer_iterator.hpp:53-81) -> canonical (:51) -> hash
+ * (rectangular_binary_matrix.hpp:155-164) -> insert/increment
+ * (large_hash_array.hpp:291-295,509-597,741-752).  Asynchronous. */
+int  jfgpu_count_ascii_dev(jfgpu_table* t, const char* d_bases, size_t n);
+int  jfgpu_count_ascii(jfgpu_table* t, const char* bases, size_t n);      /* host buffer (staged H2D) */
+
+/* hash_counter::add(key, val) for a batch of already-encoded k-mers
+ * (hash_counter.hpp:122-126; SWIG HashCounter.add swig/hash_counter.i:13-27).
+ * is_new (optional, n bytes) receives 1 where the key was not present. */
+int  jfgpu_add_keys_dev(jfgpu_table* t, const uint64_t* d_keys, size_t n, uint64_t val, uint8_t* d_is_new);
+int  jfgpu_add_keys(jfgpu_table* t, const uint64_t* keys, size_t n, uint64_t val, uint8_t* is_new);
+
+/* array::get_val_for_key (large_hash_array.hpp:354-372) for a batch.  vals[i] = 0 and
+ * found[i] = 0 when absent.  Keys must already be canonical if the table is. */
+int  jfgpu_lookup_dev(jfgpu_table* t, const uint64_t* d_keys, size_t n, uint64_t* d_vals, uint8_t* d_found);
+int  jfgpu_lookup(jfgpu_table* t, const uint64_t* keys, size_t n, uint64_t* vals, uint8_t* found);
+
+/* ---- multi-GPU: hash-prefix partition --------------------- */
+/* Encode + canonicalise + hash one contract buffer and bucket the k-mers by owning
+ * shard instead of inserting them.  d_keys_out has room for `capacity` keys; shard
+ * s's keys are written contiguously at d_keys_out + offsets[s] ... in arbitrary
+ * order, with counts[s] of them; offsets are the exclusive prefix sum of counts
+ * (so the buffer is densely packed and ready for an all-to-all-v).
+ * counts_out: host array [1 << shard_bits].  Synchronous. */
+int  jfgpu_partition_ascii_dev(jfgpu_table* t, const char* d_bases, size_t n,
+                               uint64_t* d_keys_out, size_t capacity, uint64_t* counts_out);
+
+/* ---- results path ------------------------------------------------------ */
+int  jfgpu_stats_compute(jfgpu_table* t, uint64_t lower, uint64_t upper, jfgpu_stats* out);
+/* histo_main.cc:34-45: histo[0] counts vals < base, histo[n-1] vals > ceil,
+ * else histo[(val-base)/inc]. */
+int  jfgpu_histo(jfgpu_table* t, uint64_t base, uint64_t ceil, uint64_t inc, uint64_t* histo, uint64_t nb_buckets);
+/* sorted_dumper + binary_writer (sorted_dumper.hpp:57-101, binary_dumper.hpp:36-40):
+ * produce this shard's records in ascending (pos, key) order, fixed width
+ * ceil(2k/8) key bytes + out_counter_len count bytes (saturated), filtered to
+ * lower <= count <= upper.  _begin returns the total record count; _next streams
+ * the records in order into a host buffer of `capacity_records` records (at least
+ * one tile = jfgpu_info.tile_slots), *n_read == 0 marks the end; whole tiles are
+ * sorted on the device, so every chunk is a contiguous piece of the file body. */
+int  jfgpu_dump_begin(jfgpu_table* t, uint64_t lower, uint64_t upper, uint64_t* n_records, uint32_t* record_bytes);
+int  jfgpu_dump_next(jfgpu_table* t, void* out, uint64_t capacity_records, uint64_t* n_read);
+int  jfgpu_dump_end(jfgpu_table* t);
+
+/* ---- measurement helpers (bench.py; not part of the reference surface) -- */
+/* Per-kernel HIP-event timing on the table's stream.  which: 0 count, 1 add_keys,
+ * 2 partition, 3 lookup.  Returns accumulated milliseconds and launches since the
+ * last reset. */
+int  jfgpu_profile_enable(jfgpu_table* t, int on);
+int  jfgpu_profile_get(jfgpu_table* t, int which, double* ms, uint64_t* launches, uint64_t* units);
+int  jfgpu_profile_reset(jfgpu_table* t);
+/* Synthetic reads: n_reads records of read_len uniform iid bases, each followed by
+ * one 'N' separator (the contract buffer the parser would produce for a FASTA of
+ * such reads); counter-based RNG so any slice is reproducible.  d_out needs
+ * n_reads * (read_len + 1) bytes.  first_read offsets the read index. */
+int  jfgpu_gen_reads_dev(jfgpu_table* t, char* d_out, uint64_t first_read, uint64_t n_reads, uint32_t read_len, uint64_t seed);
+/* Random-access roofline denominator: n independent 64-bit atomicAdds
+ * at uniformly random slots of this table's own memory (table must be cleared
+ * afterwards).  Returns updates per second. */
+int  jfgpu_gups(jfgpu_table* t, uint64_t n_updates, int mode, double* updates_per_s);
+/* Raw device memory for callers without torch. */
+int  jfgpu_malloc_dev(jfgpu_table* t, size_t bytes, void** out);
+int  jfgpu_free_dev(jfgpu_table* t, void* p);
+int  jfgpu_memcpy_h2d(jfgpu_table* t, void* d_dst, const void* src, size_t bytes);
+int  jfgpu_memcpy_d2h(jfgpu_table* t, void* dst, const void* d_src, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JFGPU_H */

@@ -1,0 +1,286 @@
+"""ctypes binding of the C ABI in include/jfgpu.h (jellyfish_amd/lib/libjfgpu.so).
+
+This is plumbing for tests/ and bench.py: one Python method per C entry point, no
+logic of its own and NO fallback -- if the HIP library is missing or there is no
+GPU, calls raise.  The reference-shaped host API (mer_dna / hash_counter /
+file_header / dumpers) is the C++ facade under jellyfish_amd/include/.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libjfgpu.so")
+
+OK, E_INVALID, E_NO_DEVICE, E_ALLOC, E_FULL, E_HIP, E_UNSUPPORTED = range(7)
+
+
+class JfgpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"jfgpu error {code}: {msg}")
+        self.code = code
+        self.msg = msg
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("k", C.c_uint32), ("canonical", C.c_uint32), ("size", C.c_uint64), ("device", C.c_int32),
+        ("shard_bits", C.c_uint32), ("shard_id", C.c_uint32), ("matrix_seed", C.c_uint64),
+        ("matrix_columns", C.POINTER(C.c_uint64)), ("out_counter_len", C.c_uint32), ("reserved", C.c_uint32),
+    ]
+
+
+class Info(C.Structure):
+    _fields_ = [
+        ("k", C.c_uint32), ("key_len", C.c_uint32), ("canonical", C.c_uint32), ("lsize", C.c_uint32),
+        ("size", C.c_uint64), ("local_size", C.c_uint64), ("shard_bits", C.c_uint32), ("shard_id", C.c_uint32),
+        ("val_len", C.c_uint32), ("slot_bytes", C.c_uint32), ("tile_slots", C.c_uint32),
+        ("matrix_identity", C.c_uint32), ("out_counter_len", C.c_uint32), ("max_reprobe", C.c_uint32),
+        ("table_bytes", C.c_uint64),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [("unique", C.c_uint64), ("distinct", C.c_uint64), ("total", C.c_uint64),
+                ("max_count", C.c_uint64), ("occupied", C.c_uint64), ("mers_fed", C.c_uint64)]
+
+
+# name -> (restype, argtypes); also the list tests check against include/jfgpu.h
+_P = C.c_void_p
+SIGNATURES = {
+    "jfgpu_last_error": (C.c_char_p, []),
+    "jfgpu_abi_version": (C.c_int, []),
+    "jfgpu_device_count": (C.c_int, []),
+    "jfgpu_create": (C.c_int, [C.POINTER(Params), C.POINTER(_P)]),
+    "jfgpu_destroy": (None, [_P]),
+    "jfgpu_get_info": (C.c_int, [_P, C.POINTER(Info)]),
+    "jfgpu_get_matrix": (C.c_int, [_P, _P]),
+    "jfgpu_clear": (C.c_int, [_P]),
+    "jfgpu_sync": (C.c_int, [_P]),
+    "jfgpu_count_ascii_dev": (C.c_int, [_P, _P, C.c_size_t]),
+    "jfgpu_count_ascii": (C.c_int, [_P, _P, C.c_size_t]),
+    "jfgpu_add_keys_dev": (C.c_int, [_P, _P, C.c_size_t, C.c_uint64, _P]),
+    "jfgpu_add_keys": (C.c_int, [_P, _P, C.c_size_t, C.c_uint64, _P]),
+    "jfgpu_lookup_dev": (C.c_int, [_P, _P, C.c_size_t, _P, _P]),
+    "jfgpu_lookup": (C.c_int, [_P, _P, C.c_size_t, _P, _P]),
+    "jfgpu_partition_ascii_dev": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, _P]),
+    "jfgpu_stats_compute": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.POINTER(Stats)]),
+    "jfgpu_histo": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64, _P, C.c_uint64]),
+    "jfgpu_dump_begin": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+    "jfgpu_dump_next": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "jfgpu_dump_end": (C.c_int, [_P]),
+    "jfgpu_profile_enable": (C.c_int, [_P, C.c_int]),
+    "jfgpu_profile_get": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "jfgpu_profile_reset": (C.c_int, [_P]),
+    "jfgpu_gen_reads_dev": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64]),
+    "jfgpu_gups": (C.c_int, [_P, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
+    "jfgpu_malloc_dev": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "jfgpu_free_dev": (C.c_int, [_P, _P]),
+    "jfgpu_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "jfgpu_memcpy_d2h": (C.c_int, [_P, _P, _P, C.c_size_t]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libjfgpu.so.  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `make engine` "
+                              "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _check(rc):
+    if rc != OK:
+        raise JfgpuError(rc, load().jfgpu_last_error().decode(errors="replace"))
+
+
+def device_count():
+    return load().jfgpu_device_count()
+
+
+def _ptr(x):
+    """numpy array -> host pointer; int -> raw (device) pointer; torch tensor -> data_ptr()."""
+    if x is None:
+        return None
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    if isinstance(x, int):
+        return x
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    raise TypeError(type(x))
+
+
+class Table:
+    """One hash shard in one GPU's HBM (jfgpu_table*)."""
+
+    def __init__(self, k, size, canonical=True, device=-1, shard_bits=0, shard_id=0, matrix_seed=0,
+                 matrix_columns=None, out_counter_len=4):
+        self._lib = load()
+        p = Params()
+        p.k, p.canonical, p.size, p.device = k, int(bool(canonical)), int(size), device
+        p.shard_bits, p.shard_id, p.matrix_seed = shard_bits, shard_id, matrix_seed
+        self._cols = None
+        if matrix_columns is not None:
+            self._cols = np.ascontiguousarray(matrix_columns, dtype=np.uint64)
+            p.matrix_columns = self._cols.ctypes.data_as(C.POINTER(C.c_uint64))
+        p.out_counter_len = out_counter_len
+        h = _P()
+        _check(self._lib.jfgpu_create(C.byref(p), C.byref(h)))
+        self._h = h
+        self.info = Info()
+        _check(self._lib.jfgpu_get_info(self._h, C.byref(self.info)))
+        self.k = k
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.jfgpu_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- geometry
+    def matrix(self):
+        cols = np.zeros(2 * self.k, dtype=np.uint64)
+        _check(self._lib.jfgpu_get_matrix(self._h, cols.ctypes.data))
+        return cols
+
+    def clear(self):
+        _check(self._lib.jfgpu_clear(self._h))
+
+    def sync(self):
+        _check(self._lib.jfgpu_sync(self._h))
+
+    # -- hot path
+    def count_ascii(self, bases: bytes):
+        buf = np.frombuffer(bases, dtype=np.uint8)
+        _check(self._lib.jfgpu_count_ascii(self._h, buf.ctypes.data if len(bases) else None, len(bases)))
+
+    def count_ascii_dev(self, d_ptr, n):
+        _check(self._lib.jfgpu_count_ascii_dev(self._h, _ptr(d_ptr), n))
+
+    def add_keys(self, keys, val=1, want_new=False):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        is_new = np.zeros(len(keys), dtype=np.uint8) if want_new else None
+        _check(self._lib.jfgpu_add_keys(self._h, keys.ctypes.data, len(keys), val, _ptr(is_new)))
+        return is_new
+
+    def add_keys_dev(self, d_keys, n, val=1, d_is_new=None):
+        _check(self._lib.jfgpu_add_keys_dev(self._h, _ptr(d_keys), n, val, _ptr(d_is_new)))
+
+    def lookup(self, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        vals = np.zeros(len(keys), dtype=np.uint64)
+        found = np.zeros(len(keys), dtype=np.uint8)
+        _check(self._lib.jfgpu_lookup(self._h, keys.ctypes.data, len(keys), vals.ctypes.data, found.ctypes.data))
+        return vals, found.astype(bool)
+
+    def partition_ascii_dev(self, d_bases, n, d_keys_out, capacity):
+        counts = np.zeros(1 << self.info.shard_bits, dtype=np.uint64)
+        _check(self._lib.jfgpu_partition_ascii_dev(self._h, _ptr(d_bases), n, _ptr(d_keys_out), capacity, counts.ctypes.data))
+        return counts
+
+    # -- results
+    def stats(self, lower=0, upper=2 ** 64 - 1):
+        s = Stats()
+        _check(self._lib.jfgpu_stats_compute(self._h, lower, upper, C.byref(s)))
+        return s
+
+    def histo(self, low=1, high=10000, inc=1):
+        """Same bucket arithmetic as histo_main.cc:60-66; returns (first_col, inc, counts)."""
+        base = 0 if inc >= low else low - inc
+        ceil = high + inc
+        nb = (ceil + inc - base) // inc
+        h = np.zeros(nb, dtype=np.uint64)
+        _check(self._lib.jfgpu_histo(self._h, base, ceil, inc, h.ctypes.data, nb))
+        return base, inc, h
+
+    def dump_records(self, lower=0, upper=2 ** 64 - 1, chunk_records=1 << 20):
+        """All records of this shard in (pos, key) order as one uint8 array (n, record_bytes)."""
+        n = C.c_uint64()
+        rb = C.c_uint32()
+        _check(self._lib.jfgpu_dump_begin(self._h, lower, upper, C.byref(n), C.byref(rb)))
+        try:
+            chunk_records = max(chunk_records, self.info.tile_slots)
+            out = np.zeros((n.value, rb.value), dtype=np.uint8)
+            buf = np.zeros((chunk_records, rb.value), dtype=np.uint8)
+            got = 0
+            while True:
+                nr = C.c_uint64()
+                _check(self._lib.jfgpu_dump_next(self._h, buf.ctypes.data, chunk_records, C.byref(nr)))
+                if nr.value == 0:
+                    break
+                out[got:got + nr.value] = buf[:nr.value]
+                got += nr.value
+            assert got == n.value, (got, n.value)
+            return out
+        finally:
+            _check(self._lib.jfgpu_dump_end(self._h))
+
+    # -- measurement helpers
+    def profile_enable(self, on=True):
+        _check(self._lib.jfgpu_profile_enable(self._h, int(on)))
+
+    def profile_get(self, which):
+        ms, ln, un = C.c_double(), C.c_uint64(), C.c_uint64()
+        _check(self._lib.jfgpu_profile_get(self._h, which, C.byref(ms), C.byref(ln), C.byref(un)))
+        return ms.value, ln.value, un.value
+
+    def profile_reset(self):
+        _check(self._lib.jfgpu_profile_reset(self._h))
+
+    def gen_reads_dev(self, d_out, first_read, n_reads, read_len, seed):
+        _check(self._lib.jfgpu_gen_reads_dev(self._h, _ptr(d_out), first_read, n_reads, read_len, seed))
+
+    def gups(self, n_updates, mode=0):
+        v = C.c_double()
+        _check(self._lib.jfgpu_gups(self._h, n_updates, mode, C.byref(v)))
+        return v.value
+
+    def malloc(self, nbytes):
+        p = _P()
+        _check(self._lib.jfgpu_malloc_dev(self._h, nbytes, C.byref(p)))
+        return p.value
+
+    def free(self, p):
+        _check(self._lib.jfgpu_free_dev(self._h, p))
+
+    def h2d(self, d_dst, src: np.ndarray):
+        src = np.ascontiguousarray(src)
+        _check(self._lib.jfgpu_memcpy_h2d(self._h, d_dst, src.ctypes.data, src.nbytes))
+
+    def d2h(self, d_src, nbytes):
+        out = np.zeros(nbytes, dtype=np.uint8)
+        _check(self._lib.jfgpu_memcpy_d2h(self._h, out.ctypes.data, d_src, nbytes))
+        return out
+
+
+def decode_records(recs: np.ndarray, k: int, counter_len: int):
+    """(n, record_bytes) uint8 -> (keys uint64 (n,), counts uint64 (n,)) for k <= 32
+    (binary_dumper.hpp:36-40 layout: ceil(2k/8) key bytes LE, then counter_len bytes LE)."""
+    kb = (2 * k + 7) // 8
+    n = len(recs)
+    keys = np.zeros(n, dtype=np.uint64)
+    cnts = np.zeros(n, dtype=np.uint64)
+    for b in range(kb):
+        keys |= recs[:, b].astype(np.uint64) << np.uint64(8 * b)
+    for b in range(counter_len):
+        cnts |= recs[:, kb + b].astype(np.uint64) << np.uint64(8 * b)
+    return keys, cnts

@@ -1,0 +1,386 @@
+// jellyfish_amd/cli/jellyfish_amd.cc -- `jellyfish-amd <cmd>`: the reference's CLI verbs on
+// top of the MI355X engine.
+//
+//   count  sub_commands/count_main.cc:218-385 (+ count_main_cmdline.yaggo for the options)
+//   dump   sub_commands/dump_main.cc:36-88
+//   histo  sub_commands/histo_main.cc:34-90
+//   stats  sub_commands/stats_main.cc:33-79
+//   query  sub_commands/query_main.cc:44-123
+//   info   sub_commands/info_main.cc:31-54
+// Dispatch like sub_commands/jellyfish.cc:138-158.  The option parsers are written by hand
+// (the reference generates them with yaggo); names, defaults and output text follow the
+// reference so scripts keep working.  dump/histo/stats/query/info are plain sequential file
+// readers (I/O bound, host only); count drives the GPU through the hash_counter facade.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <limits>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include <jellyfish_amd/dumpers.hpp>
+#include <jellyfish_amd/sequence_parser.hpp>
+
+using namespace jellyfish_amd;
+
+namespace {
+
+[[noreturn]] void die(const std::string& msg) {   // err::die (include/jellyfish/err.hpp:77-82)
+  std::cerr << msg << std::endl;
+  exit(1);
+}
+
+// yaggo "suffix" numbers: k, M, G, T, ... = powers of 1000
+uint64_t parse_suffix(const std::string& s, const char* opt) {
+  char* end = nullptr;
+  const double v = strtod(s.c_str(), &end);
+  double mult = 1;
+  if(end && *end) {
+    switch(*end) {
+    case 'k': mult = 1e3; break; case 'M': mult = 1e6; break; case 'G': mult = 1e9; break;
+    case 'T': mult = 1e12; break; case 'P': mult = 1e15; break; case 'E': mult = 1e18; break;
+    default: die(std::string("Invalid numeric suffix in option ") + opt + " '" + s + "'");
+    }
+    if(end[1]) die(std::string("Invalid number for option ") + opt + " '" + s + "'");
+  }
+  return (uint64_t)(v * mult);
+}
+
+struct ArgCursor {
+  int argc; char** argv; int i = 1;
+  bool more() const { return i < argc; }
+  std::string cur() const { return argv[i]; }
+  // value of an option given as "-x VAL", "-xVAL", "--long VAL" or "--long=VAL"
+  std::string value(const std::string& shortf, const std::string& longf) {
+    std::string a = argv[i];
+    if(!longf.empty() && a.rfind(longf + "=", 0) == 0) return a.substr(longf.size() + 1);
+    if(!shortf.empty() && a.size() > shortf.size() && a.rfind(shortf, 0) == 0 && a[1] != '-') return a.substr(shortf.size());
+    if(i + 1 >= argc) die("Missing argument for option " + a);
+    return argv[++i];
+  }
+  bool is(const std::string& shortf, const std::string& longf) const {
+    std::string a = argv[i];
+    if(!longf.empty() && (a == longf || a.rfind(longf + "=", 0) == 0)) return true;
+    if(!shortf.empty() && a.rfind(shortf, 0) == 0 && (a.size() == shortf.size() || a[1] != '-')) return true;
+    return false;
+  }
+};
+
+double seconds_since(std::chrono::steady_clock::time_point t0) {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// ---------------------------------------------------------------- count
+int count_main(int argc, char* argv[]) {
+  auto start_time = std::chrono::steady_clock::now();
+  file_header header;
+  header.fill_standard();
+  header.set_cmdline(argc, argv);
+
+  unsigned mer_len = 0, threads = 1, counter_len = 7, out_counter_len = 4, reprobes = 126, Files = 1;
+  uint64_t size = 0, lower = 0, upper = std::numeric_limits<uint64_t>::max();
+  bool size_given = false, lower_given = false, upper_given = false, canonical = false, text = false, no_write = false;
+  int device = -1;
+  std::string output = "mer_counts.jf", timing;
+  std::vector<std::string> files;
+  ArgCursor a{argc, argv};
+  for(; a.more(); ++a.i) {
+    if(a.is("-m", "--mer-len")) mer_len = (unsigned)strtoul(a.value("-m", "--mer-len").c_str(), 0, 10);
+    else if(a.is("-s", "--size")) { size = parse_suffix(a.value("-s", "--size"), "-s"); size_given = true; }
+    else if(a.is("-t", "--threads")) threads = (unsigned)strtoul(a.value("-t", "--threads").c_str(), 0, 10);
+    else if(a.is("-F", "--Files")) Files = (unsigned)strtoul(a.value("-F", "--Files").c_str(), 0, 10);
+    else if(a.is("-c", "--counter-len")) counter_len = (unsigned)strtoul(a.value("-c", "--counter-len").c_str(), 0, 10);
+    else if(a.is("", "--out-counter-len")) out_counter_len = (unsigned)strtoul(a.value("", "--out-counter-len").c_str(), 0, 10);
+    else if(a.is("-p", "--reprobes")) reprobes = (unsigned)strtoul(a.value("-p", "--reprobes").c_str(), 0, 10);
+    else if(a.is("-o", "--output")) output = a.value("-o", "--output");
+    else if(a.is("-L", "--lower-count")) { lower = strtoull(a.value("-L", "--lower-count").c_str(), 0, 10); lower_given = true; }
+    else if(a.is("-U", "--upper-count")) { upper = strtoull(a.value("-U", "--upper-count").c_str(), 0, 10); upper_given = true; }
+    else if(a.is("", "--timing")) timing = a.value("", "--timing");
+    else if(a.is("", "--device")) device = atoi(a.value("", "--device").c_str());
+    else if(a.cur() == "-C" || a.cur() == "--canonical") canonical = true;
+    else if(a.cur() == "--text") text = true;
+    else if(a.cur() == "--no-write") no_write = true;
+    else if(a.cur() == "--disk" || a.cur() == "--no-merge" || a.cur() == "--no-unlink") { /* spill-to-disk knobs: the table lives in HBM */ }
+    else if(a.is("", "--bc") || a.is("", "--bf-size") || a.is("", "--bf-fp") || a.is("", "--if") || a.is("-Q", "--min-qual-char") ||
+            a.is("-q", "--min-quality") || a.is("-g", "--generator") || a.is("-G", "--Generators") || a.is("", "--sam"))
+      die("Option '" + a.cur() + "' is not supported by jellyfish-amd yet");
+    else if(a.cur() == "-h" || a.cur() == "--help") {
+      std::cout << "Usage: jellyfish-amd count [options] file:path+\n\n"
+                   "Count k-mers in fasta or fastq files on an MI355X\n\n"
+                   " -m, --mer-len=uint32       *Length of mer\n"
+                   " -s, --size=uint64          *Initial hash size\n"
+                   " -t, --threads=uint32        Number of threads (1)\n"
+                   " -o, --output=string         Output file (mer_counts.jf)\n"
+                   " -c, --counter-len=Length    Length bits of counting field (7)\n"
+                   "     --out-counter-len=bytes Length in bytes of counter field in output (4)\n"
+                   " -C, --canonical             Count both strand, canonical representation (false)\n"
+                   " -p, --reprobes=uint32       Maximum number of reprobes (126)\n"
+                   " -L, --lower-count=uint64    Don't output k-mer with count < lower-count\n"
+                   " -U, --upper-count=uint64    Don't output k-mer with count > upper-count\n"
+                   "     --text                  Dump in text format (false)\n"
+                   "     --timing=Timing file    Print timing information\n"
+                   "     --device=int            HIP device ordinal (current)\n";
+      return 0;
+    } else if(a.cur().size() > 1 && a.cur()[0] == '-' && a.cur() != "-") die("Unknown option '" + a.cur() + "'");
+    else files.push_back(a.cur());
+  }
+  if(!mer_len) die("Error: mandatory switch missing: -m, --mer-len");
+  if(!size_given) die("Error: mandatory switch missing: -s, --size");
+  if(files.empty()) die("Error: at least 1 file argument is required");
+  (void)threads; (void)counter_len; (void)reprobes; (void)Files;
+  if(mer_len > 32) die("jellyfish-amd: mer length > 32 is not built yet");
+  if(text) out_counter_len = 8;   // text counts are not saturated (text_dumper.hpp:18-20)
+
+  mer_dna::k(mer_len);
+  header.canonical(canonical);
+  std::unique_ptr<mer_hash> ary;
+  try {
+    ary.reset(new mer_hash(size, mer_len * 2, counter_len, threads, reprobes, canonical, device, out_counter_len));
+  } catch(std::exception& e) { die(std::string("Failed to allocate the hash: ") + e.what()); }
+
+  std::unique_ptr<dumper_base> dumper;
+  if(text) dumper.reset(new text_dumper(threads, output.c_str(), &header));
+  else dumper.reset(new binary_dumper(out_counter_len, ary->key_len(), threads, output.c_str(), &header));
+  const double init_s = seconds_since(start_time);
+
+  auto count_start = std::chrono::steady_clock::now();
+  try {
+    sequence_parser parser(mer_len);
+    for(const auto& f : files)
+      parser.parse_file(f.c_str(), [&](const char* buf, size_t n) { ary->count_sequence(buf, n); });
+    ary->done();
+  } catch(std::exception& e) { die(e.what()); }
+  const double count_s = seconds_since(count_start);
+
+  auto write_start = std::chrono::steady_clock::now();
+  if(!no_write) {
+    try {
+      dumper->one_file(true);
+      if(lower_given) dumper->min(lower);
+      if(upper_given) dumper->max(upper);
+      dumper->dump(ary->ary());
+    } catch(std::exception& e) { die(e.what()); }
+  }
+  const double write_s = seconds_since(write_start);
+
+  if(!timing.empty()) {   // count_main.cc:375-382
+    std::ofstream tf(timing);
+    tf << "Init     " << init_s << "\n"
+       << "Counting " << count_s << "\n"
+       << "Writing  " << write_s << "\n";
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------- readers
+struct db_file {
+  std::ifstream is;
+  file_header header;
+  explicit db_file(const std::string& path) : is(path, std::ios::binary) {
+    if(!is.good()) die("Failed to open input file '" + path + "'");
+    if(!header.read(is)) die("Failed to parse header of file '" + path + "'");
+    mer_dna::k(header.key_len() / 2);
+  }
+};
+
+template <typename F> void for_each_record(db_file& db, F f) {
+  if(db.header.format() == binary_dumper::format) { binary_reader r(db.is, &db.header); while(r.next()) f(r.key(), r.val()); }
+  else if(db.header.format() == text_dumper::format) { text_reader r(db.is, &db.header); while(r.next()) f(r.key(), r.val()); }
+  else die("Unknown format '" + db.header.format() + "'");
+}
+
+int dump_main(int argc, char* argv[]) {
+  bool column = false, tab = false;
+  uint64_t lower = 0, upper = std::numeric_limits<uint64_t>::max();
+  std::string output, db;
+  ArgCursor a{argc, argv};
+  for(; a.more(); ++a.i) {
+    if(a.cur() == "-c" || a.cur() == "--column") column = true;
+    else if(a.cur() == "-t" || a.cur() == "--tab") tab = true;
+    else if(a.cur() == "-ct" || a.cur() == "-tc") column = tab = true;
+    else if(a.is("-L", "--lower-count")) lower = strtoull(a.value("-L", "--lower-count").c_str(), 0, 10);
+    else if(a.is("-U", "--upper-count")) upper = strtoull(a.value("-U", "--upper-count").c_str(), 0, 10);
+    else if(a.is("-o", "--output")) output = a.value("-o", "--output");
+    else db = a.cur();
+  }
+  if(db.empty()) die("Usage: jellyfish-amd dump [-c] [-t] [-L l] [-U u] [-o out] db:path");
+  std::ios::sync_with_stdio(false);
+  std::ofstream fout;
+  if(!output.empty()) { fout.open(output); if(!fout.good()) die("Error opening output file '" + output + "'"); }
+  std::ostream& out = output.empty() ? std::cout : fout;
+  db_file f(db);
+  const char spacer = tab ? '\t' : ' ';
+  for_each_record(f, [&](const mer_dna& k, uint64_t v) {
+    if(v < lower || v > upper) return;
+    if(column) out << k << spacer << v << "\n";
+    else out << ">" << v << "\n" << k << "\n";
+  });
+  return 0;
+}
+
+int histo_main(int argc, char* argv[]) {
+  uint64_t low = 1, high = 10000, inc = 1;
+  bool full = false;
+  std::string output, db;
+  ArgCursor a{argc, argv};
+  for(; a.more(); ++a.i) {
+    if(a.is("-l", "--low")) low = strtoull(a.value("-l", "--low").c_str(), 0, 10);
+    else if(a.is("-h", "--high")) high = strtoull(a.value("-h", "--high").c_str(), 0, 10);
+    else if(a.is("-i", "--increment")) inc = strtoull(a.value("-i", "--increment").c_str(), 0, 10);
+    else if(a.is("-t", "--threads")) (void)a.value("-t", "--threads");
+    else if(a.cur() == "-f" || a.cur() == "--full") full = true;
+    else if(a.is("-o", "--output")) output = a.value("-o", "--output");
+    else db = a.cur();
+  }
+  if(db.empty()) die("Usage: jellyfish-amd histo [-l low] [-h high] [-i inc] [-f] [-o out] db:path");
+  if(high < low) die("High count value must be >= to low count value");
+  if(!inc) die("Increment must be > 0");
+  std::ofstream fout;
+  if(!output.empty()) { fout.open(output); if(!fout.good()) die("Error opening output file '" + output + "'"); }
+  std::ostream& out = output.empty() ? std::cout : fout;
+  db_file f(db);
+  const uint64_t base = inc >= low ? 0 : low - inc, ceil = high + inc;
+  const uint64_t nb = (ceil + inc - base) / inc;
+  std::vector<uint64_t> histo(nb, 0);
+  for_each_record(f, [&](const mer_dna&, uint64_t v) {
+    if(v < base) ++histo[0]; else if(v > ceil) ++histo[nb - 1]; else ++histo[(v - base) / inc];
+  });
+  uint64_t col = base;
+  for(uint64_t i = 0; i < nb; ++i, col += inc)
+    if(histo[i] > 0 || full) out << col << " " << histo[i] << "\n";
+  return 0;
+}
+
+int stats_main(int argc, char* argv[]) {
+  uint64_t lower = 0, upper = std::numeric_limits<uint64_t>::max();
+  std::string output, db;
+  ArgCursor a{argc, argv};
+  for(; a.more(); ++a.i) {
+    if(a.is("-L", "--lower-count")) lower = strtoull(a.value("-L", "--lower-count").c_str(), 0, 10);
+    else if(a.is("-U", "--upper-count")) upper = strtoull(a.value("-U", "--upper-count").c_str(), 0, 10);
+    else if(a.is("-o", "--output")) output = a.value("-o", "--output");
+    else db = a.cur();
+  }
+  if(db.empty()) die("Usage: jellyfish-amd stats [-L l] [-U u] [-o out] db:path");
+  std::ofstream fout;
+  if(!output.empty()) { fout.open(output); if(!fout.good()) die("Error opening output file '" + output + "'"); }
+  std::ostream& out = output.empty() ? std::cout : fout;
+  db_file f(db);
+  uint64_t uniq = 0, distinct = 0, total = 0, max = 0;
+  for_each_record(f, [&](const mer_dna&, uint64_t v) {
+    if(v < lower || v > upper) return;
+    uniq += v == 1; total += v; max = std::max(max, v); ++distinct;
+  });
+  out << "Unique:    " << uniq << "\n" << "Distinct:  " << distinct << "\n"
+      << "Total:     " << total << "\n" << "Max_count: " << max << "\n";
+  return 0;
+}
+
+int query_main(int argc, char* argv[]) {
+  std::string output, db;
+  std::vector<std::string> mers, sequences;
+  bool interactive = false;
+  ArgCursor a{argc, argv};
+  for(; a.more(); ++a.i) {
+    if(a.is("-s", "--sequence")) sequences.push_back(a.value("-s", "--sequence"));
+    else if(a.is("-o", "--output")) output = a.value("-o", "--output");
+    else if(a.cur() == "-i" || a.cur() == "--interactive") interactive = true;
+    else if(a.cur() == "-l" || a.cur() == "--load" || a.cur() == "-L" || a.cur() == "--no-load") {}
+    else if(db.empty()) db = a.cur();
+    else mers.push_back(a.cur());
+  }
+  if(db.empty()) die("Usage: jellyfish-amd query [-s file] [-i] [-o out] db:path [mers...]");
+  std::ofstream fout;
+  if(!output.empty()) { fout.open(output); if(!fout.good()) die("Error opening output file '" + output + "'"); }
+  std::ostream& out = output.empty() ? std::cout : fout;
+  std::ifstream in(db, std::ios::binary);
+  file_header header(in);
+  if(!in.good()) die("Failed to parse header of file '" + db + "'");
+  mer_dna::k(header.key_len() / 2);
+  if(header.format() != binary_dumper::format)
+    die("Unsupported format '" + header.format() + "'. Must be a bloom counter or binary list.");
+  mapped_file map(db.c_str());
+  binary_query bq(map.base() + header.offset(), header.key_len(), header.counter_len(), header.matrix(), header.size() - 1,
+                  map.length() - header.offset());
+  const bool canonical = header.canonical();
+  const unsigned k = mer_dna::k();
+  // query_from_sequence (query_main.cc:44-51): every (canonical) k-mer of the files, in order
+  for(const auto& path : sequences) {
+    sequence_parser parser(k);
+    parser.parse_file(path.c_str(), [&](const char* buf, size_t n) {
+      mer_dna m(k), rc(k);
+      unsigned filled = 0;
+      for(size_t i = 0; i < n; ++i) {
+        const int code = mer_dna::code(buf[i]);
+        if(code < 0) { filled = 0; continue; }
+        m.shift_left(code); rc.shift_right(3 - code);
+        if(++filled >= k) {
+          filled = k;
+          const mer_dna& q = (!canonical || m < rc) ? m : rc;
+          out << q << " " << bq.check(q) << "\n";
+        }
+      }
+    });
+  }
+  auto one = [&](const std::string& s, bool show_mer) {
+    try {
+      mer_dna m(k);
+      m = s;
+      if(canonical) m.canonicalize();
+      if(show_mer) out << m << " " << bq.check(m) << "\n";
+      else out << bq.check(m) << std::endl;
+    } catch(std::length_error&) { std::cerr << "Invalid mer '" << s << "'\n"; }
+  };
+  for(const auto& s : mers) one(s, true);
+  if(interactive) { std::string line; while(std::getline(std::cin, line)) one(line, false); }
+  return 0;
+}
+
+int info_main(int argc, char* argv[]) {
+  bool json = false, skip = false, cmd = false;
+  std::string db;
+  for(int i = 1; i < argc; ++i) {
+    std::string a = argv[i];
+    if(a == "-j" || a == "--json") json = true; else if(a == "-s" || a == "--skip") skip = true;
+    else if(a == "-c" || a == "--cmd") cmd = true; else db = a;
+  }
+  if(db.empty()) die("Usage: jellyfish-amd info [-j] [-c] [-s] db:path");
+  std::ifstream is(db, std::ios::binary);
+  file_header header;
+  if(!header.read(is)) die("Failed to parse header of file '" + db + "'");
+  if(skip) { std::cout << is.rdbuf(); return 0; }
+  if(json) { std::cout << header.root().dump() << "\n"; return 0; }
+  if(cmd) { for(const auto& s : header.cmdline()) std::cout << s << " "; std::cout << "\n"; return 0; }
+  std::cout << "command: "; for(const auto& s : header.cmdline()) std::cout << s << " "; std::cout << "\n";
+  std::cout << "where: " << header["hostname"] << ":" << header["pwd"] << "\n"
+            << "when: " << header["time"] << "\n"
+            << "canonical: " << (header.canonical() ? "yes" : "no") << "\n";
+  return 0;
+}
+
+}  // namespace
+
+int main(int argc, char* argv[]) {
+  const char* usage =
+      "Usage: jellyfish-amd <cmd> [options] arg...\n"
+      "Where <cmd> is one of: count, stats, histo, dump, query, info.\n"
+      "Options:\n  --version        Display version\n  --help           Display this message\n";
+  if(argc < 2) { std::cerr << "Too few arguments\n" << usage; return 1; }
+  const std::string cmd = argv[1];
+  if(cmd == "--version" || cmd == "-V") { std::cout << "jellyfish-amd 0.1 (MI355X engine for jellyfish 2.3.1 files)\n"; return 0; }
+  if(cmd == "--help" || cmd == "-h") { std::cout << usage; return 0; }
+  try {
+    if(cmd == "count") return count_main(argc - 1, argv + 1);
+    if(cmd == "dump") return dump_main(argc - 1, argv + 1);
+    if(cmd == "histo") return histo_main(argc - 1, argv + 1);
+    if(cmd == "stats") return stats_main(argc - 1, argv + 1);
+    if(cmd == "query") return query_main(argc - 1, argv + 1);
+    if(cmd == "info") return info_main(argc - 1, argv + 1);
+  } catch(std::exception& e) { die(e.what()); }
+  std::cerr << "Unknown command '" << cmd << "'\n" << usage;
+  return 1;
+}

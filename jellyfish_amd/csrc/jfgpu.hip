@@ -1,0 +1,637 @@
+// jellyfish_amd/csrc/jfgpu.hip -- C ABI (include/jfgpu.h) over the gfx950 kernels.
+//
+// Host-side role in the reference: the part of sub_commands/count_main.cc that
+// owns the table (mer_hash ctor, :275), drives the counting threads (:331-333)
+// and hands the table to the dumper (:349-355).  Here the "threads" are HIP
+// kernels enqueued on one stream per table; there is no CPU fallback.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/jfgpu.h"
+#include "gf2_matrix.hpp"
+#include "kernels.hip.hpp"
+
+using namespace jfgpu;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if(e_ != hipSuccess)                                                                      \
+      return fail(e_ == hipErrorOutOfMemory ? JFGPU_E_ALLOC : (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice ? JFGPU_E_NO_DEVICE : JFGPU_E_HIP), \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                          \
+  } while(0)
+
+constexpr uint64_t kDefaultSeed = 0x6A656C6C79666973ull;  // "jellyfis"
+constexpr size_t kStageBytes = 64u << 20;                  // host->device staging chunk
+constexpr int kNumProf = 4;
+
+struct ProfSpan { hipEvent_t a, b; int which; uint64_t units; };
+
+}  // namespace
+
+struct jfgpu_table {
+  jfgpu_params params{};
+  TableGeom g{};
+  Gf2Matrix matrix;
+  int device = 0;
+  int n_cu = 256;
+  hipStream_t stream = nullptr;
+  DevTable dt{};
+  uint64_t* d_fwd = nullptr;
+  uint64_t* d_inv = nullptr;
+  uint64_t ovf_cap = 0;
+  bool returning = false;
+  uint32_t out_counter_len = 4;
+  // staging for host buffers
+  uint8_t* d_stage[2] = {nullptr, nullptr};
+  hipEvent_t stage_done[2] = {nullptr, nullptr};
+  int stage_next = 0;
+  // profiling
+  bool prof_on = false;
+  std::vector<ProfSpan> prof_pending;
+  std::vector<hipEvent_t> ev_pool;
+  double prof_ms[kNumProf] = {0, 0, 0, 0};
+  uint64_t prof_launches[kNumProf] = {0, 0, 0, 0};
+  uint64_t prof_units[kNumProf] = {0, 0, 0, 0};
+  // dump state
+  bool dump_open = false;
+  uint64_t dump_lower = 0, dump_upper = 0;
+  int dump_have_ovf = 0;
+  std::vector<uint64_t> dump_prefix;  // per tile exclusive prefix, size n_tiles + 1
+  uint64_t dump_tile_cursor = 0;
+  uint8_t* d_dump = nullptr; uint64_t dump_cap_records = 0;
+  uint64_t* d_tile_off = nullptr; uint64_t tile_off_cap = 0;
+};
+
+namespace {
+
+int use(const jfgpu_table* t) {
+  if(!t) return fail(JFGPU_E_INVALID, "null table");
+  HIP_TRY(hipSetDevice(t->device));
+  return JFGPU_OK;
+}
+
+uint64_t n_tiles_of(const jfgpu_table* t) { return 1ull << (t->g.lsize_l - t->g.tile_bits); }
+
+int grid_for(const jfgpu_table* t, uint64_t work_items) {
+  uint64_t g = std::min<uint64_t>(work_items, (uint64_t)t->n_cu * 8);
+  return (int)std::max<uint64_t>(g, 1);
+}
+
+hipEvent_t get_event(jfgpu_table* t) {
+  if(!t->ev_pool.empty()) { hipEvent_t e = t->ev_pool.back(); t->ev_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  hipEventCreate(&e);
+  return e;
+}
+
+struct ProfScope {  // records a HIP-event pair around a launch on the table's stream
+  jfgpu_table* t; int which; uint64_t units; hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(jfgpu_table* t_, int w, uint64_t u) : t(t_), which(w), units(u) {
+    if(t->prof_on) { a = get_event(t); b = get_event(t); hipEventRecord(a, t->stream); }
+  }
+  ~ProfScope() {
+    if(t->prof_on) { hipEventRecord(b, t->stream); t->prof_pending.push_back({a, b, which, units}); }
+  }
+};
+
+void prof_collect(jfgpu_table* t) {
+  for(auto& s : t->prof_pending) {
+    float ms = 0;
+    hipEventSynchronize(s.b);
+    if(hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+      t->prof_ms[s.which] += ms; t->prof_launches[s.which] += 1; t->prof_units[s.which] += s.units;
+    }
+    t->ev_pool.push_back(s.a); t->ev_pool.push_back(s.b);
+  }
+  t->prof_pending.clear();
+}
+
+int read_counters(jfgpu_table* t, uint64_t* out /* CTR_COUNT */) {
+  HIP_TRY(hipMemcpyAsync(out, t->dt.counters, sizeof(uint64_t) * CTR_COUNT, hipMemcpyDeviceToHost, t->stream));
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  return JFGPU_OK;
+}
+
+int check_deferred(jfgpu_table* t, uint64_t* ctr_out = nullptr) {
+  uint64_t c[CTR_COUNT];
+  int rc = read_counters(t, c);
+  if(rc) return rc;
+  if(ctr_out) memcpy(ctr_out, c, sizeof(c));
+  if(c[CTR_MISROUTED])
+    return fail(JFGPU_E_INVALID, std::to_string(c[CTR_MISROUTED]) + " k-mers were added to a shard that does not own them");
+  if(c[CTR_FULL]) return fail(JFGPU_E_FULL, "Hash full");
+  if(c[CTR_OVF_FULL]) return fail(JFGPU_E_FULL, "Hash full (count overflow table exhausted)");
+  return JFGPU_OK;
+}
+
+// Splits a device buffer pointer into a 16-byte aligned base and [lo, hi).
+void align_buffer(const char* d, size_t n, const uint8_t*& base, int64_t& lo, int64_t& hi) {
+  const uintptr_t p = (uintptr_t)d;
+  const uintptr_t a = p & ~(uintptr_t)15;
+  base = (const uint8_t*)a; lo = (int64_t)(p - a); hi = lo + (int64_t)n;
+}
+
+int launch_count(jfgpu_table* t, const char* d_bases, size_t n) {
+  if(n < t->g.k) return JFGPU_OK;
+  const uint8_t* base; int64_t lo, hi;
+  align_buffer(d_bases, n, base, lo, hi);
+  const int64_t n_tiles = (hi + kTilePos - 1) / kTilePos;
+  const int grid = grid_for(t, (uint64_t)n_tiles);
+  ProfScope ps(t, 0, n);
+  if(t->returning) hipLaunchKernelGGL(count_ascii_kernel<true>, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, base, lo, hi);
+  else             hipLaunchKernelGGL(count_ascii_kernel<false>, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, base, lo, hi);
+  HIP_TRY(hipGetLastError());
+  return JFGPU_OK;
+}
+
+int ensure_stage(jfgpu_table* t) {
+  for(int i = 0; i < 2; ++i) {
+    if(!t->d_stage[i]) HIP_TRY(hipMalloc((void**)&t->d_stage[i], kStageBytes));
+    if(!t->stage_done[i]) HIP_TRY(hipEventCreateWithFlags(&t->stage_done[i], hipEventDisableTiming));
+  }
+  return JFGPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* jfgpu_last_error(void) { return g_err.c_str(); }
+int jfgpu_abi_version(void) { return JFGPU_ABI_VERSION; }
+
+int jfgpu_device_count(void) {
+  int n = 0;
+  if(hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
+  if(!p || !out) return fail(JFGPU_E_INVALID, "null argument");
+  *out = nullptr;
+  if(p->k < 1) return fail(JFGPU_E_INVALID, "mer length must be >= 1");
+  if(p->k > 32) return fail(JFGPU_E_UNSUPPORTED, "mer length > 32 (multi-word keys) is not built yet");
+  if(p->shard_bits > 8) return fail(JFGPU_E_INVALID, "at most 256 shards");
+  if(p->shard_id >= (1u << p->shard_bits)) return fail(JFGPU_E_INVALID, "shard_id out of range");
+  int ndev = 0;
+  if(hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(JFGPU_E_NO_DEVICE, "no HIP device: the engine has no CPU fallback");
+  int dev = p->device;
+  if(dev < 0) HIP_TRY(hipGetDevice(&dev));
+  if(dev >= ndev) return fail(JFGPU_E_NO_DEVICE, "device ordinal out of range");
+  HIP_TRY(hipSetDevice(dev));
+
+  // size -> lsize (large_hash_array.hpp:156-157 rounds up to a power of two, :997-1000 caps at 4^k)
+  uint32_t lsize = 0;
+  while(lsize < 63 && (1ull << lsize) < p->size) ++lsize;
+  lsize = std::max(lsize, geom_min_lsize(p->k, p->shard_bits));
+  lsize = std::max(lsize, p->shard_bits);
+  lsize = std::max<uint32_t>(lsize, 1);
+  lsize = std::min<uint32_t>(lsize, 2 * p->k);
+  if(lsize < p->shard_bits) return fail(JFGPU_E_INVALID, "more shards than 4^k table positions");
+
+  std::unique_ptr<jfgpu_table> t(new jfgpu_table);
+  t->params = *p; t->params.matrix_columns = nullptr;
+  t->device = dev;
+  t->out_counter_len = p->out_counter_len ? p->out_counter_len : 4;
+  if(t->out_counter_len > 8) return fail(JFGPU_E_INVALID, "out_counter_len must be <= 8");
+  if(!geom_init(t->g, p->k, lsize, p->shard_bits, p->shard_id, p->canonical ? 1 : 0))
+    return fail(JFGPU_E_INVALID, "table geometry does not fit a 64-bit slot");
+
+  // hash matrix (large_hash_array.hpp:992-1001)
+  if(p->matrix_columns) {
+    t->matrix.r = lsize; t->matrix.c = 2 * p->k;
+    t->matrix.columns.assign(p->matrix_columns, p->matrix_columns + 2 * p->k);
+    t->matrix.identity = gf2_is_low_identity(t->matrix);
+  } else {
+    t->matrix = gf2_random(lsize, 2 * p->k, p->matrix_seed ? p->matrix_seed : kDefaultSeed);
+  }
+  std::vector<uint64_t> fwd, inv;
+  if(!gf2_build_tables(t->matrix, fwd, inv))
+    return fail(JFGPU_E_INVALID, "hash matrix: low r x r block is singular");
+
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  t->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  HIP_TRY(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
+
+  const uint64_t n_slots = 1ull << t->g.lsize_l;
+  t->ovf_cap = std::max<uint64_t>(1ull << 12, std::min<uint64_t>(n_slots / 256, 1ull << 26));
+  { uint64_t c = 1; while(c < t->ovf_cap) c <<= 1; t->ovf_cap = c; }
+  t->returning = t->g.cnt_bits < 40;
+
+  DevTable& d = t->dt;
+  d.g = t->g;
+  HIP_TRY(hipMalloc((void**)&d.slots, n_slots * sizeof(uint64_t)));
+  HIP_TRY(hipMalloc((void**)&t->d_fwd, fwd.size() * sizeof(uint64_t)));
+  HIP_TRY(hipMalloc((void**)&t->d_inv, inv.size() * sizeof(uint64_t)));
+  HIP_TRY(hipMalloc((void**)&d.ovf_key, t->ovf_cap * sizeof(uint64_t)));
+  HIP_TRY(hipMalloc((void**)&d.ovf_cnt, t->ovf_cap * sizeof(uint64_t)));
+  HIP_TRY(hipMalloc((void**)&d.counters, CTR_COUNT * sizeof(uint64_t)));
+  d.fwd_tbl = t->d_fwd; d.inv_tbl = t->d_inv; d.ovf_mask = t->ovf_cap - 1;
+  HIP_TRY(hipMemcpy(t->d_fwd, fwd.data(), fwd.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(t->d_inv, inv.data(), inv.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+  // dump kernel needs > 64 KiB of dynamic LDS
+  const size_t dump_lds = ((size_t)8 << t->g.tile_bits) + ((size_t)2 << t->g.tile_bits) + (size_t)t->g.nbytes * 2048;
+  HIP_TRY(hipFuncSetAttribute((const void*)dump_tiles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dump_lds));
+  jfgpu_table* raw = t.release();
+  int rc = jfgpu_clear(raw);
+  if(rc) { jfgpu_destroy(raw); return rc; }
+  *out = raw;
+  return JFGPU_OK;
+}
+
+void jfgpu_destroy(jfgpu_table* t) {
+  if(!t) return;
+  hipSetDevice(t->device);
+  if(t->stream) hipStreamSynchronize(t->stream);
+  prof_collect(t);
+  for(auto e : t->ev_pool) hipEventDestroy(e);
+  hipFree(t->dt.slots); hipFree(t->d_fwd); hipFree(t->d_inv);
+  hipFree(t->dt.ovf_key); hipFree(t->dt.ovf_cnt); hipFree(t->dt.counters);
+  for(int i = 0; i < 2; ++i) { if(t->d_stage[i]) hipFree(t->d_stage[i]); if(t->stage_done[i]) hipEventDestroy(t->stage_done[i]); }
+  if(t->d_dump) hipFree(t->d_dump);
+  if(t->d_tile_off) hipFree(t->d_tile_off);
+  if(t->stream) hipStreamDestroy(t->stream);
+  delete t;
+}
+
+int jfgpu_get_info(const jfgpu_table* t, jfgpu_info* o) {
+  if(!t || !o) return fail(JFGPU_E_INVALID, "null argument");
+  memset(o, 0, sizeof(*o));
+  o->k = t->g.k; o->key_len = t->g.key_bits; o->canonical = t->g.canonical;
+  o->lsize = t->g.lsize_g; o->size = 1ull << t->g.lsize_g; o->local_size = 1ull << t->g.lsize_l;
+  o->shard_bits = t->g.shard_bits; o->shard_id = t->g.shard_id;
+  o->val_len = t->g.cnt_bits; o->slot_bytes = 8; o->tile_slots = 1u << t->g.tile_bits;
+  o->matrix_identity = t->matrix.identity ? 1 : 0;
+  o->out_counter_len = t->out_counter_len;
+  o->max_reprobe = (1u << t->g.tile_bits) - 1;
+  o->table_bytes = (1ull << t->g.lsize_l) * 8;
+  return JFGPU_OK;
+}
+
+int jfgpu_get_matrix(const jfgpu_table* t, uint64_t* columns) {
+  if(!t || !columns) return fail(JFGPU_E_INVALID, "null argument");
+  memcpy(columns, t->matrix.columns.data(), sizeof(uint64_t) * t->matrix.c);
+  return JFGPU_OK;
+}
+
+int jfgpu_clear(jfgpu_table* t) {
+  int rc = use(t); if(rc) return rc;
+  HIP_TRY(hipMemsetAsync(t->dt.slots, 0, (1ull << t->g.lsize_l) * sizeof(uint64_t), t->stream));
+  HIP_TRY(hipMemsetAsync(t->dt.ovf_key, 0, t->ovf_cap * sizeof(uint64_t), t->stream));
+  HIP_TRY(hipMemsetAsync(t->dt.ovf_cnt, 0, t->ovf_cap * sizeof(uint64_t), t->stream));
+  HIP_TRY(hipMemsetAsync(t->dt.counters, 0, CTR_COUNT * sizeof(uint64_t), t->stream));
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  return JFGPU_OK;
+}
+
+int jfgpu_sync(jfgpu_table* t) {
+  int rc = use(t); if(rc) return rc;
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  return check_deferred(t);
+}
+
+int jfgpu_count_ascii_dev(jfgpu_table* t, const char* d_bases, size_t n) {
+  int rc = use(t); if(rc) return rc;
+  if(t->g.shard_bits) return fail(JFGPU_E_INVALID, "sharded table: route k-mers with jfgpu_partition_ascii_dev + jfgpu_add_keys_dev");
+  if(!d_bases && n) return fail(JFGPU_E_INVALID, "null buffer");
+  return launch_count(t, d_bases, n);
+}
+
+int jfgpu_count_ascii(jfgpu_table* t, const char* bases, size_t n) {
+  int rc = use(t); if(rc) return rc;
+  if(t->g.shard_bits) return fail(JFGPU_E_INVALID, "sharded table: route k-mers with jfgpu_partition_ascii_dev + jfgpu_add_keys_dev");
+  if(!bases && n) return fail(JFGPU_E_INVALID, "null buffer");
+  if(n < t->g.k) return JFGPU_OK;
+  rc = ensure_stage(t); if(rc) return rc;
+  // Chunks overlap by k-1 bytes so that every window is seen exactly once (the same
+  // "seam" idea as mer_overlap_sequence_parser.hpp:164-167,182-184).
+  const size_t step = kStageBytes - (t->g.k - 1);
+  for(size_t o = 0; o < n; o += step) {
+    const size_t len = std::min(kStageBytes, n - o);
+    const int b = t->stage_next; t->stage_next ^= 1;
+    HIP_TRY(hipEventSynchronize(t->stage_done[b]));  // kernel that last read this buffer has finished
+    HIP_TRY(hipMemcpyAsync(t->d_stage[b], bases + o, len, hipMemcpyHostToDevice, t->stream));
+    rc = launch_count(t, (const char*)t->d_stage[b], len); if(rc) return rc;
+    HIP_TRY(hipEventRecord(t->stage_done[b], t->stream));
+    if(o + len >= n) break;
+  }
+  return JFGPU_OK;
+}
+
+int jfgpu_add_keys_dev(jfgpu_table* t, const uint64_t* d_keys, size_t n, uint64_t val, uint8_t* d_is_new) {
+  int rc = use(t); if(rc) return rc;
+  if(!n) return JFGPU_OK;
+  if(!d_keys) return fail(JFGPU_E_INVALID, "null keys");
+  const int grid = grid_for(t, (n + kBlock - 1) / kBlock);
+  ProfScope ps(t, 1, n);
+  if(val == 1 && !d_is_new) {
+    if(t->returning) hipLaunchKernelGGL(add_keys_one_kernel<true>, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, d_keys, (uint64_t)n);
+    else             hipLaunchKernelGGL(add_keys_one_kernel<false>, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, d_keys, (uint64_t)n);
+  } else {
+    hipLaunchKernelGGL(add_keys_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, d_keys, (uint64_t)n, val, d_is_new);
+  }
+  HIP_TRY(hipGetLastError());
+  return JFGPU_OK;
+}
+
+int jfgpu_add_keys(jfgpu_table* t, const uint64_t* keys, size_t n, uint64_t val, uint8_t* is_new) {
+  int rc = use(t); if(rc) return rc;
+  if(!n) return JFGPU_OK;
+  uint64_t* d_k = nullptr; uint8_t* d_n = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_k, n * sizeof(uint64_t)));
+  if(is_new && hipMalloc((void**)&d_n, n) != hipSuccess) { hipFree(d_k); return fail(JFGPU_E_ALLOC, "hipMalloc is_new"); }
+  hipError_t e = hipMemcpyAsync(d_k, keys, n * sizeof(uint64_t), hipMemcpyHostToDevice, t->stream);
+  if(e == hipSuccess) { rc = jfgpu_add_keys_dev(t, d_k, n, val, d_n); }
+  if(e == hipSuccess && !rc && is_new) e = hipMemcpyAsync(is_new, d_n, n, hipMemcpyDeviceToHost, t->stream);
+  hipStreamSynchronize(t->stream);
+  hipFree(d_k); if(d_n) hipFree(d_n);
+  if(e != hipSuccess) return fail(JFGPU_E_HIP, hipGetErrorString(e));
+  if(rc) return rc;
+  return check_deferred(t);
+}
+
+int jfgpu_lookup_dev(jfgpu_table* t, const uint64_t* d_keys, size_t n, uint64_t* d_vals, uint8_t* d_found) {
+  int rc = use(t); if(rc) return rc;
+  if(!n) return JFGPU_OK;
+  if(!d_keys || !d_vals) return fail(JFGPU_E_INVALID, "null argument");
+  uint64_t c[CTR_COUNT];
+  rc = check_deferred(t, c); if(rc) return rc;
+  const int grid = grid_for(t, (n + kBlock - 1) / kBlock);
+  ProfScope ps(t, 3, n);
+  hipLaunchKernelGGL(lookup_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, d_keys, (uint64_t)n, d_vals, d_found,
+                     (int)(c[CTR_OVF_USED] != 0));
+  HIP_TRY(hipGetLastError());
+  return JFGPU_OK;
+}
+
+int jfgpu_lookup(jfgpu_table* t, const uint64_t* keys, size_t n, uint64_t* vals, uint8_t* found) {
+  int rc = use(t); if(rc) return rc;
+  if(!n) return JFGPU_OK;
+  uint64_t *d_k = nullptr, *d_v = nullptr; uint8_t* d_f = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_k, n * sizeof(uint64_t)));
+  if(hipMalloc((void**)&d_v, n * sizeof(uint64_t)) != hipSuccess || hipMalloc((void**)&d_f, n) != hipSuccess) {
+    hipFree(d_k); if(d_v) hipFree(d_v);
+    return fail(JFGPU_E_ALLOC, "hipMalloc lookup buffers");
+  }
+  hipError_t e = hipMemcpyAsync(d_k, keys, n * sizeof(uint64_t), hipMemcpyHostToDevice, t->stream);
+  if(e == hipSuccess) rc = jfgpu_lookup_dev(t, d_k, n, d_v, d_f);
+  if(e == hipSuccess && !rc) e = hipMemcpyAsync(vals, d_v, n * sizeof(uint64_t), hipMemcpyDeviceToHost, t->stream);
+  if(e == hipSuccess && !rc && found) e = hipMemcpyAsync(found, d_f, n, hipMemcpyDeviceToHost, t->stream);
+  hipStreamSynchronize(t->stream);
+  hipFree(d_k); hipFree(d_v); hipFree(d_f);
+  if(e != hipSuccess) return fail(JFGPU_E_HIP, hipGetErrorString(e));
+  return rc;
+}
+
+int jfgpu_partition_ascii_dev(jfgpu_table* t, const char* d_bases, size_t n, uint64_t* d_keys_out, size_t capacity,
+                              uint64_t* counts_out) {
+  int rc = use(t); if(rc) return rc;
+  if(!counts_out) return fail(JFGPU_E_INVALID, "null counts_out");
+  const uint32_t n_shards = 1u << t->g.shard_bits;
+  for(uint32_t i = 0; i < n_shards; ++i) counts_out[i] = 0;
+  if(n < t->g.k) return JFGPU_OK;
+  if(!d_bases || !d_keys_out) return fail(JFGPU_E_INVALID, "null buffer");
+  unsigned long long* d_cnt = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_cnt, sizeof(unsigned long long) * n_shards));
+  HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long) * n_shards, t->stream));
+  const uint8_t* base; int64_t lo, hi;
+  align_buffer(d_bases, n, base, lo, hi);
+  const int64_t n_tiles = (hi + kTilePos - 1) / kTilePos;
+  const int grid = grid_for(t, (uint64_t)n_tiles);
+  {
+    ProfScope ps(t, 2, n);
+    hipLaunchKernelGGL(partition_count_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, base, lo, hi, d_cnt);
+  }
+  std::vector<unsigned long long> h(n_shards);
+  hipError_t e = hipMemcpyAsync(h.data(), d_cnt, sizeof(unsigned long long) * n_shards, hipMemcpyDeviceToHost, t->stream);
+  if(e == hipSuccess) e = hipStreamSynchronize(t->stream);
+  if(e != hipSuccess) { hipFree(d_cnt); return fail(JFGPU_E_HIP, hipGetErrorString(e)); }
+  uint64_t total = 0;
+  std::vector<unsigned long long> offs(n_shards);
+  for(uint32_t i = 0; i < n_shards; ++i) { offs[i] = total; total += h[i]; counts_out[i] = h[i]; }
+  if(total > capacity) { hipFree(d_cnt); return fail(JFGPU_E_INVALID, "partition buffer too small: need " + std::to_string(total) + " keys"); }
+  e = hipMemcpyAsync(d_cnt, offs.data(), sizeof(unsigned long long) * n_shards, hipMemcpyHostToDevice, t->stream);
+  if(e == hipSuccess) {
+    ProfScope ps(t, 2, 0);
+    hipLaunchKernelGGL(partition_scatter_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, base, lo, hi, d_cnt, d_keys_out);
+    e = hipGetLastError();
+  }
+  if(e == hipSuccess) e = hipStreamSynchronize(t->stream);
+  hipFree(d_cnt);
+  if(e != hipSuccess) return fail(JFGPU_E_HIP, hipGetErrorString(e));
+  return JFGPU_OK;
+}
+
+int jfgpu_stats_compute(jfgpu_table* t, uint64_t lower, uint64_t upper, jfgpu_stats* out) {
+  int rc = use(t); if(rc) return rc;
+  if(!out) return fail(JFGPU_E_INVALID, "null out");
+  uint64_t c[CTR_COUNT];
+  rc = check_deferred(t, c); if(rc) return rc;
+  unsigned long long* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, 4 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), t->stream));
+  const int grid = grid_for(t, (1ull << t->g.lsize_l) / kBlock + 1);
+  hipLaunchKernelGGL(stats_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, lower, upper, (int)(c[CTR_OVF_USED] != 0), d);
+  unsigned long long h[4];
+  hipError_t e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, t->stream);
+  if(e == hipSuccess) e = hipStreamSynchronize(t->stream);
+  hipFree(d);
+  if(e != hipSuccess) return fail(JFGPU_E_HIP, hipGetErrorString(e));
+  out->unique = h[0]; out->distinct = h[1]; out->total = h[2]; out->max_count = h[3];
+  out->occupied = h[1]; out->mers_fed = c[CTR_MERS];
+  return JFGPU_OK;
+}
+
+int jfgpu_histo(jfgpu_table* t, uint64_t base, uint64_t ceil, uint64_t inc, uint64_t* histo, uint64_t nb) {
+  int rc = use(t); if(rc) return rc;
+  if(!histo || !nb || !inc) return fail(JFGPU_E_INVALID, "bad histogram arguments");
+  uint64_t c[CTR_COUNT];
+  rc = check_deferred(t, c); if(rc) return rc;
+  unsigned long long* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, nb * sizeof(unsigned long long)));
+  HIP_TRY(hipMemsetAsync(d, 0, nb * sizeof(unsigned long long), t->stream));
+  const int grid = grid_for(t, (1ull << t->g.lsize_l) / kBlock + 1);
+  hipLaunchKernelGGL(histo_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, base, ceil, inc, nb, (int)(c[CTR_OVF_USED] != 0), d);
+  hipError_t e = hipMemcpyAsync(histo, d, nb * sizeof(uint64_t), hipMemcpyDeviceToHost, t->stream);
+  if(e == hipSuccess) e = hipStreamSynchronize(t->stream);
+  hipFree(d);
+  if(e != hipSuccess) return fail(JFGPU_E_HIP, hipGetErrorString(e));
+  return JFGPU_OK;
+}
+
+int jfgpu_dump_begin(jfgpu_table* t, uint64_t lower, uint64_t upper, uint64_t* n_records, uint32_t* record_bytes) {
+  int rc = use(t); if(rc) return rc;
+  uint64_t c[CTR_COUNT];
+  rc = check_deferred(t, c); if(rc) return rc;
+  const uint64_t nt = n_tiles_of(t);
+  uint32_t* d_cnt = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_cnt, nt * sizeof(uint32_t)));
+  t->dump_have_ovf = c[CTR_OVF_USED] != 0;
+  hipLaunchKernelGGL(tile_count_kernel, dim3(grid_for(t, nt)), dim3(kBlock), 0, t->stream, t->dt, lower, upper,
+                     t->dump_have_ovf, nt, d_cnt);
+  std::vector<uint32_t> h(nt);
+  hipError_t e = hipMemcpyAsync(h.data(), d_cnt, nt * sizeof(uint32_t), hipMemcpyDeviceToHost, t->stream);
+  if(e == hipSuccess) e = hipStreamSynchronize(t->stream);
+  hipFree(d_cnt);
+  if(e != hipSuccess) return fail(JFGPU_E_HIP, hipGetErrorString(e));
+  t->dump_prefix.assign(nt + 1, 0);
+  for(uint64_t i = 0; i < nt; ++i) t->dump_prefix[i + 1] = t->dump_prefix[i] + h[i];
+  t->dump_lower = lower; t->dump_upper = upper; t->dump_tile_cursor = 0; t->dump_open = true;
+  if(n_records) *n_records = t->dump_prefix[nt];
+  if(record_bytes) *record_bytes = (t->g.key_bits + 7) / 8 + t->out_counter_len;
+  return JFGPU_OK;
+}
+
+int jfgpu_dump_next(jfgpu_table* t, void* out, uint64_t capacity_records, uint64_t* n_read) {
+  int rc = use(t); if(rc) return rc;
+  if(!t->dump_open) return fail(JFGPU_E_INVALID, "jfgpu_dump_begin not called");
+  if(!out || !n_read) return fail(JFGPU_E_INVALID, "null argument");
+  *n_read = 0;
+  const uint64_t nt = n_tiles_of(t);
+  const uint64_t tsz = 1ull << t->g.tile_bits;
+  if(capacity_records < tsz) return fail(JFGPU_E_INVALID, "dump buffer must hold at least one tile (" + std::to_string(tsz) + " records)");
+  uint64_t t0 = t->dump_tile_cursor;
+  while(t0 < nt && t->dump_prefix[t0 + 1] == t->dump_prefix[t0]) ++t0;  // skip empty tiles
+  if(t0 >= nt) { t->dump_tile_cursor = nt; return JFGPU_OK; }
+  // largest t1 with prefix[t1] - prefix[t0] <= capacity
+  const uint64_t limit = t->dump_prefix[t0] + capacity_records;
+  uint64_t t1 = std::upper_bound(t->dump_prefix.begin() + t0, t->dump_prefix.end(), limit) - t->dump_prefix.begin() - 1;
+  t1 = std::min(t1, nt);
+  const uint64_t ntile = t1 - t0, nrec = t->dump_prefix[t1] - t->dump_prefix[t0];
+  const uint32_t key_bytes = (t->g.key_bits + 7) / 8, rec = key_bytes + t->out_counter_len;
+  if(t->dump_cap_records < nrec) {
+    if(t->d_dump) hipFree(t->d_dump);
+    t->d_dump = nullptr; t->dump_cap_records = 0;
+    HIP_TRY(hipMalloc((void**)&t->d_dump, std::max<uint64_t>(nrec, capacity_records) * rec));
+    t->dump_cap_records = std::max<uint64_t>(nrec, capacity_records);
+  }
+  if(t->tile_off_cap < ntile) {
+    if(t->d_tile_off) hipFree(t->d_tile_off);
+    t->d_tile_off = nullptr; t->tile_off_cap = 0;
+    HIP_TRY(hipMalloc((void**)&t->d_tile_off, ntile * sizeof(uint64_t)));
+    t->tile_off_cap = ntile;
+  }
+  std::vector<uint64_t> offs(ntile);
+  for(uint64_t i = 0; i < ntile; ++i) offs[i] = t->dump_prefix[t0 + i] - t->dump_prefix[t0];
+  HIP_TRY(hipMemcpyAsync(t->d_tile_off, offs.data(), ntile * sizeof(uint64_t), hipMemcpyHostToDevice, t->stream));
+  const size_t lds = ((size_t)8 << t->g.tile_bits) + ((size_t)2 << t->g.tile_bits) + (size_t)t->g.nbytes * 2048;
+  hipLaunchKernelGGL(dump_tiles_kernel, dim3(grid_for(t, ntile)), dim3(kBlock), lds, t->stream, t->dt, t->dump_lower,
+                     t->dump_upper, t->dump_have_ovf, t0, ntile, (const uint64_t*)t->d_tile_off, t->d_dump, key_bytes,
+                     t->out_counter_len);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out, t->d_dump, nrec * rec, hipMemcpyDeviceToHost, t->stream));
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  t->dump_tile_cursor = t1;
+  *n_read = nrec;
+  return JFGPU_OK;
+}
+
+int jfgpu_dump_end(jfgpu_table* t) {
+  int rc = use(t); if(rc) return rc;
+  t->dump_open = false;
+  t->dump_prefix.clear(); t->dump_prefix.shrink_to_fit();
+  if(t->d_dump) { hipFree(t->d_dump); t->d_dump = nullptr; t->dump_cap_records = 0; }
+  if(t->d_tile_off) { hipFree(t->d_tile_off); t->d_tile_off = nullptr; t->tile_off_cap = 0; }
+  return JFGPU_OK;
+}
+
+int jfgpu_profile_enable(jfgpu_table* t, int on) {
+  int rc = use(t); if(rc) return rc;
+  t->prof_on = on != 0;
+  return JFGPU_OK;
+}
+
+int jfgpu_profile_get(jfgpu_table* t, int which, double* ms, uint64_t* launches, uint64_t* units) {
+  int rc = use(t); if(rc) return rc;
+  if(which < 0 || which >= kNumProf) return fail(JFGPU_E_INVALID, "bad profile slot");
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  prof_collect(t);
+  if(ms) *ms = t->prof_ms[which];
+  if(launches) *launches = t->prof_launches[which];
+  if(units) *units = t->prof_units[which];
+  return JFGPU_OK;
+}
+
+int jfgpu_profile_reset(jfgpu_table* t) {
+  int rc = use(t); if(rc) return rc;
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  prof_collect(t);
+  for(int i = 0; i < kNumProf; ++i) { t->prof_ms[i] = 0; t->prof_launches[i] = 0; t->prof_units[i] = 0; }
+  return JFGPU_OK;
+}
+
+int jfgpu_gen_reads_dev(jfgpu_table* t, char* d_out, uint64_t first_read, uint64_t n_reads, uint32_t read_len, uint64_t seed) {
+  int rc = use(t); if(rc) return rc;
+  if(!n_reads) return JFGPU_OK;
+  if(!d_out) return fail(JFGPU_E_INVALID, "null buffer");
+  if(read_len < 1 || read_len > 2048) return fail(JFGPU_E_INVALID, "read_len must be in [1, 2048]");
+  if(((uintptr_t)d_out & 15) != 0) return fail(JFGPU_E_INVALID, "gen_reads: output must be 16-byte aligned");
+  const uint64_t vecs = (n_reads * ((uint64_t)read_len + 1) + 15) / 16;
+  hipLaunchKernelGGL(gen_reads_kernel, dim3(grid_for(t, (vecs + kBlock - 1) / kBlock)), dim3(kBlock), 0, t->stream,
+                     (uint8_t*)d_out, first_read, n_reads, read_len, seed);
+  HIP_TRY(hipGetLastError());
+  return JFGPU_OK;
+}
+
+int jfgpu_gups(jfgpu_table* t, uint64_t n_updates, int mode, double* ups) {
+  int rc = use(t); if(rc) return rc;
+  if(!ups) return fail(JFGPU_E_INVALID, "null out");
+  unsigned long long* d_sink = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_sink, sizeof(unsigned long long)));
+  HIP_TRY(hipMemsetAsync(d_sink, 0, sizeof(unsigned long long), t->stream));
+  hipEvent_t a, b;
+  HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
+  const uint64_t mask = (1ull << t->g.lsize_l) - 1;
+  const int grid = grid_for(t, (n_updates + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(gups_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->dt.slots, mask, std::min<uint64_t>(n_updates, 1u << 20), mode, 1ull, d_sink);  // warm-up
+  HIP_TRY(hipEventRecord(a, t->stream));
+  hipLaunchKernelGGL(gups_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->dt.slots, mask, n_updates, mode, 42ull, d_sink);
+  HIP_TRY(hipEventRecord(b, t->stream));
+  HIP_TRY(hipEventSynchronize(b));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, a, b));
+  hipEventDestroy(a); hipEventDestroy(b); hipFree(d_sink);
+  *ups = ms > 0 ? (double)n_updates / (ms * 1e-3) : 0;
+  return JFGPU_OK;
+}
+
+int jfgpu_malloc_dev(jfgpu_table* t, size_t bytes, void** out) {
+  int rc = use(t); if(rc) return rc;
+  if(!out) return fail(JFGPU_E_INVALID, "null out");
+  HIP_TRY(hipMalloc(out, bytes ? bytes : 16));
+  return JFGPU_OK;
+}
+int jfgpu_free_dev(jfgpu_table* t, void* p) {
+  int rc = use(t); if(rc) return rc;
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  HIP_TRY(hipFree(p));
+  return JFGPU_OK;
+}
+int jfgpu_memcpy_h2d(jfgpu_table* t, void* d_dst, const void* src, size_t bytes) {
+  int rc = use(t); if(rc) return rc;
+  HIP_TRY(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, t->stream));
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  return JFGPU_OK;
+}
+int jfgpu_memcpy_d2h(jfgpu_table* t, void* dst, const void* d_src, size_t bytes) {
+  int rc = use(t); if(rc) return rc;
+  HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, t->stream));
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  return JFGPU_OK;
+}
+
+}  // extern "C"

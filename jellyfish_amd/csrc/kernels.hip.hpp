@@ -1,0 +1,515 @@
+// jellyfish_amd/csrc/kernels.hip.hpp -- gfx950 (CDNA4) device code of the hot path.
+//
+// What each kernel replaces in the reference (paths relative to /root/reference):
+//   count_ascii_kernel   the COUNT loop of mer_counter_base::start
+//                        (sub_commands/count_main.cc:152-163): mer_iterator
+//                        (mer_iterator.hpp:53-81) + RectangularBinaryMatrix::times
+//                        (rectangular_binary_matrix.hpp:155-164) + array_base::add
+//                        (large_hash_array.hpp:291-295,509-597,741-752)
+//   add_keys_kernel      hash_counter::add on encoded mers (hash_counter.hpp:91-126)
+//   lookup_kernel        array_base::get_val_for_key (large_hash_array.hpp:354-372)
+//   partition_*_kernel   new: hash-prefix routing of k-mers to their owning GPU
+//   stats/histo/dump     region iterators + sorted_dumper + binary_writer
+//                        (large_hash_iterator.hpp, sorted_dumper.hpp:57-101,
+//                        binary_dumper.hpp:36-40)
+//
+// Design notes (see DESIGN.md for the numbers):
+//   * wave64 everywhere; blocks of 256 threads = 4 waves, one per SIMD.
+//   * sequence bytes are read once, 16 B per lane (1 KiB per wave-instruction),
+//     converted to 2-bit codes + an invalid mask in registers and exchanged with
+//     the neighbouring lanes through LDS (k-1 <= 31 bases of halo = two words).
+//   * the GF(2) hash is 2k/8 LDS table look-ups (the matrix is linear), not
+//     2k select-XORs.
+//   * the table lives in HBM as 64-bit slots; claim = one 64-bit atomicCAS,
+//     increment = one 64-bit atomicAdd.  Integer / indexing work: no MFMA.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kmer_core.hpp"
+
+namespace jfgpu {
+
+constexpr int kBlock = 256;
+constexpr int kPerThread = kPerLane;           // positions per lane per tile (16)
+constexpr int kTilePos = kBlock * kPerThread;  // 4096 sequence positions per block iteration
+
+enum Counter : int { CTR_FULL = 0, CTR_MERS = 1, CTR_OVF_FULL = 2, CTR_OVF_USED = 3, CTR_MISROUTED = 4, CTR_COUNT = 8 };
+
+struct DevTable {
+  TableGeom g;
+  uint64_t* slots;            // [1 << lsize_l]
+  const uint64_t* fwd_tbl;    // [nbytes * 256]   key -> pos
+  const uint64_t* inv_tbl;    // [nbytes * 256]   (rem, pos) -> low key bits
+  uint64_t* ovf_key;          // overflow side table, keyed by slot index + 1 (0 = empty)
+  uint64_t* ovf_cnt;          // units of 2^cnt_bits
+  uint64_t ovf_mask;          // capacity - 1
+  uint64_t* counters;         // [CTR_COUNT]
+};
+
+// ---- overflow side table ----------------------------------------------------
+// A slot's count field wrapped: remember `units` x 2^cnt_bits for that slot.  Keyed by
+// the slot index, which identifies the key (keys never move while the table lives).
+__device__ inline void ovf_add(const DevTable& T, uint64_t slot, uint64_t units) {
+  const uint64_t want = slot + 1;
+  uint64_t h = (slot * 0x9E3779B97F4A7C15ull) >> 20;
+  for(uint64_t p = 0; p <= T.ovf_mask; ++p) {
+    const uint64_t s = (h + p) & T.ovf_mask;
+    unsigned long long old = atomicCAS((unsigned long long*)&T.ovf_key[s], 0ull, (unsigned long long)want);
+    if(old == 0ull) atomicAdd((unsigned long long*)&T.counters[CTR_OVF_USED], 1ull);
+    if(old == 0ull || old == want) {
+      atomicAdd((unsigned long long*)&T.ovf_cnt[s], (unsigned long long)units);
+      return;
+    }
+  }
+  atomicAdd((unsigned long long*)&T.counters[CTR_OVF_FULL], 1ull);
+}
+
+__device__ inline uint64_t ovf_get(const DevTable& T, uint64_t slot) {
+  const uint64_t want = slot + 1;
+  uint64_t h = (slot * 0x9E3779B97F4A7C15ull) >> 20;
+  for(uint64_t p = 0; p <= T.ovf_mask; ++p) {
+    const uint64_t s = (h + p) & T.ovf_mask;
+    const uint64_t k = T.ovf_key[s];
+    if(k == 0) return 0;
+    if(k == want) return T.ovf_cnt[s];
+  }
+  return 0;
+}
+
+__device__ inline uint64_t full_count(const DevTable& T, uint64_t word, uint64_t slot, bool have_ovf) {
+  uint64_t c = slot_count(T.g, word);
+  if(have_ovf) c += ovf_get(T, slot) << T.g.cnt_bits;
+  return c;
+}
+
+// ---- insert / increment -------------------------------------------------------
+// large_hash_array.hpp:509-597 (claim_key) + :741-752 (add_val), restated for a
+// 64-bit [count|occ|tag] slot: CAS the whole word from 0 to claim, atomicAdd on
+// the top field to increment.  Returns true when the key was new.
+// RETURNING selects the add that reads back the old value (needed only when the
+// count field can wrap; a fire-and-forget add otherwise).
+template <bool RETURNING>
+__device__ inline bool table_add(const DevTable& T, const uint64_t* fwd_lds, uint64_t key, uint64_t cnt) {
+  const TableGeom& g = T.g;
+  const uint64_t pos = hash_tables(fwd_lds, key, g.nbytes);
+  const SlotAddr a = slot_addr(g, pos);
+  if(a.shard != g.shard_id) {  // a key that belongs to another GPU's shard must never land here
+    atomicAdd((unsigned long long*)&T.counters[CTR_MISROUTED], 1ull);
+    return false;
+  }
+  const uint64_t tag = make_tag(g, key, a.idx0);
+  const uint64_t low = g.occ_bit | tag;
+  const uint64_t add = cnt << (g.tag_bits + 1);
+  const uint64_t neww = add | low;
+  const uint32_t tmask = (uint32_t)g.tile_mask;
+  for(uint32_t p = 0; p <= tmask; ++p) {
+    const uint64_t slot = a.tile_base + probe_slot(a.idx0, p, tmask);
+    unsigned long long* addr = (unsigned long long*)&T.slots[slot];
+    const unsigned long long old = atomicCAS(addr, 0ull, (unsigned long long)neww);
+    if(old == 0ull) return true;
+    if((old & g.low_mask) == low) {
+      if(RETURNING) {
+        const unsigned long long prev = atomicAdd(addr, (unsigned long long)add);
+        if((prev >> (g.tag_bits + 1)) + cnt > g.cnt_max) ovf_add(T, slot, 1);
+      } else {
+        __hip_atomic_fetch_add(addr, (unsigned long long)add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return false;
+    }
+  }
+  atomicAdd((unsigned long long*)&T.counters[CTR_FULL], 1ull);  // tile exhausted: "Hash full"
+  return false;
+}
+
+// Arbitrary 64-bit increment (hash_counter::add(key, val)): split into field-sized pieces.
+__device__ inline bool table_add_val(const DevTable& T, const uint64_t* fwd_lds, uint64_t key, uint64_t val) {
+  const TableGeom& g = T.g;
+  const uint64_t lowpart = val & g.cnt_max;
+  const uint64_t units = g.cnt_bits >= 64 ? 0 : (val >> g.cnt_bits);
+  // one claim-or-find with the low part (possibly 0: still claims the key, like set())
+  const uint64_t pos = hash_tables(fwd_lds, key, g.nbytes);
+  const SlotAddr a = slot_addr(g, pos);
+  if(a.shard != g.shard_id) {
+    atomicAdd((unsigned long long*)&T.counters[CTR_MISROUTED], 1ull);
+    return false;
+  }
+  const uint64_t tag = make_tag(g, key, a.idx0);
+  const uint64_t low = g.occ_bit | tag;
+  const uint64_t add = lowpart << (g.tag_bits + 1);
+  const uint32_t tmask = (uint32_t)g.tile_mask;
+  for(uint32_t p = 0; p <= tmask; ++p) {
+    const uint64_t slot = a.tile_base + probe_slot(a.idx0, p, tmask);
+    unsigned long long* addr = (unsigned long long*)&T.slots[slot];
+    const unsigned long long old = atomicCAS(addr, 0ull, (unsigned long long)(add | low));
+    bool mine = false, is_new = false;
+    if(old == 0ull) { mine = true; is_new = true; }
+    else if((old & g.low_mask) == low) {
+      mine = true;
+      if(add) {
+        const unsigned long long prev = atomicAdd(addr, (unsigned long long)add);
+        if((prev >> (g.tag_bits + 1)) + lowpart > g.cnt_max) ovf_add(T, slot, 1);
+      }
+    }
+    if(mine) {
+      if(units) ovf_add(T, slot, units);
+      return is_new;
+    }
+  }
+  atomicAdd((unsigned long long*)&T.counters[CTR_FULL], 1ull);
+  return false;
+}
+
+__device__ inline LaneWords stage_tile(const uint8_t* __restrict__ base, int64_t tile_start, int64_t lo, int64_t hi,
+                                       uint32_t* s_codes, uint32_t* s_inv) {
+  const int tid = threadIdx.x;
+  uint32_t c, v;
+  load_pack16(base, tile_start + 16 * tid, lo, hi, c, v);
+  s_codes[tid + 2] = c; s_inv[tid + 2] = v;
+  if(tid < 2) {
+    uint32_t hc, hv;
+    load_pack16(base, tile_start - 32 + 16 * tid, lo, hi, hc, hv);
+    s_codes[tid] = hc; s_inv[tid] = hv;
+  }
+  __syncthreads();
+  LaneWords L;
+  L.cur = c;
+  L.p1 = s_codes[tid + 1];
+  L.p2 = s_codes[tid];
+  L.inv48 = ((uint64_t)s_inv[tid] << 32) | ((uint64_t)s_inv[tid + 1] << 16) | v;
+  return L;
+}
+
+__device__ inline void load_tables_lds(uint64_t* dst, const uint64_t* src, uint32_t nbytes) {
+  for(uint32_t i = threadIdx.x; i < nbytes * 256; i += blockDim.x) dst[i] = src[i];
+}
+
+// ---- K2+K3 fused: count every k-mer of a contract buffer ----------------------
+// base: 16-byte aligned; valid bytes are [lo, hi).
+template <bool RETURNING>
+__global__ __launch_bounds__(kBlock) void count_ascii_kernel(DevTable T, const uint8_t* __restrict__ base,
+                                                             int64_t lo, int64_t hi) {
+  __shared__ uint64_t s_fwd[8 * 256];
+  __shared__ uint32_t s_codes[kBlock + 2];
+  __shared__ uint32_t s_inv[kBlock + 2];
+  load_tables_lds(s_fwd, T.fwd_tbl, T.g.nbytes);
+  const int64_t n_tiles = (hi + kTilePos - 1) / kTilePos;
+  uint32_t my_mers = 0;
+  for(int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    __syncthreads();  // previous iteration's LDS reads done (also orders the table load)
+    const LaneWords L = stage_tile(base, tile * kTilePos, lo, hi, s_codes, s_inv);
+    // run-length merge of consecutive identical k-mers (homopolymers / short tandem
+    // repeats are the heavy hitters of real data): one atomic per run, not per k-mer.
+    uint64_t prev = 0; uint32_t run = 0;
+    for_each_kmer(T.g, L, [&](int, uint64_t key) {
+      ++my_mers;
+      if(run && key == prev) { ++run; return; }
+      if(run) table_add<RETURNING>(T, s_fwd, prev, run);
+      prev = key; run = 1;
+    });
+    if(run) table_add<RETURNING>(T, s_fwd, prev, run);
+  }
+  // one counter update per wave
+  uint64_t w = my_mers;
+  for(int o = 32; o > 0; o >>= 1) w += __shfl_down(w, o, 64);
+  if((threadIdx.x & 63) == 0 && w) atomicAdd((unsigned long long*)&T.counters[CTR_MERS], (unsigned long long)w);
+}
+
+// ---- hash_counter::add on encoded keys -----------------------------------------
+__global__ __launch_bounds__(kBlock) void add_keys_kernel(DevTable T, const uint64_t* __restrict__ keys, uint64_t n,
+                                                          uint64_t val, uint8_t* __restrict__ is_new) {
+  __shared__ uint64_t s_fwd[8 * 256];
+  load_tables_lds(s_fwd, T.fwd_tbl, T.g.nbytes);
+  __syncthreads();
+  for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t key = keys[i] & T.g.key_mask;
+    const bool nw = table_add_val(T, s_fwd, key, val);
+    if(is_new) is_new[i] = nw ? 1 : 0;
+  }
+}
+
+// Same, but val == 1 and no is_new: the receive side of the multi-GPU exchange.
+template <bool RETURNING>
+__global__ __launch_bounds__(kBlock) void add_keys_one_kernel(DevTable T, const uint64_t* __restrict__ keys, uint64_t n) {
+  __shared__ uint64_t s_fwd[8 * 256];
+  load_tables_lds(s_fwd, T.fwd_tbl, T.g.nbytes);
+  __syncthreads();
+  for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    table_add<RETURNING>(T, s_fwd, keys[i] & T.g.key_mask, 1);
+}
+
+// ---- get_val_for_key -------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void lookup_kernel(DevTable T, const uint64_t* __restrict__ keys, uint64_t n,
+                                                        uint64_t* __restrict__ vals, uint8_t* __restrict__ found,
+                                                        int have_ovf) {
+  __shared__ uint64_t s_fwd[8 * 256];
+  load_tables_lds(s_fwd, T.fwd_tbl, T.g.nbytes);
+  __syncthreads();
+  const TableGeom& g = T.g;
+  const uint32_t tmask = (uint32_t)g.tile_mask;
+  for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t key = keys[i] & g.key_mask;
+    const uint64_t pos = hash_tables(s_fwd, key, g.nbytes);
+    const SlotAddr a = slot_addr(g, pos);
+    uint64_t val = 0; uint8_t fnd = 0;
+    if(a.shard == g.shard_id) {
+      const uint64_t low = g.occ_bit | make_tag(g, key, a.idx0);
+      for(uint32_t p = 0; p <= tmask; ++p) {
+        const uint64_t slot = a.tile_base + probe_slot(a.idx0, p, tmask);
+        const uint64_t w = T.slots[slot];
+        if(w == 0) break;
+        if((w & g.low_mask) == low) { val = full_count(T, w, slot, have_ovf); fnd = 1; break; }
+      }
+    }
+    vals[i] = val;
+    if(found) found[i] = fnd;
+  }
+}
+
+// ---- multi-GPU routing: count per shard, then scatter ----------------------------
+// Pass A: how many k-mers of this buffer belong to each shard.
+__global__ __launch_bounds__(kBlock) void partition_count_kernel(DevTable T, const uint8_t* __restrict__ base,
+                                                                 int64_t lo, int64_t hi,
+                                                                 unsigned long long* __restrict__ shard_counts) {
+  __shared__ uint64_t s_fwd[8 * 256];
+  __shared__ uint32_t s_codes[kBlock + 2];
+  __shared__ uint32_t s_inv[kBlock + 2];
+  __shared__ uint32_t s_hist[256];
+  load_tables_lds(s_fwd, T.fwd_tbl, T.g.nbytes);
+  const uint32_t n_shards = 1u << T.g.shard_bits;
+  for(uint32_t i = threadIdx.x; i < n_shards; i += blockDim.x) s_hist[i] = 0;
+  const int64_t n_tiles = (hi + kTilePos - 1) / kTilePos;
+  for(int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    __syncthreads();
+    const LaneWords L = stage_tile(base, tile * kTilePos, lo, hi, s_codes, s_inv);
+    for_each_kmer(T.g, L, [&](int, uint64_t key) {
+      const uint64_t pos = hash_tables(s_fwd, key, T.g.nbytes);
+      atomicAdd(&s_hist[(uint32_t)(pos >> T.g.lsize_l)], 1u);
+    });
+  }
+  __syncthreads();
+  for(uint32_t i = threadIdx.x; i < n_shards; i += blockDim.x)
+    if(s_hist[i]) atomicAdd(&shard_counts[i], (unsigned long long)s_hist[i]);
+}
+
+// Pass B: write each k-mer into its shard's region.  cursors[s] starts at the
+// region's offset; a block reserves its share with one atomic per (tile, shard).
+__global__ __launch_bounds__(kBlock) void partition_scatter_kernel(DevTable T, const uint8_t* __restrict__ base,
+                                                                   int64_t lo, int64_t hi,
+                                                                   unsigned long long* __restrict__ cursors,
+                                                                   uint64_t* __restrict__ out) {
+  __shared__ uint64_t s_fwd[8 * 256];
+  __shared__ uint32_t s_codes[kBlock + 2];
+  __shared__ uint32_t s_inv[kBlock + 2];
+  __shared__ uint32_t s_hist[256];
+  __shared__ unsigned long long s_base[256];
+  load_tables_lds(s_fwd, T.fwd_tbl, T.g.nbytes);
+  const uint32_t n_shards = 1u << T.g.shard_bits;
+  const int64_t n_tiles = (hi + kTilePos - 1) / kTilePos;
+  for(int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    __syncthreads();
+    for(uint32_t i = threadIdx.x; i < n_shards; i += blockDim.x) s_hist[i] = 0;
+    const LaneWords L = stage_tile(base, tile * kTilePos, lo, hi, s_codes, s_inv);  // contains a barrier
+    // indexed by the unrolled position j (compile-time after unrolling) so these stay in VGPRs
+    uint64_t keys[kPerThread]; uint32_t shard[kPerThread]; uint32_t rank[kPerThread]; uint32_t vmask = 0;
+    for_each_kmer(T.g, L, [&](int j, uint64_t key) {
+      const uint64_t pos = hash_tables(s_fwd, key, T.g.nbytes);
+      const uint32_t s = (uint32_t)(pos >> T.g.lsize_l);
+      keys[j] = key; shard[j] = s;
+      rank[j] = atomicAdd(&s_hist[s], 1u);
+      vmask |= 1u << j;
+    });
+    __syncthreads();
+    for(uint32_t i = threadIdx.x; i < n_shards; i += blockDim.x)
+      s_base[i] = s_hist[i] ? atomicAdd(&cursors[i], (unsigned long long)s_hist[i]) : 0ull;
+    __syncthreads();
+#pragma unroll
+    for(int j = 0; j < kPerThread; ++j)
+      if((vmask >> j) & 1u) out[s_base[shard[j]] + rank[j]] = keys[j];
+  }
+}
+
+// ---- stats (stats_main.cc:33-46) ---------------------------------------------------
+// out: [0] unique [1] distinct [2] total [3] max
+__global__ __launch_bounds__(kBlock) void stats_kernel(DevTable T, uint64_t lower, uint64_t upper, int have_ovf,
+                                                       unsigned long long* __restrict__ out) {
+  const uint64_t n = 1ull << T.g.lsize_l;
+  uint64_t uniq = 0, dist = 0, tot = 0, mx = 0;
+  for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t w = T.slots[i];
+    if(!w) continue;
+    const uint64_t c = full_count(T, w, i, have_ovf);
+    if(c < lower || c > upper) continue;
+    uniq += (c == 1); ++dist; tot += c; mx = c > mx ? c : mx;
+  }
+  for(int o = 32; o > 0; o >>= 1) {
+    uniq += __shfl_down(uniq, o, 64); dist += __shfl_down(dist, o, 64); tot += __shfl_down(tot, o, 64);
+    const uint64_t m2 = __shfl_down(mx, o, 64); mx = m2 > mx ? m2 : mx;
+  }
+  if((threadIdx.x & 63) == 0) {
+    if(uniq) atomicAdd(&out[0], (unsigned long long)uniq);
+    if(dist) atomicAdd(&out[1], (unsigned long long)dist);
+    if(tot) atomicAdd(&out[2], (unsigned long long)tot);
+    if(mx) atomicMax(&out[3], (unsigned long long)mx);
+  }
+}
+
+// ---- histo (histo_main.cc:34-45) -----------------------------------------------------
+constexpr uint32_t kHistoLds = 8192;  // buckets privatised per block
+__global__ __launch_bounds__(kBlock) void histo_kernel(DevTable T, uint64_t hbase, uint64_t hceil, uint64_t inc,
+                                                       uint64_t nb, int have_ovf, unsigned long long* __restrict__ histo) {
+  __shared__ uint32_t s_h[kHistoLds];
+  const uint32_t nl = nb < kHistoLds ? (uint32_t)nb : kHistoLds;
+  for(uint32_t i = threadIdx.x; i < nl; i += blockDim.x) s_h[i] = 0;
+  __syncthreads();
+  const uint64_t n = 1ull << T.g.lsize_l;
+  for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t w = T.slots[i];
+    if(!w) continue;
+    const uint64_t c = full_count(T, w, i, have_ovf);
+    uint64_t b;
+    if(c < hbase) b = 0; else if(c > hceil) b = nb - 1; else b = (c - hbase) / inc;
+    if(b < nl) atomicAdd(&s_h[(uint32_t)b], 1u); else atomicAdd(&histo[b], 1ull);
+  }
+  __syncthreads();
+  for(uint32_t i = threadIdx.x; i < nl; i += blockDim.x)
+    if(s_h[i]) atomicAdd(&histo[i], (unsigned long long)s_h[i]);
+}
+
+// ---- sorted dump ------------------------------------------------------------------------
+// Pass 1: records per tile after the [lower, upper] filter.
+__global__ __launch_bounds__(kBlock) void tile_count_kernel(DevTable T, uint64_t lower, uint64_t upper, int have_ovf,
+                                                            uint64_t n_tiles, uint32_t* __restrict__ tile_counts) {
+  __shared__ uint32_t s_sum[kBlock / 64];
+  const uint32_t tsz = 1u << T.g.tile_bits;
+  for(uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const uint64_t tb = tile << T.g.tile_bits;
+    uint32_t c = 0;
+    for(uint32_t i = threadIdx.x; i < tsz; i += blockDim.x) {
+      const uint64_t w = T.slots[tb + i];
+      if(!w) continue;
+      const uint64_t cnt = full_count(T, w, tb + i, have_ovf);
+      c += (cnt >= lower && cnt <= upper);
+    }
+    for(int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if(threadIdx.x == 0) { uint32_t s = 0; for(int i = 0; i < kBlock / 64; ++i) s += s_sum[i]; tile_counts[tile] = s; }
+    __syncthreads();
+  }
+}
+
+// Pass 2: one block per tile.  Load the tile into LDS, bitonic-sort by tag (== (pos, key)
+// order, mer_heap.hpp:26-30), rebuild each key with the inverse tables and emit
+// fixed-width records (binary_dumper.hpp:36-40) at the tile's record offset.
+// Dynamic LDS: tsz * 8 (words) + tsz * 2 (slot index) + nbytes * 2048 (inverse tables).
+__global__ __launch_bounds__(kBlock) void dump_tiles_kernel(DevTable T, uint64_t lower, uint64_t upper, int have_ovf,
+                                                            uint64_t tile0, uint64_t n_tiles,
+                                                            const uint64_t* __restrict__ tile_offsets,  // record offset of tile (relative to tile0's)
+                                                            uint8_t* __restrict__ out, uint32_t key_bytes, uint32_t val_bytes) {
+  extern __shared__ __align__(16) unsigned char s_raw[];
+  const uint32_t tsz = 1u << T.g.tile_bits;
+  uint64_t* s_w = reinterpret_cast<uint64_t*>(s_raw);
+  uint64_t* s_invt = s_w + tsz;
+  uint16_t* s_idx = reinterpret_cast<uint16_t*>(s_invt + T.g.nbytes * 256);
+  load_tables_lds(s_invt, T.inv_tbl, T.g.nbytes);
+  const uint64_t tagmask = T.g.occ_bit - 1;
+  const uint64_t SENT = ~0ull;
+  const uint64_t maxval = val_bytes >= 8 ? ~0ull : ((1ull << (8 * val_bytes)) - 1);
+  const uint32_t rec = key_bytes + val_bytes;
+  for(uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const uint64_t tile = tile0 + t;
+    const uint64_t tb = tile << T.g.tile_bits;
+    __syncthreads();
+    for(uint32_t i = threadIdx.x; i < tsz; i += blockDim.x) {
+      uint64_t w = T.slots[tb + i];
+      uint64_t sk = SENT;
+      if(w) {
+        const uint64_t cnt = full_count(T, w, tb + i, have_ovf);
+        if(cnt >= lower && cnt <= upper) sk = w;
+      }
+      s_w[i] = sk; s_idx[i] = (uint16_t)i;
+    }
+    __syncthreads();
+    // bitonic sort ascending on (word & tagmask), sentinels last
+    for(uint32_t size = 2; size <= tsz; size <<= 1) {
+      for(uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+        for(uint32_t i = threadIdx.x; i < tsz / 2; i += blockDim.x) {
+          const uint32_t lo = ((i & ~(stride - 1)) << 1) | (i & (stride - 1));
+          const uint32_t hi = lo | stride;
+          const bool up = (lo & size) == 0;
+          const uint64_t a = s_w[lo], b = s_w[hi];
+          const uint64_t ka = a == SENT ? SENT : (a & tagmask), kb = b == SENT ? SENT : (b & tagmask);
+          if((ka > kb) == up) {
+            s_w[lo] = b; s_w[hi] = a;
+            const uint16_t ia = s_idx[lo]; s_idx[lo] = s_idx[hi]; s_idx[hi] = ia;
+          }
+        }
+        __syncthreads();
+      }
+    }
+    uint8_t* dst0 = out + tile_offsets[t] * rec;
+    for(uint32_t i = threadIdx.x; i < tsz; i += blockDim.x) {
+      const uint64_t w = s_w[i];
+      if(w == SENT) continue;
+      const uint64_t key = slot_key(T.g, s_invt, w, tb);
+      uint64_t cnt = slot_count(T.g, w);
+      if(have_ovf) cnt += ovf_get(T, tb + s_idx[i]) << T.g.cnt_bits;
+      if(cnt > maxval) cnt = maxval;
+      uint8_t* d = dst0 + (uint64_t)i * rec;
+      for(uint32_t b = 0; b < key_bytes; ++b) d[b] = (uint8_t)(key >> (8 * b));
+      for(uint32_t b = 0; b < val_bytes; ++b) d[key_bytes + b] = (uint8_t)(cnt >> (8 * b));
+    }
+  }
+}
+
+// ---- synthetic reads (generate_sequence-like: iid uniform bases) ---------------------------
+__device__ inline uint64_t mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(kBlock) void gen_reads_kernel(uint8_t* __restrict__ out, uint64_t first_read, uint64_t n_reads,
+                                                           uint32_t read_len, uint64_t seed) {
+  const uint64_t stride = (uint64_t)read_len + 1;
+  const uint64_t total = n_reads * stride;
+  for(uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v * 16 < total; v += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t p0 = v * 16;
+    uint64_t r = p0 / stride; uint32_t off = (uint32_t)(p0 - r * stride);
+    uint32_t w[4] = {0, 0, 0, 0};
+    uint64_t draw = 0; uint64_t draw_id = ~0ull;
+    for(int i = 0; i < 16; ++i) {
+      uint32_t ch = 0;
+      if(p0 + i < total) {
+        if(off == read_len) ch = 'N';
+        else {
+          const uint64_t id = (first_read + r) * 64 + (off >> 5);   // 32 bases per draw
+          if(id != draw_id) { draw_id = id; draw = mix64(mix64(seed + 0x9E3779B97F4A7C15ull * (id + 1))); }
+          ch = (uint32_t)("ACGT"[(draw >> (2 * (off & 31))) & 3]);
+        }
+      }
+      w[i >> 2] |= ch << (8 * (i & 3));
+      if(++off == stride) { off = 0; ++r; }
+    }
+    if(p0 + 16 <= total) *reinterpret_cast<uint4*>(out + p0) = make_uint4(w[0], w[1], w[2], w[3]);
+    else for(int i = 0; i < 16 && p0 + i < total; ++i) out[p0 + i] = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
+  }
+}
+
+// ---- random-access roofline probes (R_gups) ------------------------------------
+// mode 0: fire-and-forget atomicAdd   mode 1: returning atomicAdd   mode 2: atomicCAS(0 -> x)
+// mode 3: plain load + dependent fire-and-forget atomicAdd
+__global__ __launch_bounds__(kBlock) void gups_kernel(uint64_t* __restrict__ tab, uint64_t mask, uint64_t n, int mode,
+                                                      uint64_t seed, unsigned long long* __restrict__ sink) {
+  uint64_t acc = 0;
+  for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t s = mix64(seed + i * 0x9E3779B97F4A7C15ull) & mask;
+    unsigned long long* a = (unsigned long long*)&tab[s];
+    if(mode == 0) __hip_atomic_fetch_add(a, 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if(mode == 1) acc += atomicAdd(a, 1ull << 32);
+    else if(mode == 2) acc += atomicCAS(a, 0ull, (unsigned long long)(i | 1));
+    else { const uint64_t v = tab[s]; __hip_atomic_fetch_add(a, (1ull << 32) + (v & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  }
+  if(acc == 0x123456789ull) atomicAdd(sink, 1ull);
+}
+
+}  // namespace jfgpu

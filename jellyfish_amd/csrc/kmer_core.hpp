@@ -1,0 +1,233 @@
+// jellyfish_amd/csrc/kmer_core.hpp
+//
+// Pure arithmetic of the hot path, shared by the HIP kernels (device) and the
+// host-side geometry/matrix set-up.  No memory traffic here: character classes,
+// 2-bit packing, reverse complement, GF(2) hash by byte tables, slot word
+// packing.  Reference semantics being reproduced (paths relative to
+// /root/reference):
+//   include/jellyfish/mer_dna.hpp:38-55        character -> code
+//   include/jellyfish/mer_iterator.hpp:53-81   rolling forward / reverse-complement mers
+//   include/jellyfish/mer_dna.hpp:227-250      canonical = numerically smaller
+//   include/jellyfish/rectangular_binary_matrix.hpp:223-261  pos = M * key over GF(2)
+//   include/jellyfish/large_hash_array.hpp:509-597  quotienting: only key bits above lsize stored
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define JF_HD __host__ __device__ __forceinline__
+#else
+#define JF_HD inline
+#endif
+
+namespace jfgpu {
+
+constexpr uint32_t kMaxTileBits = 13;   // probe domain = 8192 slots = 64 KiB: fits LDS, see DESIGN.md
+constexpr uint32_t kMinCountBits = 16;  // in-slot count field never narrower than this
+
+// ---- character classes ----------------------------------------------------
+// A a->0, C c->1, G g->2, T t->3; everything else (N, IUPAC, '\n', ...) -> 4 = reset.
+JF_HD uint32_t base_code(uint32_t c) {
+  const uint32_t u = c & 0xDFu;                 // fold ASCII case
+  const uint32_t x = (u >> 1) & 3u;             // A:0 C:1 G:3 T:2
+  const uint32_t code = x ^ (x >> 1);           // A:0 C:1 G:2 T:3
+  // letters 0x41 'A', 0x43 'C', 0x47 'G', 0x54 'T' as a 32-entry bit set over 0x40..0x5F
+  const uint32_t valid_set = (1u << 1) | (1u << 3) | (1u << 7) | (1u << 20);
+  const bool ok = ((u ^ 0x40u) < 32u) && ((valid_set >> (u & 31u)) & 1u);
+  return ok ? code : 4u;
+}
+
+// Pack 16 characters (little-endian in 4 dwords) into a 32-bit code word and a
+// 16-bit invalid mask.  Base j (0 = first character) sits at bits [2(15-j)+1 : 2(15-j)]
+// of codes and bit (15-j) of inval, so that earlier bases are MORE significant
+// and consecutive words concatenate into one big-endian base stream.
+JF_HD void pack16(const uint32_t w[4], uint32_t& codes, uint32_t& inval) {
+  uint32_t c = 0, v = 0;
+#pragma unroll
+  for(int i = 0; i < 4; ++i) {
+#pragma unroll
+    for(int b = 0; b < 4; ++b) {
+      const uint32_t code = base_code((w[i] >> (8 * b)) & 0xFFu);
+      c = (c << 2) | (code & 3u);
+      v = (v << 1) | (code >> 2);
+    }
+  }
+  codes = c;
+  inval = v;
+}
+
+// Reverse complement of a k-mer held in the low 2k bits of x (k <= 32).
+JF_HD uint64_t revcomp64(uint64_t x, uint32_t k) {
+  x = ~x;
+  x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+  x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+  x = ((x >> 8) & 0x00FF00FF00FF00FFull) | ((x & 0x00FF00FF00FF00FFull) << 8);
+  x = ((x >> 16) & 0x0000FFFF0000FFFFull) | ((x & 0x0000FFFF0000FFFFull) << 16);
+  x = (x >> 32) | (x << 32);
+  return x >> (64 - 2 * k);
+}
+
+// ---- table geometry ---------------------------------------------------------
+// One slot = one 64-bit word:   [ count : cnt_bits | occupied : 1 | tag : tag_bits ]
+//   tag = (idx0 << rem_bits) | rem
+//   rem  = key >> lsize_g              (key bits the hash position does not determine)
+//   idx0 = position inside the tile    (low tile_bits bits of the hash position)
+// The tile index (remaining position bits) is implied by the slot address, the
+// shard by the owning GPU.  Probing is triangular and wraps inside the tile, so
+// (tile, tag) identifies the key exactly wherever in the tile it finally lands.
+// Numeric order of tags inside a tile == the reference's (pos, key) dump order.
+// Count at the TOP: an atomic add that overflows the field carries out of the
+// word and cannot corrupt the tag; the wrap is detected from the returned old
+// value and spilled to the overflow side table (the reference's "large entry"
+// idea, offsets_key_value.hpp:35-46).
+struct TableGeom {
+  uint32_t k, key_bits;
+  uint32_t lsize_g, lsize_l;      // log2 global / local (this shard) slots
+  uint32_t shard_bits, shard_id;
+  uint32_t tile_bits, rem_bits, tag_bits, cnt_bits;
+  uint32_t nbytes;                // bytes of a key fed to the hash tables = ceil(2k/8)
+  uint32_t canonical;
+  uint64_t key_mask, tile_mask, rem_mask, local_mask;
+  uint64_t occ_bit, low_mask, inc, cnt_max;
+};
+
+// Fills every derived field from (k, lsize_g, shard_bits, shard_id, canonical).
+// Returns false when the combination cannot be packed into a 64-bit slot.
+inline bool geom_init(TableGeom& g, uint32_t k, uint32_t lsize_g, uint32_t shard_bits, uint32_t shard_id,
+                      uint32_t canonical) {
+  if(k < 1 || k > 32 || lsize_g > 2 * k || shard_bits > lsize_g) return false;
+  g.k = k; g.key_bits = 2 * k; g.lsize_g = lsize_g; g.shard_bits = shard_bits; g.shard_id = shard_id;
+  g.lsize_l = lsize_g - shard_bits;
+  g.tile_bits = g.lsize_l < kMaxTileBits ? g.lsize_l : kMaxTileBits;
+  g.rem_bits = g.key_bits - lsize_g;
+  g.tag_bits = g.tile_bits + g.rem_bits;
+  if(g.tag_bits + 1 + kMinCountBits > 64) return false;
+  g.cnt_bits = 63 - g.tag_bits;
+  g.nbytes = (g.key_bits + 7) / 8;
+  g.canonical = canonical;
+  g.key_mask = g.key_bits == 64 ? ~0ull : ((1ull << g.key_bits) - 1);
+  g.tile_mask = (1ull << g.tile_bits) - 1;
+  g.rem_mask = g.rem_bits == 0 ? 0 : ((1ull << g.rem_bits) - 1);
+  g.local_mask = (1ull << g.lsize_l) - 1;
+  g.occ_bit = 1ull << g.tag_bits;
+  g.low_mask = (g.occ_bit << 1) - 1;
+  g.inc = g.occ_bit << 1;
+  g.cnt_max = (1ull << g.cnt_bits) - 1;
+  return true;
+}
+
+// Smallest global lsize the slot format admits for this k (so that cnt_bits >= kMinCountBits).
+inline uint32_t geom_min_lsize(uint32_t k, uint32_t shard_bits) {
+  // tag_bits = tile_bits + 2k - lsize_g <= 63 - kMinCountBits, tile_bits <= kMaxTileBits
+  int need = (int)(2 * k + kMaxTileBits) - (int)(63 - kMinCountBits);
+  if(need < 0) need = 0;
+  if((uint32_t)need < shard_bits) need = (int)shard_bits;
+  if((uint32_t)need > 2 * k) need = (int)(2 * k);
+  return (uint32_t)need;
+}
+
+// pos = M * key via byte tables: tbl[b * 256 + v] = XOR of the columns selected by
+// byte b of the key having value v.  (H is linear over GF(2).)
+JF_HD uint64_t hash_tables(const uint64_t* tbl, uint64_t key, uint32_t nbytes) {
+  uint64_t pos = 0;
+#pragma unroll 8
+  for(uint32_t b = 0; b < nbytes; ++b) pos ^= tbl[b * 256 + ((key >> (8 * b)) & 0xFF)];
+  return pos;
+}
+
+struct SlotAddr {
+  uint64_t tile_base;  // first slot of the tile (local slot index)
+  uint32_t idx0;       // home position inside the tile
+  uint32_t shard;      // owning shard of the global position
+};
+
+JF_HD SlotAddr slot_addr(const TableGeom& g, uint64_t pos_g) {
+  SlotAddr a;
+  a.shard = (uint32_t)(pos_g >> g.lsize_l);
+  const uint64_t local = pos_g & g.local_mask;
+  a.idx0 = (uint32_t)(local & g.tile_mask);
+  a.tile_base = local & ~g.tile_mask;
+  return a;
+}
+
+JF_HD uint64_t make_tag(const TableGeom& g, uint64_t key, uint32_t idx0) {
+  const uint64_t rem = g.lsize_g >= 64 ? 0 : (key >> g.lsize_g);
+  return ((uint64_t)idx0 << g.rem_bits) | rem;
+}
+
+// Slot word -> key.  inv_tbl are byte tables of the inverse map
+// (rem, pos_g) -> low lsize_g key bits.
+JF_HD uint64_t slot_key(const TableGeom& g, const uint64_t* inv_tbl, uint64_t word, uint64_t tile_base) {
+  const uint64_t tag = word & (g.occ_bit - 1);
+  const uint64_t rem = tag & g.rem_mask;
+  const uint64_t idx0 = tag >> g.rem_bits;
+  const uint64_t pos_g = ((uint64_t)g.shard_id << g.lsize_l) | tile_base | idx0;
+  const uint64_t v = (g.lsize_g >= 64 ? 0 : (rem << g.lsize_g)) | pos_g;
+  const uint64_t lo = hash_tables(inv_tbl, v, g.nbytes);
+  return (g.lsize_g >= 64 ? 0 : (rem << g.lsize_g)) | lo;
+}
+
+JF_HD uint64_t slot_count(const TableGeom& g, uint64_t word) { return word >> (g.tag_bits + 1); }
+
+// triangular probe sequence inside a tile: idx0 + p(p+1)/2 (mod tile size) visits every
+// slot of a power-of-two tile exactly once for p = 0 .. size-1.
+JF_HD uint32_t probe_slot(uint32_t idx0, uint32_t p, uint32_t tile_mask) {
+  return (idx0 + ((p * (p + 1)) >> 1)) & tile_mask;
+}
+
+// One aligned 16-byte vector of sequence (global_load_dwordx4 on the device).
+JF_HD void load16(const uint8_t* p, uint32_t w[4]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint4 v = *reinterpret_cast<const uint4*>(p);
+  w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+#else
+  for(int i = 0; i < 4; ++i)
+    w[i] = (uint32_t)p[4 * i] | ((uint32_t)p[4 * i + 1] << 8) | ((uint32_t)p[4 * i + 2] << 16) | ((uint32_t)p[4 * i + 3] << 24);
+#endif
+}
+
+constexpr int kPerLane = 16;  // sequence positions handled by one lane per tile
+
+// ---- sequence tile -> per-lane packed words -----------------------------------
+// Loads 16 sequence bytes for this lane (positions [off, off+16) of the aligned
+// buffer), forcing everything outside [lo, hi) invalid.
+JF_HD void load_pack16(const uint8_t* __restrict__ base, int64_t off, int64_t lo, int64_t hi,
+                                   uint32_t& codes, uint32_t& inval) {
+  if(off + 16 <= lo || off >= hi || off < 0) { codes = 0; inval = 0xFFFFu; return; }
+  uint32_t w[4];
+  if(off + 16 <= hi) {
+    load16(base + off, w);
+  } else {  // ragged tail: never read past the caller's buffer
+    w[0] = w[1] = w[2] = w[3] = 0;
+    for(int i = 0; i < 16 && off + i < hi; ++i) w[i >> 2] |= (uint32_t)base[off + i] << (8 * (i & 3));
+  }
+  pack16(w, codes, inval);
+  if(off < lo) inval |= (0xFFFFu << (16 - (int)(lo - off))) & 0xFFFFu;        // first (lo-off) positions
+  if(off + 16 > hi) inval |= (1u << (int)(off + 16 - hi)) - 1u;               // last positions
+}
+
+// Per-lane k-mer extraction state for one tile.
+struct LaneWords {
+  uint32_t cur, p1, p2;     // code words: own 16 bases, previous 16, the 16 before those
+  uint64_t inv48;           // invalid bits of the same 48 positions (bit 15-j of each 16)
+};
+
+// Calls f(j, key) for every valid (canonical) k-mer ending at one of this lane's 16
+// positions, in order.  mer_iterator.hpp:67-76 + :51.
+template <typename F>
+JF_HD void for_each_kmer(const TableGeom& g, const LaneWords& L, F&& f) {
+  const uint32_t k = g.k;
+  uint64_t fw = (((uint64_t)L.p2 << 32) | L.p1) & g.key_mask;   // k-mer ending just before this lane
+  uint64_t rc = revcomp64(fw, k);
+  const uint64_t kwin = k >= 64 ? ~0ull : ((1ull << k) - 1);
+  const uint32_t rc_shift = 2 * (k - 1);
+#pragma unroll
+  for(int j = 0; j < kPerLane; ++j) {
+    const uint64_t c = (L.cur >> (2 * (15 - j))) & 3u;
+    fw = ((fw << 2) | c) & g.key_mask;
+    rc = (rc >> 2) | ((3ull - c) << rc_shift);
+    const bool valid = ((L.inv48 >> (15 - j)) & kwin) == 0;
+    if(valid) f(j, (g.canonical && rc < fw) ? rc : fw);
+  }
+}
+
+}  // namespace jfgpu

@@ -1,0 +1,273 @@
+// jellyfish_amd/include/jellyfish_amd/dumpers.hpp
+//
+// Results path on the host, API-shaped like the reference's dumpers and readers:
+//   binary_dumper / text_dumper   include/jellyfish/binary_dumper.hpp:46-76,
+//                                 text_dumper.hpp, sorted_dumper.hpp:57-101, dumper.hpp:68-91
+//   binary_reader / text_reader   binary_dumper.hpp:82-109, text_dumper.hpp
+//   binary_query                  binary_dumper.hpp:112-213 (interpolation search on pos)
+// The (pos, key) sort the reference does with a per-thread min-heap happens on
+// the GPU, tile by tile (jfgpu_dump_next); the host only streams bytes to the file.
+#pragma once
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <cmath>
+#include <fstream>
+#include <iostream>
+#include <limits>
+#include <sstream>
+
+#include "hash_counter.hpp"
+
+namespace jellyfish_amd {
+
+struct ErrorWriting : public std::runtime_error {   // dumper_t::ErrorWriting, dumper.hpp:37
+  explicit ErrorWriting(const std::string& s) : std::runtime_error(s) {}
+};
+
+class dumper_base {
+public:
+  dumper_base(const char* file_prefix, file_header* header)
+      : prefix_(file_prefix), header_(header), min_(0), max_(std::numeric_limits<uint64_t>::max()) {}
+  virtual ~dumper_base() {}
+  void one_file(bool v) { one_file_ = v; }
+  void min(uint64_t m) { min_ = m; }
+  void max(uint64_t m) { max_ = m; }
+  int nb_files() const { return nb_files_; }
+  virtual void dump(hash_counter* ary) = 0;
+
+protected:
+  std::string prefix_;
+  file_header* header_;
+  uint64_t min_, max_;
+  bool one_file_ = true;
+  int nb_files_ = 0;
+  std::string next_path() {   // dumper.hpp:45-61: prefix itself when one_file, else prefix + index
+    std::string p = prefix_;
+    if(!one_file_) p += std::to_string(nb_files_);
+    ++nb_files_;
+    return p;
+  }
+};
+
+// binary/sorted: header, then fixed-width records key (ceil(2k/8) bytes LE) + count
+// (val_len bytes LE, saturated) in ascending (pos, key) order.
+class binary_dumper : public dumper_base {
+public:
+  static constexpr const char* format = "binary/sorted";
+  binary_dumper(int val_len /* bytes */, int key_len /* bits */, int nb_threads, const char* file_prefix, file_header* header = 0)
+      : dumper_base(file_prefix, header), val_len_(val_len), key_len_(key_len) { (void)nb_threads; }
+
+  void dump(hash_counter* ary) override {
+    if((int)ary->info().out_counter_len != val_len_)
+      throw std::length_error("binary_dumper: table was created with a different out_counter_len");
+    const std::string path = next_path();
+    std::ofstream out(path, std::ios::binary | std::ios::trunc);
+    if(!out.good()) throw ErrorWriting("Can't open file '" + path + "'");
+    if(header_) {
+      ary->update_header(*header_);
+      header_->format(format);
+      header_->counter_len(val_len_);
+      header_->write(out);
+    }
+    ary->flush();
+    uint64_t n = 0; uint32_t rec = 0;
+    jf_check(jfgpu_dump_begin(ary->handle(), min_, max_, &n, &rec));
+    const uint64_t cap = std::max<uint64_t>((uint64_t)4 << 20, ary->info().tile_slots);
+    std::vector<char> buf(cap * rec);
+    try {
+      while(true) {
+        uint64_t got = 0;
+        jf_check(jfgpu_dump_next(ary->handle(), buf.data(), cap, &got));
+        if(!got) break;
+        out.write(buf.data(), got * rec);
+        if(!out.good()) throw ErrorWriting("Error while writing '" + path + "'");
+      }
+    } catch(...) { jfgpu_dump_end(ary->handle()); throw; }
+    jf_check(jfgpu_dump_end(ary->handle()));
+    out.close();
+  }
+
+private:
+  int val_len_, key_len_;
+};
+
+inline void write_text_records(hash_counter* ary, uint64_t min, uint64_t max, std::ostream& out) {
+  uint64_t n = 0; uint32_t rec = 0;
+  jf_check(jfgpu_dump_begin(ary->handle(), min, max, &n, &rec));
+  const uint64_t cap = std::max<uint64_t>((uint64_t)1 << 20, ary->info().tile_slots);
+  std::vector<unsigned char> buf(cap * rec);
+  const unsigned k = ary->info().k, kb = (2 * k + 7) / 8, vb = rec - kb;
+  mer_dna m(k);
+  std::string line;
+  try {
+    while(true) {
+      uint64_t got = 0;
+      jf_check(jfgpu_dump_next(ary->handle(), buf.data(), cap, &got));
+      if(!got) break;
+      line.clear();
+      for(uint64_t i = 0; i < got; ++i) {
+        const unsigned char* r = &buf[i * rec];
+        uint64_t key = 0, val = 0;
+        memcpy(&key, r, kb); memcpy(&val, r + kb, vb);
+        m.word__(0) = key;
+        line += m.to_str(); line += ' '; line += std::to_string(val); line += '\n';
+      }
+      out.write(line.data(), line.size());
+    }
+  } catch(...) { jfgpu_dump_end(ary->handle()); throw; }
+  jf_check(jfgpu_dump_end(ary->handle()));
+}
+
+// text/sorted: same header, then "KMER count\n" lines (text_dumper.hpp:18-20); counts are not
+// saturated in text, so the table must be created with out_counter_len = 8 for exactness.
+class text_dumper : public dumper_base {
+public:
+  static constexpr const char* format = "text/sorted";
+  text_dumper(int nb_threads, const char* file_prefix, file_header* header = 0) : dumper_base(file_prefix, header) { (void)nb_threads; }
+  void dump(hash_counter* ary) override {
+    const std::string path = next_path();
+    std::ofstream out(path, std::ios::binary | std::ios::trunc);
+    if(!out.good()) throw ErrorWriting("Can't open file '" + path + "'");
+    if(header_) {
+      ary->update_header(*header_);
+      header_->format(format);
+      header_->write(out);
+    }
+    ary->flush();
+    write_text_records(ary, min_, max_, out);
+    if(!out.good()) throw ErrorWriting("Error while writing '" + path + "'");
+  }
+};
+
+// Sequential reader of binary/sorted (binary_dumper.hpp:82-109).
+class binary_reader {
+public:
+  binary_reader(std::istream& is, file_header* header)
+      : is_(is), val_len_(header->counter_len()), key_(header->key_len() / 2), m_(header->matrix()),
+        size_mask_(header->size() - 1) {}
+  const mer_dna& key() const { return key_; }
+  const uint64_t& val() const { return val_; }
+  size_t pos() const { return m_.times(key_.data()) & size_mask_; }
+  bool next() {
+    key_.read_bytes(is_);
+    val_ = 0;
+    is_.read((char*)&val_, val_len_);
+    return is_.good();
+  }
+private:
+  std::istream& is_;
+  const int val_len_;
+  mer_dna key_;
+  uint64_t val_ = 0;
+  const header_matrix m_;
+  const size_t size_mask_;
+};
+
+class text_reader {
+public:
+  text_reader(std::istream& is, file_header* header) : is_(is), key_(header->key_len() / 2) {}
+  const mer_dna& key() const { return key_; }
+  const uint64_t& val() const { return val_; }
+  bool next() {
+    std::string s;
+    is_ >> s >> val_;
+    if(!is_.good() && s.empty()) return false;
+    try { key_ = s; } catch(std::length_error&) { return false; }
+    return !is_.fail();
+  }
+private:
+  std::istream& is_;
+  mer_dna key_;
+  uint64_t val_ = 0;
+};
+
+// Read-only memory map of a whole file (include/jellyfish/mapped_file.hpp).
+class mapped_file {
+public:
+  explicit mapped_file(const char* path) {
+    int fd = open(path, O_RDONLY);
+    if(fd < 0) throw std::runtime_error(std::string("Can't open file '") + path + "'");
+    struct stat st;
+    if(fstat(fd, &st) < 0) { close(fd); throw std::runtime_error("Can't stat file"); }
+    length_ = st.st_size;
+    base_ = length_ ? (char*)mmap(nullptr, length_, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
+    close(fd);
+    if(base_ == (char*)MAP_FAILED) throw std::runtime_error("Can't mmap file");
+  }
+  ~mapped_file() { if(base_) munmap(base_, length_); }
+  char* base() const { return base_; }
+  size_t length() const { return length_; }
+private:
+  char* base_ = nullptr;
+  size_t length_ = 0;
+};
+
+// Random access into a binary/sorted body (binary_dumper.hpp:112-213): interpolation
+// search on pos = matrix * key & mask, then a short linear scan.
+class binary_query {
+public:
+  binary_query(const char* data, unsigned key_len /* bits */, unsigned val_len /* bytes */, const header_matrix& m,
+               size_t mask, size_t size)
+      : data_(data), val_len_(val_len), key_len_(key_len / 8 + (key_len % 8 != 0)), m_(m), mask_(mask),
+        record_len_(val_len + key_len_), last_id_(size / record_len_), k_(key_len / 2) {
+    if(size % record_len_ != 0)
+      throw std::length_error("Size of database (" + std::to_string(size) + ") must be a multiple of the length of a record (" +
+                              std::to_string(record_len_) + ")");
+    if(last_id_) {
+      first_key_ = key_at(0); first_pos_ = key_pos(first_key_);
+      last_key_ = key_at(last_id_ - 1); last_pos_ = key_pos(last_key_);
+    }
+  }
+
+  bool val_id(const mer_dna& key, uint64_t* res, uint64_t* id) const {
+    if(last_id_ == 0) return false;
+    uint64_t first = 0, last = last_id_, first_pos = first_pos_, last_pos = last_pos_;
+    const uint64_t pos = key_pos(key);
+    uint64_t cid = 0;
+    if(key == first_key_) { *res = val_at(0); *id = 0; return true; }
+    cid = last_id_ - 1;
+    if(key == last_key_) { *res = val_at(cid); *id = cid; return true; }
+    if(pos < first_pos_ || pos > last_pos_) return false;
+    for(uint64_t diff = last - first; diff >= 8; diff = last - first) {
+      cid = first + (uint64_t)lrint(diff * ((double)(pos - first_pos) / (double)(last_pos - first_pos)));
+      cid = std::max(first + 1, cid);
+      cid = std::min(cid, last - 1);
+      const mer_dna mid = key_at(cid);
+      if(key == mid) { *res = val_at(cid); *id = cid; return true; }
+      const uint64_t mid_pos = key_pos(mid);
+      if(mid_pos > pos || (mid_pos == pos && mid > key)) { last = cid; last_pos = mid_pos; }
+      else { first = cid; first_pos = mid_pos; }
+    }
+    for(cid = first + 1; cid < last; ++cid)
+      if(key == key_at(cid)) { *res = val_at(cid); *id = cid; return true; }
+    return false;
+  }
+  uint64_t operator[](const mer_dna& key) const { uint64_t r, id; return val_id(key, &r, &id) ? r : 0; }
+  uint64_t check(const mer_dna& key) const { return (*this)[key]; }
+
+private:
+  const char* data_;
+  unsigned val_len_, key_len_;
+  header_matrix m_;
+  size_t mask_, record_len_, last_id_;
+  unsigned k_;
+  mer_dna first_key_{1u}, last_key_{1u};
+  uint64_t first_pos_ = 0, last_pos_ = 0;
+
+  mer_dna key_at(size_t id) const {
+    mer_dna k(k_);
+    memcpy(k.data__(), data_ + id * record_len_, key_len_);
+    k.clean_msw();
+    return k;
+  }
+  uint64_t val_at(size_t id) const {
+    uint64_t v = 0;
+    memcpy(&v, data_ + id * record_len_ + key_len_, val_len_);
+    return v;
+  }
+  uint64_t key_pos(const mer_dna& key) const { return m_.times(key.data()) & mask_; }
+};
+
+}  // namespace jellyfish_amd

@@ -1,0 +1,162 @@
+// jellyfish_amd/include/jellyfish_amd/hash_counter.hpp
+//
+// C++ facade over the C ABI (include/jfgpu.h) with the API shape of the
+// reference's jellyfish::cooperative::hash_counter<mer_dna> and its array
+// (include/jellyfish/hash_counter.hpp:50-172, large_hash_array.hpp:196-226,
+// 354-372): the table lives in one GPU's HBM, add() calls are batched on the
+// host and retired by kernels, done() == jfgpu_sync.  Errors cross the C ABI as
+// codes and are re-thrown here as the exception types the reference throws
+// (std::runtime_error("Hash full"), hash_counter.hpp:194-195; allocation failure,
+// large_hash_array.hpp:169-172).
+#pragma once
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/jfgpu.h"
+#include "file_header.hpp"
+#include "mer_dna.hpp"
+
+namespace jellyfish_amd {
+
+struct ErrorAllocation : public std::runtime_error {
+  explicit ErrorAllocation(const std::string& s) : std::runtime_error(s) {}
+};
+
+inline void jf_check(int rc) {
+  if(rc == JFGPU_OK) return;
+  const std::string msg = jfgpu_last_error();
+  switch(rc) {
+  case JFGPU_E_ALLOC: throw ErrorAllocation(msg);
+  case JFGPU_E_INVALID: throw std::length_error(msg);
+  default: throw std::runtime_error(msg);
+  }
+}
+
+class hash_counter {
+public:
+  // hash_counter(size, key_len (bits), val_len (bits), nb_threads, reprobe_limit)
+  // (hash_counter.hpp:56-64).  val_len / nb_threads / reprobe_limit are CPU-table
+  // knobs: accepted for source compatibility, the device slot format fixes them.
+  hash_counter(size_t size, uint16_t key_len, uint16_t val_len, uint16_t nb_threads, uint16_t reprobe_limit = 126,
+               bool canonical = false, int device = -1, uint32_t out_counter_len = 4, uint64_t matrix_seed = 0)
+      : nb_threads_(nb_threads) {
+    (void)val_len; (void)reprobe_limit;
+    if(key_len == 0 || key_len % 2) throw std::length_error("key_len must be an even number of bits");
+    jfgpu_params p;
+    memset(&p, 0, sizeof p);
+    p.k = key_len / 2; p.canonical = canonical; p.size = size; p.device = device;
+    p.matrix_seed = matrix_seed; p.out_counter_len = out_counter_len;
+    jf_check(jfgpu_create(&p, &t_));
+    jf_check(jfgpu_get_info(t_, &info_));
+    pending_.reserve(kBatch);
+  }
+  ~hash_counter() { if(t_) jfgpu_destroy(t_); }
+  hash_counter(const hash_counter&) = delete;
+  hash_counter& operator=(const hash_counter&) = delete;
+
+  jfgpu_table* handle() { return t_; }
+  size_t size() const { return info_.size; }
+  uint16_t key_len() const { return (uint16_t)info_.key_len; }
+  uint16_t val_len() const { return (uint16_t)info_.val_len; }
+  uint16_t lsize() const { return (uint16_t)info_.lsize; }
+  uint16_t nb_threads() const { return nb_threads_; }
+  uint16_t max_reprobe() const { return (uint16_t)std::min<uint32_t>(info_.max_reprobe, 65535); }
+  const jfgpu_info& info() const { return info_; }
+  hash_counter* ary() { return this; }   // hash_counter::ary() (hash_counter.hpp:70)
+
+  header_matrix matrix() const {
+    header_matrix m;
+    m.r = info_.lsize; m.c = info_.key_len; m.identity = info_.matrix_identity;
+    m.columns.assign(m.c, 0);
+    jf_check(jfgpu_get_matrix(t_, m.columns.data()));
+    return m;
+  }
+
+  // file_header::update_from_ary (file_header.hpp:25-33)
+  void update_header(file_header& h) const {
+    h.size(info_.size);
+    h.key_len(info_.key_len);
+    h.val_len(info_.val_len);
+    h.matrix(matrix());
+    // The probing schedule is never serialised; readers only need the fields to exist and
+    // merge only compares reprobes[max_reprobe] across files (merge_files.cc:128,145-146).
+    // Advertise triangular numbers capped to the tile, like the reference's quadratic_reprobes.
+    const unsigned mr = std::min<unsigned>(info_.max_reprobe, 126);
+    h.max_reprobe(mr);
+    std::vector<size_t> rp(mr + 1);
+    for(unsigned i = 0; i <= mr; ++i) rp[i] = i == 0 ? 1 : (size_t)i * (i + 1) / 2;
+    h.set_reprobes(rp);
+  }
+
+  // ---- hot path -----------------------------------------------------------
+  // One parser-contract buffer (count_main.cc:152-163 loop body on the device).
+  void count_sequence(const char* bases, size_t n) { flush(); jf_check(jfgpu_count_ascii(t_, bases, n)); }
+
+  // hash_counter::add(k, v) (hash_counter.hpp:122-126): batched, thread-safe.
+  void add(const mer_dna& k, uint64_t v) {
+    std::lock_guard<std::mutex> lock(mu_);
+    if(v != pending_val_ && !pending_.empty()) flush_locked();
+    pending_val_ = v;
+    pending_.push_back(k.word(0));
+    if(pending_.size() >= kBatch) flush_locked();
+  }
+  // add(k, v, &is_new, &id) (hash_counter.hpp:91-115): synchronous (SWIG HashCounter.add).
+  void add(const mer_dna& k, uint64_t v, bool* is_new, size_t* id = nullptr) {
+    flush();
+    uint64_t key = k.word(0);
+    uint8_t nw = 0;
+    jf_check(jfgpu_add_keys(t_, &key, 1, v, &nw));
+    if(is_new) *is_new = nw != 0;
+    if(id) *id = 0;
+  }
+  // set(k) (hash_counter.hpp:132-145): make the key present with value 0.
+  void set(const mer_dna& k, bool* is_new = nullptr, size_t* id = nullptr) { add(k, 0, is_new, id); }
+  // update_add(k, v) (hash_counter.hpp:150-166): add only if the key is present.
+  bool update_add(const mer_dna& k, uint64_t v) {
+    uint64_t val = 0;
+    if(!get_val_for_key(k, &val)) return false;
+    bool is_new;
+    add(k, v, &is_new);
+    return true;
+  }
+  // done() (hash_counter.hpp:169-172): everything retired; throws "Hash full" if it did not fit.
+  void done() { flush(); jf_check(jfgpu_sync(t_)); }
+  void clear() { std::lock_guard<std::mutex> lock(mu_); pending_.clear(); jf_check(jfgpu_clear(t_)); }
+
+  // array::get_val_for_key (large_hash_array.hpp:354-372)
+  bool get_val_for_key(const mer_dna& k, uint64_t* val) {
+    flush();
+    uint64_t key = k.word(0), v = 0;
+    uint8_t f = 0;
+    jf_check(jfgpu_lookup(t_, &key, 1, &v, &f));
+    if(val) *val = v;
+    return f != 0;
+  }
+  bool has_key(const mer_dna& k) { return get_val_for_key(k, nullptr); }
+
+  void flush() { std::lock_guard<std::mutex> lock(mu_); flush_locked(); }
+
+private:
+  static constexpr size_t kBatch = 1 << 20;
+  jfgpu_table* t_ = nullptr;
+  jfgpu_info info_;
+  uint16_t nb_threads_;
+  std::mutex mu_;
+  std::vector<uint64_t> pending_;
+  uint64_t pending_val_ = 1;
+
+  void flush_locked() {
+    if(pending_.empty()) return;
+    std::vector<uint64_t> batch;
+    batch.swap(pending_);
+    pending_.reserve(kBatch);
+    jf_check(jfgpu_add_keys(t_, batch.data(), batch.size(), pending_val_, nullptr));
+  }
+};
+
+typedef hash_counter mer_hash;
+typedef hash_counter mer_array;
+
+}  // namespace jellyfish_amd

@@ -1,0 +1,318 @@
+"""Parity of the HIP hot path against the oracle, through the C ABI.  -m gpu only.
+
+Bar: bit-exact {k-mer -> count} (integer work), dump in the reference's (pos, key)
+order under the table's own matrix, same edge cases the reference tests cover
+(N / IUPAC / lower case resets, buffers shorter than k, empty input, count-field
+overflow = the reference's "large" entries, -L/-U filters)."""
+import random
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd_seq(rng, n, alphabet="ACGT"):
+    return "".join(rng.choice(alphabet) for _ in range(n)).encode()
+
+
+def oracle_map(seq, k, canonical):
+    keys, cnt = O.count(seq, k, canonical)
+    return dict(zip(keys[:, 0].tolist(), cnt.tolist()))
+
+
+def table_map(capi, t, lower=0, upper=2 ** 64 - 1, check_order=True):
+    recs = t.dump_records(lower, upper, chunk_records=1 << 16)
+    keys, cnts = capi.decode_records(recs, t.k, t.info.out_counter_len)
+    if check_order and len(keys) > 1:
+        cols = None if t.info.matrix_identity else t.matrix()
+        sub = slice(0, min(len(keys), 20000))
+        pos = O.matrix_times(cols, t.info.lsize, 2 * t.k, keys[sub])
+        pk = list(zip(pos.tolist(), keys[sub].tolist()))
+        assert pk == sorted(pk), "dump not in (pos, key) order"
+        assert len(set(pk)) == len(pk)
+    assert len(set(keys.tolist())) == len(keys), "duplicate key in dump"
+    return dict(zip(keys.tolist(), cnts.tolist()))
+
+
+CASES = [
+    # k, canonical, n, alphabet, size
+    (21, True, 50000, "ACGT", 1 << 17),
+    (21, False, 50000, "ACGT", 1 << 17),
+    (21, True, 30000, "ACGTacgtNnRY-\n", 1 << 16),
+    (15, True, 200000, "ACGT", 1 << 18),
+    (5, True, 10000, "ACGT", 1 << 12),       # 4^5 = 1024 < size: identity matrix, direct indexing
+    (1, False, 1000, "ACGTN", 16),
+    (2, True, 5000, "ACGT", 16),
+    (31, True, 40000, "ACGT", 1 << 16),      # engine raises the table to its k=31 minimum
+    (32, False, 40000, "ACGTN", 1 << 16),
+    (32, True, 20000, "AC", 1 << 16),
+    (16, True, 60000, "AT", 1 << 17),        # low complexity: many duplicates / run-length merges
+    (21, True, 70000, "A", 1 << 12),         # one k-mer, count 69980
+    (24, True, 4096 * 3 + 17, "ACGT", 1 << 15),
+]
+
+
+@pytest.mark.parametrize("k,canonical,n,alphabet,size", CASES)
+def test_count_matches_oracle(gpu, k, canonical, n, alphabet, size):
+    rng = random.Random(k * 1000 + n)
+    seq = rnd_seq(rng, n, alphabet)
+    exp = oracle_map(seq, k, canonical)
+    with gpu.Table(k, size, canonical=canonical) as t:
+        t.count_ascii(seq)
+        t.sync()
+        got = table_map(gpu, t)
+        assert got == exp
+        st = t.stats()
+        assert st.distinct == len(exp)
+        assert st.total == sum(exp.values())
+        assert st.mers_fed == sum(exp.values())
+        assert st.unique == sum(1 for v in exp.values() if v == 1)
+        assert st.max_count == (max(exp.values()) if exp else 0)
+
+
+@pytest.mark.parametrize("n", [0, 1, 20, 21, 22, 4095, 4096, 4097, 4116, 4117, 8192 + 20])
+def test_ragged_lengths(gpu, n):
+    """empty / shorter than k / tile-boundary lengths; windows must not leak across calls."""
+    rng = random.Random(n)
+    k = 21
+    seq = rnd_seq(rng, n)
+    exp = oracle_map(seq, k, True)
+    with gpu.Table(k, 1 << 15) as t:
+        t.count_ascii(seq)
+        t.count_ascii(b"")
+        t.sync()
+        assert table_map(gpu, t) == exp
+
+
+def test_calls_do_not_share_windows(gpu):
+    rng = random.Random(5)
+    a, b = rnd_seq(rng, 1000), rnd_seq(rng, 1000)
+    k = 21
+    exp = oracle_map(a + b"N" + b, k, True)
+    with gpu.Table(k, 1 << 14) as t:
+        t.count_ascii(a)
+        t.count_ascii(b)
+        t.sync()
+        assert table_map(gpu, t) == exp
+
+
+def test_unaligned_device_buffer(gpu):
+    """The kernel reads 16-byte vectors from an aligned base; any device pointer must work."""
+    rng = random.Random(9)
+    k = 21
+    seq = rnd_seq(rng, 30000, "ACGTN")
+    with gpu.Table(k, 1 << 16) as t:
+        d = t.malloc(len(seq) + 64)
+        try:
+            for lead in (0, 1, 7, 15):
+                t.clear()
+                t.h2d(d + lead, np.frombuffer(seq, dtype=np.uint8))
+                t.count_ascii_dev(d + lead, len(seq))
+                t.sync()
+                assert table_map(gpu, t, check_order=False) == oracle_map(seq, k, True), lead
+        finally:
+            t.free(d)
+
+
+def test_lookup_and_add_keys(gpu):
+    rng = random.Random(11)
+    k = 21
+    seq = rnd_seq(rng, 40000)
+    exp = oracle_map(seq, k, True)
+    with gpu.Table(k, 1 << 17) as t:
+        t.count_ascii(seq)
+        t.sync()
+        keys = np.array(list(exp.keys()), dtype=np.uint64)
+        vals, found = t.lookup(keys)
+        assert found.all() and vals.tolist() == [exp[x] for x in keys.tolist()]
+        absent = np.array([x for x in (rng.getrandbits(42) for _ in range(2000)) if x not in exp], dtype=np.uint64)
+        vals, found = t.lookup(absent)
+        assert not found.any() and not vals.any()
+        # hash_counter::add(key, val, &is_new)
+        is_new = t.add_keys(np.concatenate([keys[:100], absent[:50]]), val=5, want_new=True)
+        assert is_new[:100].sum() == 0 and is_new[100:].sum() == len(absent[:50])
+        vals, found = t.lookup(np.concatenate([keys[:100], absent[:50]]))
+        assert vals[:100].tolist() == [exp[x] + 5 for x in keys[:100].tolist()]
+        assert vals[100:].tolist() == [5] * len(absent[:50])
+
+
+def test_count_field_overflow(gpu):
+    """k=31 at the minimum table size has a 16-bit in-slot count: larger counts spill to
+    the side table (the reference's 'large' entries, tests/small_mers.sh, LargeValue)."""
+    k = 31
+    with gpu.Table(k, 1 << 20, canonical=False) as t:
+        assert t.info.val_len == 16
+        key = np.array([0x123456789ABCDEF], dtype=np.uint64)
+        t.add_keys(np.repeat(key, 70000), val=1)              # 70000 single increments -> wraps once
+        t.add_keys(np.array([42], dtype=np.uint64), val=2 ** 40 + 3)
+        t.add_keys(np.array([43], dtype=np.uint64), val=65535)
+        t.add_keys(np.array([43], dtype=np.uint64), val=1)
+        vals, found = t.lookup(np.array([key[0], 42, 43, 44], dtype=np.uint64))
+        assert found.tolist() == [True, True, True, False]
+        assert vals.tolist() == [70000, 2 ** 40 + 3, 65536, 0]
+        st = t.stats()
+        assert (st.distinct, st.total, st.max_count) == (3, 70000 + 2 ** 40 + 3 + 65536, 2 ** 40 + 3)
+        recs = t.dump_records()
+        keys, cnts = gpu.decode_records(recs, k, 4)
+        got = dict(zip(keys.tolist(), cnts.tolist()))
+        assert got == {int(key[0]): 70000, 42: 2 ** 32 - 1, 43: 65536}     # file counts saturate at 4 bytes
+    # a homopolymer run through the count kernel: run-length merged adds also wrap correctly
+    with gpu.Table(k, 1 << 20, canonical=True) as t:
+        t.count_ascii(b"A" * (70000 + k - 1))
+        t.sync()
+        vals, _ = t.lookup(np.array([0], dtype=np.uint64))
+        assert vals.tolist() == [70000]
+
+
+def test_lower_upper_and_histo(gpu):
+    rng = random.Random(13)
+    k = 8
+    seq = rnd_seq(rng, 300000)
+    exp = oracle_map(seq, k, True)
+    with gpu.Table(k, 1 << 16) as t:
+        t.count_ascii(seq)
+        t.sync()
+        lo, hi = 3, 6
+        assert table_map(gpu, t, lo, hi) == {a: b for a, b in exp.items() if lo <= b <= hi}
+        base, inc, h = t.histo(1, 10000, 1)
+        ref = {}
+        for v in exp.values():
+            ref[v] = ref.get(v, 0) + 1
+        got = {base + i * inc: int(c) for i, c in enumerate(h) if c}
+        assert got == ref
+        st = t.stats(lo, hi)
+        assert st.distinct == sum(1 for v in exp.values() if lo <= v <= hi)
+
+
+def test_hash_full_is_reported(gpu):
+    """More distinct k-mers than slots: the reference throws 'Hash full'
+    (hash_counter.hpp:194-195); the engine must fail loudly too, never drop silently."""
+    rng = random.Random(17)
+    k = 21
+    seq = rnd_seq(rng, 40000)
+    with gpu.Table(k, 1 << 12) as t:
+        t.count_ascii(seq)
+        with pytest.raises(gpu.JfgpuError) as e:
+            t.sync()
+        assert e.value.code == gpu.E_FULL and "Hash full" in e.value.msg
+
+
+def test_explicit_matrix_round_trip(gpu):
+    """A table built from another table's matrix (what a reader of our header would do)
+    hashes identically."""
+    rng = random.Random(19)
+    k = 21
+    seq = rnd_seq(rng, 20000)
+    with gpu.Table(k, 1 << 16, matrix_seed=77) as a:
+        cols = a.matrix()
+        a.count_ascii(seq); a.sync()
+        ra = a.dump_records()
+    with gpu.Table(k, 1 << 16, matrix_columns=cols) as b:
+        assert (b.matrix() == cols).all()
+        b.count_ascii(seq); b.sync()
+        assert (b.dump_records() == ra).all()
+
+
+def test_sharded_partition_equals_single_table(gpu):
+    """Hash-prefix sharding on one GPU: 4 shard tables fed through
+    partition -> add_keys hold exactly the single-table result, and the
+    concatenation of the shard dumps in shard order is the single-table dump."""
+    rng = random.Random(23)
+    k = 21
+    seq = rnd_seq(rng, 120000, "ACGTN")
+    exp = oracle_map(seq, k, True)
+    with gpu.Table(k, 1 << 18) as single:
+        single.count_ascii(seq); single.sync()
+        whole = single.dump_records()
+        cols = single.matrix()
+    sb = 2
+    shards = [gpu.Table(k, 1 << 18, shard_bits=sb, shard_id=s) for s in range(1 << sb)]
+    try:
+        assert all((s.matrix() == cols).all() for s in shards)
+        t0 = shards[0]
+        d_seq = t0.malloc(len(seq) + 16)
+        d_keys = t0.malloc(8 * len(seq))
+        t0.h2d(d_seq, np.frombuffer(seq, dtype=np.uint8))
+        counts = shards[1].partition_ascii_dev(d_seq, len(seq), d_keys, len(seq))
+        assert counts.sum() == sum(exp.values())
+        off = 0
+        for s, t in enumerate(shards):
+            t.add_keys_dev(d_keys + 8 * off, int(counts[s]), 1)
+            t.sync()
+            off += int(counts[s])
+        # a key routed to the wrong shard is an error, not a silent insert
+        wrong = shards[0]
+        with pytest.raises(gpu.JfgpuError):
+            wrong.add_keys_dev(d_keys + 8 * int(counts[0]), min(int(counts[1]), 100), 1)
+            wrong.sync()
+        parts = [t.dump_records() for t in shards[1:]]
+        t0.free(d_seq); t0.free(d_keys)
+        merged = {}
+        for s, t in enumerate(shards[1:], start=1):
+            kk, cc = gpu.decode_records(parts[s - 1], k, 4)
+            merged.update(dict(zip(kk.tolist(), cc.tolist())))
+        # shard 0 was polluted on purpose above; rebuild it cleanly
+        shards[0].clear()
+        d_keys2 = shards[0].malloc(8 * len(seq))
+        d_seq2 = shards[0].malloc(len(seq) + 16)
+        shards[0].h2d(d_seq2, np.frombuffer(seq, dtype=np.uint8))
+        counts2 = shards[0].partition_ascii_dev(d_seq2, len(seq), d_keys2, len(seq))
+        assert (counts2 == counts).all()
+        shards[0].add_keys_dev(d_keys2, int(counts2[0]), 1); shards[0].sync()
+        p0 = shards[0].dump_records()
+        shards[0].free(d_keys2); shards[0].free(d_seq2)
+        kk, cc = gpu.decode_records(p0, k, 4)
+        merged.update(dict(zip(kk.tolist(), cc.tolist())))
+        assert merged == exp
+        assert (np.concatenate([p0] + parts) == whole).all()
+    finally:
+        for t in shards:
+            t.close()
+
+
+def test_device_generator_is_reproducible_and_counts_match(gpu):
+    """bench.py's synthetic reads: any slice regenerates identically; GPU counts on the
+    device-resident buffer equal the oracle's on the same bytes."""
+    k, L, n_reads = 21, 150, 4000
+    with gpu.Table(k, 1 << 21) as t:
+        nbytes = n_reads * (L + 1)
+        d = t.malloc(nbytes + 16)
+        t.gen_reads_dev(d, 0, n_reads, L, 42)
+        whole = t.d2h(d, nbytes).tobytes()
+        t.gen_reads_dev(d, 1000, 500, L, 42)
+        part = t.d2h(d, 500 * (L + 1)).tobytes()
+        assert part == whole[1000 * (L + 1):1500 * (L + 1)]
+        assert set(whole) <= set(b"ACGTN") and whole.count(b"N") == n_reads
+        t.gen_reads_dev(d, 0, n_reads, L, 42)
+        t.count_ascii_dev(d, nbytes)
+        t.sync()
+        exp = oracle_map(whole, k, True)
+        assert sum(exp.values()) == n_reads * (L - k + 1)
+        assert table_map(gpu, t) == exp
+        t.free(d)
+
+
+def test_large_run_invariants(gpu):
+    """Size-independent properties at a size the oracle would not finish quickly:
+    sum of counts == number of windows; stats consistent with histo; re-counting the same
+    input doubles every count (linearity)."""
+    k, L, n_reads = 21, 150, 2_000_000      # 300 Mbp, 260 M k-mers
+    with gpu.Table(k, 1 << 29) as t:
+        nbytes = n_reads * (L + 1)
+        d = t.malloc(nbytes + 16)
+        t.gen_reads_dev(d, 0, n_reads, L, 7)
+        t.count_ascii_dev(d, nbytes)
+        t.sync()
+        s1 = t.stats()
+        assert s1.total == n_reads * (L - k + 1) == s1.mers_fed
+        base, inc, h = t.histo(1, 100, 1)
+        assert int(h.sum()) == s1.distinct and int((h * (base + np.arange(len(h)))).sum()) == s1.total
+        t.count_ascii_dev(d, nbytes)
+        t.sync()
+        s2 = t.stats()
+        assert (s2.distinct, s2.total, s2.unique) == (s1.distinct, 2 * s1.total, 0)
+        assert s2.max_count == 2 * s1.max_count
+        t.free(d)
