@@ -1,0 +1,155 @@
+"""CPU-side checks of the product's host logic (no GPU, no compute calls):
+  * the pure arithmetic shared with the kernels (kmer_core.hpp / gf2_matrix.hpp), replayed
+    lane by lane on the host by tests/host/core_emu.cc, equals the oracle;
+  * libjfgpu.so loads and exports every symbol include/jfgpu.h declares; without a GPU every
+    entry point fails loudly (no fallback);
+  * the jellyfish-amd read-side verbs decode files written by the REFERENCE."""
+import json
+import os
+import random
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+MANIFEST = json.load(open(os.path.join(GOLD, "manifest.json")))
+
+
+@pytest.fixture(scope="module")
+def core_emu(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("emu") / "core_emu")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wno-unknown-pragmas", "-o", exe,
+                           os.path.join(ROOT, "tests", "host", "core_emu.cc")])
+    return exe
+
+
+def test_device_arithmetic_on_host_matches_oracle(core_emu):
+    rng = random.Random(7)
+    for trial in range(60):
+        k = rng.choice([1, 2, 5, 15, 16, 17, 21, 24, 31, 32])
+        can = rng.choice([0, 1])
+        n = rng.choice([0, 1, max(k - 1, 0), k, k + 1, 100, 4095, 4096, 4097, 4096 + k, 9000, 20000])
+        alpha = rng.choice(["ACGT", "ACGTacgt", "ACGTN", "ACGTACGTACGTACGTACGTN\nxRY", "A", "AT"])
+        seq = "".join(rng.choice(alpha) for _ in range(n))
+        lsize = max(min(2 * k, rng.choice([4, 10, 13, 14, 20, 26])), max(0, 2 * k - 34), 1)
+        sb = min(rng.choice([0, 0, 1, 3]), lsize)
+        lead = rng.randrange(16)
+        out = subprocess.run([core_emu, str(k), str(can), str(lsize), str(sb), str(lead)], input=seq.encode(),
+                             capture_output=True, check=True)
+        lines = out.stdout.decode().splitlines()
+        cols = np.array([int(x) for x in lines[0].split()[1:]], dtype=np.uint64)
+        got = np.array([[int(x) for x in l.split()] for l in lines[1:]], dtype=np.uint64).reshape(-1, 3)
+        exp = O.extract(seq.encode(), k, bool(can))[:, 0] if n else np.zeros(0, dtype=np.uint64)
+        assert len(got) == len(exp) and (got[:, 0] == exp).all(), (k, can, n, lead)
+        if len(exp):
+            pos = O.matrix_times(cols, lsize, 2 * k, exp[:1500])
+            assert (pos == got[:1500, 1]).all()                 # byte-table hash == matrix product
+            assert (got[:, 2] == got[:, 0]).all()               # slot word -> key round trip (inverse tables)
+
+
+def declared_functions():
+    hdr = open(os.path.join(ROOT, "include", "jfgpu.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(jfgpu_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from jellyfish_amd import capi
+    lib = capi.load()
+    names = declared_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), "libjfgpu.so does not export " + n
+    assert sorted(capi.SIGNATURES) == names, "capi.py and include/jfgpu.h disagree"
+    assert lib.jfgpu_abi_version() == 1
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    from jellyfish_amd import capi
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(capi.JfgpuError) as e:
+        capi.Table(21, 1 << 20)
+    assert e.value.code == capi.E_NO_DEVICE
+
+
+@pytest.fixture(scope="module")
+def cli():
+    subprocess.check_call(["make", "-s", "cli"], cwd=ROOT)
+    exe = os.path.join(ROOT, "bin", "jellyfish-amd")
+    assert os.access(exe, os.X_OK)
+    return exe
+
+
+@pytest.mark.parametrize("name", ["reads150_k21C", "edge_k8C"])
+def test_cli_reads_reference_written_files(cli, name):
+    jf = os.path.join(GOLD, name + ".ref.jf")
+    dump = subprocess.check_output([cli, "dump", "-c", jf]).decode().splitlines()
+    assert sorted(dump) == open(os.path.join(GOLD, name + ".dump")).read().splitlines()
+    assert subprocess.check_output([cli, "histo", jf]).decode() == open(os.path.join(GOLD, name + ".histo")).read()
+    assert subprocess.check_output([cli, "stats", jf]).decode() == open(os.path.join(GOLD, name + ".stats")).read()
+    # query: every dumped k-mer is found with its count through the interpolation search
+    sample = dump[:: max(1, len(dump) // 200)]
+    out = subprocess.check_output([cli, "query", jf] + [l.split()[0] for l in sample]).decode().splitlines()
+    assert out == sample
+    k = len(dump[0].split()[0])
+    absent = "ACGT" * 16
+    out = subprocess.check_output([cli, "query", jf, absent[:k]]).decode().split()
+    assert out[1] == "0" or (out[0] + " " + out[1]) in dump
+    info = json.loads(subprocess.check_output([cli, "info", "-j", jf]).decode())
+    assert info["format"] == "binary/sorted" and info["key_len"] == 2 * k
+
+
+def test_cli_query_sequence_matches_golden(cli):
+    case = next(c for c in MANIFEST["cases"] if c["name"] == "reads150_k21C")
+    jf = os.path.join(GOLD, "reads150_k21C.ref.jf")
+    out = subprocess.check_output([cli, "query", jf, "-s", os.path.join(GOLD, case["input"])]).decode().splitlines()
+    exp = dict(l.split() for l in open(os.path.join(GOLD, "reads150_k21C.dump")))
+    seq = O.parse_file(open(os.path.join(GOLD, case["input"]), "rb").read())
+    kmers = O.extract(seq, 21, True)
+    assert len(out) == len(kmers)
+    for line, km in zip(out[:500], kmers[:500]):
+        s, c = line.split()
+        assert s == O.to_str(km, 21) and exp[s] == c
+
+
+def test_header_writer_is_reference_compatible(tmp_path):
+    """Round-trip our header writer through the independent Python decoder: 9-digit length,
+    compact JSON with sorted keys, NUL padding to 8 bytes (generic_file_header.hpp:88-111)."""
+    src = tmp_path / "hdr.cc"
+    src.write_text(r'''
+#include <jellyfish_amd/file_header.hpp>
+#include <fstream>
+int main(int argc, char** argv) {
+  jellyfish_amd::file_header h;
+  h.format("binary/sorted"); h.size(1u << 20); h.key_len(42); h.val_len(7); h.counter_len(4); h.canonical(true);
+  jellyfish_amd::header_matrix m; m.r = 20; m.c = 42; m.identity = false; m.columns.assign(42, 0);
+  for(unsigned i = 0; i < 42; ++i) m.columns[i] = (0x9E3779B97F4A7C15ull * (i + 1)) & 0xFFFFF;
+  h.matrix(m); h.max_reprobe(3); h.set_reprobes({1, 1, 3, 6}); h.set_cmdline(argc, argv);
+  { std::ofstream out(argv[1], std::ios::binary); h.write(out); out << "BODY"; }
+  std::ifstream in(argv[1], std::ios::binary); jellyfish_amd::file_header r(in);
+  bool ok = r.size() == (1u << 20) && r.key_len() == 42 && r.canonical() && r.matrix().columns == m.columns &&
+            r.offset() % 8 == 0 && r.max_reprobe_offset() == 6;
+  char body[5] = {0}; in.read(body, 4);
+  return ok && std::string(body) == "BODY" ? 0 : 1;
+}
+''')
+    exe = tmp_path / "hdr"
+    subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "jellyfish_amd", "include"), "-o", str(exe), str(src)])
+    f = tmp_path / "h.bin"
+    subprocess.check_call([str(exe), str(f)])
+    data = f.read_bytes()
+    hlen = int(data[:9])
+    assert (9 + hlen) % 8 == 0 and data[9 + hlen:] == b"BODY"
+    js = data[9:9 + hlen].rstrip(b"\0").decode()
+    h = json.loads(js)
+    assert list(h) == sorted(h) and " " not in js.replace(str(f), "").replace("  ", "")
+    assert h["matrix1"]["r"] == 20 and len(h["matrix1"]["columns"]) == 42 and h["alignment"] == 8
+    if O.have_ref():   # and the REFERENCE's header parser accepts it
+        out = subprocess.check_output([O.REF_JF, "header", str(f)]).decode()
+        assert '"key_len" : 42' in out
