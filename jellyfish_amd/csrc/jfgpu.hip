@@ -241,6 +241,9 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
   HIP_TRY(hipMalloc((void**)&d.ovf_cnt, t->ovf_cap * sizeof(uint64_t)));
   HIP_TRY(hipMalloc((void**)&d.counters, CTR_COUNT * sizeof(uint64_t)));
   d.fwd_tbl = t->d_fwd; d.inv_tbl = t->d_inv; d.ovf_mask = t->ovf_cap - 1;
+  // Give up on a tile after 1024 probes (load > 99.8%); the reference gives up after 126
+  // (count_main_cmdline.yaggo -p).  Small tiles are probed exhaustively.
+  d.max_probe = (uint32_t)std::min<uint64_t>(t->g.tile_mask, 1023);
   HIP_TRY(hipMemcpy(t->d_fwd, fwd.data(), fwd.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(t->d_inv, inv.data(), inv.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
   // dump kernel needs > 64 KiB of dynamic LDS
@@ -277,7 +280,7 @@ int jfgpu_get_info(const jfgpu_table* t, jfgpu_info* o) {
   o->val_len = t->g.cnt_bits; o->slot_bytes = 8; o->tile_slots = 1u << t->g.tile_bits;
   o->matrix_identity = t->matrix.identity ? 1 : 0;
   o->out_counter_len = t->out_counter_len;
-  o->max_reprobe = (1u << t->g.tile_bits) - 1;
+  o->max_reprobe = t->dt.max_probe;
   o->table_bytes = (1ull << t->g.lsize_l) * 8;
   return JFGPU_OK;
 }

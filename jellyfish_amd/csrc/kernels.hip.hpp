@@ -44,6 +44,7 @@ struct DevTable {
   uint64_t* ovf_cnt;          // units of 2^cnt_bits
   uint64_t ovf_mask;          // capacity - 1
   uint64_t* counters;         // [CTR_COUNT]
+  uint32_t max_probe;         // last probe index tried before declaring the tile full
 };
 
 // ---- overflow side table ----------------------------------------------------
@@ -102,7 +103,7 @@ __device__ inline bool table_add(const DevTable& T, const uint64_t* fwd_lds, uin
   const uint64_t add = cnt << (g.tag_bits + 1);
   const uint64_t neww = add | low;
   const uint32_t tmask = (uint32_t)g.tile_mask;
-  for(uint32_t p = 0; p <= tmask; ++p) {
+  for(uint32_t p = 0; p <= T.max_probe; ++p) {
     const uint64_t slot = a.tile_base + probe_slot(a.idx0, p, tmask);
     unsigned long long* addr = (unsigned long long*)&T.slots[slot];
     const unsigned long long old = atomicCAS(addr, 0ull, (unsigned long long)neww);
@@ -137,7 +138,7 @@ __device__ inline bool table_add_val(const DevTable& T, const uint64_t* fwd_lds,
   const uint64_t low = g.occ_bit | tag;
   const uint64_t add = lowpart << (g.tag_bits + 1);
   const uint32_t tmask = (uint32_t)g.tile_mask;
-  for(uint32_t p = 0; p <= tmask; ++p) {
+  for(uint32_t p = 0; p <= T.max_probe; ++p) {
     const uint64_t slot = a.tile_base + probe_slot(a.idx0, p, tmask);
     unsigned long long* addr = (unsigned long long*)&T.slots[slot];
     const unsigned long long old = atomicCAS(addr, 0ull, (unsigned long long)(add | low));
@@ -191,11 +192,18 @@ __global__ __launch_bounds__(kBlock) void count_ascii_kernel(DevTable T, const u
   __shared__ uint64_t s_fwd[8 * 256];
   __shared__ uint32_t s_codes[kBlock + 2];
   __shared__ uint32_t s_inv[kBlock + 2];
+  __shared__ int s_abort;
   load_tables_lds(s_fwd, T.fwd_tbl, T.g.nbytes);
   const int64_t n_tiles = (hi + kTilePos - 1) / kTilePos;
   uint32_t my_mers = 0;
   for(int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    __syncthreads();  // previous iteration's LDS reads done (also orders the table load)
+    // "Hash full" already raised by some block: the result is void, stop burning probes (the
+    // host reports the error at jfgpu_sync).  One lane polls, the barrier makes it block-uniform
+    // and also fences the previous iteration's LDS reads.
+    if(threadIdx.x == 0)
+      s_abort = __hip_atomic_load(&T.counters[CTR_FULL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    __syncthreads();
+    if(s_abort) break;
     const LaneWords L = stage_tile(base, tile * kTilePos, lo, hi, s_codes, s_inv);
     // run-length merge of consecutive identical k-mers (homopolymers / short tandem
     // repeats are the heavy hitters of real data): one atomic per run, not per k-mer.
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(kBlock) void lookup_kernel(DevTable T, const uint64
     uint64_t val = 0; uint8_t fnd = 0;
     if(a.shard == g.shard_id) {
       const uint64_t low = g.occ_bit | make_tag(g, key, a.idx0);
-      for(uint32_t p = 0; p <= tmask; ++p) {
+      for(uint32_t p = 0; p <= T.max_probe; ++p) {
         const uint64_t slot = a.tile_base + probe_slot(a.idx0, p, tmask);
         const uint64_t w = T.slots[slot];
         if(w == 0) break;

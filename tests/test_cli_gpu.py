@@ -1,0 +1,88 @@
+"""Drop-in check of the whole `count` verb on the GPU (-m gpu): jellyfish-amd count writes a
+binary/sorted (or text/sorted) file that (a) decodes to the reference's golden dump and (b) is
+read, order-checked and queried by the REFERENCE's own readers (oracle/_ref/ref_jf travels to the
+GPU box prebuilt; /root/reference itself is never touched at run time)."""
+import json
+import os
+import subprocess
+
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+MANIFEST = json.load(open(os.path.join(GOLD, "manifest.json")))
+CLI = os.path.join(ROOT, "bin", "jellyfish-amd")
+
+
+@pytest.fixture(scope="module")
+def cli(gpu):
+    subprocess.check_call(["make", "-s", "cli"], cwd=ROOT)
+    return CLI
+
+
+@pytest.mark.parametrize("case", MANIFEST["cases"], ids=lambda c: c["name"])
+def test_count_file_matches_reference_golden(cli, case, tmp_path):
+    name, k = case["name"], case["k"]
+    out = str(tmp_path / "out.jf")
+    cmd = [cli, "count", "-m", str(k), "-s", case["size"], "-t", "4", "-o", out, "--timing", str(tmp_path / "timing")]
+    if case["canonical"]:
+        cmd.append("-C")
+    subprocess.check_call(cmd + [os.path.join(GOLD, case["input"])])
+    golden = open(os.path.join(GOLD, name + ".dump")).read().splitlines()
+    mine = subprocess.check_output([cli, "dump", "-c", out]).decode().splitlines()
+    assert sorted(mine) == golden
+    assert subprocess.check_output([cli, "histo", out]).decode() == open(os.path.join(GOLD, name + ".histo")).read()
+    assert subprocess.check_output([cli, "stats", out]).decode() == open(os.path.join(GOLD, name + ".stats")).read()
+    t = open(tmp_path / "timing").read().split()
+    assert t[0::2] == ["Init", "Counting", "Writing"]                      # count_main.cc:377-382 labels
+    if O.have_ref():
+        # the reference's binary_reader / binary_query consume our file unchanged
+        ref = subprocess.check_output([O.REF_JF, "dump", "-c", out]).decode().splitlines()
+        assert ref == mine
+        assert subprocess.check_output([O.REF_JF, "dump", "--check-order", out]).decode().startswith("ORDER OK %d" % len(golden))
+        assert subprocess.check_output([O.REF_JF, "histo", out]).decode() == open(os.path.join(GOLD, name + ".histo")).read()
+        assert subprocess.check_output([O.REF_JF, "stats", out]).decode() == open(os.path.join(GOLD, name + ".stats")).read()
+        sample = golden[:: max(1, len(golden) // 100)]
+        q = subprocess.check_output([O.REF_JF, "query", out] + [l.split()[0] for l in sample]).decode().splitlines()
+        assert q == sample
+
+
+def test_count_text_format_and_bounds(cli, tmp_path):
+    case = next(c for c in MANIFEST["cases"] if c["name"] == "reads150_k5C")
+    inp = os.path.join(GOLD, case["input"])
+    golden = [l.split() for l in open(os.path.join(GOLD, "reads150_k5C.dump"))]
+    txt = str(tmp_path / "t.jf")
+    subprocess.check_call([cli, "count", "-m", "5", "-C", "-s", "4k", "--text", "-o", txt, inp])
+    got = sorted(subprocess.check_output([cli, "dump", "-c", txt]).decode().splitlines())
+    assert got == [" ".join(g) for g in golden]
+    lo, hi = 10, 14
+    lu = str(tmp_path / "lu.jf")
+    subprocess.check_call([cli, "count", "-m", "5", "-C", "-s", "4k", "-L", str(lo), "-U", str(hi), "-o", lu, inp])
+    got = sorted(subprocess.check_output([cli, "dump", "-c", lu]).decode().splitlines())
+    assert got == [" ".join(g) for g in golden if lo <= int(g[1]) <= hi]
+    if O.have_ref():
+        assert sorted(subprocess.check_output([O.REF_JF, "dump", "-c", txt]).decode().splitlines()) == [" ".join(g) for g in golden]
+
+
+def test_count_multiple_files_and_hash_full(cli, tmp_path):
+    fa = os.path.join(GOLD, "reads150_s42.fa")
+    fq = os.path.join(GOLD, "reads_fq_s1473540700.fq")
+    out = str(tmp_path / "two.jf")
+    subprocess.check_call([cli, "count", "-m", "21", "-C", "-s", "64k", "-o", out, fa, fq])
+    exp = {}
+    for n in ("reads150_k21C", "fastq_k21C"):
+        for l in open(os.path.join(GOLD, n + ".dump")):
+            a, c = l.split()
+            exp[a] = exp.get(a, 0) + int(c)
+    got = dict((a, int(c)) for a, c in (l.split() for l in subprocess.check_output([cli, "dump", "-c", out]).decode().splitlines()))
+    assert got == exp
+    # too small a table must fail loudly ("Hash full", hash_counter.hpp:194-195), exit code 1
+    r = subprocess.run([cli, "count", "-m", "21", "-C", "-s", "1k", "-o", str(tmp_path / "full.jf"), fa], capture_output=True)
+    assert r.returncode == 1 and b"Hash full" in r.stderr
+    r = subprocess.run([cli, "count", "-m", "21", "-s", "64k", "-o", str(tmp_path / "bad.jf"), os.path.join(GOLD, "manifest.json")],
+                       capture_output=True)
+    assert r.returncode == 1 and b"Unsupported format" in r.stderr

@@ -1,5 +1,5 @@
-"""First-contact measurements on the GPU box (not part of the test suite):
-random-access roofline probes (R_gups) and a first count throughput number."""
+"""Measurements on the GPU box (not part of the test suite): random-access roofline probes
+(R_gups) at several table sizes and the count kernel's throughput on 1 Gbp."""
 import json
 import sys
 import time
@@ -9,25 +9,21 @@ from jellyfish_amd import capi
 
 res = {}
 k, L = 21, 150
-for lsize in (27, 31, 34):
-    t0 = time.time()
+for lsize in (31, 34):
     with capi.Table(k, 1 << lsize) as t:
-        res[f"create_2^{lsize}_s"] = round(time.time() - t0, 3)
         n = 1 << 28
         for mode, name in ((0, "add_noret"), (1, "add_ret"), (2, "cas"), (3, "load+add")):
             ups = t.gups(n, mode)
             res[f"gups_{name}_2^{lsize}"] = round(ups / 1e9, 3)
             print(lsize, name, round(ups / 1e9, 3), "G updates/s", flush=True)
-        tc = time.time(); t.clear(); res[f"clear_2^{lsize}_s"] = round(time.time() - tc, 3)
-        # count throughput: 1 Gbp of synthetic reads resident in HBM
+        t.clear()
         n_reads = 6_666_667
         nbytes = n_reads * (L + 1)
         d = t.malloc(nbytes + 16)
         t.gen_reads_dev(d, 0, n_reads, L, 42)
         t.sync()
         t.profile_enable(True)
-        for rep in range(3):
-            t.count_ascii_dev(d, nbytes)
+        t.count_ascii_dev(d, nbytes)
         t.sync()
         ms, launches, units = t.profile_get(0)
         kmers = n_reads * (L - k + 1) * launches
