@@ -125,6 +125,8 @@ def main():
         for mode, name in ((0, "atomic_add"), (2, "atomic_cas")):
             gups[name] = t.gups(1 << 28, mode)
     t.clear()
+    if world == 1:
+        t.reserve(n_reads * stride)      # Init phase: workspace for one sync-to-sync span (like -s presizes the table)
 
     if world == 1:
         def run_step(i):
@@ -171,9 +173,15 @@ def main():
     assert int(tot[0]) == total_kmers, "counted %d k-mers, expected %d" % (int(tot[0]), total_kmers)
 
     if rank == 0:
-        which = 0 if world == 1 else 1
+        slot_names = ["count_direct", "add_keys", "shard_partition", "lookup", "p1_partition", "p2_partition", "tile_insert", "items_direct"]
+        kernels = {}
+        for i, nm in enumerate(slot_names):
+            kms, kl, ku = t.profile_get(i)
+            if kl:
+                kernels[nm] = {"ms": round(kms, 3), "launches": kl, "units": ku}
+        which = max(range(len(slot_names)), key=lambda i: t.profile_get(i)[0])
         ms, launches, _ = t.profile_get(which)
-        per_launch_kmers = n_reads * kmers_per_read / max(launches, 1) if world == 1 else int(st.total) / max(launches, 1)
+        per_launch_kmers = int(st.total) / max(launches, 1)
         avg_ms = ms / max(launches, 1)
         achieved = per_launch_kmers * B_ALG / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         value = total_kmers / elapsed
@@ -188,7 +196,8 @@ def main():
                        "load_factor": float(tot[1]) / float(world << args.lsize),
                        "distinct": int(tot[1]), "total_kmers": total_kmers,
                        "parallelism": "single GPU" if world == 1 else "hash-prefix shard x%d + all-to-all" % world},
-            "roofline": {"bound": "hbm", "kernel": "count_ascii_kernel" if world == 1 else "add_keys_one_kernel",
+            "kernels": kernels,
+            "roofline": {"bound": "hbm", "kernel": slot_names[which],
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "bytes_per_kmer": B_ALG, "kmers_per_launch": per_launch_kmers,
                          "avg_launch_ms": avg_ms, "launches": launches,

@@ -158,9 +158,19 @@ int  jfgpu_dump_begin(jfgpu_table* t, uint64_t lower, uint64_t upper, uint64_t* 
 int  jfgpu_dump_next(jfgpu_table* t, void* out, uint64_t capacity_records, uint64_t* n_read);
 int  jfgpu_dump_end(jfgpu_table* t);
 
+/* Insert strategy.  0 auto (default), 1 direct (global 64-bit atomics, kernels.hip.hpp),
+ * 2 partitioned (radix partition + LDS-resident tiles, kernels_part.hip.hpp; large batches
+ * are buffered on the device and applied at the next jfgpu_sync / read).  Results are
+ * bit-identical; the environment variable JFGPU_MODE=direct|partitioned sets the default. */
+int  jfgpu_set_mode(jfgpu_table* t, int mode);
+/* Optional: pre-size the partitioned path's device workspace for `input_bytes` of sequence
+ * between two syncs (what `-s` is to the table, hash_counter.hpp:56-64: a hint that moves
+ * allocation out of the counting phase).  Without it the workspace grows on demand. */
+int  jfgpu_reserve(jfgpu_table* t, uint64_t input_bytes);
+
 /* ---- measurement helpers (bench.py; not part of the reference surface) -- */
-/* Per-kernel HIP-event timing on the table's stream.  which: 0 count, 1 add_keys,
- * 2 partition, 3 lookup.  Returns accumulated milliseconds and launches since the
+/* Per-kernel HIP-event timing on the table's stream.  which: 0 count (direct), 1 add_keys,
+ * 2 shard partition, 3 lookup, 4 P1 partition, 5 P2 partition, 6 tile insert, 7 items-direct.  Returns accumulated milliseconds and launches since the
  * last reset. */
 int  jfgpu_profile_enable(jfgpu_table* t, int on);
 int  jfgpu_profile_get(jfgpu_table* t, int which, double* ms, uint64_t* launches, uint64_t* units);

@@ -70,6 +70,8 @@ SIGNATURES = {
     "jfgpu_dump_begin": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "jfgpu_dump_next": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "jfgpu_dump_end": (C.c_int, [_P]),
+    "jfgpu_set_mode": (C.c_int, [_P, C.c_int]),
+    "jfgpu_reserve": (C.c_int, [_P, C.c_uint64]),
     "jfgpu_profile_enable": (C.c_int, [_P, C.c_int]),
     "jfgpu_profile_get": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "jfgpu_profile_reset": (C.c_int, [_P]),
@@ -233,6 +235,13 @@ class Table:
             return out
         finally:
             _check(self._lib.jfgpu_dump_end(self._h))
+
+    def set_mode(self, mode):
+        """0 auto, 1 direct (global atomics), 2 partitioned (LDS tiles)."""
+        _check(self._lib.jfgpu_set_mode(self._h, mode))
+
+    def reserve(self, input_bytes):
+        _check(self._lib.jfgpu_reserve(self._h, int(input_bytes)))
 
     # -- measurement helpers
     def profile_enable(self, on=True):

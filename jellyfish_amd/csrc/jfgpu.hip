@@ -16,6 +16,7 @@
 #include "../../include/jfgpu.h"
 #include "gf2_matrix.hpp"
 #include "kernels.hip.hpp"
+#include "kernels_part.hip.hpp"
 
 using namespace jfgpu;
 
@@ -35,7 +36,10 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 constexpr uint64_t kDefaultSeed = 0x6A656C6C79666973ull;  // "jellyfis"
 constexpr size_t kStageBytes = 64u << 20;                  // host->device staging chunk
-constexpr int kNumProf = 4;
+constexpr int kNumProf = 8;   // 0 count 1 add_keys 2 shard-partition 3 lookup 4 P1 5 P2 6 tile-insert 7 items-direct
+enum Mode { MODE_AUTO = 0, MODE_DIRECT = 1, MODE_PARTITIONED = 2 };
+
+struct PendingBatch { void* items; uint64_t* off; uint64_t cap_items; };
 
 struct ProfSpan { hipEvent_t a, b; int which; uint64_t units; };
 
@@ -62,9 +66,22 @@ struct jfgpu_table {
   bool prof_on = false;
   std::vector<ProfSpan> prof_pending;
   std::vector<hipEvent_t> ev_pool;
-  double prof_ms[kNumProf] = {0, 0, 0, 0};
-  uint64_t prof_launches[kNumProf] = {0, 0, 0, 0};
-  uint64_t prof_units[kNumProf] = {0, 0, 0, 0};
+  double prof_ms[kNumProf] = {};
+  uint64_t prof_launches[kNumProf] = {};
+  uint64_t prof_units[kNumProf] = {};
+  // partitioned insert path (kernels_part.hip.hpp)
+  int mode = MODE_AUTO;
+  bool part_ok = false;          // geometry admits the partitioned path
+  PartGeom pg{};
+  bool item32 = false;
+  bool pristine = true;          // table known all-zero: tile_insert may skip the tile read
+  std::vector<PendingBatch> pending;
+  uint64_t pending_bytes = 0;
+  uint32_t* d_M1 = nullptr; int g1 = 0;
+  uint32_t* d_M2 = nullptr; int g2 = 0;
+  // workspace arena for pending batches and flush temporaries: bump-allocated, reset at flush,
+  // grown geometrically (allocation of tens of GB costs ~100 ms, so never inside the hot path twice)
+  uint8_t* ws = nullptr; size_t ws_cap = 0, ws_used = 0;
   // dump state
   bool dump_open = false;
   uint64_t dump_lower = 0, dump_upper = 0;
@@ -137,6 +154,10 @@ int check_deferred(jfgpu_table* t, uint64_t* ctr_out = nullptr) {
   return JFGPU_OK;
 }
 
+bool use_partitioned(const jfgpu_table* t, size_t nbytes);
+int part_ingest(jfgpu_table* t, const uint8_t* base, int64_t lo, int64_t hi, bool from_keys, uint64_t max_items);
+int part_flush(jfgpu_table* t);
+
 // Splits a device buffer pointer into a 16-byte aligned base and [lo, hi).
 void align_buffer(const char* d, size_t n, const uint8_t*& base, int64_t& lo, int64_t& hi) {
   const uintptr_t p = (uintptr_t)d;
@@ -148,6 +169,11 @@ int launch_count(jfgpu_table* t, const char* d_bases, size_t n) {
   if(n < t->g.k) return JFGPU_OK;
   const uint8_t* base; int64_t lo, hi;
   align_buffer(d_bases, n, base, lo, hi);
+  if(use_partitioned(t, n)) {
+    const int rc = part_ingest(t, base, lo, hi, false, n);
+    if(rc >= 0) return rc;          // < 0: no memory for the pending batch -> direct kernel below
+  }
+  t->pristine = false;
   const int64_t n_tiles = (hi + kTilePos - 1) / kTilePos;
   const int grid = grid_for(t, (uint64_t)n_tiles);
   ProfScope ps(t, 0, n);
@@ -163,6 +189,209 @@ int ensure_stage(jfgpu_table* t) {
     if(!t->stage_done[i]) HIP_TRY(hipEventCreateWithFlags(&t->stage_done[i], hipEventDisableTiming));
   }
   return JFGPU_OK;
+}
+
+
+// ---- partitioned insert path: host orchestration (kernels_part.hip.hpp) -------------------
+constexpr uint64_t kPartMinBytes = 1u << 20;   // AUTO: smaller device batches take the direct kernel
+
+void part_geom_init(jfgpu_table* t) {
+  const uint32_t bits = t->g.lsize_l - t->g.tile_bits;   // tile-index bits to resolve
+  t->part_ok = false;
+  if(t->g.tile_bits < kMaxTileBits) return;               // tiny table: one partial tile
+  uint32_t b1, b2;
+  if(bits <= 11) { b1 = bits; b2 = 0; }
+  else { b2 = std::min<uint32_t>(11, (bits + 1) / 2); b1 = bits - b2; }
+  if(b1 > 11) return;
+  t->pg.b1 = b1; t->pg.b2 = b2;
+  t->pg.rest_shift = t->g.lsize_l - b1;
+  t->pg.item_bits = t->pg.rest_shift + t->g.rem_bits;
+  if(t->pg.item_bits > 64) return;
+  t->item32 = t->pg.item_bits <= 32;
+  t->part_ok = true;
+}
+
+size_t item_size(const jfgpu_table* t) { return t->item32 ? 4 : 8; }
+
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Grow the arena to at least `need` bytes.  Only legal while it holds nothing (ws_used == 0).
+int ws_grow(jfgpu_table* t, size_t need) {
+  if(need <= t->ws_cap) return JFGPU_OK;
+  size_t want = std::max(need + need / 8, t->ws_cap * 2);
+  size_t free_b = 0, total_b = 0;
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  if(t->ws) { hipFree(t->ws); t->ws = nullptr; t->ws_cap = 0; }
+  HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  const size_t keep = (size_t)2 << 30;                      // leave room for the caller's buffers
+  if(want + keep > free_b) want = need;
+  if(want + keep / 2 > free_b) return -1;
+  HIP_TRY(hipMalloc((void**)&t->ws, want));
+  t->ws_cap = want;
+  return JFGPU_OK;
+}
+
+void* ws_alloc(jfgpu_table* t, size_t bytes) {
+  const size_t at = align_up(t->ws_used, 256);
+  if(at + bytes > t->ws_cap) return nullptr;
+  t->ws_used = at + bytes;
+  return t->ws + at;
+}
+
+template <typename ITEM>
+void launch_p1(jfgpu_table* t, bool scatter, bool from_keys, const uint8_t* base, int64_t lo, int64_t hi,
+               const uint64_t* d_off, void* d_items) {
+  const dim3 grid(t->g1), block(kPBlock);
+  ITEM* out = (ITEM*)d_items;
+#define P1(SC, FK, RT) hipLaunchKernelGGL((p1_kernel<ITEM, SC, FK, RT>), grid, block, 0, t->stream, t->dt, t->pg, base, lo, hi, t->d_M1, d_off, out)
+  const bool rt = t->returning;
+  if(!scatter) { if(from_keys) P1(false, true, false); else P1(false, false, false); }
+  else if(from_keys) { if(rt) P1(true, true, true); else P1(true, true, false); }
+  else { if(rt) P1(true, false, true); else P1(true, false, false); }
+#undef P1
+}
+
+int part_flush(jfgpu_table* t);
+
+// One batch (contract buffer or key array, on the device) through P1 into a pending batch.
+int part_ingest(jfgpu_table* t, const uint8_t* base, int64_t lo, int64_t hi, bool from_keys, uint64_t max_items) {
+  if(!max_items) return JFGPU_OK;
+  const uint32_t nb = 1u << t->pg.b1;
+  if(!t->d_M1) {
+    t->g1 = 2 * t->n_cu;   // two 1024-thread blocks per CU: one stages while the other computes
+    HIP_TRY(hipMalloc((void**)&t->d_M1, (size_t)t->g1 * kMaxBuckets * sizeof(uint32_t)));
+  }
+  if(t->pending.size() >= kMaxSeg) { int rc = part_flush(t); if(rc) return rc; }
+  const size_t bytes = max_items * item_size(t);
+  const size_t need = align_up(bytes, 256) + align_up((nb + 1) * sizeof(uint64_t), 256) + 512;
+  if(t->ws_used + need > t->ws_cap) {
+    if(!t->pending.empty()) { int rc = part_flush(t); if(rc) return rc; }   // apply what is pending, arena is empty again
+    if(need > t->ws_cap) { int rc = ws_grow(t, need); if(rc) return rc; }     // rc < 0: no memory -> caller goes direct
+  }
+  PendingBatch b{nullptr, nullptr, max_items};
+  b.items = ws_alloc(t, bytes);
+  b.off = (uint64_t*)ws_alloc(t, (nb + 1) * sizeof(uint64_t));
+  if(!b.items || !b.off) return fail(JFGPU_E_ALLOC, "partition workspace exhausted");
+  {
+    ProfScope ps(t, 4, (uint64_t)(from_keys ? hi : hi - lo));
+    if(t->item32) launch_p1<uint32_t>(t, false, from_keys, base, lo, hi, b.off, b.items);
+    else          launch_p1<uint64_t>(t, false, from_keys, base, lo, hi, b.off, b.items);
+    hipLaunchKernelGGL(scan_matrix_kernel, dim3(1), dim3(1024), 0, t->stream, t->d_M1, (uint32_t)t->g1, nb, (const uint64_t*)nullptr, b.off);
+    if(t->item32) launch_p1<uint32_t>(t, true, from_keys, base, lo, hi, b.off, b.items);
+    else          launch_p1<uint64_t>(t, true, from_keys, base, lo, hi, b.off, b.items);
+  }
+  hipError_t e = hipGetLastError();
+  t->pending.push_back(b);
+  t->pending_bytes += bytes;
+  if(e != hipSuccess) return fail(JFGPU_E_HIP, hipGetErrorString(e));
+  return JFGPU_OK;
+}
+
+template <typename ITEM>
+int part_flush_t(jfgpu_table* t) {
+  const uint32_t nb1 = 1u << t->pg.b1, nb2 = 1u << t->pg.b2;
+  const size_t nbatch = t->pending.size();
+  // bucket sizes of every pending batch (one small D2H; also drains the stream)
+  std::vector<uint64_t> offs(nbatch * (nb1 + 1));
+  for(size_t s = 0; s < nbatch; ++s)
+    HIP_TRY(hipMemcpyAsync(&offs[s * (nb1 + 1)], t->pending[s].off, (nb1 + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, t->stream));
+  uint64_t ctr[CTR_COUNT];
+  HIP_TRY(hipMemcpyAsync(ctr, t->dt.counters, sizeof(ctr), hipMemcpyDeviceToHost, t->stream));
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  std::vector<uint64_t> bucket_tot(nb1, 0);
+  uint64_t total = 0, max_bucket = 0;
+  for(size_t s = 0; s < nbatch; ++s)
+    for(uint32_t j = 0; j < nb1; ++j) bucket_tot[j] += offs[s * (nb1 + 1) + j + 1] - offs[s * (nb1 + 1) + j];
+  for(uint32_t j = 0; j < nb1; ++j) { total += bucket_tot[j]; max_bucket = std::max(max_bucket, bucket_tot[j]); }
+  const uint64_t n_tiles = n_tiles_of(t);
+  SegList S1; memset(&S1, 0, sizeof S1);
+  S1.n = (uint32_t)nbatch;
+  for(size_t s = 0; s < nbatch; ++s) { S1.items[s] = t->pending[s].items; S1.off[s] = t->pending[s].off; }
+  const size_t tile_lds = (size_t)8 << t->g.tile_bits;
+  // always LOAD-capable: a tile is read only if its dirty byte is set (clean after jfgpu_clear)
+  const bool rt = t->returning, load = true;
+  auto launch_tiles = [&](const SegList& S, uint64_t tile0, uint32_t ntile, uint64_t units) {
+    ProfScope ps(t, 6, units);
+    const dim3 grid((unsigned)std::min<uint64_t>(ntile, (uint64_t)t->n_cu * 16)), block(kPBlock);
+#define TI(RT, LD) hipLaunchKernelGGL((tile_insert_kernel<ITEM, RT, LD>), grid, block, tile_lds, t->stream, t->dt, S, tile0, ntile)
+    if(rt) { if(load) TI(true, true); else TI(true, false); } else { if(load) TI(false, true); else TI(false, false); }
+#undef TI
+  };
+  if(total == 0) {
+    // nothing to insert
+  } else if(t->mode != MODE_PARTITIONED && total < n_tiles * 256) {
+    // too few items to be worth streaming the tiles: global atomics straight from the items
+    for(size_t s = 0; s < nbatch; ++s) {
+      const uint64_t n = offs[s * (nb1 + 1) + nb1];
+      if(!n) continue;
+      ProfScope ps(t, 7, n);
+      const dim3 grid((unsigned)grid_for(t, (n + kBlock - 1) / kBlock)), block(kBlock);
+      if(rt) hipLaunchKernelGGL((items_direct_kernel<ITEM, true>), grid, block, 0, t->stream, t->dt, t->pg, (const ITEM*)t->pending[s].items, (const uint64_t*)t->pending[s].off);
+      else   hipLaunchKernelGGL((items_direct_kernel<ITEM, false>), grid, block, 0, t->stream, t->dt, t->pg, (const ITEM*)t->pending[s].items, (const uint64_t*)t->pending[s].off);
+    }
+  } else if(t->pg.b2 == 0) {
+    launch_tiles(S1, 0, nb1, total);
+  } else {
+    // breadth-first: every P1 bucket through P2 in one launch per pass, then every tile in one launch
+    const int g2 = 32;
+    if(!t->d_M2) HIP_TRY(hipMalloc((void**)&t->d_M2, (size_t)nb1 * g2 * nb2 * sizeof(uint32_t)));
+    ITEM* tmp = nullptr; uint64_t *d_goff = nullptr, *d_base = nullptr;
+    bool tmp_owned = false;
+    d_goff = (uint64_t*)ws_alloc(t, (n_tiles + 1) * sizeof(uint64_t));
+    d_base = (uint64_t*)ws_alloc(t, nb1 * sizeof(uint64_t));
+    tmp = (ITEM*)ws_alloc(t, std::max<uint64_t>(total, 1) * sizeof(ITEM));
+    if(!d_goff || !d_base || !tmp) {     // arena too small for the flush temporaries: one-off allocation
+      tmp_owned = true;
+      tmp = nullptr; d_goff = nullptr; d_base = nullptr;
+      HIP_TRY(hipMalloc((void**)&tmp, std::max<uint64_t>(total, 1) * sizeof(ITEM)));
+      if(hipMalloc((void**)&d_goff, (n_tiles + 1) * sizeof(uint64_t)) != hipSuccess ||
+         hipMalloc((void**)&d_base, nb1 * sizeof(uint64_t)) != hipSuccess) {
+        hipFree(tmp); if(d_goff) hipFree(d_goff);
+        return fail(JFGPU_E_ALLOC, "hipMalloc partition offsets");
+      }
+    }
+    std::vector<uint64_t> base(nb1);
+    { uint64_t run = 0; for(uint32_t j = 0; j < nb1; ++j) { base[j] = run; run += bucket_tot[j]; } }
+    HIP_TRY(hipMemcpyAsync(d_base, base.data(), nb1 * sizeof(uint64_t), hipMemcpyHostToDevice, t->stream));
+    {
+      ProfScope ps(t, 5, total);
+      const dim3 grid(g2, nb1), block(kPBlock);
+      hipLaunchKernelGGL((p2_kernel<ITEM, false>), grid, block, 0, t->stream, t->pg, t->g.tag_bits, S1, t->d_M2, (const uint64_t*)d_goff, tmp);
+      hipLaunchKernelGGL(scan_matrix_kernel, dim3(nb1), dim3(1024), 0, t->stream, t->d_M2, (uint32_t)g2, nb2, (const uint64_t*)d_base, d_goff);
+      constexpr int per_thread = sizeof(ITEM) == 4 ? 16 : 8;
+      hipLaunchKernelGGL((p2_scatter_sorted_kernel<ITEM, per_thread>), grid, block, (size_t)kPBlock * per_thread * sizeof(ITEM), t->stream,
+                         t->pg, t->g.tag_bits, S1, (const uint32_t*)t->d_M2, (const uint64_t*)d_goff, tmp);
+    }
+    SegList S2; memset(&S2, 0, sizeof S2);
+    S2.n = 1; S2.items[0] = tmp; S2.off[0] = d_goff;
+    launch_tiles(S2, 0, (uint32_t)n_tiles, total);
+    hipError_t e = hipStreamSynchronize(t->stream);
+    if(tmp_owned) { hipFree(tmp); hipFree(d_goff); hipFree(d_base); }
+    if(e != hipSuccess) return fail(JFGPU_E_HIP, hipGetErrorString(e));
+  }
+  hipError_t e = hipGetLastError();
+  if(e == hipSuccess) e = hipStreamSynchronize(t->stream);
+  t->pending.clear(); t->pending_bytes = 0; t->ws_used = 0;
+  if(total) t->pristine = false;
+  if(e != hipSuccess) return fail(JFGPU_E_HIP, hipGetErrorString(e));
+  return JFGPU_OK;
+}
+
+int part_flush(jfgpu_table* t) {
+  if(t->pending.empty()) return JFGPU_OK;
+  return t->item32 ? part_flush_t<uint32_t>(t) : part_flush_t<uint64_t>(t);
+}
+
+void part_discard(jfgpu_table* t) {
+  if(t->stream) hipStreamSynchronize(t->stream);
+  t->pending.clear(); t->pending_bytes = 0; t->ws_used = 0;
+}
+
+bool use_partitioned(const jfgpu_table* t, size_t nbytes) {
+  if(!t->part_ok || t->mode == MODE_DIRECT) return false;
+  if(t->mode == MODE_PARTITIONED) return true;
+  return nbytes >= kPartMinBytes || !t->pending.empty();
 }
 
 }  // namespace
@@ -240,6 +469,7 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
   HIP_TRY(hipMalloc((void**)&d.ovf_key, t->ovf_cap * sizeof(uint64_t)));
   HIP_TRY(hipMalloc((void**)&d.ovf_cnt, t->ovf_cap * sizeof(uint64_t)));
   HIP_TRY(hipMalloc((void**)&d.counters, CTR_COUNT * sizeof(uint64_t)));
+  HIP_TRY(hipMalloc((void**)&d.dirty, (size_t)1 << (t->g.lsize_l - t->g.tile_bits)));
   d.fwd_tbl = t->d_fwd; d.inv_tbl = t->d_inv; d.ovf_mask = t->ovf_cap - 1;
   // Give up on a tile after 1024 probes (load > 99.8%); the reference gives up after 126
   // (count_main_cmdline.yaggo -p).  Small tiles are probed exhaustively.
@@ -249,6 +479,20 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
   // dump kernel needs > 64 KiB of dynamic LDS
   const size_t dump_lds = ((size_t)8 << t->g.tile_bits) + ((size_t)2 << t->g.tile_bits) + (size_t)t->g.nbytes * 2048;
   HIP_TRY(hipFuncSetAttribute((const void*)dump_tiles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dump_lds));
+  part_geom_init(t.get());
+  if(const char* m = getenv("JFGPU_MODE")) {
+    if(!strcmp(m, "direct")) t->mode = MODE_DIRECT;
+    else if(!strcmp(m, "partitioned")) t->mode = MODE_PARTITIONED;
+  }
+  {
+    const int tl = (int)((size_t)8 << t->g.tile_bits);
+#define TATTR(I, R, L) HIP_TRY(hipFuncSetAttribute((const void*)tile_insert_kernel<I, R, L>, hipFuncAttributeMaxDynamicSharedMemorySize, tl))
+    TATTR(uint32_t, true, true); TATTR(uint32_t, true, false); TATTR(uint32_t, false, true); TATTR(uint32_t, false, false);
+    TATTR(uint64_t, true, true); TATTR(uint64_t, true, false); TATTR(uint64_t, false, true); TATTR(uint64_t, false, false);
+#undef TATTR
+    HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint32_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * 16 * 4));
+    HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint64_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * 8 * 8));
+  }
   jfgpu_table* raw = t.release();
   int rc = jfgpu_clear(raw);
   if(rc) { jfgpu_destroy(raw); return rc; }
@@ -263,10 +507,14 @@ void jfgpu_destroy(jfgpu_table* t) {
   prof_collect(t);
   for(auto e : t->ev_pool) hipEventDestroy(e);
   hipFree(t->dt.slots); hipFree(t->d_fwd); hipFree(t->d_inv);
-  hipFree(t->dt.ovf_key); hipFree(t->dt.ovf_cnt); hipFree(t->dt.counters);
+  hipFree(t->dt.ovf_key); hipFree(t->dt.ovf_cnt); hipFree(t->dt.counters); hipFree(t->dt.dirty);
   for(int i = 0; i < 2; ++i) { if(t->d_stage[i]) hipFree(t->d_stage[i]); if(t->stage_done[i]) hipEventDestroy(t->stage_done[i]); }
   if(t->d_dump) hipFree(t->d_dump);
   if(t->d_tile_off) hipFree(t->d_tile_off);
+  part_discard(t);
+  if(t->d_M1) hipFree(t->d_M1);
+  if(t->d_M2) hipFree(t->d_M2);
+  if(t->ws) hipFree(t->ws);
   if(t->stream) hipStreamDestroy(t->stream);
   delete t;
 }
@@ -293,16 +541,20 @@ int jfgpu_get_matrix(const jfgpu_table* t, uint64_t* columns) {
 
 int jfgpu_clear(jfgpu_table* t) {
   int rc = use(t); if(rc) return rc;
+  part_discard(t);
   HIP_TRY(hipMemsetAsync(t->dt.slots, 0, (1ull << t->g.lsize_l) * sizeof(uint64_t), t->stream));
   HIP_TRY(hipMemsetAsync(t->dt.ovf_key, 0, t->ovf_cap * sizeof(uint64_t), t->stream));
   HIP_TRY(hipMemsetAsync(t->dt.ovf_cnt, 0, t->ovf_cap * sizeof(uint64_t), t->stream));
   HIP_TRY(hipMemsetAsync(t->dt.counters, 0, CTR_COUNT * sizeof(uint64_t), t->stream));
+  HIP_TRY(hipMemsetAsync(t->dt.dirty, 0, (size_t)1 << (t->g.lsize_l - t->g.tile_bits), t->stream));
   HIP_TRY(hipStreamSynchronize(t->stream));
+  t->pristine = true;
   return JFGPU_OK;
 }
 
 int jfgpu_sync(jfgpu_table* t) {
   int rc = use(t); if(rc) return rc;
+  rc = part_flush(t); if(rc) return rc;
   HIP_TRY(hipStreamSynchronize(t->stream));
   return check_deferred(t);
 }
@@ -339,6 +591,12 @@ int jfgpu_add_keys_dev(jfgpu_table* t, const uint64_t* d_keys, size_t n, uint64_
   int rc = use(t); if(rc) return rc;
   if(!n) return JFGPU_OK;
   if(!d_keys) return fail(JFGPU_E_INVALID, "null keys");
+  if(val == 1 && !d_is_new && use_partitioned(t, n * 8)) {
+    const int prc = part_ingest(t, (const uint8_t*)d_keys, 0, (int64_t)n, true, n);
+    if(prc >= 0) return prc;
+  }
+  if(d_is_new || val != 1) { rc = part_flush(t); if(rc) return rc; }   // is_new / set() must see earlier adds
+  t->pristine = false;
   const int grid = grid_for(t, (n + kBlock - 1) / kBlock);
   ProfScope ps(t, 1, n);
   if(val == 1 && !d_is_new) {
@@ -369,6 +627,7 @@ int jfgpu_add_keys(jfgpu_table* t, const uint64_t* keys, size_t n, uint64_t val,
 
 int jfgpu_lookup_dev(jfgpu_table* t, const uint64_t* d_keys, size_t n, uint64_t* d_vals, uint8_t* d_found) {
   int rc = use(t); if(rc) return rc;
+  rc = part_flush(t); if(rc) return rc;
   if(!n) return JFGPU_OK;
   if(!d_keys || !d_vals) return fail(JFGPU_E_INVALID, "null argument");
   uint64_t c[CTR_COUNT];
@@ -441,6 +700,7 @@ int jfgpu_partition_ascii_dev(jfgpu_table* t, const char* d_bases, size_t n, uin
 
 int jfgpu_stats_compute(jfgpu_table* t, uint64_t lower, uint64_t upper, jfgpu_stats* out) {
   int rc = use(t); if(rc) return rc;
+  rc = part_flush(t); if(rc) return rc;
   if(!out) return fail(JFGPU_E_INVALID, "null out");
   uint64_t c[CTR_COUNT];
   rc = check_deferred(t, c); if(rc) return rc;
@@ -461,6 +721,7 @@ int jfgpu_stats_compute(jfgpu_table* t, uint64_t lower, uint64_t upper, jfgpu_st
 
 int jfgpu_histo(jfgpu_table* t, uint64_t base, uint64_t ceil, uint64_t inc, uint64_t* histo, uint64_t nb) {
   int rc = use(t); if(rc) return rc;
+  rc = part_flush(t); if(rc) return rc;
   if(!histo || !nb || !inc) return fail(JFGPU_E_INVALID, "bad histogram arguments");
   uint64_t c[CTR_COUNT];
   rc = check_deferred(t, c); if(rc) return rc;
@@ -478,6 +739,7 @@ int jfgpu_histo(jfgpu_table* t, uint64_t base, uint64_t ceil, uint64_t inc, uint
 
 int jfgpu_dump_begin(jfgpu_table* t, uint64_t lower, uint64_t upper, uint64_t* n_records, uint32_t* record_bytes) {
   int rc = use(t); if(rc) return rc;
+  rc = part_flush(t); if(rc) return rc;
   uint64_t c[CTR_COUNT];
   rc = check_deferred(t, c); if(rc) return rc;
   const uint64_t nt = n_tiles_of(t);
@@ -552,6 +814,31 @@ int jfgpu_dump_end(jfgpu_table* t) {
   return JFGPU_OK;
 }
 
+int jfgpu_reserve(jfgpu_table* t, uint64_t input_bytes) {
+  int rc = use(t); if(rc) return rc;
+  if(!t->part_ok || t->mode == MODE_DIRECT) return JFGPU_OK;
+  rc = part_flush(t); if(rc) return rc;
+  const uint32_t nb1 = 1u << t->pg.b1, nb2 = 1u << t->pg.b2;
+  // pending items (upper bound: one per input byte) + the P2 output of the same size + offsets
+  const size_t need = 2 * align_up(input_bytes * item_size(t), 256) + (n_tiles_of(t) + 1 + nb1) * sizeof(uint64_t) +
+                      (size_t)kMaxSeg * (align_up((nb1 + 1) * sizeof(uint64_t), 256) + 768) + ((size_t)1 << 20);
+  rc = ws_grow(t, need);
+  if(rc < 0) return fail(JFGPU_E_ALLOC, "not enough device memory to reserve the partition workspace");
+  if(rc) return rc;
+  if(!t->d_M1) { t->g1 = 2 * t->n_cu; HIP_TRY(hipMalloc((void**)&t->d_M1, (size_t)t->g1 * kMaxBuckets * sizeof(uint32_t))); }
+  if(t->pg.b2 && !t->d_M2) HIP_TRY(hipMalloc((void**)&t->d_M2, (size_t)nb1 * 32 * nb2 * sizeof(uint32_t)));
+  return JFGPU_OK;
+}
+
+int jfgpu_set_mode(jfgpu_table* t, int mode) {
+  int rc = use(t); if(rc) return rc;
+  if(mode < 0 || mode > 2) return fail(JFGPU_E_INVALID, "mode must be 0 (auto), 1 (direct) or 2 (partitioned)");
+  if(mode == MODE_PARTITIONED && !t->part_ok) return fail(JFGPU_E_UNSUPPORTED, "table geometry has no partitioned path");
+  rc = part_flush(t); if(rc) return rc;
+  t->mode = mode;
+  return JFGPU_OK;
+}
+
 int jfgpu_profile_enable(jfgpu_table* t, int on) {
   int rc = use(t); if(rc) return rc;
   t->prof_on = on != 0;
@@ -599,6 +886,8 @@ int jfgpu_gups(jfgpu_table* t, uint64_t n_updates, int mode, double* ups) {
   hipEvent_t a, b;
   HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
   const uint64_t mask = (1ull << t->g.lsize_l) - 1;
+  t->pristine = false;
+  HIP_TRY(hipMemsetAsync(t->dt.dirty, 1, (size_t)1 << (t->g.lsize_l - t->g.tile_bits), t->stream));
   const int grid = grid_for(t, (n_updates + kBlock - 1) / kBlock);
   hipLaunchKernelGGL(gups_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->dt.slots, mask, std::min<uint64_t>(n_updates, 1u << 20), mode, 1ull, d_sink);  // warm-up
   HIP_TRY(hipEventRecord(a, t->stream));

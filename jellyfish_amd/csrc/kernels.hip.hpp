@@ -33,7 +33,7 @@ constexpr int kBlock = 256;
 constexpr int kPerThread = kPerLane;           // positions per lane per tile (16)
 constexpr int kTilePos = kBlock * kPerThread;  // 4096 sequence positions per block iteration
 
-enum Counter : int { CTR_FULL = 0, CTR_MERS = 1, CTR_OVF_FULL = 2, CTR_OVF_USED = 3, CTR_MISROUTED = 4, CTR_COUNT = 8 };
+enum Counter : int { CTR_FULL = 0, CTR_MERS = 1, CTR_OVF_FULL = 2, CTR_OVF_USED = 3, CTR_MISROUTED = 4, CTR_DIRECT = 5, CTR_COUNT = 8 };
 
 struct DevTable {
   TableGeom g;
@@ -45,6 +45,7 @@ struct DevTable {
   uint64_t ovf_mask;          // capacity - 1
   uint64_t* counters;         // [CTR_COUNT]
   uint32_t max_probe;         // last probe index tried before declaring the tile full
+  uint8_t* dirty;             // one byte per tile: something was ever inserted (tile_insert may skip reading clean tiles)
 };
 
 // ---- overflow side table ----------------------------------------------------
@@ -98,6 +99,7 @@ __device__ inline bool table_add(const DevTable& T, const uint64_t* fwd_lds, uin
     atomicAdd((unsigned long long*)&T.counters[CTR_MISROUTED], 1ull);
     return false;
   }
+  { uint8_t* d = &T.dirty[a.tile_base >> g.tile_bits]; if(!*d) *d = 1; }
   const uint64_t tag = make_tag(g, key, a.idx0);
   const uint64_t low = g.occ_bit | tag;
   const uint64_t add = cnt << (g.tag_bits + 1);
@@ -134,6 +136,7 @@ __device__ inline bool table_add_val(const DevTable& T, const uint64_t* fwd_lds,
     atomicAdd((unsigned long long*)&T.counters[CTR_MISROUTED], 1ull);
     return false;
   }
+  { uint8_t* d = &T.dirty[a.tile_base >> g.tile_bits]; if(!*d) *d = 1; }
   const uint64_t tag = make_tag(g, key, a.idx0);
   const uint64_t low = g.occ_bit | tag;
   const uint64_t add = lowpart << (g.tag_bits + 1);

@@ -1,0 +1,407 @@
+// jellyfish_amd/csrc/kernels_part.hip.hpp -- the partitioned insert path (gfx950).
+//
+// Why: device-scope 64-bit atomics on MI355X retire at ~21 G/s whatever the table size
+// (profiles/r01_gups_probe.txt), so the fused kernel in kernels.hip.hpp cannot pass ~20 G
+// k-mers/s.  Sequential HBM traffic is two orders of magnitude cheaper per byte, so large
+// batches are inserted WITHOUT global atomics:
+//
+//   P1  encode+canonical+hash, then radix-partition the hashed k-mers by the upper b1 bits of
+//       their table position into "items" (p1_kernel, count pass + scatter pass)
+//   P2  (tables with more than 2^11 tiles) partition one P1 bucket by the next b2 bits so that
+//       one sub-bucket = one 64 KiB tile (p2_kernel, count + scatter)
+//   T   one workgroup owns one tile: tile -> LDS, LDS ds_cmpst/ds_add inserts (duplicates
+//       aggregate here for free), LDS -> tile (tile_insert_kernel)
+//
+// The table format is untouched (same slots, same tile-local triangular probing as
+// large_hash_array.hpp:509-597 restated in kernels.hip.hpp::table_add), so lookups, stats and
+// the sorted dump do not care which path inserted a key; results are bit-identical.
+//
+// item = (tile_rest << tag_bits) | tag : everything about a k-mer except the P1 bucket.
+//   tag       = (idx0 << rem_bits) | (key >> lsize_g)   exactly the slot's tag field
+//   tile_rest = the b2 tile-index bits P2 still has to resolve
+// 32-bit items whenever lsize_l - b1 + rem_bits <= 32 (k=21 at 2^34 slots: 24 + 8 = 32).
+//
+// No global atomics in the passes either: the count pass leaves a [block][bucket] histogram
+// matrix, a scan turns it into each block's private write cursor per bucket, and the scatter
+// pass replays the same block->chunk assignment.
+#pragma once
+#include "kernels.hip.hpp"
+
+namespace jfgpu {
+
+constexpr int kPBlock = 1024;                 // threads per block in the partition passes
+constexpr int kPTilePos = kPBlock * kPerLane; // 16384 sequence positions per block iteration
+constexpr int kMaxBuckets = 2048;             // per pass
+constexpr int kMaxSeg = 64;                   // pending batches per flush
+
+struct PartGeom {
+  uint32_t b1, b2;          // bits consumed by P1 / P2 (b2 == 0: P1 buckets are tiles)
+  uint32_t item_bits;       // lsize_l - b1 + rem_bits
+  uint32_t rest_shift;      // lsize_l - b1: low local-position bits kept in the item
+};
+
+// Pending batches: batch s holds items grouped by P1 bucket, off[s][j] .. off[s][j+1].
+struct SegList {
+  const void* items[kMaxSeg];
+  const uint64_t* off[kMaxSeg];
+  uint32_t n;
+};
+
+template <typename ITEM>
+__device__ inline ITEM make_item(const TableGeom& g, const PartGeom& P, uint64_t key, uint64_t local) {
+  const uint64_t rest = local & ((1ull << P.rest_shift) - 1);
+  const uint64_t rem = g.lsize_g >= 64 ? 0 : (key >> g.lsize_g);
+  return (ITEM)((rest << g.rem_bits) | rem);
+}
+
+// ---- P1 ------------------------------------------------------------------------------
+// SCATTER == false: histogram of this block's k-mers per bucket -> M[blockIdx][*]
+// SCATTER == true : replay, items written at bucket_off[j] + M[blockIdx][j] + running count
+// FROM_KEYS       : input is an array of encoded k-mers (hash_counter::add batches / the
+//                   receive side of the multi-GPU exchange) instead of a contract buffer
+// Runs of >= 2 identical consecutive k-mers in one lane (homopolymers, tandem repeats) bypass
+// the partition and go straight to the table with one atomic per run (scatter pass only).
+template <typename ITEM, bool SCATTER, bool FROM_KEYS, bool RETURNING>
+__global__ __launch_bounds__(kPBlock) void p1_kernel(DevTable T, PartGeom P, const uint8_t* __restrict__ base, int64_t lo,
+                                                     int64_t hi, uint32_t* __restrict__ M,
+                                                     const uint64_t* __restrict__ bucket_off, ITEM* __restrict__ out) {
+  __shared__ uint64_t s_fwd[8 * 256];
+  __shared__ uint32_t s_codes[kPBlock + 2];
+  __shared__ uint32_t s_inv[kPBlock + 2];
+  __shared__ unsigned long long s_cur[kMaxBuckets];
+  const uint32_t nb = 1u << P.b1;
+  load_tables_lds(s_fwd, T.fwd_tbl, T.g.nbytes);
+  for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x)
+    s_cur[j] = SCATTER ? (bucket_off[j] + M[(size_t)blockIdx.x * nb + j]) : 0ull;
+  uint32_t my_mers = 0, my_direct = 0;
+  const uint32_t bshift = T.g.lsize_l - P.b1;
+
+  auto emit = [&](uint64_t key) {
+    const uint64_t pos = hash_tables(s_fwd, key, T.g.nbytes);
+    const uint64_t local = pos & T.g.local_mask;
+    if((uint32_t)(pos >> T.g.lsize_l) != T.g.shard_id) {   // not ours: never silently inserted
+      if(SCATTER) atomicAdd((unsigned long long*)&T.counters[CTR_MISROUTED], 1ull);
+      return;
+    }
+    const uint32_t b = P.b1 ? (uint32_t)(local >> bshift) : 0u;
+    const unsigned long long at = atomicAdd(&s_cur[b], 1ull);
+    if(SCATTER) out[at] = make_item<ITEM>(T.g, P, key, local);
+  };
+
+  if(FROM_KEYS) {
+    const uint64_t* keys = reinterpret_cast<const uint64_t*>(base);
+    const int64_t n = hi;
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t b0 = (int64_t)blockIdx.x * per, b1e = b0 + per < n ? b0 + per : n;
+    __syncthreads();
+    for(int64_t i = b0 + threadIdx.x; i < b1e; i += blockDim.x) { emit(keys[i] & T.g.key_mask); ++my_mers; }
+  } else {
+    const int64_t n_tiles = (hi + kPTilePos - 1) / kPTilePos;
+    for(int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+      __syncthreads();
+      const LaneWords L = stage_tile(base, tile * kPTilePos, lo, hi, s_codes, s_inv);
+      uint64_t prev = 0; uint32_t run = 0;
+      auto flush_run = [&]() {
+        if(run == 1) emit(prev);
+        else if(run > 1) {
+          if(SCATTER) { table_add<RETURNING>(T, s_fwd, prev, run); ++my_direct; }
+        }
+      };
+      for_each_kmer(T.g, L, [&](int, uint64_t key) {
+        ++my_mers;
+        if(run && key == prev) { ++run; return; }
+        flush_run();
+        prev = key; run = 1;
+      });
+      flush_run();
+    }
+  }
+  __syncthreads();
+  if(!SCATTER) {
+    for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) M[(size_t)blockIdx.x * nb + j] = (uint32_t)s_cur[j];
+    uint64_t w = my_mers;
+    for(int o = 32; o > 0; o >>= 1) w += __shfl_down(w, o, 64);
+    if((threadIdx.x & 63) == 0 && w) atomicAdd((unsigned long long*)&T.counters[CTR_MERS], (unsigned long long)w);
+  } else if(my_direct) {
+    atomicAdd((unsigned long long*)&T.counters[CTR_DIRECT], (unsigned long long)my_direct);
+  }
+}
+
+// ---- histogram matrix -> private cursors ------------------------------------------------
+// One block per group (P1: the single group; P2: one group per P1 bucket).  Group q owns the
+// sub-matrix M[q][nblk][nb] (row = block).  Every bucket column becomes its exclusive prefix
+// over the blocks, and off[q * nb + j] = base[q] + exclusive prefix of the column totals, so
+// `off` is one global offset array with n_groups * nb + 1 entries (the last written by the
+// last group).  base == nullptr means 0.
+__global__ __launch_bounds__(1024) void scan_matrix_kernel(uint32_t* __restrict__ M, uint32_t nblk, uint32_t nb,
+                                                           const uint64_t* __restrict__ base, uint64_t* __restrict__ off) {
+  __shared__ unsigned long long s_tot[kMaxBuckets];
+  __shared__ unsigned long long s_wave[16];
+  const uint32_t q = blockIdx.x;
+  uint32_t* Mq = M + (size_t)q * nblk * nb;
+  for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) {
+    uint64_t run = 0;
+#pragma unroll 8
+    for(uint32_t b = 0; b < nblk; ++b) {
+      const uint32_t v = Mq[(size_t)b * nb + j];
+      Mq[(size_t)b * nb + j] = (uint32_t)run;
+      run += v;
+    }
+    s_tot[j] = run;
+  }
+  for(uint32_t j = nb + threadIdx.x; j < kMaxBuckets; j += blockDim.x) s_tot[j] = 0;
+  __syncthreads();
+  // exclusive scan of s_tot[0 .. 2048): two adjacent entries per thread, wave scan, then wave totals
+  const uint32_t t = threadIdx.x;
+  const unsigned long long a = s_tot[2 * t], b = s_tot[2 * t + 1];
+  unsigned long long incl = a + b;
+  for(int o = 1; o < 64; o <<= 1) {
+    const unsigned long long up = __shfl_up(incl, o, 64);
+    if((int)(t & 63) >= o) incl += up;
+  }
+  if((t & 63) == 63) s_wave[t >> 6] = incl;
+  __syncthreads();
+  unsigned long long wbase = 0;
+  for(uint32_t w = 0; w < (t >> 6); ++w) wbase += s_wave[w];
+  const unsigned long long excl = wbase + incl - (a + b);
+  const unsigned long long g0 = base ? base[q] : 0ull;
+  if(2 * t < nb) off[(size_t)q * nb + 2 * t] = g0 + excl;
+  if(2 * t + 1 < nb) off[(size_t)q * nb + 2 * t + 1] = g0 + excl + a;
+  if(q == gridDim.x - 1 && t == 1023) off[(size_t)gridDim.x * nb] = g0 + excl + a + b;
+}
+
+// ---- P2: every P1 bucket -> its tiles, one launch -------------------------------------------
+// grid = (G2, 2^b1): blockIdx.y is the P1 bucket, blockIdx.x owns a contiguous slice of that
+// bucket's items (the concatenation over pending batches of
+// items[s][off[s][bucket] .. off[s][bucket+1]); same slice in both passes).
+// M is [bucket][G2][2^b2]; goff the global per-tile offsets produced by scan_matrix_kernel.
+template <typename ITEM, bool SCATTER>
+__global__ __launch_bounds__(kPBlock) void p2_kernel(PartGeom P, uint32_t tag_bits, SegList S, uint32_t* __restrict__ M,
+                                                     const uint64_t* __restrict__ goff, ITEM* __restrict__ out) {
+  __shared__ unsigned long long s_cur[kMaxBuckets];
+  __shared__ unsigned long long s_seg_lo[kMaxSeg + 1];
+  const uint32_t nb = 1u << P.b2;
+  const uint32_t bucket = blockIdx.y;
+  uint32_t* Mq = M + ((size_t)bucket * gridDim.x + blockIdx.x) * nb;
+  for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x)
+    s_cur[j] = SCATTER ? (goff[(size_t)bucket * nb + j] + Mq[j]) : 0ull;
+  if(threadIdx.x == 0) {
+    unsigned long long c = 0;
+    for(uint32_t s = 0; s < S.n; ++s) { s_seg_lo[s] = c; c += S.off[s][bucket + 1] - S.off[s][bucket]; }
+    s_seg_lo[S.n] = c;
+  }
+  __syncthreads();
+  const uint64_t n = s_seg_lo[S.n];
+  const uint64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const uint64_t my_lo = (uint64_t)blockIdx.x * per, my_hi = my_lo + per < n ? my_lo + per : n;
+  for(uint32_t s = 0; s < S.n; ++s) {
+    const uint64_t slo = s_seg_lo[s], shi = s_seg_lo[s + 1];
+    const uint64_t a = my_lo > slo ? my_lo : slo, b = my_hi < shi ? my_hi : shi;
+    if(a >= b) continue;
+    const ITEM* src = reinterpret_cast<const ITEM*>(S.items[s]) + S.off[s][bucket] - slo;
+    for(uint64_t v = a + threadIdx.x; v < b; v += blockDim.x) {
+      const ITEM it = src[v];
+      const uint32_t d = (uint32_t)((uint64_t)it >> tag_bits) & (nb - 1);
+      const unsigned long long at = atomicAdd(&s_cur[d], 1ull);
+      if(SCATTER) out[at] = it;
+    }
+  }
+  if(!SCATTER) {
+    __syncthreads();
+    for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) Mq[j] = (uint32_t)s_cur[j];
+  }
+}
+
+// Block-wide exclusive scan of nb (<= 2048) uint32 counters in LDS: in[] -> out[].
+// 1024 threads, two adjacent entries per thread, wave prefix by __shfl_up, 16 wave totals.
+__device__ inline void block_excl_scan_2048(const uint32_t* in, uint32_t* out, uint32_t nb, uint32_t* s_wave /*[16]*/) {
+  const uint32_t t = threadIdx.x;
+  const uint32_t a = 2 * t < nb ? in[2 * t] : 0u, b = 2 * t + 1 < nb ? in[2 * t + 1] : 0u;
+  uint32_t incl = a + b;
+  for(int o = 1; o < 64; o <<= 1) {
+    const uint32_t up = __shfl_up(incl, o, 64);
+    if((int)(t & 63) >= o) incl += up;
+  }
+  if((t & 63) == 63) s_wave[t >> 6] = incl;
+  __syncthreads();
+  uint32_t wbase = 0;
+  for(uint32_t w = 0; w < (t >> 6); ++w) wbase += s_wave[w];
+  const uint32_t excl = wbase + incl - (a + b);
+  if(2 * t < nb) out[2 * t] = excl;
+  if(2 * t + 1 < nb) out[2 * t + 1] = excl + a;
+}
+
+// P2 scatter with write combining: scattered 4-byte stores top out at ~50-100 G items/s on
+// MI355X (one L2 transaction each), so every block first counting-sorts a chunk of kChunk
+// items by destination bucket in LDS and then writes whole runs (consecutive lanes ->
+// consecutive addresses).  Same block->slice assignment and per-(block, bucket) cursors as
+// p2_kernel<.., false> counted, so positions are exact and no global atomic is needed.
+template <typename ITEM, int PER_THREAD>
+__global__ __launch_bounds__(kPBlock) void p2_scatter_sorted_kernel(PartGeom P, uint32_t tag_bits, SegList S,
+                                                                    const uint32_t* __restrict__ M,
+                                                                    const uint64_t* __restrict__ goff, ITEM* __restrict__ out) {
+  constexpr int kChunk = kPBlock * PER_THREAD;
+  extern __shared__ __align__(16) unsigned char s_dyn[];
+  ITEM* s_item = reinterpret_cast<ITEM*>(s_dyn);                       // [kChunk]
+  __shared__ unsigned long long s_gcur[kMaxBuckets];
+  __shared__ uint32_t s_hist[kMaxBuckets];
+  __shared__ uint32_t s_lstart[kMaxBuckets];
+  __shared__ uint32_t s_wave[16];
+  __shared__ unsigned long long s_seg_lo[kMaxSeg + 1];
+  const uint32_t nb = 1u << P.b2;
+  const uint32_t bucket = blockIdx.y;
+  const uint32_t* Mq = M + ((size_t)bucket * gridDim.x + blockIdx.x) * nb;
+  for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) s_gcur[j] = goff[(size_t)bucket * nb + j] + Mq[j];
+  if(threadIdx.x == 0) {
+    unsigned long long c = 0;
+    for(uint32_t s = 0; s < S.n; ++s) { s_seg_lo[s] = c; c += S.off[s][bucket + 1] - S.off[s][bucket]; }
+    s_seg_lo[S.n] = c;
+  }
+  __syncthreads();
+  const uint64_t n = s_seg_lo[S.n];
+  const uint64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const uint64_t my_lo = (uint64_t)blockIdx.x * per, my_hi = my_lo + per < n ? my_lo + per : n;
+  for(uint64_t c0 = my_lo; c0 < my_hi; c0 += kChunk) {
+    const uint64_t c1 = c0 + kChunk < my_hi ? c0 + kChunk : my_hi;
+    for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) s_hist[j] = 0;
+    __syncthreads();
+    ITEM it[PER_THREAD]; uint32_t dr[PER_THREAD];   // digit << 16 | rank is not enough (rank < 16384, digit < 2048): 11 + 14 bits
+    uint32_t s = 0;   // v grows with r: the batch index only moves forward
+#pragma unroll
+    for(int r = 0; r < PER_THREAD; ++r) {
+      const uint64_t v = c0 + (uint64_t)r * kPBlock + threadIdx.x;
+      dr[r] = 0xFFFFFFFFu;
+      if(v < c1) {
+        // locate v in the virtual concatenation of the pending batches
+        while(s + 1 < S.n && v >= s_seg_lo[s + 1]) ++s;
+        it[r] = reinterpret_cast<const ITEM*>(S.items[s])[S.off[s][bucket] + (v - s_seg_lo[s])];
+      }
+    }
+#pragma unroll
+    for(int r = 0; r < PER_THREAD; ++r) {
+      const uint64_t v = c0 + (uint64_t)r * kPBlock + threadIdx.x;
+      if(v < c1) {
+        const uint32_t d = (uint32_t)((uint64_t)it[r] >> tag_bits) & (nb - 1);
+        dr[r] = (d << 16) | atomicAdd(&s_hist[d], 1u);
+      }
+    }
+    __syncthreads();
+    block_excl_scan_2048(s_hist, s_lstart, nb, s_wave);
+    __syncthreads();
+#pragma unroll
+    for(int r = 0; r < PER_THREAD; ++r)
+      if(dr[r] != 0xFFFFFFFFu) s_item[s_lstart[dr[r] >> 16] + (dr[r] & 0xFFFFu)] = it[r];
+    __syncthreads();
+    const uint32_t cn = (uint32_t)(c1 - c0);
+    for(uint32_t i = threadIdx.x; i < cn; i += blockDim.x) {
+      const ITEM v = s_item[i];
+      const uint32_t d = (uint32_t)((uint64_t)v >> tag_bits) & (nb - 1);
+      out[s_gcur[d] + (i - s_lstart[d])] = v;
+    }
+    __syncthreads();
+    for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) s_gcur[j] += s_hist[j];
+    // next iteration zeroes s_hist after this barrier-protected update
+    __syncthreads();
+  }
+}
+
+// ---- T: one workgroup owns one tile in LDS --------------------------------------------------
+// Tile index = tile0 + t; its items are, for each segment s, items[s][off[s][t] .. off[s][t+1]).
+// LOAD == false: the whole table is known to be all-zero (fresh / cleared): never read tiles.
+// LOAD == true : read a tile only if its dirty byte says something was ever inserted into it.
+// Same claim-or-increment protocol as table_add, on LDS words (ds_cmpst_rtn_b64 / ds_add_u64).
+template <typename ITEM, bool RETURNING, bool LOAD>
+__global__ __launch_bounds__(kPBlock) void tile_insert_kernel(DevTable T, SegList S, uint64_t tile0, uint32_t n_tiles) {
+  extern __shared__ __align__(16) unsigned char s_raw[];
+  unsigned long long* s_tile = reinterpret_cast<unsigned long long*>(s_raw);
+  const TableGeom& g = T.g;
+  const uint32_t tsz = 1u << g.tile_bits, tmask = tsz - 1;
+  const uint64_t tagmask = g.occ_bit - 1;
+  for(uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    // every lane reads the (few) offsets itself: one broadcast line, no extra barrier
+    uint64_t n_items = 0;
+    for(uint32_t s = 0; s < S.n; ++s) n_items += S.off[s][t + 1] - S.off[s][t];
+    if(n_items == 0) continue;                                   // block-uniform
+    uint64_t* gt = T.slots + ((tile0 + t) << g.tile_bits);
+    const bool load = LOAD && T.dirty[tile0 + t] != 0;              // block-uniform
+    for(uint32_t i = threadIdx.x * 2; i < tsz; i += blockDim.x * 2) {   // tile -> LDS, 16 B per lane per step
+      ulonglong2 v = make_ulonglong2(0ull, 0ull);
+      if(load) v = *reinterpret_cast<const ulonglong2*>(gt + i);
+      *reinterpret_cast<ulonglong2*>(s_tile + i) = v;
+    }
+    __syncthreads();
+    for(uint32_t s = 0; s < S.n; ++s) {
+      const uint64_t a = S.off[s][t], b = S.off[s][t + 1];
+      const ITEM* src = reinterpret_cast<const ITEM*>(S.items[s]);
+      for(uint64_t v = a + threadIdx.x; v < b; v += blockDim.x) {
+        const uint64_t tag = (uint64_t)src[v] & tagmask;
+        const uint32_t idx0 = (uint32_t)(tag >> g.rem_bits);
+        const uint64_t low = g.occ_bit | tag;
+        const uint64_t neww = g.inc | low;
+        bool done = false;
+        for(uint32_t p = 0; p <= T.max_probe; ++p) {
+          const uint32_t slot = probe_slot(idx0, p, tmask);
+          const unsigned long long old = atomicCAS(&s_tile[slot], 0ull, (unsigned long long)neww);
+          if(old == 0ull) { done = true; break; }
+          if((old & g.low_mask) == low) {
+            if(RETURNING) {
+              const unsigned long long prev = atomicAdd(&s_tile[slot], (unsigned long long)g.inc);
+              if((prev >> (g.tag_bits + 1)) + 1 > g.cnt_max) ovf_add(T, ((tile0 + t) << g.tile_bits) + slot, 1);
+            } else {
+              atomicAdd(&s_tile[slot], (unsigned long long)g.inc);
+            }
+            done = true; break;
+          }
+        }
+        if(!done) atomicAdd((unsigned long long*)&T.counters[CTR_FULL], 1ull);
+      }
+    }
+    __syncthreads();
+    for(uint32_t i = threadIdx.x * 2; i < tsz; i += blockDim.x * 2)
+      *reinterpret_cast<ulonglong2*>(gt + i) = *reinterpret_cast<const ulonglong2*>(s_tile + i);
+    if(threadIdx.x == 0) T.dirty[tile0 + t] = 1;
+    __syncthreads();
+  }
+}
+
+// Fallback when a flush holds too few items to be worth streaming the tiles: insert the
+// pending items with global atomics (same protocol as table_add, tag and tile precomputed).
+template <typename ITEM, bool RETURNING>
+__global__ __launch_bounds__(kBlock) void items_direct_kernel(DevTable T, PartGeom P, const ITEM* __restrict__ items,
+                                                              const uint64_t* __restrict__ off) {
+  const TableGeom& g = T.g;
+  const uint32_t nb = 1u << P.b1, tmask = (uint32_t)g.tile_mask;
+  const uint64_t tagmask = g.occ_bit - 1;
+  const uint64_t n = off[nb];
+  for(uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x) {
+    // bucket of item v: largest j with off[j] <= v
+    uint32_t lo = 0, hi = nb;
+    while(hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if(off[mid] <= v) lo = mid; else hi = mid; }
+    const uint64_t it = (uint64_t)items[v];
+    const uint64_t tag = it & tagmask;
+    const uint64_t tile = ((uint64_t)lo << P.b2) | ((it >> g.tag_bits) & ((1ull << P.b2) - 1));
+    const uint64_t tile_base = tile << g.tile_bits;
+    const uint32_t idx0 = (uint32_t)(tag >> g.rem_bits);
+    { uint8_t* d = &T.dirty[tile]; if(!*d) *d = 1; }
+    const uint64_t low = g.occ_bit | tag, neww = g.inc | low;
+    bool done = false;
+    for(uint32_t p = 0; p <= T.max_probe; ++p) {
+      const uint64_t slot = tile_base + probe_slot(idx0, p, tmask);
+      unsigned long long* addr = (unsigned long long*)&T.slots[slot];
+      const unsigned long long old = atomicCAS(addr, 0ull, (unsigned long long)neww);
+      if(old == 0ull) { done = true; break; }
+      if((old & g.low_mask) == low) {
+        if(RETURNING) {
+          const unsigned long long prev = atomicAdd(addr, (unsigned long long)g.inc);
+          if((prev >> (g.tag_bits + 1)) + 1 > g.cnt_max) ovf_add(T, slot, 1);
+        } else {
+          __hip_atomic_fetch_add(addr, (unsigned long long)g.inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        done = true; break;
+      }
+    }
+    if(!done) atomicAdd((unsigned long long*)&T.counters[CTR_FULL], 1ull);
+  }
+}
+
+}  // namespace jfgpu

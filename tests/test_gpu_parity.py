@@ -316,3 +316,98 @@ def test_large_run_invariants(gpu):
         assert (s2.distinct, s2.total, s2.unique) == (s1.distinct, 2 * s1.total, 0)
         assert s2.max_count == 2 * s1.max_count
         t.free(d)
+
+
+# ---- both insert strategies must give bit-identical tables --------------------------------------
+MODES = {"direct": 1, "partitioned": 2}
+
+
+@pytest.mark.parametrize("mode", ["direct", "partitioned"])
+@pytest.mark.parametrize("k,canonical,n,alphabet,size", [
+    (21, True, 60000, "ACGT", 1 << 17),        # 16 tiles, single-level partition (b1 = 4)
+    (21, True, 200000, "ACGTN", 1 << 25),      # 4096 tiles: two-level partition, 32-bit items
+    (31, True, 200000, "ACGT", 1 << 28),       # two-level, 64-bit items, 16-bit count field
+    (16, True, 250000, "AT", 1 << 20),         # duplicates: LDS aggregation + run-length bypass
+    (21, False, 100000, "A", 1 << 16),         # one k-mer 99980 times: all through the run bypass
+    (13, True, 400000, "ACGT", 1 << 26),       # 4^13 = 2^26: identity matrix, rem_bits = 0
+])
+def test_modes_match_oracle(gpu, mode, k, canonical, n, alphabet, size):
+    rng = random.Random(k * 7 + n)
+    seq = rnd_seq(rng, n, alphabet)
+    exp = oracle_map(seq, k, canonical)
+    with gpu.Table(k, size, canonical=canonical) as t:
+        t.set_mode(MODES[mode])
+        d = t.malloc(len(seq) + 64)
+        t.h2d(d + 3, np.frombuffer(seq, dtype=np.uint8))
+        third = len(seq) // 3
+        # three device batches with k-1 overlap (every window exactly once), applied at sync
+        t.count_ascii_dev(d + 3, third)
+        t.count_ascii_dev(d + 3 + third - (k - 1), third + (k - 1))
+        t.count_ascii_dev(d + 3 + 2 * third - (k - 1), len(seq) - 2 * third + (k - 1))
+        t.sync()
+        assert table_map(gpu, t) == exp
+        st = t.stats()
+        assert (st.distinct, st.total, st.mers_fed) == (len(exp), sum(exp.values()), sum(exp.values()))
+        # a second round on top of a non-empty table (tile_insert must LOAD), plus encoded keys
+        t.count_ascii_dev(d + 3, len(seq))
+        keys = np.array(list(exp.keys())[:5000], dtype=np.uint64)
+        t.add_keys(keys, 1)
+        vals, found = t.lookup(keys)            # lookup applies whatever is still pending
+        assert found.all() and vals.tolist() == [2 * exp[x] + 1 for x in keys.tolist()]
+        t.sync()
+        got = table_map(gpu, t, check_order=False)
+        assert got == {a: 2 * c + (1 if i < 5000 else 0) for i, (a, c) in enumerate(exp.items())}
+        t.free(d)
+
+
+def test_partitioned_host_buffers_and_auto_fallback(gpu):
+    """Host-buffer entry through the staged path, and AUTO's fallback to global atomics when a
+    flush holds too few items per tile to be worth streaming the table."""
+    rng = random.Random(29)
+    k = 21
+    seq = rnd_seq(rng, 2_500_000)
+    exp = oracle_map(seq, k, True)
+    for size, mode in ((1 << 22, 2), (1 << 30, 0), (1 << 23, 0)):
+        with gpu.Table(k, size) as t:
+            t.set_mode(mode)
+            t.count_ascii(seq)
+            t.sync()
+            st = t.stats()
+            assert (st.distinct, st.total) == (len(exp), sum(exp.values())), (size, mode)
+            keys = np.array(list(exp.keys())[:20000], dtype=np.uint64)
+            vals, found = t.lookup(keys)
+            assert found.all() and vals.tolist() == [exp[x] for x in keys.tolist()]
+
+
+def test_partitioned_hash_full(gpu):
+    rng = random.Random(31)
+    seq = rnd_seq(rng, 200000)
+    with gpu.Table(21, 1 << 16) as t:
+        t.set_mode(2)
+        t.count_ascii(seq)
+        with pytest.raises(gpu.JfgpuError) as e:
+            t.sync()
+        assert e.value.code == gpu.E_FULL
+
+
+def test_partitioned_large_run_invariants(gpu):
+    """300 Mbp through the partitioned path into a 2^29 table: sum of counts == windows, the
+    table equals the direct path's table slot for slot as a {key -> count} map (dump compare)."""
+    k, L, n_reads = 21, 150, 2_000_000
+    dumps = []
+    for mode in (1, 2):
+        with gpu.Table(k, 1 << 29) as t:
+            t.set_mode(mode)
+            nbytes = n_reads * (L + 1)
+            d = t.malloc(nbytes + 16)
+            t.gen_reads_dev(d, 0, n_reads, L, 7)
+            half = (n_reads // 2) * (L + 1)
+            t.count_ascii_dev(d, half)
+            t.count_ascii_dev(d + half, nbytes - half)
+            t.sync()
+            s = t.stats()
+            assert s.total == n_reads * (L - k + 1) == s.mers_fed
+            base, inc, h = t.histo(1, 100, 1)
+            dumps.append((s.distinct, s.unique, s.max_count, h.tolist()))
+            t.free(d)
+    assert dumps[0] == dumps[1]
