@@ -278,8 +278,13 @@ int part_ingest(jfgpu_table* t, const uint8_t* base, int64_t lo, int64_t hi, boo
     if(t->item32) launch_p1<uint32_t>(t, false, from_keys, base, lo, hi, b.off, b.items);
     else          launch_p1<uint64_t>(t, false, from_keys, base, lo, hi, b.off, b.items);
     hipLaunchKernelGGL(scan_matrix_kernel, dim3(1), dim3(1024), 0, t->stream, t->d_M1, (uint32_t)t->g1, nb, (const uint64_t*)nullptr, b.off);
-    if(t->item32) launch_p1<uint32_t>(t, true, from_keys, base, lo, hi, b.off, b.items);
-    else          launch_p1<uint64_t>(t, true, from_keys, base, lo, hi, b.off, b.items);
+    if(t->item32 && !from_keys) {     // write-combining scatter (whole runs per bucket)
+      const size_t lds = (size_t)kPTilePos * 6;
+      if(t->returning) hipLaunchKernelGGL(p1_scatter_sorted_kernel<true>, dim3(t->g1), dim3(kPBlock), lds, t->stream, t->dt, t->pg, base, lo, hi, (const uint32_t*)t->d_M1, (const uint64_t*)b.off, (uint32_t*)b.items);
+      else             hipLaunchKernelGGL(p1_scatter_sorted_kernel<false>, dim3(t->g1), dim3(kPBlock), lds, t->stream, t->dt, t->pg, base, lo, hi, (const uint32_t*)t->d_M1, (const uint64_t*)b.off, (uint32_t*)b.items);
+    }
+    else if(t->item32) launch_p1<uint32_t>(t, true, from_keys, base, lo, hi, b.off, b.items);
+    else               launch_p1<uint64_t>(t, true, from_keys, base, lo, hi, b.off, b.items);
   }
   hipError_t e = hipGetLastError();
   t->pending.push_back(b);
@@ -490,6 +495,8 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     TATTR(uint32_t, true, true); TATTR(uint32_t, true, false); TATTR(uint32_t, false, true); TATTR(uint32_t, false, false);
     TATTR(uint64_t, true, true); TATTR(uint64_t, true, false); TATTR(uint64_t, false, true); TATTR(uint64_t, false, false);
 #undef TATTR
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_sorted_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_sorted_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint32_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * 16 * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint64_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * 8 * 8));
   }

@@ -231,6 +231,78 @@ __device__ inline void block_excl_scan_2048(const uint32_t* in, uint32_t* out, u
   if(2 * t + 1 < nb) out[2 * t + 1] = excl + a;
 }
 
+// P1 scatter with write combining (32-bit items, contract-buffer input).  One block iteration =
+// 16384 sequence positions = one chunk: every lane keeps its <= 17 emitted items in registers,
+// the block counting-sorts them by bucket in LDS and writes whole runs.  Same tile->block
+// assignment as the count pass, so the per-(block, bucket) cursors derived from M are exact.
+template <bool RETURNING>
+__global__ __launch_bounds__(kPBlock) void p1_scatter_sorted_kernel(DevTable T, PartGeom P, const uint8_t* __restrict__ base,
+                                                                    int64_t lo, int64_t hi, const uint32_t* __restrict__ M,
+                                                                    const uint64_t* __restrict__ bucket_off,
+                                                                    uint32_t* __restrict__ out) {
+  extern __shared__ __align__(16) unsigned char s_dyn[];
+  uint32_t* s_item = reinterpret_cast<uint32_t*>(s_dyn);                          // [kPTilePos]
+  uint16_t* s_bkt = reinterpret_cast<uint16_t*>(s_dyn + (size_t)kPTilePos * 4);   // [kPTilePos]
+  __shared__ uint64_t s_fwd[8 * 256];
+  __shared__ uint32_t s_codes[kPBlock + 2];
+  __shared__ uint32_t s_inv[kPBlock + 2];
+  __shared__ unsigned long long s_gcur[kMaxBuckets];
+  __shared__ uint32_t s_hist[kMaxBuckets];
+  __shared__ uint32_t s_lstart[kMaxBuckets];
+  __shared__ uint32_t s_wave[16];
+  const uint32_t nb = 1u << P.b1;
+  load_tables_lds(s_fwd, T.fwd_tbl, T.g.nbytes);
+  for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) s_gcur[j] = bucket_off[j] + M[(size_t)blockIdx.x * nb + j];
+  const uint32_t bshift = T.g.lsize_l - P.b1;
+  uint32_t my_direct = 0;
+  const int64_t n_tiles = (hi + kPTilePos - 1) / kPTilePos;
+  for(int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    __syncthreads();
+    for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) s_hist[j] = 0;
+    const LaneWords L = stage_tile(base, tile * kPTilePos, lo, hi, s_codes, s_inv);   // barrier inside
+    uint32_t it[kPerLane + 1], dr[kPerLane + 1];
+#pragma unroll
+    for(int e = 0; e <= kPerLane; ++e) dr[e] = 0xFFFFFFFFu;
+    uint64_t prev = 0; uint32_t run = 0;
+    auto flush_run = [&](int site) {
+      if(run == 1) {
+        const uint64_t pos = hash_tables(s_fwd, prev, T.g.nbytes);
+        const uint64_t local = pos & T.g.local_mask;
+        const uint32_t b = P.b1 ? (uint32_t)(local >> bshift) : 0u;
+        it[site] = make_item<uint32_t>(T.g, P, prev, local);
+        dr[site] = (b << 16) | atomicAdd(&s_hist[b], 1u);
+      } else if(run > 1) {
+        table_add<RETURNING>(T, s_fwd, prev, run);
+        ++my_direct;
+      }
+    };
+    for_each_kmer(T.g, L, [&](int j, uint64_t key) {
+      if(run && key == prev) { ++run; return; }
+      flush_run(j);
+      prev = key; run = 1;
+    });
+    flush_run(kPerLane);
+    __syncthreads();
+    block_excl_scan_2048(s_hist, s_lstart, nb, s_wave);
+    __syncthreads();
+#pragma unroll
+    for(int e = 0; e <= kPerLane; ++e)
+      if(dr[e] != 0xFFFFFFFFu) {
+        const uint32_t at = s_lstart[dr[e] >> 16] + (dr[e] & 0xFFFFu);
+        s_item[at] = it[e]; s_bkt[at] = (uint16_t)(dr[e] >> 16);
+      }
+    __syncthreads();
+    const uint32_t cn = s_lstart[nb - 1] + s_hist[nb - 1];
+    for(uint32_t i = threadIdx.x; i < cn; i += blockDim.x) {
+      const uint32_t b = s_bkt[i];
+      out[s_gcur[b] + (i - s_lstart[b])] = s_item[i];
+    }
+    __syncthreads();
+    for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) s_gcur[j] += s_hist[j];
+  }
+  if(my_direct) atomicAdd((unsigned long long*)&T.counters[CTR_DIRECT], (unsigned long long)my_direct);
+}
+
 // P2 scatter with write combining: scattered 4-byte stores top out at ~50-100 G items/s on
 // MI355X (one L2 transaction each), so every block first counting-sorts a chunk of kChunk
 // items by destination bucket in LDS and then writes whole runs (consecutive lanes ->
