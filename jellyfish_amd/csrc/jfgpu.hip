@@ -832,6 +832,8 @@ int jfgpu_reserve(jfgpu_table* t, uint64_t input_bytes) {
   rc = ws_grow(t, need);
   if(rc < 0) return fail(JFGPU_E_ALLOC, "not enough device memory to reserve the partition workspace");
   if(rc) return rc;
+  // touch every page once now: first-touch of fresh device pages costs ~40% on the first pass over them
+  HIP_TRY(hipMemsetAsync(t->ws, 0, t->ws_cap, t->stream));
   if(!t->d_M1) { t->g1 = 2 * t->n_cu; HIP_TRY(hipMalloc((void**)&t->d_M1, (size_t)t->g1 * kMaxBuckets * sizeof(uint32_t))); }
   if(t->pg.b2 && !t->d_M2) HIP_TRY(hipMalloc((void**)&t->d_M2, (size_t)nb1 * 32 * nb2 * sizeof(uint32_t)));
   return JFGPU_OK;

@@ -48,6 +48,11 @@ struct DevTable {
   uint8_t* dirty;             // one byte per tile: something was ever inserted (tile_insert may skip reading clean tiles)
 };
 
+// Workgroup barrier that orders LDS only.  __syncthreads() also waits for every outstanding
+// global store of the wave (s_waitcnt vmcnt(0)), which serialises "write a chunk to HBM" with
+// "start the next chunk" in the streaming kernels; here the only cross-wave traffic is LDS.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---- overflow side table ----------------------------------------------------
 // A slot's count field wrapped: remember `units` x 2^cnt_bits for that slot.  Keyed by
 // the slot index, which identifies the key (keys never move while the table lives).
@@ -174,7 +179,7 @@ __device__ inline LaneWords stage_tile(const uint8_t* __restrict__ base, int64_t
     load_pack16(base, tile_start - 32 + 16 * tid, lo, hi, hc, hv);
     s_codes[tid] = hc; s_inv[tid] = hv;
   }
-  __syncthreads();
+  lds_barrier();
   LaneWords L;
   L.cur = c;
   L.p1 = s_codes[tid + 1];

@@ -93,12 +93,12 @@ __global__ __launch_bounds__(kPBlock) void p1_kernel(DevTable T, PartGeom P, con
     const int64_t n = hi;
     const int64_t per = (n + gridDim.x - 1) / gridDim.x;
     const int64_t b0 = (int64_t)blockIdx.x * per, b1e = b0 + per < n ? b0 + per : n;
-    __syncthreads();
+    lds_barrier();
     for(int64_t i = b0 + threadIdx.x; i < b1e; i += blockDim.x) { emit(keys[i] & T.g.key_mask); ++my_mers; }
   } else {
     const int64_t n_tiles = (hi + kPTilePos - 1) / kPTilePos;
     for(int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-      __syncthreads();
+      lds_barrier();
       const LaneWords L = stage_tile(base, tile * kPTilePos, lo, hi, s_codes, s_inv);
       uint64_t prev = 0; uint32_t run = 0;
       auto flush_run = [&]() {
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kPBlock) void p1_kernel(DevTable T, PartGeom P, con
       flush_run();
     }
   }
-  __syncthreads();
+  lds_barrier();
   if(!SCATTER) {
     for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) M[(size_t)blockIdx.x * nb + j] = (uint32_t)s_cur[j];
     uint64_t w = my_mers;
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(1024) void scan_matrix_kernel(uint32_t* __restrict_
     s_tot[j] = run;
   }
   for(uint32_t j = nb + threadIdx.x; j < kMaxBuckets; j += blockDim.x) s_tot[j] = 0;
-  __syncthreads();
+  lds_barrier();
   // exclusive scan of s_tot[0 .. 2048): two adjacent entries per thread, wave scan, then wave totals
   const uint32_t t = threadIdx.x;
   const unsigned long long a = s_tot[2 * t], b = s_tot[2 * t + 1];
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(1024) void scan_matrix_kernel(uint32_t* __restrict_
     if((int)(t & 63) >= o) incl += up;
   }
   if((t & 63) == 63) s_wave[t >> 6] = incl;
-  __syncthreads();
+  lds_barrier();
   unsigned long long wbase = 0;
   for(uint32_t w = 0; w < (t >> 6); ++w) wbase += s_wave[w];
   const unsigned long long excl = wbase + incl - (a + b);
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(kPBlock) void p2_kernel(PartGeom P, uint32_t tag_bi
     for(uint32_t s = 0; s < S.n; ++s) { s_seg_lo[s] = c; c += S.off[s][bucket + 1] - S.off[s][bucket]; }
     s_seg_lo[S.n] = c;
   }
-  __syncthreads();
+  lds_barrier();
   const uint64_t n = s_seg_lo[S.n];
   const uint64_t per = (n + gridDim.x - 1) / gridDim.x;
   const uint64_t my_lo = (uint64_t)blockIdx.x * per, my_hi = my_lo + per < n ? my_lo + per : n;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(kPBlock) void p2_kernel(PartGeom P, uint32_t tag_bi
     }
   }
   if(!SCATTER) {
-    __syncthreads();
+    lds_barrier();
     for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) Mq[j] = (uint32_t)s_cur[j];
   }
 }
@@ -223,7 +223,7 @@ __device__ inline void block_excl_scan_2048(const uint32_t* in, uint32_t* out, u
     if((int)(t & 63) >= o) incl += up;
   }
   if((t & 63) == 63) s_wave[t >> 6] = incl;
-  __syncthreads();
+  lds_barrier();
   uint32_t wbase = 0;
   for(uint32_t w = 0; w < (t >> 6); ++w) wbase += s_wave[w];
   const uint32_t excl = wbase + incl - (a + b);
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(kPBlock) void p1_scatter_sorted_kernel(DevTable T, 
   uint32_t my_direct = 0;
   const int64_t n_tiles = (hi + kPTilePos - 1) / kPTilePos;
   for(int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    __syncthreads();
+    lds_barrier();
     for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) s_hist[j] = 0;
     const LaneWords L = stage_tile(base, tile * kPTilePos, lo, hi, s_codes, s_inv);   // barrier inside
     uint32_t it[kPerLane + 1], dr[kPerLane + 1];
@@ -282,22 +282,22 @@ __global__ __launch_bounds__(kPBlock) void p1_scatter_sorted_kernel(DevTable T, 
       prev = key; run = 1;
     });
     flush_run(kPerLane);
-    __syncthreads();
+    lds_barrier();
     block_excl_scan_2048(s_hist, s_lstart, nb, s_wave);
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for(int e = 0; e <= kPerLane; ++e)
       if(dr[e] != 0xFFFFFFFFu) {
         const uint32_t at = s_lstart[dr[e] >> 16] + (dr[e] & 0xFFFFu);
         s_item[at] = it[e]; s_bkt[at] = (uint16_t)(dr[e] >> 16);
       }
-    __syncthreads();
+    lds_barrier();
     const uint32_t cn = s_lstart[nb - 1] + s_hist[nb - 1];
     for(uint32_t i = threadIdx.x; i < cn; i += blockDim.x) {
       const uint32_t b = s_bkt[i];
       out[s_gcur[b] + (i - s_lstart[b])] = s_item[i];
     }
-    __syncthreads();
+    lds_barrier();
     for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) s_gcur[j] += s_hist[j];
   }
   if(my_direct) atomicAdd((unsigned long long*)&T.counters[CTR_DIRECT], (unsigned long long)my_direct);
@@ -315,65 +315,61 @@ __global__ __launch_bounds__(kPBlock) void p2_scatter_sorted_kernel(PartGeom P, 
   constexpr int kChunk = kPBlock * PER_THREAD;
   extern __shared__ __align__(16) unsigned char s_dyn[];
   ITEM* s_item = reinterpret_cast<ITEM*>(s_dyn);                       // [kChunk]
-  __shared__ unsigned long long s_gcur[kMaxBuckets];
+  __shared__ unsigned long long s_delta[kMaxBuckets];                  // global write cursor of bucket d minus its start in the sorted chunk
   __shared__ uint32_t s_hist[kMaxBuckets];
   __shared__ uint32_t s_lstart[kMaxBuckets];
   __shared__ uint32_t s_wave[16];
-  __shared__ unsigned long long s_seg_lo[kMaxSeg + 1];
   const uint32_t nb = 1u << P.b2;
   const uint32_t bucket = blockIdx.y;
   const uint32_t* Mq = M + ((size_t)bucket * gridDim.x + blockIdx.x) * nb;
-  for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) s_gcur[j] = goff[(size_t)bucket * nb + j] + Mq[j];
-  if(threadIdx.x == 0) {
-    unsigned long long c = 0;
-    for(uint32_t s = 0; s < S.n; ++s) { s_seg_lo[s] = c; c += S.off[s][bucket + 1] - S.off[s][bucket]; }
-    s_seg_lo[S.n] = c;
-  }
-  __syncthreads();
-  const uint64_t n = s_seg_lo[S.n];
+  for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) { s_delta[j] = goff[(size_t)bucket * nb + j] + Mq[j]; s_lstart[j] = 0; s_hist[j] = 0; }
+  // this bucket's items = concatenation over the pending batches (block-uniform scalars)
+  uint64_t n = 0;
+  for(uint32_t s = 0; s < S.n; ++s) n += S.off[s][bucket + 1] - S.off[s][bucket];
   const uint64_t per = (n + gridDim.x - 1) / gridDim.x;
   const uint64_t my_lo = (uint64_t)blockIdx.x * per, my_hi = my_lo + per < n ? my_lo + per : n;
   for(uint64_t c0 = my_lo; c0 < my_hi; c0 += kChunk) {
     const uint64_t c1 = c0 + kChunk < my_hi ? c0 + kChunk : my_hi;
-    for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) s_hist[j] = 0;
-    __syncthreads();
-    ITEM it[PER_THREAD]; uint32_t dr[PER_THREAD];   // digit << 16 | rank is not enough (rank < 16384, digit < 2048): 11 + 14 bits
-    uint32_t s = 0;   // v grows with r: the batch index only moves forward
+    lds_barrier();                                      // previous chunk's readers of s_hist/s_lstart/s_item are done
+    // the cursor of bucket d advances by what the previous chunk wrote; delta is re-based on the new lstart below
+    for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) { s_delta[j] += (unsigned long long)s_hist[j] + s_lstart[j]; s_hist[j] = 0; }
+    ITEM it[PER_THREAD]; uint32_t dr[PER_THREAD];       // digit << 16 | rank inside the chunk
 #pragma unroll
-    for(int r = 0; r < PER_THREAD; ++r) {
-      const uint64_t v = c0 + (uint64_t)r * kPBlock + threadIdx.x;
-      dr[r] = 0xFFFFFFFFu;
-      if(v < c1) {
-        // locate v in the virtual concatenation of the pending batches
-        while(s + 1 < S.n && v >= s_seg_lo[s + 1]) ++s;
-        it[r] = reinterpret_cast<const ITEM*>(S.items[s])[S.off[s][bucket] + (v - s_seg_lo[s])];
+    for(int r = 0; r < PER_THREAD; ++r) { dr[r] = 0xFFFFFFFFu; it[r] = 0; }
+    uint64_t slo = 0;
+    for(uint32_t s = 0; s < S.n; ++s) {                 // uniform loop: usually one or two batches overlap a chunk
+      const uint64_t o0 = S.off[s][bucket], len = S.off[s][bucket + 1] - o0, shi = slo + len;
+      if(shi > c0 && slo < c1) {
+        const ITEM* src = reinterpret_cast<const ITEM*>(S.items[s]) + o0;
+#pragma unroll
+        for(int r = 0; r < PER_THREAD; ++r) {
+          const uint64_t v = c0 + (uint64_t)r * kPBlock + threadIdx.x;
+          if(v < c1 && v >= slo && v < shi) { it[r] = src[v - slo]; dr[r] = 0; }
+        }
       }
+      slo = shi;
     }
+    lds_barrier();
 #pragma unroll
-    for(int r = 0; r < PER_THREAD; ++r) {
-      const uint64_t v = c0 + (uint64_t)r * kPBlock + threadIdx.x;
-      if(v < c1) {
+    for(int r = 0; r < PER_THREAD; ++r)
+      if(dr[r] != 0xFFFFFFFFu) {
         const uint32_t d = (uint32_t)((uint64_t)it[r] >> tag_bits) & (nb - 1);
         dr[r] = (d << 16) | atomicAdd(&s_hist[d], 1u);
       }
-    }
-    __syncthreads();
+    lds_barrier();
     block_excl_scan_2048(s_hist, s_lstart, nb, s_wave);
-    __syncthreads();
+    lds_barrier();
+    for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) s_delta[j] -= s_lstart[j];
 #pragma unroll
     for(int r = 0; r < PER_THREAD; ++r)
       if(dr[r] != 0xFFFFFFFFu) s_item[s_lstart[dr[r] >> 16] + (dr[r] & 0xFFFFu)] = it[r];
-    __syncthreads();
+    lds_barrier();
     const uint32_t cn = (uint32_t)(c1 - c0);
     for(uint32_t i = threadIdx.x; i < cn; i += blockDim.x) {
       const ITEM v = s_item[i];
       const uint32_t d = (uint32_t)((uint64_t)v >> tag_bits) & (nb - 1);
-      out[s_gcur[d] + (i - s_lstart[d])] = v;
+      out[s_delta[d] + i] = v;                         // run of bucket d: consecutive lanes, consecutive addresses
     }
-    __syncthreads();
-    for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) s_gcur[j] += s_hist[j];
-    // next iteration zeroes s_hist after this barrier-protected update
-    __syncthreads();
   }
 }
 
@@ -401,7 +397,7 @@ __global__ __launch_bounds__(kPBlock) void tile_insert_kernel(DevTable T, SegLis
       if(load) v = *reinterpret_cast<const ulonglong2*>(gt + i);
       *reinterpret_cast<ulonglong2*>(s_tile + i) = v;
     }
-    __syncthreads();
+    lds_barrier();
     for(uint32_t s = 0; s < S.n; ++s) {
       const uint64_t a = S.off[s][t], b = S.off[s][t + 1];
       const ITEM* src = reinterpret_cast<const ITEM*>(S.items[s]);
@@ -428,11 +424,11 @@ __global__ __launch_bounds__(kPBlock) void tile_insert_kernel(DevTable T, SegLis
         if(!done) atomicAdd((unsigned long long*)&T.counters[CTR_FULL], 1ull);
       }
     }
-    __syncthreads();
+    lds_barrier();
     for(uint32_t i = threadIdx.x * 2; i < tsz; i += blockDim.x * 2)
       *reinterpret_cast<ulonglong2*>(gt + i) = *reinterpret_cast<const ulonglong2*>(s_tile + i);
     if(threadIdx.x == 0) T.dirty[tile0 + t] = 1;
-    __syncthreads();
+    lds_barrier();
   }
 }
 

@@ -127,11 +127,30 @@ inline uint32_t geom_min_lsize(uint32_t k, uint32_t shard_bits) {
 
 // pos = M * key via byte tables: tbl[b * 256 + v] = XOR of the columns selected by
 // byte b of the key having value v.  (H is linear over GF(2).)
-JF_HD uint64_t hash_tables(const uint64_t* tbl, uint64_t key, uint32_t nbytes) {
+template <int NB>
+JF_HD uint64_t hash_tables_n(const uint64_t* tbl, uint64_t key) {
+  // constant byte positions: the key bytes come out of the two dwords with v_bfe_u32, no 64-bit shifts
+  const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
   uint64_t pos = 0;
-#pragma unroll 8
-  for(uint32_t b = 0; b < nbytes; ++b) pos ^= tbl[b * 256 + ((key >> (8 * b)) & 0xFF)];
+#pragma unroll
+  for(int b = 0; b < NB; ++b) {
+    const uint32_t w = b < 4 ? lo : hi;
+    pos ^= tbl[b * 256 + ((w >> (8 * (b & 3))) & 0xFFu)];
+  }
   return pos;
+}
+
+JF_HD uint64_t hash_tables(const uint64_t* tbl, uint64_t key, uint32_t nbytes) {
+  switch(nbytes) {   // wave-uniform: one scalar branch, then a fully unrolled body
+  case 1: return hash_tables_n<1>(tbl, key);
+  case 2: return hash_tables_n<2>(tbl, key);
+  case 3: return hash_tables_n<3>(tbl, key);
+  case 4: return hash_tables_n<4>(tbl, key);
+  case 5: return hash_tables_n<5>(tbl, key);
+  case 6: return hash_tables_n<6>(tbl, key);
+  case 7: return hash_tables_n<7>(tbl, key);
+  default: return hash_tables_n<8>(tbl, key);
+  }
 }
 
 struct SlotAddr {
