@@ -378,15 +378,87 @@ __global__ __launch_bounds__(kPBlock) void p2_scatter_sorted_kernel(PartGeom P, 
 // LOAD == false: the whole table is known to be all-zero (fresh / cleared): never read tiles.
 // LOAD == true : read a tile only if its dirty byte says something was ever inserted into it.
 // Same claim-or-increment protocol as table_add, on LDS words (ds_cmpst_rtn_b64 / ds_add_u64).
+template <typename ITEM, bool RETURNING>
+__device__ inline void tile_insert_one(const DevTable& T, unsigned long long* s_tile, uint64_t item, uint64_t tile_index) {
+  const TableGeom& g = T.g;
+  const uint32_t tmask = (1u << g.tile_bits) - 1;
+  const uint64_t tag = item & (g.occ_bit - 1);
+  const uint32_t idx0 = (uint32_t)(tag >> g.rem_bits);
+  const uint64_t low = g.occ_bit | tag;
+  const uint64_t neww = g.inc | low;
+  for(uint32_t p = 0; p <= T.max_probe; ++p) {
+    const uint32_t slot = probe_slot(idx0, p, tmask);
+    const unsigned long long old = atomicCAS(&s_tile[slot], 0ull, (unsigned long long)neww);
+    if(old == 0ull) return;
+    if((old & g.low_mask) == low) {
+      if(RETURNING) {
+        const unsigned long long prev = atomicAdd(&s_tile[slot], (unsigned long long)g.inc);
+        if((prev >> (g.tag_bits + 1)) + 1 > g.cnt_max) ovf_add(T, (tile_index << g.tile_bits) + slot, 1);
+      } else {
+        atomicAdd(&s_tile[slot], (unsigned long long)g.inc);
+      }
+      return;
+    }
+  }
+  atomicAdd((unsigned long long*)&T.counters[CTR_FULL], 1ull);
+}
+
 template <typename ITEM, bool RETURNING, bool LOAD>
 __global__ __launch_bounds__(kPBlock) void tile_insert_kernel(DevTable T, SegList S, uint64_t tile0, uint32_t n_tiles) {
   extern __shared__ __align__(16) unsigned char s_raw[];
   unsigned long long* s_tile = reinterpret_cast<unsigned long long*>(s_raw);
   const TableGeom& g = T.g;
-  const uint32_t tsz = 1u << g.tile_bits, tmask = tsz - 1;
-  const uint64_t tagmask = g.occ_bit - 1;
+  const uint32_t tsz = 1u << g.tile_bits;
+  if(S.n == 1) {
+    // Fast path (one packed item array, e.g. the P2 output).  Software pipeline over this block's
+    // tiles: offsets are fetched two tiles ahead and the items one tile ahead into registers, so the
+    // dependent global loads (offset -> items) never sit on the critical path of a tile.
+    constexpr int NP = 6;                                   // register-prefetched items per lane (6144 per tile)
+    const uint64_t* off = S.off[0];
+    const ITEM* src = reinterpret_cast<const ITEM*>(S.items[0]);
+    const uint32_t G = gridDim.x;
+    uint32_t t = blockIdx.x;
+    uint64_t a0 = 0, b0 = 0, a1 = 0, b1 = 0; uint8_t d0 = 0, d1 = 0;
+    ITEM cur[NP];
+    if(t < n_tiles) { a0 = off[t]; b0 = off[t + 1]; d0 = LOAD ? T.dirty[tile0 + t] : 0; }
+    if(t + G < n_tiles) { a1 = off[t + G]; b1 = off[t + G + 1]; d1 = LOAD ? T.dirty[tile0 + t + G] : 0; }
+#pragma unroll
+    for(int r = 0; r < NP; ++r) { const uint64_t v = a0 + (uint64_t)r * kPBlock + threadIdx.x; cur[r] = v < b0 ? src[v] : (ITEM)0; }
+    for(; t < n_tiles; t += G) {
+      // issue the loads of the following tiles first
+      uint64_t a2 = 0, b2 = 0; uint8_t d2 = 0;
+      if(t + 2 * G < n_tiles) { a2 = off[t + 2 * G]; b2 = off[t + 2 * G + 1]; d2 = LOAD ? T.dirty[tile0 + t + 2 * G] : 0; }
+      ITEM nxt[NP];
+#pragma unroll
+      for(int r = 0; r < NP; ++r) { const uint64_t v = a1 + (uint64_t)r * kPBlock + threadIdx.x; nxt[r] = v < b1 ? src[v] : (ITEM)0; }
+      if(b0 > a0) {                                          // block-uniform
+        uint64_t* gt = T.slots + ((tile0 + t) << g.tile_bits);
+        const bool load = LOAD && d0 != 0;
+        for(uint32_t i = threadIdx.x * 2; i < tsz; i += blockDim.x * 2) {
+          ulonglong2 v = make_ulonglong2(0ull, 0ull);
+          if(load) v = *reinterpret_cast<const ulonglong2*>(gt + i);
+          *reinterpret_cast<ulonglong2*>(s_tile + i) = v;
+        }
+        lds_barrier();
+#pragma unroll
+        for(int r = 0; r < NP; ++r)
+          if(a0 + (uint64_t)r * kPBlock + threadIdx.x < b0) tile_insert_one<ITEM, RETURNING>(T, s_tile, (uint64_t)cur[r], tile0 + t);
+        for(uint64_t v = a0 + (uint64_t)NP * kPBlock + threadIdx.x; v < b0; v += kPBlock)   // rare: an over-full tile
+          tile_insert_one<ITEM, RETURNING>(T, s_tile, (uint64_t)src[v], tile0 + t);
+        lds_barrier();
+        for(uint32_t i = threadIdx.x * 2; i < tsz; i += blockDim.x * 2)
+          *reinterpret_cast<ulonglong2*>(gt + i) = *reinterpret_cast<const ulonglong2*>(s_tile + i);
+        if(threadIdx.x == 0) T.dirty[tile0 + t] = 1;
+        lds_barrier();
+      }
+      a0 = a1; b0 = b1; d0 = d1; a1 = a2; b1 = b2; d1 = d2;
+#pragma unroll
+      for(int r = 0; r < NP; ++r) cur[r] = nxt[r];
+    }
+    return;
+  }
   for(uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-    // every lane reads the (few) offsets itself: one broadcast line, no extra barrier
+    // general path (several pending batches, single-level tables): every lane reads the offsets itself
     uint64_t n_items = 0;
     for(uint32_t s = 0; s < S.n; ++s) n_items += S.off[s][t + 1] - S.off[s][t];
     if(n_items == 0) continue;                                   // block-uniform
@@ -401,28 +473,8 @@ __global__ __launch_bounds__(kPBlock) void tile_insert_kernel(DevTable T, SegLis
     for(uint32_t s = 0; s < S.n; ++s) {
       const uint64_t a = S.off[s][t], b = S.off[s][t + 1];
       const ITEM* src = reinterpret_cast<const ITEM*>(S.items[s]);
-      for(uint64_t v = a + threadIdx.x; v < b; v += blockDim.x) {
-        const uint64_t tag = (uint64_t)src[v] & tagmask;
-        const uint32_t idx0 = (uint32_t)(tag >> g.rem_bits);
-        const uint64_t low = g.occ_bit | tag;
-        const uint64_t neww = g.inc | low;
-        bool done = false;
-        for(uint32_t p = 0; p <= T.max_probe; ++p) {
-          const uint32_t slot = probe_slot(idx0, p, tmask);
-          const unsigned long long old = atomicCAS(&s_tile[slot], 0ull, (unsigned long long)neww);
-          if(old == 0ull) { done = true; break; }
-          if((old & g.low_mask) == low) {
-            if(RETURNING) {
-              const unsigned long long prev = atomicAdd(&s_tile[slot], (unsigned long long)g.inc);
-              if((prev >> (g.tag_bits + 1)) + 1 > g.cnt_max) ovf_add(T, ((tile0 + t) << g.tile_bits) + slot, 1);
-            } else {
-              atomicAdd(&s_tile[slot], (unsigned long long)g.inc);
-            }
-            done = true; break;
-          }
-        }
-        if(!done) atomicAdd((unsigned long long*)&T.counters[CTR_FULL], 1ull);
-      }
+      for(uint64_t v = a + threadIdx.x; v < b; v += blockDim.x)
+        tile_insert_one<ITEM, RETURNING>(T, s_tile, (uint64_t)src[v], tile0 + t);
     }
     lds_barrier();
     for(uint32_t i = threadIdx.x * 2; i < tsz; i += blockDim.x * 2)
