@@ -127,10 +127,16 @@ def main():
         for mode, name in ((0, "atomic_add"), (2, "atomic_cas")):
             gups[name] = t.gups(1 << 28, mode)
     t.clear()
-    if world == 1:
-        t.reserve(n_reads * stride)      # Init phase: workspace for one sync-to-sync span (like -s presizes the table)
+    force_dist = os.environ.get("JFGPU_BENCH_FORCE_DIST") == "1"     # exercise the N>1 code path on one GPU
+    if world > 1 or force_dist:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    # Init phase: workspace for one sync-to-sync span (like -s presizes the table)
+    t.reserve(n_reads * stride if world == 1 and not force_dist else int(n_reads * kmers_per_read * 1.02) + (1 << 20))
 
-    if world == 1:
+    if world == 1 and not force_dist:
         def run_step(i):
             p, n = batch(i)
             t.count_ascii_dev(p, n)
@@ -145,7 +151,7 @@ def main():
     def fence():
         t.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
 
     for i in range(warmup):
@@ -197,7 +203,7 @@ def main():
                        "k": K, "read_len": READ_LEN, "reads_per_gpu": n_reads, "table_slots_per_gpu": 1 << args.lsize,
                        "load_factor": float(tot[1]) / float(world << args.lsize),
                        "distinct": int(tot[1]), "total_kmers": total_kmers,
-                       "parallelism": "single GPU" if world == 1 else "hash-prefix shard x%d + all-to-all" % world},
+                       "parallelism": ("single GPU" if not force_dist else "single GPU through the sharded code path") if world == 1 else "hash-prefix shard x%d + all-to-all" % world},
             "kernels": kernels,
             "roofline": {"bound": "hbm", "kernel": slot_names[which],
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -226,7 +232,7 @@ def main():
                 assert mine == ref_stats, "GPU and reference disagree on the sample:\n%s\n%s" % (mine, ref_stats)
         print(json.dumps(out), flush=True)
     t.close()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -110,6 +110,10 @@ int  jfgpu_clear(jfgpu_table* t);
  * "Hash full" (the device cannot throw mid-kernel). == every thread called
  * hash_counter::done() (hash_counter.hpp:169-172). */
 int  jfgpu_sync(jfgpu_table* t);
+/* Wait until the kernels enqueued so far have finished WITHOUT applying pending partitioned
+ * batches: after it returns, device buffers handed to jfgpu_count_ascii_dev / jfgpu_add_keys_dev
+ * may be reused (their k-mers have been copied into the engine's workspace). */
+int  jfgpu_wait(jfgpu_table* t);
 
 /* ---- the hot path ------------------------------------------------------ */
 /* mer_counter_base::start COUNT loop (sub_commands/count_main.cc:152-163) over one

@@ -58,6 +58,7 @@ SIGNATURES = {
     "jfgpu_get_matrix": (C.c_int, [_P, _P]),
     "jfgpu_clear": (C.c_int, [_P]),
     "jfgpu_sync": (C.c_int, [_P]),
+    "jfgpu_wait": (C.c_int, [_P]),
     "jfgpu_count_ascii_dev": (C.c_int, [_P, _P, C.c_size_t]),
     "jfgpu_count_ascii": (C.c_int, [_P, _P, C.c_size_t]),
     "jfgpu_add_keys_dev": (C.c_int, [_P, _P, C.c_size_t, C.c_uint64, _P]),
@@ -169,6 +170,9 @@ class Table:
 
     def sync(self):
         _check(self._lib.jfgpu_sync(self._h))
+
+    def wait(self):
+        _check(self._lib.jfgpu_wait(self._h))
 
     # -- hot path
     def count_ascii(self, bases: bytes):

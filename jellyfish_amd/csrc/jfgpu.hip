@@ -566,6 +566,12 @@ int jfgpu_sync(jfgpu_table* t) {
   return check_deferred(t);
 }
 
+int jfgpu_wait(jfgpu_table* t) {
+  int rc = use(t); if(rc) return rc;
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  return JFGPU_OK;
+}
+
 int jfgpu_count_ascii_dev(jfgpu_table* t, const char* d_bases, size_t n) {
   int rc = use(t); if(rc) return rc;
   if(t->g.shard_bits) return fail(JFGPU_E_INVALID, "sharded table: route k-mers with jfgpu_partition_ascii_dev + jfgpu_add_keys_dev");

@@ -28,9 +28,16 @@ def shard_bits_for(world_size: int) -> int:
     return sb
 
 
-def exchange_keys(send: torch.Tensor, send_counts: List[int], group=None) -> Tuple[torch.Tensor, List[int]]:
+MAX_KEYS_PER_MESSAGE = 1 << 27   # 1 GiB per peer per round
+
+
+def exchange_keys(send: torch.Tensor, send_counts: List[int], group=None):
     """All-to-all-v of routed k-mers.  `send` holds the keys for rank 0, then rank 1, ...
-    Returns (received keys, per-source counts)."""
+    Returns a list of (received keys, count) pieces (order is irrelevant to the table).
+
+    Messages are capped at 1 GiB per peer: a single 6.9 GB self-message (world size 1, one
+    1 Gbp batch) was silently not delivered by RCCL 2.26, and byte counts above 2^31 are a
+    classic overflow spot, so large exchanges run in rounds."""
     world = dist.get_world_size(group)
     assert len(send_counts) == world
     dev = send.device
@@ -38,11 +45,25 @@ def exchange_keys(send: torch.Tensor, send_counts: List[int], group=None) -> Tup
     rc = torch.empty(world, dtype=torch.int64, device=dev)
     dist.all_to_all_single(rc, sc, group=group)
     recv_counts = [int(x) for x in rc.tolist()]
-    total_send = int(sum(send_counts))
-    recv = torch.empty(int(sum(recv_counts)), dtype=torch.int64, device=dev)
-    dist.all_to_all_single(recv, send[:total_send], output_split_sizes=recv_counts, input_split_sizes=list(send_counts),
-                           group=group)
-    return recv, recv_counts
+    gmax = torch.tensor([max(max(send_counts), max(recv_counts))], dtype=torch.int64, device=dev)
+    dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)
+    rounds = max(1, -(-int(gmax.item()) // MAX_KEYS_PER_MESSAGE))
+    send_off = [0]
+    for c in send_counts:
+        send_off.append(send_off[-1] + int(c))
+    pieces = []
+    for r in range(rounds):
+        lo = r * MAX_KEYS_PER_MESSAGE
+        s_part = [max(0, min(int(c) - lo, MAX_KEYS_PER_MESSAGE)) for c in send_counts]
+        r_part = [max(0, min(int(c) - lo, MAX_KEYS_PER_MESSAGE)) for c in recv_counts]
+        recv = torch.empty(int(sum(r_part)), dtype=torch.int64, device=dev)
+        if rounds == 1:
+            dist.all_to_all_single(recv, send[:send_off[-1]], output_split_sizes=r_part, input_split_sizes=s_part, group=group)
+        else:   # this round's slice of every peer's region, packed (all_to_all_single wants one contiguous input)
+            ins = torch.cat([send[send_off[p] + lo: send_off[p] + lo + s_part[p]] for p in range(world)])
+            dist.all_to_all_single(recv, ins, output_split_sizes=r_part, input_split_sizes=s_part, group=group)
+        pieces.append((recv, int(sum(r_part))))
+    return pieces
 
 
 class ShardedCounter:
@@ -59,12 +80,13 @@ class ShardedCounter:
     def step(self, batch):
         """Route one batch of this rank's input and insert what this rank owns."""
         send, counts = self.backend.partition(batch)
-        recv, rcounts = exchange_keys(send, counts, self.group)
-        n = int(sum(rcounts))
-        self.backend.insert(recv, n)
+        got = 0
+        for recv, n in exchange_keys(send, counts, self.group):
+            self.backend.insert(recv, n)
+            got += n
         self.sent += int(sum(counts))
-        self.received += n
-        return n
+        self.received += got
+        return got
 
 
 class GpuBackend:
@@ -83,8 +105,10 @@ class GpuBackend:
         return self.send, [int(c) for c in counts]
 
     def insert(self, recv: torch.Tensor, n: int):
-        torch.cuda.current_stream(self.device).synchronize()     # the all-to-all has landed
-        self.t.sync()                                             # previous insert retired -> its buffer may go
-        self._keep = recv                                         # keep alive while the kernel reads it
+        # device-wide: the collective runs on RCCL's own stream; waiting only for torch's current
+        # stream let the insert kernel read the receive buffer before the data had landed
+        torch.cuda.synchronize(self.device)
+        self.t.wait()                                             # previous insert/P1 has consumed its buffer
+        self._keep = recv                                         # keep alive while the kernel reads it (the previous one is free now)
         if n:
-            self.t.add_keys_dev(recv.data_ptr(), n, 1)
+            self.t.add_keys_dev(recv.data_ptr(), n, 1)           # direct insert, or P1-partitioned and applied at sync

@@ -16,6 +16,8 @@ import numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
 import oracle_lib as O
 from jellyfish_amd.dist import ShardedCounter, shard_bits_for
+import jellyfish_amd.dist as jd
+jd.MAX_KEYS_PER_MESSAGE = int(os.environ.get("JF_TEST_MAXMSG", str(1 << 27)))   # small => multi-round exchange
 
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
@@ -54,15 +56,15 @@ dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_sharded_exchange_equals_single_table(tmp_path, world):
+@pytest.mark.parametrize("world,maxmsg", [(2, 1 << 27), (4, 1 << 27), (2, 300)])
+def test_sharded_exchange_equals_single_table(tmp_path, world, maxmsg):
     import json
     import numpy as np
     import oracle_lib as O
     w = tmp_path / "worker.py"
     w.write_text(WORKER)
-    port = 29600 + world
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    port = 29600 + world + (maxmsg % 7)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", JF_TEST_MAXMSG=str(maxmsg))
     subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                     "--master-addr", "127.0.0.1", "--master-port", str(port), str(w), ROOT, str(tmp_path)],
                    check=True, env=env, timeout=300, capture_output=True)
