@@ -162,6 +162,38 @@ int  jfgpu_dump_begin(jfgpu_table* t, uint64_t lower, uint64_t upper, uint64_t* 
 int  jfgpu_dump_next(jfgpu_table* t, void* out, uint64_t capacity_records, uint64_t* n_read);
 int  jfgpu_dump_end(jfgpu_table* t);
 
+/* ---- Bloom counter: `jellyfish bc` and `count --bc` (BASELINE config 3) ------------------- */
+typedef struct jfgpu_bloom jfgpu_bloom;   /* opaque: ceil(m/5) bytes of base-3 cells in HBM */
+typedef struct jfgpu_bloom_params {
+  uint32_t k, canonical;
+  uint64_t m;                 /* number of cells (bloom_base::m(); header "size") */
+  uint32_t nb_hashes;         /* header "nb_hashes" */
+  int32_t  device;            /* -1 = current */
+  uint64_t seed;              /* for the two random 64 x 2k matrices; 0 = default */
+  const uint64_t* matrix1;    /* optional explicit matrices, 2k columns each, file-header order */
+  const uint64_t* matrix2;    /*   (what load_bloom_filter reads back, count_main.cc:191-206) */
+} jfgpu_bloom_params;
+/* bloom_base::opt_m / opt_k (bloom_common.hpp:61-66) */
+uint64_t jfgpu_bc_opt_m(double fp, uint64_t n);
+uint32_t jfgpu_bc_opt_k(double fp);
+/* mer_dna_bloom_counter ctor (bc_main.cc:114-120) / dtor */
+int  jfgpu_bc_create(const jfgpu_bloom_params* p, jfgpu_bloom** out);
+void jfgpu_bc_destroy(jfgpu_bloom* b);
+/* mer_bloom_counter::start (bc_main.cc:67-71): filter.insert(*mers) for every k-mer of a contract buffer */
+int  jfgpu_bc_insert_ascii_dev(jfgpu_bloom* b, const char* d_bases, size_t n);
+int  jfgpu_bc_insert_ascii(jfgpu_bloom* b, const char* bases, size_t n);
+int  jfgpu_bc_sync(jfgpu_bloom* b, uint64_t* mers_fed);
+int  jfgpu_bc_get_info(const jfgpu_bloom* b, uint64_t* m, uint32_t* nb_hashes, uint64_t* nb_bytes,
+                       uint64_t* matrix1 /* [2k] or NULL */, uint64_t* matrix2);
+/* write_bits / the istream ctor: the raw ceil(m/5) bytes of a "bloomcounter" file body */
+int  jfgpu_bc_read(jfgpu_bloom* b, uint8_t* out);
+int  jfgpu_bc_load(jfgpu_bloom* b, const uint8_t* data);
+/* bloom_base::check / insert on encoded k-mers (query_main.cc Bloom branch); out[i] = 0, 1 or 2 */
+int  jfgpu_bc_keys(jfgpu_bloom* b, const uint64_t* keys, size_t n, uint8_t* out, int do_insert);
+/* count --bc: from now on jfgpu_count_* admits a k-mer only if check(m) > 1 (count_main.cc:115-118).
+ * b == NULL detaches.  The Bloom counter must outlive its use. */
+int  jfgpu_attach_bloom(jfgpu_table* t, jfgpu_bloom* b);
+
 /* Insert strategy.  0 auto (default), 1 direct (global 64-bit atomics, kernels.hip.hpp),
  * 2 partitioned (radix partition + LDS-resident tiles, kernels_part.hip.hpp; large batches
  * are buffered on the device and applied at the next jfgpu_sync / read).  Results are

@@ -41,6 +41,12 @@ class Info(C.Structure):
     ]
 
 
+class BloomParams(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("canonical", C.c_uint32), ("m", C.c_uint64), ("nb_hashes", C.c_uint32),
+                ("device", C.c_int32), ("seed", C.c_uint64), ("matrix1", C.POINTER(C.c_uint64)),
+                ("matrix2", C.POINTER(C.c_uint64))]
+
+
 class Stats(C.Structure):
     _fields_ = [("unique", C.c_uint64), ("distinct", C.c_uint64), ("total", C.c_uint64),
                 ("max_count", C.c_uint64), ("occupied", C.c_uint64), ("mers_fed", C.c_uint64)]
@@ -71,6 +77,18 @@ SIGNATURES = {
     "jfgpu_dump_begin": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "jfgpu_dump_next": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "jfgpu_dump_end": (C.c_int, [_P]),
+    "jfgpu_bc_opt_m": (C.c_uint64, [C.c_double, C.c_uint64]),
+    "jfgpu_bc_opt_k": (C.c_uint32, [C.c_double]),
+    "jfgpu_bc_create": (C.c_int, [C.POINTER(BloomParams), C.POINTER(_P)]),
+    "jfgpu_bc_destroy": (None, [_P]),
+    "jfgpu_bc_insert_ascii_dev": (C.c_int, [_P, _P, C.c_size_t]),
+    "jfgpu_bc_insert_ascii": (C.c_int, [_P, _P, C.c_size_t]),
+    "jfgpu_bc_sync": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "jfgpu_bc_get_info": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), _P, _P]),
+    "jfgpu_bc_read": (C.c_int, [_P, _P]),
+    "jfgpu_bc_load": (C.c_int, [_P, _P]),
+    "jfgpu_bc_keys": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_int]),
+    "jfgpu_attach_bloom": (C.c_int, [_P, _P]),
     "jfgpu_set_mode": (C.c_int, [_P, C.c_int]),
     "jfgpu_reserve": (C.c_int, [_P, C.c_uint64]),
     "jfgpu_profile_enable": (C.c_int, [_P, C.c_int]),
@@ -240,6 +258,11 @@ class Table:
         finally:
             _check(self._lib.jfgpu_dump_end(self._h))
 
+    def attach_bloom(self, bloom):
+        """count --bc: admit only k-mers the Bloom counter has seen at least twice (None detaches)."""
+        self._bloom = bloom
+        _check(self._lib.jfgpu_attach_bloom(self._h, bloom._h if bloom is not None else None))
+
     def set_mode(self, mode):
         """0 auto, 1 direct (global atomics), 2 partitioned (LDS tiles)."""
         _check(self._lib.jfgpu_set_mode(self._h, mode))
@@ -283,6 +306,79 @@ class Table:
         out = np.zeros(nbytes, dtype=np.uint8)
         _check(self._lib.jfgpu_memcpy_d2h(self._h, out.ctypes.data, d_src, nbytes))
         return out
+
+
+class Bloom:
+    """Bloom counter of `jellyfish bc` in HBM (jfgpu_bloom*)."""
+
+    def __init__(self, k, m, nb_hashes, canonical=True, device=-1, seed=0, matrix1=None, matrix2=None):
+        self._lib = load()
+        p = BloomParams()
+        p.k, p.canonical, p.m, p.nb_hashes, p.device, p.seed = k, int(bool(canonical)), int(m), int(nb_hashes), device, seed
+        self._m1 = self._m2 = None
+        if matrix1 is not None:
+            self._m1 = np.ascontiguousarray(matrix1, dtype=np.uint64)
+            self._m2 = np.ascontiguousarray(matrix2, dtype=np.uint64)
+            p.matrix1 = self._m1.ctypes.data_as(C.POINTER(C.c_uint64))
+            p.matrix2 = self._m2.ctypes.data_as(C.POINTER(C.c_uint64))
+        h = _P()
+        _check(self._lib.jfgpu_bc_create(C.byref(p), C.byref(h)))
+        self._h = h
+        self.k = k
+        m_, nh, nbytes = C.c_uint64(), C.c_uint32(), C.c_uint64()
+        self.matrix1 = np.zeros(2 * k, dtype=np.uint64)
+        self.matrix2 = np.zeros(2 * k, dtype=np.uint64)
+        _check(self._lib.jfgpu_bc_get_info(self._h, C.byref(m_), C.byref(nh), C.byref(nbytes), self.matrix1.ctypes.data, self.matrix2.ctypes.data))
+        self.m, self.nb_hashes, self.nb_bytes = m_.value, nh.value, nbytes.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.jfgpu_bc_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def insert_ascii(self, bases: bytes):
+        buf = np.frombuffer(bases, dtype=np.uint8)
+        _check(self._lib.jfgpu_bc_insert_ascii(self._h, buf.ctypes.data if len(bases) else None, len(bases)))
+
+    def insert_ascii_dev(self, d_ptr, n):
+        _check(self._lib.jfgpu_bc_insert_ascii_dev(self._h, _ptr(d_ptr), n))
+
+    def sync(self):
+        n = C.c_uint64()
+        _check(self._lib.jfgpu_bc_sync(self._h, C.byref(n)))
+        return n.value
+
+    def read(self):
+        out = np.zeros(self.nb_bytes, dtype=np.uint8)
+        _check(self._lib.jfgpu_bc_read(self._h, out.ctypes.data))
+        return out
+
+    def load(self, data):
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        assert len(data) == self.nb_bytes
+        _check(self._lib.jfgpu_bc_load(self._h, data.ctypes.data))
+
+    def keys(self, keys, insert=False):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        out = np.zeros(len(keys), dtype=np.uint8)
+        _check(self._lib.jfgpu_bc_keys(self._h, keys.ctypes.data, len(keys), out.ctypes.data, int(insert)))
+        return out
+
+
+def opt_m(fp, n):
+    return load().jfgpu_bc_opt_m(fp, n)
+
+
+def opt_k(fp):
+    return load().jfgpu_bc_opt_k(fp)
 
 
 def decode_records(recs: np.ndarray, k: int, counter_len: int):

@@ -85,7 +85,7 @@ int count_main(int argc, char* argv[]) {
   uint64_t size = 0, lower = 0, upper = std::numeric_limits<uint64_t>::max();
   bool size_given = false, lower_given = false, upper_given = false, canonical = false, text = false, no_write = false;
   int device = -1;
-  std::string output = "mer_counts.jf", timing;
+  std::string output = "mer_counts.jf", timing, bc_path;
   std::vector<std::string> files;
   ArgCursor a{argc, argv};
   for(; a.more(); ++a.i) {
@@ -101,11 +101,12 @@ int count_main(int argc, char* argv[]) {
     else if(a.is("-U", "--upper-count")) { upper = strtoull(a.value("-U", "--upper-count").c_str(), 0, 10); upper_given = true; }
     else if(a.is("", "--timing")) timing = a.value("", "--timing");
     else if(a.is("", "--device")) device = atoi(a.value("", "--device").c_str());
+    else if(a.is("", "--bc")) bc_path = a.value("", "--bc");
     else if(a.cur() == "-C" || a.cur() == "--canonical") canonical = true;
     else if(a.cur() == "--text") text = true;
     else if(a.cur() == "--no-write") no_write = true;
     else if(a.cur() == "--disk" || a.cur() == "--no-merge" || a.cur() == "--no-unlink") { /* spill-to-disk knobs: the table lives in HBM */ }
-    else if(a.is("", "--bc") || a.is("", "--bf-size") || a.is("", "--bf-fp") || a.is("", "--if") || a.is("-Q", "--min-qual-char") ||
+    else if(a.is("", "--bf-size") || a.is("", "--bf-fp") || a.is("", "--if") || a.is("-Q", "--min-qual-char") ||
             a.is("-q", "--min-quality") || a.is("-g", "--generator") || a.is("-G", "--Generators") || a.is("", "--sam"))
       die("Option '" + a.cur() + "' is not supported by jellyfish-amd yet");
     else if(a.cur() == "-h" || a.cur() == "--help") {
@@ -142,6 +143,27 @@ int count_main(int argc, char* argv[]) {
     ary.reset(new mer_hash(size, mer_len * 2, counter_len, threads, reprobes, canonical, device, out_counter_len));
   } catch(std::exception& e) { die(std::string("Failed to allocate the hash: ") + e.what()); }
 
+  // Bloom counter read from file to filter out low frequency k-mers, two pass algorithm
+  // (load_bloom_filter, count_main.cc:191-206,313-316)
+  jfgpu_bloom* bc = nullptr;
+  if(!bc_path.empty()) {
+    std::ifstream in(bc_path, std::ios::in | std::ios::binary);
+    file_header bh(in);
+    if(!in.good()) die("Failed to parse bloom filter file '" + bc_path + "'");
+    if(bh.format() != "bloomcounter") die("Invalid format '" + bh.format() + "'. Expected 'bloomcounter'");
+    if(bh.key_len() != mer_len * 2) die("Invalid mer length in bloom filter");
+    header_matrix m1 = bh.matrix(1), m2 = bh.matrix(2);
+    jfgpu_bloom_params bp;
+    memset(&bp, 0, sizeof bp);
+    bp.k = mer_len; bp.canonical = canonical; bp.m = bh.size(); bp.nb_hashes = (uint32_t)bh.nb_hashes(); bp.device = device;
+    bp.matrix1 = m1.columns.data(); bp.matrix2 = m2.columns.data();
+    if(jfgpu_bc_create(&bp, &bc)) die(std::string("Failed to create the bloom filter: ") + jfgpu_last_error());
+    std::vector<uint8_t> body(bh.size() / 5 + (bh.size() % 5 != 0));
+    in.read((char*)body.data(), body.size());
+    if(!in.good()) die("Bloom filter file is truncated");
+    if(jfgpu_bc_load(bc, body.data()) || jfgpu_attach_bloom(ary->handle(), bc)) die(jfgpu_last_error());
+  }
+
   std::unique_ptr<dumper_base> dumper;
   if(text) dumper.reset(new text_dumper(threads, output.c_str(), &header));
   else dumper.reset(new binary_dumper(out_counter_len, ary->key_len(), threads, output.c_str(), &header));
@@ -167,11 +189,85 @@ int count_main(int argc, char* argv[]) {
   }
   const double write_s = seconds_since(write_start);
 
+  if(bc) { jfgpu_attach_bloom(ary->handle(), nullptr); jfgpu_bc_destroy(bc); }
+
   if(!timing.empty()) {   // count_main.cc:375-382
     std::ofstream tf(timing);
     tf << "Init     " << init_s << "\n"
        << "Counting " << count_s << "\n"
        << "Writing  " << write_s << "\n";
+  }
+  return 0;
+}
+
+
+// ---------------------------------------------------------------- bc  (sub_commands/bc_main.cc:84-161)
+int bc_main(int argc, char* argv[]) {
+  auto start_time = std::chrono::steady_clock::now();
+  file_header header;
+  header.fill_standard();
+  header.set_cmdline(argc, argv);
+  unsigned mer_len = 0; uint64_t size = 0; double fpr = 0.001; bool canonical = false, size_given = false;
+  int device = -1;
+  std::string output = "mer_bloom_filter", timing;
+  std::vector<std::string> files;
+  ArgCursor a{argc, argv};
+  for(; a.more(); ++a.i) {
+    if(a.is("-m", "--mer-len")) mer_len = (unsigned)strtoul(a.value("-m", "--mer-len").c_str(), 0, 10);
+    else if(a.is("-s", "--size")) { size = parse_suffix(a.value("-s", "--size"), "-s"); size_given = true; }
+    else if(a.is("-f", "--fpr")) fpr = atof(a.value("-f", "--fpr").c_str());
+    else if(a.is("-t", "--threads")) (void)a.value("-t", "--threads");
+    else if(a.is("-F", "--Files")) (void)a.value("-F", "--Files");
+    else if(a.is("-o", "--output")) output = a.value("-o", "--output");
+    else if(a.is("", "--timing")) timing = a.value("", "--timing");
+    else if(a.is("", "--device")) device = atoi(a.value("", "--device").c_str());
+    else if(a.cur() == "-C" || a.cur() == "--canonical") canonical = true;
+    else if(a.cur().size() > 1 && a.cur()[0] == '-') die("Unknown option '" + a.cur() + "'");
+    else files.push_back(a.cur());
+  }
+  if(!mer_len) die("Error: mandatory switch missing: -m, --mer-len");
+  if(!size_given) die("Error: mandatory switch missing: -s, --size");
+  if(files.empty()) die("Error: at least 1 file argument is required");
+  if(mer_len > 32) die("jellyfish-amd: mer length > 32 is not built yet");
+  mer_dna::k(mer_len);
+  header.canonical(canonical);
+  std::ofstream out(output, std::ios::binary | std::ios::trunc);
+  if(!out.good()) die("Can't open output file '" + output + "'");
+  jfgpu_bloom_params bp;
+  memset(&bp, 0, sizeof bp);
+  bp.k = mer_len; bp.canonical = canonical; bp.device = device;
+  bp.m = jfgpu_bc_opt_m(fpr, size); bp.nb_hashes = jfgpu_bc_opt_k(fpr);
+  jfgpu_bloom* bc = nullptr;
+  if(jfgpu_bc_create(&bp, &bc)) die(std::string("Failed to create the bloom filter: ") + jfgpu_last_error());
+  uint64_t m = 0, nbytes = 0; uint32_t nh = 0;
+  header_matrix m1, m2;
+  m1.r = m2.r = 64; m1.c = m2.c = 2 * mer_len; m1.columns.assign(m1.c, 0); m2.columns.assign(m2.c, 0);
+  jfgpu_bc_get_info(bc, &m, &nh, &nbytes, m1.columns.data(), m2.columns.data());
+  header.format("bloomcounter");
+  header.key_len(mer_len * 2);
+  header.matrix(m1, 1);
+  header.matrix(m2, 2);
+  header.size(m);
+  header.nb_hashes(nh);
+  header.write(out);
+  const double init_s = seconds_since(start_time);
+  auto count_start = std::chrono::steady_clock::now();
+  try {
+    sequence_parser parser(mer_len);
+    for(const auto& f : files)
+      parser.parse_file(f.c_str(), [&](const char* buf, size_t n) { if(jfgpu_bc_insert_ascii(bc, buf, n)) throw std::runtime_error(jfgpu_last_error()); });
+    if(jfgpu_bc_sync(bc, nullptr)) throw std::runtime_error(jfgpu_last_error());
+  } catch(std::exception& e) { die(e.what()); }
+  const double count_s = seconds_since(count_start);
+  auto write_start = std::chrono::steady_clock::now();
+  std::vector<uint8_t> body(nbytes);
+  if(jfgpu_bc_read(bc, body.data())) die(jfgpu_last_error());
+  out.write((const char*)body.data(), body.size());
+  out.close();
+  jfgpu_bc_destroy(bc);
+  if(!timing.empty()) {
+    std::ofstream tf(timing);
+    tf << "Init     " << init_s << "\n" << "Counting " << count_s << "\n" << "Writing  " << seconds_since(write_start) << "\n";
   }
   return 0;
 }
@@ -367,7 +463,7 @@ int info_main(int argc, char* argv[]) {
 int main(int argc, char* argv[]) {
   const char* usage =
       "Usage: jellyfish-amd <cmd> [options] arg...\n"
-      "Where <cmd> is one of: count, stats, histo, dump, query, info.\n"
+      "Where <cmd> is one of: count, bc, stats, histo, dump, query, info.\n"
       "Options:\n  --version        Display version\n  --help           Display this message\n";
   if(argc < 2) { std::cerr << "Too few arguments\n" << usage; return 1; }
   const std::string cmd = argv[1];
@@ -375,6 +471,7 @@ int main(int argc, char* argv[]) {
   if(cmd == "--help" || cmd == "-h") { std::cout << usage; return 0; }
   try {
     if(cmd == "count") return count_main(argc - 1, argv + 1);
+    if(cmd == "bc") return bc_main(argc - 1, argv + 1);
     if(cmd == "dump") return dump_main(argc - 1, argv + 1);
     if(cmd == "histo") return histo_main(argc - 1, argv + 1);
     if(cmd == "stats") return stats_main(argc - 1, argv + 1);

@@ -35,6 +35,16 @@ constexpr int kTilePos = kBlock * kPerThread;  // 4096 sequence positions per bl
 
 enum Counter : int { CTR_FULL = 0, CTR_MERS = 1, CTR_OVF_FULL = 2, CTR_OVF_USED = 3, CTR_MISROUTED = 4, CTR_DIRECT = 5, CTR_COUNT = 8 };
 
+// Bloom counter view (kernels_bloom.hip.hpp); data == nullptr: no filter attached.
+struct DevBloom {
+  uint32_t* data;             // ceil(m/5) bytes, addressed as dwords
+  uint64_t m;                 // number of base-3 cells
+  uint32_t nh;                // hash functions per key
+  uint32_t nbytes;            // key bytes fed to the tables
+  const uint64_t* tbl1;       // byte tables of the two 64-row matrices
+  const uint64_t* tbl2;
+};
+
 struct DevTable {
   TableGeom g;
   uint64_t* slots;            // [1 << lsize_l]
@@ -45,6 +55,7 @@ struct DevTable {
   uint64_t ovf_mask;          // capacity - 1
   uint64_t* counters;         // [CTR_COUNT]
   uint32_t max_probe;         // last probe index tried before declaring the tile full
+  DevBloom bloom;             // count --bc filter (data == nullptr: none)
   uint8_t* dirty;             // one byte per tile: something was ever inserted (tile_insert may skip reading clean tiles)
 };
 
@@ -52,6 +63,8 @@ struct DevTable {
 // global store of the wave (s_waitcnt vmcnt(0)), which serialises "write a chunk to HBM" with
 // "start the next chunk" in the streaming kernels; here the only cross-wave traffic is LDS.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ inline bool bloom_admits(const DevBloom& B, uint64_t key);   // kernels_bloom.hip.hpp
 
 // ---- overflow side table ----------------------------------------------------
 // A slot's count field wrapped: remember `units` x 2^cnt_bits for that slot.  Keyed by
@@ -218,6 +231,7 @@ __global__ __launch_bounds__(kBlock) void count_ascii_kernel(DevTable T, const u
     uint64_t prev = 0; uint32_t run = 0;
     for_each_kmer(T.g, L, [&](int, uint64_t key) {
       ++my_mers;
+      if(T.bloom.data && !bloom_admits(T.bloom, key)) return;     // count --bc (count_main.cc:115-118)
       if(run && key == prev) { ++run; return; }
       if(run) table_add<RETURNING>(T, s_fwd, prev, run);
       prev = key; run = 1;

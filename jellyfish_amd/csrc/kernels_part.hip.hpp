@@ -109,6 +109,7 @@ __global__ __launch_bounds__(kPBlock) void p1_kernel(DevTable T, PartGeom P, con
       };
       for_each_kmer(T.g, L, [&](int, uint64_t key) {
         ++my_mers;
+        if(T.bloom.data && !bloom_admits(T.bloom, key)) return;   // count --bc; read-only, so both passes agree
         if(run && key == prev) { ++run; return; }
         flush_run();
         prev = key; run = 1;
@@ -277,6 +278,7 @@ __global__ __launch_bounds__(kPBlock) void p1_scatter_sorted_kernel(DevTable T, 
       }
     };
     for_each_kmer(T.g, L, [&](int j, uint64_t key) {
+      if(T.bloom.data && !bloom_admits(T.bloom, key)) return;
       if(run && key == prev) { ++run; return; }
       flush_run(j);
       prev = key; run = 1;

@@ -72,6 +72,32 @@ def main():
         manifest["cases"].append({"name": name, "input": os.path.basename(path), "k": k, "canonical": canonical,
                                   "size": size, "ref_jf": os.path.basename(jf) if keep_jf else None,
                                   "distinct": len(dump)})
+    # ---- config 3: Bloom counter first pass (jellyfish bc) and count --bc ------------------------
+    # input in which roughly half of the reads occur twice, so the filter really separates k-mers
+    lines = open(fa).read().splitlines()
+    recs = [lines[i:i + 4] for i in range(0, len(lines), 4)]       # header + 3 sequence lines per 150-base read
+    dup = os.path.join(OUT, "reads150_dup.fa")
+    with open(dup, "w") as f:
+        for r in recs + recs[: len(recs) // 2]:
+            f.write("\n".join(r) + "\n")
+    for name, k, canonical in (("bc_k21C", 21, True), ("bc_k31", 31, False)):
+        bcf = os.path.join(OUT, name + ".ref.bc")
+        cmd = [REF_JF, "bc", "-m", str(k), "-s", "9000", "-f", "0.001", "-t", "2", "-o", bcf, dup]
+        if canonical:
+            cmd.insert(2, "-C")
+        subprocess.run(cmd, check=True, env=env, cwd=OUT)
+        jf = os.path.join(OUT, name + ".filtered.jf")
+        cmd = [REF_JF, "count", "-m", str(k), "-s", "64k", "-t", "2", "--bc", bcf, "-o", jf, dup]
+        if canonical:
+            cmd.insert(2, "-C")
+        subprocess.run(cmd, check=True, env=env, cwd=OUT)
+        d = sorted(run([REF_JF, "dump", "-c", jf]).splitlines())
+        with open(os.path.join(OUT, name + ".filtered.dump"), "w") as f:
+            f.write("\n".join(d) + "\n")
+        os.unlink(jf)
+        manifest.setdefault("bloom", []).append({"name": name, "input": "reads150_dup.fa", "k": k, "canonical": canonical,
+                                                 "n": 9000, "fpr": 0.001, "ref_bc": name + ".ref.bc", "kept": len(d)})
+
     # the reference's own golden md5s for this path (tests/parallel_hashing.sh:7-19), reproduced by
     # oracle/_ref at survey/build time; tests/test_oracle.py re-checks them whenever oracle/_ref exists
     manifest["reference_md5"] = {
@@ -85,6 +111,7 @@ def main():
         "binary.stats": "c30cba4fe2886cea4abb27f5c30ea35e",
         "m15_s2M_L2_U3.histo": "94625cd2d59e278f08421a673eb0926a",
         "query_one_count": "45fb383344e0fb0b7540718339be4c03",
+        "bloom_counter_noop.histo": "9251799dd5dbd3f617124aa2ff72112a",
     }
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1)

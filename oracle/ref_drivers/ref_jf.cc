@@ -10,6 +10,7 @@
 //   histo : sub_commands/histo_main.cc:34-90
 //   stats : sub_commands/stats_main.cc:33-79
 //   query : sub_commands/query_main.cc:44-123
+//   bc    : sub_commands/bc_main.cc:51-72,109-148 ; count --bc : count_main.cc:99-131,191-206,313-316
 // so its outputs ARE the reference's outputs for the hot path.  Only tests/,
 // __graft_entry__.smoke() and bench.py's cpu_baseline leg may execute it.
 #include <config.h>
@@ -31,6 +32,7 @@
 #include <jellyfish/mer_overlap_sequence_parser.hpp>
 #include <jellyfish/mer_iterator.hpp>
 #include <jellyfish/mapped_file.hpp>
+#include <jellyfish/mer_dna_bloom_counter.hpp>
 #include <jellyfish/jellyfish.hpp>
 
 using jellyfish::mer_dna;
@@ -49,15 +51,18 @@ class ref_counter : public jellyfish::thread_exec {
   mer_hash&       ary_;
   sequence_parser parser_;
   bool            canonical_;
+  const jellyfish::mer_dna_bloom_counter* bc_;   // count --bc filter (count_main.cc:109-119), may be null
 public:
   std::vector<size_t> counts_;
-  ref_counter(int nb_threads, mer_hash& ary, stream_manager_type& streams, bool canonical)
+  ref_counter(int nb_threads, mer_hash& ary, stream_manager_type& streams, bool canonical,
+              const jellyfish::mer_dna_bloom_counter* bc = 0)
     : ary_(ary), parser_(mer_dna::k(), streams.nb_streams(), 3 * nb_threads, 4096, streams),
-      canonical_(canonical), counts_(nb_threads, 0) { ary_.reset_done(); }
+      canonical_(canonical), bc_(bc), counts_(nb_threads, 0) { ary_.reset_done(); }
   virtual void start(int thid) {
     size_t count = 0;
     for(mer_iterator_type mers(parser_, canonical_); mers; ++mers) {
-      ary_.add(*mers, 1);
+      if(!bc_ || bc_->check(*mers) > 1)
+        ary_.add(*mers, 1);
       ++count;
     }
     counts_[thid] = count;
@@ -82,6 +87,7 @@ static int do_count(int argc, char* argv[]) {
   bool        canonical = false, text = false, no_write = false, lower_given = false, upper_given = false;
   const char* output = "mer_counts.jf";
   const char* timing = 0;
+  const char* bc_path = 0;
   file_vector files;
   for(int i = 1; i < argc; ++i) {
     std::string a(argv[i]);
@@ -100,6 +106,7 @@ static int do_count(int argc, char* argv[]) {
     else if(a == "--text") text = true;
     else if(a == "--no-write") no_write = true;
     else if(a == "--timing") timing = next();
+    else if(a == "--bc") bc_path = next();
     else files.push_back(argv[i]);
   }
   if(!k || !size || files.empty()) {
@@ -119,9 +126,17 @@ static int do_count(int argc, char* argv[]) {
   ary.dumper(dumper.get());
   double t1 = now_s();
 
+  std::unique_ptr<jellyfish::mer_dna_bloom_counter> bc;
+  if(bc_path) {   // load_bloom_filter, count_main.cc:191-206
+    std::ifstream in(bc_path, std::ios::in | std::ios::binary);
+    jellyfish::file_header bh(in);
+    if(!in.good() || bh.format() != "bloomcounter" || bh.key_len() != k * 2) { std::cerr << "bad bloom counter file\n"; return 1; }
+    jellyfish::hash_pair<mer_dna> fns(bh.matrix(1), bh.matrix(2));
+    bc.reset(new jellyfish::mer_dna_bloom_counter(bh.size(), bh.nb_hashes(), in, fns));
+  }
   stream_manager_type streams(Files);
   streams.paths(files.begin(), files.end());
-  ref_counter counter(threads, ary, streams, canonical);
+  ref_counter counter(threads, ary, streams, canonical, bc.get());
   counter.exec_join(threads);
   double t2 = now_s();
   size_t total = 0;
@@ -141,6 +156,60 @@ static int do_count(int argc, char* argv[]) {
        << "Writing  " << (t3 - t2) << "\n"
        << "Mers     " << total << "\n";
   }
+  return 0;
+}
+
+
+// ---- bc: jellyfish bc (Bloom counter first pass), bc_main.cc:51-72,109-148 ----
+class ref_bloom_counter : public jellyfish::thread_exec {
+  jellyfish::mer_dna_bloom_counter& filter_;
+  sequence_parser                   parser_;
+  bool                              canonical_;
+public:
+  ref_bloom_counter(int nb_threads, jellyfish::mer_dna_bloom_counter& filter, stream_manager_type& streams, bool canonical)
+    : filter_(filter), parser_(mer_dna::k(), streams.nb_streams(), 3 * nb_threads, 4096, streams), canonical_(canonical) { }
+  virtual void start(int thid) {
+    for(mer_iterator_type mers(parser_, canonical_); mers; ++mers) filter_.insert(*mers);
+  }
+};
+
+static int do_bc(int argc, char* argv[]) {
+  unsigned k = 0, threads = 1; uint64_t size = 0; double fpr = 0.001; bool canonical = false;
+  const char* output = "mer_bloom_filter";
+  file_vector files;
+  for(int i = 1; i < argc; ++i) {
+    std::string a(argv[i]);
+    if(a == "-m") k = atoi(argv[++i]);
+    else if(a == "-s") size = parse_size(argv[++i]);
+    else if(a == "-t") threads = atoi(argv[++i]);
+    else if(a == "-f") fpr = atof(argv[++i]);
+    else if(a == "-o") output = argv[++i];
+    else if(a == "-C") canonical = true;
+    else files.push_back(argv[i]);
+  }
+  if(!k || !size || files.empty()) { std::cerr << "usage: ref_jf bc -m K -s N [-f fpr] [-C] [-t T] [-o out] files...\n"; return 1; }
+  jellyfish::file_header header;
+  header.fill_standard();
+  header.set_cmdline(argc, argv);
+  mer_dna::k(k);
+  header.canonical(canonical);
+  std::ofstream out(output);
+  if(!out.good()) { std::cerr << "Can't open output file\n"; return 1; }
+  header.format("bloomcounter");
+  header.key_len(k * 2);
+  jellyfish::hash_pair<mer_dna> hash_fns;
+  header.matrix(hash_fns.m1, 1);
+  header.matrix(hash_fns.m2, 2);
+  jellyfish::mer_dna_bloom_counter filter(fpr, size, hash_fns);
+  header.size(filter.m());
+  header.nb_hashes(filter.k());
+  header.write(out);
+  stream_manager_type streams(1);
+  streams.paths(files.begin(), files.end());
+  ref_bloom_counter counter(threads, filter, streams, canonical);
+  counter.exec_join(threads);
+  filter.write_bits(out);
+  out.close();
   return 0;
 }
 
@@ -296,7 +365,7 @@ static int do_header(int argc, char* argv[]) {
 }
 
 int main(int argc, char* argv[]) {
-  if(argc < 2) { std::cerr << "usage: ref_jf <count|dump|histo|stats|query|header> ...\n"; return 1; }
+  if(argc < 2) { std::cerr << "usage: ref_jf <count|bc|dump|histo|stats|query|header> ...\n"; return 1; }
   std::string cmd(argv[1]);
   try {
     if(cmd == "count")  return do_count(argc - 1, argv + 1);
@@ -305,6 +374,7 @@ int main(int argc, char* argv[]) {
     if(cmd == "stats")  return do_stats(argc - 1, argv + 1);
     if(cmd == "query")  return do_query(argc - 1, argv + 1);
     if(cmd == "header") return do_header(argc - 1, argv + 1);
+    if(cmd == "bc")     return do_bc(argc - 1, argv + 1);
   } catch(std::exception& e) {
     std::cerr << "ref_jf: " << e.what() << "\n";
     return 1;

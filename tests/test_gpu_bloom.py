@@ -1,0 +1,109 @@
+"""BASELINE config 3 on the GPU (-m gpu): Bloom-counter first pass (`jellyfish bc`) and `count --bc`,
+bit/byte-exact against the reference's golden files and the oracle restatement."""
+import json
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from test_oracle import read_bc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+MANIFEST = json.load(open(os.path.join(GOLD, "manifest.json")))
+
+
+@pytest.mark.parametrize("case", MANIFEST["bloom"], ids=lambda c: c["name"])
+def test_bloom_bytes_identical_to_reference(gpu, case):
+    header, body = read_bc(os.path.join(GOLD, case["ref_bc"]))
+    k, can = case["k"], case["canonical"]
+    m1 = np.array(header["matrix1"]["columns"], dtype=np.uint64)
+    m2 = np.array(header["matrix2"]["columns"], dtype=np.uint64)
+    seq = O.parse_file(open(os.path.join(GOLD, case["input"]), "rb").read())
+    with gpu.Bloom(k, header["size"], header["nb_hashes"], canonical=can, matrix1=m1, matrix2=m2) as b:
+        assert b.nb_bytes == len(body)
+        b.insert_ascii(seq)
+        assert b.sync() == len(O.extract(seq, k, can))
+        assert (b.read() == body).all()                       # same file body as jellyfish bc wrote
+        # check() on encoded k-mers: everything inserted reads back >= 1; twice-seen k-mers read 2
+        keys, cnt = O.count(seq, k, can)
+        chk = b.keys(keys[:, 0])
+        assert ((chk == 2) | (cnt < 2)).all() and (chk >= 1).all()
+        # count --bc: only k-mers the filter saw at least twice are admitted (count_main.cc:115-118)
+        golden = open(os.path.join(GOLD, case["name"] + ".filtered.dump")).read().splitlines()
+        for mode in (1, 2):
+            with gpu.Table(k, 1 << 16, canonical=can) as t:
+                t.set_mode(mode)
+                t.attach_bloom(b)
+                t.count_ascii(seq)
+                t.sync()
+                recs = t.dump_records()
+                kk, cc = gpu.decode_records(recs, k, 4)
+                got = sorted("%s %d" % (O.to_str(np.array([a], dtype=np.uint64), k), c) for a, c in zip(kk.tolist(), cc.tolist()))
+                assert got == golden, mode
+                assert t.stats().mers_fed == len(O.extract(seq, k, can))     # ++count for every mer, filtered or not
+                t.attach_bloom(None)
+
+
+def test_bloom_against_oracle_on_random_input(gpu):
+    """Own random matrices, larger input with lower-case / N resets, saturation at 2, load() round trip."""
+    rng = random.Random(41)
+    k = 25
+    seq = "".join(rng.choice("ACGTacgtN") for _ in range(200000)).encode()
+    seq = seq + seq[:60000]                                   # part of it twice
+    n = 150000
+    m, nh = gpu.opt_m(0.001, n), gpu.opt_k(0.001)
+    assert (m, nh) == (14 * n, 10)
+    with gpu.Bloom(k, m, nh, canonical=True, seed=5) as b:
+        b.insert_ascii(seq)
+        b.sync()
+        got = b.read()
+        kmers = O.extract(seq, k, True)
+        h0 = O.matrix_times(b.matrix1, 64, 2 * k, kmers)
+        h1 = O.matrix_times(b.matrix2, 64, 2 * k, kmers)
+        data = np.zeros(b.nb_bytes, dtype=np.uint8)
+        L = O.lib()
+        for x, y in zip(h0.tolist(), h1.tolist()):
+            L.jfo_bc_insert(data.ctypes.data, m, nh, x, y)
+        assert (got == data).all()
+        assert got.max() <= 242
+        with gpu.Bloom(k, m, nh, canonical=True, matrix1=b.matrix1, matrix2=b.matrix2) as c:
+            c.load(got)
+            sample = kmers[::97, 0]
+            assert (c.keys(sample) == b.keys(sample)).all()
+            assert (c.keys(sample, insert=True) == b.keys(sample)).all()      # insert returns the previous minimum
+
+
+def test_cli_bc_and_count_bc(gpu, tmp_path):
+    """jellyfish-amd bc writes a bloomcounter file the REFERENCE loads (ref_jf count --bc), and
+    jellyfish-amd count --bc on the reference's golden .bc gives the reference's filtered dump."""
+    subprocess.check_call(["make", "-s", "cli"], cwd=ROOT)
+    cli = os.path.join(ROOT, "bin", "jellyfish-amd")
+    case = MANIFEST["bloom"][0]
+    inp = os.path.join(GOLD, case["input"])
+    out = str(tmp_path / "f.jf")
+    subprocess.check_call([cli, "count", "-m", "21", "-C", "-s", "64k", "--bc", os.path.join(GOLD, case["ref_bc"]), "-o", out, inp])
+    got = sorted(subprocess.check_output([cli, "dump", "-c", out]).decode().splitlines())
+    assert got == open(os.path.join(GOLD, case["name"] + ".filtered.dump")).read().splitlines()
+    mine = str(tmp_path / "mine.bc")
+    subprocess.check_call([cli, "bc", "-m", "21", "-C", "-s", "9000", "-o", mine, inp])
+    header, body = read_bc(mine)
+    assert header["format"] == "bloomcounter" and header["size"] == 126000 and header["nb_hashes"] == 10
+    assert len(body) == 25200 and header["matrix1"]["r"] == 64 and len(header["matrix2"]["columns"]) == 42
+    out2 = str(tmp_path / "f2.jf")
+    subprocess.check_call([cli, "count", "-m", "21", "-C", "-s", "64k", "--bc", mine, "-o", out2, inp])
+    a = sorted(subprocess.check_output([cli, "dump", "-c", out2]).decode().splitlines())
+    if O.have_ref():
+        out3 = str(tmp_path / "f3.jf")
+        subprocess.check_call([O.REF_JF, "count", "-m", "21", "-C", "-s", "64k", "--bc", mine, "-o", out3, inp])
+        b = sorted(subprocess.check_output([O.REF_JF, "dump", "-c", out3]).decode().splitlines())
+        assert a == b
+    # every k-mer that truly occurs at least twice survives any correct filter
+    seq = O.parse_file(open(inp, "rb").read())
+    keys, cnt = O.count(seq, 21, True)
+    twice = {O.to_str(keys[i], 21) for i in range(len(keys)) if cnt[i] >= 2}
+    assert twice <= {l.split()[0] for l in a}

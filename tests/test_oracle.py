@@ -176,3 +176,39 @@ def test_oracle_ref_reproduces_reference_golden_md5(tmp_path):
     assert md5([O.REF_JF, "stats", "bin.jf"]) == g["binary.stats"]
     subprocess.check_call([O.REF_JF, "count", "-t", "4", "-o", "lu.jf", "-s", "2M", "-C", "-m", "15", "-L", "2", "-U", "3", "seq10m.fa"], cwd=d)
     assert md5([O.REF_JF, "histo", "lu.jf"]) == g["m15_s2M_L2_U3.histo"]
+
+
+def read_bc(path):
+    data = open(path, "rb").read()
+    hlen = int(data[:9])
+    header = json.loads(data[9:9 + hlen].rstrip(b"\0"))
+    return header, np.frombuffer(data[9 + hlen:], dtype=np.uint8)
+
+
+@pytest.mark.parametrize("case", MANIFEST["bloom"], ids=lambda c: c["name"])
+def test_bloom_restatement_reproduces_reference_file(case):
+    """The reference wrote <name>.ref.bc (bc_main.cc:109-148).  Replaying row a14 of SURVEY 8(a)
+    (cells (h0 % m + i (h1 % m)) % m, saturating base-3 digits) with the file's own matrices must
+    give the byte-identical body, and `count --bc` (check > 1) the reference's filtered dump."""
+    header, body = read_bc(os.path.join(GOLD, case["ref_bc"]))
+    k, can = case["k"], case["canonical"]
+    assert header["format"] == "bloomcounter" and header["key_len"] == 2 * k
+    m, nh = header["size"], header["nb_hashes"]
+    assert m == 9000 * 14 and nh == 10 and len(body) == (m + 4) // 5       # opt_m / opt_k at fpr 0.001
+    m1 = np.array(header["matrix1"]["columns"], dtype=np.uint64)
+    m2 = np.array(header["matrix2"]["columns"], dtype=np.uint64)
+    seq = O.parse_file(open(os.path.join(GOLD, case["input"]), "rb").read())
+    kmers = O.extract(seq, k, can)
+    h0 = O.matrix_times(m1, 64, 2 * k, kmers)
+    h1 = O.matrix_times(m2, 64, 2 * k, kmers)
+    data = np.zeros(len(body), dtype=np.uint8)
+    L = O.lib()
+    for a, b in zip(h0.tolist(), h1.tolist()):
+        L.jfo_bc_insert(data.ctypes.data, m, nh, a, b)
+    assert (data == body).all()
+    keys, cnt = O.count(seq, k, can)
+    kh0 = O.matrix_times(m1, 64, 2 * k, keys)
+    kh1 = O.matrix_times(m2, 64, 2 * k, keys)
+    kept = sorted("%s %d" % (O.to_str(keys[i], k), cnt[i]) for i in range(len(keys))
+                  if L.jfo_bc_check(data.ctypes.data, m, nh, int(kh0[i]), int(kh1[i])) > 1)
+    assert kept == open(os.path.join(GOLD, case["name"] + ".filtered.dump")).read().splitlines()
