@@ -12,7 +12,7 @@ all: engine cli oracle
 
 engine: $(LIBDIR)/libjfgpu.so
 
-$(LIBDIR)/libjfgpu.so: $(CSRC)/jfgpu.hip $(CSRC)/kernels.hip.hpp $(CSRC)/kmer_core.hpp $(CSRC)/gf2_matrix.hpp include/jfgpu.h
+$(LIBDIR)/libjfgpu.so: $(wildcard $(CSRC)/*.hip) $(wildcard $(CSRC)/*.hpp) include/jfgpu.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/jfgpu.hip
 

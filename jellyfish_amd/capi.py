@@ -163,6 +163,7 @@ class Table:
         self.info = Info()
         _check(self._lib.jfgpu_get_info(self._h, C.byref(self.info)))
         self.k = k
+        self.key_words = (2 * k + 63) // 64
 
     def close(self):
         if getattr(self, "_h", None):
@@ -201,7 +202,7 @@ class Table:
         _check(self._lib.jfgpu_count_ascii_dev(self._h, _ptr(d_ptr), n))
 
     def add_keys(self, keys, val=1, want_new=False):
-        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        keys = np.ascontiguousarray(keys, dtype=np.uint64).reshape(-1, self.key_words)   # (n, words) little-endian words
         is_new = np.zeros(len(keys), dtype=np.uint8) if want_new else None
         _check(self._lib.jfgpu_add_keys(self._h, keys.ctypes.data, len(keys), val, _ptr(is_new)))
         return is_new
@@ -210,7 +211,7 @@ class Table:
         _check(self._lib.jfgpu_add_keys_dev(self._h, _ptr(d_keys), n, val, _ptr(d_is_new)))
 
     def lookup(self, keys):
-        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        keys = np.ascontiguousarray(keys, dtype=np.uint64).reshape(-1, self.key_words)
         vals = np.zeros(len(keys), dtype=np.uint64)
         found = np.zeros(len(keys), dtype=np.uint8)
         _check(self._lib.jfgpu_lookup(self._h, keys.ctypes.data, len(keys), vals.ctypes.data, found.ctypes.data))
@@ -382,14 +383,16 @@ def opt_k(fp):
 
 
 def decode_records(recs: np.ndarray, k: int, counter_len: int):
-    """(n, record_bytes) uint8 -> (keys uint64 (n,), counts uint64 (n,)) for k <= 32
-    (binary_dumper.hpp:36-40 layout: ceil(2k/8) key bytes LE, then counter_len bytes LE)."""
+    """(n, record_bytes) uint8 -> (keys, counts uint64 (n,)); keys is uint64 (n,) for k <= 32 and
+    (n, ceil(k/32)) little-endian words otherwise (binary_dumper.hpp:36-40 layout: ceil(2k/8) key
+    bytes LE, then counter_len bytes LE)."""
     kb = (2 * k + 7) // 8
+    kw = (2 * k + 63) // 64
     n = len(recs)
-    keys = np.zeros(n, dtype=np.uint64)
+    keys = np.zeros((n, kw), dtype=np.uint64)
     cnts = np.zeros(n, dtype=np.uint64)
     for b in range(kb):
-        keys |= recs[:, b].astype(np.uint64) << np.uint64(8 * b)
+        keys[:, b // 8] |= recs[:, b].astype(np.uint64) << np.uint64(8 * (b % 8))
     for b in range(counter_len):
         cnts |= recs[:, kb + b].astype(np.uint64) << np.uint64(8 * b)
-    return keys, cnts
+    return (keys[:, 0] if kw == 1 else keys), cnts

@@ -133,7 +133,7 @@ int count_main(int argc, char* argv[]) {
   if(!size_given) die("Error: mandatory switch missing: -s, --size");
   if(files.empty()) die("Error: at least 1 file argument is required");
   (void)threads; (void)counter_len; (void)reprobes; (void)Files;
-  if(mer_len > 32) die("jellyfish-amd: mer length > 32 is not built yet");
+  if(mer_len > 64) die("jellyfish-amd: mer length > 64 is not built yet");
   if(text) out_counter_len = 8;   // text counts are not saturated (text_dumper.hpp:18-20)
 
   mer_dna::k(mer_len);

@@ -19,6 +19,7 @@
 #include "kernels.hip.hpp"
 #include "kernels_part.hip.hpp"
 #include "kernels_bloom.hip.hpp"
+#include "kernels_wide.hip.hpp"
 
 using namespace jfgpu;
 
@@ -60,6 +61,10 @@ struct jfgpu_table {
   uint64_t ovf_cap = 0;
   bool returning = false;
   uint32_t out_counter_len = 4;
+  // two-word keys (33 <= k <= 64): 128-bit slots, kernels_wide.hip.hpp
+  bool wide = false;
+  WideTable wt{};
+  uint32_t key_words = 1;
   // staging for host buffers
   uint8_t* d_stage[2] = {nullptr, nullptr};
   hipEvent_t stage_done[2] = {nullptr, nullptr};
@@ -171,6 +176,14 @@ int launch_count(jfgpu_table* t, const char* d_bases, size_t n) {
   if(n < t->g.k) return JFGPU_OK;
   const uint8_t* base; int64_t lo, hi;
   align_buffer(d_bases, n, base, lo, hi);
+  if(t->wide) {
+    const int64_t nt = (hi + kTilePos - 1) / kTilePos;
+    ProfScope ps(t, 0, n);
+    if(t->returning) hipLaunchKernelGGL(count_ascii_wide_kernel<true>, dim3(grid_for(t, (uint64_t)nt)), dim3(kBlock), 0, t->stream, t->wt, base, lo, hi);
+    else             hipLaunchKernelGGL(count_ascii_wide_kernel<false>, dim3(grid_for(t, (uint64_t)nt)), dim3(kBlock), 0, t->stream, t->wt, base, lo, hi);
+    HIP_TRY(hipGetLastError());
+    return JFGPU_OK;
+  }
   if(use_partitioned(t, n)) {
     const int rc = part_ingest(t, base, lo, hi, false, n);
     if(rc >= 0) return rc;          // < 0: no memory for the pending batch -> direct kernel below
@@ -179,8 +192,10 @@ int launch_count(jfgpu_table* t, const char* d_bases, size_t n) {
   const int64_t n_tiles = (hi + kTilePos - 1) / kTilePos;
   const int grid = grid_for(t, (uint64_t)n_tiles);
   ProfScope ps(t, 0, n);
-  if(t->returning) hipLaunchKernelGGL(count_ascii_kernel<true>, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, base, lo, hi);
-  else             hipLaunchKernelGGL(count_ascii_kernel<false>, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, base, lo, hi);
+  const bool bl = t->dt.bloom.data != nullptr;
+#define CA(RT, BL) hipLaunchKernelGGL((count_ascii_kernel<RT, BL>), dim3(grid), dim3(kBlock), 0, t->stream, t->dt, base, lo, hi)
+  if(t->returning) { if(bl) CA(true, true); else CA(true, false); } else { if(bl) CA(false, true); else CA(false, false); }
+#undef CA
   HIP_TRY(hipGetLastError());
   return JFGPU_OK;
 }
@@ -246,11 +261,12 @@ void launch_p1(jfgpu_table* t, bool scatter, bool from_keys, const uint8_t* base
                const uint64_t* d_off, void* d_items) {
   const dim3 grid(t->g1), block(kPBlock);
   ITEM* out = (ITEM*)d_items;
-#define P1(SC, FK, RT) hipLaunchKernelGGL((p1_kernel<ITEM, SC, FK, RT>), grid, block, 0, t->stream, t->dt, t->pg, base, lo, hi, t->d_M1, d_off, out)
-  const bool rt = t->returning;
-  if(!scatter) { if(from_keys) P1(false, true, false); else P1(false, false, false); }
-  else if(from_keys) { if(rt) P1(true, true, true); else P1(true, true, false); }
-  else { if(rt) P1(true, false, true); else P1(true, false, false); }
+#define P1(SC, FK, RT, BL) hipLaunchKernelGGL((p1_kernel<ITEM, SC, FK, RT, BL>), grid, block, 0, t->stream, t->dt, t->pg, base, lo, hi, t->d_M1, d_off, out)
+  const bool rt = t->returning, bl = t->dt.bloom.data != nullptr && !from_keys;   // the filter applies to the sequence feed only
+  if(!scatter) { if(from_keys) P1(false, true, false, false); else if(bl) P1(false, false, false, true); else P1(false, false, false, false); }
+  else if(from_keys) { if(rt) P1(true, true, true, false); else P1(true, true, false, false); }
+  else if(bl) { if(rt) P1(true, false, true, true); else P1(true, false, false, true); }
+  else { if(rt) P1(true, false, true, false); else P1(true, false, false, false); }
 #undef P1
 }
 
@@ -282,8 +298,10 @@ int part_ingest(jfgpu_table* t, const uint8_t* base, int64_t lo, int64_t hi, boo
     hipLaunchKernelGGL(scan_matrix_kernel, dim3(1), dim3(1024), 0, t->stream, t->d_M1, (uint32_t)t->g1, nb, (const uint64_t*)nullptr, b.off);
     if(t->item32 && !from_keys) {     // write-combining scatter (whole runs per bucket)
       const size_t lds = (size_t)kPTilePos * 6;
-      if(t->returning) hipLaunchKernelGGL(p1_scatter_sorted_kernel<true>, dim3(t->g1), dim3(kPBlock), lds, t->stream, t->dt, t->pg, base, lo, hi, (const uint32_t*)t->d_M1, (const uint64_t*)b.off, (uint32_t*)b.items);
-      else             hipLaunchKernelGGL(p1_scatter_sorted_kernel<false>, dim3(t->g1), dim3(kPBlock), lds, t->stream, t->dt, t->pg, base, lo, hi, (const uint32_t*)t->d_M1, (const uint64_t*)b.off, (uint32_t*)b.items);
+      const bool bl = t->dt.bloom.data != nullptr;
+#define PS(RT, BL) hipLaunchKernelGGL((p1_scatter_sorted_kernel<RT, BL>), dim3(t->g1), dim3(kPBlock), lds, t->stream, t->dt, t->pg, base, lo, hi, (const uint32_t*)t->d_M1, (const uint64_t*)b.off, (uint32_t*)b.items)
+      if(t->returning) { if(bl) PS(true, true); else PS(true, false); } else { if(bl) PS(false, true); else PS(false, false); }
+#undef PS
     }
     else if(t->item32) launch_p1<uint32_t>(t, true, from_keys, base, lo, hi, b.off, b.items);
     else               launch_p1<uint64_t>(t, true, from_keys, base, lo, hi, b.off, b.items);
@@ -418,7 +436,8 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
   if(!p || !out) return fail(JFGPU_E_INVALID, "null argument");
   *out = nullptr;
   if(p->k < 1) return fail(JFGPU_E_INVALID, "mer length must be >= 1");
-  if(p->k > 32) return fail(JFGPU_E_UNSUPPORTED, "mer length > 32 (multi-word keys) is not built yet");
+  if(p->k > 64) return fail(JFGPU_E_UNSUPPORTED, "mer length > 64 (more than two key words) is not built yet");
+  if(p->k > 32 && p->shard_bits) return fail(JFGPU_E_UNSUPPORTED, "sharded tables with mer length > 32 are not built yet");
   if(p->shard_bits > 8) return fail(JFGPU_E_INVALID, "at most 256 shards");
   if(p->shard_id >= (1u << p->shard_bits)) return fail(JFGPU_E_INVALID, "shard_id out of range");
   int ndev = 0;
@@ -430,20 +449,30 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
   HIP_TRY(hipSetDevice(dev));
 
   // size -> lsize (large_hash_array.hpp:156-157 rounds up to a power of two, :997-1000 caps at 4^k)
+  const bool wide = p->k > 32;
   uint32_t lsize = 0;
   while(lsize < 63 && (1ull << lsize) < p->size) ++lsize;
-  lsize = std::max(lsize, geom_min_lsize(p->k, p->shard_bits));
-  lsize = std::max(lsize, p->shard_bits);
-  lsize = std::max<uint32_t>(lsize, 1);
-  lsize = std::min<uint32_t>(lsize, 2 * p->k);
-  if(lsize < p->shard_bits) return fail(JFGPU_E_INVALID, "more shards than 4^k table positions");
+  if(wide) {
+    lsize = std::max(lsize, wide_min_lsize(p->k));
+    lsize = std::min<uint32_t>(lsize, 48);
+  } else {
+    lsize = std::max(lsize, geom_min_lsize(p->k, p->shard_bits));
+    lsize = std::max(lsize, p->shard_bits);
+    lsize = std::max<uint32_t>(lsize, 1);
+    lsize = std::min<uint32_t>(lsize, 2 * p->k);
+    if(lsize < p->shard_bits) return fail(JFGPU_E_INVALID, "more shards than 4^k table positions");
+  }
 
   std::unique_ptr<jfgpu_table> t(new jfgpu_table);
   t->params = *p; t->params.matrix_columns = nullptr;
   t->device = dev;
   t->out_counter_len = p->out_counter_len ? p->out_counter_len : 4;
   if(t->out_counter_len > 8) return fail(JFGPU_E_INVALID, "out_counter_len must be <= 8");
-  if(!geom_init(t->g, p->k, lsize, p->shard_bits, p->shard_id, p->canonical ? 1 : 0))
+  t->wide = wide; t->key_words = wide ? 2 : 1;
+  if(wide) {
+    if(!wide_geom_init(t->wt.W, p->k, lsize, p->canonical ? 1 : 0)) return fail(JFGPU_E_INVALID, "table geometry does not fit a 128-bit slot");
+    t->g = t->wt.W.g;
+  } else if(!geom_init(t->g, p->k, lsize, p->shard_bits, p->shard_id, p->canonical ? 1 : 0))
     return fail(JFGPU_E_INVALID, "table geometry does not fit a 64-bit slot");
 
   // hash matrix (large_hash_array.hpp:992-1001)
@@ -470,7 +499,7 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
 
   DevTable& d = t->dt;
   d.g = t->g;
-  HIP_TRY(hipMalloc((void**)&d.slots, n_slots * sizeof(uint64_t)));
+  HIP_TRY(hipMalloc((void**)&d.slots, n_slots * sizeof(uint64_t) * t->key_words));
   HIP_TRY(hipMalloc((void**)&t->d_fwd, fwd.size() * sizeof(uint64_t)));
   HIP_TRY(hipMalloc((void**)&t->d_inv, inv.size() * sizeof(uint64_t)));
   HIP_TRY(hipMalloc((void**)&d.ovf_key, t->ovf_cap * sizeof(uint64_t)));
@@ -486,8 +515,15 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
   // dump kernel needs > 64 KiB of dynamic LDS
   const size_t dump_lds = ((size_t)8 << t->g.tile_bits) + ((size_t)2 << t->g.tile_bits) + (size_t)t->g.nbytes * 2048;
   HIP_TRY(hipFuncSetAttribute((const void*)dump_tiles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dump_lds));
-  part_geom_init(t.get());
-  if(const char* m = getenv("JFGPU_MODE")) {
+  if(wide) {
+    WideTable& w = t->wt;
+    w.slots = d.slots; w.fwd_tbl = d.fwd_tbl; w.inv_tbl = d.inv_tbl; w.ovf_key = d.ovf_key; w.ovf_cnt = d.ovf_cnt;
+    w.ovf_mask = d.ovf_mask; w.counters = d.counters; w.max_probe = d.max_probe;
+    t->part_ok = false; t->mode = MODE_DIRECT;
+    const int wl = (int)(((size_t)16 << t->g.tile_bits) + ((size_t)2 << t->g.tile_bits));
+    HIP_TRY(hipFuncSetAttribute((const void*)dump_tiles_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
+  } else part_geom_init(t.get());
+  if(!wide) if(const char* m = getenv("JFGPU_MODE")) {
     if(!strcmp(m, "direct")) t->mode = MODE_DIRECT;
     else if(!strcmp(m, "partitioned")) t->mode = MODE_PARTITIONED;
   }
@@ -497,8 +533,10 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     TATTR(uint32_t, true, true); TATTR(uint32_t, true, false); TATTR(uint32_t, false, true); TATTR(uint32_t, false, false);
     TATTR(uint64_t, true, true); TATTR(uint64_t, true, false); TATTR(uint64_t, false, true); TATTR(uint64_t, false, false);
 #undef TATTR
-    HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_sorted_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
-    HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_sorted_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_sorted_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_sorted_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_sorted_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_sorted_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint32_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * 16 * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint64_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * 8 * 8));
   }
@@ -534,11 +572,11 @@ int jfgpu_get_info(const jfgpu_table* t, jfgpu_info* o) {
   o->k = t->g.k; o->key_len = t->g.key_bits; o->canonical = t->g.canonical;
   o->lsize = t->g.lsize_g; o->size = 1ull << t->g.lsize_g; o->local_size = 1ull << t->g.lsize_l;
   o->shard_bits = t->g.shard_bits; o->shard_id = t->g.shard_id;
-  o->val_len = t->g.cnt_bits; o->slot_bytes = 8; o->tile_slots = 1u << t->g.tile_bits;
+  o->val_len = t->g.cnt_bits; o->slot_bytes = 8 * t->key_words; o->tile_slots = 1u << t->g.tile_bits;
   o->matrix_identity = t->matrix.identity ? 1 : 0;
   o->out_counter_len = t->out_counter_len;
   o->max_reprobe = t->dt.max_probe;
-  o->table_bytes = (1ull << t->g.lsize_l) * 8;
+  o->table_bytes = (1ull << t->g.lsize_l) * 8 * t->key_words;
   return JFGPU_OK;
 }
 
@@ -551,7 +589,7 @@ int jfgpu_get_matrix(const jfgpu_table* t, uint64_t* columns) {
 int jfgpu_clear(jfgpu_table* t) {
   int rc = use(t); if(rc) return rc;
   part_discard(t);
-  HIP_TRY(hipMemsetAsync(t->dt.slots, 0, (1ull << t->g.lsize_l) * sizeof(uint64_t), t->stream));
+  HIP_TRY(hipMemsetAsync(t->dt.slots, 0, (1ull << t->g.lsize_l) * sizeof(uint64_t) * t->key_words, t->stream));
   HIP_TRY(hipMemsetAsync(t->dt.ovf_key, 0, t->ovf_cap * sizeof(uint64_t), t->stream));
   HIP_TRY(hipMemsetAsync(t->dt.ovf_cnt, 0, t->ovf_cap * sizeof(uint64_t), t->stream));
   HIP_TRY(hipMemsetAsync(t->dt.counters, 0, CTR_COUNT * sizeof(uint64_t), t->stream));
@@ -606,6 +644,12 @@ int jfgpu_add_keys_dev(jfgpu_table* t, const uint64_t* d_keys, size_t n, uint64_
   int rc = use(t); if(rc) return rc;
   if(!n) return JFGPU_OK;
   if(!d_keys) return fail(JFGPU_E_INVALID, "null keys");
+  if(t->wide) {
+    ProfScope ps(t, 1, n);
+    hipLaunchKernelGGL(add_keys_wide_kernel, dim3(grid_for(t, (n + kBlock - 1) / kBlock)), dim3(kBlock), 0, t->stream, t->wt, d_keys, (uint64_t)n, val, d_is_new);
+    HIP_TRY(hipGetLastError());
+    return JFGPU_OK;
+  }
   if(val == 1 && !d_is_new && use_partitioned(t, n * 8)) {
     const int prc = part_ingest(t, (const uint8_t*)d_keys, 0, (int64_t)n, true, n);
     if(prc >= 0) return prc;
@@ -628,9 +672,9 @@ int jfgpu_add_keys(jfgpu_table* t, const uint64_t* keys, size_t n, uint64_t val,
   int rc = use(t); if(rc) return rc;
   if(!n) return JFGPU_OK;
   uint64_t* d_k = nullptr; uint8_t* d_n = nullptr;
-  HIP_TRY(hipMalloc((void**)&d_k, n * sizeof(uint64_t)));
+  HIP_TRY(hipMalloc((void**)&d_k, n * sizeof(uint64_t) * t->key_words));
   if(is_new && hipMalloc((void**)&d_n, n) != hipSuccess) { hipFree(d_k); return fail(JFGPU_E_ALLOC, "hipMalloc is_new"); }
-  hipError_t e = hipMemcpyAsync(d_k, keys, n * sizeof(uint64_t), hipMemcpyHostToDevice, t->stream);
+  hipError_t e = hipMemcpyAsync(d_k, keys, n * sizeof(uint64_t) * t->key_words, hipMemcpyHostToDevice, t->stream);
   if(e == hipSuccess) { rc = jfgpu_add_keys_dev(t, d_k, n, val, d_n); }
   if(e == hipSuccess && !rc && is_new) e = hipMemcpyAsync(is_new, d_n, n, hipMemcpyDeviceToHost, t->stream);
   hipStreamSynchronize(t->stream);
@@ -649,6 +693,11 @@ int jfgpu_lookup_dev(jfgpu_table* t, const uint64_t* d_keys, size_t n, uint64_t*
   rc = check_deferred(t, c); if(rc) return rc;
   const int grid = grid_for(t, (n + kBlock - 1) / kBlock);
   ProfScope ps(t, 3, n);
+  if(t->wide) {
+    hipLaunchKernelGGL(lookup_wide_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->wt, d_keys, (uint64_t)n, d_vals, d_found, (int)(c[CTR_OVF_USED] != 0));
+    HIP_TRY(hipGetLastError());
+    return JFGPU_OK;
+  }
   hipLaunchKernelGGL(lookup_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, d_keys, (uint64_t)n, d_vals, d_found,
                      (int)(c[CTR_OVF_USED] != 0));
   HIP_TRY(hipGetLastError());
@@ -659,12 +708,12 @@ int jfgpu_lookup(jfgpu_table* t, const uint64_t* keys, size_t n, uint64_t* vals,
   int rc = use(t); if(rc) return rc;
   if(!n) return JFGPU_OK;
   uint64_t *d_k = nullptr, *d_v = nullptr; uint8_t* d_f = nullptr;
-  HIP_TRY(hipMalloc((void**)&d_k, n * sizeof(uint64_t)));
+  HIP_TRY(hipMalloc((void**)&d_k, n * sizeof(uint64_t) * t->key_words));
   if(hipMalloc((void**)&d_v, n * sizeof(uint64_t)) != hipSuccess || hipMalloc((void**)&d_f, n) != hipSuccess) {
     hipFree(d_k); if(d_v) hipFree(d_v);
     return fail(JFGPU_E_ALLOC, "hipMalloc lookup buffers");
   }
-  hipError_t e = hipMemcpyAsync(d_k, keys, n * sizeof(uint64_t), hipMemcpyHostToDevice, t->stream);
+  hipError_t e = hipMemcpyAsync(d_k, keys, n * sizeof(uint64_t) * t->key_words, hipMemcpyHostToDevice, t->stream);
   if(e == hipSuccess) rc = jfgpu_lookup_dev(t, d_k, n, d_v, d_f);
   if(e == hipSuccess && !rc) e = hipMemcpyAsync(vals, d_v, n * sizeof(uint64_t), hipMemcpyDeviceToHost, t->stream);
   if(e == hipSuccess && !rc && found) e = hipMemcpyAsync(found, d_f, n, hipMemcpyDeviceToHost, t->stream);
@@ -678,6 +727,7 @@ int jfgpu_partition_ascii_dev(jfgpu_table* t, const char* d_bases, size_t n, uin
                               uint64_t* counts_out) {
   int rc = use(t); if(rc) return rc;
   if(!counts_out) return fail(JFGPU_E_INVALID, "null counts_out");
+  if(t->wide) return fail(JFGPU_E_UNSUPPORTED, "hash-prefix partition with mer length > 32 is not built yet");
   const uint32_t n_shards = 1u << t->g.shard_bits;
   for(uint32_t i = 0; i < n_shards; ++i) counts_out[i] = 0;
   if(n < t->g.k) return JFGPU_OK;
@@ -723,7 +773,8 @@ int jfgpu_stats_compute(jfgpu_table* t, uint64_t lower, uint64_t upper, jfgpu_st
   HIP_TRY(hipMalloc((void**)&d, 4 * sizeof(unsigned long long)));
   HIP_TRY(hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), t->stream));
   const int grid = grid_for(t, (1ull << t->g.lsize_l) / kBlock + 1);
-  hipLaunchKernelGGL(stats_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, lower, upper, (int)(c[CTR_OVF_USED] != 0), d);
+  if(t->wide) hipLaunchKernelGGL(scan_wide_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->wt, 0, lower, upper, (int)(c[CTR_OVF_USED] != 0), 0ull, 0ull, 1ull, 1ull, d, (uint32_t*)nullptr);
+  else hipLaunchKernelGGL(stats_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, lower, upper, (int)(c[CTR_OVF_USED] != 0), d);
   unsigned long long h[4];
   hipError_t e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, t->stream);
   if(e == hipSuccess) e = hipStreamSynchronize(t->stream);
@@ -744,7 +795,8 @@ int jfgpu_histo(jfgpu_table* t, uint64_t base, uint64_t ceil, uint64_t inc, uint
   HIP_TRY(hipMalloc((void**)&d, nb * sizeof(unsigned long long)));
   HIP_TRY(hipMemsetAsync(d, 0, nb * sizeof(unsigned long long), t->stream));
   const int grid = grid_for(t, (1ull << t->g.lsize_l) / kBlock + 1);
-  hipLaunchKernelGGL(histo_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, base, ceil, inc, nb, (int)(c[CTR_OVF_USED] != 0), d);
+  if(t->wide) hipLaunchKernelGGL(scan_wide_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->wt, 1, 0ull, ~0ull, (int)(c[CTR_OVF_USED] != 0), base, ceil, inc, nb, d, (uint32_t*)nullptr);
+  else hipLaunchKernelGGL(histo_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, base, ceil, inc, nb, (int)(c[CTR_OVF_USED] != 0), d);
   hipError_t e = hipMemcpyAsync(histo, d, nb * sizeof(uint64_t), hipMemcpyDeviceToHost, t->stream);
   if(e == hipSuccess) e = hipStreamSynchronize(t->stream);
   hipFree(d);
@@ -761,6 +813,11 @@ int jfgpu_dump_begin(jfgpu_table* t, uint64_t lower, uint64_t upper, uint64_t* n
   uint32_t* d_cnt = nullptr;
   HIP_TRY(hipMalloc((void**)&d_cnt, nt * sizeof(uint32_t)));
   t->dump_have_ovf = c[CTR_OVF_USED] != 0;
+  if(t->wide) {
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, nt * sizeof(uint32_t), t->stream));
+    hipLaunchKernelGGL(scan_wide_kernel, dim3(grid_for(t, (1ull << t->g.lsize_l) / kBlock + 1)), dim3(kBlock), 0, t->stream, t->wt, 2, lower, upper,
+                       t->dump_have_ovf, 0ull, 0ull, 1ull, 1ull, (unsigned long long*)nullptr, d_cnt);
+  } else
   hipLaunchKernelGGL(tile_count_kernel, dim3(grid_for(t, nt)), dim3(kBlock), 0, t->stream, t->dt, lower, upper,
                      t->dump_have_ovf, nt, d_cnt);
   std::vector<uint32_t> h(nt);
@@ -808,10 +865,16 @@ int jfgpu_dump_next(jfgpu_table* t, void* out, uint64_t capacity_records, uint64
   std::vector<uint64_t> offs(ntile);
   for(uint64_t i = 0; i < ntile; ++i) offs[i] = t->dump_prefix[t0 + i] - t->dump_prefix[t0];
   HIP_TRY(hipMemcpyAsync(t->d_tile_off, offs.data(), ntile * sizeof(uint64_t), hipMemcpyHostToDevice, t->stream));
+  if(t->wide) {
+    const size_t wl = ((size_t)16 << t->g.tile_bits) + ((size_t)2 << t->g.tile_bits);
+    hipLaunchKernelGGL(dump_tiles_wide_kernel, dim3(grid_for(t, ntile)), dim3(kBlock), wl, t->stream, t->wt, t->dump_lower, t->dump_upper,
+                       t->dump_have_ovf, t0, ntile, (const uint64_t*)t->d_tile_off, t->d_dump, key_bytes, t->out_counter_len);
+  } else {
   const size_t lds = ((size_t)8 << t->g.tile_bits) + ((size_t)2 << t->g.tile_bits) + (size_t)t->g.nbytes * 2048;
   hipLaunchKernelGGL(dump_tiles_kernel, dim3(grid_for(t, ntile)), dim3(kBlock), lds, t->stream, t->dt, t->dump_lower,
                      t->dump_upper, t->dump_have_ovf, t0, ntile, (const uint64_t*)t->d_tile_off, t->d_dump, key_bytes,
                      t->out_counter_len);
+  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out, t->d_dump, nrec * rec, hipMemcpyDeviceToHost, t->stream));
   HIP_TRY(hipStreamSynchronize(t->stream));
@@ -1124,7 +1187,7 @@ int jfgpu_attach_bloom(jfgpu_table* t, jfgpu_bloom* b) {   // count --bc (count_
   if(!b) { memset(&t->dt.bloom, 0, sizeof t->dt.bloom); return JFGPU_OK; }
   if(b->device != t->device) return fail(JFGPU_E_INVALID, "Bloom counter lives on another device");
   if(b->g.k != t->g.k) return fail(JFGPU_E_INVALID, "Invalid mer length in bloom filter");
-  if(t->g.shard_bits) return fail(JFGPU_E_UNSUPPORTED, "count --bc on a sharded table is not built yet");
+  if(t->g.shard_bits || t->wide) return fail(JFGPU_E_UNSUPPORTED, "count --bc on a sharded / two-word-key table is not built yet");
   HIP_TRY(hipStreamSynchronize(b->stream));
   t->dt.bloom = b->view();
   return JFGPU_OK;

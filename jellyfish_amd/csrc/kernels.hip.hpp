@@ -207,7 +207,7 @@ __device__ inline void load_tables_lds(uint64_t* dst, const uint64_t* src, uint3
 
 // ---- K2+K3 fused: count every k-mer of a contract buffer ----------------------
 // base: 16-byte aligned; valid bytes are [lo, hi).
-template <bool RETURNING>
+template <bool RETURNING, bool BLOOM>
 __global__ __launch_bounds__(kBlock) void count_ascii_kernel(DevTable T, const uint8_t* __restrict__ base,
                                                              int64_t lo, int64_t hi) {
   __shared__ uint64_t s_fwd[8 * 256];
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(kBlock) void count_ascii_kernel(DevTable T, const u
     uint64_t prev = 0; uint32_t run = 0;
     for_each_kmer(T.g, L, [&](int, uint64_t key) {
       ++my_mers;
-      if(T.bloom.data && !bloom_admits(T.bloom, key)) return;     // count --bc (count_main.cc:115-118)
+      if(BLOOM && !bloom_admits(T.bloom, key)) return;            // count --bc (count_main.cc:115-118); compiled out otherwise
       if(run && key == prev) { ++run; return; }
       if(run) table_add<RETURNING>(T, s_fwd, prev, run);
       prev = key; run = 1;

@@ -61,7 +61,7 @@ __device__ inline ITEM make_item(const TableGeom& g, const PartGeom& P, uint64_t
 //                   receive side of the multi-GPU exchange) instead of a contract buffer
 // Runs of >= 2 identical consecutive k-mers in one lane (homopolymers, tandem repeats) bypass
 // the partition and go straight to the table with one atomic per run (scatter pass only).
-template <typename ITEM, bool SCATTER, bool FROM_KEYS, bool RETURNING>
+template <typename ITEM, bool SCATTER, bool FROM_KEYS, bool RETURNING, bool BLOOM>
 __global__ __launch_bounds__(kPBlock) void p1_kernel(DevTable T, PartGeom P, const uint8_t* __restrict__ base, int64_t lo,
                                                      int64_t hi, uint32_t* __restrict__ M,
                                                      const uint64_t* __restrict__ bucket_off, ITEM* __restrict__ out) {
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(kPBlock) void p1_kernel(DevTable T, PartGeom P, con
       };
       for_each_kmer(T.g, L, [&](int, uint64_t key) {
         ++my_mers;
-        if(T.bloom.data && !bloom_admits(T.bloom, key)) return;   // count --bc; read-only, so both passes agree
+        if(BLOOM && !bloom_admits(T.bloom, key)) return;          // count --bc; read-only, so both passes agree
         if(run && key == prev) { ++run; return; }
         flush_run();
         prev = key; run = 1;
@@ -236,7 +236,7 @@ __device__ inline void block_excl_scan_2048(const uint32_t* in, uint32_t* out, u
 // 16384 sequence positions = one chunk: every lane keeps its <= 17 emitted items in registers,
 // the block counting-sorts them by bucket in LDS and writes whole runs.  Same tile->block
 // assignment as the count pass, so the per-(block, bucket) cursors derived from M are exact.
-template <bool RETURNING>
+template <bool RETURNING, bool BLOOM>
 __global__ __launch_bounds__(kPBlock) void p1_scatter_sorted_kernel(DevTable T, PartGeom P, const uint8_t* __restrict__ base,
                                                                     int64_t lo, int64_t hi, const uint32_t* __restrict__ M,
                                                                     const uint64_t* __restrict__ bucket_off,
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(kPBlock) void p1_scatter_sorted_kernel(DevTable T, 
       }
     };
     for_each_kmer(T.g, L, [&](int j, uint64_t key) {
-      if(T.bloom.data && !bloom_admits(T.bloom, key)) return;
+      if(BLOOM && !bloom_admits(T.bloom, key)) return;
       if(run && key == prev) { ++run; return; }
       flush_run(j);
       prev = key; run = 1;

@@ -109,9 +109,9 @@ inline void write_text_records(hash_counter* ary, uint64_t min, uint64_t max, st
       line.clear();
       for(uint64_t i = 0; i < got; ++i) {
         const unsigned char* r = &buf[i * rec];
-        uint64_t key = 0, val = 0;
-        memcpy(&key, r, kb); memcpy(&val, r + kb, vb);
-        m.word__(0) = key;
+        uint64_t val = 0;
+        memset(m.data__(), 0, m.nb_words() * sizeof(uint64_t));
+        memcpy(m.data__(), r, kb); memcpy(&val, r + kb, vb);
         line += m.to_str(); line += ' '; line += std::to_string(val); line += '\n';
       }
       out.write(line.data(), line.size());

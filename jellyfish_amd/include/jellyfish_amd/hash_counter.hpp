@@ -50,7 +50,8 @@ public:
     p.matrix_seed = matrix_seed; p.out_counter_len = out_counter_len;
     jf_check(jfgpu_create(&p, &t_));
     jf_check(jfgpu_get_info(t_, &info_));
-    pending_.reserve(kBatch);
+    kw_ = (key_len + 63) / 64;
+    pending_.reserve(kBatch * kw_);
   }
   ~hash_counter() { if(t_) jfgpu_destroy(t_); }
   hash_counter(const hash_counter&) = delete;
@@ -99,15 +100,14 @@ public:
     std::lock_guard<std::mutex> lock(mu_);
     if(v != pending_val_ && !pending_.empty()) flush_locked();
     pending_val_ = v;
-    pending_.push_back(k.word(0));
-    if(pending_.size() >= kBatch) flush_locked();
+    for(unsigned i = 0; i < kw_; ++i) pending_.push_back(k.word(i));
+    if(pending_.size() >= kBatch * kw_) flush_locked();
   }
   // add(k, v, &is_new, &id) (hash_counter.hpp:91-115): synchronous (SWIG HashCounter.add).
   void add(const mer_dna& k, uint64_t v, bool* is_new, size_t* id = nullptr) {
     flush();
-    uint64_t key = k.word(0);
     uint8_t nw = 0;
-    jf_check(jfgpu_add_keys(t_, &key, 1, v, &nw));
+    jf_check(jfgpu_add_keys(t_, k.data(), 1, v, &nw));
     if(is_new) *is_new = nw != 0;
     if(id) *id = 0;
   }
@@ -128,9 +128,9 @@ public:
   // array::get_val_for_key (large_hash_array.hpp:354-372)
   bool get_val_for_key(const mer_dna& k, uint64_t* val) {
     flush();
-    uint64_t key = k.word(0), v = 0;
+    uint64_t v = 0;
     uint8_t f = 0;
-    jf_check(jfgpu_lookup(t_, &key, 1, &v, &f));
+    jf_check(jfgpu_lookup(t_, k.data(), 1, &v, &f));
     if(val) *val = v;
     return f != 0;
   }
@@ -143,6 +143,7 @@ private:
   jfgpu_table* t_ = nullptr;
   jfgpu_info info_;
   uint16_t nb_threads_;
+  unsigned kw_ = 1;                 // 64-bit words per key
   std::mutex mu_;
   std::vector<uint64_t> pending_;
   uint64_t pending_val_ = 1;
@@ -151,8 +152,8 @@ private:
     if(pending_.empty()) return;
     std::vector<uint64_t> batch;
     batch.swap(pending_);
-    pending_.reserve(kBatch);
-    jf_check(jfgpu_add_keys(t_, batch.data(), batch.size(), pending_val_, nullptr));
+    pending_.reserve(kBatch * kw_);
+    jf_check(jfgpu_add_keys(t_, batch.data(), batch.size() / kw_, pending_val_, nullptr));
   }
 };
 

@@ -49,6 +49,10 @@ def main():
         ("reads150_k31C", fa, 31, True, "64k"),
         ("reads150_k32", fa, 32, False, "64k"),
         ("reads150_k5C", fa, 5, True, "64k"),
+        ("reads150_k33C", fa, 33, True, "64k"),
+        ("reads150_k63C", fa, 63, True, "64k"),
+        ("reads150_k64", fa, 64, False, "64k"),
+        ("edge_k40C", edge, 40, True, "4k"),
         ("fastq_k21C", fq, 21, True, "64k"),
         ("edge_k8C", edge, 8, True, "4k"),
         ("edge_k21C", edge, 21, True, "4k"),

@@ -1,0 +1,115 @@
+"""BASELINE config 5 on the GPU (-m gpu): two-word keys, 33 <= k <= 64, 128-bit slots claimed with
+64-bit atomics.  Bit-exact {k-mer -> count} against the multi-word oracle (the reference's
+ceil(k/32)-word mer_dna, mer_dna.hpp:143-170; tests/large_key.sh is the reference's own check of
+this path), dump in (pos, key) order, lookups, hash_counter::add, count-field overflow."""
+import random
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd_seq(rng, n, alphabet="ACGT"):
+    return "".join(rng.choice(alphabet) for _ in range(n)).encode()
+
+
+def oracle_map(seq, k, canonical):
+    keys, cnt = O.count(seq, k, canonical)
+    return {tuple(r): c for r, c in zip(keys.tolist(), cnt.tolist())}
+
+
+def table_map(capi, t):
+    recs = t.dump_records(chunk_records=1 << 16)
+    keys, cnts = capi.decode_records(recs, t.k, t.info.out_counter_len)
+    assert len({tuple(r) for r in keys.tolist()}) == len(keys)
+    if len(keys) > 1:                                          # (pos, key) order under the table's matrix
+        sub = keys[:5000]
+        pos = O.matrix_times(t.matrix(), t.info.lsize, 2 * t.k, sub)
+        pk = [(p, r[1], r[0]) for p, r in zip(pos.tolist(), sub.tolist())]     # key compared from the top word
+        assert pk == sorted(pk)
+    return {tuple(r): c for r, c in zip(keys.tolist(), cnts.tolist())}
+
+
+@pytest.mark.parametrize("k,canonical,n,alphabet", [
+    (33, True, 40000, "ACGT"), (33, False, 20000, "ACGTN"), (40, True, 30000, "ACGTacgtNRY"),
+    (48, True, 30000, "ACGT"), (63, True, 40000, "ACGT"), (63, False, 30000, "ACGTN"),
+    (64, True, 30000, "ACGT"), (64, False, 4096 * 2 + 70, "ACGT"),
+    (50, True, 60000, "AT"), (63, True, 50000, "A"), (40, True, 39, "ACGT"), (40, True, 40, "ACGT"),
+])
+def test_wide_count_matches_oracle(gpu, k, canonical, n, alphabet):
+    rng = random.Random(k * 31 + n)
+    seq = rnd_seq(rng, n, alphabet)
+    exp = oracle_map(seq, k, canonical)
+    with gpu.Table(k, 1 << 16, canonical=canonical) as t:
+        assert t.info.slot_bytes == 16 and t.key_words == 2
+        t.count_ascii(seq)
+        t.sync()
+        assert table_map(gpu, t) == exp
+        st = t.stats()
+        assert (st.distinct, st.total, st.mers_fed) == (len(exp), sum(exp.values()), sum(exp.values()))
+        assert st.unique == sum(1 for v in exp.values() if v == 1)
+        assert st.max_count == (max(exp.values()) if exp else 0)
+        if exp:
+            keys = np.array(list(exp.keys()), dtype=np.uint64)
+            vals, found = t.lookup(keys)
+            assert found.all() and vals.tolist() == list(exp.values())
+            absent = np.array([[rng.getrandbits(64), rng.getrandbits(2 * k - 64)] for _ in range(500)], dtype=np.uint64)
+            absent = np.array([r for r in absent.tolist() if tuple(r) not in exp], dtype=np.uint64)
+            vals, found = t.lookup(absent)
+            assert not found.any() and not vals.any()
+        base, inc, h = t.histo(1, 100000, 1)
+        ref = {}
+        for v in exp.values():
+            ref[v] = ref.get(v, 0) + 1
+        assert {base + i * inc: int(c) for i, c in enumerate(h) if c} == ref
+
+
+def test_wide_add_keys_and_overflow(gpu):
+    k = 63
+    rng = random.Random(3)
+    with gpu.Table(k, 1 << 16, canonical=False) as t:
+        keys = np.array([[rng.getrandbits(64), rng.getrandbits(62)] for _ in range(3000)], dtype=np.uint64)
+        is_new = t.add_keys(keys, val=3, want_new=True)
+        assert is_new.all()
+        assert not t.add_keys(keys[:100], val=2, want_new=True).any()
+        vals, found = t.lookup(keys)
+        assert found.all() and vals[:100].tolist() == [5] * 100 and vals[100:].tolist() == [3] * 2900
+        # same low word, different high word: distinct keys (exercises the lo/hi split of the tag)
+        twins = np.array([[keys[0, 0], (int(keys[0, 1]) ^ 1)], [keys[0, 0] ^ np.uint64(1 << 40), keys[0, 1]]], dtype=np.uint64)
+        vals, found = t.lookup(twins)
+        assert not found.any()
+        big = 2 ** 50 + 7                                      # beyond the in-slot count field: side table
+        assert t.info.val_len < 50
+        t.add_keys(twins[:1], val=big)
+        t.add_keys(np.repeat(twins[1:2], 5000, axis=0), val=1)
+        vals, found = t.lookup(twins)
+        assert vals.tolist() == [big, 5000]
+        st = t.stats()
+        assert st.distinct == 3002 and st.max_count == big
+        recs = t.dump_records()
+        kk, cc = gpu.decode_records(recs, k, 4)
+        got = {tuple(r): c for r, c in zip(kk.tolist(), cc.tolist())}
+        assert got[tuple(twins[0].tolist())] == 2 ** 32 - 1 and got[tuple(twins[1].tolist())] == 5000
+
+
+def test_wide_hash_full_and_lower_upper(gpu):
+    rng = random.Random(5)
+    k = 40
+    seq = rnd_seq(rng, 150000, "ACGT")
+    with gpu.Table(k, 1 << 13) as t:                           # engine minimum 2^13 slots < 150k distinct
+        if t.info.size < 150000:
+            t.count_ascii(seq)
+            with pytest.raises(gpu.JfgpuError) as e:
+                t.sync()
+            assert e.value.code == gpu.E_FULL
+    seq = rnd_seq(rng, 30000, "AC")
+    exp = oracle_map(seq, 34, True)
+    with gpu.Table(34, 1 << 16) as t:
+        t.count_ascii(seq)
+        t.sync()
+        recs = t.dump_records(2, 3)
+        kk, cc = gpu.decode_records(recs, 34, 4)
+        assert {tuple(r): c for r, c in zip(kk.tolist(), cc.tolist())} == {a: b for a, b in exp.items() if 2 <= b <= 3}
