@@ -193,6 +193,14 @@ def main():
         avg_ms = ms / max(launches, 1)
         achieved = per_launch_kmers * B_ALG / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         value = total_kmers / elapsed
+        # HBM bytes per launch of the named kernel: PMC counters cannot be read from inside this process, so
+        # the figure comes from the committed rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this same command
+        # (profiles/r01_traffic.json); only quoted when the run matches that configuration.
+        traffic, traffic_src = None, None
+        tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tj) and world == 1 and slot_names[which] == "tile_insert" and abs(args.gbp - 10.0) < 1e-9 and args.lsize == 34:
+            traffic = json.load(open(tj))["tile_insert_timed_launch_bytes"]
+            traffic_src = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, same command)"
         out = {
             "metric": "k-mers/sec at k=21 canonical, 150 bp synthetic reads, bit-exact counts",
             "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -207,7 +215,7 @@ def main():
             "kernels": kernels,
             "roofline": {"bound": "hbm", "kernel": slot_names[which],
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "bytes_per_kmer": B_ALG, "kmers_per_launch": per_launch_kmers,
+                         "traffic": traffic, "traffic_source": traffic_src, "bytes_per_kmer": B_ALG, "kmers_per_launch": per_launch_kmers,
                          "avg_launch_ms": avg_ms, "launches": launches,
                          "whole_path_achieved": value * B_ALG / 1e9, "whole_path_frac": value * B_ALG / 1e9 / HBM_PEAK_GBS,
                          "note": "achieved/frac follow the contract: the named (largest-total-time) kernel's k-mers per launch x 17.15 B / its "
