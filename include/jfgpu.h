@@ -194,6 +194,13 @@ int  jfgpu_bc_keys(jfgpu_bloom* b, const uint64_t* keys, size_t n, uint8_t* out,
  * b == NULL detaches.  The Bloom counter must outlive its use. */
 int  jfgpu_attach_bloom(jfgpu_table* t, jfgpu_bloom* b);
 
+/* hash_counter::do_size_doubling(bool) (hash_counter.hpp:78-79).  On (default): the size given at
+ * creation is a hint, the table doubles itself (device-side rehash, one more matrix row) before it
+ * could exceed 80 % load, as long as device memory allows; jfgpu_get_info / jfgpu_get_matrix report
+ * the current geometry.  Off: a full table is the deferred error "Hash full".  One-word keys,
+ * unsharded tables only for now. */
+int  jfgpu_set_growth(jfgpu_table* t, int on);
+
 /* Insert strategy.  0 auto (default), 1 direct (global 64-bit atomics, kernels.hip.hpp),
  * 2 partitioned (radix partition + LDS-resident tiles, kernels_part.hip.hpp; large batches
  * are buffered on the device and applied at the next jfgpu_sync / read).  Results are

@@ -89,6 +89,7 @@ SIGNATURES = {
     "jfgpu_bc_load": (C.c_int, [_P, _P]),
     "jfgpu_bc_keys": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_int]),
     "jfgpu_attach_bloom": (C.c_int, [_P, _P]),
+    "jfgpu_set_growth": (C.c_int, [_P, C.c_int]),
     "jfgpu_set_mode": (C.c_int, [_P, C.c_int]),
     "jfgpu_reserve": (C.c_int, [_P, C.c_uint64]),
     "jfgpu_profile_enable": (C.c_int, [_P, C.c_int]),
@@ -189,6 +190,7 @@ class Table:
 
     def sync(self):
         _check(self._lib.jfgpu_sync(self._h))
+        _check(self._lib.jfgpu_get_info(self._h, C.byref(self.info)))     # the table may have doubled itself
 
     def wait(self):
         _check(self._lib.jfgpu_wait(self._h))
@@ -263,6 +265,13 @@ class Table:
         """count --bc: admit only k-mers the Bloom counter has seen at least twice (None detaches)."""
         self._bloom = bloom
         _check(self._lib.jfgpu_attach_bloom(self._h, bloom._h if bloom is not None else None))
+
+    def set_growth(self, on):
+        _check(self._lib.jfgpu_set_growth(self._h, int(bool(on))))
+
+    def refresh_info(self):
+        _check(self._lib.jfgpu_get_info(self._h, C.byref(self.info)))
+        return self.info
 
     def set_mode(self, mode):
         """0 auto, 1 direct (global atomics), 2 partitioned (LDS tiles)."""

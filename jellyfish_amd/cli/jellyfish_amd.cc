@@ -83,7 +83,7 @@ int count_main(int argc, char* argv[]) {
 
   unsigned mer_len = 0, threads = 1, counter_len = 7, out_counter_len = 4, reprobes = 126, Files = 1;
   uint64_t size = 0, lower = 0, upper = std::numeric_limits<uint64_t>::max();
-  bool size_given = false, lower_given = false, upper_given = false, canonical = false, text = false, no_write = false;
+  bool size_given = false, lower_given = false, upper_given = false, canonical = false, text = false, no_write = false, disk = false;
   int device = -1;
   std::string output = "mer_counts.jf", timing, bc_path;
   std::vector<std::string> files;
@@ -105,7 +105,8 @@ int count_main(int argc, char* argv[]) {
     else if(a.cur() == "-C" || a.cur() == "--canonical") canonical = true;
     else if(a.cur() == "--text") text = true;
     else if(a.cur() == "--no-write") no_write = true;
-    else if(a.cur() == "--disk" || a.cur() == "--no-merge" || a.cur() == "--no-unlink") { /* spill-to-disk knobs: the table lives in HBM */ }
+    else if(a.cur() == "--disk") disk = true;   // do_size_doubling(false) (count_main.cc:276-277); no spill files yet: a full table is an error
+    else if(a.cur() == "--no-merge" || a.cur() == "--no-unlink") { /* spill-to-disk knobs */ }
     else if(a.is("", "--bf-size") || a.is("", "--bf-fp") || a.is("", "--if") || a.is("-Q", "--min-qual-char") ||
             a.is("-q", "--min-quality") || a.is("-g", "--generator") || a.is("-G", "--Generators") || a.is("", "--sam"))
       die("Option '" + a.cur() + "' is not supported by jellyfish-amd yet");
@@ -142,6 +143,7 @@ int count_main(int argc, char* argv[]) {
   try {
     ary.reset(new mer_hash(size, mer_len * 2, counter_len, threads, reprobes, canonical, device, out_counter_len));
   } catch(std::exception& e) { die(std::string("Failed to allocate the hash: ") + e.what()); }
+  if(disk) ary->do_size_doubling(false);
 
   // Bloom counter read from file to filter out low frequency k-mers, two pass algorithm
   // (load_bloom_filter, count_main.cc:191-206,313-316)

@@ -61,6 +61,10 @@ struct jfgpu_table {
   uint64_t ovf_cap = 0;
   bool returning = false;
   uint32_t out_counter_len = 4;
+  // size doubling (hash_counter::do_size_doubling): occupancy bookkeeping, see ensure_capacity()
+  bool grow_on = true;
+  uint64_t occ_known = 0, fed_since = 0;
+  uint64_t grow_seed = 0;
   // two-word keys (33 <= k <= 64): 128-bit slots, kernels_wide.hip.hpp
   bool wide = false;
   WideTable wt{};
@@ -164,6 +168,8 @@ int check_deferred(jfgpu_table* t, uint64_t* ctr_out = nullptr) {
 bool use_partitioned(const jfgpu_table* t, size_t nbytes);
 int part_ingest(jfgpu_table* t, const uint8_t* base, int64_t lo, int64_t hi, bool from_keys, uint64_t max_items);
 int part_flush(jfgpu_table* t);
+int table_grow(jfgpu_table* t);
+int measure_occupancy(jfgpu_table* t);
 
 // Splits a device buffer pointer into a 16-byte aligned base and [lo, hi).
 void align_buffer(const char* d, size_t n, const uint8_t*& base, int64_t& lo, int64_t& hi) {
@@ -172,7 +178,7 @@ void align_buffer(const char* d, size_t n, const uint8_t*& base, int64_t& lo, in
   base = (const uint8_t*)a; lo = (int64_t)(p - a); hi = lo + (int64_t)n;
 }
 
-int launch_count(jfgpu_table* t, const char* d_bases, size_t n) {
+int launch_count_chunk(jfgpu_table* t, const char* d_bases, size_t n) {
   if(n < t->g.k) return JFGPU_OK;
   const uint8_t* base; int64_t lo, hi;
   align_buffer(d_bases, n, base, lo, hi);
@@ -198,6 +204,54 @@ int launch_count(jfgpu_table* t, const char* d_bases, size_t n) {
 #undef CA
   HIP_TRY(hipGetLastError());
   return JFGPU_OK;
+}
+
+
+// How many more k-mers may be enqueued before the table could exceed 80 % load, assuming every one
+// of them is new (an upper bound: duplicates are only discovered by inserting).
+uint64_t capacity_limit(const jfgpu_table* t) { return ((1ull << t->g.lsize_l) / 10) * 8; }
+bool capacity_managed(const jfgpu_table* t) { return t->grow_on && !t->wide && t->g.shard_bits == 0 && t->g.lsize_g < t->g.key_bits; }
+
+// The size passed at creation is a hint (doc/Readme.md:67-72; hash_counter::handle_full_ary,
+// hash_counter.hpp:178-198): before enqueuing `incoming` potential new keys make sure they cannot
+// overflow the table -- measure the true occupancy when the running upper bound runs out, double the
+// table (cooperative rehash on the device) when it is really more than half full.  Returns the
+// number of k-mers that may be enqueued now (<= incoming, > 0).
+int ensure_capacity(jfgpu_table* t, uint64_t incoming, uint64_t* allowed) {
+  *allowed = incoming;
+  if(!capacity_managed(t)) return JFGPU_OK;
+  uint64_t limit = capacity_limit(t);
+  if(t->occ_known + t->fed_since + incoming <= limit) { t->fed_since += incoming; return JFGPU_OK; }
+  int rc = measure_occupancy(t); if(rc) return rc;
+  const uint64_t min_piece = std::min<uint64_t>(incoming, 65536);      // never enqueue less than this at a time
+  while(true) {
+    limit = capacity_limit(t);
+    const uint64_t headroom = limit > t->occ_known ? limit - t->occ_known : 0;
+    const bool really_full = t->occ_known > (1ull << t->g.lsize_l) / 2;
+    if(!really_full && headroom >= min_piece) break;
+    if(t->g.lsize_g >= t->g.key_bits) break;                             // 4^k positions: cannot fill up
+    rc = table_grow(t);
+    if(rc < 0) break;            // no memory for a bigger table: carry on, "Hash full" if it really overflows
+    if(rc) return rc;
+  }
+  limit = capacity_limit(t);
+  const uint64_t headroom = limit > t->occ_known ? limit - t->occ_known : 0;
+  *allowed = std::min<uint64_t>(incoming, std::max<uint64_t>(headroom, min_piece));
+  t->fed_since += *allowed;
+  return JFGPU_OK;
+}
+
+int launch_count(jfgpu_table* t, const char* d_bases, size_t n) {
+  if(n < t->g.k) return JFGPU_OK;
+  if(!capacity_managed(t)) return launch_count_chunk(t, d_bases, n);
+  size_t off = 0;
+  while(true) {
+    uint64_t take = 0;
+    int rc = ensure_capacity(t, n - off, &take); if(rc) return rc;
+    rc = launch_count_chunk(t, d_bases + off, (size_t)take); if(rc) return rc;
+    if(off + take >= n) return JFGPU_OK;
+    off += take - (t->g.k - 1);          // next piece re-reads the last k-1 characters: every window exactly once
+  }
 }
 
 int ensure_stage(jfgpu_table* t) {
@@ -413,6 +467,85 @@ void part_discard(jfgpu_table* t) {
   t->pending.clear(); t->pending_bytes = 0; t->ws_used = 0;
 }
 
+
+int measure_occupancy(jfgpu_table* t) {
+  int rc = part_flush(t); if(rc) return rc;
+  uint64_t c[CTR_COUNT];
+  rc = check_deferred(t, c); if(rc) return rc;
+  unsigned long long* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, 4 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), t->stream));
+  hipLaunchKernelGGL(stats_kernel, dim3(grid_for(t, (1ull << t->g.lsize_l) / kBlock + 1)), dim3(kBlock), 0, t->stream, t->dt,
+                     0ull, ~0ull, 0, d);
+  unsigned long long h[4];
+  hipError_t e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, t->stream);
+  if(e == hipSuccess) e = hipStreamSynchronize(t->stream);
+  hipFree(d);
+  if(e != hipSuccess) return fail(JFGPU_E_HIP, hipGetErrorString(e));
+  t->occ_known = h[1]; t->fed_since = 0;
+  return JFGPU_OK;
+}
+
+// Double the table: one more matrix row (so old positions are the low bits of new ones), new slots,
+// rehash on the device, swap.  < 0: not possible (memory) -- the caller carries on with the old table.
+int table_grow(jfgpu_table* t) {
+  int rc = part_flush(t); if(rc) return rc;
+  uint64_t ctr[CTR_COUNT];
+  rc = check_deferred(t, ctr); if(rc) return rc;
+  const uint32_t r = t->g.lsize_g, c = t->g.key_bits;
+  if(r >= c) return -1;
+  // extend the matrix by a random top row until the (r+1) x (r+1) low block is invertible again
+  Gf2Matrix m2 = t->matrix; m2.r = r + 1; m2.identity = false;
+  std::vector<uint64_t> fwd, inv;
+  uint64_t st = (t->params.matrix_seed ? t->params.matrix_seed : kDefaultSeed) ^ (0xD6E8FEB86659FD93ull * (r + 1)) ^ t->grow_seed;
+  for(int tries = 0; ; ++tries) {
+    for(uint32_t j = 0; j < c; ++j) m2.columns[j] = (t->matrix.columns[j] & ((1ull << r) - 1)) | ((splitmix64(st) & 1ull) << r);
+    if(gf2_build_tables(m2, fwd, inv)) break;
+    if(tries > 1000) return fail(JFGPU_E_INVALID, "could not extend the hash matrix");
+  }
+  TableGeom g2;
+  if(!geom_init(g2, t->g.k, r + 1, 0, 0, t->g.canonical)) return -1;
+  const uint64_t n2 = 1ull << g2.lsize_l;
+  uint64_t cap2 = std::max<uint64_t>(1ull << 12, std::min<uint64_t>(n2 / 256, 1ull << 26));
+  { uint64_t x = 1; while(x < cap2) x <<= 1; cap2 = x; }
+  DevTable nd = t->dt;
+  nd.g = g2; nd.slots = nullptr; nd.ovf_key = nd.ovf_cnt = nullptr; nd.dirty = nullptr;
+  uint64_t *nf = nullptr, *ni = nullptr;
+  size_t free_b = 0, total_b = 0;
+  HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  if(n2 * 8 + cap2 * 16 + ((size_t)1 << 30) > free_b) return -1;
+  bool ok = hipMalloc((void**)&nd.slots, n2 * 8) == hipSuccess && hipMalloc((void**)&nd.ovf_key, cap2 * 8) == hipSuccess &&
+            hipMalloc((void**)&nd.ovf_cnt, cap2 * 8) == hipSuccess && hipMalloc((void**)&nd.dirty, (size_t)1 << (g2.lsize_l - g2.tile_bits)) == hipSuccess &&
+            hipMalloc((void**)&nf, fwd.size() * 8) == hipSuccess && hipMalloc((void**)&ni, inv.size() * 8) == hipSuccess;
+  if(!ok) {
+    hipFree(nd.slots); hipFree(nd.ovf_key); hipFree(nd.ovf_cnt); hipFree(nd.dirty); hipFree(nf); hipFree(ni);
+    (void)hipGetLastError();
+    return -1;
+  }
+  nd.fwd_tbl = nf; nd.inv_tbl = ni; nd.ovf_mask = cap2 - 1;
+  nd.max_probe = (uint32_t)std::min<uint64_t>(g2.tile_mask, 1023);
+  HIP_TRY(hipMemsetAsync(nd.slots, 0, n2 * 8, t->stream));
+  HIP_TRY(hipMemsetAsync(nd.ovf_key, 0, cap2 * 8, t->stream));
+  HIP_TRY(hipMemsetAsync(nd.ovf_cnt, 0, cap2 * 8, t->stream));
+  HIP_TRY(hipMemsetAsync(nd.dirty, 0, (size_t)1 << (g2.lsize_l - g2.tile_bits), t->stream));
+  HIP_TRY(hipMemcpyAsync(nf, fwd.data(), fwd.size() * 8, hipMemcpyHostToDevice, t->stream));
+  HIP_TRY(hipMemcpyAsync(ni, inv.data(), inv.size() * 8, hipMemcpyHostToDevice, t->stream));
+  hipLaunchKernelGGL(rehash_kernel, dim3(grid_for(t, (1ull << t->g.lsize_l) / kBlock + 1)), dim3(kBlock), 0, t->stream, t->dt, nd,
+                     (int)(ctr[CTR_OVF_USED] != 0));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  // swap in
+  hipFree(t->dt.slots); hipFree(t->dt.ovf_key); hipFree(t->dt.ovf_cnt); hipFree(t->dt.dirty); hipFree(t->d_fwd); hipFree(t->d_inv);
+  t->dt = nd; t->g = g2; t->matrix = m2; t->d_fwd = nf; t->d_inv = ni; t->ovf_cap = cap2;
+  t->returning = t->g.cnt_bits < 40;
+  if(t->d_M2) { hipFree(t->d_M2); t->d_M2 = nullptr; }
+  part_geom_init(t);
+  if(t->mode == MODE_PARTITIONED && !t->part_ok) t->mode = MODE_AUTO;
+  t->pristine = false;
+  ++t->grow_seed;
+  return check_deferred(t);
+}
+
 bool use_partitioned(const jfgpu_table* t, size_t nbytes) {
   if(!t->part_ok || t->mode == MODE_DIRECT) return false;
   if(t->mode == MODE_PARTITIONED) return true;
@@ -595,7 +728,7 @@ int jfgpu_clear(jfgpu_table* t) {
   HIP_TRY(hipMemsetAsync(t->dt.counters, 0, CTR_COUNT * sizeof(uint64_t), t->stream));
   HIP_TRY(hipMemsetAsync(t->dt.dirty, 0, (size_t)1 << (t->g.lsize_l - t->g.tile_bits), t->stream));
   HIP_TRY(hipStreamSynchronize(t->stream));
-  t->pristine = true;
+  t->pristine = true; t->occ_known = 0; t->fed_since = 0;
   return JFGPU_OK;
 }
 
@@ -649,6 +782,14 @@ int jfgpu_add_keys_dev(jfgpu_table* t, const uint64_t* d_keys, size_t n, uint64_
     hipLaunchKernelGGL(add_keys_wide_kernel, dim3(grid_for(t, (n + kBlock - 1) / kBlock)), dim3(kBlock), 0, t->stream, t->wt, d_keys, (uint64_t)n, val, d_is_new);
     HIP_TRY(hipGetLastError());
     return JFGPU_OK;
+  }
+  if(capacity_managed(t)) {
+    uint64_t take = 0;
+    rc = ensure_capacity(t, n, &take); if(rc) return rc;
+    if(take < n) {                       // feed the rest in further pieces (each re-checks the occupancy)
+      rc = jfgpu_add_keys_dev(t, d_keys + take, n - take, val, d_is_new ? d_is_new + take : nullptr); if(rc) return rc;
+      n = take;
+    }
   }
   if(val == 1 && !d_is_new && use_partitioned(t, n * 8)) {
     const int prc = part_ingest(t, (const uint8_t*)d_keys, 0, (int64_t)n, true, n);
@@ -889,6 +1030,12 @@ int jfgpu_dump_end(jfgpu_table* t) {
   t->dump_prefix.clear(); t->dump_prefix.shrink_to_fit();
   if(t->d_dump) { hipFree(t->d_dump); t->d_dump = nullptr; t->dump_cap_records = 0; }
   if(t->d_tile_off) { hipFree(t->d_tile_off); t->d_tile_off = nullptr; t->tile_off_cap = 0; }
+  return JFGPU_OK;
+}
+
+int jfgpu_set_growth(jfgpu_table* t, int on) {
+  int rc = use(t); if(rc) return rc;
+  t->grow_on = on != 0;
   return JFGPU_OK;
 }
 

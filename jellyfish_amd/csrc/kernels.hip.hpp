@@ -358,6 +358,20 @@ __global__ __launch_bounds__(kBlock) void partition_scatter_kernel(DevTable T, c
   }
 }
 
+// ---- cooperative size doubling (hash_counter::double_size, hash_counter.hpp:200-238) -------------
+// Every entry of the old table is re-derived (slot -> key by the inverse tables) and inserted with its
+// full count into the new, twice as large table (one more matrix row).  Hash tables are read through
+// the caches here: growth is rare and the kernel is bound by the random inserts anyway.
+__global__ __launch_bounds__(kBlock) void rehash_kernel(DevTable old, DevTable neu, int have_ovf) {
+  const uint64_t n = 1ull << old.g.lsize_l;
+  for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t w = old.slots[i];
+    if(!w) continue;
+    const uint64_t key = slot_key(old.g, old.inv_tbl, w, i & ~old.g.tile_mask);
+    table_add_val(neu, neu.fwd_tbl, key, full_count(old, w, i, have_ovf));
+  }
+}
+
 // ---- stats (stats_main.cc:33-46) ---------------------------------------------------
 // out: [0] unique [1] distinct [2] total [3] max
 __global__ __launch_bounds__(kBlock) void stats_kernel(DevTable T, uint64_t lower, uint64_t upper, int have_ovf,

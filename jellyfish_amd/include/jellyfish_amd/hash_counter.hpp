@@ -75,8 +75,14 @@ public:
     return m;
   }
 
+  // The table may have doubled itself since construction (size is a hint): re-read the geometry.
+  void refresh_info() { jf_check(jfgpu_get_info(t_, &info_)); }
+  // hash_counter::do_size_doubling (hash_counter.hpp:78-79)
+  void do_size_doubling(bool v) { jf_check(jfgpu_set_growth(t_, v ? 1 : 0)); }
+
   // file_header::update_from_ary (file_header.hpp:25-33)
-  void update_header(file_header& h) const {
+  void update_header(file_header& h) {
+    refresh_info();
     h.size(info_.size);
     h.key_len(info_.key_len);
     h.val_len(info_.val_len);
@@ -122,7 +128,7 @@ public:
     return true;
   }
   // done() (hash_counter.hpp:169-172): everything retired; throws "Hash full" if it did not fit.
-  void done() { flush(); jf_check(jfgpu_sync(t_)); }
+  void done() { flush(); jf_check(jfgpu_sync(t_)); refresh_info(); }
   void clear() { std::lock_guard<std::mutex> lock(mu_); pending_.clear(); jf_check(jfgpu_clear(t_)); }
 
   // array::get_val_for_key (large_hash_array.hpp:354-372)

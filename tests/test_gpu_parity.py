@@ -194,6 +194,7 @@ def test_hash_full_is_reported(gpu):
     k = 21
     seq = rnd_seq(rng, 40000)
     with gpu.Table(k, 1 << 12) as t:
+        t.set_growth(False)                       # hash_counter::do_size_doubling(false)
         t.count_ascii(seq)
         with pytest.raises(gpu.JfgpuError) as e:
             t.sync()
@@ -384,6 +385,7 @@ def test_partitioned_hash_full(gpu):
     seq = rnd_seq(rng, 200000)
     with gpu.Table(21, 1 << 16) as t:
         t.set_mode(2)
+        t.set_growth(False)
         t.count_ascii(seq)
         with pytest.raises(gpu.JfgpuError) as e:
             t.sync()
@@ -411,3 +413,42 @@ def test_partitioned_large_run_invariants(gpu):
             dumps.append((s.distinct, s.unique, s.max_count, h.tolist()))
             t.free(d)
     assert dumps[0] == dumps[1]
+
+
+# ---- the size is a hint: cooperative doubling (hash_counter::double_size, hash_counter.hpp:200-238) ------
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("k,size,n", [(21, 1 << 13, 400000), (15, 16, 200000), (31, 1 << 10, 150000), (8, 64, 300000)])
+def test_table_grows_like_the_reference(gpu, mode, k, size, n):
+    """tests/parallel_hashing.sh:23-29: `-s 2M` on 10 M distinct 15-mers must give the same histogram as a
+    presized table.  Here: a tiny hint, several feeds, lookups in between; counts stay exact through
+    every doubling and the dump is ordered under the FINAL matrix."""
+    rng = random.Random(k + n)
+    seq = rnd_seq(rng, n, "ACGTN")
+    exp = oracle_map(seq, k, True)
+    with gpu.Table(k, size) as t:
+        first = t.info.lsize
+        try:
+            t.set_mode(mode)
+        except gpu.JfgpuError:
+            pytest.skip("no partitioned path for this tiny geometry")
+        third = len(seq) // 3
+        d = t.malloc(len(seq) + 64)
+        t.h2d(d, np.frombuffer(seq, dtype=np.uint8))
+        t.count_ascii_dev(d, third)
+        keys = np.array(list(exp.keys())[:1000], dtype=np.uint64)
+        t.lookup(keys)                                        # forces a flush + sync in the middle
+        t.count_ascii_dev(d + third - (k - 1), len(seq) - third + (k - 1))
+        t.sync()
+        if (1 << first) * 0.8 < len(exp):                      # the hint really was too small
+            assert t.info.lsize > first or t.info.lsize == 2 * k   # it did grow (or reached 4^k positions)
+        assert table_map(gpu, t) == exp
+        st = t.stats()
+        assert (st.distinct, st.total, st.mers_fed) == (len(exp), sum(exp.values()), sum(exp.values()))
+        vals, found = t.lookup(keys)
+        assert found.all() and vals.tolist() == [exp[x] for x in keys.tolist()]
+        # hash_counter::add after growth, with large values (overflow side table survives the rehash)
+        t.add_keys(keys[:10], val=2 ** 45)
+        t.add_keys(np.array([x for x in range(5000, 5000 + 60000)], dtype=np.uint64) & np.uint64((1 << (2 * k)) - 1), val=1)
+        vals, found = t.lookup(keys[:10])
+        assert vals.tolist() == [exp[x] + 2 ** 45 for x in keys[:10].tolist()]
+        t.free(d)
