@@ -149,6 +149,8 @@ def main():
             sc.step(batch(i))
 
     def fence():
+        if world > 1 or force_dist:
+            sc.finish()                  # last step's exchange + insert
         t.sync()
         torch.cuda.synchronize()
         if world > 1 or force_dist:

@@ -357,8 +357,11 @@ int part_ingest(jfgpu_table* t, const uint8_t* base, int64_t lo, int64_t hi, boo
       if(t->returning) { if(bl) PS(true, true); else PS(true, false); } else { if(bl) PS(false, true); else PS(false, false); }
 #undef PS
     }
-    else if(t->item32) launch_p1<uint32_t>(t, true, from_keys, base, lo, hi, b.off, b.items);
-    else               launch_p1<uint64_t>(t, true, from_keys, base, lo, hi, b.off, b.items);
+    else if(t->item32) {              // encoded keys, 32-bit items: same write-combining scatter
+      hipLaunchKernelGGL(p1_keys_scatter_sorted_kernel, dim3(t->g1), dim3(kPBlock), (size_t)kPTilePos * 6, t->stream, t->dt, t->pg,
+                         (const uint64_t*)base, hi, (const uint32_t*)t->d_M1, (const uint64_t*)b.off, (uint32_t*)b.items);
+    }
+    else launch_p1<uint64_t>(t, true, from_keys, base, lo, hi, b.off, b.items);
   }
   hipError_t e = hipGetLastError();
   t->pending.push_back(b);
@@ -670,6 +673,7 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_sorted_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_sorted_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_sorted_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_keys_scatter_sorted_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint32_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * 16 * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint64_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * 8 * 8));
   }

@@ -32,7 +32,7 @@ namespace jfgpu {
 constexpr int kPBlock = 1024;                 // threads per block in the partition passes
 constexpr int kPTilePos = kPBlock * kPerLane; // 16384 sequence positions per block iteration
 constexpr int kMaxBuckets = 2048;             // per pass
-constexpr int kMaxSeg = 64;                   // pending batches per flush
+constexpr int kMaxSeg = 128;                  // pending batches per flush
 
 struct PartGeom {
   uint32_t b1, b2;          // bits consumed by P1 / P2 (b2 == 0: P1 buckets are tiles)
@@ -303,6 +303,71 @@ __global__ __launch_bounds__(kPBlock) void p1_scatter_sorted_kernel(DevTable T, 
     for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) s_gcur[j] += s_hist[j];
   }
   if(my_direct) atomicAdd((unsigned long long*)&T.counters[CTR_DIRECT], (unsigned long long)my_direct);
+}
+
+// The same write-combining scatter for a batch of encoded k-mers (hash_counter::add batches and the
+// receive side of the multi-GPU exchange).  Block b owns the contiguous slice the count pass
+// (p1_kernel<.., false, true, ..>) gave it and walks it in chunks of 16384 keys.
+__global__ __launch_bounds__(kPBlock) void p1_keys_scatter_sorted_kernel(DevTable T, PartGeom P, const uint64_t* __restrict__ keys,
+                                                                         int64_t n, const uint32_t* __restrict__ M,
+                                                                         const uint64_t* __restrict__ bucket_off,
+                                                                         uint32_t* __restrict__ out) {
+  extern __shared__ __align__(16) unsigned char s_dyn[];
+  uint32_t* s_item = reinterpret_cast<uint32_t*>(s_dyn);                          // [kPTilePos]
+  uint16_t* s_bkt = reinterpret_cast<uint16_t*>(s_dyn + (size_t)kPTilePos * 4);   // [kPTilePos]
+  __shared__ uint64_t s_fwd[8 * 256];
+  __shared__ unsigned long long s_gcur[kMaxBuckets];
+  __shared__ uint32_t s_hist[kMaxBuckets];
+  __shared__ uint32_t s_lstart[kMaxBuckets];
+  __shared__ uint32_t s_wave[16];
+  const uint32_t nb = 1u << P.b1;
+  load_tables_lds(s_fwd, T.fwd_tbl, T.g.nbytes);
+  for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) s_gcur[j] = bucket_off[j] + M[(size_t)blockIdx.x * nb + j];
+  const uint32_t bshift = T.g.lsize_l - P.b1;
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t b0 = (int64_t)blockIdx.x * per, b1e = b0 + per < n ? b0 + per : n;
+  for(int64_t c0 = b0; c0 < b1e; c0 += kPTilePos) {
+    lds_barrier();
+    for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) s_hist[j] = 0;
+    uint64_t kk[kPerLane];
+#pragma unroll
+    for(int e = 0; e < kPerLane; ++e) {
+      const int64_t i = c0 + (int64_t)e * kPBlock + threadIdx.x;
+      kk[e] = i < b1e ? keys[i] : 0;
+    }
+    lds_barrier();
+    uint32_t it[kPerLane], dr[kPerLane];
+#pragma unroll
+    for(int e = 0; e < kPerLane; ++e) {
+      dr[e] = 0xFFFFFFFFu;
+      if(c0 + (int64_t)e * kPBlock + threadIdx.x < b1e) {
+        const uint64_t key = kk[e] & T.g.key_mask;
+        const uint64_t pos = hash_tables(s_fwd, key, T.g.nbytes);
+        if((uint32_t)(pos >> T.g.lsize_l) != T.g.shard_id) { atomicAdd((unsigned long long*)&T.counters[CTR_MISROUTED], 1ull); continue; }
+        const uint64_t local = pos & T.g.local_mask;
+        const uint32_t b = P.b1 ? (uint32_t)(local >> bshift) : 0u;
+        it[e] = make_item<uint32_t>(T.g, P, key, local);
+        dr[e] = (b << 16) | atomicAdd(&s_hist[b], 1u);
+      }
+    }
+    lds_barrier();
+    block_excl_scan_2048(s_hist, s_lstart, nb, s_wave);
+    lds_barrier();
+#pragma unroll
+    for(int e = 0; e < kPerLane; ++e)
+      if(dr[e] != 0xFFFFFFFFu) {
+        const uint32_t at = s_lstart[dr[e] >> 16] + (dr[e] & 0xFFFFu);
+        s_item[at] = it[e]; s_bkt[at] = (uint16_t)(dr[e] >> 16);
+      }
+    lds_barrier();
+    const uint32_t cn = s_lstart[nb - 1] + s_hist[nb - 1];
+    for(uint32_t i = threadIdx.x; i < cn; i += blockDim.x) {
+      const uint32_t b = s_bkt[i];
+      out[s_gcur[b] + (i - s_lstart[b])] = s_item[i];
+    }
+    lds_barrier();
+    for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) s_gcur[j] += s_hist[j];
+  }
 }
 
 // P2 scatter with write combining: scattered 4-byte stores top out at ~50-100 G items/s on

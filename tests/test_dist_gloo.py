@@ -47,6 +47,7 @@ batches.append(b"")                          # a rank with nothing to send in on
 be = OracleBackend()
 sc = ShardedCounter(be)
 for b in batches: sc.step(b)
+sc.finish()
 tot = torch.tensor([sc.sent, sc.received], dtype=torch.int64)
 dist.all_reduce(tot)
 assert tot[0] == tot[1], "k-mers lost or duplicated in the exchange"
