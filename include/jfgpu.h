@@ -41,7 +41,8 @@ enum {
   JFGPU_E_ALLOC = 3,      /* large_hash::array::ErrorAllocation, large_hash_array.hpp:55,169-172 */
   JFGPU_E_FULL = 4,       /* std::runtime_error("Hash full"), hash_counter.hpp:194-195 */
   JFGPU_E_HIP = 5,        /* HIP runtime error */
-  JFGPU_E_UNSUPPORTED = 6 /* feature not built yet (e.g. k > 32) */
+  JFGPU_E_UNSUPPORTED = 6,/* feature not built yet (e.g. k > 32) */
+  JFGPU_E_FORMAT = 7      /* device parser: chunk is not in the strict layout it handles; give it to the host parser */
 };
 
 typedef struct jfgpu_table jfgpu_table; /* opaque: one hash shard resident in one GPU's HBM */
@@ -210,6 +211,39 @@ int  jfgpu_set_mode(jfgpu_table* t, int mode);
  * between two syncs (what `-s` is to the table, hash_counter.hpp:56-64: a hint that moves
  * allocation out of the counting phase).  Without it the workspace grows on demand. */
 int  jfgpu_reserve(jfgpu_table* t, uint64_t input_bytes);
+
+/* ---- sequence files parsed on the device -------------------
+ * Replaces mer_overlap_sequence_parser::read_fasta / read_fastq
+ * (include/jellyfish/mer_overlap_sequence_parser.hpp:160-215): raw FASTA / FASTQ bytes in, the
+ * contract buffer (sequence lines concatenated, headers and qualities dropped, one 'N' per record
+ * boundary) out -- in device memory, ready for jfgpu_count_ascii_dev / jfgpu_bc_insert_ascii_dev /
+ * jfgpu_partition_ascii_dev.
+ *
+ * A chunk is n <= 2^31 bytes that start at the beginning of a line and end at the end of one.
+ *   FASTA  may be cut at ANY line boundary: pass JFGPU_PARSE_CONTINUE for every chunk of a file but
+ *          the first and the parser prepends the previous chunk's last k-1 characters (the
+ *          reference's "seam", :164-167,182-184), so no k-mer is lost or seen twice.
+ *   FASTQ  chunks hold whole 4-line records.  Wrapped sequence / quality lines, blank lines or a
+ *          quality string of the wrong length give JFGPU_E_FORMAT and produce nothing: pass that
+ *          chunk to the host parser, which implements the reference's general reader and its
+ *          "Invalid fastq sequence" error (:292-309).
+ * The returned buffer belongs to the parser and stays valid until the second-next parse call
+ * (two buffers alternate), so one chunk can be counted while the next is parsed.  Calls are
+ * synchronous: on return the buffer is complete. */
+typedef struct jfgpu_parser jfgpu_parser;
+#define JFGPU_PARSE_FASTA    1u
+#define JFGPU_PARSE_FASTQ    2u
+#define JFGPU_PARSE_CONTINUE 4u
+int  jfgpu_parser_create(int device, uint32_t k, jfgpu_parser** out);
+void jfgpu_parser_destroy(jfgpu_parser* p);
+/* d_bytes: device memory, readable up to the next multiple of 16 bytes. */
+int  jfgpu_parser_parse_dev(jfgpu_parser* p, const char* d_bytes, size_t n, unsigned flags,
+                            const char** d_out, size_t* n_out, uint64_t* n_records);
+/* bytes: host memory (e.g. the mmap of the file); copied to the device, then as above. */
+int  jfgpu_parser_parse(jfgpu_parser* p, const char* bytes, size_t n, unsigned flags,
+                        const char** d_out, size_t* n_out, uint64_t* n_records);
+/* Milliseconds the parse kernels of the last call took on the device (HIP events). */
+int  jfgpu_parser_last_ms(jfgpu_parser* p, double* ms);
 
 /* ---- measurement helpers (bench.py; not part of the reference surface) -- */
 /* Per-kernel HIP-event timing on the table's stream.  which: 0 count (direct), 1 add_keys,

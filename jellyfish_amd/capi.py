@@ -13,7 +13,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libjfgpu.so")
 
-OK, E_INVALID, E_NO_DEVICE, E_ALLOC, E_FULL, E_HIP, E_UNSUPPORTED = range(7)
+OK, E_INVALID, E_NO_DEVICE, E_ALLOC, E_FULL, E_HIP, E_UNSUPPORTED, E_FORMAT = range(8)
+PARSE_FASTA, PARSE_FASTQ, PARSE_CONTINUE = 1, 2, 4
 
 
 class JfgpuError(RuntimeError):
@@ -89,6 +90,11 @@ SIGNATURES = {
     "jfgpu_bc_load": (C.c_int, [_P, _P]),
     "jfgpu_bc_keys": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_int]),
     "jfgpu_attach_bloom": (C.c_int, [_P, _P]),
+    "jfgpu_parser_create": (C.c_int, [C.c_int, C.c_uint32, C.POINTER(_P)]),
+    "jfgpu_parser_destroy": (None, [_P]),
+    "jfgpu_parser_parse_dev": (C.c_int, [_P, _P, C.c_size_t, C.c_uint, C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
+    "jfgpu_parser_parse": (C.c_int, [_P, _P, C.c_size_t, C.c_uint, C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
+    "jfgpu_parser_last_ms": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "jfgpu_set_growth": (C.c_int, [_P, C.c_int]),
     "jfgpu_set_mode": (C.c_int, [_P, C.c_int]),
     "jfgpu_reserve": (C.c_int, [_P, C.c_uint64]),
@@ -405,3 +411,39 @@ def decode_records(recs: np.ndarray, k: int, counter_len: int):
     for b in range(counter_len):
         cnts |= recs[:, kb + b].astype(np.uint64) << np.uint64(8 * b)
     return (keys[:, 0] if kw == 1 else keys), cnts
+
+
+class Parser:
+    """FASTA / FASTQ bytes -> contract buffer on the device (jfgpu_parser*)."""
+
+    def __init__(self, k, device=-1):
+        self._lib = load()
+        h = _P()
+        _check(self._lib.jfgpu_parser_create(device, k, C.byref(h)))
+        self._h = h
+        self.records = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.jfgpu_parser_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _call(self, fn, ptr, n, flags):
+        out, n_out, recs = _P(), C.c_size_t(), C.c_uint64()
+        _check(fn(self._h, ptr, n, flags, C.byref(out), C.byref(n_out), C.byref(recs)))
+        self.records = recs.value
+        return (out.value or 0), n_out.value
+
+    def parse(self, data: bytes, flags):
+        """Host bytes in; (device pointer, length) of the contract buffer out."""
+        return self._call(self._lib.jfgpu_parser_parse, data, len(data), flags)
+
+    def parse_dev(self, d_ptr, n, flags):
+        return self._call(self._lib.jfgpu_parser_parse_dev, _ptr(d_ptr), n, flags)
+
+    def last_ms(self):
+        ms = C.c_double()
+        _check(self._lib.jfgpu_parser_last_ms(self._h, C.byref(ms)))
+        return ms.value

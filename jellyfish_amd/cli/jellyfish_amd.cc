@@ -24,6 +24,7 @@
 
 #include <jellyfish_amd/dumpers.hpp>
 #include <jellyfish_amd/sequence_parser.hpp>
+#include <jellyfish_amd/device_parser.hpp>
 
 using namespace jellyfish_amd;
 
@@ -83,7 +84,7 @@ int count_main(int argc, char* argv[]) {
 
   unsigned mer_len = 0, threads = 1, counter_len = 7, out_counter_len = 4, reprobes = 126, Files = 1;
   uint64_t size = 0, lower = 0, upper = std::numeric_limits<uint64_t>::max();
-  bool size_given = false, lower_given = false, upper_given = false, canonical = false, text = false, no_write = false, disk = false;
+  bool size_given = false, lower_given = false, upper_given = false, canonical = false, text = false, no_write = false, disk = false, host_parse = false;
   int device = -1;
   std::string output = "mer_counts.jf", timing, bc_path;
   std::vector<std::string> files;
@@ -105,6 +106,7 @@ int count_main(int argc, char* argv[]) {
     else if(a.cur() == "-C" || a.cur() == "--canonical") canonical = true;
     else if(a.cur() == "--text") text = true;
     else if(a.cur() == "--no-write") no_write = true;
+    else if(a.cur() == "--host-parse") host_parse = true;   // read the files with the host reader instead of the device parser
     else if(a.cur() == "--disk") disk = true;   // do_size_doubling(false) (count_main.cc:276-277); no spill files yet: a full table is an error
     else if(a.cur() == "--no-merge" || a.cur() == "--no-unlink") { /* spill-to-disk knobs */ }
     else if(a.is("", "--bf-size") || a.is("", "--bf-fp") || a.is("", "--if") || a.is("-Q", "--min-qual-char") ||
@@ -125,7 +127,8 @@ int count_main(int argc, char* argv[]) {
                    " -U, --upper-count=uint64    Don't output k-mer with count > upper-count\n"
                    "     --text                  Dump in text format (false)\n"
                    "     --timing=Timing file    Print timing information\n"
-                   "     --device=int            HIP device ordinal (current)\n";
+                   "     --device=int            HIP device ordinal (current)\n"
+                   "     --host-parse            Parse the sequence files on the host (default: on the device)\n";
       return 0;
     } else if(a.cur().size() > 1 && a.cur()[0] == '-' && a.cur() != "-") die("Unknown option '" + a.cur() + "'");
     else files.push_back(a.cur());
@@ -172,10 +175,19 @@ int count_main(int argc, char* argv[]) {
   const double init_s = seconds_since(start_time);
 
   auto count_start = std::chrono::steady_clock::now();
+  double parse_ms = 0; size_t fallback_bytes = 0;
   try {
-    sequence_parser parser(mer_len);
-    for(const auto& f : files)
-      parser.parse_file(f.c_str(), [&](const char* buf, size_t n) { ary->count_sequence(buf, n); });
+    if(host_parse) {
+      sequence_parser parser(mer_len);
+      for(const auto& f : files)
+        parser.parse_file(f.c_str(), [&](const char* buf, size_t n) { ary->count_sequence(buf, n); });
+    } else {
+      device_sequence_parser parser(mer_len, device);
+      for(const auto& f : files)
+        parser.parse_file(f.c_str(), [&](const char* d_buf, size_t n) { ary->count_sequence_dev(d_buf, n); },
+                          [&](const char* buf, size_t n) { ary->count_sequence(buf, n); }, [&]() { ary->wait_consumed(); });
+      parse_ms = parser.device_ms(); fallback_bytes = parser.host_fallback_bytes();
+    }
     ary->done();
   } catch(std::exception& e) { die(e.what()); }
   const double count_s = seconds_since(count_start);
@@ -198,6 +210,8 @@ int count_main(int argc, char* argv[]) {
     tf << "Init     " << init_s << "\n"
        << "Counting " << count_s << "\n"
        << "Writing  " << write_s << "\n";
+    if(!host_parse && getenv("JFGPU_TIMING_DETAIL"))     // extra lines only on request: the file keeps the reference's three
+      tf << "DeviceParse " << parse_ms / 1e3 << "\n" << "HostParsedBytes " << fallback_bytes << "\n";
   }
   return 0;
 }
@@ -209,7 +223,7 @@ int bc_main(int argc, char* argv[]) {
   file_header header;
   header.fill_standard();
   header.set_cmdline(argc, argv);
-  unsigned mer_len = 0; uint64_t size = 0; double fpr = 0.001; bool canonical = false, size_given = false;
+  unsigned mer_len = 0; uint64_t size = 0; double fpr = 0.001; bool canonical = false, size_given = false, host_parse = false;
   int device = -1;
   std::string output = "mer_bloom_filter", timing;
   std::vector<std::string> files;
@@ -224,6 +238,7 @@ int bc_main(int argc, char* argv[]) {
     else if(a.is("", "--timing")) timing = a.value("", "--timing");
     else if(a.is("", "--device")) device = atoi(a.value("", "--device").c_str());
     else if(a.cur() == "-C" || a.cur() == "--canonical") canonical = true;
+    else if(a.cur() == "--host-parse") host_parse = true;
     else if(a.cur().size() > 1 && a.cur()[0] == '-') die("Unknown option '" + a.cur() + "'");
     else files.push_back(a.cur());
   }
@@ -255,9 +270,17 @@ int bc_main(int argc, char* argv[]) {
   const double init_s = seconds_since(start_time);
   auto count_start = std::chrono::steady_clock::now();
   try {
-    sequence_parser parser(mer_len);
-    for(const auto& f : files)
-      parser.parse_file(f.c_str(), [&](const char* buf, size_t n) { if(jfgpu_bc_insert_ascii(bc, buf, n)) throw std::runtime_error(jfgpu_last_error()); });
+    auto host_sink = [&](const char* buf, size_t n) { if(jfgpu_bc_insert_ascii(bc, buf, n)) throw std::runtime_error(jfgpu_last_error()); };
+    if(host_parse) {
+      sequence_parser parser(mer_len);
+      for(const auto& f : files) parser.parse_file(f.c_str(), host_sink);
+    } else {
+      device_sequence_parser parser(mer_len, device);
+      for(const auto& f : files)
+        parser.parse_file(f.c_str(),
+                          [&](const char* d_buf, size_t n) { if(jfgpu_bc_insert_ascii_dev(bc, d_buf, n)) throw std::runtime_error(jfgpu_last_error()); },
+                          host_sink, [&]() { if(jfgpu_bc_sync(bc, nullptr)) throw std::runtime_error(jfgpu_last_error()); });
+    }
     if(jfgpu_bc_sync(bc, nullptr)) throw std::runtime_error(jfgpu_last_error());
   } catch(std::exception& e) { die(e.what()); }
   const double count_s = seconds_since(count_start);

@@ -100,6 +100,10 @@ public:
   // ---- hot path -----------------------------------------------------------
   // One parser-contract buffer (count_main.cc:152-163 loop body on the device).
   void count_sequence(const char* bases, size_t n) { flush(); jf_check(jfgpu_count_ascii(t_, bases, n)); }
+  // The same for a buffer already in device memory (device_sequence_parser); wait_consumed() says
+  // when buffers handed over so far may be overwritten.
+  void count_sequence_dev(const char* d_bases, size_t n) { flush(); jf_check(jfgpu_count_ascii_dev(t_, d_bases, n)); }
+  void wait_consumed() { jf_check(jfgpu_wait(t_)); }
 
   // hash_counter::add(k, v) (hash_counter.hpp:122-126): batched, thread-safe.
   void add(const mer_dna& k, uint64_t v) {

@@ -92,3 +92,58 @@ def test_count_multiple_files_and_hash_full(cli, tmp_path):
     r = subprocess.run([cli, "count", "-m", "21", "-s", "64k", "-o", str(tmp_path / "bad.jf"), os.path.join(GOLD, "manifest.json")],
                        capture_output=True)
     assert r.returncode == 1 and b"Unsupported format" in r.stderr
+
+
+def _wrapped_fastq(n):
+    import random
+    rng = random.Random(5)
+    out = []
+    for r in range(n):
+        seq = "".join(rng.choice("ACGT") for _ in range(120))
+        out.append("@r%d\n%s\n%s\n+\n%s\n%s\n" % (r, seq[:70], seq[70:], "I" * 70, "I" * 50))
+    return "".join(out).encode()
+
+
+def test_device_parse_equals_host_parse(cli, tmp_path):
+    """The default feed (device parser) and --host-parse write byte-identical files, for FASTA, strict
+    FASTQ, and wrapped FASTQ (which the device parser hands back to the host reader)."""
+    inputs = {"fa": os.path.join(GOLD, "edge_cases.fa"),
+              "fq": os.path.join(GOLD, [f for f in os.listdir(GOLD) if f.endswith(".fq")][0])}
+    w = tmp_path / "wrapped.fq"
+    w.write_bytes(_wrapped_fastq(500))
+    inputs["wrapped"] = str(w)
+    for tag, inp in inputs.items():
+        a, b = str(tmp_path / (tag + ".dev.jf")), str(tmp_path / (tag + ".host.jf"))
+        base = [cli, "count", "-m", "21", "-C", "-s", "1M"]
+        env = dict(os.environ, JFGPU_TIMING_DETAIL="1")
+        subprocess.check_call(base + ["-o", a, "--timing", str(tmp_path / "tm"), inp], env=env)
+        subprocess.check_call(base + ["-o", b, "--host-parse", inp])
+        da = subprocess.check_output([cli, "dump", "-c", a])
+        assert da == subprocess.check_output([cli, "dump", "-c", b]) and len(da) > 0
+        tm = dict(l.split() for l in open(tmp_path / "tm"))
+        assert (int(tm["HostParsedBytes"]) > 0) == (tag == "wrapped")
+    bad = tmp_path / "bad.fq"
+    bad.write_bytes(b"@r\nACGTACGTACGTACGTACGTACGT\n+\nIIII\n")
+    r = subprocess.run([cli, "count", "-m", "21", "-s", "1M", "-o", str(tmp_path / "x.jf"), str(bad)], capture_output=True)
+    assert r.returncode != 0 and b"Invalid fastq sequence" in r.stderr      # mer_overlap_sequence_parser.hpp:308
+
+
+def test_many_chunks_equal_one(cli, tmp_path):
+    """Small device chunks (JFGPU_PARSE_CHUNK) cut a multi-line FASTA and a FASTQ in many places."""
+    import random
+    rng = random.Random(11)
+    fa = tmp_path / "multi.fa"
+    with open(fa, "wb") as f:
+        for r in range(300):
+            seq = "".join(rng.choice("ACGT") for _ in range(rng.choice([30, 500, 3000])))
+            f.write((">s%d\n" % r).encode())
+            for i in range(0, len(seq), 60):
+                f.write(seq[i:i + 60].encode() + b"\n")
+    fq = os.path.join(GOLD, [f for f in os.listdir(GOLD) if f.endswith(".fq")][0])
+    for inp in (str(fa), fq):
+        outs = []
+        for chunk in ("65536", "1073741824"):
+            o = str(tmp_path / ("c" + chunk + ".jf"))
+            subprocess.check_call([cli, "count", "-m", "25", "-C", "-s", "2M", "-o", o, inp], env=dict(os.environ, JFGPU_PARSE_CHUNK=chunk))
+            outs.append(subprocess.check_output([cli, "dump", "-c", o]))
+        assert outs[0] == outs[1] and len(outs[0]) > 0

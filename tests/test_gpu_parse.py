@@ -1,0 +1,199 @@
+"""Device-side FASTA / FASTQ parse (jfgpu_parser_*, kernels_parse.hip.hpp) against the oracle's
+parser and the reference binary.  -m gpu only.
+
+The device writes one 'N' for EVERY header (the reference writes none before a file's first record,
+mer_overlap_sequence_parser.hpp:173-176), so buffers are compared with leading 'N's stripped;
+k-mer counts are compared exactly."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def dev_parse(capi, parser, data, flags, holder):
+    ptr, n = parser.parse(data, flags)
+    return bytes(holder.d2h(ptr, n)) if n else b""
+
+
+@pytest.fixture()
+def tools(gpu):
+    t = gpu.Table(k=21, size=1 << 12)      # only used for raw device copies
+    p = gpu.Parser(21)
+    yield gpu, p, t
+    p.close(); t.close()
+
+
+def rnd_fasta(rng, n_records, eol=b"\n", width=None, final_newline=True, junk=True):
+    out = bytearray()
+    for r in range(n_records):
+        out += b">read_%d some > description" % r + eol
+        ln = rng.choice([0, 1, 5, 20, 21, 59, 60, 61, 150, 400, 5000]) if junk else 150
+        seq = bytes(rng.choice(b"ACGTACGTACGTacgtNnR>") if junk else rng.choice(b"ACGT") for _ in range(ln))
+        w = width or rng.choice([1, 7, 60, 80, 10 ** 9])
+        for i in range(0, len(seq), w):
+            out += seq[i:i + w] + eol
+        if junk and rng.random() < 0.1:
+            out += eol                          # blank line inside / after a record
+    if not final_newline:
+        while out and out[-1:] in (b"\n", b"\r"):
+            out = out[:-1]
+    return bytes(out)
+
+
+def rnd_fastq(rng, n_records, eol=b"\n", final_newline=True):
+    out = bytearray()
+    for r in range(n_records):
+        ln = rng.choice([0, 1, 20, 21, 36, 100, 150, 151, 250])
+        seq = bytes(rng.choice(b"ACGTACGTACGTN") for _ in range(ln))
+        qual = bytes(rng.choice(b"@+IIIIFFF#>!5") for _ in range(ln))     # '@' and '+' may start a quality line
+        out += b"@r%d" % r + eol + seq + eol + (b"+" if r % 2 else b"+r%d" % r) + eol + qual + eol
+    if not final_newline:
+        out = out[:-len(eol)]
+    return bytes(out)
+
+
+@pytest.mark.parametrize("name", ["reads150_s42.fa", "edge_cases.fa", "reads150_dup.fa"])
+def test_golden_fasta(tools, name):
+    capi, p, t = tools
+    data = open(os.path.join(GOLD, name), "rb").read()
+    got = dev_parse(capi, p, data, capi.PARSE_FASTA, t)
+    assert got.lstrip(b"N") == O.parse_file(data).lstrip(b"N")
+    assert p.records == sum(1 for l in data.split(b"\n") if l.startswith(b">"))
+
+
+def test_golden_fastq(tools):
+    capi, p, t = tools
+    name = [f for f in os.listdir(GOLD) if f.endswith((".fq", ".fastq"))][0]
+    data = open(os.path.join(GOLD, name), "rb").read()
+    got = dev_parse(capi, p, data, capi.PARSE_FASTQ, t)
+    assert got.lstrip(b"N") == O.parse_file(data).lstrip(b"N")
+    assert p.records == data.count(b"\n") // 4
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("eol", [b"\n", b"\r\n"])
+def test_random_fasta_layouts(tools, seed, eol):
+    capi, p, t = tools
+    rng = random.Random(1000 + seed)
+    data = rnd_fasta(rng, rng.choice([1, 3, 40, 400]), eol=eol, final_newline=bool(seed & 1))
+    got = dev_parse(capi, p, data, capi.PARSE_FASTA, t)
+    assert got.lstrip(b"N") == O.parse_file(data).lstrip(b"N")
+
+
+def test_fasta_carriage_return_runs(tools):
+    capi, p, t = tools
+    data = b">a\r\r\nACGT\r\r\n\r\nAC\rGT\nTTTT\r\n\r>b\nGGGG\r"
+    got = dev_parse(capi, p, data, capi.PARSE_FASTA, t)
+    assert got.lstrip(b"N") == O.parse_file(data).lstrip(b"N")
+    assert b"AC\rGT" in got                     # a lone '\r' inside a line is data (breaks the k-mer), not a line end
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fasta_chunks_with_seam(tools, seed):
+    """A file cut at arbitrary line boundaries: chunk i+1 starts with the last k-1 characters of the
+    output so far, and the stream minus the seams is the one-shot output."""
+    capi, p, t = tools
+    rng = random.Random(77 + seed)
+    data = rnd_fasta(rng, 300, width=rng.choice([3, 60]), junk=bool(seed & 1))
+    whole = dev_parse(capi, p, data, capi.PARSE_FASTA, t)
+    cuts = sorted(rng.sample([i + 1 for i, c in enumerate(data) if c == 10 and i + 1 < len(data)], 12))
+    stream = b""
+    for i, (a, b) in enumerate(zip([0] + cuts, cuts + [len(data)])):
+        got = dev_parse(capi, p, data[a:b], capi.PARSE_FASTA | (capi.PARSE_CONTINUE if i else 0), t)
+        seam = min(len(stream), 20)
+        assert got[:seam] == stream[len(stream) - seam:]
+        stream += got[seam:]
+    assert stream == whole
+
+
+@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("eol", [b"\n", b"\r\n"])
+def test_random_fastq(tools, seed, eol):
+    capi, p, t = tools
+    rng = random.Random(500 + seed)
+    data = rnd_fastq(rng, rng.choice([1, 2, 50, 3000]), eol=eol, final_newline=bool(seed & 1))
+    got = dev_parse(capi, p, data, capi.PARSE_FASTQ, t)
+    assert got.lstrip(b"N") == O.parse_file(data).lstrip(b"N")
+
+
+@pytest.mark.parametrize("bad", [
+    b"@r\nACGT\nACGT\n+\nIIII\nIIII\n",                 # wrapped sequence
+    b"@r\nACGT\n+\nIII\n",                               # short quality
+    b"@r\nACGT\n+\nIIII\n\n@s\nAC\n+\nII\n",             # blank line between records
+    b"@r\nACGT\n+\nIIII\n@s\nAC\n",                      # truncated last record
+    b"@r\nACGT\n-\nIIII\n",                              # no '+' line
+])
+def test_fastq_outside_the_strict_layout_is_refused(tools, bad):
+    capi, p, t = tools
+    with pytest.raises(capi.JfgpuError) as e:
+        p.parse(bad, capi.PARSE_FASTQ)
+    assert e.value.code == capi.E_FORMAT
+    # the parser is still usable afterwards
+    good = b"@r\nACGT\n+\nIIII\n"
+    assert dev_parse(capi, p, good, capi.PARSE_FASTQ, t) == b"NACGT"
+
+
+def test_empty_and_tiny_chunks(tools):
+    capi, p, t = tools
+    assert p.parse(b"", capi.PARSE_FASTA) == (0, 0)
+    assert dev_parse(capi, p, b">x", capi.PARSE_FASTA, t) == b"N"
+    assert dev_parse(capi, p, b">x\nA", capi.PARSE_FASTA, t) == b"NA"
+    assert dev_parse(capi, p, b"ACGT\n", capi.PARSE_FASTA, t) == b"ACGT"     # a chunk may start inside a record
+
+
+@pytest.mark.parametrize("fmt", ["fa", "fq"])
+def test_parse_then_count_equals_reference(gpu, tmp_path, fmt):
+    """File bytes -> device parse -> device count == the reference binary on the same file."""
+    if not O.have_ref():
+        pytest.skip("oracle/_ref not built")
+    rng = random.Random(9)
+    data = rnd_fasta(rng, 2000, eol=b"\r\n", junk=True) if fmt == "fa" else rnd_fastq(rng, 4000)
+    path = tmp_path / ("x." + fmt)
+    path.write_bytes(data)
+    k = 21
+    ref_lines, _ = O.ref_count_dump(str(path), k, 1 << 20, canonical=True, workdir=str(tmp_path))
+    t = gpu.Table(k=k, size=1 << 20, canonical=True)
+    p = gpu.Parser(k)
+    try:
+        ptr, n = p.parse(data, gpu.PARSE_FASTA if fmt == "fa" else gpu.PARSE_FASTQ)
+        t.count_ascii_dev(ptr, n)
+        t.sync()
+        recs = t.dump_records()
+        keys, cnts = gpu.decode_records(recs, k, t.info.out_counter_len)
+        mine = sorted("%s %d" % (O.to_str(np.array([kk], dtype=np.uint64), k), c) for kk, c in zip(keys.tolist(), cnts.tolist()))
+        assert mine == ref_lines
+    finally:
+        p.close(); t.close()
+
+
+def test_large_chunk_properties(gpu):
+    """64 MiB of FASTA: output length = bases + records, no newline or header byte survives, and the
+    k-mer total equals records * (len - k + 1)."""
+    n_reads, ln, k = 400000, 150, 21
+    rng = np.random.default_rng(3)
+    seq = rng.integers(0, 4, size=(n_reads, ln), dtype=np.uint8)
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)[seq]
+    rows = [b">r%07d\n" % i for i in range(n_reads)]
+    hdr = np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(n_reads, -1)
+    half = ln // 2
+    nl = np.full((n_reads, 1), 10, dtype=np.uint8)
+    data = np.concatenate([hdr, bases[:, :half], nl, bases[:, half:], nl], axis=1).tobytes()
+    t = gpu.Table(k=k, size=1 << 27, canonical=True)
+    p = gpu.Parser(k)
+    try:
+        ptr, n = p.parse(data, gpu.PARSE_FASTA)
+        assert n == n_reads * (ln + 1) and p.records == n_reads
+        out = bytes(t.d2h(ptr, n))
+        arr = np.frombuffer(out, dtype=np.uint8).reshape(n_reads, ln + 1)
+        assert (arr[:, 0] == ord("N")).all() and (arr[:, 1:] == bases).all()
+        t.count_ascii_dev(ptr, n)
+        s = t.stats()
+        assert s.total == n_reads * (ln - k + 1)
+    finally:
+        p.close(); t.close()
