@@ -1461,7 +1461,9 @@ int jfgpu_parser_parse_dev(jfgpu_parser* p, const char* d_bytes, size_t n, unsig
   HIP_TRY(hipStreamSynchronize(p->stream));
   uint64_t records = res.records;
   if(fmt == JFGPU_PARSE_FASTQ) {
-    const uint64_t lines = res.lines + (last != '\n' ? 1 : 0);
+    // a last line without '\n' still counts; so does an EMPTY last quality line (a record with no bases at the
+    // end of a file whose final newline is missing) -- the record check below compares the two lengths anyway
+    const uint64_t lines = res.lines + ((last != '\n' || res.lines % 4 == 3) ? 1 : 0);
     uint64_t flags_bad = 0;
     if(res.lines > max_lines) flags_bad |= PF_TOO_MANY_LINES;
     else if(lines % 4) flags_bad |= PF_TRUNCATED;

@@ -29,12 +29,12 @@ def tools(gpu):
     p.close(); t.close()
 
 
-def rnd_fasta(rng, n_records, eol=b"\n", width=None, final_newline=True, junk=True):
+def rnd_fasta(rng, n_records, eol=b"\n", width=None, final_newline=True, junk=True, alphabet=b"ACGTACGTACGTacgtNnR>"):
     out = bytearray()
     for r in range(n_records):
         out += b">read_%d some > description" % r + eol
         ln = rng.choice([0, 1, 5, 20, 21, 59, 60, 61, 150, 400, 5000]) if junk else 150
-        seq = bytes(rng.choice(b"ACGTACGTACGTacgtNnR>") if junk else rng.choice(b"ACGT") for _ in range(ln))
+        seq = bytes(rng.choice(alphabet) if junk else rng.choice(b"ACGT") for _ in range(ln))
         w = width or rng.choice([1, 7, 60, 80, 10 ** 9])
         for i in range(0, len(seq), w):
             out += seq[i:i + w] + eol
@@ -149,11 +149,17 @@ def test_empty_and_tiny_chunks(tools):
 
 @pytest.mark.parametrize("fmt", ["fa", "fq"])
 def test_parse_then_count_equals_reference(gpu, tmp_path, fmt):
-    """File bytes -> device parse -> device count == the reference binary on the same file."""
+    """File bytes -> device parse -> device count == the reference binary on the same file.
+
+    No '>' inside sequence lines here: when a line longer than the reference's 4 KiB parser buffer is
+    split exactly in front of a '>', the reference takes the continuation for a header and drops the
+    rest of that line (read_sequence's peek() != stop test after a capacity-limited get(),
+    mer_overlap_sequence_parser.hpp:264-266) -- an artifact of its buffer size that neither the oracle
+    nor the engine reproduces; both keep a mid-line '>' as a k-mer-breaking character."""
     if not O.have_ref():
         pytest.skip("oracle/_ref not built")
     rng = random.Random(9)
-    data = rnd_fasta(rng, 2000, eol=b"\r\n", junk=True) if fmt == "fa" else rnd_fastq(rng, 4000)
+    data = rnd_fasta(rng, 2000, eol=b"\r\n", junk=True, alphabet=b"ACGTACGTACGTacgtNnRY-") if fmt == "fa" else rnd_fastq(rng, 4000)
     path = tmp_path / ("x." + fmt)
     path.write_bytes(data)
     k = 21
