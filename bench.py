@@ -200,9 +200,9 @@ def main():
         # (profiles/r01_traffic.json); only quoted when the run matches that configuration.
         traffic, traffic_src = None, None
         tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tj) and world == 1 and slot_names[which] == "tile_insert" and abs(args.gbp - 10.0) < 1e-9 and args.lsize == 34:
-            traffic = json.load(open(tj))["tile_insert_timed_launch_bytes"]
-            traffic_src = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, same command)"
+        if os.path.exists(tj) and world == 1 and not force_dist and abs(args.gbp - 10.0) < 1e-9 and args.lsize == 34 and steps == 10:
+            traffic = json.load(open(tj)).get("per_timed_launch_bytes", {}).get(slot_names[which])
+            traffic_src = None if traffic is None else "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, same command)"
         out = {
             "metric": "k-mers/sec at k=21 canonical, 150 bp synthetic reads, bit-exact counts",
             "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": steps, "warmup": warmup,

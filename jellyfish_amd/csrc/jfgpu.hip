@@ -318,6 +318,14 @@ void launch_p1(jfgpu_table* t, bool scatter, bool from_keys, const uint8_t* base
   ITEM* out = (ITEM*)d_items;
 #define P1(SC, FK, RT, BL) hipLaunchKernelGGL((p1_kernel<ITEM, SC, FK, RT, BL>), grid, block, 0, t->stream, t->dt, t->pg, base, lo, hi, t->d_M1, d_off, out)
   const bool rt = t->returning, bl = t->dt.bloom.data != nullptr && !from_keys;   // the filter applies to the sequence feed only
+  // the common key widths get kernels with the byte count of the hash compiled in (no per-k-mer switch)
+#define P1N(FK, N) hipLaunchKernelGGL((p1_kernel<ITEM, false, FK, false, false, N>), grid, block, 0, t->stream, t->dt, t->pg, base, lo, hi, t->d_M1, d_off, out)
+  if(!scatter && !bl && t->g.nbytes >= 6) {
+    if(from_keys) { if(t->g.nbytes == 6) P1N(true, 6); else if(t->g.nbytes == 7) P1N(true, 7); else P1N(true, 8); }
+    else { if(t->g.nbytes == 6) P1N(false, 6); else if(t->g.nbytes == 7) P1N(false, 7); else P1N(false, 8); }
+    return;
+  }
+#undef P1N
   if(!scatter) { if(from_keys) P1(false, true, false, false); else if(bl) P1(false, false, false, true); else P1(false, false, false, false); }
   else if(from_keys) { if(rt) P1(true, true, true, false); else P1(true, true, false, false); }
   else if(bl) { if(rt) P1(true, false, true, true); else P1(true, false, false, true); }
@@ -355,12 +363,17 @@ int part_ingest(jfgpu_table* t, const uint8_t* base, int64_t lo, int64_t hi, boo
       const size_t lds = (size_t)kPTilePos * 6;
       const bool bl = t->dt.bloom.data != nullptr;
 #define PS(RT, BL) hipLaunchKernelGGL((p1_scatter_sorted_kernel<RT, BL>), dim3(t->g1), dim3(kPBlock), lds, t->stream, t->dt, t->pg, base, lo, hi, (const uint32_t*)t->d_M1, (const uint64_t*)b.off, (uint32_t*)b.items)
-      if(t->returning) { if(bl) PS(true, true); else PS(true, false); } else { if(bl) PS(false, true); else PS(false, false); }
+#define PSN(N) hipLaunchKernelGGL((p1_scatter_sorted_kernel<false, false, N>), dim3(t->g1), dim3(kPBlock), lds, t->stream, t->dt, t->pg, base, lo, hi, (const uint32_t*)t->d_M1, (const uint64_t*)b.off, (uint32_t*)b.items)
+      if(!t->returning && !bl && t->g.nbytes >= 6) { if(t->g.nbytes == 6) PSN(6); else if(t->g.nbytes == 7) PSN(7); else PSN(8); }
+      else if(t->returning) { if(bl) PS(true, true); else PS(true, false); } else { if(bl) PS(false, true); else PS(false, false); }
+#undef PSN
 #undef PS
     }
     else if(t->item32) {              // encoded keys, 32-bit items: same write-combining scatter
-      hipLaunchKernelGGL(p1_keys_scatter_sorted_kernel, dim3(t->g1), dim3(kPBlock), (size_t)kPTilePos * 6, t->stream, t->dt, t->pg,
-                         (const uint64_t*)base, hi, (const uint32_t*)t->d_M1, (const uint64_t*)b.off, (uint32_t*)b.items);
+#define PK(N) hipLaunchKernelGGL(p1_keys_scatter_sorted_kernel<N>, dim3(t->g1), dim3(kPBlock), (size_t)kPTilePos * 6, t->stream, t->dt, t->pg, \
+                                 (const uint64_t*)base, hi, (const uint32_t*)t->d_M1, (const uint64_t*)b.off, (uint32_t*)b.items)
+      if(t->g.nbytes == 6) PK(6); else if(t->g.nbytes == 7) PK(7); else if(t->g.nbytes == 8) PK(8); else PK(0);
+#undef PK
     }
     else launch_p1<uint64_t>(t, true, from_keys, base, lo, hi, b.off, b.items);
   }
@@ -674,7 +687,10 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_sorted_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_sorted_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_sorted_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
-    HIP_TRY(hipFuncSetAttribute((const void*)p1_keys_scatter_sorted_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
+#define PATTR(N) HIP_TRY(hipFuncSetAttribute((const void*)p1_keys_scatter_sorted_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6)); \
+                 HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_sorted_kernel<false, false, N>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6))
+    PATTR(0); PATTR(6); PATTR(7); PATTR(8);
+#undef PATTR
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint32_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * 16 * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint64_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * 8 * 8));
   }

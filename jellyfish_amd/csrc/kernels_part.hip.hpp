@@ -54,6 +54,40 @@ __device__ inline ITEM make_item(const TableGeom& g, const PartGeom& P, uint64_t
   return (ITEM)((rest << g.rem_bits) | rem);
 }
 
+// Runs of identical consecutive k-mers (homopolymers, tandem repeats) bypass the partition: one
+// table_add per run.  They are rare, so the hot unrolled loops only note that a lane saw one and
+// this rolled replay of the lane's 16 positions applies them -- one copy of the probing code per
+// kernel instead of seventeen.
+template <bool RETURNING, bool BLOOM>
+__device__ inline uint32_t apply_runs(const DevTable& T, const uint64_t* s_fwd, const LaneWords& L) {
+  const TableGeom& g = T.g;
+  const uint32_t k = g.k;
+  uint64_t fw = (((uint64_t)L.p2 << 32) | L.p1) & g.key_mask;
+  uint64_t rc = revcomp64(fw, k);
+  const uint64_t kwin = k >= 64 ? ~0ull : ((1ull << k) - 1);
+  const uint32_t rc_shift = 2 * (k - 1);
+  uint64_t prev = 0; uint32_t run = 0, applied = 0;
+#pragma unroll 1
+  for(int j = 0; j <= kPerLane; ++j) {          // the extra iteration only closes the last run
+    uint64_t key = 0;
+    bool have = false;
+    if(j < kPerLane) {
+      const uint64_t c = (L.cur >> (2 * (15 - j))) & 3u;
+      fw = ((fw << 2) | c) & g.key_mask;
+      rc = (rc >> 2) | ((3ull - c) << rc_shift);
+      if(((L.inv48 >> (15 - j)) & kwin) == 0) {
+        key = (g.canonical && rc < fw) ? rc : fw;
+        have = !BLOOM || bloom_admits(T.bloom, key);
+      }
+      if(!have) continue;
+      if(run && key == prev) { ++run; continue; }
+    }
+    if(run > 1) { table_add<RETURNING>(T, s_fwd, prev, run); ++applied; }
+    prev = key; run = have ? 1 : 0;
+  }
+  return applied;
+}
+
 // ---- P1 ------------------------------------------------------------------------------
 // SCATTER == false: histogram of this block's k-mers per bucket -> M[blockIdx][*]
 // SCATTER == true : replay, items written at bucket_off[j] + M[blockIdx][j] + running count
@@ -61,7 +95,7 @@ __device__ inline ITEM make_item(const TableGeom& g, const PartGeom& P, uint64_t
 //                   receive side of the multi-GPU exchange) instead of a contract buffer
 // Runs of >= 2 identical consecutive k-mers in one lane (homopolymers, tandem repeats) bypass
 // the partition and go straight to the table with one atomic per run (scatter pass only).
-template <typename ITEM, bool SCATTER, bool FROM_KEYS, bool RETURNING, bool BLOOM>
+template <typename ITEM, bool SCATTER, bool FROM_KEYS, bool RETURNING, bool BLOOM, int NB = 0>
 __global__ __launch_bounds__(kPBlock) void p1_kernel(DevTable T, PartGeom P, const uint8_t* __restrict__ base, int64_t lo,
                                                      int64_t hi, uint32_t* __restrict__ M,
                                                      const uint64_t* __restrict__ bucket_off, ITEM* __restrict__ out) {
@@ -77,7 +111,7 @@ __global__ __launch_bounds__(kPBlock) void p1_kernel(DevTable T, PartGeom P, con
   const uint32_t bshift = T.g.lsize_l - P.b1;
 
   auto emit = [&](uint64_t key) {
-    const uint64_t pos = hash_tables(s_fwd, key, T.g.nbytes);
+    const uint64_t pos = hash_tables_t<NB>(s_fwd, key, T.g.nbytes);
     const uint64_t local = pos & T.g.local_mask;
     if((uint32_t)(pos >> T.g.lsize_l) != T.g.shard_id) {   // not ours: never silently inserted
       if(SCATTER) atomicAdd((unsigned long long*)&T.counters[CTR_MISROUTED], 1ull);
@@ -100,12 +134,10 @@ __global__ __launch_bounds__(kPBlock) void p1_kernel(DevTable T, PartGeom P, con
     for(int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
       lds_barrier();
       const LaneWords L = stage_tile(base, tile * kPTilePos, lo, hi, s_codes, s_inv);
-      uint64_t prev = 0; uint32_t run = 0;
+      uint64_t prev = 0; uint32_t run = 0; bool long_runs = false;
       auto flush_run = [&]() {
         if(run == 1) emit(prev);
-        else if(run > 1) {
-          if(SCATTER) { table_add<RETURNING>(T, s_fwd, prev, run); ++my_direct; }
-        }
+        else if(run > 1) long_runs = true;
       };
       for_each_kmer(T.g, L, [&](int, uint64_t key) {
         ++my_mers;
@@ -115,6 +147,7 @@ __global__ __launch_bounds__(kPBlock) void p1_kernel(DevTable T, PartGeom P, con
         prev = key; run = 1;
       });
       flush_run();
+      if(SCATTER && long_runs) my_direct += apply_runs<RETURNING, BLOOM>(T, s_fwd, L);
     }
   }
   lds_barrier();
@@ -236,7 +269,7 @@ __device__ inline void block_excl_scan_2048(const uint32_t* in, uint32_t* out, u
 // 16384 sequence positions = one chunk: every lane keeps its <= 17 emitted items in registers,
 // the block counting-sorts them by bucket in LDS and writes whole runs.  Same tile->block
 // assignment as the count pass, so the per-(block, bucket) cursors derived from M are exact.
-template <bool RETURNING, bool BLOOM>
+template <bool RETURNING, bool BLOOM, int NB = 0>
 __global__ __launch_bounds__(kPBlock) void p1_scatter_sorted_kernel(DevTable T, PartGeom P, const uint8_t* __restrict__ base,
                                                                     int64_t lo, int64_t hi, const uint32_t* __restrict__ M,
                                                                     const uint64_t* __restrict__ bucket_off,
@@ -264,18 +297,15 @@ __global__ __launch_bounds__(kPBlock) void p1_scatter_sorted_kernel(DevTable T, 
     uint32_t it[kPerLane + 1], dr[kPerLane + 1];
 #pragma unroll
     for(int e = 0; e <= kPerLane; ++e) dr[e] = 0xFFFFFFFFu;
-    uint64_t prev = 0; uint32_t run = 0;
+    uint64_t prev = 0; uint32_t run = 0; bool long_runs = false;
     auto flush_run = [&](int site) {
       if(run == 1) {
-        const uint64_t pos = hash_tables(s_fwd, prev, T.g.nbytes);
+        const uint64_t pos = hash_tables_t<NB>(s_fwd, prev, T.g.nbytes);
         const uint64_t local = pos & T.g.local_mask;
         const uint32_t b = P.b1 ? (uint32_t)(local >> bshift) : 0u;
         it[site] = make_item<uint32_t>(T.g, P, prev, local);
         dr[site] = (b << 16) | atomicAdd(&s_hist[b], 1u);
-      } else if(run > 1) {
-        table_add<RETURNING>(T, s_fwd, prev, run);
-        ++my_direct;
-      }
+      } else if(run > 1) long_runs = true;
     };
     for_each_kmer(T.g, L, [&](int j, uint64_t key) {
       if(BLOOM && !bloom_admits(T.bloom, key)) return;
@@ -284,6 +314,7 @@ __global__ __launch_bounds__(kPBlock) void p1_scatter_sorted_kernel(DevTable T, 
       prev = key; run = 1;
     });
     flush_run(kPerLane);
+    if(long_runs) my_direct += apply_runs<RETURNING, BLOOM>(T, s_fwd, L);
     lds_barrier();
     block_excl_scan_2048(s_hist, s_lstart, nb, s_wave);
     lds_barrier();
@@ -308,6 +339,7 @@ __global__ __launch_bounds__(kPBlock) void p1_scatter_sorted_kernel(DevTable T, 
 // The same write-combining scatter for a batch of encoded k-mers (hash_counter::add batches and the
 // receive side of the multi-GPU exchange).  Block b owns the contiguous slice the count pass
 // (p1_kernel<.., false, true, ..>) gave it and walks it in chunks of 16384 keys.
+template <int NB = 0>
 __global__ __launch_bounds__(kPBlock) void p1_keys_scatter_sorted_kernel(DevTable T, PartGeom P, const uint64_t* __restrict__ keys,
                                                                          int64_t n, const uint32_t* __restrict__ M,
                                                                          const uint64_t* __restrict__ bucket_off,
@@ -342,7 +374,7 @@ __global__ __launch_bounds__(kPBlock) void p1_keys_scatter_sorted_kernel(DevTabl
       dr[e] = 0xFFFFFFFFu;
       if(c0 + (int64_t)e * kPBlock + threadIdx.x < b1e) {
         const uint64_t key = kk[e] & T.g.key_mask;
-        const uint64_t pos = hash_tables(s_fwd, key, T.g.nbytes);
+        const uint64_t pos = hash_tables_t<NB>(s_fwd, key, T.g.nbytes);
         if((uint32_t)(pos >> T.g.lsize_l) != T.g.shard_id) { atomicAdd((unsigned long long*)&T.counters[CTR_MISROUTED], 1ull); continue; }
         const uint64_t local = pos & T.g.local_mask;
         const uint32_t b = P.b1 ? (uint32_t)(local >> bshift) : 0u;

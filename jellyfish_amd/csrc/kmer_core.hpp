@@ -140,6 +140,11 @@ JF_HD uint64_t hash_tables_n(const uint64_t* tbl, uint64_t key) {
   return pos;
 }
 
+// NB > 0: the number of key bytes is a compile-time constant of the kernel (no per-k-mer switch);
+// NB == 0: decided at run time.
+template <int NB>
+JF_HD uint64_t hash_tables_t(const uint64_t* tbl, uint64_t key, uint32_t nbytes);
+
 JF_HD uint64_t hash_tables(const uint64_t* tbl, uint64_t key, uint32_t nbytes) {
   switch(nbytes) {   // wave-uniform: one scalar branch, then a fully unrolled body
   case 1: return hash_tables_n<1>(tbl, key);
@@ -151,6 +156,12 @@ JF_HD uint64_t hash_tables(const uint64_t* tbl, uint64_t key, uint32_t nbytes) {
   case 7: return hash_tables_n<7>(tbl, key);
   default: return hash_tables_n<8>(tbl, key);
   }
+}
+
+template <int NB>
+JF_HD uint64_t hash_tables_t(const uint64_t* tbl, uint64_t key, uint32_t nbytes) {
+  if constexpr(NB == 0) return hash_tables(tbl, key, nbytes);
+  else return hash_tables_n<NB>(tbl, key);
 }
 
 struct SlotAddr {
