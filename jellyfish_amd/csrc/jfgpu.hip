@@ -43,7 +43,11 @@ constexpr size_t kStageBytes = 64u << 20;                  // host->device stagi
 constexpr int kNumProf = 8;   // 0 count 1 add_keys 2 shard-partition 3 lookup 4 P1 5 P2 6 tile-insert 7 items-direct
 enum Mode { MODE_AUTO = 0, MODE_DIRECT = 1, MODE_PARTITIONED = 2 };
 
-struct PendingBatch { void* items; uint64_t* off; uint64_t cap_items; };
+struct PendingBatch {
+  void* items; uint64_t* off; uint64_t cap_items;
+  uint32_t gran_cap = 0;                      // > 0: single-pass ("granule") batch, items per bucket region; off is in pair format
+  unsigned long long* tot = nullptr;          // granule batch: exact items per bucket
+};
 
 struct ProfSpan { hipEvent_t a, b; int which; uint64_t units; };
 
@@ -89,6 +93,8 @@ struct jfgpu_table {
   bool pristine = true;          // table known all-zero: tile_insert may skip the tile read
   std::vector<PendingBatch> pending;
   uint64_t pending_bytes = 0;
+  int p1_single = -1;            // single-pass P1: -1 auto (large batches), 0 never, 1 whenever the geometry allows (JFGPU_P1_SINGLE)
+  double p1_slack = 0.03;        // head-room of a bucket region over the mean (JFGPU_P1_SLACK; negative forces the exhausted path)
   uint32_t* d_M1 = nullptr; int g1 = 0;
   uint32_t* d_M2 = nullptr; int g2 = 0;
   // workspace arena for pending batches and flush temporaries: bump-allocated, reset at flush,
@@ -335,6 +341,21 @@ void launch_p1(jfgpu_table* t, bool scatter, bool from_keys, const uint8_t* base
 
 int part_flush(jfgpu_table* t);
 
+// Single-pass P1 (p1_scatter_granule_kernel): items per bucket region, 0 when the batch takes the exact
+// two-pass scheme.  Every block may strand part of one reservation per bucket, so small batches would be
+// mostly holes: auto mode wants the mean bucket load to be at least 4x that.
+uint32_t granule_cap(const jfgpu_table* t, bool from_keys, uint64_t max_items) {
+  if(!t->item32 || from_keys || t->pg.b2 == 0 || t->pg.b1 > 10 || t->p1_single == 0 || !t->g1) return 0;
+  const uint64_t nb = 1ull << t->pg.b1, strand = (uint64_t)t->g1 * kGran;
+  const uint64_t mean = (max_items + nb - 1) / nb;
+  if(t->p1_single < 0 && mean < 4 * strand) return 0;
+  const double want = (double)mean * (1.0 + t->p1_slack) + (double)strand;
+  uint64_t cap = want < (double)kGran ? kGran : (uint64_t)want;
+  cap = (cap + kGran - 1) / kGran * kGran;
+  if(cap > 0xFFFF0000ull) return 0;
+  return (uint32_t)cap;
+}
+
 // One batch (contract buffer or key array, on the device) through P1 into a pending batch.
 int part_ingest(jfgpu_table* t, const uint8_t* base, int64_t lo, int64_t hi, bool from_keys, uint64_t max_items) {
   if(!max_items) return JFGPU_OK;
@@ -344,17 +365,36 @@ int part_ingest(jfgpu_table* t, const uint8_t* base, int64_t lo, int64_t hi, boo
     HIP_TRY(hipMalloc((void**)&t->d_M1, (size_t)t->g1 * kMaxBuckets * sizeof(uint32_t)));
   }
   if(t->pending.size() >= kMaxSeg) { int rc = part_flush(t); if(rc) return rc; }
-  const size_t bytes = max_items * item_size(t);
-  const size_t need = align_up(bytes, 256) + align_up((nb + 1) * sizeof(uint64_t), 256) + 512;
+  const uint32_t gcap = granule_cap(t, from_keys, max_items);
+  const size_t bytes = gcap ? (size_t)nb * gcap * sizeof(uint32_t) : max_items * item_size(t);
+  const size_t need = align_up(bytes, 256) + align_up((2 * nb + 1) * sizeof(uint64_t), 256) + (gcap ? align_up(nb * 16, 256) : 0) + 1024;
   if(t->ws_used + need > t->ws_cap) {
     if(!t->pending.empty()) { int rc = part_flush(t); if(rc) return rc; }   // apply what is pending, arena is empty again
     if(need > t->ws_cap) { int rc = ws_grow(t, need); if(rc) return rc; }     // rc < 0: no memory -> caller goes direct
   }
   PendingBatch b{nullptr, nullptr, max_items};
   b.items = ws_alloc(t, bytes);
-  b.off = (uint64_t*)ws_alloc(t, (nb + 1) * sizeof(uint64_t));
+  b.off = (uint64_t*)ws_alloc(t, (2 * nb + 1) * sizeof(uint64_t));
   if(!b.items || !b.off) return fail(JFGPU_E_ALLOC, "partition workspace exhausted");
-  {
+  if(gcap) {
+    // one pass: reservations of kGran items inside fixed bucket regions (p1_scatter_granule_kernel)
+    unsigned int* gcur = (unsigned int*)ws_alloc(t, nb * 16);           // gcur[2 nb] (u32) then tot[nb] (u64)
+    if(!gcur) return fail(JFGPU_E_ALLOC, "partition workspace exhausted");
+    b.gran_cap = gcap; b.tot = (unsigned long long*)(gcur + 2 * nb);
+    HIP_TRY(hipMemsetAsync(gcur, 0, nb * 16, t->stream));
+    ProfScope ps(t, 4, (uint64_t)(hi - lo));
+    const size_t lds = (size_t)kPTilePos * 6;
+    const bool bl = t->dt.bloom.data != nullptr;
+#define PG(RT, BL, N) hipLaunchKernelGGL((p1_scatter_granule_kernel<RT, BL, N>), dim3(t->g1), dim3(kPBlock), lds, t->stream, t->dt, t->pg, base, lo, hi, gcap, gcur, b.tot, (uint32_t*)b.items)
+    if(bl) { if(t->returning) PG(true, true, 0); else PG(false, true, 0); }
+    else if(t->returning) PG(true, false, 0);
+    else if(t->g.nbytes == 6) PG(false, false, 6);
+    else if(t->g.nbytes == 7) PG(false, false, 7);
+    else if(t->g.nbytes == 8) PG(false, false, 8);
+    else PG(false, false, 0);
+#undef PG
+    hipLaunchKernelGGL(granule_finish_kernel, dim3((nb + 255) / 256), dim3(256), 0, t->stream, gcur, gcap, nb, b.off);
+  } else {
     ProfScope ps(t, 4, (uint64_t)(from_keys ? hi : hi - lo));
     if(t->item32) launch_p1<uint32_t>(t, false, from_keys, base, lo, hi, b.off, b.items);
     else          launch_p1<uint64_t>(t, false, from_keys, base, lo, hi, b.off, b.items);
@@ -389,12 +429,22 @@ int part_flush_t(jfgpu_table* t) {
   const uint32_t nb1 = 1u << t->pg.b1, nb2 = 1u << t->pg.b2;
   const size_t nbatch = t->pending.size();
   // bucket sizes of every pending batch (one small D2H; also drains the stream)
+  // (granule batches: the exact per-bucket counts, stored as a running sum so both kinds read alike)
   std::vector<uint64_t> offs(nbatch * (nb1 + 1));
-  for(size_t s = 0; s < nbatch; ++s)
-    HIP_TRY(hipMemcpyAsync(&offs[s * (nb1 + 1)], t->pending[s].off, (nb1 + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, t->stream));
+  for(size_t s = 0; s < nbatch; ++s) {
+    const PendingBatch& pb = t->pending[s];
+    if(pb.gran_cap) HIP_TRY(hipMemcpyAsync(&offs[s * (nb1 + 1) + 1], pb.tot, nb1 * sizeof(uint64_t), hipMemcpyDeviceToHost, t->stream));
+    else HIP_TRY(hipMemcpyAsync(&offs[s * (nb1 + 1)], pb.off, (nb1 + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, t->stream));
+  }
   uint64_t ctr[CTR_COUNT];
   HIP_TRY(hipMemcpyAsync(ctr, t->dt.counters, sizeof(ctr), hipMemcpyDeviceToHost, t->stream));
   HIP_TRY(hipStreamSynchronize(t->stream));
+  for(size_t s = 0; s < nbatch; ++s)
+    if(t->pending[s].gran_cap) {
+      uint64_t* o = &offs[s * (nb1 + 1)];
+      o[0] = 0;
+      for(uint32_t j = 0; j < nb1; ++j) o[j + 1] += o[j];
+    }
   std::vector<uint64_t> bucket_tot(nb1, 0);
   uint64_t total = 0, max_bucket = 0;
   for(size_t s = 0; s < nbatch; ++s)
@@ -403,7 +453,7 @@ int part_flush_t(jfgpu_table* t) {
   const uint64_t n_tiles = n_tiles_of(t);
   SegList S1; memset(&S1, 0, sizeof S1);
   S1.n = (uint32_t)nbatch;
-  for(size_t s = 0; s < nbatch; ++s) { S1.items[s] = t->pending[s].items; S1.off[s] = t->pending[s].off; }
+  for(size_t s = 0; s < nbatch; ++s) { S1.items[s] = t->pending[s].items; S1.off[s] = t->pending[s].off; S1.sh[s] = t->pending[s].gran_cap ? 1 : 0; }
   const size_t tile_lds = (size_t)8 << t->g.tile_bits;
   // always LOAD-capable: a tile is read only if its dirty byte is set (clean after jfgpu_clear)
   const bool rt = t->returning, load = true;
@@ -422,9 +472,11 @@ int part_flush_t(jfgpu_table* t) {
       const uint64_t n = offs[s * (nb1 + 1) + nb1];
       if(!n) continue;
       ProfScope ps(t, 7, n);
-      const dim3 grid((unsigned)grid_for(t, (n + kBlock - 1) / kBlock)), block(kBlock);
-      if(rt) hipLaunchKernelGGL((items_direct_kernel<ITEM, true>), grid, block, 0, t->stream, t->dt, t->pg, (const ITEM*)t->pending[s].items, (const uint64_t*)t->pending[s].off);
-      else   hipLaunchKernelGGL((items_direct_kernel<ITEM, false>), grid, block, 0, t->stream, t->dt, t->pg, (const ITEM*)t->pending[s].items, (const uint64_t*)t->pending[s].off);
+      const uint64_t span = t->pending[s].gran_cap ? (uint64_t)nb1 * t->pending[s].gran_cap : n;
+      const dim3 grid((unsigned)grid_for(t, (span + kBlock - 1) / kBlock)), block(kBlock);
+      const uint64_t gc = t->pending[s].gran_cap;
+      if(rt) hipLaunchKernelGGL((items_direct_kernel<ITEM, true>), grid, block, 0, t->stream, t->dt, t->pg, (const ITEM*)t->pending[s].items, (const uint64_t*)t->pending[s].off, gc);
+      else   hipLaunchKernelGGL((items_direct_kernel<ITEM, false>), grid, block, 0, t->stream, t->dt, t->pg, (const ITEM*)t->pending[s].items, (const uint64_t*)t->pending[s].off, gc);
     }
   } else if(t->pg.b2 == 0) {
     launch_tiles(S1, 0, nb1, total);
@@ -677,6 +729,8 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     if(!strcmp(m, "direct")) t->mode = MODE_DIRECT;
     else if(!strcmp(m, "partitioned")) t->mode = MODE_PARTITIONED;
   }
+  if(const char* m = getenv("JFGPU_P1_SINGLE")) t->p1_single = atoi(m) ? 1 : 0;     // tuning / test knobs of the single-pass P1
+  if(const char* m = getenv("JFGPU_P1_SLACK")) t->p1_slack = atof(m);
   {
     const int tl = (int)((size_t)8 << t->g.tile_bits);
 #define TATTR(I, R, L) HIP_TRY(hipFuncSetAttribute((const void*)tile_insert_kernel<I, R, L>, hipFuncAttributeMaxDynamicSharedMemorySize, tl))
@@ -688,9 +742,13 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_sorted_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_sorted_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
 #define PATTR(N) HIP_TRY(hipFuncSetAttribute((const void*)p1_keys_scatter_sorted_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6)); \
-                 HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_sorted_kernel<false, false, N>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6))
+                 HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_sorted_kernel<false, false, N>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6)); \
+                 HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_granule_kernel<false, false, N>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6))
     PATTR(0); PATTR(6); PATTR(7); PATTR(8);
 #undef PATTR
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_granule_kernel<true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_granule_kernel<false, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_granule_kernel<true, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint32_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * 16 * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint64_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * 8 * 8));
   }
@@ -1066,8 +1124,12 @@ int jfgpu_reserve(jfgpu_table* t, uint64_t input_bytes) {
   rc = part_flush(t); if(rc) return rc;
   const uint32_t nb1 = 1u << t->pg.b1, nb2 = 1u << t->pg.b2;
   // pending items (upper bound: one per input byte) + the P2 output of the same size + offsets
-  const size_t need = 2 * align_up(input_bytes * item_size(t), 256) + (n_tiles_of(t) + 1 + nb1) * sizeof(uint64_t) +
-                      (size_t)kMaxSeg * (align_up((nb1 + 1) * sizeof(uint64_t), 256) + 768) + ((size_t)1 << 20);
+  // (single-pass P1 batches are regions with head-room: slack + one stranded reservation per block and bucket)
+  const size_t pend = align_up(input_bytes * item_size(t), 256);
+  const size_t strand = (size_t)nb1 * (2 * (size_t)t->n_cu) * kGran * sizeof(uint32_t);          // per batch
+  const size_t headroom = t->item32 && t->pg.b2 ? (size_t)(pend * ((t->p1_slack > 0 ? t->p1_slack : 0.0) + 0.05)) + 2 * strand : 0;
+  const size_t need = 2 * pend + headroom + (n_tiles_of(t) + 1 + nb1) * sizeof(uint64_t) +
+                      (size_t)kMaxSeg * (align_up((2 * nb1 + 1) * sizeof(uint64_t), 256) + align_up(nb1 * 16, 256) + 1280) + ((size_t)1 << 20);
   rc = ws_grow(t, need);
   if(rc < 0) return fail(JFGPU_E_ALLOC, "not enough device memory to reserve the partition workspace");
   if(rc) return rc;

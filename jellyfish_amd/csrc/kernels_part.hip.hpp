@@ -41,11 +41,20 @@ struct PartGeom {
 };
 
 // Pending batches: batch s holds items grouped by P1 bucket, off[s][j] .. off[s][j+1].
+// sh[s] == 0: buckets are packed, bucket j = [off[j], off[j+1]).
+// sh[s] == 1: "granule" batches of the single-pass P1: bucket j = [off[2j], off[2j+1]) inside its own
+//             fixed-capacity region, and entries equal to the all-ones item are holes to skip.
 struct SegList {
   const void* items[kMaxSeg];
   const uint64_t* off[kMaxSeg];
+  uint8_t sh[kMaxSeg];
   uint32_t n;
 };
+__device__ inline uint64_t seg_lo(const SegList& S, uint32_t s, uint32_t j) { return S.off[s][(size_t)j << S.sh[s]]; }
+__device__ inline uint64_t seg_hi(const SegList& S, uint32_t s, uint32_t j) { return S.off[s][((size_t)j << S.sh[s]) + 1]; }
+template <typename ITEM> __device__ inline bool is_hole(const SegList& S, uint32_t s, ITEM it) { return S.sh[s] && it == (ITEM)~(ITEM)0; }
+
+constexpr uint32_t kGran = 64;                // items per reservation of the single-pass P1
 
 template <typename ITEM>
 __device__ inline ITEM make_item(const TableGeom& g, const PartGeom& P, uint64_t key, uint64_t local) {
@@ -221,7 +230,7 @@ __global__ __launch_bounds__(kPBlock) void p2_kernel(PartGeom P, uint32_t tag_bi
     s_cur[j] = SCATTER ? (goff[(size_t)bucket * nb + j] + Mq[j]) : 0ull;
   if(threadIdx.x == 0) {
     unsigned long long c = 0;
-    for(uint32_t s = 0; s < S.n; ++s) { s_seg_lo[s] = c; c += S.off[s][bucket + 1] - S.off[s][bucket]; }
+    for(uint32_t s = 0; s < S.n; ++s) { s_seg_lo[s] = c; c += seg_hi(S, s, bucket) - seg_lo(S, s, bucket); }
     s_seg_lo[S.n] = c;
   }
   lds_barrier();
@@ -232,9 +241,10 @@ __global__ __launch_bounds__(kPBlock) void p2_kernel(PartGeom P, uint32_t tag_bi
     const uint64_t slo = s_seg_lo[s], shi = s_seg_lo[s + 1];
     const uint64_t a = my_lo > slo ? my_lo : slo, b = my_hi < shi ? my_hi : shi;
     if(a >= b) continue;
-    const ITEM* src = reinterpret_cast<const ITEM*>(S.items[s]) + S.off[s][bucket] - slo;
+    const ITEM* src = reinterpret_cast<const ITEM*>(S.items[s]) + seg_lo(S, s, bucket) - slo;
     for(uint64_t v = a + threadIdx.x; v < b; v += blockDim.x) {
       const ITEM it = src[v];
+      if(is_hole(S, s, it)) continue;
       const uint32_t d = (uint32_t)((uint64_t)it >> tag_bits) & (nb - 1);
       const unsigned long long at = atomicAdd(&s_cur[d], 1ull);
       if(SCATTER) out[at] = it;
@@ -424,7 +434,7 @@ __global__ __launch_bounds__(kPBlock) void p2_scatter_sorted_kernel(PartGeom P, 
   for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) { s_delta[j] = goff[(size_t)bucket * nb + j] + Mq[j]; s_lstart[j] = 0; s_hist[j] = 0; }
   // this bucket's items = concatenation over the pending batches (block-uniform scalars)
   uint64_t n = 0;
-  for(uint32_t s = 0; s < S.n; ++s) n += S.off[s][bucket + 1] - S.off[s][bucket];
+  for(uint32_t s = 0; s < S.n; ++s) n += seg_hi(S, s, bucket) - seg_lo(S, s, bucket);
   const uint64_t per = (n + gridDim.x - 1) / gridDim.x;
   const uint64_t my_lo = (uint64_t)blockIdx.x * per, my_hi = my_lo + per < n ? my_lo + per : n;
   for(uint64_t c0 = my_lo; c0 < my_hi; c0 += kChunk) {
@@ -437,13 +447,13 @@ __global__ __launch_bounds__(kPBlock) void p2_scatter_sorted_kernel(PartGeom P, 
     for(int r = 0; r < PER_THREAD; ++r) { dr[r] = 0xFFFFFFFFu; it[r] = 0; }
     uint64_t slo = 0;
     for(uint32_t s = 0; s < S.n; ++s) {                 // uniform loop: usually one or two batches overlap a chunk
-      const uint64_t o0 = S.off[s][bucket], len = S.off[s][bucket + 1] - o0, shi = slo + len;
+      const uint64_t o0 = seg_lo(S, s, bucket), len = seg_hi(S, s, bucket) - o0, shi = slo + len;
       if(shi > c0 && slo < c1) {
         const ITEM* src = reinterpret_cast<const ITEM*>(S.items[s]) + o0;
 #pragma unroll
         for(int r = 0; r < PER_THREAD; ++r) {
           const uint64_t v = c0 + (uint64_t)r * kPBlock + threadIdx.x;
-          if(v < c1 && v >= slo && v < shi) { it[r] = src[v - slo]; dr[r] = 0; }
+          if(v < c1 && v >= slo && v < shi) { const ITEM x = src[v - slo]; if(!is_hole(S, s, x)) { it[r] = x; dr[r] = 0; } }
         }
       }
       slo = shi;
@@ -463,7 +473,7 @@ __global__ __launch_bounds__(kPBlock) void p2_scatter_sorted_kernel(PartGeom P, 
     for(int r = 0; r < PER_THREAD; ++r)
       if(dr[r] != 0xFFFFFFFFu) s_item[s_lstart[dr[r] >> 16] + (dr[r] & 0xFFFFu)] = it[r];
     lds_barrier();
-    const uint32_t cn = (uint32_t)(c1 - c0);
+    const uint32_t cn = s_lstart[nb - 1] + s_hist[nb - 1];       // items of this chunk that are not holes
     for(uint32_t i = threadIdx.x; i < cn; i += blockDim.x) {
       const ITEM v = s_item[i];
       const uint32_t d = (uint32_t)((uint64_t)v >> tag_bits) & (nb - 1);
@@ -559,7 +569,7 @@ __global__ __launch_bounds__(kPBlock) void tile_insert_kernel(DevTable T, SegLis
   for(uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
     // general path (several pending batches, single-level tables): every lane reads the offsets itself
     uint64_t n_items = 0;
-    for(uint32_t s = 0; s < S.n; ++s) n_items += S.off[s][t + 1] - S.off[s][t];
+    for(uint32_t s = 0; s < S.n; ++s) n_items += seg_hi(S, s, t) - seg_lo(S, s, t);
     if(n_items == 0) continue;                                   // block-uniform
     uint64_t* gt = T.slots + ((tile0 + t) << g.tile_bits);
     const bool load = LOAD && T.dirty[tile0 + t] != 0;              // block-uniform
@@ -570,10 +580,12 @@ __global__ __launch_bounds__(kPBlock) void tile_insert_kernel(DevTable T, SegLis
     }
     lds_barrier();
     for(uint32_t s = 0; s < S.n; ++s) {
-      const uint64_t a = S.off[s][t], b = S.off[s][t + 1];
+      const uint64_t a = seg_lo(S, s, t), b = seg_hi(S, s, t);
       const ITEM* src = reinterpret_cast<const ITEM*>(S.items[s]);
-      for(uint64_t v = a + threadIdx.x; v < b; v += blockDim.x)
-        tile_insert_one<ITEM, RETURNING>(T, s_tile, (uint64_t)src[v], tile0 + t);
+      for(uint64_t v = a + threadIdx.x; v < b; v += blockDim.x) {
+        const ITEM x = src[v];
+        if(!is_hole(S, s, x)) tile_insert_one<ITEM, RETURNING>(T, s_tile, (uint64_t)x, tile0 + t);
+      }
     }
     lds_barrier();
     for(uint32_t i = threadIdx.x * 2; i < tsz; i += blockDim.x * 2)
@@ -583,43 +595,184 @@ __global__ __launch_bounds__(kPBlock) void tile_insert_kernel(DevTable T, SegLis
   }
 }
 
+// One item of P1 bucket `bucket` straight into the table with global atomics (same protocol as
+// table_add; tag and tile are already in the item).
+template <bool RETURNING>
+__device__ inline void item_direct_insert(const DevTable& T, const PartGeom& P, uint32_t bucket, uint64_t it) {
+  const TableGeom& g = T.g;
+  const uint32_t tmask = (uint32_t)g.tile_mask;
+  const uint64_t tag = it & (g.occ_bit - 1);
+  const uint64_t tile = ((uint64_t)bucket << P.b2) | ((it >> g.tag_bits) & ((1ull << P.b2) - 1));
+  const uint64_t tile_base = tile << g.tile_bits;
+  const uint32_t idx0 = (uint32_t)(tag >> g.rem_bits);
+  { uint8_t* d = &T.dirty[tile]; if(!*d) *d = 1; }
+  const uint64_t low = g.occ_bit | tag, neww = g.inc | low;
+  for(uint32_t p = 0; p <= T.max_probe; ++p) {
+    const uint64_t slot = tile_base + probe_slot(idx0, p, tmask);
+    unsigned long long* addr = (unsigned long long*)&T.slots[slot];
+    const unsigned long long old = atomicCAS(addr, 0ull, (unsigned long long)neww);
+    if(old == 0ull) return;
+    if((old & g.low_mask) == low) {
+      if(RETURNING) {
+        const unsigned long long prev = atomicAdd(addr, (unsigned long long)g.inc);
+        if((prev >> (g.tag_bits + 1)) + 1 > g.cnt_max) ovf_add(T, slot, 1);
+      } else {
+        __hip_atomic_fetch_add(addr, (unsigned long long)g.inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return;
+    }
+  }
+  atomicAdd((unsigned long long*)&T.counters[CTR_FULL], 1ull);
+}
+
 // Fallback when a flush holds too few items to be worth streaming the tiles: insert the
-// pending items with global atomics (same protocol as table_add, tag and tile precomputed).
+// pending items with global atomics.  cap == 0: packed batch (off[nb] items, bucket by binary
+// search); cap > 0: granule batch, bucket j occupies [j * cap, off[2j+1]) and holes are skipped.
 template <typename ITEM, bool RETURNING>
 __global__ __launch_bounds__(kBlock) void items_direct_kernel(DevTable T, PartGeom P, const ITEM* __restrict__ items,
-                                                              const uint64_t* __restrict__ off) {
-  const TableGeom& g = T.g;
-  const uint32_t nb = 1u << P.b1, tmask = (uint32_t)g.tile_mask;
-  const uint64_t tagmask = g.occ_bit - 1;
-  const uint64_t n = off[nb];
+                                                              const uint64_t* __restrict__ off, uint64_t cap) {
+  const uint32_t nb = 1u << P.b1;
+  const uint64_t n = cap ? (uint64_t)nb * cap : off[nb];
   for(uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x) {
-    // bucket of item v: largest j with off[j] <= v
-    uint32_t lo = 0, hi = nb;
-    while(hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if(off[mid] <= v) lo = mid; else hi = mid; }
-    const uint64_t it = (uint64_t)items[v];
-    const uint64_t tag = it & tagmask;
-    const uint64_t tile = ((uint64_t)lo << P.b2) | ((it >> g.tag_bits) & ((1ull << P.b2) - 1));
-    const uint64_t tile_base = tile << g.tile_bits;
-    const uint32_t idx0 = (uint32_t)(tag >> g.rem_bits);
-    { uint8_t* d = &T.dirty[tile]; if(!*d) *d = 1; }
-    const uint64_t low = g.occ_bit | tag, neww = g.inc | low;
-    bool done = false;
-    for(uint32_t p = 0; p <= T.max_probe; ++p) {
-      const uint64_t slot = tile_base + probe_slot(idx0, p, tmask);
-      unsigned long long* addr = (unsigned long long*)&T.slots[slot];
-      const unsigned long long old = atomicCAS(addr, 0ull, (unsigned long long)neww);
-      if(old == 0ull) { done = true; break; }
-      if((old & g.low_mask) == low) {
-        if(RETURNING) {
-          const unsigned long long prev = atomicAdd(addr, (unsigned long long)g.inc);
-          if((prev >> (g.tag_bits + 1)) + 1 > g.cnt_max) ovf_add(T, slot, 1);
-        } else {
-          __hip_atomic_fetch_add(addr, (unsigned long long)g.inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t lo = 0;
+    if(cap) {
+      lo = (uint32_t)(v / cap);
+      if(v >= off[2 * (size_t)lo + 1]) continue;
+    } else {                                  // bucket of item v: largest j with off[j] <= v
+      uint32_t hi = nb;
+      while(hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if(off[mid] <= v) lo = mid; else hi = mid; }
+    }
+    const ITEM it = items[v];
+    if(cap && it == (ITEM)~(ITEM)0) continue;
+    item_direct_insert<RETURNING>(T, P, lo, (uint64_t)it);
+  }
+}
+
+// ---- P1 in one pass (32-bit items, contract-buffer input, two-level tables) -------------------
+// The count pass of the exact scheme costs a second encode+hash of the whole batch.  Here bucket j
+// of a batch owns a fixed region of `cap` items and blocks reserve space in it kGran items at a
+// time (one global atomicAdd per reservation: ~1 per 64 items), so placement needs no histogram
+// matrix.  What a block leaves unused in its last reservation of a bucket is filled with the
+// all-ones item (a hole the consumers skip); a real all-ones item, and anything that does not fit
+// the region any more (skewed input), goes straight to the table with global atomics.
+//   gcur[j]  reservations handed out in bucket j (in items, multiples of kGran), zeroed per batch
+//   tot[j]   exact number of items stored for bucket j (the flush sizes P2's output from it)
+template <bool RETURNING, bool BLOOM, int NB>
+__global__ __launch_bounds__(kPBlock) void p1_scatter_granule_kernel(DevTable T, PartGeom P, const uint8_t* __restrict__ base,
+                                                                     int64_t lo, int64_t hi, uint32_t cap,
+                                                                     unsigned int* __restrict__ gcur,
+                                                                     unsigned long long* __restrict__ tot,
+                                                                     uint32_t* __restrict__ out) {
+  constexpr uint32_t kNoRoom = 0xFFFFFFFFu;
+  constexpr int kMaxB = 1024;
+  extern __shared__ __align__(16) unsigned char s_dyn[];
+  uint32_t* s_item = reinterpret_cast<uint32_t*>(s_dyn);                          // [kPTilePos]
+  uint16_t* s_bkt = reinterpret_cast<uint16_t*>(s_dyn + (size_t)kPTilePos * 4);   // [kPTilePos]
+  __shared__ uint64_t s_fwd[8 * 256];
+  __shared__ uint32_t s_codes[kPBlock + 2];
+  __shared__ uint32_t s_inv[kPBlock + 2];
+  __shared__ uint32_t s_cur[kMaxB];      // next free position of this block in bucket b's region (relative)
+  __shared__ uint16_t s_room[kMaxB];     // items left in the current reservation
+  __shared__ uint32_t s_hist[kMaxB];
+  __shared__ uint32_t s_lstart[kMaxB];
+  __shared__ uint32_t s_pos0[kMaxB];     // where this chunk's run of bucket b starts ...
+  __shared__ uint16_t s_split[kMaxB];    // ... how many of its items fit there ...
+  __shared__ uint32_t s_pos1[kMaxB];     // ... and where the rest goes (kNoRoom: region exhausted)
+  __shared__ uint32_t s_cnt[kMaxB];      // items this block stored per bucket
+  __shared__ uint32_t s_wave[16];
+  const uint32_t nb = 1u << P.b1;
+  load_tables_lds(s_fwd, T.fwd_tbl, T.g.nbytes);
+  for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) { s_cur[j] = 0; s_room[j] = 0; s_cnt[j] = 0; }
+  const uint32_t bshift = T.g.lsize_l - P.b1;
+  uint32_t my_direct = 0, my_mers = 0;
+  const int64_t n_tiles = (hi + kPTilePos - 1) / kPTilePos;
+  for(int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    lds_barrier();
+    for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) s_hist[j] = 0;
+    const LaneWords L = stage_tile(base, tile * kPTilePos, lo, hi, s_codes, s_inv);   // barrier inside
+    uint32_t it[kPerLane + 1], dr[kPerLane + 1];
+#pragma unroll
+    for(int e = 0; e <= kPerLane; ++e) dr[e] = 0xFFFFFFFFu;
+    uint64_t prev = 0; uint32_t run = 0; bool long_runs = false;
+    auto flush_run = [&](int site) {
+      if(run == 1) {
+        const uint64_t pos = hash_tables_t<NB>(s_fwd, prev, T.g.nbytes);
+        const uint64_t local = pos & T.g.local_mask;
+        const uint32_t b = (uint32_t)(local >> bshift);
+        it[site] = make_item<uint32_t>(T.g, P, prev, local);
+        dr[site] = (b << 16) | atomicAdd(&s_hist[b], 1u);
+      } else if(run > 1) long_runs = true;
+    };
+    for_each_kmer(T.g, L, [&](int j, uint64_t key) {
+      ++my_mers;
+      if(BLOOM && !bloom_admits(T.bloom, key)) return;
+      if(run && key == prev) { ++run; return; }
+      flush_run(j);
+      prev = key; run = 1;
+    });
+    flush_run(kPerLane);
+    if(long_runs) my_direct += apply_runs<RETURNING, BLOOM>(T, s_fwd, L);
+    lds_barrier();
+    block_excl_scan_2048(s_hist, s_lstart, nb, s_wave);
+    lds_barrier();
+#pragma unroll
+    for(int e = 0; e <= kPerLane; ++e)
+      if(dr[e] != 0xFFFFFFFFu) {
+        const uint32_t at = s_lstart[dr[e] >> 16] + (dr[e] & 0xFFFFu);
+        s_item[at] = it[e]; s_bkt[at] = (uint16_t)(dr[e] >> 16);
+      }
+    // placement of every bucket's run: what fits the current reservation, the rest in a new one
+    for(uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {
+      const uint32_t h = s_hist[b], room = s_room[b], cur = s_cur[b];
+      s_pos0[b] = cur;
+      if(h <= room) { s_split[b] = (uint16_t)h; s_cur[b] = cur + h; s_room[b] = (uint16_t)(room - h); s_cnt[b] += h; }
+      else {
+        const uint32_t need = h - room, take = (need + kGran - 1) / kGran * kGran;
+        const uint32_t g0 = atomicAdd(&gcur[b], take);
+        s_split[b] = (uint16_t)room;
+        if((uint64_t)g0 + take <= cap) { s_pos1[b] = g0; s_cur[b] = g0 + need; s_room[b] = (uint16_t)(take - need); s_cnt[b] += h; }
+        else {                                                                                 // region exhausted
+          s_pos1[b] = kNoRoom; s_cur[b] = cur + room; s_room[b] = 0; s_cnt[b] += room;
+          if(g0 < cap) atomicMax(&gcur[nb + b], cap - g0);       // everything below g0 was handed out successfully
         }
-        done = true; break;
       }
     }
-    if(!done) atomicAdd((unsigned long long*)&T.counters[CTR_FULL], 1ull);
+    lds_barrier();
+    const uint32_t cn = s_lstart[nb - 1] + s_hist[nb - 1];
+    for(uint32_t i = threadIdx.x; i < cn; i += blockDim.x) {
+      const uint32_t b = s_bkt[i], r = i - s_lstart[b], sp = s_split[b];
+      const uint32_t v = s_item[i];
+      uint32_t rel = s_pos0[b] + r;
+      bool direct = false;
+      if(r >= sp) { const uint32_t p1 = s_pos1[b]; if(p1 == kNoRoom) direct = true; else rel = p1 + (r - sp); }
+      if(!direct) {
+        out[(uint64_t)b * cap + rel] = v;
+        if(v == 0xFFFFFFFFu) { direct = true; atomicSub(&s_cnt[b], 1u); }   // its slot now reads as a hole
+      }
+      if(direct) { item_direct_insert<RETURNING>(T, P, b, (uint64_t)v); ++my_direct; }
+    }
+  }
+  lds_barrier();
+  for(uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {
+    const uint32_t room = s_room[b], cur = s_cur[b];
+    for(uint32_t r = 0; r < room; ++r) out[(uint64_t)b * cap + cur + r] = 0xFFFFFFFFu;
+    if(s_cnt[b]) atomicAdd(&tot[b], (unsigned long long)s_cnt[b]);
+  }
+  if(my_direct) atomicAdd((unsigned long long*)&T.counters[CTR_DIRECT], (unsigned long long)my_direct);
+  uint64_t w = my_mers;
+  for(int o = 32; o > 0; o >>= 1) w += __shfl_down(w, o, 64);
+  if((threadIdx.x & 63) == 0 && w) atomicAdd((unsigned long long*)&T.counters[CTR_MERS], (unsigned long long)w);
+}
+
+// After the granule pass: bucket bounds in the pair format of SegList (sh == 1).
+__global__ void granule_finish_kernel(const unsigned int* __restrict__ gcur, uint32_t cap, uint32_t nb, uint64_t* __restrict__ off2) {
+  for(uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nb; j += gridDim.x * blockDim.x) {
+    const uint32_t shortfall = gcur[nb + j];                     // > 0: some reservation did not fit
+    uint64_t used = gcur[j];
+    if(shortfall) used = shortfall <= cap ? cap - shortfall : 0;
+    else if(used > cap) used = cap;
+    off2[2 * (size_t)j] = (uint64_t)j * cap;
+    off2[2 * (size_t)j + 1] = (uint64_t)j * cap + used;
   }
 }
 

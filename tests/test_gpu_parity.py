@@ -452,3 +452,98 @@ def test_table_grows_like_the_reference(gpu, mode, k, size, n):
         vals, found = t.lookup(keys[:10])
         assert vals.tolist() == [exp[x] + 2 ** 45 for x in keys[:10].tolist()]
         t.free(d)
+
+
+# ---- single-pass P1 (p1_scatter_granule_kernel): fixed bucket regions, reservations of 64 items ----------
+def _solve_key_for_item(cols, lsize, k, pos_target, top_bits):
+    """Key whose bits >= lsize are `top_bits` and whose position under the table's matrix is pos_target:
+    Gaussian elimination over GF(2) on the (invertible) block acting on the low lsize key bits."""
+    c = 2 * k
+    col = lambda j: int(cols[c - 1 - j])          # image of key bit j
+    rhs = pos_target
+    for j in range(lsize, c):
+        if (top_bits >> (j - lsize)) & 1:
+            rhs ^= col(j)
+    rows = []                                     # one equation per position bit: sum_j x_j * col(j)[i] = rhs[i]
+    for i in range(lsize):
+        coeff = 0
+        for j in range(lsize):
+            coeff |= ((col(j) >> i) & 1) << j
+        rows.append([coeff, (rhs >> i) & 1])
+    x = 0
+    piv = []
+    r = 0
+    for j in range(lsize):
+        p = next((q for q in range(r, lsize) if (rows[q][0] >> j) & 1), None)
+        assert p is not None, "low block is not invertible"
+        rows[r], rows[p] = rows[p], rows[r]
+        for q in range(lsize):
+            if q != r and (rows[q][0] >> j) & 1:
+                rows[q][0] ^= rows[r][0]; rows[q][1] ^= rows[r][1]
+        piv.append((j, r)); r += 1
+    for j, r_ in piv:
+        x |= rows[r_][1] << j
+    return x | (top_bits << lsize)
+
+
+@pytest.mark.parametrize("k,canonical,n,alphabet,slack", [
+    (16, True, 600000, "ACGT", "0.03"),
+    (16, True, 600000, "ACGTN", "-0.95"),      # regions far too small: most items take the exhausted-region path
+    (15, True, 500000, "AT", "0.03"),          # duplicates and homopolymer runs
+    (19, False, 400000, "ACGT", "0.03"),       # 2k - b1 = 32: every 32-bit value is a real item, the all-ones one is planted
+])
+def test_single_pass_p1_matches_oracle(gpu, monkeypatch, k, canonical, n, alphabet, slack):
+    monkeypatch.setenv("JFGPU_P1_SINGLE", "1")
+    monkeypatch.setenv("JFGPU_P1_SLACK", slack)
+    rng = random.Random(k * 11 + n)
+    seq = rnd_seq(rng, n, alphabet)
+    with gpu.Table(k, 1 << 25, canonical=canonical) as t:      # 4096 tiles: b1 = b2 = 6, 32-bit items for k <= 19
+        t.set_mode(2)
+        t.set_growth(False)
+        if k == 19:
+            lsize = t.info.lsize
+            assert lsize == 25 and not t.info.matrix_identity
+            rest_bits = lsize - 6
+            key = _solve_key_for_item(t.matrix(), lsize, k, (5 << rest_bits) | ((1 << rest_bits) - 1), (1 << (2 * k - lsize)) - 1)
+            planted = O.to_str(np.array([key], dtype=np.uint64), k).encode()
+            seq = seq[:1000] + b"N" + planted + b"N" + seq[1000:] + b"N" + planted
+        exp = oracle_map(seq, k, canonical)
+        d = t.malloc(len(seq) + 64)
+        t.h2d(d + 5, np.frombuffer(seq, dtype=np.uint8))
+        half = len(seq) // 2
+        t.count_ascii_dev(d + 5, half)
+        t.count_ascii_dev(d + 5 + half - (k - 1), len(seq) - half + (k - 1))
+        t.sync()
+        assert table_map(gpu, t) == exp
+        st = t.stats()
+        assert (st.distinct, st.total, st.mers_fed) == (len(exp), sum(exp.values()), sum(exp.values()))
+        if k == 19:
+            vals, found = t.lookup(np.array([key], dtype=np.uint64))
+            assert found.all() and vals.tolist() == [exp[key]] and exp[key] >= 2
+        # second round over a non-empty table
+        t.count_ascii_dev(d + 5, len(seq))
+        t.sync()
+        assert table_map(gpu, t, check_order=False) == {a: 2 * c for a, c in exp.items()}
+        t.free(d)
+
+
+def test_single_pass_p1_large_equals_two_pass(gpu, monkeypatch):
+    """300 Mbp, k = 16 (32-bit items), 2^29 slots: the single-pass and the exact two-pass partition fill
+    identical tables (stats + histogram), and the k-mer total is the window count."""
+    k, L, n_reads = 16, 150, 2_000_000
+    res = []
+    for single in ("0", "1"):
+        monkeypatch.setenv("JFGPU_P1_SINGLE", single)
+        with gpu.Table(k, 1 << 29) as t:
+            t.set_mode(2)
+            nbytes = n_reads * (L + 1)
+            d = t.malloc(nbytes + 16)
+            t.gen_reads_dev(d, 0, n_reads, L, 11)
+            t.count_ascii_dev(d, nbytes)
+            t.sync()
+            s = t.stats()
+            assert s.total == n_reads * (L - k + 1) == s.mers_fed
+            base, inc, h = t.histo(1, 100, 1)
+            res.append((s.distinct, s.unique, s.max_count, h.tolist()))
+            t.free(d)
+    assert res[0] == res[1]
