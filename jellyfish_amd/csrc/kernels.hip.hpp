@@ -201,6 +201,47 @@ __device__ inline LaneWords stage_tile(const uint8_t* __restrict__ base, int64_t
   return L;
 }
 
+// The same in two halves, so a kernel can issue the loads of its NEXT tile before it works on the
+// current one: tile_fetch only loads (4 + 4 registers), tile_stage packs and publishes to LDS.
+struct TileRaw { uint32_t w[4]; uint32_t h[4]; };
+__device__ inline void raw16(const uint8_t* __restrict__ base, int64_t off, int64_t lo, int64_t hi, uint32_t w[4]) {
+  w[0] = w[1] = w[2] = w[3] = 0;
+  if(off + 16 <= lo || off >= hi || off < 0) return;
+  if(off + 16 <= hi) load16(base + off, w);
+  else for(int i = 0; i < 16 && off + i < hi; ++i) w[i >> 2] |= (uint32_t)base[off + i] << (8 * (i & 3));
+}
+__device__ inline void edges16(const uint32_t w[4], int64_t off, int64_t lo, int64_t hi, uint32_t& codes, uint32_t& inval) {
+  if(off + 16 <= lo || off >= hi || off < 0) { codes = 0; inval = 0xFFFFu; return; }
+  pack16(w, codes, inval);
+  if(off < lo) inval |= (0xFFFFu << (16 - (int)(lo - off))) & 0xFFFFu;
+  if(off + 16 > hi) inval |= (1u << (int)(off + 16 - hi)) - 1u;
+}
+__device__ inline TileRaw tile_fetch(const uint8_t* __restrict__ base, int64_t tile_start, int64_t lo, int64_t hi) {
+  TileRaw R;
+  raw16(base, tile_start + 16 * (int64_t)threadIdx.x, lo, hi, R.w);
+  R.h[0] = R.h[1] = R.h[2] = R.h[3] = 0;
+  if(threadIdx.x < 2) raw16(base, tile_start - 32 + 16 * (int64_t)threadIdx.x, lo, hi, R.h);
+  return R;
+}
+__device__ inline LaneWords tile_stage(const TileRaw& R, int64_t tile_start, int64_t lo, int64_t hi, uint32_t* s_codes, uint32_t* s_inv) {
+  const int tid = threadIdx.x;
+  uint32_t c, v;
+  edges16(R.w, tile_start + 16 * (int64_t)tid, lo, hi, c, v);
+  s_codes[tid + 2] = c; s_inv[tid + 2] = v;
+  if(tid < 2) {
+    uint32_t hc, hv;
+    edges16(R.h, tile_start - 32 + 16 * (int64_t)tid, lo, hi, hc, hv);
+    s_codes[tid] = hc; s_inv[tid] = hv;
+  }
+  lds_barrier();
+  LaneWords L;
+  L.cur = c;
+  L.p1 = s_codes[tid + 1];
+  L.p2 = s_codes[tid];
+  L.inv48 = ((uint64_t)s_inv[tid] << 32) | ((uint64_t)s_inv[tid + 1] << 16) | v;
+  return L;
+}
+
 __device__ inline void load_tables_lds(uint64_t* dst, const uint64_t* src, uint32_t nbytes) {
   for(uint32_t i = threadIdx.x; i < nbytes * 256; i += blockDim.x) dst[i] = src[i];
 }

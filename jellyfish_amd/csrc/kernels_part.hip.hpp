@@ -47,12 +47,11 @@ struct PartGeom {
 struct SegList {
   const void* items[kMaxSeg];
   const uint64_t* off[kMaxSeg];
-  uint8_t sh[kMaxSeg];
+  uint32_t sh[kMaxSeg];
   uint32_t n;
 };
 __device__ inline uint64_t seg_lo(const SegList& S, uint32_t s, uint32_t j) { return S.off[s][(size_t)j << S.sh[s]]; }
 __device__ inline uint64_t seg_hi(const SegList& S, uint32_t s, uint32_t j) { return S.off[s][((size_t)j << S.sh[s]) + 1]; }
-template <typename ITEM> __device__ inline bool is_hole(const SegList& S, uint32_t s, ITEM it) { return S.sh[s] && it == (ITEM)~(ITEM)0; }
 
 constexpr uint32_t kGran = 64;                // items per reservation of the single-pass P1
 
@@ -242,9 +241,10 @@ __global__ __launch_bounds__(kPBlock) void p2_kernel(PartGeom P, uint32_t tag_bi
     const uint64_t a = my_lo > slo ? my_lo : slo, b = my_hi < shi ? my_hi : shi;
     if(a >= b) continue;
     const ITEM* src = reinterpret_cast<const ITEM*>(S.items[s]) + seg_lo(S, s, bucket) - slo;
+    const bool holes = S.sh[s] != 0;                      // block-uniform
     for(uint64_t v = a + threadIdx.x; v < b; v += blockDim.x) {
       const ITEM it = src[v];
-      if(is_hole(S, s, it)) continue;
+      if(holes && it == (ITEM)~(ITEM)0) continue;
       const uint32_t d = (uint32_t)((uint64_t)it >> tag_bits) & (nb - 1);
       const unsigned long long at = atomicAdd(&s_cur[d], 1ull);
       if(SCATTER) out[at] = it;
@@ -446,14 +446,16 @@ __global__ __launch_bounds__(kPBlock) void p2_scatter_sorted_kernel(PartGeom P, 
 #pragma unroll
     for(int r = 0; r < PER_THREAD; ++r) { dr[r] = 0xFFFFFFFFu; it[r] = 0; }
     uint64_t slo = 0;
+    uint32_t hm = 0;                                    // items that came from a batch with holes
     for(uint32_t s = 0; s < S.n; ++s) {                 // uniform loop: usually one or two batches overlap a chunk
       const uint64_t o0 = seg_lo(S, s, bucket), len = seg_hi(S, s, bucket) - o0, shi = slo + len;
       if(shi > c0 && slo < c1) {
         const ITEM* src = reinterpret_cast<const ITEM*>(S.items[s]) + o0;
+        const bool holes = S.sh[s] != 0;
 #pragma unroll
         for(int r = 0; r < PER_THREAD; ++r) {
           const uint64_t v = c0 + (uint64_t)r * kPBlock + threadIdx.x;
-          if(v < c1 && v >= slo && v < shi) { const ITEM x = src[v - slo]; if(!is_hole(S, s, x)) { it[r] = x; dr[r] = 0; } }
+          if(v < c1 && v >= slo && v < shi) { it[r] = src[v - slo]; dr[r] = 0; if(holes) hm |= 1u << r; }   // no use of the loaded value here: 16 loads in flight
         }
       }
       slo = shi;
@@ -462,6 +464,7 @@ __global__ __launch_bounds__(kPBlock) void p2_scatter_sorted_kernel(PartGeom P, 
 #pragma unroll
     for(int r = 0; r < PER_THREAD; ++r)
       if(dr[r] != 0xFFFFFFFFu) {
+        if(((hm >> r) & 1) && it[r] == (ITEM)~(ITEM)0) { dr[r] = 0xFFFFFFFFu; continue; }   // a hole
         const uint32_t d = (uint32_t)((uint64_t)it[r] >> tag_bits) & (nb - 1);
         dr[r] = (d << 16) | atomicAdd(&s_hist[d], 1u);
       }
@@ -582,9 +585,10 @@ __global__ __launch_bounds__(kPBlock) void tile_insert_kernel(DevTable T, SegLis
     for(uint32_t s = 0; s < S.n; ++s) {
       const uint64_t a = seg_lo(S, s, t), b = seg_hi(S, s, t);
       const ITEM* src = reinterpret_cast<const ITEM*>(S.items[s]);
+      const bool holes = S.sh[s] != 0;
       for(uint64_t v = a + threadIdx.x; v < b; v += blockDim.x) {
         const ITEM x = src[v];
-        if(!is_hole(S, s, x)) tile_insert_one<ITEM, RETURNING>(T, s_tile, (uint64_t)x, tile0 + t);
+        if(!(holes && x == (ITEM)~(ITEM)0)) tile_insert_one<ITEM, RETURNING>(T, s_tile, (uint64_t)x, tile0 + t);
       }
     }
     lds_barrier();
@@ -686,10 +690,12 @@ __global__ __launch_bounds__(kPBlock) void p1_scatter_granule_kernel(DevTable T,
   const uint32_t bshift = T.g.lsize_l - P.b1;
   uint32_t my_direct = 0, my_mers = 0;
   const int64_t n_tiles = (hi + kPTilePos - 1) / kPTilePos;
+  TileRaw R = tile_fetch(base, (int64_t)blockIdx.x * kPTilePos, lo, hi);
   for(int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     lds_barrier();
     for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) s_hist[j] = 0;
-    const LaneWords L = stage_tile(base, tile * kPTilePos, lo, hi, s_codes, s_inv);   // barrier inside
+    const LaneWords L = tile_stage(R, tile * kPTilePos, lo, hi, s_codes, s_inv);      // barrier inside
+    R = tile_fetch(base, (tile + gridDim.x) * kPTilePos, lo, hi);                      // next tile's bytes travel while this one is worked on
     uint32_t it[kPerLane + 1], dr[kPerLane + 1];
 #pragma unroll
     for(int e = 0; e <= kPerLane; ++e) dr[e] = 0xFFFFFFFFu;
@@ -715,25 +721,30 @@ __global__ __launch_bounds__(kPBlock) void p1_scatter_granule_kernel(DevTable T,
     lds_barrier();
     block_excl_scan_2048(s_hist, s_lstart, nb, s_wave);
     lds_barrier();
+    // Placement of every bucket's run (nb <= blockDim: one bucket per thread): what fits the current
+    // reservation stays there, the rest goes to a new one.  The reservation (a global atomic) is issued
+    // first, its round trip overlaps the LDS scatter, its answer is used afterwards.
+    const uint32_t pb = threadIdx.x;
+    uint32_t ph = 0, proom = 0, pcur = 0, need = 0, take = 0, g0 = 0;
+    if(pb < nb) {
+      ph = s_hist[pb]; proom = s_room[pb]; pcur = s_cur[pb];
+      if(ph > proom) { need = ph - proom; take = (need + kGran - 1) / kGran * kGran; g0 = atomicAdd(&gcur[pb], take); }
+    }
 #pragma unroll
     for(int e = 0; e <= kPerLane; ++e)
       if(dr[e] != 0xFFFFFFFFu) {
         const uint32_t at = s_lstart[dr[e] >> 16] + (dr[e] & 0xFFFFu);
         s_item[at] = it[e]; s_bkt[at] = (uint16_t)(dr[e] >> 16);
       }
-    // placement of every bucket's run: what fits the current reservation, the rest in a new one
-    for(uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {
-      const uint32_t h = s_hist[b], room = s_room[b], cur = s_cur[b];
-      s_pos0[b] = cur;
-      if(h <= room) { s_split[b] = (uint16_t)h; s_cur[b] = cur + h; s_room[b] = (uint16_t)(room - h); s_cnt[b] += h; }
+    if(pb < nb) {
+      s_pos0[pb] = pcur;
+      if(!take) { s_split[pb] = (uint16_t)ph; s_cur[pb] = pcur + ph; s_room[pb] = (uint16_t)(proom - ph); s_cnt[pb] += ph; }
       else {
-        const uint32_t need = h - room, take = (need + kGran - 1) / kGran * kGran;
-        const uint32_t g0 = atomicAdd(&gcur[b], take);
-        s_split[b] = (uint16_t)room;
-        if((uint64_t)g0 + take <= cap) { s_pos1[b] = g0; s_cur[b] = g0 + need; s_room[b] = (uint16_t)(take - need); s_cnt[b] += h; }
+        s_split[pb] = (uint16_t)proom;
+        if((uint64_t)g0 + take <= cap) { s_pos1[pb] = g0; s_cur[pb] = g0 + need; s_room[pb] = (uint16_t)(take - need); s_cnt[pb] += ph; }
         else {                                                                                 // region exhausted
-          s_pos1[b] = kNoRoom; s_cur[b] = cur + room; s_room[b] = 0; s_cnt[b] += room;
-          if(g0 < cap) atomicMax(&gcur[nb + b], cap - g0);       // everything below g0 was handed out successfully
+          s_pos1[pb] = kNoRoom; s_cur[pb] = pcur + proom; s_room[pb] = 0; s_cnt[pb] += proom;
+          if(g0 < cap) atomicMax(&gcur[nb + pb], cap - g0);       // everything below g0 was handed out successfully
         }
       }
     }
