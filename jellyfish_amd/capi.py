@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libjfgpu.so")
+LIB_PATH = os.environ.get("JFGPU_LIB") or os.path.join(_HERE, "lib", "libjfgpu.so")   # JFGPU_LIB: experimental builds (tools/)
 
 OK, E_INVALID, E_NO_DEVICE, E_ALLOC, E_FULL, E_HIP, E_UNSUPPORTED, E_FORMAT = range(8)
 PARSE_FASTA, PARSE_FASTQ, PARSE_CONTINUE = 1, 2, 4

@@ -815,6 +815,11 @@ int jfgpu_sync(jfgpu_table* t) {
   int rc = use(t); if(rc) return rc;
   rc = part_flush(t); if(rc) return rc;
   HIP_TRY(hipStreamSynchronize(t->stream));
+#ifdef JFGPU_TILE_PROF
+  { uint64_t c[CTR_COUNT]; if(read_counters(t, c) == JFGPU_OK)
+      fprintf(stderr, "[tile prof] wait+prefetch %llu  fill %llu  insert %llu  store %llu (shader clocks, summed over blocks)\n",
+              (unsigned long long)c[CTR_PROF0], (unsigned long long)c[CTR_PROF0 + 1], (unsigned long long)c[CTR_PROF0 + 2], (unsigned long long)c[CTR_PROF0 + 3]); }
+#endif
   return check_deferred(t);
 }
 

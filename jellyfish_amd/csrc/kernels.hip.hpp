@@ -33,7 +33,8 @@ constexpr int kBlock = 256;
 constexpr int kPerThread = kPerLane;           // positions per lane per tile (16)
 constexpr int kTilePos = kBlock * kPerThread;  // 4096 sequence positions per block iteration
 
-enum Counter : int { CTR_FULL = 0, CTR_MERS = 1, CTR_OVF_FULL = 2, CTR_OVF_USED = 3, CTR_MISROUTED = 4, CTR_DIRECT = 5, CTR_COUNT = 8 };
+enum Counter : int { CTR_FULL = 0, CTR_MERS = 1, CTR_OVF_FULL = 2, CTR_OVF_USED = 3, CTR_MISROUTED = 4, CTR_DIRECT = 5,
+                     CTR_PROF0 = 8 /* .. 11: phase clocks of a -DJFGPU_TILE_PROF build */, CTR_COUNT = 12 };
 
 // Bloom counter view (kernels_bloom.hip.hpp); data == nullptr: no filter attached.
 struct DevBloom {

@@ -536,6 +536,12 @@ __global__ __launch_bounds__(kPBlock) void tile_insert_kernel(DevTable T, SegLis
     if(t + G < n_tiles) { a1 = off[t + G]; b1 = off[t + G + 1]; d1 = LOAD ? T.dirty[tile0 + t + G] : 0; }
 #pragma unroll
     for(int r = 0; r < NP; ++r) { const uint64_t v = a0 + (uint64_t)r * kPBlock + threadIdx.x; cur[r] = v < b0 ? src[v] : (ITEM)0; }
+#ifdef JFGPU_TILE_PROF
+    long long pc0 = 0, pc1 = 0, pc2 = 0, pc3 = 0, pt = clock64();
+#define TP(acc) do { const long long n_ = clock64(); acc += n_ - pt; pt = n_; } while(0)
+#else
+#define TP(acc) do {} while(0)
+#endif
     for(; t < n_tiles; t += G) {
       // issue the loads of the following tiles first
       uint64_t a2 = 0, b2 = 0; uint8_t d2 = 0;
@@ -543,6 +549,7 @@ __global__ __launch_bounds__(kPBlock) void tile_insert_kernel(DevTable T, SegLis
       ITEM nxt[NP];
 #pragma unroll
       for(int r = 0; r < NP; ++r) { const uint64_t v = a1 + (uint64_t)r * kPBlock + threadIdx.x; nxt[r] = v < b1 ? src[v] : (ITEM)0; }
+      TP(pc0);
       if(b0 > a0) {                                          // block-uniform
         uint64_t* gt = T.slots + ((tile0 + t) << g.tile_bits);
         const bool load = LOAD && d0 != 0;
@@ -552,21 +559,33 @@ __global__ __launch_bounds__(kPBlock) void tile_insert_kernel(DevTable T, SegLis
           *reinterpret_cast<ulonglong2*>(s_tile + i) = v;
         }
         lds_barrier();
+        TP(pc1);
 #pragma unroll
         for(int r = 0; r < NP; ++r)
           if(a0 + (uint64_t)r * kPBlock + threadIdx.x < b0) tile_insert_one<ITEM, RETURNING>(T, s_tile, (uint64_t)cur[r], tile0 + t);
         for(uint64_t v = a0 + (uint64_t)NP * kPBlock + threadIdx.x; v < b0; v += kPBlock)   // rare: an over-full tile
           tile_insert_one<ITEM, RETURNING>(T, s_tile, (uint64_t)src[v], tile0 + t);
         lds_barrier();
+        TP(pc2);
         for(uint32_t i = threadIdx.x * 2; i < tsz; i += blockDim.x * 2)
           *reinterpret_cast<ulonglong2*>(gt + i) = *reinterpret_cast<const ulonglong2*>(s_tile + i);
         if(threadIdx.x == 0) T.dirty[tile0 + t] = 1;
         lds_barrier();
+        TP(pc3);
       }
       a0 = a1; b0 = b1; d0 = d1; a1 = a2; b1 = b2; d1 = d2;
 #pragma unroll
       for(int r = 0; r < NP; ++r) cur[r] = nxt[r];
     }
+#ifdef JFGPU_TILE_PROF
+    if(threadIdx.x == 0) {      // wave 0's view: prefetch issue + waits / fill / insert / store, in shader clocks
+      atomicAdd((unsigned long long*)&T.counters[CTR_PROF0 + 0], (unsigned long long)pc0);
+      atomicAdd((unsigned long long*)&T.counters[CTR_PROF0 + 1], (unsigned long long)pc1);
+      atomicAdd((unsigned long long*)&T.counters[CTR_PROF0 + 2], (unsigned long long)pc2);
+      atomicAdd((unsigned long long*)&T.counters[CTR_PROF0 + 3], (unsigned long long)pc3);
+    }
+#endif
+#undef TP
     return;
   }
   for(uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {

@@ -1,0 +1,171 @@
+// Micro-benchmark of the tile-insert inner phase on gfx950: a 64 KiB LDS tile (8192 x 64-bit slots), ~4133
+// random inserts per tile by 1024 threads, no global traffic.  Prices the claim primitive.
+// hipcc --offload-arch=gfx950 -O3 -o lds_tile_probe lds_tile_probe.hip
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+constexpr int kThreads = 1024, kTiles = 64, kSlots = 8192;
+__device__ inline uint32_t mix(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void probe(uint32_t* out, int items_per_lane_x16) {
+  extern __shared__ __align__(16) unsigned long long s_tile[];
+  uint32_t acc = 0;
+  for(int t = 0; t < kTiles; ++t) {
+    for(uint32_t i = threadIdx.x * 2; i < kSlots; i += kThreads * 2) { s_tile[i] = 0; s_tile[i + 1] = 0; }
+    __syncthreads();
+    uint32_t x = mix(threadIdx.x * 2654435761u + blockIdx.x * 40503u + t * 977u + 1u);
+    // 4133 items per tile on average: every lane does 4, lanes < 37 a fifth
+    const int n = 4 + (threadIdx.x < 37 ? 1 : 0);
+    if(MODE == 6) {                                // all of the lane's items probe concurrently, one round = one CAS latency
+      constexpr int NP = 5;
+      uint32_t idx[NP], pp[NP]; unsigned long long tg[NP], old[NP];
+      uint32_t pend = 0;
+#pragma unroll
+      for(int r = 0; r < NP; ++r) {
+        x = x * 1664525u + 1013904223u;
+        idx[r] = (x >> 8) & (kSlots - 1); tg[r] = ((unsigned long long)(x | 1u) << 1) | 1ull; pp[r] = 0;
+        if(r < n) pend |= 1u << r;
+      }
+      while(pend) {
+        uint32_t sl[NP];
+#pragma unroll
+        for(int r = 0; r < NP; ++r) {                // unconditional: items already placed hit a spare slot behind the tile
+          sl[r] = ((pend >> r) & 1) ? ((idx[r] + pp[r] * (pp[r] + 1) / 2) & (kSlots - 1)) : (uint32_t)(kSlots + (threadIdx.x & 63));
+          old[r] = atomicCAS(&s_tile[sl[r]], 0ull, tg[r]);
+        }
+#pragma unroll
+        for(int r = 0; r < NP; ++r) {
+          const bool pe = (pend >> r) & 1;
+          const bool placed = old[r] == 0ull, same = old[r] == tg[r];
+          if(pe && same && !placed) atomicAdd(&s_tile[sl[r]], 1ull << 40);          // rare branch
+          pp[r] += (pe && !placed && !same) ? 1u : 0u;
+          if(pe && (placed || same || pp[r] >= 64)) pend &= ~(1u << r);
+        }
+      }
+    } else if(MODE == 10) {                        // round 1 with all items in flight, losers compacted per wave in an LDS queue
+      constexpr int NP = 5, QCAP = 96;
+      unsigned long long* wq = s_tile + kSlots + 64 + (threadIdx.x >> 6) * QCAP;
+      uint32_t xs[NP]; unsigned long long old[NP];
+#pragma unroll
+      for(int r = 0; r < NP; ++r) { x = x * 1664525u + 1013904223u; xs[r] = x; }
+#pragma unroll
+      for(int r = 0; r < NP; ++r)
+        if(r < n) old[r] = atomicCAS(&s_tile[(xs[r] >> 8) & (kSlots - 1)], 0ull, ((unsigned long long)(xs[r] | 1u) << 1) | 1ull);
+      uint32_t qn = 0;                             // wave-uniform
+#pragma unroll
+      for(int r = 0; r < NP; ++r) {
+        const unsigned long long tag = ((unsigned long long)(xs[r] | 1u) << 1) | 1ull;
+        bool loser = false;
+        if(r < n && old[r] != 0ull) { if(old[r] == tag) atomicAdd(&s_tile[(xs[r] >> 8) & (kSlots - 1)], 1ull << 40); else loser = true; }
+        const unsigned long long m = __ballot(loser);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+        if(loser && qn + rank < QCAP) wq[qn + rank] = ((unsigned long long)1 << 32) | xs[r];
+        qn += __popcll(m); if(qn > QCAP) qn = QCAP;        // (probe only: overflow dropped)
+      }
+      while(qn) {
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t nq = qn; qn = 0;
+        for(uint32_t i0 = 0; i0 < nq; i0 += 64) {
+          const uint32_t i = i0 + (threadIdx.x & 63);
+          bool loser = false; unsigned long long e = 0;
+          if(i < nq) {
+            e = wq[i];
+            const uint32_t cx = (uint32_t)e, p = (uint32_t)(e >> 32);
+            const unsigned long long tag = ((unsigned long long)(cx | 1u) << 1) | 1ull;
+            const uint32_t slot = (((cx >> 8) & (kSlots - 1)) + p * (p + 1) / 2) & (kSlots - 1);
+            const unsigned long long o = atomicCAS(&s_tile[slot], 0ull, tag);
+            if(o != 0ull) { if(o == tag) atomicAdd(&s_tile[slot], 1ull << 40); else if(p < 63) { loser = true; e += 1ull << 32; } }
+          }
+          const unsigned long long m = __ballot(loser);
+          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+          if(loser) wq[qn + rank] = e;
+          qn += __popcll(m);
+        }
+      }
+    } else if(MODE == 7) {                         // one probe loop for all of the lane's items (a placed lane moves to its next item)
+      uint32_t xs[5];
+#pragma unroll
+      for(int r = 0; r < 5; ++r) { x = x * 1664525u + 1013904223u; xs[r] = x; }
+      uint32_t r = 0, p = 0, cx = xs[0];
+      while(true) {
+        const uint32_t idx0 = (cx >> 8) & (kSlots - 1);
+        const unsigned long long tag = ((unsigned long long)(cx | 1u) << 1) | 1ull;
+        const uint32_t slot = (idx0 + p * (p + 1) / 2) & (kSlots - 1);
+        const unsigned long long old = atomicCAS(&s_tile[slot], 0ull, tag);
+        bool done = old == 0ull;
+        if(!done && old == tag) { atomicAdd(&s_tile[slot], 1ull << 40); done = true; }
+        if(!done && ++p >= 64) done = true;
+        if(done) { if(++r >= (uint32_t)n) break; p = 0; cx = r == 1 ? xs[1] : r == 2 ? xs[2] : r == 3 ? xs[3] : xs[4]; }
+      }
+    } else
+    for(int r = 0; r < n; ++r) {
+      x = x * 1664525u + 1013904223u;
+      const uint32_t idx0 = (x >> 8) & (kSlots - 1);
+      const unsigned long long tag = ((unsigned long long)(x | 1u) << 1) | 1ull;   // never 0
+      if(MODE == 0) {                              // 64-bit CAS claim with triangular probing (what the kernel does)
+        for(uint32_t p = 0; p < 64; ++p) {
+          const uint32_t slot = (idx0 + p * (p + 1) / 2) & (kSlots - 1);
+          const unsigned long long old = atomicCAS(&s_tile[slot], 0ull, tag);
+          if(old == 0ull) break;
+          if(old == tag) { atomicAdd(&s_tile[slot], 1ull << 40); break; }
+        }
+      } else if(MODE == 1) {                       // 32-bit CAS on the low word
+        uint32_t* w = reinterpret_cast<uint32_t*>(s_tile);
+        for(uint32_t p = 0; p < 64; ++p) {
+          const uint32_t slot = (idx0 + p * (p + 1) / 2) & (kSlots - 1);
+          const uint32_t old = atomicCAS(&w[2 * slot], 0u, (uint32_t)tag);
+          if(old == 0u) break;
+          if(old == (uint32_t)tag) { atomicAdd(&w[2 * slot + 1], 1u); break; }
+        }
+      } else if(MODE == 2) {                       // one 64-bit CAS, no probing (cost of the primitive alone)
+        acc += (uint32_t)atomicCAS(&s_tile[idx0], 0ull, tag);
+      } else if(MODE == 3) {                       // one non-returning 64-bit add
+        atomicAdd(&s_tile[idx0], tag);
+      } else if(MODE == 4) {                       // plain 64-bit store
+        s_tile[idx0] = tag;
+      } else if(MODE == 8) {                       // the probing loop, but every first probe finds its slot empty (no collisions)
+        const uint32_t slot0 = (threadIdx.x + r * kThreads) & (kSlots - 1);
+        for(uint32_t p = 0; p < 64; ++p) {
+          const uint32_t slot = (slot0 + p * (p + 1) / 2) & (kSlots - 1);
+          const unsigned long long old = atomicCAS(&s_tile[slot], 0ull, tag);
+          if(old == 0ull) break;
+          if(old == tag) { atomicAdd(&s_tile[slot], 1ull << 40); break; }
+        }
+      } else if(MODE == 9) {                       // one CAS at a conflict-free, bank-friendly slot
+        acc += (uint32_t)atomicCAS(&s_tile[(threadIdx.x + r * kThreads) & (kSlots - 1)], 0ull, tag);
+      } else if(MODE == 5) {                       // read, then CAS only if empty or equal (test-and-test-and-set)
+        for(uint32_t p = 0; p < 64; ++p) {
+          const uint32_t slot = (idx0 + p * (p + 1) / 2) & (kSlots - 1);
+          unsigned long long old = s_tile[slot];
+          if(old == 0ull) old = atomicCAS(&s_tile[slot], 0ull, tag);
+          if(old == 0ull) break;
+          if(old == tag) { atomicAdd(&s_tile[slot], 1ull << 40); break; }
+        }
+      }
+    }
+    __syncthreads();
+    acc += (uint32_t)s_tile[threadIdx.x];
+  }
+  if(acc == 0xdeadbeef) out[0] = acc;
+}
+
+template <int MODE> double run(uint32_t* d_out, int blocks) {
+  hipFuncSetAttribute((const void*)probe<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (kSlots + 64 + 16 * 96) * 8);
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  probe<MODE><<<blocks, kThreads, (kSlots + 64 + 16 * 96) * 8>>>(d_out, 0); hipDeviceSynchronize();
+  hipEventRecord(a); probe<MODE><<<blocks, kThreads, (kSlots + 64 + 16 * 96) * 8>>>(d_out, 0); hipEventRecord(b); hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b); return ms;
+}
+int main() {
+  uint32_t* d_out; hipMalloc(&d_out, 64);
+  hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
+  const int cus = p.multiProcessorCount, blocks = cus * 2;    // 2 blocks per CU resident (64 KiB each), one round
+  const double clk = p.clockRate * 1e3;
+  const char* names[] = {"64-bit CAS claim + probing", "32-bit CAS claim + probing", "one 64-bit CAS", "one 64-bit add (no return)", "plain 64-bit store", "read first, CAS if empty", "concurrent rounds (5 CAS in flight)", "persistent lane loop", "probing loop, no collisions, linear slots", "one CAS, linear slots", "round 1 in flight + per-wave loser queue"};
+  double ms[11] = {run<0>(d_out, blocks), run<1>(d_out, blocks), run<2>(d_out, blocks), run<3>(d_out, blocks), run<4>(d_out, blocks), run<5>(d_out, blocks), run<6>(d_out, blocks), run<7>(d_out, blocks), run<8>(d_out, blocks), run<9>(d_out, blocks), run<10>(d_out, blocks)};
+  for(int m = 0; m < 11; ++m)
+    printf("%-30s %8.3f ms  -> %8.0f clk per tile per block (2 blocks/CU), %6.3f inserts/clk/CU\n", names[m], ms[m], ms[m] * 1e-3 * clk / kTiles,
+           2.0 * kTiles * 4133.0 / (ms[m] * 1e-3 * clk));
+  return 0;
+}
