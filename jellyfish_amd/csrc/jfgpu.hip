@@ -345,7 +345,8 @@ int part_flush(jfgpu_table* t);
 // two-pass scheme.  Every block may strand part of one reservation per bucket, so small batches would be
 // mostly holes: auto mode wants the mean bucket load to be at least 4x that.
 uint32_t granule_cap(const jfgpu_table* t, bool from_keys, uint64_t max_items) {
-  if(!t->item32 || from_keys || t->pg.b2 == 0 || t->pg.b1 > 10 || t->p1_single == 0 || !t->g1) return 0;
+  (void)from_keys;
+  if(!t->item32 || t->pg.b2 == 0 || t->pg.b1 > 10 || t->p1_single == 0 || !t->g1) return 0;
   const uint64_t nb = 1ull << t->pg.b1, strand = (uint64_t)t->g1 * kGran;
   const uint64_t mean = (max_items + nb - 1) / nb;
   if(t->p1_single < 0 && mean < 4 * strand) return 0;
@@ -382,17 +383,28 @@ int part_ingest(jfgpu_table* t, const uint8_t* base, int64_t lo, int64_t hi, boo
     if(!gcur) return fail(JFGPU_E_ALLOC, "partition workspace exhausted");
     b.gran_cap = gcap; b.tot = (unsigned long long*)(gcur + 2 * nb);
     HIP_TRY(hipMemsetAsync(gcur, 0, nb * 16, t->stream));
-    ProfScope ps(t, 4, (uint64_t)(hi - lo));
+    ProfScope ps(t, 4, (uint64_t)(from_keys ? hi : hi - lo));
     const size_t lds = (size_t)kPTilePos * 6;
-    const bool bl = t->dt.bloom.data != nullptr;
+    const bool bl = t->dt.bloom.data != nullptr && !from_keys;
+#define PK(RT, N) hipLaunchKernelGGL((p1_keys_granule_kernel<RT, N>), dim3(t->g1), dim3(kPBlock), lds, t->stream, t->dt, t->pg, (const uint64_t*)base, hi, gcap, gcur, b.tot, (uint32_t*)b.items)
+    if(from_keys) {
+      if(t->returning) PK(true, 0);
+      else if(t->g.nbytes == 6) PK(false, 6);
+      else if(t->g.nbytes == 7) PK(false, 7);
+      else if(t->g.nbytes == 8) PK(false, 8);
+      else PK(false, 0);
+    } else
 #define PG(RT, BL, N) hipLaunchKernelGGL((p1_scatter_granule_kernel<RT, BL, N>), dim3(t->g1), dim3(kPBlock), lds, t->stream, t->dt, t->pg, base, lo, hi, gcap, gcur, b.tot, (uint32_t*)b.items)
-    if(bl) { if(t->returning) PG(true, true, 0); else PG(false, true, 0); }
-    else if(t->returning) PG(true, false, 0);
-    else if(t->g.nbytes == 6) PG(false, false, 6);
-    else if(t->g.nbytes == 7) PG(false, false, 7);
-    else if(t->g.nbytes == 8) PG(false, false, 8);
-    else PG(false, false, 0);
+    {
+      if(bl) { if(t->returning) PG(true, true, 0); else PG(false, true, 0); }
+      else if(t->returning) PG(true, false, 0);
+      else if(t->g.nbytes == 6) PG(false, false, 6);
+      else if(t->g.nbytes == 7) PG(false, false, 7);
+      else if(t->g.nbytes == 8) PG(false, false, 8);
+      else PG(false, false, 0);
+    }
 #undef PG
+#undef PK
     hipLaunchKernelGGL(granule_finish_kernel, dim3((nb + 255) / 256), dim3(256), 0, t->stream, gcur, gcap, nb, b.off);
   } else {
     ProfScope ps(t, 4, (uint64_t)(from_keys ? hi : hi - lo));
@@ -746,6 +758,11 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
                  HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_granule_kernel<false, false, N>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6))
     PATTR(0); PATTR(6); PATTR(7); PATTR(8);
 #undef PATTR
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_keys_granule_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_keys_granule_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_keys_granule_kernel<false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_keys_granule_kernel<false, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_keys_granule_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_granule_kernel<true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_granule_kernel<false, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_granule_kernel<true, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));

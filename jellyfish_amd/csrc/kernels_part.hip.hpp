@@ -680,39 +680,113 @@ __global__ __launch_bounds__(kBlock) void items_direct_kernel(DevTable T, PartGe
 // the region any more (skewed input), goes straight to the table with global atomics.
 //   gcur[j]  reservations handed out in bucket j (in items, multiples of kGran), zeroed per batch
 //   tot[j]   exact number of items stored for bucket j (the flush sizes P2's output from it)
+constexpr int kGranMaxB = 1024;             // buckets of the single-pass kernels (one per thread)
+
+// Per-block state of the single-pass scatter, in LDS, shared by the contract-buffer and the key-array
+// kernels.  emit(): given this chunk's per-bucket histogram (hist) and every lane's items (it) with
+// bucket << 16 | rank (dr; 0xFFFFFFFF = none), place the chunk in the bucket regions and write it out.
+struct GranuleLds {
+  uint32_t cur[kGranMaxB];      // next free position of this block in bucket b's region (relative)
+  uint16_t room[kGranMaxB];     // items left in the current reservation
+  uint32_t hist[kGranMaxB];
+  uint32_t lstart[kGranMaxB];
+  uint32_t pos0[kGranMaxB];     // where this chunk's run of bucket b starts ...
+  uint16_t split[kGranMaxB];    // ... how many of its items fit there ...
+  uint32_t pos1[kGranMaxB];     // ... and where the rest goes (kNoRoom: region exhausted)
+  uint32_t cnt[kGranMaxB];      // items this block stored per bucket
+  uint32_t wave[16];
+};
+constexpr uint32_t kNoRoom = 0xFFFFFFFFu;
+
+__device__ inline void granule_init(GranuleLds& G, uint32_t nb) {
+  for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) { G.cur[j] = 0; G.room[j] = 0; G.cnt[j] = 0; }
+}
+
+template <bool RETURNING, int N>
+__device__ inline uint32_t granule_emit(GranuleLds& G, const DevTable& T, const PartGeom& P, uint32_t nb, uint32_t cap,
+                                        unsigned int* __restrict__ gcur, uint32_t* __restrict__ out, uint32_t* s_item, uint16_t* s_bkt,
+                                        const uint32_t (&it)[N], const uint32_t (&dr)[N]) {
+  lds_barrier();
+  block_excl_scan_2048(G.hist, G.lstart, nb, G.wave);
+  lds_barrier();
+  // Placement of every bucket's run (nb <= blockDim: one bucket per thread): what fits the current
+  // reservation stays there, the rest goes to a new one.  The reservation (a global atomic) is issued
+  // first, its round trip overlaps the LDS scatter, its answer is used afterwards.
+  const uint32_t pb = threadIdx.x;
+  uint32_t ph = 0, proom = 0, pcur = 0, need = 0, take = 0, g0 = 0;
+  if(pb < nb) {
+    ph = G.hist[pb]; proom = G.room[pb]; pcur = G.cur[pb];
+    if(ph > proom) { need = ph - proom; take = (need + kGran - 1) / kGran * kGran; g0 = atomicAdd(&gcur[pb], take); }
+  }
+#pragma unroll
+  for(int e = 0; e < N; ++e)
+    if(dr[e] != 0xFFFFFFFFu) {
+      const uint32_t at = G.lstart[dr[e] >> 16] + (dr[e] & 0xFFFFu);
+      s_item[at] = it[e]; s_bkt[at] = (uint16_t)(dr[e] >> 16);
+    }
+  if(pb < nb) {
+    G.pos0[pb] = pcur;
+    if(!take) { G.split[pb] = (uint16_t)ph; G.cur[pb] = pcur + ph; G.room[pb] = (uint16_t)(proom - ph); G.cnt[pb] += ph; }
+    else {
+      G.split[pb] = (uint16_t)proom;
+      if((uint64_t)g0 + take <= cap) { G.pos1[pb] = g0; G.cur[pb] = g0 + need; G.room[pb] = (uint16_t)(take - need); G.cnt[pb] += ph; }
+      else {                                                                                 // region exhausted
+        G.pos1[pb] = kNoRoom; G.cur[pb] = pcur + proom; G.room[pb] = 0; G.cnt[pb] += proom;
+        if(g0 < cap) atomicMax(&gcur[nb + pb], cap - g0);       // everything below g0 was handed out successfully
+      }
+    }
+  }
+  lds_barrier();
+  uint32_t direct_n = 0;
+  const uint32_t cn = G.lstart[nb - 1] + G.hist[nb - 1];
+  for(uint32_t i = threadIdx.x; i < cn; i += blockDim.x) {
+    const uint32_t b = s_bkt[i], r = i - G.lstart[b], sp = G.split[b];
+    const uint32_t v = s_item[i];
+    uint32_t rel = G.pos0[b] + r;
+    bool direct = false;
+    if(r >= sp) { const uint32_t p1 = G.pos1[b]; if(p1 == kNoRoom) direct = true; else rel = p1 + (r - sp); }
+    if(!direct) {
+      out[(uint64_t)b * cap + rel] = v;
+      if(v == 0xFFFFFFFFu) { direct = true; atomicSub(&G.cnt[b], 1u); }   // its slot now reads as a hole
+    }
+    if(direct) { item_direct_insert<RETURNING>(T, P, b, (uint64_t)v); ++direct_n; }
+  }
+  return direct_n;
+}
+
+// Kernel end: unused tails of the last reservations become holes, exact per-bucket counts go to tot.
+__device__ inline void granule_finish(GranuleLds& G, uint32_t nb, uint32_t cap, unsigned long long* __restrict__ tot, uint32_t* __restrict__ out) {
+  lds_barrier();
+  for(uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {
+    const uint32_t room = G.room[b], cur = G.cur[b];
+    for(uint32_t r = 0; r < room; ++r) out[(uint64_t)b * cap + cur + r] = 0xFFFFFFFFu;
+    if(G.cnt[b]) atomicAdd(&tot[b], (unsigned long long)G.cnt[b]);
+  }
+}
+
 template <bool RETURNING, bool BLOOM, int NB>
 __global__ __launch_bounds__(kPBlock) void p1_scatter_granule_kernel(DevTable T, PartGeom P, const uint8_t* __restrict__ base,
                                                                      int64_t lo, int64_t hi, uint32_t cap,
                                                                      unsigned int* __restrict__ gcur,
                                                                      unsigned long long* __restrict__ tot,
                                                                      uint32_t* __restrict__ out) {
-  constexpr uint32_t kNoRoom = 0xFFFFFFFFu;
-  constexpr int kMaxB = 1024;
   extern __shared__ __align__(16) unsigned char s_dyn[];
   uint32_t* s_item = reinterpret_cast<uint32_t*>(s_dyn);                          // [kPTilePos]
   uint16_t* s_bkt = reinterpret_cast<uint16_t*>(s_dyn + (size_t)kPTilePos * 4);   // [kPTilePos]
   __shared__ uint64_t s_fwd[8 * 256];
   __shared__ uint32_t s_codes[kPBlock + 2];
   __shared__ uint32_t s_inv[kPBlock + 2];
-  __shared__ uint32_t s_cur[kMaxB];      // next free position of this block in bucket b's region (relative)
-  __shared__ uint16_t s_room[kMaxB];     // items left in the current reservation
-  __shared__ uint32_t s_hist[kMaxB];
-  __shared__ uint32_t s_lstart[kMaxB];
-  __shared__ uint32_t s_pos0[kMaxB];     // where this chunk's run of bucket b starts ...
-  __shared__ uint16_t s_split[kMaxB];    // ... how many of its items fit there ...
-  __shared__ uint32_t s_pos1[kMaxB];     // ... and where the rest goes (kNoRoom: region exhausted)
-  __shared__ uint32_t s_cnt[kMaxB];      // items this block stored per bucket
-  __shared__ uint32_t s_wave[16];
+  __shared__ GranuleLds G;
   const uint32_t nb = 1u << P.b1;
   load_tables_lds(s_fwd, T.fwd_tbl, T.g.nbytes);
-  for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) { s_cur[j] = 0; s_room[j] = 0; s_cnt[j] = 0; }
+  granule_init(G, nb);
   const uint32_t bshift = T.g.lsize_l - P.b1;
   uint32_t my_direct = 0, my_mers = 0;
   const int64_t n_tiles = (hi + kPTilePos - 1) / kPTilePos;
   TileRaw R = tile_fetch(base, (int64_t)blockIdx.x * kPTilePos, lo, hi);
   for(int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     lds_barrier();
-    for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) s_hist[j] = 0;
+    for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) G.hist[j] = 0;
     const LaneWords L = tile_stage(R, tile * kPTilePos, lo, hi, s_codes, s_inv);      // barrier inside
     R = tile_fetch(base, (tile + gridDim.x) * kPTilePos, lo, hi);                      // next tile's bytes travel while this one is worked on
     uint32_t it[kPerLane + 1], dr[kPerLane + 1];
@@ -725,7 +799,7 @@ __global__ __launch_bounds__(kPBlock) void p1_scatter_granule_kernel(DevTable T,
         const uint64_t local = pos & T.g.local_mask;
         const uint32_t b = (uint32_t)(local >> bshift);
         it[site] = make_item<uint32_t>(T.g, P, prev, local);
-        dr[site] = (b << 16) | atomicAdd(&s_hist[b], 1u);
+        dr[site] = (b << 16) | atomicAdd(&G.hist[b], 1u);
       } else if(run > 1) long_runs = true;
     };
     for_each_kmer(T.g, L, [&](int j, uint64_t key) {
@@ -737,61 +811,67 @@ __global__ __launch_bounds__(kPBlock) void p1_scatter_granule_kernel(DevTable T,
     });
     flush_run(kPerLane);
     if(long_runs) my_direct += apply_runs<RETURNING, BLOOM>(T, s_fwd, L);
-    lds_barrier();
-    block_excl_scan_2048(s_hist, s_lstart, nb, s_wave);
-    lds_barrier();
-    // Placement of every bucket's run (nb <= blockDim: one bucket per thread): what fits the current
-    // reservation stays there, the rest goes to a new one.  The reservation (a global atomic) is issued
-    // first, its round trip overlaps the LDS scatter, its answer is used afterwards.
-    const uint32_t pb = threadIdx.x;
-    uint32_t ph = 0, proom = 0, pcur = 0, need = 0, take = 0, g0 = 0;
-    if(pb < nb) {
-      ph = s_hist[pb]; proom = s_room[pb]; pcur = s_cur[pb];
-      if(ph > proom) { need = ph - proom; take = (need + kGran - 1) / kGran * kGran; g0 = atomicAdd(&gcur[pb], take); }
-    }
-#pragma unroll
-    for(int e = 0; e <= kPerLane; ++e)
-      if(dr[e] != 0xFFFFFFFFu) {
-        const uint32_t at = s_lstart[dr[e] >> 16] + (dr[e] & 0xFFFFu);
-        s_item[at] = it[e]; s_bkt[at] = (uint16_t)(dr[e] >> 16);
-      }
-    if(pb < nb) {
-      s_pos0[pb] = pcur;
-      if(!take) { s_split[pb] = (uint16_t)ph; s_cur[pb] = pcur + ph; s_room[pb] = (uint16_t)(proom - ph); s_cnt[pb] += ph; }
-      else {
-        s_split[pb] = (uint16_t)proom;
-        if((uint64_t)g0 + take <= cap) { s_pos1[pb] = g0; s_cur[pb] = g0 + need; s_room[pb] = (uint16_t)(take - need); s_cnt[pb] += ph; }
-        else {                                                                                 // region exhausted
-          s_pos1[pb] = kNoRoom; s_cur[pb] = pcur + proom; s_room[pb] = 0; s_cnt[pb] += proom;
-          if(g0 < cap) atomicMax(&gcur[nb + pb], cap - g0);       // everything below g0 was handed out successfully
-        }
-      }
-    }
-    lds_barrier();
-    const uint32_t cn = s_lstart[nb - 1] + s_hist[nb - 1];
-    for(uint32_t i = threadIdx.x; i < cn; i += blockDim.x) {
-      const uint32_t b = s_bkt[i], r = i - s_lstart[b], sp = s_split[b];
-      const uint32_t v = s_item[i];
-      uint32_t rel = s_pos0[b] + r;
-      bool direct = false;
-      if(r >= sp) { const uint32_t p1 = s_pos1[b]; if(p1 == kNoRoom) direct = true; else rel = p1 + (r - sp); }
-      if(!direct) {
-        out[(uint64_t)b * cap + rel] = v;
-        if(v == 0xFFFFFFFFu) { direct = true; atomicSub(&s_cnt[b], 1u); }   // its slot now reads as a hole
-      }
-      if(direct) { item_direct_insert<RETURNING>(T, P, b, (uint64_t)v); ++my_direct; }
-    }
+    my_direct += granule_emit<RETURNING>(G, T, P, nb, cap, gcur, out, s_item, s_bkt, it, dr);
   }
-  lds_barrier();
-  for(uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {
-    const uint32_t room = s_room[b], cur = s_cur[b];
-    for(uint32_t r = 0; r < room; ++r) out[(uint64_t)b * cap + cur + r] = 0xFFFFFFFFu;
-    if(s_cnt[b]) atomicAdd(&tot[b], (unsigned long long)s_cnt[b]);
-  }
+  granule_finish(G, nb, cap, tot, out);
   if(my_direct) atomicAdd((unsigned long long*)&T.counters[CTR_DIRECT], (unsigned long long)my_direct);
   uint64_t w = my_mers;
   for(int o = 32; o > 0; o >>= 1) w += __shfl_down(w, o, 64);
   if((threadIdx.x & 63) == 0 && w) atomicAdd((unsigned long long*)&T.counters[CTR_MERS], (unsigned long long)w);
+}
+
+// The same for a batch of encoded k-mers (hash_counter::add batches, the receive side of the multi-GPU
+// exchange): block b walks its contiguous slice in chunks of 16384 keys.
+template <bool RETURNING, int NB>
+__global__ __launch_bounds__(kPBlock) void p1_keys_granule_kernel(DevTable T, PartGeom P, const uint64_t* __restrict__ keys, int64_t n,
+                                                                  uint32_t cap, unsigned int* __restrict__ gcur,
+                                                                  unsigned long long* __restrict__ tot, uint32_t* __restrict__ out) {
+  extern __shared__ __align__(16) unsigned char s_dyn[];
+  uint32_t* s_item = reinterpret_cast<uint32_t*>(s_dyn);
+  uint16_t* s_bkt = reinterpret_cast<uint16_t*>(s_dyn + (size_t)kPTilePos * 4);
+  __shared__ uint64_t s_fwd[8 * 256];
+  __shared__ GranuleLds G;
+  const uint32_t nb = 1u << P.b1;
+  load_tables_lds(s_fwd, T.fwd_tbl, T.g.nbytes);
+  granule_init(G, nb);
+  const uint32_t bshift = T.g.lsize_l - P.b1;
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t b0 = (int64_t)blockIdx.x * per, b1e = b0 + per < n ? b0 + per : n;
+  uint32_t my_direct = 0, misrouted = 0;
+  if(threadIdx.x == 0 && b1e > b0) atomicAdd((unsigned long long*)&T.counters[CTR_MERS], (unsigned long long)(b1e - b0));
+  uint64_t kk[kPerLane];
+  auto fetch = [&](int64_t c0) {
+#pragma unroll
+    for(int e = 0; e < kPerLane; ++e) {
+      const int64_t i = c0 + (int64_t)e * kPBlock + threadIdx.x;
+      kk[e] = i < b1e ? keys[i] : 0;
+    }
+  };
+  fetch(b0);
+  for(int64_t c0 = b0; c0 < b1e; c0 += kPTilePos) {
+    lds_barrier();
+    for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) G.hist[j] = 0;
+    lds_barrier();
+    uint32_t it[kPerLane], dr[kPerLane];
+#pragma unroll
+    for(int e = 0; e < kPerLane; ++e) {
+      dr[e] = 0xFFFFFFFFu;
+      if(c0 + (int64_t)e * kPBlock + threadIdx.x < b1e) {
+        const uint64_t key = kk[e] & T.g.key_mask;
+        const uint64_t pos = hash_tables_t<NB>(s_fwd, key, T.g.nbytes);
+        if((uint32_t)(pos >> T.g.lsize_l) != T.g.shard_id) { ++misrouted; continue; }
+        const uint64_t local = pos & T.g.local_mask;
+        const uint32_t b = (uint32_t)(local >> bshift);
+        it[e] = make_item<uint32_t>(T.g, P, key, local);
+        dr[e] = (b << 16) | atomicAdd(&G.hist[b], 1u);
+      }
+    }
+    fetch(c0 + kPTilePos);                                 // next chunk's keys travel during the sort and the write-out
+    my_direct += granule_emit<RETURNING>(G, T, P, nb, cap, gcur, out, s_item, s_bkt, it, dr);
+  }
+  granule_finish(G, nb, cap, tot, out);
+  if(my_direct) atomicAdd((unsigned long long*)&T.counters[CTR_DIRECT], (unsigned long long)my_direct);
+  if(misrouted) atomicAdd((unsigned long long*)&T.counters[CTR_MISROUTED], (unsigned long long)misrouted);
 }
 
 // After the granule pass: bucket bounds in the pair format of SegList (sh == 1).

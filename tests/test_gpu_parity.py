@@ -547,3 +547,45 @@ def test_single_pass_p1_large_equals_two_pass(gpu, monkeypatch):
             res.append((s.distinct, s.unique, s.max_count, h.tolist()))
             t.free(d)
     assert res[0] == res[1]
+
+
+@pytest.mark.parametrize("slack", ["0.03", "-0.9"])
+def test_single_pass_p1_from_keys_and_shards(gpu, monkeypatch, slack):
+    """Encoded k-mers (the receive side of the multi-GPU exchange) through the single-pass partition:
+    two shard tables of 2^25 slots fed with their routed keys hold exactly the oracle's counts; a key
+    that belongs to the other shard is reported, not inserted."""
+    monkeypatch.setenv("JFGPU_P1_SINGLE", "1")
+    monkeypatch.setenv("JFGPU_P1_SLACK", slack)
+    rng = random.Random(41)
+    k = 16
+    seq = rnd_seq(rng, 500000, "ACGTN")
+    exp = oracle_map(seq, k, True)
+    shards = [gpu.Table(k, 1 << 26, shard_bits=1, shard_id=s) for s in range(2)]      # 2^25 local slots each
+    try:
+        for t in shards:
+            t.set_mode(2); t.set_growth(False)
+        t0 = shards[0]
+        d_seq = t0.malloc(len(seq) + 16)
+        d_keys = t0.malloc(8 * len(seq))
+        t0.h2d(d_seq, np.frombuffer(seq, dtype=np.uint8))
+        counts = t0.partition_ascii_dev(d_seq, len(seq), d_keys, len(seq))
+        assert counts.sum() == sum(exp.values())
+        merged, off = {}, 0
+        for s, t in enumerate(shards):
+            n = int(counts[s])
+            t.add_keys_dev(d_keys + 8 * off, n // 2, 1)                 # two batches per shard
+            t.add_keys_dev(d_keys + 8 * (off + n // 2), n - n // 2, 1)
+            t.sync()
+            st = t.stats()
+            assert st.total == n == st.mers_fed
+            kk, cc = gpu.decode_records(t.dump_records(), k, 4)
+            merged.update(dict(zip(kk.tolist(), cc.tolist())))
+            off += n
+        assert merged == exp
+        with pytest.raises(gpu.JfgpuError):
+            shards[0].add_keys_dev(d_keys + 8 * int(counts[0]), min(int(counts[1]), 1000), 1)
+            shards[0].sync()
+        t0.free(d_seq); t0.free(d_keys)
+    finally:
+        for t in shards:
+            t.close()

@@ -83,6 +83,32 @@ __global__ __launch_bounds__(kThreads) void probe(uint32_t* out, int items_per_l
           qn += __popcll(m);
         }
       }
+    } else if(MODE == 11) {                        // round 1 with all items in flight; losers finish in ONE per-lane loop
+      constexpr int NP = 5;
+      uint32_t xs[NP]; unsigned long long old[NP];
+#pragma unroll
+      for(int r = 0; r < NP; ++r) { x = x * 1664525u + 1013904223u; xs[r] = x; }
+#pragma unroll
+      for(int r = 0; r < NP; ++r)
+        if(r < n) old[r] = atomicCAS(&s_tile[(xs[r] >> 8) & (kSlots - 1)], 0ull, ((unsigned long long)(xs[r] | 1u) << 1) | 1ull);
+      uint32_t pend = 0;
+#pragma unroll
+      for(int r = 0; r < NP; ++r) {
+        const unsigned long long tag = ((unsigned long long)(xs[r] | 1u) << 1) | 1ull;
+        if(r < n && old[r] != 0ull) { if(old[r] == tag) atomicAdd(&s_tile[(xs[r] >> 8) & (kSlots - 1)], 1ull << 40); else pend |= 1u << r; }
+      }
+      uint32_t p = 1;
+      while(pend) {
+        const uint32_t r = __ffs(pend) - 1;
+        const uint32_t cx = r == 0 ? xs[0] : r == 1 ? xs[1] : r == 2 ? xs[2] : r == 3 ? xs[3] : xs[4];
+        const unsigned long long tag = ((unsigned long long)(cx | 1u) << 1) | 1ull;
+        const uint32_t slot = (((cx >> 8) & (kSlots - 1)) + p * (p + 1) / 2) & (kSlots - 1);
+        const unsigned long long o = atomicCAS(&s_tile[slot], 0ull, tag);
+        bool done = o == 0ull;
+        if(!done && o == tag) { atomicAdd(&s_tile[slot], 1ull << 40); done = true; }
+        if(!done && ++p >= 64) done = true;
+        if(done) { pend &= pend - 1; p = 1; }
+      }
     } else if(MODE == 7) {                         // one probe loop for all of the lane's items (a placed lane moves to its next item)
       uint32_t xs[5];
 #pragma unroll
@@ -162,9 +188,9 @@ int main() {
   hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
   const int cus = p.multiProcessorCount, blocks = cus * 2;    // 2 blocks per CU resident (64 KiB each), one round
   const double clk = p.clockRate * 1e3;
-  const char* names[] = {"64-bit CAS claim + probing", "32-bit CAS claim + probing", "one 64-bit CAS", "one 64-bit add (no return)", "plain 64-bit store", "read first, CAS if empty", "concurrent rounds (5 CAS in flight)", "persistent lane loop", "probing loop, no collisions, linear slots", "one CAS, linear slots", "round 1 in flight + per-wave loser queue"};
-  double ms[11] = {run<0>(d_out, blocks), run<1>(d_out, blocks), run<2>(d_out, blocks), run<3>(d_out, blocks), run<4>(d_out, blocks), run<5>(d_out, blocks), run<6>(d_out, blocks), run<7>(d_out, blocks), run<8>(d_out, blocks), run<9>(d_out, blocks), run<10>(d_out, blocks)};
-  for(int m = 0; m < 11; ++m)
+  const char* names[] = {"64-bit CAS claim + probing", "32-bit CAS claim + probing", "one 64-bit CAS", "one 64-bit add (no return)", "plain 64-bit store", "read first, CAS if empty", "concurrent rounds (5 CAS in flight)", "persistent lane loop", "probing loop, no collisions, linear slots", "one CAS, linear slots", "round 1 in flight + per-wave loser queue", "round 1 in flight + one loop for the lane's losers"};
+  double ms[12] = {run<0>(d_out, blocks), run<1>(d_out, blocks), run<2>(d_out, blocks), run<3>(d_out, blocks), run<4>(d_out, blocks), run<5>(d_out, blocks), run<6>(d_out, blocks), run<7>(d_out, blocks), run<8>(d_out, blocks), run<9>(d_out, blocks), run<10>(d_out, blocks), run<11>(d_out, blocks)};
+  for(int m = 0; m < 12; ++m)
     printf("%-30s %8.3f ms  -> %8.0f clk per tile per block (2 blocks/CU), %6.3f inserts/clk/CU\n", names[m], ms[m], ms[m] * 1e-3 * clk / kTiles,
            2.0 * kTiles * 4133.0 / (ms[m] * 1e-3 * clk));
   return 0;
