@@ -242,6 +242,10 @@ int  jfgpu_parser_parse_dev(jfgpu_parser* p, const char* d_bytes, size_t n, unsi
 /* bytes: host memory (e.g. the mmap of the file); copied to the device, then as above. */
 int  jfgpu_parser_parse(jfgpu_parser* p, const char* bytes, size_t n, unsigned flags,
                         const char** d_out, size_t* n_out, uint64_t* n_records);
+/* Pinned host staging owned by the parser (which = 0 or 1, grown on demand): fill one while the other
+ * is being parsed, then pass it to jfgpu_parser_parse -- the host-to-device copy of a pinned buffer runs
+ * at PCIe speed, that of pageable memory (an mmap'ed file) at a fraction of it. */
+int  jfgpu_parser_host_buffer(jfgpu_parser* p, int which, size_t bytes, char** out);
 /* Milliseconds the parse kernels of the last call took on the device (HIP events). */
 int  jfgpu_parser_last_ms(jfgpu_parser* p, double* ms);
 

@@ -94,6 +94,7 @@ SIGNATURES = {
     "jfgpu_parser_destroy": (None, [_P]),
     "jfgpu_parser_parse_dev": (C.c_int, [_P, _P, C.c_size_t, C.c_uint, C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
     "jfgpu_parser_parse": (C.c_int, [_P, _P, C.c_size_t, C.c_uint, C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
+    "jfgpu_parser_host_buffer": (C.c_int, [_P, C.c_int, C.c_size_t, C.POINTER(_P)]),
     "jfgpu_parser_last_ms": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "jfgpu_set_growth": (C.c_int, [_P, C.c_int]),
     "jfgpu_set_mode": (C.c_int, [_P, C.c_int]),

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include <jellyfish_amd/dumpers.hpp>
+#include <sys/stat.h>
 #include <jellyfish_amd/sequence_parser.hpp>
 #include <jellyfish_amd/device_parser.hpp>
 
@@ -176,6 +177,11 @@ int count_main(int argc, char* argv[]) {
 
   auto count_start = std::chrono::steady_clock::now();
   double parse_ms = 0; size_t fallback_bytes = 0;
+  {   // size the device workspace for the whole input up front (file sizes are an upper bound of the sequence)
+    uint64_t total = 0;
+    for(const auto& f : files) { struct stat st; if(stat(f.c_str(), &st) == 0 && S_ISREG(st.st_mode)) total += (uint64_t)st.st_size; }
+    if(!host_parse && total > ((uint64_t)64 << 20)) ary->expect_input(std::min<uint64_t>(total, (uint64_t)12 << 30));
+  }
   try {
     if(host_parse) {
       sequence_parser parser(mer_len);

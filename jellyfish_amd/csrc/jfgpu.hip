@@ -1460,6 +1460,7 @@ struct jfgpu_parser {
   uint32_t* d_nlpos = nullptr; size_t nlpos_cap = 0;
   ParseResult* d_res = nullptr;
   uint8_t* d_carry = nullptr; uint32_t carry_len = 0;      // last k-1 characters of the previous chunk's output
+  char* h_pin[2] = {nullptr, nullptr}; size_t pin_cap[2] = {0, 0};   // pinned host staging for callers that read files
   double last_ms = 0;
 };
 
@@ -1509,6 +1510,7 @@ void jfgpu_parser_destroy(jfgpu_parser* p) {
   if(p->stream) hipStreamSynchronize(p->stream);
   hipFree(p->d_raw); hipFree(p->d_out[0]); hipFree(p->d_out[1]); hipFree(p->d_agg); hipFree(p->d_start);
   hipFree(p->d_nlpos); hipFree(p->d_res); hipFree(p->d_carry);
+  for(int i = 0; i < 2; ++i) if(p->h_pin[i]) hipHostFree(p->h_pin[i]);
   if(p->ev_a) hipEventDestroy(p->ev_a);
   if(p->ev_b) hipEventDestroy(p->ev_b);
   if(p->stream) hipStreamDestroy(p->stream);
@@ -1615,6 +1617,19 @@ int jfgpu_parser_parse(jfgpu_parser* p, const char* bytes, size_t n, unsigned fl
     HIP_TRY(hipMemcpyAsync(p->d_raw, bytes, n, hipMemcpyHostToDevice, p->stream));
   }
   return jfgpu_parser_parse_dev(p, (const char*)p->d_raw, n, flags, d_out, n_out, n_records);
+}
+
+int jfgpu_parser_host_buffer(jfgpu_parser* p, int which, size_t bytes, char** out) {
+  int rc = use_p(p); if(rc) return rc;
+  if(!out || which < 0 || which > 1) return fail(JFGPU_E_INVALID, "bad argument");
+  *out = nullptr;
+  if(bytes > p->pin_cap[which]) {
+    if(p->h_pin[which]) { HIP_TRY(hipHostFree(p->h_pin[which])); p->h_pin[which] = nullptr; p->pin_cap[which] = 0; }
+    HIP_TRY(hipHostMalloc((void**)&p->h_pin[which], bytes, hipHostMallocDefault));
+    p->pin_cap[which] = bytes;
+  }
+  *out = p->h_pin[which];
+  return JFGPU_OK;
 }
 
 int jfgpu_parser_last_ms(jfgpu_parser* p, double* ms) {

@@ -104,6 +104,9 @@ public:
   // when buffers handed over so far may be overwritten.
   void count_sequence_dev(const char* d_bases, size_t n) { flush(); jf_check(jfgpu_count_ascii_dev(t_, d_bases, n)); }
   void wait_consumed() { jf_check(jfgpu_wait(t_)); }
+  // Expected amount of sequence before the next done(): lets the engine size its partition workspace once
+  // instead of growing it batch by batch (each growth applies what is pending first).  Best effort.
+  void expect_input(uint64_t bytes) { flush(); jfgpu_reserve(t_, bytes); }
 
   // hash_counter::add(k, v) (hash_counter.hpp:122-126): batched, thread-safe.
   void add(const mer_dna& k, uint64_t v) {

@@ -115,8 +115,12 @@ def test_device_parse_equals_host_parse(cli, tmp_path):
     for tag, inp in inputs.items():
         a, b = str(tmp_path / (tag + ".dev.jf")), str(tmp_path / (tag + ".host.jf"))
         base = [cli, "count", "-m", "21", "-C", "-s", "1M"]
-        env = dict(os.environ, JFGPU_TIMING_DETAIL="1")
-        subprocess.check_call(base + ["-o", a, "--timing", str(tmp_path / "tm"), inp], env=env)
+        for pinned in ("1", "0"):
+            env = dict(os.environ, JFGPU_TIMING_DETAIL="1", JFGPU_FEED_PINNED=pinned, JFGPU_PARSE_CHUNK="16384")
+            subprocess.check_call(base + ["-o", a, "--timing", str(tmp_path / "tm"), inp], env=env)
+            if pinned == "1":
+                first = subprocess.check_output([cli, "dump", "-c", a])
+        assert first == subprocess.check_output([cli, "dump", "-c", a])
         subprocess.check_call(base + ["-o", b, "--host-parse", inp])
         da = subprocess.check_output([cli, "dump", "-c", a])
         assert da == subprocess.check_output([cli, "dump", "-c", b]) and len(da) > 0
@@ -142,8 +146,10 @@ def test_many_chunks_equal_one(cli, tmp_path):
     fq = os.path.join(GOLD, [f for f in os.listdir(GOLD) if f.endswith(".fq")][0])
     for inp in (str(fa), fq):
         outs = []
-        for chunk in ("65536", "1073741824"):
-            o = str(tmp_path / ("c" + chunk + ".jf"))
-            subprocess.check_call([cli, "count", "-m", "25", "-C", "-s", "2M", "-o", o, inp], env=dict(os.environ, JFGPU_PARSE_CHUNK=chunk))
+        for chunk, pinned in (("65536", "0"), ("1073741824", "0"), ("65536", "1"), ("20000", "1")):
+            o = str(tmp_path / ("c" + chunk + pinned + ".jf"))
+            # pinned = 1: the large-file feed (parallel pread into two pinned buffers, tails carried over)
+            subprocess.check_call([cli, "count", "-m", "25", "-C", "-s", "2M", "-o", o, inp],
+                                  env=dict(os.environ, JFGPU_PARSE_CHUNK=chunk, JFGPU_FEED_PINNED=pinned))
             outs.append(subprocess.check_output([cli, "dump", "-c", o]))
-        assert outs[0] == outs[1] and len(outs[0]) > 0
+        assert all(x == outs[0] for x in outs) and len(outs[0]) > 0

@@ -35,11 +35,11 @@ for fmt in ("fa", "fq"):
     path = os.path.join(tmp, "feed_bench." + fmt)
     write(path, fmt == "fq")
     size = os.path.getsize(path)
-    for mode in ("device", "host"):
+    for mode in ("device", "device_pinned", "host"):
         tm = os.path.join(tmp, "feed_tm")
-        cmd = [CLI, "count", "-m", "21", "-C", "-s", "2G", "--no-write", "--timing", tm, path] + (["--host-parse"] if mode == "host" else [])
+        cmd = [CLI, "count", "-m", "21", "-C", "-s", "8G" if n_reads > 20_000_000 else "2G", "--no-write", "--timing", tm, path] + (["--host-parse"] if mode == "host" else [])
         t0 = time.time()
-        subprocess.check_call(cmd, env=dict(os.environ, JFGPU_TIMING_DETAIL="1"))
+        subprocess.check_call(cmd, env=dict(os.environ, JFGPU_TIMING_DETAIL="1", JFGPU_FEED_PINNED="1" if mode == "device_pinned" else "0"))
         wall = time.time() - t0
         t = dict(l.split() for l in open(tm))
         res["%s_%s" % (fmt, mode)] = {"file_bytes": size, "wall_s": round(wall, 3), "counting_s": float(t["Counting"]), "init_s": float(t["Init"]),
