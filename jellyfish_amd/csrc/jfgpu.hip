@@ -93,6 +93,9 @@ struct jfgpu_table {
   bool pristine = true;          // table known all-zero: tile_insert may skip the tile read
   std::vector<PendingBatch> pending;
   uint64_t pending_bytes = 0;
+  int flush_groups = 1;          // P2 / tile-insert pipeline depth of a flush (JFGPU_FLUSH_GROUPS).  Measured: 8 groups on two
+                                 // streams run P2 and T concurrently but no faster (both are LDS-bound), so one launch each is the default
+  hipStream_t stream2 = nullptr; hipEvent_t flush_ev[2] = {nullptr, nullptr}; hipEvent_t flush_done = nullptr;
   int p1_single = -1;            // single-pass P1: -1 auto (large batches), 0 never, 1 whenever the geometry allows (JFGPU_P1_SINGLE)
   double p1_slack = 0.03;        // head-room of a bucket region over the mean (JFGPU_P1_SLACK; negative forces the exhausted path)
   uint32_t* d_M1 = nullptr; int g1 = 0;
@@ -410,7 +413,7 @@ int part_ingest(jfgpu_table* t, const uint8_t* base, int64_t lo, int64_t hi, boo
     ProfScope ps(t, 4, (uint64_t)(from_keys ? hi : hi - lo));
     if(t->item32) launch_p1<uint32_t>(t, false, from_keys, base, lo, hi, b.off, b.items);
     else          launch_p1<uint64_t>(t, false, from_keys, base, lo, hi, b.off, b.items);
-    hipLaunchKernelGGL(scan_matrix_kernel, dim3(1), dim3(1024), 0, t->stream, t->d_M1, (uint32_t)t->g1, nb, (const uint64_t*)nullptr, b.off);
+    hipLaunchKernelGGL(scan_matrix_kernel, dim3(1), dim3(1024), 0, t->stream, t->d_M1, (uint32_t)t->g1, nb, (const uint64_t*)nullptr, b.off, 0u);
     if(t->item32 && !from_keys) {     // write-combining scatter (whole runs per bucket)
       const size_t lds = (size_t)kPTilePos * 6;
       const bool bl = t->dt.bloom.data != nullptr;
@@ -462,6 +465,7 @@ int part_flush_t(jfgpu_table* t) {
   for(size_t s = 0; s < nbatch; ++s)
     for(uint32_t j = 0; j < nb1; ++j) bucket_tot[j] += offs[s * (nb1 + 1) + j + 1] - offs[s * (nb1 + 1) + j];
   for(uint32_t j = 0; j < nb1; ++j) { total += bucket_tot[j]; max_bucket = std::max(max_bucket, bucket_tot[j]); }
+  if(max_bucket > 0xF0000000ull) return fail(JFGPU_E_UNSUPPORTED, "more than 2^32 pending k-mers in one partition bucket: sync more often");
   const uint64_t n_tiles = n_tiles_of(t);
   SegList S1; memset(&S1, 0, sizeof S1);
   S1.n = (uint32_t)nbatch;
@@ -514,18 +518,52 @@ int part_flush_t(jfgpu_table* t) {
     std::vector<uint64_t> base(nb1);
     { uint64_t run = 0; for(uint32_t j = 0; j < nb1; ++j) { base[j] = run; run += bucket_tot[j]; } }
     HIP_TRY(hipMemcpyAsync(d_base, base.data(), nb1 * sizeof(uint64_t), hipMemcpyHostToDevice, t->stream));
-    {
-      ProfScope ps(t, 5, total);
-      const dim3 grid(g2, nb1), block(kPBlock);
-      hipLaunchKernelGGL((p2_kernel<ITEM, false>), grid, block, 0, t->stream, t->pg, t->g.tag_bits, S1, t->d_M2, (const uint64_t*)d_goff, tmp);
-      hipLaunchKernelGGL(scan_matrix_kernel, dim3(nb1), dim3(1024), 0, t->stream, t->d_M2, (uint32_t)g2, nb2, (const uint64_t*)d_base, d_goff);
-      constexpr int per_thread = sizeof(ITEM) == 4 ? 16 : 8;
-      hipLaunchKernelGGL((p2_scatter_sorted_kernel<ITEM, per_thread>), grid, block, (size_t)kPBlock * per_thread * sizeof(ITEM), t->stream,
-                         t->pg, t->g.tag_bits, S1, (const uint32_t*)t->d_M2, (const uint64_t*)d_goff, tmp);
+    // Optionally (JFGPU_FLUSH_GROUPS > 1) the P1 buckets go through P2 and the tile insert in groups, P2 on the
+    // table's stream and the tile insert on a second one, so that group g's tiles are inserted while group g+1
+    // is partitioned (one P2-scatter block, 88 KB LDS, and one tile block, 64 KB, fit a CU together).
+    const uint32_t n_groups = t->flush_groups > 1 && nb1 >= (uint32_t)t->flush_groups * 8 ? (uint32_t)t->flush_groups : 1;
+    const uint32_t gsz = nb1 / n_groups;
+    if(n_groups > 1 && !t->stream2) {
+      HIP_TRY(hipStreamCreateWithFlags(&t->stream2, hipStreamNonBlocking));
+      for(auto& ev : t->flush_ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&t->flush_done, hipEventDisableTiming));
     }
-    SegList S2; memset(&S2, 0, sizeof S2);
-    S2.n = 1; S2.items[0] = tmp; S2.off[0] = d_goff;
-    launch_tiles(S2, 0, (uint32_t)n_tiles, total);
+    hipEvent_t p2a = nullptr, p2b = nullptr, ta = nullptr, tb = nullptr;
+    if(t->prof_on) { p2a = get_event(t); p2b = get_event(t); ta = get_event(t); tb = get_event(t); hipEventRecord(p2a, t->stream); }
+    constexpr int per_thread = sizeof(ITEM) == 4 ? 16 : 8;
+    for(uint32_t g = 0; g < n_groups; ++g) {
+      const uint32_t b0 = g * gsz, nbk = g + 1 == n_groups ? nb1 - b0 : gsz;
+      const dim3 grid(g2, nbk), block(kPBlock);
+      hipLaunchKernelGGL((p2_kernel<ITEM, false>), grid, block, 0, t->stream, t->pg, t->g.tag_bits, S1, t->d_M2, (const uint64_t*)d_goff, tmp, b0);
+      hipLaunchKernelGGL(scan_matrix_kernel, dim3(nbk), dim3(1024), 0, t->stream, t->d_M2, (uint32_t)g2, nb2, (const uint64_t*)d_base, d_goff, b0);
+      hipLaunchKernelGGL((p2_scatter_sorted_kernel<ITEM, per_thread>), grid, block, (size_t)kPBlock * per_thread * sizeof(ITEM), t->stream,
+                         t->pg, t->g.tag_bits, S1, (const uint32_t*)t->d_M2, (const uint64_t*)d_goff, tmp, b0);
+      const uint64_t tile_start = (uint64_t)b0 << t->pg.b2;
+      const uint32_t ntile = nbk << t->pg.b2;
+      SegList S2; memset(&S2, 0, sizeof S2);
+      S2.n = 1; S2.items[0] = tmp; S2.off[0] = d_goff + tile_start;
+      hipStream_t ts = t->stream;
+      if(n_groups > 1) {
+        HIP_TRY(hipEventRecord(t->flush_ev[g & 1], t->stream));
+        HIP_TRY(hipStreamWaitEvent(t->stream2, t->flush_ev[g & 1], 0));
+        ts = t->stream2;
+      }
+      if(t->prof_on && g == 0) hipEventRecord(ta, ts);
+      const dim3 tgrid((unsigned)std::min<uint64_t>(ntile, (uint64_t)t->n_cu * 16));
+#define TI(RT, LD) hipLaunchKernelGGL((tile_insert_kernel<ITEM, RT, LD>), tgrid, block, tile_lds, ts, t->dt, S2, tile_start, ntile)
+      if(rt) TI(true, true); else TI(false, true);
+#undef TI
+      if(t->prof_on && g + 1 == n_groups) hipEventRecord(tb, ts);
+    }
+    if(t->prof_on) {
+      hipEventRecord(p2b, t->stream);
+      t->prof_pending.push_back({p2a, p2b, 5, total});
+      t->prof_pending.push_back({ta, tb, 6, total});
+    }
+    if(n_groups > 1) {        // the table's stream continues only after the last tiles are in
+      HIP_TRY(hipEventRecord(t->flush_done, t->stream2));
+      HIP_TRY(hipStreamWaitEvent(t->stream, t->flush_done, 0));
+    }
     hipError_t e = hipStreamSynchronize(t->stream);
     if(tmp_owned) { hipFree(tmp); hipFree(d_goff); hipFree(d_base); }
     if(e != hipSuccess) return fail(JFGPU_E_HIP, hipGetErrorString(e));
@@ -743,6 +781,7 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
   }
   if(const char* m = getenv("JFGPU_P1_SINGLE")) t->p1_single = atoi(m) ? 1 : 0;     // tuning / test knobs of the single-pass P1
   if(const char* m = getenv("JFGPU_P1_SLACK")) t->p1_slack = atof(m);
+  if(const char* m = getenv("JFGPU_FLUSH_GROUPS")) t->flush_groups = std::max(1, atoi(m));
   {
     const int tl = (int)((size_t)8 << t->g.tile_bits);
 #define TATTR(I, R, L) HIP_TRY(hipFuncSetAttribute((const void*)tile_insert_kernel<I, R, L>, hipFuncAttributeMaxDynamicSharedMemorySize, tl))
@@ -791,6 +830,9 @@ void jfgpu_destroy(jfgpu_table* t) {
   if(t->d_M1) hipFree(t->d_M1);
   if(t->d_M2) hipFree(t->d_M2);
   if(t->ws) hipFree(t->ws);
+  if(t->stream2) hipStreamDestroy(t->stream2);
+  for(auto ev : t->flush_ev) if(ev) hipEventDestroy(ev);
+  if(t->flush_done) hipEventDestroy(t->flush_done);
   if(t->stream) hipStreamDestroy(t->stream);
   delete t;
 }

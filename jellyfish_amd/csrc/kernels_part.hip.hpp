@@ -176,10 +176,10 @@ __global__ __launch_bounds__(kPBlock) void p1_kernel(DevTable T, PartGeom P, con
 // `off` is one global offset array with n_groups * nb + 1 entries (the last written by the
 // last group).  base == nullptr means 0.
 __global__ __launch_bounds__(1024) void scan_matrix_kernel(uint32_t* __restrict__ M, uint32_t nblk, uint32_t nb,
-                                                           const uint64_t* __restrict__ base, uint64_t* __restrict__ off) {
+                                                           const uint64_t* __restrict__ base, uint64_t* __restrict__ off, uint32_t q0) {
   __shared__ unsigned long long s_tot[kMaxBuckets];
   __shared__ unsigned long long s_wave[16];
-  const uint32_t q = blockIdx.x;
+  const uint32_t q = q0 + blockIdx.x;
   uint32_t* Mq = M + (size_t)q * nblk * nb;
   for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) {
     uint64_t run = 0;
@@ -209,7 +209,9 @@ __global__ __launch_bounds__(1024) void scan_matrix_kernel(uint32_t* __restrict_
   const unsigned long long g0 = base ? base[q] : 0ull;
   if(2 * t < nb) off[(size_t)q * nb + 2 * t] = g0 + excl;
   if(2 * t + 1 < nb) off[(size_t)q * nb + 2 * t + 1] = g0 + excl + a;
-  if(q == gridDim.x - 1 && t == 1023) off[(size_t)gridDim.x * nb] = g0 + excl + a + b;
+  // the entry after this group's last bucket: the end of the whole array, or the same value the next group
+  // will write as its first entry (base[q+1] = base[q] + this total), so a consumer of group q alone is complete
+  if(t == 1023) off[(size_t)(q + 1) * nb] = g0 + excl + a + b;
 }
 
 // ---- P2: every P1 bucket -> its tiles, one launch -------------------------------------------
@@ -219,11 +221,11 @@ __global__ __launch_bounds__(1024) void scan_matrix_kernel(uint32_t* __restrict_
 // M is [bucket][G2][2^b2]; goff the global per-tile offsets produced by scan_matrix_kernel.
 template <typename ITEM, bool SCATTER>
 __global__ __launch_bounds__(kPBlock) void p2_kernel(PartGeom P, uint32_t tag_bits, SegList S, uint32_t* __restrict__ M,
-                                                     const uint64_t* __restrict__ goff, ITEM* __restrict__ out) {
+                                                     const uint64_t* __restrict__ goff, ITEM* __restrict__ out, uint32_t bucket0) {
   __shared__ unsigned long long s_cur[kMaxBuckets];
   __shared__ unsigned long long s_seg_lo[kMaxSeg + 1];
   const uint32_t nb = 1u << P.b2;
-  const uint32_t bucket = blockIdx.y;
+  const uint32_t bucket = bucket0 + blockIdx.y;
   uint32_t* Mq = M + ((size_t)bucket * gridDim.x + blockIdx.x) * nb;
   for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x)
     s_cur[j] = SCATTER ? (goff[(size_t)bucket * nb + j] + Mq[j]) : 0ull;
@@ -420,18 +422,19 @@ __global__ __launch_bounds__(kPBlock) void p1_keys_scatter_sorted_kernel(DevTabl
 template <typename ITEM, int PER_THREAD>
 __global__ __launch_bounds__(kPBlock) void p2_scatter_sorted_kernel(PartGeom P, uint32_t tag_bits, SegList S,
                                                                     const uint32_t* __restrict__ M,
-                                                                    const uint64_t* __restrict__ goff, ITEM* __restrict__ out) {
+                                                                    const uint64_t* __restrict__ goff, ITEM* __restrict__ out, uint32_t bucket0) {
   constexpr int kChunk = kPBlock * PER_THREAD;
   extern __shared__ __align__(16) unsigned char s_dyn[];
   ITEM* s_item = reinterpret_cast<ITEM*>(s_dyn);                       // [kChunk]
-  __shared__ unsigned long long s_delta[kMaxBuckets];                  // global write cursor of bucket d minus its start in the sorted chunk
+  __shared__ uint32_t s_delta[kMaxBuckets];     // write cursor of sub-bucket d (relative to the bucket's first item) minus its start in the sorted chunk, mod 2^32
   __shared__ uint32_t s_hist[kMaxBuckets];
   __shared__ uint32_t s_lstart[kMaxBuckets];
   __shared__ uint32_t s_wave[16];
   const uint32_t nb = 1u << P.b2;
-  const uint32_t bucket = blockIdx.y;
+  const uint32_t bucket = bucket0 + blockIdx.y;
   const uint32_t* Mq = M + ((size_t)bucket * gridDim.x + blockIdx.x) * nb;
-  for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) { s_delta[j] = goff[(size_t)bucket * nb + j] + Mq[j]; s_lstart[j] = 0; s_hist[j] = 0; }
+  const uint64_t base0 = goff[(size_t)bucket * nb];     // a bucket holds < 2^32 items (checked by the host)
+  for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) { s_delta[j] = (uint32_t)(goff[(size_t)bucket * nb + j] - base0) + Mq[j]; s_lstart[j] = 0; s_hist[j] = 0; }
   // this bucket's items = concatenation over the pending batches (block-uniform scalars)
   uint64_t n = 0;
   for(uint32_t s = 0; s < S.n; ++s) n += seg_hi(S, s, bucket) - seg_lo(S, s, bucket);
@@ -441,7 +444,7 @@ __global__ __launch_bounds__(kPBlock) void p2_scatter_sorted_kernel(PartGeom P, 
     const uint64_t c1 = c0 + kChunk < my_hi ? c0 + kChunk : my_hi;
     lds_barrier();                                      // previous chunk's readers of s_hist/s_lstart/s_item are done
     // the cursor of bucket d advances by what the previous chunk wrote; delta is re-based on the new lstart below
-    for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) { s_delta[j] += (unsigned long long)s_hist[j] + s_lstart[j]; s_hist[j] = 0; }
+    for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) { s_delta[j] += s_hist[j] + s_lstart[j]; s_hist[j] = 0; }
     ITEM it[PER_THREAD]; uint32_t dr[PER_THREAD];       // digit << 16 | rank inside the chunk
 #pragma unroll
     for(int r = 0; r < PER_THREAD; ++r) { dr[r] = 0xFFFFFFFFu; it[r] = 0; }
@@ -480,7 +483,7 @@ __global__ __launch_bounds__(kPBlock) void p2_scatter_sorted_kernel(PartGeom P, 
     for(uint32_t i = threadIdx.x; i < cn; i += blockDim.x) {
       const ITEM v = s_item[i];
       const uint32_t d = (uint32_t)((uint64_t)v >> tag_bits) & (nb - 1);
-      out[s_delta[d] + i] = v;                         // run of bucket d: consecutive lanes, consecutive addresses
+      out[base0 + (uint32_t)(s_delta[d] + i)] = v;     // run of bucket d: consecutive lanes, consecutive addresses
     }
   }
 }
