@@ -538,6 +538,7 @@ int part_flush_t(jfgpu_table* t) {
       hipLaunchKernelGGL(scan_matrix_kernel, dim3(nbk), dim3(1024), 0, t->stream, t->d_M2, (uint32_t)g2, nb2, (const uint64_t*)d_base, d_goff, b0);
       hipLaunchKernelGGL((p2_scatter_sorted_kernel<ITEM, per_thread>), grid, block, (size_t)kPBlock * per_thread * sizeof(ITEM), t->stream,
                          t->pg, t->g.tag_bits, S1, (const uint32_t*)t->d_M2, (const uint64_t*)d_goff, tmp, b0);
+      if(t->prof_on && g + 1 == n_groups) hipEventRecord(p2b, t->stream);
       const uint64_t tile_start = (uint64_t)b0 << t->pg.b2;
       const uint32_t ntile = nbk << t->pg.b2;
       SegList S2; memset(&S2, 0, sizeof S2);
@@ -556,7 +557,6 @@ int part_flush_t(jfgpu_table* t) {
       if(t->prof_on && g + 1 == n_groups) hipEventRecord(tb, ts);
     }
     if(t->prof_on) {
-      hipEventRecord(p2b, t->stream);
       t->prof_pending.push_back({p2a, p2b, 5, total});
       t->prof_pending.push_back({ta, tb, 6, total});
     }
