@@ -202,6 +202,16 @@ int  jfgpu_attach_bloom(jfgpu_table* t, jfgpu_bloom* b);
  * unsharded tables only for now. */
 int  jfgpu_set_growth(jfgpu_table* t, int on);
 
+/* What jfgpu_count_ascii(_dev) does with every k-mer (mer_counter_base::start, count_main.cc:152-184):
+ *   JFGPU_OP_COUNT   add(m, 1)                                   the default
+ *   JFGPU_OP_PRIME   set(m): the key enters the table with count 0   first pass of `count --if` (:289-295)
+ *   JFGPU_OP_UPDATE  update_add(m, 1): counted only if already there  second pass of `count --if`
+ * Keys with count 0 are real entries: stats, histo and dumps report them like the reference does. */
+#define JFGPU_OP_COUNT  0
+#define JFGPU_OP_PRIME  1
+#define JFGPU_OP_UPDATE 2
+int  jfgpu_set_operation(jfgpu_table* t, int op);
+
 /* Insert strategy.  0 auto (default), 1 direct (global 64-bit atomics, kernels.hip.hpp),
  * 2 partitioned (radix partition + LDS-resident tiles, kernels_part.hip.hpp; large batches
  * are buffered on the device and applied at the next jfgpu_sync / read).  Results are

@@ -97,6 +97,7 @@ SIGNATURES = {
     "jfgpu_parser_host_buffer": (C.c_int, [_P, C.c_int, C.c_size_t, C.POINTER(_P)]),
     "jfgpu_parser_last_ms": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "jfgpu_set_growth": (C.c_int, [_P, C.c_int]),
+    "jfgpu_set_operation": (C.c_int, [_P, C.c_int]),
     "jfgpu_set_mode": (C.c_int, [_P, C.c_int]),
     "jfgpu_reserve": (C.c_int, [_P, C.c_uint64]),
     "jfgpu_profile_enable": (C.c_int, [_P, C.c_int]),
@@ -279,6 +280,10 @@ class Table:
     def refresh_info(self):
         _check(self._lib.jfgpu_get_info(self._h, C.byref(self.info)))
         return self.info
+
+    def set_operation(self, op):
+        """0 count, 1 prime (set), 2 update (count only what is already there): the passes of `count --if`."""
+        _check(self._lib.jfgpu_set_operation(self._h, op))
 
     def set_mode(self, mode):
         """0 auto, 1 direct (global atomics), 2 partitioned (LDS tiles)."""

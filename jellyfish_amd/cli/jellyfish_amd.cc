@@ -88,12 +88,13 @@ int count_main(int argc, char* argv[]) {
   bool size_given = false, lower_given = false, upper_given = false, canonical = false, text = false, no_write = false, disk = false, host_parse = false;
   int device = -1;
   std::string output = "mer_counts.jf", timing, bc_path;
-  std::vector<std::string> files;
+  std::vector<std::string> files, if_files;
   ArgCursor a{argc, argv};
   for(; a.more(); ++a.i) {
     if(a.is("-m", "--mer-len")) mer_len = (unsigned)strtoul(a.value("-m", "--mer-len").c_str(), 0, 10);
     else if(a.is("-s", "--size")) { size = parse_suffix(a.value("-s", "--size"), "-s"); size_given = true; }
     else if(a.is("-t", "--threads")) threads = (unsigned)strtoul(a.value("-t", "--threads").c_str(), 0, 10);
+    else if(a.is("", "--if")) if_files.push_back(a.value("", "--if"));
     else if(a.is("-F", "--Files")) Files = (unsigned)strtoul(a.value("-F", "--Files").c_str(), 0, 10);
     else if(a.is("-c", "--counter-len")) counter_len = (unsigned)strtoul(a.value("-c", "--counter-len").c_str(), 0, 10);
     else if(a.is("", "--out-counter-len")) out_counter_len = (unsigned)strtoul(a.value("", "--out-counter-len").c_str(), 0, 10);
@@ -110,7 +111,7 @@ int count_main(int argc, char* argv[]) {
     else if(a.cur() == "--host-parse") host_parse = true;   // read the files with the host reader instead of the device parser
     else if(a.cur() == "--disk") disk = true;   // do_size_doubling(false) (count_main.cc:276-277); no spill files yet: a full table is an error
     else if(a.cur() == "--no-merge" || a.cur() == "--no-unlink") { /* spill-to-disk knobs */ }
-    else if(a.is("", "--bf-size") || a.is("", "--bf-fp") || a.is("", "--if") || a.is("-Q", "--min-qual-char") ||
+    else if(a.is("", "--bf-size") || a.is("", "--bf-fp") || a.is("-Q", "--min-qual-char") ||
             a.is("-q", "--min-quality") || a.is("-g", "--generator") || a.is("-G", "--Generators") || a.is("", "--sam"))
       die("Option '" + a.cur() + "' is not supported by jellyfish-amd yet");
     else if(a.cur() == "-h" || a.cur() == "--help") {
@@ -126,6 +127,7 @@ int count_main(int argc, char* argv[]) {
                    " -p, --reprobes=uint32       Maximum number of reprobes (126)\n"
                    " -L, --lower-count=uint64    Don't output k-mer with count < lower-count\n"
                    " -U, --upper-count=uint64    Don't output k-mer with count > upper-count\n"
+                   "     --if=path               Count only the k-mers of these fasta / fastq files (repeatable)\n"
                    "     --text                  Dump in text format (false)\n"
                    "     --timing=Timing file    Print timing information\n"
                    "     --device=int            HIP device ordinal (current)\n"
@@ -182,19 +184,27 @@ int count_main(int argc, char* argv[]) {
     for(const auto& f : files) { struct stat st; if(stat(f.c_str(), &st) == 0 && S_ISREG(st.st_mode)) total += (uint64_t)st.st_size; }
     if(!host_parse && total > ((uint64_t)64 << 20)) ary->expect_input(std::min<uint64_t>(total, (uint64_t)12 << 30));
   }
-  try {
+  auto feed = [&](const std::vector<std::string>& paths) {
     if(host_parse) {
       sequence_parser parser(mer_len);
-      for(const auto& f : files)
+      for(const auto& f : paths)
         parser.parse_file(f.c_str(), [&](const char* buf, size_t n) { ary->count_sequence(buf, n); });
     } else {
       device_sequence_parser parser(mer_len, device);
-      for(const auto& f : files)
+      for(const auto& f : paths)
         parser.parse_file(f.c_str(), [&](const char* d_buf, size_t n) { ary->count_sequence_dev(d_buf, n); },
                           [&](const char* buf, size_t n) { ary->count_sequence(buf, n); }, [&]() { ary->wait_consumed(); });
-      parse_ms = parser.device_ms(); fallback_bytes = parser.host_fallback_bytes();
+      parse_ms += parser.device_ms(); fallback_bytes += parser.host_fallback_bytes();
     }
     ary->done();
+  };
+  try {
+    if(!if_files.empty()) {   // count_main.cc:289-295: prime the hash with the --if mers, then only update
+      ary->set_operation(mer_hash::PRIME);
+      feed(if_files);
+      ary->set_operation(mer_hash::UPDATE);
+    }
+    feed(files);
   } catch(std::exception& e) { die(e.what()); }
   const double count_s = seconds_since(count_start);
 

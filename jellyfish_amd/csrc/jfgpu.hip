@@ -93,6 +93,7 @@ struct jfgpu_table {
   bool pristine = true;          // table known all-zero: tile_insert may skip the tile read
   std::vector<PendingBatch> pending;
   uint64_t pending_bytes = 0;
+  int operation = 0;             // what count_ascii does with a k-mer: 0 add, 1 set (prime), 2 update_add (jfgpu_set_operation)
   int flush_groups = 1;          // P2 / tile-insert pipeline depth of a flush (JFGPU_FLUSH_GROUPS).  Measured: 8 groups on two
                                  // streams run P2 and T concurrently but no faster (both are LDS-bound), so one launch each is the default
   hipStream_t stream2 = nullptr; hipEvent_t flush_ev[2] = {nullptr, nullptr}; hipEvent_t flush_done = nullptr;
@@ -193,6 +194,7 @@ int launch_count_chunk(jfgpu_table* t, const char* d_bases, size_t n) {
   const uint8_t* base; int64_t lo, hi;
   align_buffer(d_bases, n, base, lo, hi);
   if(t->wide) {
+    if(t->operation != 0) return fail(JFGPU_E_UNSUPPORTED, "--if (prime / update passes) with mer length > 32 is not built yet");
     const int64_t nt = (hi + kTilePos - 1) / kTilePos;
     ProfScope ps(t, 0, n);
     if(t->returning) hipLaunchKernelGGL(count_ascii_wide_kernel<true>, dim3(grid_for(t, (uint64_t)nt)), dim3(kBlock), 0, t->stream, t->wt, base, lo, hi);
@@ -200,7 +202,7 @@ int launch_count_chunk(jfgpu_table* t, const char* d_bases, size_t n) {
     HIP_TRY(hipGetLastError());
     return JFGPU_OK;
   }
-  if(use_partitioned(t, n)) {
+  if(t->operation == 0 && use_partitioned(t, n)) {        // PRIME / UPDATE passes of --if run on the direct kernel
     const int rc = part_ingest(t, base, lo, hi, false, n);
     if(rc >= 0) return rc;          // < 0: no memory for the pending batch -> direct kernel below
   }
@@ -209,7 +211,7 @@ int launch_count_chunk(jfgpu_table* t, const char* d_bases, size_t n) {
   const int grid = grid_for(t, (uint64_t)n_tiles);
   ProfScope ps(t, 0, n);
   const bool bl = t->dt.bloom.data != nullptr;
-#define CA(RT, BL) hipLaunchKernelGGL((count_ascii_kernel<RT, BL>), dim3(grid), dim3(kBlock), 0, t->stream, t->dt, base, lo, hi)
+#define CA(RT, BL) hipLaunchKernelGGL((count_ascii_kernel<RT, BL>), dim3(grid), dim3(kBlock), 0, t->stream, t->dt, base, lo, hi, t->operation)
   if(t->returning) { if(bl) CA(true, true); else CA(true, false); } else { if(bl) CA(false, true); else CA(false, false); }
 #undef CA
   HIP_TRY(hipGetLastError());
@@ -253,7 +255,7 @@ int ensure_capacity(jfgpu_table* t, uint64_t incoming, uint64_t* allowed) {
 
 int launch_count(jfgpu_table* t, const char* d_bases, size_t n) {
   if(n < t->g.k) return JFGPU_OK;
-  if(!capacity_managed(t)) return launch_count_chunk(t, d_bases, n);
+  if(!capacity_managed(t) || t->operation == 2) return launch_count_chunk(t, d_bases, n);   // an update pass adds no keys
   size_t off = 0;
   while(true) {
     uint64_t take = 0;
@@ -1201,6 +1203,14 @@ int jfgpu_reserve(jfgpu_table* t, uint64_t input_bytes) {
   HIP_TRY(hipMemsetAsync(t->ws, 0, t->ws_cap, t->stream));
   if(!t->d_M1) { t->g1 = 2 * t->n_cu; HIP_TRY(hipMalloc((void**)&t->d_M1, (size_t)t->g1 * kMaxBuckets * sizeof(uint32_t))); }
   if(t->pg.b2 && !t->d_M2) HIP_TRY(hipMalloc((void**)&t->d_M2, (size_t)nb1 * 32 * nb2 * sizeof(uint32_t)));
+  return JFGPU_OK;
+}
+
+int jfgpu_set_operation(jfgpu_table* t, int op) {
+  int rc = use(t); if(rc) return rc;
+  if(op < 0 || op > 2) return fail(JFGPU_E_INVALID, "operation must be 0 (count), 1 (prime) or 2 (update)");
+  if(op != t->operation) { rc = part_flush(t); if(rc) return rc; }     // pending adds belong to the old operation
+  t->operation = op;
   return JFGPU_OK;
 }
 

@@ -143,6 +143,36 @@ __device__ inline bool table_add(const DevTable& T, const uint64_t* fwd_lds, uin
   return false;
 }
 
+// hash_counter::update_add (hash_counter.hpp:150-166, large_hash_array.hpp update_add): increment only
+// if the key is already there -- the UPDATE pass of `count --if` (count_main.cc:173-181).  Probes like a
+// look-up: the first empty slot ends the search.
+template <bool RETURNING>
+__device__ inline bool table_update_add(const DevTable& T, const uint64_t* fwd_lds, uint64_t key, uint64_t cnt) {
+  const TableGeom& g = T.g;
+  const uint64_t pos = hash_tables(fwd_lds, key, g.nbytes);
+  const SlotAddr a = slot_addr(g, pos);
+  if(a.shard != g.shard_id) { atomicAdd((unsigned long long*)&T.counters[CTR_MISROUTED], 1ull); return false; }
+  const uint64_t low = g.occ_bit | make_tag(g, key, a.idx0);
+  const uint64_t add = cnt << (g.tag_bits + 1);
+  const uint32_t tmask = (uint32_t)g.tile_mask;
+  for(uint32_t p = 0; p <= T.max_probe; ++p) {
+    const uint64_t slot = a.tile_base + probe_slot(a.idx0, p, tmask);
+    unsigned long long* addr = (unsigned long long*)&T.slots[slot];
+    const unsigned long long old = __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if(old == 0ull) return false;
+    if((old & g.low_mask) == low) {
+      if(RETURNING) {
+        const unsigned long long prev = atomicAdd(addr, (unsigned long long)add);
+        if((prev >> (g.tag_bits + 1)) + cnt > g.cnt_max) ovf_add(T, slot, 1);
+      } else {
+        __hip_atomic_fetch_add(addr, (unsigned long long)add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return true;
+    }
+  }
+  return false;
+}
+
 // Arbitrary 64-bit increment (hash_counter::add(key, val)): split into field-sized pieces.
 __device__ inline bool table_add_val(const DevTable& T, const uint64_t* fwd_lds, uint64_t key, uint64_t val) {
   const TableGeom& g = T.g;
@@ -249,9 +279,10 @@ __device__ inline void load_tables_lds(uint64_t* dst, const uint64_t* src, uint3
 
 // ---- K2+K3 fused: count every k-mer of a contract buffer ----------------------
 // base: 16-byte aligned; valid bytes are [lo, hi).
+// op: 0 COUNT add(m, 1); 1 PRIME set(m) = claim with count 0; 2 UPDATE update_add(m, 1) (count_main.cc:152-184).
 template <bool RETURNING, bool BLOOM>
 __global__ __launch_bounds__(kBlock) void count_ascii_kernel(DevTable T, const uint8_t* __restrict__ base,
-                                                             int64_t lo, int64_t hi) {
+                                                             int64_t lo, int64_t hi, int op) {
   __shared__ uint64_t s_fwd[8 * 256];
   __shared__ uint32_t s_codes[kBlock + 2];
   __shared__ uint32_t s_inv[kBlock + 2];
@@ -271,14 +302,19 @@ __global__ __launch_bounds__(kBlock) void count_ascii_kernel(DevTable T, const u
     // run-length merge of consecutive identical k-mers (homopolymers / short tandem
     // repeats are the heavy hitters of real data): one atomic per run, not per k-mer.
     uint64_t prev = 0; uint32_t run = 0;
+    auto apply = [&](uint64_t key, uint32_t n) {
+      if(op == 0) table_add<RETURNING>(T, s_fwd, key, n);
+      else if(op == 1) table_add<RETURNING>(T, s_fwd, key, 0);
+      else table_update_add<RETURNING>(T, s_fwd, key, n);
+    };
     for_each_kmer(T.g, L, [&](int, uint64_t key) {
       ++my_mers;
       if(BLOOM && !bloom_admits(T.bloom, key)) return;            // count --bc (count_main.cc:115-118); compiled out otherwise
       if(run && key == prev) { ++run; return; }
-      if(run) table_add<RETURNING>(T, s_fwd, prev, run);
+      if(run) apply(prev, run);
       prev = key; run = 1;
     });
-    if(run) table_add<RETURNING>(T, s_fwd, prev, run);
+    if(run) apply(prev, run);
   }
   // one counter update per wave
   uint64_t w = my_mers;

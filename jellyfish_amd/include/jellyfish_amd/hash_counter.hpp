@@ -104,6 +104,10 @@ public:
   // when buffers handed over so far may be overwritten.
   void count_sequence_dev(const char* d_bases, size_t n) { flush(); jf_check(jfgpu_count_ascii_dev(t_, d_bases, n)); }
   void wait_consumed() { jf_check(jfgpu_wait(t_)); }
+  // What count_sequence does with a k-mer: COUNT add(m, 1), PRIME set(m), UPDATE update_add(m, 1)
+  // (the OPERATION of mer_counter_base, count_main.cc:133,152-184).
+  enum operation { COUNT = JFGPU_OP_COUNT, PRIME = JFGPU_OP_PRIME, UPDATE = JFGPU_OP_UPDATE };
+  void set_operation(operation op) { flush(); jf_check(jfgpu_set_operation(t_, (int)op)); }
   // Expected amount of sequence before the next done(): lets the engine size its partition workspace once
   // instead of growing it batch by batch (each growth applies what is pending first).  Best effort.
   void expect_input(uint64_t bytes) { flush(); jfgpu_reserve(t_, bytes); }

@@ -46,23 +46,30 @@ static double now_s() {
   return duration_cast<duration<double>>(steady_clock::now().time_since_epoch()).count();
 }
 
-// Same loop body as mer_counter_base::start (COUNT op, default filter).
+// Same loop bodies as mer_counter_base::start (count_main.cc:152-184): COUNT, and the PRIME / UPDATE pair
+// of `count --if` (:289-295).
+enum ref_operation { REF_COUNT, REF_PRIME, REF_UPDATE };
 class ref_counter : public jellyfish::thread_exec {
   mer_hash&       ary_;
   sequence_parser parser_;
   bool            canonical_;
   const jellyfish::mer_dna_bloom_counter* bc_;   // count --bc filter (count_main.cc:109-119), may be null
+  ref_operation   op_;
 public:
   std::vector<size_t> counts_;
   ref_counter(int nb_threads, mer_hash& ary, stream_manager_type& streams, bool canonical,
-              const jellyfish::mer_dna_bloom_counter* bc = 0)
+              const jellyfish::mer_dna_bloom_counter* bc = 0, ref_operation op = REF_COUNT)
     : ary_(ary), parser_(mer_dna::k(), streams.nb_streams(), 3 * nb_threads, 4096, streams),
-      canonical_(canonical), bc_(bc), counts_(nb_threads, 0) { ary_.reset_done(); }
+      canonical_(canonical), bc_(bc), op_(op), counts_(nb_threads, 0) { ary_.reset_done(); }
   virtual void start(int thid) {
     size_t count = 0;
+    mer_dna tmp;
     for(mer_iterator_type mers(parser_, canonical_); mers; ++mers) {
-      if(!bc_ || bc_->check(*mers) > 1)
-        ary_.add(*mers, 1);
+      if(!bc_ || bc_->check(*mers) > 1) {
+        if(op_ == REF_COUNT) ary_.add(*mers, 1);
+        else if(op_ == REF_PRIME) ary_.set(*mers);
+        else ary_.update_add(*mers, 1, tmp);
+      }
       ++count;
     }
     counts_[thid] = count;
@@ -88,11 +95,12 @@ static int do_count(int argc, char* argv[]) {
   const char* output = "mer_counts.jf";
   const char* timing = 0;
   const char* bc_path = 0;
-  file_vector files;
+  file_vector files, if_files;
   for(int i = 1; i < argc; ++i) {
     std::string a(argv[i]);
     auto next = [&]() -> const char* { if(i + 1 >= argc) { std::cerr << "missing value for " << a << "\n"; exit(1); } return argv[++i]; };
     if(a == "-m") k = atoi(next());
+    else if(a == "--if") if_files.push_back(next());
     else if(a == "-s") size = parse_size(next());
     else if(a == "-t") threads = atoi(next());
     else if(a == "-c") counter_len = atoi(next());
@@ -134,9 +142,17 @@ static int do_count(int argc, char* argv[]) {
     jellyfish::hash_pair<mer_dna> fns(bh.matrix(1), bh.matrix(2));
     bc.reset(new jellyfish::mer_dna_bloom_counter(bh.size(), bh.nb_hashes(), in, fns));
   }
+  ref_operation op = REF_COUNT;
+  if(!if_files.empty()) {   // count_main.cc:289-295: prime the hash with the mers of the --if files, then only update
+    stream_manager_type if_streams(Files);
+    if_streams.paths(if_files.begin(), if_files.end());
+    ref_counter primer(threads, ary, if_streams, canonical, 0, REF_PRIME);
+    primer.exec_join(threads);
+    op = REF_UPDATE;
+  }
   stream_manager_type streams(Files);
   streams.paths(files.begin(), files.end());
-  ref_counter counter(threads, ary, streams, canonical, bc.get());
+  ref_counter counter(threads, ary, streams, canonical, bc.get(), op);
   counter.exec_join(threads);
   double t2 = now_s();
   size_t total = 0;

@@ -153,3 +153,35 @@ def test_many_chunks_equal_one(cli, tmp_path):
                                   env=dict(os.environ, JFGPU_PARSE_CHUNK=chunk, JFGPU_FEED_PINNED=pinned))
             outs.append(subprocess.check_output([cli, "dump", "-c", o]))
         assert all(x == outs[0] for x in outs) and len(outs[0]) > 0
+
+
+@pytest.mark.parametrize("k,canonical", [(21, True), (12, False)])
+def test_count_if_equals_reference(cli, tmp_path, k, canonical):
+    """`count --if`: prime the table with the k-mers of the filter file, then only update
+    (count_main.cc:160-181,289-295).  k-mers of the filter absent from the reads stay with count 0 and are
+    written, counted by stats and shown by histo -- exactly like the reference binary on the same files."""
+    if not O.have_ref():
+        pytest.skip("oracle/_ref not built")
+    import random
+    rng = random.Random(k)
+    genome = "".join(rng.choice("ACGT") for _ in range(20000))
+    other = "".join(rng.choice("ACGT") for _ in range(3000))
+    filt = tmp_path / "filter.fa"
+    filt.write_text(">wanted\n%s\n>absent\n%s\n" % (genome[2000:7000], other))
+    reads = tmp_path / "reads.fa"
+    with open(reads, "w") as f:
+        for r in range(3000):
+            p = rng.randrange(0, len(genome) - 150)
+            f.write(">r%d\n%s\n" % (r, genome[p:p + 150]))
+    flags = ["-m", str(k), "-s", "200k"] + (["-C"] if canonical else [])
+    mine, ref = str(tmp_path / "mine.jf"), str(tmp_path / "ref.jf")
+    subprocess.check_call([cli, "count"] + flags + ["--if", str(filt), "-o", mine, str(reads)])
+    subprocess.check_call([O.REF_JF, "count"] + flags + ["--if", str(filt), "-o", ref, str(reads)])
+    a = sorted(subprocess.check_output([cli, "dump", "-c", mine]).decode().splitlines())
+    b = sorted(subprocess.check_output([O.REF_JF, "dump", "-c", ref]).decode().splitlines())
+    assert a == b and any(l.endswith(" 0") for l in a) and any(not l.endswith(" 0") for l in a)
+    for verb in ("stats", "histo"):
+        assert subprocess.check_output([cli, verb, mine]) == subprocess.check_output([O.REF_JF, verb, ref])
+    # the reference's own readers on our file
+    assert sorted(subprocess.check_output([O.REF_JF, "dump", "-c", mine]).decode().splitlines()) == b
+    assert subprocess.check_output([O.REF_JF, "dump", "--check-order", mine]).decode().startswith("ORDER OK %d" % len(b))

@@ -107,3 +107,39 @@ def test_cli_bc_and_count_bc(gpu, tmp_path):
     keys, cnt = O.count(seq, 21, True)
     twice = {O.to_str(keys[i], 21) for i in range(len(keys)) if cnt[i] >= 2}
     assert twice <= {l.split()[0] for l in a}
+
+
+def test_count_bc_single_pass_partition_equals_direct(gpu, monkeypatch):
+    """count --bc through the single-pass partition (p1_scatter_granule_kernel<.., BLOOM=true>): same table
+    as the direct kernel with the same filter attached, and k-mers seen once are filtered out."""
+    monkeypatch.setenv("JFGPU_P1_SINGLE", "1")
+    rng = random.Random(77)
+    k = 16
+    once = "".join(rng.choice("ACGT") for _ in range(300000))
+    twice = "".join(rng.choice("ACGT") for _ in range(100000))
+    seq = (once + "N" + twice + "N" + twice + "N" + "A" * 200).encode()       # includes a homopolymer run
+    n = 500000
+    with gpu.Bloom(k, gpu.opt_m(0.001, n), gpu.opt_k(0.001), canonical=True, seed=3) as b:
+        b.insert_ascii(seq)
+        b.sync()
+        res = []
+        for mode in (1, 2):
+            with gpu.Table(k, 1 << 25, canonical=True) as t:
+                t.set_mode(mode)
+                t.attach_bloom(b)
+                d = t.malloc(len(seq) + 64)
+                t.h2d(d, np.frombuffer(seq, dtype=np.uint8))
+                t.count_ascii_dev(d, len(seq))
+                t.sync()
+                st = t.stats()
+                keys, cnts = gpu.decode_records(t.dump_records(), k, 4)
+                res.append((st.distinct, st.total, dict(zip(keys.tolist(), cnts.tolist()))))
+                t.attach_bloom(None)
+                t.free(d)
+        assert res[0] == res[1]
+        kk, cc = O.count(seq, k, True)
+        exact = dict(zip(kk[:, 0].tolist(), cc.tolist()))
+        got = res[1][2]
+        assert all(got.get(key, 0) == c for key, c in exact.items() if c >= 2)          # nothing seen twice is lost
+        singles = [key for key, c in exact.items() if c == 1]
+        assert sum(1 for key in singles if key in got) < 0.01 * len(singles)            # only false positives survive

@@ -589,3 +589,35 @@ def test_single_pass_p1_from_keys_and_shards(gpu, monkeypatch, slack):
     finally:
         for t in shards:
             t.close()
+
+
+def test_prime_and_update_operations(gpu):
+    """jfgpu_set_operation: PRIME enters keys with count 0, UPDATE counts only what is there
+    (hash_counter::set / update_add, the two passes of `count --if`)."""
+    rng = random.Random(5)
+    k = 21
+    wanted = rnd_seq(rng, 5000)
+    reads = wanted[1000:3000] + b"N" + rnd_seq(rng, 4000) + b"N" + wanted[1000:3000]
+    exp_w = oracle_map(wanted, k, True)
+    exp_r = oracle_map(reads, k, True)
+    with gpu.Table(k, 1 << 16) as t:
+        t.set_operation(1)
+        t.count_ascii(wanted)
+        t.sync()
+        st = t.stats()
+        assert (st.distinct, st.total) == (len(exp_w), 0)
+        t.set_operation(2)
+        t.count_ascii(reads)
+        t.sync()
+        got = table_map(gpu, t)
+        assert got == {key: exp_r.get(key, 0) for key in exp_w}
+        base, inc, h = t.histo(0, 10, 1)
+        assert h[0] == sum(1 for key in exp_w if key not in exp_r)
+        t.set_operation(0)
+        t.count_ascii(reads)
+        t.sync()
+        got = table_map(gpu, t, check_order=False)
+        exp = {key: exp_r.get(key, 0) for key in exp_w}
+        for key, c in exp_r.items():
+            exp[key] = exp.get(key, 0) + c
+        assert got == exp
