@@ -24,6 +24,7 @@
 
 #include <jellyfish_amd/dumpers.hpp>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <jellyfish_amd/sequence_parser.hpp>
 #include <jellyfish_amd/device_parser.hpp>
 
@@ -87,7 +88,7 @@ int count_main(int argc, char* argv[]) {
   uint64_t size = 0, lower = 0, upper = std::numeric_limits<uint64_t>::max();
   bool size_given = false, lower_given = false, upper_given = false, canonical = false, text = false, no_write = false, disk = false, host_parse = false;
   int device = -1;
-  std::string output = "mer_counts.jf", timing, bc_path;
+  std::string output = "mer_counts.jf", timing, bc_path, generator, shell;
   std::vector<std::string> files, if_files;
   ArgCursor a{argc, argv};
   for(; a.more(); ++a.i) {
@@ -95,6 +96,9 @@ int count_main(int argc, char* argv[]) {
     else if(a.is("-s", "--size")) { size = parse_suffix(a.value("-s", "--size"), "-s"); size_given = true; }
     else if(a.is("-t", "--threads")) threads = (unsigned)strtoul(a.value("-t", "--threads").c_str(), 0, 10);
     else if(a.is("", "--if")) if_files.push_back(a.value("", "--if"));
+    else if(a.is("-g", "--generator")) generator = a.value("-g", "--generator");
+    else if(a.is("-G", "--Generators")) (void)a.value("-G", "--Generators");     // generators run one after the other here
+    else if(a.is("-S", "--shell")) shell = a.value("-S", "--shell");
     else if(a.is("-F", "--Files")) Files = (unsigned)strtoul(a.value("-F", "--Files").c_str(), 0, 10);
     else if(a.is("-c", "--counter-len")) counter_len = (unsigned)strtoul(a.value("-c", "--counter-len").c_str(), 0, 10);
     else if(a.is("", "--out-counter-len")) out_counter_len = (unsigned)strtoul(a.value("", "--out-counter-len").c_str(), 0, 10);
@@ -112,7 +116,7 @@ int count_main(int argc, char* argv[]) {
     else if(a.cur() == "--disk") disk = true;   // do_size_doubling(false) (count_main.cc:276-277); no spill files yet: a full table is an error
     else if(a.cur() == "--no-merge" || a.cur() == "--no-unlink") { /* spill-to-disk knobs */ }
     else if(a.is("", "--bf-size") || a.is("", "--bf-fp") || a.is("-Q", "--min-qual-char") ||
-            a.is("-q", "--min-quality") || a.is("-g", "--generator") || a.is("-G", "--Generators") || a.is("", "--sam"))
+            a.is("-q", "--min-quality") || a.is("", "--sam"))
       die("Option '" + a.cur() + "' is not supported by jellyfish-amd yet");
     else if(a.cur() == "-h" || a.cur() == "--help") {
       std::cout << "Usage: jellyfish-amd count [options] file:path+\n\n"
@@ -128,6 +132,8 @@ int count_main(int argc, char* argv[]) {
                    " -L, --lower-count=uint64    Don't output k-mer with count < lower-count\n"
                    " -U, --upper-count=uint64    Don't output k-mer with count > upper-count\n"
                    "     --if=path               Count only the k-mers of these fasta / fastq files (repeatable)\n"
+                   " -g, --generator=path        File of commands generating fast[aq] (one per line, e.g. zcat reads.fa.gz)\n"
+                   " -S, --shell=string          Shell used to run generator commands ($SHELL or /bin/sh)\n"
                    "     --text                  Dump in text format (false)\n"
                    "     --timing=Timing file    Print timing information\n"
                    "     --device=int            HIP device ordinal (current)\n"
@@ -138,7 +144,7 @@ int count_main(int argc, char* argv[]) {
   }
   if(!mer_len) die("Error: mandatory switch missing: -m, --mer-len");
   if(!size_given) die("Error: mandatory switch missing: -s, --size");
-  if(files.empty()) die("Error: at least 1 file argument is required");
+  if(files.empty() && generator.empty()) die("Error: at least 1 file argument is required");
   (void)threads; (void)counter_len; (void)reprobes; (void)Files;
   if(mer_len > 64) die("jellyfish-amd: mer length > 64 is not built yet");
   if(text) out_counter_len = 8;   // text counts are not saturated (text_dumper.hpp:18-20)
@@ -205,6 +211,37 @@ int count_main(int argc, char* argv[]) {
       ary->set_operation(mer_hash::UPDATE);
     }
     feed(files);
+    if(!generator.empty()) {
+      // -g: every line of the file is a shell command whose standard output is a fasta / fastq stream
+      // (lib/generator_manager.cc runs them through named pipes; here each is read through a pipe in turn)
+      std::ifstream gf(generator);
+      if(!gf.good()) die("Can't open generator file '" + generator + "'");
+      if(shell.empty()) { const char* e = getenv("SHELL"); shell = e && *e ? e : "/bin/sh"; }
+      sequence_parser parser(mer_len);
+      std::string cmd, data;
+      while(std::getline(gf, cmd)) {
+        if(cmd.find_first_not_of(" \t\r") == std::string::npos) continue;
+        int fds[2];
+        if(pipe(fds) != 0) die("pipe() failed");
+        const pid_t pid = fork();
+        if(pid < 0) die("fork() failed");
+        if(pid == 0) {
+          close(fds[0]); dup2(fds[1], 1); close(fds[1]);
+          execl(shell.c_str(), shell.c_str(), "-c", cmd.c_str(), (char*)0);
+          _exit(127);
+        }
+        close(fds[1]);
+        data.clear();
+        char tmp[1 << 16]; ssize_t r;
+        while((r = read(fds[0], tmp, sizeof tmp)) > 0) data.append(tmp, (size_t)r);
+        close(fds[0]);
+        int status = 0;
+        waitpid(pid, &status, 0);
+        if(!WIFEXITED(status) || WEXITSTATUS(status) != 0) die("Generator command failed: " + cmd);
+        parser.parse_memory(data.data(), data.size(), [&](const char* buf, size_t n) { ary->count_sequence(buf, n); });
+      }
+      ary->done();
+    }
   } catch(std::exception& e) { die(e.what()); }
   const double count_s = seconds_since(count_start);
 

@@ -185,3 +185,24 @@ def test_count_if_equals_reference(cli, tmp_path, k, canonical):
     # the reference's own readers on our file
     assert sorted(subprocess.check_output([O.REF_JF, "dump", "-c", mine]).decode().splitlines()) == b
     assert subprocess.check_output([O.REF_JF, "dump", "--check-order", mine]).decode().startswith("ORDER OK %d" % len(b))
+
+
+def test_generator_commands(cli, tmp_path):
+    """-g: input produced by shell commands (the reference's way to read compressed files,
+    lib/generator_manager.cc): same result as counting the files directly."""
+    import gzip
+    inp = os.path.join(GOLD, "reads150_s42.fa")
+    gz = tmp_path / "reads.fa.gz"
+    with open(inp, "rb") as f, gzip.open(gz, "wb") as g:
+        g.write(f.read())
+    gen = tmp_path / "generators"
+    gen.write_text("gzip -dc %s\n\ncat %s\n" % (gz, os.path.join(GOLD, "edge_cases.fa")))
+    a, b = str(tmp_path / "gen.jf"), str(tmp_path / "plain.jf")
+    subprocess.check_call([cli, "count", "-m", "21", "-C", "-s", "1M", "-o", a, "-g", str(gen)])
+    subprocess.check_call([cli, "count", "-m", "21", "-C", "-s", "1M", "-o", b, inp, os.path.join(GOLD, "edge_cases.fa")])
+    da = subprocess.check_output([cli, "dump", "-c", a])
+    assert da == subprocess.check_output([cli, "dump", "-c", b]) and len(da) > 0
+    bad = tmp_path / "badgen"
+    bad.write_text("exit 3\n")
+    r = subprocess.run([cli, "count", "-m", "21", "-s", "1M", "-o", a, "-g", str(bad)], capture_output=True)
+    assert r.returncode != 0 and b"Generator command failed" in r.stderr
