@@ -202,6 +202,13 @@ int  jfgpu_attach_bloom(jfgpu_table* t, jfgpu_bloom* b);
  * unsharded tables only for now. */
 int  jfgpu_set_growth(jfgpu_table* t, int on);
 
+/* The matrix a table gets when jfgpu_params gives neither matrix_columns nor matrix_seed: the one the
+ * reference itself would draw for a table of 2^lsize positions and key_len = 2k bits as the first matrix of
+ * its process (RectangularBinaryMatrix::randomize_pseudo_inverse over unseeded glibc random(),
+ * lib/rectangular_binary_matrix.cc:240-247, lib/misc.cc:66-72; identity when lsize >= key_len,
+ * large_hash_array.hpp:997-1000).  Host only: needs no device.  columns: key_len words, file-header order. */
+int  jfgpu_reference_matrix(uint32_t lsize, uint32_t key_len, uint64_t* columns);
+
 /* What jfgpu_count_ascii(_dev) does with every k-mer (mer_counter_base::start, count_main.cc:152-184):
  *   JFGPU_OP_COUNT   add(m, 1)                                   the default
  *   JFGPU_OP_PRIME   set(m): the key enters the table with count 0   first pass of `count --if` (:289-295)

@@ -97,6 +97,7 @@ SIGNATURES = {
     "jfgpu_parser_host_buffer": (C.c_int, [_P, C.c_int, C.c_size_t, C.POINTER(_P)]),
     "jfgpu_parser_last_ms": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "jfgpu_set_growth": (C.c_int, [_P, C.c_int]),
+    "jfgpu_reference_matrix": (C.c_int, [C.c_uint32, C.c_uint32, _P]),
     "jfgpu_set_operation": (C.c_int, [_P, C.c_int]),
     "jfgpu_set_mode": (C.c_int, [_P, C.c_int]),
     "jfgpu_reserve": (C.c_int, [_P, C.c_uint64]),
@@ -133,6 +134,13 @@ def load():
 def _check(rc):
     if rc != OK:
         raise JfgpuError(rc, load().jfgpu_last_error().decode(errors="replace"))
+
+
+def reference_matrix(lsize, key_len):
+    """The reference's default hash matrix for 2^lsize positions and key_len-bit keys (host only)."""
+    cols = np.zeros(key_len, dtype=np.uint64)
+    _check(load().jfgpu_reference_matrix(lsize, key_len, cols.ctypes.data))
+    return cols
 
 
 def device_count():

@@ -11,10 +11,13 @@
 //     low r key bits can be recovered from (pos, high key bits) -- the
 //     reference's "pseudo inverse" (rectangular_binary_matrix.cc:160-210,
 //     large_hash_array.hpp:992-1001).
-// Construction differs from the reference on purpose: it draws from unseeded
-// glibc random(); we use a seeded splitmix64 so every shard / rank derives the
-// same matrix from a seed.  Any such matrix is legal for the file format
-// (readers take it from the header, file_header.hpp:35-47).
+// Two constructions.  Default: the reference's own -- it draws from glibc random(), which it never
+// seeds, so for a given (lsize, 2k) the first matrix of a process is always the same one; GlibcRandom
+// below restates that generator and gf2_reference_matrix the reference's randomize + pseudo-inverse, so
+// default tables lay out, and their files read, exactly like the reference's (same (pos, key) order,
+// byte-identical file bodies).  With an explicit seed: splitmix64, for callers that want their own
+// family of matrices.  Any matrix with an invertible low block is legal for the file format (readers
+// take it from the header, file_header.hpp:35-47).
 #pragma once
 #include <stdint.h>
 #include <vector>
@@ -78,6 +81,75 @@ inline Gf2Matrix gf2_identity(uint32_t r, uint32_t c) {
   m.columns[col] = 1ull << (row - 1);
   for(uint32_t i = col + 1; i < c; ++i) m.columns[i] = m.columns[i - 1] >> 1;
   return m;
+}
+
+// glibc random() as documented (TYPE_3 additive feedback generator: x_k = x_{k-3} + x_{k-31} mod 2^32,
+// result x_k >> 1; the state is seeded from a Lehmer sequence and the first 310 values are discarded;
+// seed 1 when srandom() is never called, which is the reference's case).
+struct GlibcRandom {
+  uint32_t x[34];
+  uint32_t k = 0;                        // number of values produced so far, x[] is a ring of the last 34
+  explicit GlibcRandom(uint32_t seed = 1) {
+    int32_t v[34];
+    v[0] = (int32_t)(seed ? seed : 1);
+    for(int i = 1; i < 31; ++i) {
+      const int64_t hi = v[i - 1] / 127773, lo = v[i - 1] % 127773;
+      int64_t w = 16807 * lo - 2836 * hi;
+      if(w < 0) w += 2147483647;
+      v[i] = (int32_t)w;
+    }
+    for(int i = 31; i < 34; ++i) v[i] = v[i - 31];
+    for(int i = 0; i < 34; ++i) x[i] = (uint32_t)v[i];
+    k = 34;
+    for(int i = 0; i < 310; ++i) step();
+  }
+  uint32_t step() {
+    const uint32_t v = x[(k - 31) % 34] + x[(k - 3) % 34];
+    x[k % 34] = v; ++k;
+    return v;
+  }
+  uint32_t next() { return step() >> 1; }
+  // random_bits(64), lib/misc.cc:66-72: three 31-bit draws XORed in at bit 0, 30 and 60
+  uint64_t bits64() {
+    uint64_t res = next();
+    res ^= (uint64_t)next() << 30;
+    res ^= (uint64_t)next() << 60;
+    return res;
+  }
+};
+
+// RectangularBinaryMatrix(r, c).randomize_pseudo_inverse() (lib/rectangular_binary_matrix.cc:160-247): draw
+// c random columns, eliminate on the block of the last min(r, c) columns while applying the same column
+// operations to a low-identity matrix; the transformed identity is the hash matrix.  A singular draw is
+// thrown away and the next c columns are drawn, exactly as the reference's retry loop consumes them.
+inline Gf2Matrix gf2_reference_matrix(uint32_t r, uint32_t c, GlibcRandom& rng) {
+  Gf2Matrix m; m.r = r; m.c = c; m.columns.assign(c, 0);
+  const uint64_t cmask = r >= 64 ? ~0ull : ((1ull << r) - 1);
+  const uint32_t srow = r < c ? r : c, scol = c - srow;
+  std::vector<uint64_t> pivot(c), res(c);
+  while(true) {
+    for(uint32_t i = 0; i < c; ++i) pivot[i] = rng.bits64() & cmask;
+    for(uint32_t i = 0; i < c; ++i) res[i] = i >= scol ? (1ull << (c - 1 - i)) : 0ull;
+    bool singular = false;
+    uint64_t mask = 1ull << (srow - 1);
+    for(uint32_t i = scol; i < c && !singular; ++i, mask >>= 1) {       // lower triangular
+      if(!(pivot[i] & mask)) {
+        uint32_t j = i + 1;
+        while(j < c && !(pivot[j] & mask)) ++j;
+        if(j == c) { singular = true; break; }
+        pivot[i] ^= pivot[j]; res[i] ^= res[j];
+      }
+      for(uint32_t j = i + 1; j < c; ++j)
+        if(pivot[j] & mask) { pivot[j] ^= pivot[i]; res[j] ^= res[i]; }
+    }
+    if(singular) continue;
+    mask = 1ull << (srow - 1);
+    for(uint32_t i = scol; i < c; ++i, mask >>= 1)                        // lower identity
+      for(uint32_t j = 0; j < i; ++j)
+        if(pivot[j] & mask) { pivot[j] ^= pivot[i]; res[j] ^= res[i]; }
+    m.columns = res;
+    return m;
+  }
 }
 
 inline Gf2Matrix gf2_random(uint32_t r, uint32_t c, uint64_t seed) {

@@ -93,6 +93,8 @@ struct jfgpu_table {
   bool pristine = true;          // table known all-zero: tile_insert may skip the tile read
   std::vector<PendingBatch> pending;
   uint64_t pending_bytes = 0;
+  bool ref_matrix = false;       // default matrix family: the reference's (glibc random() stream kept in `glibc`)
+  GlibcRandom glibc;
   int operation = 0;             // what count_ascii does with a k-mer: 0 add, 1 set (prime), 2 update_add (jfgpu_set_operation)
   int flush_groups = 1;          // P2 / tile-insert pipeline depth of a flush (JFGPU_FLUSH_GROUPS).  Measured: 8 groups on two
                                  // streams run P2 and T concurrently but no faster (both are LDS-bound), so one launch each is the default
@@ -615,14 +617,23 @@ int table_grow(jfgpu_table* t) {
   rc = check_deferred(t, ctr); if(rc) return rc;
   const uint32_t r = t->g.lsize_g, c = t->g.key_bits;
   if(r >= c) return -1;
-  // extend the matrix by a random top row until the (r+1) x (r+1) low block is invertible again
   Gf2Matrix m2 = t->matrix; m2.r = r + 1; m2.identity = false;
   std::vector<uint64_t> fwd, inv;
-  uint64_t st = (t->params.matrix_seed ? t->params.matrix_seed : kDefaultSeed) ^ (0xD6E8FEB86659FD93ull * (r + 1)) ^ t->grow_seed;
-  for(int tries = 0; ; ++tries) {
-    for(uint32_t j = 0; j < c; ++j) m2.columns[j] = (t->matrix.columns[j] & ((1ull << r) - 1)) | ((splitmix64(st) & 1ull) << r);
-    if(gf2_build_tables(m2, fwd, inv)) break;
-    if(tries > 1000) return fail(JFGPU_E_INVALID, "could not extend the hash matrix");
+  if(t->ref_matrix) {
+    // like the reference: a brand-new matrix for the doubled table, next in the same random() stream
+    for(int tries = 0; ; ++tries) {
+      m2 = r + 1 >= c ? gf2_identity(r + 1, c) : gf2_reference_matrix(r + 1, c, t->glibc);
+      if(gf2_build_tables(m2, fwd, inv)) break;
+      if(tries > 1000) return fail(JFGPU_E_INVALID, "could not draw a hash matrix");
+    }
+  } else {
+    // seeded family: extend the matrix by a random top row until the (r+1) x (r+1) low block is invertible again
+    uint64_t st = (t->params.matrix_seed ? t->params.matrix_seed : kDefaultSeed) ^ (0xD6E8FEB86659FD93ull * (r + 1)) ^ t->grow_seed;
+    for(int tries = 0; ; ++tries) {
+      for(uint32_t j = 0; j < c; ++j) m2.columns[j] = (t->matrix.columns[j] & ((1ull << r) - 1)) | ((splitmix64(st) & 1ull) << r);
+      if(gf2_build_tables(m2, fwd, inv)) break;
+      if(tries > 1000) return fail(JFGPU_E_INVALID, "could not extend the hash matrix");
+    }
   }
   TableGeom g2;
   if(!geom_init(g2, t->g.k, r + 1, 0, 0, t->g.canonical)) return -1;
@@ -734,12 +745,19 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     t->matrix.r = lsize; t->matrix.c = 2 * p->k;
     t->matrix.columns.assign(p->matrix_columns, p->matrix_columns + 2 * p->k);
     t->matrix.identity = gf2_is_low_identity(t->matrix);
+  } else if(p->matrix_seed) {
+    t->matrix = gf2_random(lsize, 2 * p->k, p->matrix_seed);
   } else {
-    t->matrix = gf2_random(lsize, 2 * p->k, p->matrix_seed ? p->matrix_seed : kDefaultSeed);
+    // the reference's default: first matrix of an unseeded glibc random() stream; the stream stays with the
+    // table so that doublings draw their matrices like hash_counter::double_size does (hash_counter.hpp:210-214)
+    t->ref_matrix = true;
+    t->matrix = lsize >= 2 * p->k ? gf2_identity(lsize, 2 * p->k) : gf2_reference_matrix(lsize, 2 * p->k, t->glibc);
   }
   std::vector<uint64_t> fwd, inv;
-  if(!gf2_build_tables(t->matrix, fwd, inv))
-    return fail(JFGPU_E_INVALID, "hash matrix: low r x r block is singular");
+  while(!gf2_build_tables(t->matrix, fwd, inv)) {
+    if(!t->ref_matrix || t->matrix.identity) return fail(JFGPU_E_INVALID, "hash matrix: low r x r block is singular");
+    t->matrix = gf2_reference_matrix(lsize, 2 * p->k, t->glibc);        // cannot happen for a pseudo-inverse; belt and braces
+  }
 
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, dev));
@@ -1206,6 +1224,14 @@ int jfgpu_reserve(jfgpu_table* t, uint64_t input_bytes) {
   return JFGPU_OK;
 }
 
+int jfgpu_reference_matrix(uint32_t lsize, uint32_t key_len, uint64_t* columns) {
+  if(!columns || lsize < 1 || lsize > 64 || key_len < 2 || key_len > 128) return fail(JFGPU_E_INVALID, "bad matrix dimensions");
+  GlibcRandom rng;
+  const Gf2Matrix m = lsize >= key_len ? gf2_identity(lsize, key_len) : gf2_reference_matrix(lsize, key_len, rng);
+  for(uint32_t i = 0; i < key_len; ++i) columns[i] = m.columns[i];
+  return JFGPU_OK;
+}
+
 int jfgpu_set_operation(jfgpu_table* t, int op) {
   int rc = use(t); if(rc) return rc;
   if(op < 0 || op > 2) return fail(JFGPU_E_INVALID, "operation must be 0 (count), 1 (prime) or 2 (update)");
@@ -1370,9 +1396,16 @@ int jfgpu_bc_create(const jfgpu_bloom_params* p, jfgpu_bloom** out) {
     b->m1.r = b->m2.r = 64; b->m1.c = b->m2.c = 2 * p->k;
     b->m1.columns.assign(p->matrix1, p->matrix1 + 2 * p->k);
     b->m2.columns.assign(p->matrix2, p->matrix2 + 2 * p->k);
-  } else {
+  } else if(p->seed) {
     b->m1 = random_full_matrix(2 * p->k, st);
     b->m2 = random_full_matrix(2 * p->k, st);
+  } else {
+    // the reference's default pair (mer_dna_bloom_counter.hpp:21-26): m1 then m2, 64 x 2k, straight from random_bits()
+    GlibcRandom rng;
+    for(Gf2Matrix* m : {&b->m1, &b->m2}) {
+      m->r = 64; m->c = 2 * p->k; m->columns.assign(2 * p->k, 0);
+      for(uint32_t i = 0; i < 2 * p->k; ++i) m->columns[i] = rng.bits64();
+    }
   }
   std::vector<uint64_t> t1, t2;
   plain_tables(b->m1, t1); plain_tables(b->m2, t2);

@@ -153,3 +153,23 @@ int main(int argc, char** argv) {
     if O.have_ref():   # and the REFERENCE's header parser accepts it
         out = subprocess.check_output([O.REF_JF, "header", str(f)]).decode()
         assert '"key_len" : 42' in out
+
+
+def _header_of(path):
+    d = open(path, "rb").read()
+    n = int(d[:9])
+    return json.loads(d[9:9 + n].decode().rstrip("\0 \n")), 9 + n
+
+
+def test_default_matrix_is_the_reference_matrix():
+    """The engine's default hash matrix = the first matrix the reference draws in a fresh process (unseeded glibc
+    random() + randomize_pseudo_inverse): pinned to the headers of files the reference itself wrote."""
+    from jellyfish_amd import capi
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for name in ("reads150_k21C.ref.jf", "edge_k8C.ref.jf"):
+        hdr, _ = _header_of(os.path.join(gold, name))
+        m = hdr["matrix1"]
+        assert not m.get("identity")
+        assert capi.reference_matrix(m["r"], m["c"]).tolist() == m["columns"], name
+    # identity when the table covers the key space (large_hash_array.hpp:997-1000): column c-1-j is bit j
+    assert capi.reference_matrix(12, 10).tolist() == [1 << (9 - i) for i in range(10)]
