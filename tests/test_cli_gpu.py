@@ -239,3 +239,35 @@ def test_bc_file_is_byte_identical_to_the_reference(cli, tmp_path, case):
     cmd = [cli, "bc", "-m", str(case["k"]), "-s", str(case["n"]), "-f", str(case["fpr"]), "-o", out] + (["-C"] if case["canonical"] else [])
     subprocess.check_call(cmd + [os.path.join(GOLD, case["input"])])
     assert _body(out) == _body(os.path.join(GOLD, case["ref_bc"]))
+
+
+def test_cli_reproduces_the_reference_golden_md5s(cli, tmp_path):
+    """The reference's own integration goldens (tests/parallel_hashing.sh:7-19) on its own seeded inputs
+    (tests/generate_sequence.sh:6-7, generated here by the reference's generator built in oracle/_ref),
+    computed by jellyfish-amd: histo / stats / sorted dump md5s, incl. table doubling from -s 2M, k = 40
+    (two-word keys) and -L/-U."""
+    import hashlib
+    if not os.access(O.REF_GEN, os.X_OK):
+        pytest.skip("oracle/_ref not built")
+    g = MANIFEST["reference_md5"]
+    d = str(tmp_path)
+    subprocess.check_call([O.REF_GEN, "-o", "seq10m"] + g["seq10m"], cwd=d)
+    subprocess.check_call([O.REF_GEN, "-o", "seq1m"] + g["seq1m"], cwd=d)
+
+    def md5(cmd, post=None):
+        out = subprocess.check_output(cmd, cwd=d)
+        if post:
+            out = post(out)
+        return hashlib.md5(out).hexdigest()
+    subprocess.check_call([cli, "count", "-t", "4", "-o", "m15.jf", "-s", "2M", "-C", "-m", "15", "seq10m.fa"], cwd=d)
+    assert md5([cli, "histo", "m15.jf"]) == g["m15_s2M.histo"]
+    assert md5([cli, "stats", "m15.jf"]) == g["m15.stats"]
+    subprocess.check_call([cli, "count", "-t", "4", "-o", "m15b.jf", "-s", "16M", "-C", "-m", "15", "seq10m.fa"], cwd=d)
+    assert md5([cli, "histo", "m15b.jf"]) == g["m15_s2M.histo"]                      # ..._m15_s16M.histo: same md5
+    for flag, tag in (([], "bin"), (["--text"], "txt")):
+        subprocess.check_call([cli, "count", "-m", "40", "-t", "4", "-o", tag + ".jf", "-s", "2M"] + flag + ["seq1m_0.fa"], cwd=d)
+        assert md5([cli, "dump", "-c", tag + ".jf"], lambda o: b"".join(sorted(o.splitlines(True)))) == g["binary.dump"]
+        assert md5([cli, "histo", tag + ".jf"]) == g["binary.histo"]
+        assert md5([cli, "stats", tag + ".jf"]) == g["binary.stats"]
+    subprocess.check_call([cli, "count", "-t", "4", "-o", "lu.jf", "-s", "2M", "-C", "-m", "15", "-L", "2", "-U", "3", "seq10m.fa"], cwd=d)
+    assert md5([cli, "histo", "lu.jf"]) == g["m15_s2M_L2_U3.histo"]
