@@ -220,7 +220,8 @@ int count_main(int argc, char* argv[]) {
       sequence_parser parser(mer_len);
       std::string cmd, data;
       while(std::getline(gf, cmd)) {
-        if(cmd.find_first_not_of(" \t\r") == std::string::npos) continue;
+        const size_t first = cmd.find_first_not_of(" \t\n\v\f\r");       // blank lines and # comments are skipped
+        if(first == std::string::npos || cmd[first] == '#') continue;         // (lib/generator_manager.cc:223-226)
         int fds[2];
         if(pipe(fds) != 0) die("pipe() failed");
         const pid_t pid = fork();

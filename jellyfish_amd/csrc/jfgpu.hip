@@ -196,11 +196,10 @@ int launch_count_chunk(jfgpu_table* t, const char* d_bases, size_t n) {
   const uint8_t* base; int64_t lo, hi;
   align_buffer(d_bases, n, base, lo, hi);
   if(t->wide) {
-    if(t->operation != 0) return fail(JFGPU_E_UNSUPPORTED, "--if (prime / update passes) with mer length > 32 is not built yet");
     const int64_t nt = (hi + kTilePos - 1) / kTilePos;
     ProfScope ps(t, 0, n);
-    if(t->returning) hipLaunchKernelGGL(count_ascii_wide_kernel<true>, dim3(grid_for(t, (uint64_t)nt)), dim3(kBlock), 0, t->stream, t->wt, base, lo, hi);
-    else             hipLaunchKernelGGL(count_ascii_wide_kernel<false>, dim3(grid_for(t, (uint64_t)nt)), dim3(kBlock), 0, t->stream, t->wt, base, lo, hi);
+    if(t->returning) hipLaunchKernelGGL(count_ascii_wide_kernel<true>, dim3(grid_for(t, (uint64_t)nt)), dim3(kBlock), 0, t->stream, t->wt, base, lo, hi, t->operation);
+    else             hipLaunchKernelGGL(count_ascii_wide_kernel<false>, dim3(grid_for(t, (uint64_t)nt)), dim3(kBlock), 0, t->stream, t->wt, base, lo, hi, t->operation);
     HIP_TRY(hipGetLastError());
     return JFGPU_OK;
   }

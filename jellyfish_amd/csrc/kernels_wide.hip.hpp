@@ -146,6 +146,33 @@ __device__ inline bool wide_add(const WideTable& T, const uint64_t* fwd_lds, u12
   return false;
 }
 
+// update_add on a 128-bit slot: increment only if the key is there (the UPDATE pass of `count --if`).
+template <bool RETURNING>
+__device__ inline bool wide_update_add(const WideTable& T, const uint64_t* fwd_lds, u128 key, uint64_t cnt) {
+  const TableGeom& g = T.W.g;
+  const uint64_t pos = hash_tables_wide(fwd_lds, key, g.nbytes);
+  const SlotAddr a = slot_addr(g, pos);
+  const WideSlot w = wide_words(T.W, key, a.idx0);
+  const uint64_t add = cnt << (g.tag_bits + 1);
+  const uint32_t tmask = (uint32_t)g.tile_mask;
+  for(uint32_t p = 0; p <= T.max_probe; ++p) {
+    const uint64_t slot = a.tile_base + probe_slot(a.idx0, p, tmask);
+    const uint64_t hi = __hip_atomic_load(&T.slots[2 * slot + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if(hi == 0) return false;
+    if((hi & g.low_mask) != w.hi_low) continue;
+    if(__hip_atomic_load(&T.slots[2 * slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != w.lo) continue;
+    unsigned long long* hp = (unsigned long long*)&T.slots[2 * slot + 1];
+    if(RETURNING) {
+      const unsigned long long prev = atomicAdd(hp, (unsigned long long)add);
+      if((prev >> (g.tag_bits + 1)) + cnt > g.cnt_max) { const DevTable d = ovf_view(T); ovf_add(d, slot, 1); }
+    } else {
+      __hip_atomic_fetch_add(hp, (unsigned long long)add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return true;
+  }
+  return false;
+}
+
 // hash_counter::add(key, val) with an arbitrary 64-bit val: low part in the slot, the rest in the side table
 __device__ inline bool wide_add_val(const WideTable& T, const uint64_t* fwd_lds, u128 key, uint64_t val) {
   const TableGeom& g = T.W.g;
@@ -206,7 +233,7 @@ __device__ inline void for_each_kmer_wide(const WideGeom& W, const LaneWordsW& L
 }
 
 template <bool RETURNING>
-__global__ __launch_bounds__(kBlock) void count_ascii_wide_kernel(WideTable T, const uint8_t* __restrict__ base, int64_t lo, int64_t hi) {
+__global__ __launch_bounds__(kBlock) void count_ascii_wide_kernel(WideTable T, const uint8_t* __restrict__ base, int64_t lo, int64_t hi, int op) {
   __shared__ uint64_t s_fwd[16 * 256];
   __shared__ uint32_t s_codes[kBlock + 4];
   __shared__ uint32_t s_inv[kBlock + 4];
@@ -220,13 +247,18 @@ __global__ __launch_bounds__(kBlock) void count_ascii_wide_kernel(WideTable T, c
     if(s_abort) break;
     const LaneWordsW L = stage_tile_wide(base, tile * kTilePos, lo, hi, s_codes, s_inv);
     u128 prev = 0; uint32_t run = 0;
+    auto apply = [&](u128 key, uint32_t n) {               // op: 0 add, 1 set (prime), 2 update_add (count_main.cc:152-184)
+      if(op == 0) wide_add<RETURNING>(T, s_fwd, key, n);
+      else if(op == 1) wide_add<RETURNING>(T, s_fwd, key, 0);
+      else wide_update_add<RETURNING>(T, s_fwd, key, n);
+    };
     for_each_kmer_wide(T.W, L, [&](int, u128 key) {
       ++my_mers;
       if(run && key == prev) { ++run; return; }
-      if(run) wide_add<RETURNING>(T, s_fwd, prev, run);
+      if(run) apply(prev, run);
       prev = key; run = 1;
     });
-    if(run) wide_add<RETURNING>(T, s_fwd, prev, run);
+    if(run) apply(prev, run);
   }
   uint64_t w = my_mers;
   for(int o = 32; o > 0; o >>= 1) w += __shfl_down(w, o, 64);

@@ -271,3 +271,55 @@ def test_cli_reproduces_the_reference_golden_md5s(cli, tmp_path):
         assert md5([cli, "stats", tag + ".jf"]) == g["binary.stats"]
     subprocess.check_call([cli, "count", "-t", "4", "-o", "lu.jf", "-s", "2M", "-C", "-m", "15", "-L", "2", "-U", "3", "seq10m.fa"], cwd=d)
     assert md5([cli, "histo", "lu.jf"]) == g["m15_s2M_L2_U3.histo"]
+
+
+def test_cli_reproduces_more_reference_goldens(cli, tmp_path):
+    """Further md5 goldens of the reference's active integration tests, computed by jellyfish-amd:
+    tests/multi_file.sh:7-27 (six files; gunzip generators with comments), tests/subset_hashing.sh:7-19
+    (`--if`, k = 35 two-word keys and k = 10), tests/merge.sh:7-20 first block (k = 40 -C over five files),
+    tests/small_mers.sh (k = 2..10: the histogram does not depend on the size hint).
+    Two-word tables do not double yet, so those runs get a size hint that fits (the goldens are histograms and do
+    not depend on it)."""
+    import gzip
+    import hashlib
+    if not os.access(O.REF_GEN, os.X_OK):
+        pytest.skip("oracle/_ref not built")
+    g = MANIFEST["reference_md5"]
+    d = str(tmp_path)
+    subprocess.check_call([O.REF_GEN, "-o", "seq10m"] + g["seq10m"], cwd=d)
+    subprocess.check_call([O.REF_GEN, "-o", "seq1m"] + g["seq1m"], cwd=d)
+
+    def histo_md5(jf):
+        return hashlib.md5(subprocess.check_output([cli, "histo", jf], cwd=d)).hexdigest()
+    seq1m = ["seq1m_%d.fa" % i for i in range(5)]
+    # multi_file.sh
+    subprocess.check_call([cli, "count", "-t", "4", "-F", "4", "-o", "mf.jf", "-s", "2M", "-C", "-m", "15",
+                           "seq1m_0.fa", "seq1m_1.fa", "seq1m_2.fa", "seq10m.fa", "seq1m_3.fa", "seq1m_4.fa"], cwd=d)
+    assert histo_md5("mf.jf") == "d93b7678037814c256d1d9120a0e6422"
+    with open(os.path.join(d, "gunzip_cmds"), "w") as f:
+        f.write("  \n  # Empty lines and comments just for fun\n")
+        for name in seq1m:
+            with open(os.path.join(d, name), "rb") as src, gzip.open(os.path.join(d, name + ".gz"), "wb") as dst:
+                dst.write(src.read())
+            f.write("gunzip -c ./%s.gz\n" % name)
+    subprocess.check_call([cli, "count", "-t", "4", "-g", "gunzip_cmds", "-G", "2", "-C", "-m", "15", "-s", "2M", "-o", "mfz.jf", "seq10m.fa"], cwd=d)
+    assert histo_md5("mfz.jf") == "d93b7678037814c256d1d9120a0e6422"
+    with open(os.path.join(d, "fail_cmds"), "w") as f:
+        f.write("false\n")
+    assert subprocess.run([cli, "count", "-g", "fail_cmds", "-C", "-m", "15", "-s", "2M", "-o", "fail.jf"], cwd=d, capture_output=True).returncode != 0
+    assert subprocess.run([cli, "count", "-C", "-m", "15", "-s", "2M", "-o", "fail.jf", "non_existent_sequence.fa"], cwd=d, capture_output=True).returncode != 0
+    # subset_hashing.sh
+    files = ["--if", "seq1m_0.fa", "--if", "seq1m_2.fa", "seq1m_1.fa", "seq1m_0.fa", "seq1m_3.fa", "seq1m_2.fa"]
+    subprocess.check_call([cli, "count", "-t", "4", "-o", "if35.jf", "-s", "8M", "-C", "-m", "35"] + files, cwd=d)
+    assert histo_md5("if35.jf") == "bd7a5f6ba000b282cd79cb9f342e7ede"
+    subprocess.check_call([cli, "count", "-t", "4", "-o", "if10.jf", "-s", "6M", "-C", "-m", "10"] + files, cwd=d)
+    assert histo_md5("if10.jf") == "8eb6d4a50aeba178e4847c2da71dbb70"
+    # merge.sh, first block
+    subprocess.check_call([cli, "count", "-t", "4", "-o", "m40.jf", "-s", "8M", "-C", "-m", "40",
+                           "seq1m_0.fa", "seq1m_1.fa", "seq1m_0.fa", "seq1m_2.fa", "seq1m_2.fa"], cwd=d)
+    assert histo_md5("m40.jf") == "72f1913b3503114c7df7a4dcc68ce867"
+    # small_mers.sh
+    for k in range(2, 11):
+        subprocess.check_call([cli, "count", "-t", "4", "-o", "a.jf", "-s", "10M", "-c", "25", "-m", str(k), "-C", "seq10m.fa"], cwd=d)
+        subprocess.check_call([cli, "count", "-t", "4", "-o", "b.jf", "-s", "1k", "-c", "5", "-m", str(k), "-C", "seq10m.fa"], cwd=d)
+        assert subprocess.check_output([cli, "histo", "a.jf"], cwd=d) == subprocess.check_output([cli, "histo", "b.jf"], cwd=d)
