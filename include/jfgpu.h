@@ -198,8 +198,8 @@ int  jfgpu_attach_bloom(jfgpu_table* t, jfgpu_bloom* b);
 /* hash_counter::do_size_doubling(bool) (hash_counter.hpp:78-79).  On (default): the size given at
  * creation is a hint, the table doubles itself (device-side rehash, one more matrix row) before it
  * could exceed 80 % load, as long as device memory allows; jfgpu_get_info / jfgpu_get_matrix report
- * the current geometry.  Off: a full table is the deferred error "Hash full".  One-word keys,
- * unsharded tables only for now. */
+ * the current geometry.  Off: a full table is the deferred error "Hash full".  Unsharded tables
+ * only for now (one- and two-word keys). */
 int  jfgpu_set_growth(jfgpu_table* t, int on);
 
 /* The matrix a table gets when jfgpu_params gives neither matrix_columns nor matrix_seed: the one the

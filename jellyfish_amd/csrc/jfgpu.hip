@@ -223,7 +223,7 @@ int launch_count_chunk(jfgpu_table* t, const char* d_bases, size_t n) {
 // How many more k-mers may be enqueued before the table could exceed 80 % load, assuming every one
 // of them is new (an upper bound: duplicates are only discovered by inserting).
 uint64_t capacity_limit(const jfgpu_table* t) { return ((1ull << t->g.lsize_l) / 10) * 8; }
-bool capacity_managed(const jfgpu_table* t) { return t->grow_on && !t->wide && t->g.shard_bits == 0 && t->g.lsize_g < t->g.key_bits; }
+bool capacity_managed(const jfgpu_table* t) { return t->grow_on && t->g.shard_bits == 0 && t->g.lsize_g < t->g.key_bits && (!t->wide || t->g.lsize_g < 48); }
 
 // The size passed at creation is a hint (doc/Readme.md:67-72; hash_counter::handle_full_ary,
 // hash_counter.hpp:178-198): before enqueuing `incoming` potential new keys make sure they cannot
@@ -597,8 +597,9 @@ int measure_occupancy(jfgpu_table* t) {
   unsigned long long* d = nullptr;
   HIP_TRY(hipMalloc((void**)&d, 4 * sizeof(unsigned long long)));
   HIP_TRY(hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), t->stream));
-  hipLaunchKernelGGL(stats_kernel, dim3(grid_for(t, (1ull << t->g.lsize_l) / kBlock + 1)), dim3(kBlock), 0, t->stream, t->dt,
-                     0ull, ~0ull, 0, d);
+  const int grid = grid_for(t, (1ull << t->g.lsize_l) / kBlock + 1);
+  if(t->wide) hipLaunchKernelGGL(scan_wide_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->wt, 0, 0ull, ~0ull, 0, 0ull, 0ull, 1ull, 1ull, d, (uint32_t*)nullptr);
+  else hipLaunchKernelGGL(stats_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, 0ull, ~0ull, 0, d);
   unsigned long long h[4];
   hipError_t e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, t->stream);
   if(e == hipSuccess) e = hipStreamSynchronize(t->stream);
@@ -635,8 +636,11 @@ int table_grow(jfgpu_table* t) {
     }
   }
   TableGeom g2;
-  if(!geom_init(g2, t->g.k, r + 1, 0, 0, t->g.canonical)) return -1;
+  WideGeom w2;
+  if(t->wide) { if(!wide_geom_init(w2, t->g.k, r + 1, t->g.canonical)) return -1; g2 = w2.g; }
+  else if(!geom_init(g2, t->g.k, r + 1, 0, 0, t->g.canonical)) return -1;
   const uint64_t n2 = 1ull << g2.lsize_l;
+  const size_t slot_bytes = 8 * (size_t)t->key_words;
   uint64_t cap2 = std::max<uint64_t>(1ull << 12, std::min<uint64_t>(n2 / 256, 1ull << 26));
   { uint64_t x = 1; while(x < cap2) x <<= 1; cap2 = x; }
   DevTable nd = t->dt;
@@ -644,8 +648,8 @@ int table_grow(jfgpu_table* t) {
   uint64_t *nf = nullptr, *ni = nullptr;
   size_t free_b = 0, total_b = 0;
   HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-  if(n2 * 8 + cap2 * 16 + ((size_t)1 << 30) > free_b) return -1;
-  bool ok = hipMalloc((void**)&nd.slots, n2 * 8) == hipSuccess && hipMalloc((void**)&nd.ovf_key, cap2 * 8) == hipSuccess &&
+  if(n2 * slot_bytes + cap2 * 16 + ((size_t)1 << 30) > free_b) return -1;
+  bool ok = hipMalloc((void**)&nd.slots, n2 * slot_bytes) == hipSuccess && hipMalloc((void**)&nd.ovf_key, cap2 * 8) == hipSuccess &&
             hipMalloc((void**)&nd.ovf_cnt, cap2 * 8) == hipSuccess && hipMalloc((void**)&nd.dirty, (size_t)1 << (g2.lsize_l - g2.tile_bits)) == hipSuccess &&
             hipMalloc((void**)&nf, fwd.size() * 8) == hipSuccess && hipMalloc((void**)&ni, inv.size() * 8) == hipSuccess;
   if(!ok) {
@@ -655,12 +659,19 @@ int table_grow(jfgpu_table* t) {
   }
   nd.fwd_tbl = nf; nd.inv_tbl = ni; nd.ovf_mask = cap2 - 1;
   nd.max_probe = (uint32_t)std::min<uint64_t>(g2.tile_mask, 1023);
-  HIP_TRY(hipMemsetAsync(nd.slots, 0, n2 * 8, t->stream));
+  HIP_TRY(hipMemsetAsync(nd.slots, 0, n2 * slot_bytes, t->stream));
   HIP_TRY(hipMemsetAsync(nd.ovf_key, 0, cap2 * 8, t->stream));
   HIP_TRY(hipMemsetAsync(nd.ovf_cnt, 0, cap2 * 8, t->stream));
   HIP_TRY(hipMemsetAsync(nd.dirty, 0, (size_t)1 << (g2.lsize_l - g2.tile_bits), t->stream));
   HIP_TRY(hipMemcpyAsync(nf, fwd.data(), fwd.size() * 8, hipMemcpyHostToDevice, t->stream));
   HIP_TRY(hipMemcpyAsync(ni, inv.data(), inv.size() * 8, hipMemcpyHostToDevice, t->stream));
+  WideTable nw = t->wt;
+  if(t->wide) {
+    nw.W = w2; nw.slots = nd.slots; nw.fwd_tbl = nf; nw.inv_tbl = ni; nw.ovf_key = nd.ovf_key; nw.ovf_cnt = nd.ovf_cnt;
+    nw.ovf_mask = nd.ovf_mask; nw.counters = nd.counters; nw.max_probe = nd.max_probe;
+    hipLaunchKernelGGL(rehash_wide_kernel, dim3(grid_for(t, (1ull << t->g.lsize_l) / kBlock + 1)), dim3(kBlock), 0, t->stream, t->wt, nw,
+                       (int)(ctr[CTR_OVF_USED] != 0));
+  } else
   hipLaunchKernelGGL(rehash_kernel, dim3(grid_for(t, (1ull << t->g.lsize_l) / kBlock + 1)), dim3(kBlock), 0, t->stream, t->dt, nd,
                      (int)(ctr[CTR_OVF_USED] != 0));
   HIP_TRY(hipGetLastError());
@@ -670,6 +681,14 @@ int table_grow(jfgpu_table* t) {
   t->dt = nd; t->g = g2; t->matrix = m2; t->d_fwd = nf; t->d_inv = ni; t->ovf_cap = cap2;
   t->returning = t->g.cnt_bits < 40;
   if(t->d_M2) { hipFree(t->d_M2); t->d_M2 = nullptr; }
+  if(t->wide) {
+    t->wt = nw;
+    const int wl = (int)(((size_t)16 << t->g.tile_bits) + ((size_t)2 << t->g.tile_bits));
+    HIP_TRY(hipFuncSetAttribute((const void*)dump_tiles_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
+    t->pristine = false;
+    ++t->grow_seed;
+    return check_deferred(t);
+  }
   part_geom_init(t);
   if(t->mode == MODE_PARTITIONED && !t->part_ok) t->mode = MODE_AUTO;
   t->pristine = false;
@@ -939,19 +958,19 @@ int jfgpu_add_keys_dev(jfgpu_table* t, const uint64_t* d_keys, size_t n, uint64_
   int rc = use(t); if(rc) return rc;
   if(!n) return JFGPU_OK;
   if(!d_keys) return fail(JFGPU_E_INVALID, "null keys");
+  if(capacity_managed(t)) {
+    uint64_t take = 0;
+    rc = ensure_capacity(t, n, &take); if(rc) return rc;
+    if(take < n) {                       // feed the rest in further pieces (each re-checks the occupancy)
+      rc = jfgpu_add_keys_dev(t, d_keys + take * t->key_words, n - take, val, d_is_new ? d_is_new + take : nullptr); if(rc) return rc;
+      n = take;
+    }
+  }
   if(t->wide) {
     ProfScope ps(t, 1, n);
     hipLaunchKernelGGL(add_keys_wide_kernel, dim3(grid_for(t, (n + kBlock - 1) / kBlock)), dim3(kBlock), 0, t->stream, t->wt, d_keys, (uint64_t)n, val, d_is_new);
     HIP_TRY(hipGetLastError());
     return JFGPU_OK;
-  }
-  if(capacity_managed(t)) {
-    uint64_t take = 0;
-    rc = ensure_capacity(t, n, &take); if(rc) return rc;
-    if(take < n) {                       // feed the rest in further pieces (each re-checks the occupancy)
-      rc = jfgpu_add_keys_dev(t, d_keys + take, n - take, val, d_is_new ? d_is_new + take : nullptr); if(rc) return rc;
-      n = take;
-    }
   }
   if(val == 1 && !d_is_new && use_partitioned(t, n * 8)) {
     const int prc = part_ingest(t, (const uint8_t*)d_keys, 0, (int64_t)n, true, n);

@@ -308,6 +308,24 @@ __global__ __launch_bounds__(kBlock) void lookup_wide_kernel(WideTable T, const 
   }
 }
 
+// hash_counter::double_size for two-word keys: every occupied slot is decoded and re-inserted with its full
+// count into the doubled table (new matrix, one more row).  Hash tables are read through the caches.
+__global__ __launch_bounds__(kBlock) void rehash_wide_kernel(WideTable old, WideTable neu, int have_ovf) {
+  const TableGeom& g = old.W.g;
+  const DevTable od = ovf_view(old);
+  const uint64_t n = 1ull << g.lsize_l;
+  for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t hi = old.slots[2 * i + 1];
+    if(!hi) continue;
+    const uint64_t lo = old.slots[2 * i];
+    if(!lo) continue;                                    // hi claimed, never completed: holds no key
+    const u128 key = wide_slot_key(old, old.inv_tbl, lo, hi, i & ~g.tile_mask);
+    uint64_t c = slot_count(g, hi);
+    if(have_ovf) c += ovf_get(od, i) << g.cnt_bits;
+    wide_add_val(neu, neu.fwd_tbl, key, c);
+  }
+}
+
 // stats / histo / tile_count: only the hi word (count + occupancy) matters -> one strided scan.
 // what: 0 stats (out[0..3] = unique, distinct, total, max), 1 histo, 2 per-tile record counts
 __global__ __launch_bounds__(kBlock) void scan_wide_kernel(WideTable T, int what, uint64_t lower, uint64_t upper, int have_ovf,

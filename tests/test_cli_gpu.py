@@ -278,8 +278,7 @@ def test_cli_reproduces_more_reference_goldens(cli, tmp_path):
     tests/multi_file.sh:7-27 (six files; gunzip generators with comments), tests/subset_hashing.sh:7-19
     (`--if`, k = 35 two-word keys and k = 10), tests/merge.sh:7-20 first block (k = 40 -C over five files),
     tests/small_mers.sh (k = 2..10: the histogram does not depend on the size hint).
-    Two-word tables do not double yet, so those runs get a size hint that fits (the goldens are histograms and do
-    not depend on it)."""
+    Same command lines as the scripts, size hints included (two-word tables double like the others)."""
     import gzip
     import hashlib
     if not os.access(O.REF_GEN, os.X_OK):
@@ -310,12 +309,12 @@ def test_cli_reproduces_more_reference_goldens(cli, tmp_path):
     assert subprocess.run([cli, "count", "-C", "-m", "15", "-s", "2M", "-o", "fail.jf", "non_existent_sequence.fa"], cwd=d, capture_output=True).returncode != 0
     # subset_hashing.sh
     files = ["--if", "seq1m_0.fa", "--if", "seq1m_2.fa", "seq1m_1.fa", "seq1m_0.fa", "seq1m_3.fa", "seq1m_2.fa"]
-    subprocess.check_call([cli, "count", "-t", "4", "-o", "if35.jf", "-s", "8M", "-C", "-m", "35"] + files, cwd=d)
+    subprocess.check_call([cli, "count", "-t", "4", "-o", "if35.jf", "-s", "2M", "-C", "-m", "35"] + files, cwd=d)
     assert histo_md5("if35.jf") == "bd7a5f6ba000b282cd79cb9f342e7ede"
     subprocess.check_call([cli, "count", "-t", "4", "-o", "if10.jf", "-s", "6M", "-C", "-m", "10"] + files, cwd=d)
     assert histo_md5("if10.jf") == "8eb6d4a50aeba178e4847c2da71dbb70"
     # merge.sh, first block
-    subprocess.check_call([cli, "count", "-t", "4", "-o", "m40.jf", "-s", "8M", "-C", "-m", "40",
+    subprocess.check_call([cli, "count", "-t", "4", "-o", "m40.jf", "-s", "4M", "-C", "-m", "40",
                            "seq1m_0.fa", "seq1m_1.fa", "seq1m_0.fa", "seq1m_2.fa", "seq1m_2.fa"], cwd=d)
     assert histo_md5("m40.jf") == "72f1913b3503114c7df7a4dcc68ce867"
     # small_mers.sh

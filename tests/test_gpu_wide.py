@@ -101,6 +101,7 @@ def test_wide_hash_full_and_lower_upper(gpu):
     seq = rnd_seq(rng, 150000, "ACGT")
     with gpu.Table(k, 1 << 13) as t:                           # engine minimum 2^13 slots < 150k distinct
         if t.info.size < 150000:
+            t.set_growth(False)                                # --disk / do_size_doubling(false)
             t.count_ascii(seq)
             with pytest.raises(gpu.JfgpuError) as e:
                 t.sync()
@@ -113,3 +114,34 @@ def test_wide_hash_full_and_lower_upper(gpu):
         recs = t.dump_records(2, 3)
         kk, cc = gpu.decode_records(recs, 34, 4)
         assert {tuple(r): c for r, c in zip(kk.tolist(), cc.tolist())} == {a: b for a, b in exp.items() if 2 <= b <= 3}
+
+
+@pytest.mark.parametrize("k,canonical,n", [(40, True, 150000), (33, False, 120000), (48, True, 100000)])
+def test_wide_table_grows_like_the_reference(gpu, k, canonical, n):
+    """The size is a hint for two-word keys too (tests/large_key.sh: `-s 2k -m 100` must equal `-s 2M`): fed in
+    several calls with look-ups in between, the table doubles as often as needed, counts stay exact (large values
+    in the overflow side table included) and the dump is ordered under the final matrix."""
+    rng = random.Random(k + n)
+    seq = rnd_seq(rng, n, "ACGTN")
+    exp = oracle_map(seq, k, canonical)
+    with gpu.Table(k, 1 << 13, canonical=canonical) as t:
+        first = t.info.lsize
+        third = len(seq) // 3
+        t.count_ascii(seq[:third])
+        some = np.array(list(exp.keys())[:500], dtype=np.uint64)
+        t.lookup(some)
+        t.add_keys(some[:5], val=2 ** 50)
+        t.count_ascii(seq[third - (k - 1):2 * third])
+        t.count_ascii(seq[2 * third - (k - 1):])
+        t.sync()
+        assert (t.info.lsize > first or (1 << first) * 0.8 >= len(exp)) and (1 << t.info.lsize) >= len(exp)   # k = 64 starts at 2^31
+        got = table_map(gpu, t)
+        want = dict(exp)
+        for key in some[:5].tolist():
+            want[tuple(key)] += 2 ** 50
+        capped = {a: min(b, 2 ** 32 - 1) for a, b in want.items()}          # the dump saturates at 4 bytes
+        assert got == capped
+        vals, found = t.lookup(some)
+        assert found.all() and vals.tolist() == [want[tuple(x)] for x in some.tolist()]
+        st = t.stats()
+        assert (st.distinct, st.total) == (len(exp), sum(want.values()))
