@@ -77,6 +77,39 @@ double seconds_since(std::chrono::steady_clock::time_point t0) {
   return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
+// -g / -S: every line of the file is a shell command whose standard output is a fasta / fastq stream
+// (lib/generator_manager.cc runs them through named pipes; here each is read through a pipe in turn).  Blank
+// lines and # comments are skipped (:223-226); a command that fails is an error.
+static void feed_generators(const std::string& generator, std::string shell, unsigned mer_len, const sequence_parser::sink_type& sink) {
+  std::ifstream gf(generator);
+  if(!gf.good()) die("Can't open generator file '" + generator + "'");
+  if(shell.empty()) { const char* e = getenv("SHELL"); shell = e && *e ? e : "/bin/sh"; }
+  sequence_parser parser(mer_len);
+  std::string cmd, data;
+  while(std::getline(gf, cmd)) {
+    const size_t first = cmd.find_first_not_of(" \t\n\v\f\r");
+    if(first == std::string::npos || cmd[first] == '#') continue;
+    int fds[2];
+    if(pipe(fds) != 0) die("pipe() failed");
+    const pid_t pid = fork();
+    if(pid < 0) die("fork() failed");
+    if(pid == 0) {
+      close(fds[0]); dup2(fds[1], 1); close(fds[1]);
+      execl(shell.c_str(), shell.c_str(), "-c", cmd.c_str(), (char*)0);
+      _exit(127);
+    }
+    close(fds[1]);
+    data.clear();
+    char tmp[1 << 16]; ssize_t r;
+    while((r = read(fds[0], tmp, sizeof tmp)) > 0) data.append(tmp, (size_t)r);
+    close(fds[0]);
+    int status = 0;
+    waitpid(pid, &status, 0);
+    if(!WIFEXITED(status) || WEXITSTATUS(status) != 0) die("Generator command failed: " + cmd);
+    parser.parse_memory(data.data(), data.size(), sink);
+  }
+}
+
 // ---------------------------------------------------------------- count
 int count_main(int argc, char* argv[]) {
   auto start_time = std::chrono::steady_clock::now();
@@ -212,35 +245,7 @@ int count_main(int argc, char* argv[]) {
     }
     feed(files);
     if(!generator.empty()) {
-      // -g: every line of the file is a shell command whose standard output is a fasta / fastq stream
-      // (lib/generator_manager.cc runs them through named pipes; here each is read through a pipe in turn)
-      std::ifstream gf(generator);
-      if(!gf.good()) die("Can't open generator file '" + generator + "'");
-      if(shell.empty()) { const char* e = getenv("SHELL"); shell = e && *e ? e : "/bin/sh"; }
-      sequence_parser parser(mer_len);
-      std::string cmd, data;
-      while(std::getline(gf, cmd)) {
-        const size_t first = cmd.find_first_not_of(" \t\n\v\f\r");       // blank lines and # comments are skipped
-        if(first == std::string::npos || cmd[first] == '#') continue;         // (lib/generator_manager.cc:223-226)
-        int fds[2];
-        if(pipe(fds) != 0) die("pipe() failed");
-        const pid_t pid = fork();
-        if(pid < 0) die("fork() failed");
-        if(pid == 0) {
-          close(fds[0]); dup2(fds[1], 1); close(fds[1]);
-          execl(shell.c_str(), shell.c_str(), "-c", cmd.c_str(), (char*)0);
-          _exit(127);
-        }
-        close(fds[1]);
-        data.clear();
-        char tmp[1 << 16]; ssize_t r;
-        while((r = read(fds[0], tmp, sizeof tmp)) > 0) data.append(tmp, (size_t)r);
-        close(fds[0]);
-        int status = 0;
-        waitpid(pid, &status, 0);
-        if(!WIFEXITED(status) || WEXITSTATUS(status) != 0) die("Generator command failed: " + cmd);
-        parser.parse_memory(data.data(), data.size(), [&](const char* buf, size_t n) { ary->count_sequence(buf, n); });
-      }
+      feed_generators(generator, shell, mer_len, [&](const char* buf, size_t n) { ary->count_sequence(buf, n); });
       ary->done();
     }
   } catch(std::exception& e) { die(e.what()); }
@@ -279,7 +284,7 @@ int bc_main(int argc, char* argv[]) {
   header.set_cmdline(argc, argv);
   unsigned mer_len = 0; uint64_t size = 0; double fpr = 0.001; bool canonical = false, size_given = false, host_parse = false;
   int device = -1;
-  std::string output = "mer_bloom_filter", timing;
+  std::string output = "mer_bloom_filter", timing, generator, shell;
   std::vector<std::string> files;
   ArgCursor a{argc, argv};
   for(; a.more(); ++a.i) {
@@ -293,13 +298,16 @@ int bc_main(int argc, char* argv[]) {
     else if(a.is("", "--device")) device = atoi(a.value("", "--device").c_str());
     else if(a.cur() == "-C" || a.cur() == "--canonical") canonical = true;
     else if(a.cur() == "--host-parse") host_parse = true;
+    else if(a.is("-g", "--generator")) generator = a.value("-g", "--generator");
+    else if(a.is("-G", "--Generators")) (void)a.value("-G", "--Generators");
+    else if(a.is("-S", "--shell")) shell = a.value("-S", "--shell");
     else if(a.cur().size() > 1 && a.cur()[0] == '-') die("Unknown option '" + a.cur() + "'");
     else files.push_back(a.cur());
   }
   if(!mer_len) die("Error: mandatory switch missing: -m, --mer-len");
   if(!size_given) die("Error: mandatory switch missing: -s, --size");
-  if(files.empty()) die("Error: at least 1 file argument is required");
-  if(mer_len > 32) die("jellyfish-amd: mer length > 32 is not built yet");
+  if(files.empty() && generator.empty()) die("Error: at least 1 file argument is required");
+  if(mer_len > 64) die("jellyfish-amd: mer length > 64 is not built yet");
   mer_dna::k(mer_len);
   header.canonical(canonical);
   std::ofstream out(output, std::ios::binary | std::ios::trunc);
@@ -335,6 +343,7 @@ int bc_main(int argc, char* argv[]) {
                           [&](const char* d_buf, size_t n) { if(jfgpu_bc_insert_ascii_dev(bc, d_buf, n)) throw std::runtime_error(jfgpu_last_error()); },
                           host_sink, [&]() { if(jfgpu_bc_sync(bc, nullptr)) throw std::runtime_error(jfgpu_last_error()); });
     }
+    if(!generator.empty()) feed_generators(generator, shell, mer_len, host_sink);
     if(jfgpu_bc_sync(bc, nullptr)) throw std::runtime_error(jfgpu_last_error());
   } catch(std::exception& e) { die(e.what()); }
   const double count_s = seconds_since(count_start);

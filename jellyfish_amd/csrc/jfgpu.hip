@@ -809,6 +809,7 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     WideTable& w = t->wt;
     w.slots = d.slots; w.fwd_tbl = d.fwd_tbl; w.inv_tbl = d.inv_tbl; w.ovf_key = d.ovf_key; w.ovf_cnt = d.ovf_cnt;
     w.ovf_mask = d.ovf_mask; w.counters = d.counters; w.max_probe = d.max_probe;
+    memset(&w.bloom, 0, sizeof w.bloom);
     t->part_ok = false; t->mode = MODE_DIRECT;
     const int wl = (int)(((size_t)16 << t->g.tile_bits) + ((size_t)2 << t->g.tile_bits));
     HIP_TRY(hipFuncSetAttribute((const void*)dump_tiles_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
@@ -1361,6 +1362,7 @@ struct jfgpu_bloom {
   int device = 0, n_cu = 256;
   hipStream_t stream = nullptr;
   TableGeom g{};                 // only k / key_mask / canonical / nbytes are used (encode side)
+  bool wide = false; WideGeom wg{};   // 33 <= k <= 64: two-word keys
   uint64_t m = 0; uint32_t nh = 0;
   Gf2Matrix m1, m2;
   uint64_t *d_t1 = nullptr, *d_t2 = nullptr;
@@ -1397,7 +1399,7 @@ int jfgpu_bc_create(const jfgpu_bloom_params* p, jfgpu_bloom** out) {
   if(!p || !out) return fail(JFGPU_E_INVALID, "null argument");
   *out = nullptr;
   if(p->k < 1) return fail(JFGPU_E_INVALID, "mer length must be >= 1");
-  if(p->k > 32) return fail(JFGPU_E_UNSUPPORTED, "mer length > 32 (multi-word keys) is not built yet");
+  if(p->k > 64) return fail(JFGPU_E_UNSUPPORTED, "mer length > 64 (more than two key words) is not built yet");
   if(p->m < 1 || p->nb_hashes < 1 || p->nb_hashes > 64) return fail(JFGPU_E_INVALID, "bad Bloom counter size / number of hashes");
   int ndev = 0;
   if(hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(JFGPU_E_NO_DEVICE, "no HIP device: the engine has no CPU fallback");
@@ -1407,8 +1409,14 @@ int jfgpu_bc_create(const jfgpu_bloom_params* p, jfgpu_bloom** out) {
   HIP_TRY(hipSetDevice(dev));
   std::unique_ptr<jfgpu_bloom> b(new jfgpu_bloom);
   b->device = dev; b->m = p->m; b->nh = p->nb_hashes;
-  const uint32_t ls = std::max<uint32_t>(std::min<uint32_t>(2 * p->k, 13), geom_min_lsize(p->k, 0));
-  if(!geom_init(b->g, p->k, ls, 0, 0, p->canonical ? 1 : 0)) return fail(JFGPU_E_INVALID, "bad mer length");
+  if(p->k > 32) {
+    b->wide = true;
+    if(!wide_geom_init(b->wg, p->k, std::max<uint32_t>(kMaxTileBits, wide_min_lsize(p->k)), p->canonical ? 1 : 0)) return fail(JFGPU_E_INVALID, "bad mer length");
+    b->g = b->wg.g;
+  } else {
+    const uint32_t ls = std::max<uint32_t>(std::min<uint32_t>(2 * p->k, 13), geom_min_lsize(p->k, 0));
+    if(!geom_init(b->g, p->k, ls, 0, 0, p->canonical ? 1 : 0)) return fail(JFGPU_E_INVALID, "bad mer length");
+  }
   uint64_t st = p->seed ? p->seed : 0x626C6F6F6D636E74ull;
   if(p->matrix1 && p->matrix2) {
     b->m1.r = b->m2.r = 64; b->m1.c = b->m2.c = 2 * p->k;
@@ -1463,7 +1471,8 @@ int jfgpu_bc_insert_ascii_dev(jfgpu_bloom* b, const char* d_bases, size_t n) {
   align_buffer(d_bases, n, base, lo, hi);
   const int64_t n_tiles = (hi + kTilePos - 1) / kTilePos;
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(n_tiles, (int64_t)b->n_cu * 8));
-  hipLaunchKernelGGL(bloom_insert_ascii_kernel, dim3(grid), dim3(kBlock), 0, b->stream, b->view(), b->g, base, lo, hi, b->d_mers);
+  if(b->wide) hipLaunchKernelGGL(bloom_insert_ascii_wide_kernel, dim3(grid), dim3(kBlock), 0, b->stream, b->view(), b->wg, base, lo, hi, b->d_mers);
+  else hipLaunchKernelGGL(bloom_insert_ascii_kernel, dim3(grid), dim3(kBlock), 0, b->stream, b->view(), b->g, base, lo, hi, b->d_mers);
   HIP_TRY(hipGetLastError());
   return JFGPU_OK;
 }
@@ -1521,11 +1530,14 @@ int jfgpu_bc_keys(jfgpu_bloom* b, const uint64_t* keys, size_t n, uint8_t* out, 
   int rc = use_b(b); if(rc) return rc;
   if(!n) return JFGPU_OK;
   uint64_t* d_k = nullptr; uint8_t* d_o = nullptr;
-  HIP_TRY(hipMalloc((void**)&d_k, n * 8));
+  const size_t kw = b->wide ? 2 : 1;                       // words per key (little-endian words, like jfgpu_add_keys)
+  HIP_TRY(hipMalloc((void**)&d_k, n * 8 * kw));
   if(hipMalloc((void**)&d_o, n) != hipSuccess) { hipFree(d_k); return fail(JFGPU_E_ALLOC, "hipMalloc"); }
-  hipError_t e = hipMemcpyAsync(d_k, keys, n * 8, hipMemcpyHostToDevice, b->stream);
+  hipError_t e = hipMemcpyAsync(d_k, keys, n * 8 * kw, hipMemcpyHostToDevice, b->stream);
   if(e == hipSuccess) {
     const int grid = (int)std::max<size_t>(1, std::min<size_t>((n + kBlock - 1) / kBlock, (size_t)b->n_cu * 8));
+    if(b->wide) hipLaunchKernelGGL(bloom_keys_wide_kernel, dim3(grid), dim3(kBlock), 0, b->stream, b->view(), b->wg.key_mask, (const uint64_t*)d_k, (uint64_t)n, d_o, do_insert);
+    else
     hipLaunchKernelGGL(bloom_keys_kernel, dim3(grid), dim3(kBlock), 0, b->stream, b->view(), (const uint64_t*)d_k, (uint64_t)n, d_o, do_insert);
     e = hipGetLastError();
   }
@@ -1539,12 +1551,12 @@ int jfgpu_bc_keys(jfgpu_bloom* b, const uint64_t* keys, size_t n, uint8_t* out, 
 int jfgpu_attach_bloom(jfgpu_table* t, jfgpu_bloom* b) {   // count --bc (count_main.cc:191-206,313-316)
   int rc = use(t); if(rc) return rc;
   rc = part_flush(t); if(rc) return rc;
-  if(!b) { memset(&t->dt.bloom, 0, sizeof t->dt.bloom); return JFGPU_OK; }
+  if(!b) { memset(&t->dt.bloom, 0, sizeof t->dt.bloom); memset(&t->wt.bloom, 0, sizeof t->wt.bloom); return JFGPU_OK; }
   if(b->device != t->device) return fail(JFGPU_E_INVALID, "Bloom counter lives on another device");
   if(b->g.k != t->g.k) return fail(JFGPU_E_INVALID, "Invalid mer length in bloom filter");
-  if(t->g.shard_bits || t->wide) return fail(JFGPU_E_UNSUPPORTED, "count --bc on a sharded / two-word-key table is not built yet");
+  if(t->g.shard_bits) return fail(JFGPU_E_UNSUPPORTED, "count --bc on a sharded table is not built yet");
   HIP_TRY(hipStreamSynchronize(b->stream));
-  t->dt.bloom = b->view();
+  if(t->wide) t->wt.bloom = b->view(); else t->dt.bloom = b->view();
   return JFGPU_OK;
 }
 

@@ -14,6 +14,7 @@
 // Insert path: global atomics only (the partitioned path is one-word for now).
 #pragma once
 #include "kernels.hip.hpp"
+#include "kernels_bloom.hip.hpp"
 
 namespace jfgpu {
 
@@ -64,6 +65,7 @@ struct WideTable {
   uint64_t* ovf_key; uint64_t* ovf_cnt; uint64_t ovf_mask;
   uint64_t* counters;
   uint32_t max_probe;
+  DevBloom bloom;             // count --bc filter (data == nullptr: none)
 };
 
 __device__ inline DevTable ovf_view(const WideTable& T) {     // reuse ovf_add / ovf_get of the one-word code
@@ -232,6 +234,41 @@ __device__ inline void for_each_kmer_wide(const WideGeom& W, const LaneWordsW& L
   }
 }
 
+// Bloom counter on two-word keys: h0 = M1 * key, h1 = M2 * key with 64 x 2k matrices (mer_dna_bloom_counter.hpp:19-34);
+// the byte tables (16 x 256 entries each) are read through the caches.
+__device__ inline bool bloom_admits_wide(const DevBloom& B, u128 key) {
+  return bloom_check(B, hash_tables_wide(B.tbl1, key, B.nbytes), hash_tables_wide(B.tbl2, key, B.nbytes)) > 1;
+}
+
+__global__ __launch_bounds__(kBlock) void bloom_insert_ascii_wide_kernel(DevBloom B, WideGeom W, const uint8_t* __restrict__ base,
+                                                                         int64_t lo, int64_t hi, unsigned long long* __restrict__ mers) {
+  __shared__ uint32_t s_codes[kBlock + 4];
+  __shared__ uint32_t s_inv[kBlock + 4];
+  const int64_t n_tiles = (hi + kTilePos - 1) / kTilePos;
+  uint32_t my = 0;
+  for(int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    __syncthreads();
+    const LaneWordsW L = stage_tile_wide(base, tile * kTilePos, lo, hi, s_codes, s_inv);
+    for_each_kmer_wide(W, L, [&](int, u128 key) {
+      ++my;
+      bloom_insert(B, hash_tables_wide(B.tbl1, key, B.nbytes), hash_tables_wide(B.tbl2, key, B.nbytes));
+    });
+  }
+  uint64_t w = my;
+  for(int o = 32; o > 0; o >>= 1) w += __shfl_down(w, o, 64);
+  if((threadIdx.x & 63) == 0 && w) atomicAdd(mers, (unsigned long long)w);
+}
+
+__global__ __launch_bounds__(kBlock) void bloom_keys_wide_kernel(DevBloom B, u128 key_mask, const uint64_t* __restrict__ keys, uint64_t n,
+                                                                 uint8_t* __restrict__ out, int do_insert) {
+  for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const u128 key = ((((u128)keys[2 * i + 1]) << 64) | keys[2 * i]) & key_mask;
+    const uint64_t h0 = hash_tables_wide(B.tbl1, key, B.nbytes), h1 = hash_tables_wide(B.tbl2, key, B.nbytes);
+    const uint32_t r = do_insert ? bloom_insert(B, h0, h1) : bloom_check(B, h0, h1);
+    if(out) out[i] = (uint8_t)r;
+  }
+}
+
 template <bool RETURNING>
 __global__ __launch_bounds__(kBlock) void count_ascii_wide_kernel(WideTable T, const uint8_t* __restrict__ base, int64_t lo, int64_t hi, int op) {
   __shared__ uint64_t s_fwd[16 * 256];
@@ -252,8 +289,10 @@ __global__ __launch_bounds__(kBlock) void count_ascii_wide_kernel(WideTable T, c
       else if(op == 1) wide_add<RETURNING>(T, s_fwd, key, 0);
       else wide_update_add<RETURNING>(T, s_fwd, key, n);
     };
+    const bool filtered = T.bloom.data != nullptr;          // count --bc (count_main.cc:115-118)
     for_each_kmer_wide(T.W, L, [&](int, u128 key) {
       ++my_mers;
+      if(filtered && !bloom_admits_wide(T.bloom, key)) return;
       if(run && key == prev) { ++run; return; }
       if(run) apply(prev, run);
       prev = key; run = 1;

@@ -322,3 +322,38 @@ def test_cli_reproduces_more_reference_goldens(cli, tmp_path):
         subprocess.check_call([cli, "count", "-t", "4", "-o", "a.jf", "-s", "10M", "-c", "25", "-m", str(k), "-C", "seq10m.fa"], cwd=d)
         subprocess.check_call([cli, "count", "-t", "4", "-o", "b.jf", "-s", "1k", "-c", "5", "-m", str(k), "-C", "seq10m.fa"], cwd=d)
         assert subprocess.check_output([cli, "histo", "a.jf"], cwd=d) == subprocess.check_output([cli, "histo", "b.jf"], cwd=d)
+
+
+def test_bloom_counter_two_word_keys_and_reference_golden(cli, tmp_path):
+    """tests/bloom_counter.sh (k = 40): `bc` through generators, `count --bc` keeps exactly the k-mers seen twice
+    (the histogram md5 of the script), a filter built from other files lets only collisions through; and the
+    bloomcounter file itself is byte-identical to the one the reference binary writes for the same command."""
+    import gzip
+    import hashlib
+    if not O.have_ref():
+        pytest.skip("oracle/_ref not built")
+    g = MANIFEST["reference_md5"]
+    d = str(tmp_path)
+    subprocess.check_call([O.REF_GEN, "-o", "seq1m"] + g["seq1m"], cwd=d)
+    with open(os.path.join(d, "seq1m_0.fa"), "rb") as src, gzip.open(os.path.join(d, "seq1m_0.fa.gz"), "wb") as dst:
+        dst.write(src.read())
+    with open(os.path.join(d, "commands"), "w") as f:
+        f.write("gunzip -c seq1m_0.fa.gz\ngunzip -c seq1m_0.fa.gz\n")
+    subprocess.check_call([cli, "bc", "-t", "4", "-o", "twice.bc", "-s", "1M", "-C", "-m", "40", "-g", "commands", "-G", "2"], cwd=d)
+    subprocess.check_call([cli, "count", "-t", "4", "-o", "plain.jf", "-s", "2M", "-C", "-m", "40", "seq1m_0.fa"], cwd=d)
+    subprocess.check_call([cli, "count", "-t", "4", "-o", "filtered.jf", "--bc", "twice.bc", "-s", "2M", "-C", "-m", "40", "seq1m_0.fa"], cwd=d)
+    subprocess.check_call([cli, "bc", "-t", "4", "-o", "none.bc", "-s", "2M", "-C", "-m", "40", "seq1m_0.fa", "seq1m_1.fa", "seq1m_1.fa"], cwd=d)
+    subprocess.check_call([cli, "count", "-t", "4", "-o", "none.jf", "--bc", "none.bc", "-s", "1M", "-C", "-m", "40", "seq1m_0.fa"], cwd=d)
+    histo = lambda jf: subprocess.check_output([cli, "histo", jf], cwd=d)
+    assert hashlib.md5(histo("plain.jf")).hexdigest() == g["bloom_counter_noop.histo"]
+    assert hashlib.md5(histo("filtered.jf")).hexdigest() == g["bloom_counter_noop.histo"]
+    total = int(histo("plain.jf").split()[1])
+    none = histo("none.jf").split()
+    collisions = int(none[1]) if none else 0
+    assert total // 500 > collisions
+    # byte-identical to the reference's own bc on the same inputs (same default hash pair, same cells)
+    subprocess.check_call([O.REF_JF, "bc", "-m", "40", "-s", "2000000", "-C", "-o", "ref_none.bc", "seq1m_0.fa", "seq1m_1.fa", "seq1m_1.fa"], cwd=d)
+    assert _body(os.path.join(d, "none.bc")) == _body(os.path.join(d, "ref_none.bc"))
+    subprocess.check_call([O.REF_JF, "count", "-m", "40", "-s", "1000000", "-C", "--bc", "none.bc", "-o", "ref_none.jf", "seq1m_0.fa"], cwd=d)
+    assert sorted(subprocess.check_output([cli, "dump", "-c", "none.jf"], cwd=d).splitlines()) == \
+        sorted(subprocess.check_output([O.REF_JF, "dump", "-c", "ref_none.jf"], cwd=d).splitlines())
