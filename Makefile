@@ -12,7 +12,7 @@ all: engine cli oracle
 
 engine: $(LIBDIR)/libjfgpu.so
 
-$(LIBDIR)/libjfgpu.so: $(wildcard $(CSRC)/*.hip) $(wildcard $(CSRC)/*.hpp) include/jfgpu.h
+$(LIBDIR)/libjfgpu.so: $(wildcard $(CSRC)/*.hip) $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.inl) include/jfgpu.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/jfgpu.hip
 
