@@ -1,0 +1,317 @@
+// jellyfish_amd/csrc/host_partition.inl -- host orchestration of the partitioned insert path (kernels_part.hip.hpp):
+// workspace arena, P1 ingestion of a batch, the flush (P2 + tile insert).  Included by jfgpu.hip inside its
+// anonymous namespace.
+// ---- partitioned insert path: host orchestration (kernels_part.hip.hpp) -------------------
+constexpr uint64_t kPartMinBytes = 1u << 20;   // AUTO: smaller device batches take the direct kernel
+
+void part_geom_init(jfgpu_table* t) {
+  const uint32_t bits = t->g.lsize_l - t->g.tile_bits;   // tile-index bits to resolve
+  t->part_ok = false;
+  if(t->g.tile_bits < kMaxTileBits) return;               // tiny table: one partial tile
+  uint32_t b1, b2;
+  if(bits <= 11) { b1 = bits; b2 = 0; }
+  else { b2 = std::min<uint32_t>(11, (bits + 1) / 2); b1 = bits - b2; }
+  if(b1 > 11) return;
+  t->pg.b1 = b1; t->pg.b2 = b2;
+  t->pg.rest_shift = t->g.lsize_l - b1;
+  t->pg.item_bits = t->pg.rest_shift + t->g.rem_bits;
+  if(t->pg.item_bits > 64) return;
+  t->item32 = t->pg.item_bits <= 32;
+  t->part_ok = true;
+}
+
+size_t item_size(const jfgpu_table* t) { return t->item32 ? 4 : 8; }
+
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Grow the arena to at least `need` bytes.  Only legal while it holds nothing (ws_used == 0).
+int ws_grow(jfgpu_table* t, size_t need) {
+  if(need <= t->ws_cap) return JFGPU_OK;
+  size_t want = std::max(need + need / 8, t->ws_cap * 2);
+  size_t free_b = 0, total_b = 0;
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  if(t->ws) { hipFree(t->ws); t->ws = nullptr; t->ws_cap = 0; }
+  HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  const size_t keep = (size_t)2 << 30;                      // leave room for the caller's buffers
+  if(want + keep > free_b) want = need;
+  if(want + keep / 2 > free_b) return -1;
+  HIP_TRY(hipMalloc((void**)&t->ws, want));
+  t->ws_cap = want;
+  return JFGPU_OK;
+}
+
+void* ws_alloc(jfgpu_table* t, size_t bytes) {
+  const size_t at = align_up(t->ws_used, 256);
+  if(at + bytes > t->ws_cap) return nullptr;
+  t->ws_used = at + bytes;
+  return t->ws + at;
+}
+
+template <typename ITEM>
+void launch_p1(jfgpu_table* t, bool scatter, bool from_keys, const uint8_t* base, int64_t lo, int64_t hi,
+               const uint64_t* d_off, void* d_items) {
+  const dim3 grid(t->g1), block(kPBlock);
+  ITEM* out = (ITEM*)d_items;
+#define P1(SC, FK, RT, BL) hipLaunchKernelGGL((p1_kernel<ITEM, SC, FK, RT, BL>), grid, block, 0, t->stream, t->dt, t->pg, base, lo, hi, t->d_M1, d_off, out)
+  const bool rt = t->returning, bl = t->dt.bloom.data != nullptr && !from_keys;   // the filter applies to the sequence feed only
+  // the common key widths get kernels with the byte count of the hash compiled in (no per-k-mer switch)
+#define P1N(FK, N) hipLaunchKernelGGL((p1_kernel<ITEM, false, FK, false, false, N>), grid, block, 0, t->stream, t->dt, t->pg, base, lo, hi, t->d_M1, d_off, out)
+  if(!scatter && !bl && t->g.nbytes >= 6) {
+    if(from_keys) { if(t->g.nbytes == 6) P1N(true, 6); else if(t->g.nbytes == 7) P1N(true, 7); else P1N(true, 8); }
+    else { if(t->g.nbytes == 6) P1N(false, 6); else if(t->g.nbytes == 7) P1N(false, 7); else P1N(false, 8); }
+    return;
+  }
+#undef P1N
+  if(!scatter) { if(from_keys) P1(false, true, false, false); else if(bl) P1(false, false, false, true); else P1(false, false, false, false); }
+  else if(from_keys) { if(rt) P1(true, true, true, false); else P1(true, true, false, false); }
+  else if(bl) { if(rt) P1(true, false, true, true); else P1(true, false, false, true); }
+  else { if(rt) P1(true, false, true, false); else P1(true, false, false, false); }
+#undef P1
+}
+
+int part_flush(jfgpu_table* t);
+
+// Single-pass P1 (p1_scatter_granule_kernel): items per bucket region, 0 when the batch takes the exact
+// two-pass scheme.  Every block may strand part of one reservation per bucket, so small batches would be
+// mostly holes: auto mode wants the mean bucket load to be at least 4x that.
+uint32_t granule_cap(const jfgpu_table* t, bool from_keys, uint64_t max_items) {
+  (void)from_keys;
+  if(!t->item32 || t->pg.b2 == 0 || t->pg.b1 > 10 || t->p1_single == 0 || !t->g1) return 0;
+  const uint64_t nb = 1ull << t->pg.b1, strand = (uint64_t)t->g1 * kGran;
+  const uint64_t mean = (max_items + nb - 1) / nb;
+  if(t->p1_single < 0 && mean < 4 * strand) return 0;
+  const double want = (double)mean * (1.0 + t->p1_slack) + (double)strand;
+  uint64_t cap = want < (double)kGran ? kGran : (uint64_t)want;
+  cap = (cap + kGran - 1) / kGran * kGran;
+  if(cap > 0xFFFF0000ull) return 0;
+  return (uint32_t)cap;
+}
+
+// One batch (contract buffer or key array, on the device) through P1 into a pending batch.
+int part_ingest(jfgpu_table* t, const uint8_t* base, int64_t lo, int64_t hi, bool from_keys, uint64_t max_items) {
+  if(!max_items) return JFGPU_OK;
+  const uint32_t nb = 1u << t->pg.b1;
+  if(!t->d_M1) {
+    t->g1 = 2 * t->n_cu;   // two 1024-thread blocks per CU: one stages while the other computes
+    HIP_TRY(hipMalloc((void**)&t->d_M1, (size_t)t->g1 * kMaxBuckets * sizeof(uint32_t)));
+  }
+  if(t->pending.size() >= kMaxSeg) { int rc = part_flush(t); if(rc) return rc; }
+  const uint32_t gcap = granule_cap(t, from_keys, max_items);
+  const size_t bytes = gcap ? (size_t)nb * gcap * sizeof(uint32_t) : max_items * item_size(t);
+  const size_t need = align_up(bytes, 256) + align_up((2 * nb + 1) * sizeof(uint64_t), 256) + (gcap ? align_up(nb * 16, 256) : 0) + 1024;
+  if(t->ws_used + need > t->ws_cap) {
+    if(!t->pending.empty()) { int rc = part_flush(t); if(rc) return rc; }   // apply what is pending, arena is empty again
+    if(need > t->ws_cap) { int rc = ws_grow(t, need); if(rc) return rc; }     // rc < 0: no memory -> caller goes direct
+  }
+  PendingBatch b{nullptr, nullptr, max_items};
+  b.items = ws_alloc(t, bytes);
+  b.off = (uint64_t*)ws_alloc(t, (2 * nb + 1) * sizeof(uint64_t));
+  if(!b.items || !b.off) return fail(JFGPU_E_ALLOC, "partition workspace exhausted");
+  if(gcap) {
+    // one pass: reservations of kGran items inside fixed bucket regions (p1_scatter_granule_kernel)
+    unsigned int* gcur = (unsigned int*)ws_alloc(t, nb * 16);           // gcur[2 nb] (u32) then tot[nb] (u64)
+    if(!gcur) return fail(JFGPU_E_ALLOC, "partition workspace exhausted");
+    b.gran_cap = gcap; b.tot = (unsigned long long*)(gcur + 2 * nb);
+    HIP_TRY(hipMemsetAsync(gcur, 0, nb * 16, t->stream));
+    ProfScope ps(t, 4, (uint64_t)(from_keys ? hi : hi - lo));
+    const size_t lds = (size_t)kPTilePos * 6;
+    const bool bl = t->dt.bloom.data != nullptr && !from_keys;
+#define PK(RT, N) hipLaunchKernelGGL((p1_keys_granule_kernel<RT, N>), dim3(t->g1), dim3(kPBlock), lds, t->stream, t->dt, t->pg, (const uint64_t*)base, hi, gcap, gcur, b.tot, (uint32_t*)b.items)
+    if(from_keys) {
+      if(t->returning) PK(true, 0);
+      else if(t->g.nbytes == 6) PK(false, 6);
+      else if(t->g.nbytes == 7) PK(false, 7);
+      else if(t->g.nbytes == 8) PK(false, 8);
+      else PK(false, 0);
+    } else
+#define PG(RT, BL, N) hipLaunchKernelGGL((p1_scatter_granule_kernel<RT, BL, N>), dim3(t->g1), dim3(kPBlock), lds, t->stream, t->dt, t->pg, base, lo, hi, gcap, gcur, b.tot, (uint32_t*)b.items)
+    {
+      if(bl) { if(t->returning) PG(true, true, 0); else PG(false, true, 0); }
+      else if(t->returning) PG(true, false, 0);
+      else if(t->g.nbytes == 6) PG(false, false, 6);
+      else if(t->g.nbytes == 7) PG(false, false, 7);
+      else if(t->g.nbytes == 8) PG(false, false, 8);
+      else PG(false, false, 0);
+    }
+#undef PG
+#undef PK
+    hipLaunchKernelGGL(granule_finish_kernel, dim3((nb + 255) / 256), dim3(256), 0, t->stream, gcur, gcap, nb, b.off);
+  } else {
+    ProfScope ps(t, 4, (uint64_t)(from_keys ? hi : hi - lo));
+    if(t->item32) launch_p1<uint32_t>(t, false, from_keys, base, lo, hi, b.off, b.items);
+    else          launch_p1<uint64_t>(t, false, from_keys, base, lo, hi, b.off, b.items);
+    hipLaunchKernelGGL(scan_matrix_kernel, dim3(1), dim3(1024), 0, t->stream, t->d_M1, (uint32_t)t->g1, nb, (const uint64_t*)nullptr, b.off, 0u);
+    if(t->item32 && !from_keys) {     // write-combining scatter (whole runs per bucket)
+      const size_t lds = (size_t)kPTilePos * 6;
+      const bool bl = t->dt.bloom.data != nullptr;
+#define PS(RT, BL) hipLaunchKernelGGL((p1_scatter_sorted_kernel<RT, BL>), dim3(t->g1), dim3(kPBlock), lds, t->stream, t->dt, t->pg, base, lo, hi, (const uint32_t*)t->d_M1, (const uint64_t*)b.off, (uint32_t*)b.items)
+#define PSN(N) hipLaunchKernelGGL((p1_scatter_sorted_kernel<false, false, N>), dim3(t->g1), dim3(kPBlock), lds, t->stream, t->dt, t->pg, base, lo, hi, (const uint32_t*)t->d_M1, (const uint64_t*)b.off, (uint32_t*)b.items)
+      if(!t->returning && !bl && t->g.nbytes >= 6) { if(t->g.nbytes == 6) PSN(6); else if(t->g.nbytes == 7) PSN(7); else PSN(8); }
+      else if(t->returning) { if(bl) PS(true, true); else PS(true, false); } else { if(bl) PS(false, true); else PS(false, false); }
+#undef PSN
+#undef PS
+    }
+    else if(t->item32) {              // encoded keys, 32-bit items: same write-combining scatter
+#define PK(N) hipLaunchKernelGGL(p1_keys_scatter_sorted_kernel<N>, dim3(t->g1), dim3(kPBlock), (size_t)kPTilePos * 6, t->stream, t->dt, t->pg, \
+                                 (const uint64_t*)base, hi, (const uint32_t*)t->d_M1, (const uint64_t*)b.off, (uint32_t*)b.items)
+      if(t->g.nbytes == 6) PK(6); else if(t->g.nbytes == 7) PK(7); else if(t->g.nbytes == 8) PK(8); else PK(0);
+#undef PK
+    }
+    else launch_p1<uint64_t>(t, true, from_keys, base, lo, hi, b.off, b.items);
+  }
+  hipError_t e = hipGetLastError();
+  t->pending.push_back(b);
+  t->pending_bytes += bytes;
+  if(e != hipSuccess) return fail(JFGPU_E_HIP, hipGetErrorString(e));
+  return JFGPU_OK;
+}
+
+template <typename ITEM>
+int part_flush_t(jfgpu_table* t) {
+  const uint32_t nb1 = 1u << t->pg.b1, nb2 = 1u << t->pg.b2;
+  const size_t nbatch = t->pending.size();
+  // bucket sizes of every pending batch (one small D2H; also drains the stream)
+  // (granule batches: the exact per-bucket counts, stored as a running sum so both kinds read alike)
+  std::vector<uint64_t> offs(nbatch * (nb1 + 1));
+  for(size_t s = 0; s < nbatch; ++s) {
+    const PendingBatch& pb = t->pending[s];
+    if(pb.gran_cap) HIP_TRY(hipMemcpyAsync(&offs[s * (nb1 + 1) + 1], pb.tot, nb1 * sizeof(uint64_t), hipMemcpyDeviceToHost, t->stream));
+    else HIP_TRY(hipMemcpyAsync(&offs[s * (nb1 + 1)], pb.off, (nb1 + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, t->stream));
+  }
+  uint64_t ctr[CTR_COUNT];
+  HIP_TRY(hipMemcpyAsync(ctr, t->dt.counters, sizeof(ctr), hipMemcpyDeviceToHost, t->stream));
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  for(size_t s = 0; s < nbatch; ++s)
+    if(t->pending[s].gran_cap) {
+      uint64_t* o = &offs[s * (nb1 + 1)];
+      o[0] = 0;
+      for(uint32_t j = 0; j < nb1; ++j) o[j + 1] += o[j];
+    }
+  std::vector<uint64_t> bucket_tot(nb1, 0);
+  uint64_t total = 0, max_bucket = 0;
+  for(size_t s = 0; s < nbatch; ++s)
+    for(uint32_t j = 0; j < nb1; ++j) bucket_tot[j] += offs[s * (nb1 + 1) + j + 1] - offs[s * (nb1 + 1) + j];
+  for(uint32_t j = 0; j < nb1; ++j) { total += bucket_tot[j]; max_bucket = std::max(max_bucket, bucket_tot[j]); }
+  if(max_bucket > 0xF0000000ull) return fail(JFGPU_E_UNSUPPORTED, "more than 2^32 pending k-mers in one partition bucket: sync more often");
+  const uint64_t n_tiles = n_tiles_of(t);
+  SegList S1; memset(&S1, 0, sizeof S1);
+  S1.n = (uint32_t)nbatch;
+  for(size_t s = 0; s < nbatch; ++s) { S1.items[s] = t->pending[s].items; S1.off[s] = t->pending[s].off; S1.sh[s] = t->pending[s].gran_cap ? 1 : 0; }
+  const size_t tile_lds = (size_t)8 << t->g.tile_bits;
+  // always LOAD-capable: a tile is read only if its dirty byte is set (clean after jfgpu_clear)
+  const bool rt = t->returning, load = true;
+  auto launch_tiles = [&](const SegList& S, uint64_t tile0, uint32_t ntile, uint64_t units) {
+    ProfScope ps(t, 6, units);
+    const dim3 grid((unsigned)std::min<uint64_t>(ntile, (uint64_t)t->n_cu * 16)), block(kPBlock);
+#define TI(RT, LD) hipLaunchKernelGGL((tile_insert_kernel<ITEM, RT, LD>), grid, block, tile_lds, t->stream, t->dt, S, tile0, ntile)
+    if(rt) { if(load) TI(true, true); else TI(true, false); } else { if(load) TI(false, true); else TI(false, false); }
+#undef TI
+  };
+  if(total == 0) {
+    // nothing to insert
+  } else if(t->mode != MODE_PARTITIONED && total < n_tiles * 256) {
+    // too few items to be worth streaming the tiles: global atomics straight from the items
+    for(size_t s = 0; s < nbatch; ++s) {
+      const uint64_t n = offs[s * (nb1 + 1) + nb1];
+      if(!n) continue;
+      ProfScope ps(t, 7, n);
+      const uint64_t span = t->pending[s].gran_cap ? (uint64_t)nb1 * t->pending[s].gran_cap : n;
+      const dim3 grid((unsigned)grid_for(t, (span + kBlock - 1) / kBlock)), block(kBlock);
+      const uint64_t gc = t->pending[s].gran_cap;
+      if(rt) hipLaunchKernelGGL((items_direct_kernel<ITEM, true>), grid, block, 0, t->stream, t->dt, t->pg, (const ITEM*)t->pending[s].items, (const uint64_t*)t->pending[s].off, gc);
+      else   hipLaunchKernelGGL((items_direct_kernel<ITEM, false>), grid, block, 0, t->stream, t->dt, t->pg, (const ITEM*)t->pending[s].items, (const uint64_t*)t->pending[s].off, gc);
+    }
+  } else if(t->pg.b2 == 0) {
+    launch_tiles(S1, 0, nb1, total);
+  } else {
+    // breadth-first: every P1 bucket through P2 in one launch per pass, then every tile in one launch
+    const int g2 = 32;
+    if(!t->d_M2) HIP_TRY(hipMalloc((void**)&t->d_M2, (size_t)nb1 * g2 * nb2 * sizeof(uint32_t)));
+    ITEM* tmp = nullptr; uint64_t *d_goff = nullptr, *d_base = nullptr;
+    bool tmp_owned = false;
+    d_goff = (uint64_t*)ws_alloc(t, (n_tiles + 1) * sizeof(uint64_t));
+    d_base = (uint64_t*)ws_alloc(t, nb1 * sizeof(uint64_t));
+    tmp = (ITEM*)ws_alloc(t, std::max<uint64_t>(total, 1) * sizeof(ITEM));
+    if(!d_goff || !d_base || !tmp) {     // arena too small for the flush temporaries: one-off allocation
+      tmp_owned = true;
+      tmp = nullptr; d_goff = nullptr; d_base = nullptr;
+      HIP_TRY(hipMalloc((void**)&tmp, std::max<uint64_t>(total, 1) * sizeof(ITEM)));
+      if(hipMalloc((void**)&d_goff, (n_tiles + 1) * sizeof(uint64_t)) != hipSuccess ||
+         hipMalloc((void**)&d_base, nb1 * sizeof(uint64_t)) != hipSuccess) {
+        hipFree(tmp); if(d_goff) hipFree(d_goff);
+        return fail(JFGPU_E_ALLOC, "hipMalloc partition offsets");
+      }
+    }
+    std::vector<uint64_t> base(nb1);
+    { uint64_t run = 0; for(uint32_t j = 0; j < nb1; ++j) { base[j] = run; run += bucket_tot[j]; } }
+    HIP_TRY(hipMemcpyAsync(d_base, base.data(), nb1 * sizeof(uint64_t), hipMemcpyHostToDevice, t->stream));
+    // Optionally (JFGPU_FLUSH_GROUPS > 1) the P1 buckets go through P2 and the tile insert in groups, P2 on the
+    // table's stream and the tile insert on a second one, so that group g's tiles are inserted while group g+1
+    // is partitioned (one P2-scatter block, 88 KB LDS, and one tile block, 64 KB, fit a CU together).
+    const uint32_t n_groups = t->flush_groups > 1 && nb1 >= (uint32_t)t->flush_groups * 8 ? (uint32_t)t->flush_groups : 1;
+    const uint32_t gsz = nb1 / n_groups;
+    if(n_groups > 1 && !t->stream2) {
+      HIP_TRY(hipStreamCreateWithFlags(&t->stream2, hipStreamNonBlocking));
+      for(auto& ev : t->flush_ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&t->flush_done, hipEventDisableTiming));
+    }
+    hipEvent_t p2a = nullptr, p2b = nullptr, ta = nullptr, tb = nullptr;
+    if(t->prof_on) { p2a = get_event(t); p2b = get_event(t); ta = get_event(t); tb = get_event(t); hipEventRecord(p2a, t->stream); }
+    constexpr int per_thread = sizeof(ITEM) == 4 ? 16 : 8;
+    for(uint32_t g = 0; g < n_groups; ++g) {
+      const uint32_t b0 = g * gsz, nbk = g + 1 == n_groups ? nb1 - b0 : gsz;
+      const dim3 grid(g2, nbk), block(kPBlock);
+      hipLaunchKernelGGL((p2_kernel<ITEM, false>), grid, block, 0, t->stream, t->pg, t->g.tag_bits, S1, t->d_M2, (const uint64_t*)d_goff, tmp, b0);
+      hipLaunchKernelGGL(scan_matrix_kernel, dim3(nbk), dim3(1024), 0, t->stream, t->d_M2, (uint32_t)g2, nb2, (const uint64_t*)d_base, d_goff, b0);
+      hipLaunchKernelGGL((p2_scatter_sorted_kernel<ITEM, per_thread>), grid, block, (size_t)kPBlock * per_thread * sizeof(ITEM), t->stream,
+                         t->pg, t->g.tag_bits, S1, (const uint32_t*)t->d_M2, (const uint64_t*)d_goff, tmp, b0);
+      if(t->prof_on && g + 1 == n_groups) hipEventRecord(p2b, t->stream);
+      const uint64_t tile_start = (uint64_t)b0 << t->pg.b2;
+      const uint32_t ntile = nbk << t->pg.b2;
+      SegList S2; memset(&S2, 0, sizeof S2);
+      S2.n = 1; S2.items[0] = tmp; S2.off[0] = d_goff + tile_start;
+      hipStream_t ts = t->stream;
+      if(n_groups > 1) {
+        HIP_TRY(hipEventRecord(t->flush_ev[g & 1], t->stream));
+        HIP_TRY(hipStreamWaitEvent(t->stream2, t->flush_ev[g & 1], 0));
+        ts = t->stream2;
+      }
+      if(t->prof_on && g == 0) hipEventRecord(ta, ts);
+      const dim3 tgrid((unsigned)std::min<uint64_t>(ntile, (uint64_t)t->n_cu * 16));
+#define TI(RT, LD) hipLaunchKernelGGL((tile_insert_kernel<ITEM, RT, LD>), tgrid, block, tile_lds, ts, t->dt, S2, tile_start, ntile)
+      if(rt) TI(true, true); else TI(false, true);
+#undef TI
+      if(t->prof_on && g + 1 == n_groups) hipEventRecord(tb, ts);
+    }
+    if(t->prof_on) {
+      t->prof_pending.push_back({p2a, p2b, 5, total});
+      t->prof_pending.push_back({ta, tb, 6, total});
+    }
+    if(n_groups > 1) {        // the table's stream continues only after the last tiles are in
+      HIP_TRY(hipEventRecord(t->flush_done, t->stream2));
+      HIP_TRY(hipStreamWaitEvent(t->stream, t->flush_done, 0));
+    }
+    hipError_t e = hipStreamSynchronize(t->stream);
+    if(tmp_owned) { hipFree(tmp); hipFree(d_goff); hipFree(d_base); }
+    if(e != hipSuccess) return fail(JFGPU_E_HIP, hipGetErrorString(e));
+  }
+  hipError_t e = hipGetLastError();
+  if(e == hipSuccess) e = hipStreamSynchronize(t->stream);
+  t->pending.clear(); t->pending_bytes = 0; t->ws_used = 0;
+  if(total) t->pristine = false;
+  if(e != hipSuccess) return fail(JFGPU_E_HIP, hipGetErrorString(e));
+  return JFGPU_OK;
+}
+
+int part_flush(jfgpu_table* t) {
+  if(t->pending.empty()) return JFGPU_OK;
+  return t->item32 ? part_flush_t<uint32_t>(t) : part_flush_t<uint64_t>(t);
+}
+
+void part_discard(jfgpu_table* t) {
+  if(t->stream) hipStreamSynchronize(t->stream);
+  t->pending.clear(); t->pending_bytes = 0; t->ws_used = 0;
+}
+
+
