@@ -364,9 +364,10 @@ int bc_main(int argc, char* argv[]) {
 struct db_file {
   std::ifstream is;
   file_header header;
-  explicit db_file(const std::string& path) : is(path, std::ios::binary) {
-    if(!is.good()) die("Failed to open input file '" + path + "'");
-    if(!header.read(is)) die("Failed to parse header of file '" + path + "'");
+  bool ok = true;
+  explicit db_file(const std::string& path, bool die_on_error = true) : is(path, std::ios::binary) {
+    if(!is.good()) { if(die_on_error) die("Failed to open input file '" + path + "'"); ok = false; return; }
+    if(!header.read(is)) { if(die_on_error) die("Failed to parse header of file '" + path + "'"); ok = false; return; }
     mer_dna::k(header.key_len() / 2);
   }
 };
@@ -375,6 +376,124 @@ template <typename F> void for_each_record(db_file& db, F f) {
   if(db.header.format() == binary_dumper::format) { binary_reader r(db.is, &db.header); while(r.next()) f(r.key(), r.val()); }
   else if(db.header.format() == text_dumper::format) { text_reader r(db.is, &db.header); while(r.next()) f(r.key(), r.val()); }
   else die("Unknown format '" + db.header.format() + "'");
+}
+
+// ---------------------------------------------------------------- merge  (jellyfish/merge_files.cc:36-176, sub_commands/merge_main.cc)
+// k-way merge of sorted databases written with the same hash function: records of every input come in (pos, key)
+// order, so a heap of the inputs' heads yields the union in that order; equal keys are combined (sum / min / max)
+// or only tallied (Jaccard).  Host code: the inputs are files.
+struct MergeError : public std::runtime_error { explicit MergeError(const std::string& s) : std::runtime_error(s) {} };
+
+template <typename Reader, typename Writer>
+static void do_merge(std::vector<std::unique_ptr<db_file>>& files, std::ostream& out, Writer&& write, uint64_t min, uint64_t max, int op) {
+  struct head { uint64_t pos; mer_dna key; uint64_t val; size_t src; };
+  const header_matrix m = files[0]->header.matrix();
+  const uint64_t mask = files[0]->header.size() - 1;
+  std::vector<std::unique_ptr<Reader>> readers;
+  auto later = [](const head& a, const head& b) { return a.pos != b.pos ? a.pos > b.pos : a.key > b.key; };   // min-heap on (pos, key)
+  std::vector<head> heap;
+  auto push = [&](size_t i) {
+    Reader& r = *readers[i];
+    if(!r.next()) return;
+    heap.push_back(head{m.times(r.key().data()) & mask, r.key(), r.val(), i});
+    std::push_heap(heap.begin(), heap.end(), later);
+  };
+  for(size_t i = 0; i < files.size(); ++i) { readers.emplace_back(new Reader(files[i]->is, &files[i]->header)); push(i); }
+  const uint64_t nb_files = files.size();
+  uint64_t inter = 0, winter = 0, union_ = 0, wunion = 0;
+  while(!heap.empty()) {
+    const mer_dna key = heap.front().key;
+    uint64_t sum = 0, maxc = 0, minc = std::numeric_limits<uint64_t>::max(), present = 0;
+    while(!heap.empty() && heap.front().key == key) {
+      std::pop_heap(heap.begin(), heap.end(), later);
+      const head h = heap.back(); heap.pop_back();
+      ++present; sum += h.val; minc = std::min(minc, h.val); maxc = std::max(maxc, h.val);
+      push(h.src);
+    }
+    if(present < nb_files) minc = 0;               // absent from some file: count 0 there
+    if(op != 3) {
+      const uint64_t val = op == 0 ? sum : op == 1 ? minc : maxc;
+      if(val >= min && val <= max) write(out, key, val);
+    } else { inter += minc > 0; winter += minc; union_ += 1; wunion += maxc; }
+  }
+  if(op == 3) out << "Jaccard  " << (double)inter / (double)union_ << '\n' << "wJaccard " << (double)winter / (double)wunion << '\n';
+}
+
+// op: 0 sum, 1 min, 2 max, 3 Jaccard
+static void merge_files(const std::vector<std::string>& inputs, const std::string& out_file, file_header& out_header, uint64_t min, uint64_t max, int op) {
+  std::vector<std::unique_ptr<db_file>> files;
+  unsigned key_len = 0, out_counter_len = std::numeric_limits<unsigned>::max();
+  size_t max_reprobe_offset = 0, size = 0;
+  std::string format;
+  header_matrix matrix;
+  for(size_t i = 0; i < inputs.size(); ++i) {
+    std::unique_ptr<db_file> f(new db_file(inputs[i], false));
+    if(!f->is.good() || !f->ok) throw MergeError("Failed to open input file '" + inputs[i] + "'");
+    file_header& h = f->header;
+    if(i == 0) {
+      key_len = h.key_len(); max_reprobe_offset = h.max_reprobe_offset(); size = h.size(); matrix = h.matrix(); format = h.format();
+      out_header.size(size); out_header.key_len(key_len); out_header.matrix(matrix);
+      out_header.max_reprobe(h.max_reprobe()); out_header.set_reprobes(h.get_reprobes());
+      out_counter_len = std::min(out_counter_len, h.counter_len());
+    } else {
+      if(format != h.format()) throw MergeError("Can't merge files with different formats (" + format + ", " + h.format() + ")");
+      if(h.key_len() != key_len) throw MergeError("Can't merge hashes of different key lengths (" + std::to_string(key_len) + ", " + std::to_string(h.key_len()) + ")");
+      if(h.max_reprobe_offset() != max_reprobe_offset) throw MergeError("Can't merge hashes with different reprobing strategies");
+      if(h.size() != size) throw MergeError("Can't merge hash with different size (" + std::to_string(size) + ", " + std::to_string(h.size()) + ")");
+      const header_matrix hm = h.matrix();
+      if(hm.r != matrix.r || hm.c != matrix.c || hm.identity != matrix.identity || hm.columns != matrix.columns)
+        throw MergeError("Can't merge hash with different hash function");
+      out_counter_len = std::min(out_counter_len, h.counter_len());
+    }
+    files.push_back(std::move(f));
+  }
+  mer_dna::k(key_len / 2);
+  std::ofstream out(out_file, std::ios::binary | std::ios::trunc);
+  if(!out.good()) throw MergeError("Can't open out file '" + out_file + "'");
+  if(op != 3) out_header.format(format);
+  if(format == binary_dumper::format) {
+    out_header.counter_len(out_counter_len);
+    if(op != 3) out_header.write(out);
+    const unsigned kb = (key_len + 7) / 8;
+    const uint64_t vmax = out_counter_len >= 8 ? ~(uint64_t)0 : (((uint64_t)1 << (8 * out_counter_len)) - 1);
+    do_merge<binary_reader>(files, out, [&](std::ostream& o, const mer_dna& k, uint64_t v) {
+      o.write((const char*)k.data(), kb);                                  // binary_writer::write, binary_dumper.hpp:36-40
+      const uint64_t w = std::min(v, vmax);
+      o.write((const char*)&w, out_counter_len);
+    }, min, max, op);
+  } else if(format == text_dumper::format) {
+    if(op != 3) out_header.write(out);
+    do_merge<text_reader>(files, out, [&](std::ostream& o, const mer_dna& k, uint64_t v) { o << k << ' ' << v << '\n'; }, min, max, op);
+  } else throw MergeError("Unknown format '" + format + "'");
+  out.close();
+}
+
+int merge_main(int argc, char* argv[]) {
+  file_header out_header;
+  out_header.fill_standard();
+  out_header.set_cmdline(argc, argv);
+  std::string output = "mer_counts_merged.jf";
+  bool min_flag = false, max_flag = false, jaccard = false, lower_given = false, upper_given = false;
+  uint64_t lower = 0, upper = std::numeric_limits<uint64_t>::max();
+  std::vector<std::string> inputs;
+  ArgCursor a{argc, argv};
+  for(; a.more(); ++a.i) {
+    if(a.is("-o", "--output")) output = a.value("-o", "--output");
+    else if(a.cur() == "-m" || a.cur() == "--min") min_flag = true;
+    else if(a.cur() == "-M" || a.cur() == "--max") max_flag = true;
+    else if(a.cur() == "-j" || a.cur() == "--jaccard") jaccard = true;
+    else if(a.is("-L", "--lower-count")) { lower = strtoull(a.value("-L", "--lower-count").c_str(), 0, 10); lower_given = true; }
+    else if(a.is("-U", "--upper-count")) { upper = strtoull(a.value("-U", "--upper-count").c_str(), 0, 10); upper_given = true; }
+    else if(a.cur().size() > 1 && a.cur()[0] == '-') die("Unknown option '" + a.cur() + "'");
+    else inputs.push_back(a.cur());
+  }
+  if(min_flag && max_flag) die("Switches -m, --min and -M, --max conflict");
+  if(inputs.size() < 2) die("Error: at least 2 input files are required");
+  const uint64_t min = lower_given ? lower : (min_flag ? 1 : 0);
+  const uint64_t max = upper_given ? upper : std::numeric_limits<uint64_t>::max();
+  const int op = jaccard ? 3 : max_flag ? 2 : min_flag ? 1 : 0;
+  try { merge_files(inputs, output, out_header, min, max, op); } catch(MergeError& e) { die(e.what()); }
+  return 0;
 }
 
 int dump_main(int argc, char* argv[]) {
@@ -564,6 +683,7 @@ int main(int argc, char* argv[]) {
     if(cmd == "histo") return histo_main(argc - 1, argv + 1);
     if(cmd == "stats") return stats_main(argc - 1, argv + 1);
     if(cmd == "query") return query_main(argc - 1, argv + 1);
+    if(cmd == "merge") return merge_main(argc - 1, argv + 1);
     if(cmd == "info") return info_main(argc - 1, argv + 1);
   } catch(std::exception& e) { die(e.what()); }
   std::cerr << "Unknown command '" << cmd << "'\n" << usage;

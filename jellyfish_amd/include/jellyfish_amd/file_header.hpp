@@ -149,6 +149,12 @@ public:
   unsigned max_reprobe() const { return (unsigned)root_.get("max_reprobe").as_uint64(); }
   void max_reprobe(unsigned m) { root_["max_reprobe"] = Json(m); }
   size_t max_reprobe_offset() const { return root_.get("reprobes").at(max_reprobe()).as_uint64(); }
+  std::vector<size_t> get_reprobes() const {
+    std::vector<size_t> r;
+    const Json& a = root_.get("reprobes");
+    for(size_t i = 0; i < a.size(); ++i) r.push_back((size_t)a.at(i).as_uint64());
+    return r;
+  }
   void set_reprobes(const std::vector<size_t>& r) {
     Json a; a.set_array();
     for(unsigned i = 0; i <= max_reprobe() && i < r.size(); ++i) a.append(Json((unsigned long long)r[i]));

@@ -173,3 +173,37 @@ def test_default_matrix_is_the_reference_matrix():
         assert capi.reference_matrix(m["r"], m["c"]).tolist() == m["columns"], name
     # identity when the table covers the key space (large_hash_array.hpp:997-1000): column c-1-j is bit j
     assert capi.reference_matrix(12, 10).tolist() == [1 << (9 - i) for i in range(10)]
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+def test_merge_verb_reproduces_reference_goldens(cli, tmp_path):
+    """`jellyfish-amd merge` (host code) on databases written by the REFERENCE (oracle/_ref on the CPU), against the
+    goldens of tests/merge.sh:7-15,39-47: min / max / Jaccard of two k = 9 databases, and the sum of five k = 40
+    databases counted one file at a time = the histogram of counting them together."""
+    import hashlib
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json")))["reference_md5"]
+    d = str(tmp_path)
+    subprocess.check_call([O.REF_GEN, "-o", "seq1m"] + g["seq1m"], cwd=d)
+    md5 = lambda data: hashlib.md5(data).hexdigest()
+    for i in (2, 3):
+        subprocess.check_call([O.REF_JF, "count", "-t", "4", "-o", "m9_%d.jf" % i, "-C", "-m", "9", "-s", "4M", "seq1m_%d.fa" % i], cwd=d)
+    subprocess.check_call([cli, "merge", "-m", "-o", "min.jf", "m9_2.jf", "m9_3.jf"], cwd=d)
+    subprocess.check_call([cli, "merge", "-M", "-o", "max.jf", "m9_2.jf", "m9_3.jf"], cwd=d)
+    subprocess.check_call([cli, "merge", "-j", "-o", "jaccard", "m9_2.jf", "m9_3.jf"], cwd=d)
+    assert md5(subprocess.check_output([O.REF_JF, "histo", "min.jf"], cwd=d)) == "4199aa97e646281b9c36a03564f082ee"
+    assert md5(subprocess.check_output([O.REF_JF, "histo", "max.jf"], cwd=d)) == "10b5ca10bcf85183f82837ea10638a8d"
+    assert md5(open(os.path.join(d, "jaccard"), "rb").read()) == "0ff4b7a2f3f67fd26011a41f820bdf36"
+    assert subprocess.check_output([O.REF_JF, "dump", "--check-order", "max.jf"], cwd=d).decode().startswith("ORDER OK")
+    parts = []
+    for j, i in enumerate((0, 1, 0, 2, 2)):
+        parts.append("p%d.jf" % j)
+        subprocess.check_call([O.REF_JF, "count", "-t", "4", "-o", parts[-1], "-s", "4M", "-C", "-m", "40", "seq1m_%d.fa" % i], cwd=d)
+    subprocess.check_call([cli, "merge", "-o", "merged.jf"] + parts, cwd=d)
+    assert md5(subprocess.check_output([cli, "histo", "merged.jf"], cwd=d)) == "72f1913b3503114c7df7a4dcc68ce867"
+    assert md5(subprocess.check_output([O.REF_JF, "histo", "merged.jf"], cwd=d)) == "72f1913b3503114c7df7a4dcc68ce867"
+    # -L / -U on the merged counts; inputs that cannot be merged are refused with the reference's messages
+    subprocess.check_call([cli, "merge", "-L", "2", "-U", "2", "-o", "two.jf"] + parts, cwd=d)
+    lines = subprocess.check_output([cli, "dump", "-c", "two.jf"], cwd=d).decode().splitlines()
+    assert lines and all(l.endswith(" 2") for l in lines)
+    r = subprocess.run([cli, "merge", "-o", "bad.jf", "m9_2.jf", "p0.jf"], cwd=d, capture_output=True)
+    assert r.returncode != 0 and b"different key lengths" in r.stderr
