@@ -219,6 +219,13 @@ int  jfgpu_reference_matrix(uint32_t lsize, uint32_t key_len, uint64_t* columns)
 #define JFGPU_OP_UPDATE 2
 int  jfgpu_set_operation(jfgpu_table* t, int op);
 
+/* Spill instead of "Hash full" when the table may not double (jfgpu_set_growth(t, 0), i.e. `count --disk`):
+ * before the table would pass 80 % load the engine applies everything pending and calls fn(user); the callback
+ * writes the table out as one sorted run (jfgpu_dump_begin / _next / _end -- what the reference's dumper does
+ * from hash_counter::handle_full_ary, hash_counter.hpp:178-198) and returns 0; the engine then empties the table
+ * and carries on.  The runs are merged afterwards (jellyfish/merge_files.cc).  fn == NULL: no spilling. */
+int  jfgpu_set_spill(jfgpu_table* t, int (*fn)(void* user), void* user);
+
 /* Insert strategy.  0 auto (default), 1 direct (global 64-bit atomics, kernels.hip.hpp),
  * 2 partitioned (radix partition + LDS-resident tiles, kernels_part.hip.hpp; large batches
  * are buffered on the device and applied at the next jfgpu_sync / read).  Results are

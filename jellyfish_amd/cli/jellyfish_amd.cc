@@ -77,289 +77,6 @@ double seconds_since(std::chrono::steady_clock::time_point t0) {
   return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
-// -g / -S: every line of the file is a shell command whose standard output is a fasta / fastq stream
-// (lib/generator_manager.cc runs them through named pipes; here each is read through a pipe in turn).  Blank
-// lines and # comments are skipped (:223-226); a command that fails is an error.
-static void feed_generators(const std::string& generator, std::string shell, unsigned mer_len, const sequence_parser::sink_type& sink) {
-  std::ifstream gf(generator);
-  if(!gf.good()) die("Can't open generator file '" + generator + "'");
-  if(shell.empty()) { const char* e = getenv("SHELL"); shell = e && *e ? e : "/bin/sh"; }
-  sequence_parser parser(mer_len);
-  std::string cmd, data;
-  while(std::getline(gf, cmd)) {
-    const size_t first = cmd.find_first_not_of(" \t\n\v\f\r");
-    if(first == std::string::npos || cmd[first] == '#') continue;
-    int fds[2];
-    if(pipe(fds) != 0) die("pipe() failed");
-    const pid_t pid = fork();
-    if(pid < 0) die("fork() failed");
-    if(pid == 0) {
-      close(fds[0]); dup2(fds[1], 1); close(fds[1]);
-      execl(shell.c_str(), shell.c_str(), "-c", cmd.c_str(), (char*)0);
-      _exit(127);
-    }
-    close(fds[1]);
-    data.clear();
-    char tmp[1 << 16]; ssize_t r;
-    while((r = read(fds[0], tmp, sizeof tmp)) > 0) data.append(tmp, (size_t)r);
-    close(fds[0]);
-    int status = 0;
-    waitpid(pid, &status, 0);
-    if(!WIFEXITED(status) || WEXITSTATUS(status) != 0) die("Generator command failed: " + cmd);
-    parser.parse_memory(data.data(), data.size(), sink);
-  }
-}
-
-// ---------------------------------------------------------------- count
-int count_main(int argc, char* argv[]) {
-  auto start_time = std::chrono::steady_clock::now();
-  file_header header;
-  header.fill_standard();
-  header.set_cmdline(argc, argv);
-
-  unsigned mer_len = 0, threads = 1, counter_len = 7, out_counter_len = 4, reprobes = 126, Files = 1;
-  uint64_t size = 0, lower = 0, upper = std::numeric_limits<uint64_t>::max();
-  bool size_given = false, lower_given = false, upper_given = false, canonical = false, text = false, no_write = false, disk = false, host_parse = false;
-  int device = -1;
-  std::string output = "mer_counts.jf", timing, bc_path, generator, shell;
-  std::vector<std::string> files, if_files;
-  ArgCursor a{argc, argv};
-  for(; a.more(); ++a.i) {
-    if(a.is("-m", "--mer-len")) mer_len = (unsigned)strtoul(a.value("-m", "--mer-len").c_str(), 0, 10);
-    else if(a.is("-s", "--size")) { size = parse_suffix(a.value("-s", "--size"), "-s"); size_given = true; }
-    else if(a.is("-t", "--threads")) threads = (unsigned)strtoul(a.value("-t", "--threads").c_str(), 0, 10);
-    else if(a.is("", "--if")) if_files.push_back(a.value("", "--if"));
-    else if(a.is("-g", "--generator")) generator = a.value("-g", "--generator");
-    else if(a.is("-G", "--Generators")) (void)a.value("-G", "--Generators");     // generators run one after the other here
-    else if(a.is("-S", "--shell")) shell = a.value("-S", "--shell");
-    else if(a.is("-F", "--Files")) Files = (unsigned)strtoul(a.value("-F", "--Files").c_str(), 0, 10);
-    else if(a.is("-c", "--counter-len")) counter_len = (unsigned)strtoul(a.value("-c", "--counter-len").c_str(), 0, 10);
-    else if(a.is("", "--out-counter-len")) out_counter_len = (unsigned)strtoul(a.value("", "--out-counter-len").c_str(), 0, 10);
-    else if(a.is("-p", "--reprobes")) reprobes = (unsigned)strtoul(a.value("-p", "--reprobes").c_str(), 0, 10);
-    else if(a.is("-o", "--output")) output = a.value("-o", "--output");
-    else if(a.is("-L", "--lower-count")) { lower = strtoull(a.value("-L", "--lower-count").c_str(), 0, 10); lower_given = true; }
-    else if(a.is("-U", "--upper-count")) { upper = strtoull(a.value("-U", "--upper-count").c_str(), 0, 10); upper_given = true; }
-    else if(a.is("", "--timing")) timing = a.value("", "--timing");
-    else if(a.is("", "--device")) device = atoi(a.value("", "--device").c_str());
-    else if(a.is("", "--bc")) bc_path = a.value("", "--bc");
-    else if(a.cur() == "-C" || a.cur() == "--canonical") canonical = true;
-    else if(a.cur() == "--text") text = true;
-    else if(a.cur() == "--no-write") no_write = true;
-    else if(a.cur() == "--host-parse") host_parse = true;   // read the files with the host reader instead of the device parser
-    else if(a.cur() == "--disk") disk = true;   // do_size_doubling(false) (count_main.cc:276-277); no spill files yet: a full table is an error
-    else if(a.cur() == "--no-merge" || a.cur() == "--no-unlink") { /* spill-to-disk knobs */ }
-    else if(a.is("", "--bf-size") || a.is("", "--bf-fp") || a.is("-Q", "--min-qual-char") ||
-            a.is("-q", "--min-quality") || a.is("", "--sam"))
-      die("Option '" + a.cur() + "' is not supported by jellyfish-amd yet");
-    else if(a.cur() == "-h" || a.cur() == "--help") {
-      std::cout << "Usage: jellyfish-amd count [options] file:path+\n\n"
-                   "Count k-mers in fasta or fastq files on an MI355X\n\n"
-                   " -m, --mer-len=uint32       *Length of mer\n"
-                   " -s, --size=uint64          *Initial hash size\n"
-                   " -t, --threads=uint32        Number of threads (1)\n"
-                   " -o, --output=string         Output file (mer_counts.jf)\n"
-                   " -c, --counter-len=Length    Length bits of counting field (7)\n"
-                   "     --out-counter-len=bytes Length in bytes of counter field in output (4)\n"
-                   " -C, --canonical             Count both strand, canonical representation (false)\n"
-                   " -p, --reprobes=uint32       Maximum number of reprobes (126)\n"
-                   " -L, --lower-count=uint64    Don't output k-mer with count < lower-count\n"
-                   " -U, --upper-count=uint64    Don't output k-mer with count > upper-count\n"
-                   "     --if=path               Count only the k-mers of these fasta / fastq files (repeatable)\n"
-                   " -g, --generator=path        File of commands generating fast[aq] (one per line, e.g. zcat reads.fa.gz)\n"
-                   " -S, --shell=string          Shell used to run generator commands ($SHELL or /bin/sh)\n"
-                   "     --text                  Dump in text format (false)\n"
-                   "     --timing=Timing file    Print timing information\n"
-                   "     --device=int            HIP device ordinal (current)\n"
-                   "     --host-parse            Parse the sequence files on the host (default: on the device)\n";
-      return 0;
-    } else if(a.cur().size() > 1 && a.cur()[0] == '-' && a.cur() != "-") die("Unknown option '" + a.cur() + "'");
-    else files.push_back(a.cur());
-  }
-  if(!mer_len) die("Error: mandatory switch missing: -m, --mer-len");
-  if(!size_given) die("Error: mandatory switch missing: -s, --size");
-  if(files.empty() && generator.empty()) die("Error: at least 1 file argument is required");
-  (void)threads; (void)counter_len; (void)reprobes; (void)Files;
-  if(mer_len > 64) die("jellyfish-amd: mer length > 64 is not built yet");
-  if(text) out_counter_len = 8;   // text counts are not saturated (text_dumper.hpp:18-20)
-
-  mer_dna::k(mer_len);
-  header.canonical(canonical);
-  std::unique_ptr<mer_hash> ary;
-  try {
-    ary.reset(new mer_hash(size, mer_len * 2, counter_len, threads, reprobes, canonical, device, out_counter_len));
-  } catch(std::exception& e) { die(std::string("Failed to allocate the hash: ") + e.what()); }
-  if(disk) ary->do_size_doubling(false);
-
-  // Bloom counter read from file to filter out low frequency k-mers, two pass algorithm
-  // (load_bloom_filter, count_main.cc:191-206,313-316)
-  jfgpu_bloom* bc = nullptr;
-  if(!bc_path.empty()) {
-    std::ifstream in(bc_path, std::ios::in | std::ios::binary);
-    file_header bh(in);
-    if(!in.good()) die("Failed to parse bloom filter file '" + bc_path + "'");
-    if(bh.format() != "bloomcounter") die("Invalid format '" + bh.format() + "'. Expected 'bloomcounter'");
-    if(bh.key_len() != mer_len * 2) die("Invalid mer length in bloom filter");
-    header_matrix m1 = bh.matrix(1), m2 = bh.matrix(2);
-    jfgpu_bloom_params bp;
-    memset(&bp, 0, sizeof bp);
-    bp.k = mer_len; bp.canonical = canonical; bp.m = bh.size(); bp.nb_hashes = (uint32_t)bh.nb_hashes(); bp.device = device;
-    bp.matrix1 = m1.columns.data(); bp.matrix2 = m2.columns.data();
-    if(jfgpu_bc_create(&bp, &bc)) die(std::string("Failed to create the bloom filter: ") + jfgpu_last_error());
-    std::vector<uint8_t> body(bh.size() / 5 + (bh.size() % 5 != 0));
-    in.read((char*)body.data(), body.size());
-    if(!in.good()) die("Bloom filter file is truncated");
-    if(jfgpu_bc_load(bc, body.data()) || jfgpu_attach_bloom(ary->handle(), bc)) die(jfgpu_last_error());
-  }
-
-  std::unique_ptr<dumper_base> dumper;
-  if(text) dumper.reset(new text_dumper(threads, output.c_str(), &header));
-  else dumper.reset(new binary_dumper(out_counter_len, ary->key_len(), threads, output.c_str(), &header));
-  const double init_s = seconds_since(start_time);
-
-  auto count_start = std::chrono::steady_clock::now();
-  double parse_ms = 0; size_t fallback_bytes = 0;
-  {   // size the device workspace for the whole input up front (file sizes are an upper bound of the sequence)
-    uint64_t total = 0;
-    for(const auto& f : files) { struct stat st; if(stat(f.c_str(), &st) == 0 && S_ISREG(st.st_mode)) total += (uint64_t)st.st_size; }
-    if(!host_parse && total > ((uint64_t)64 << 20)) ary->expect_input(std::min<uint64_t>(total, (uint64_t)12 << 30));
-  }
-  auto feed = [&](const std::vector<std::string>& paths) {
-    if(host_parse) {
-      sequence_parser parser(mer_len);
-      for(const auto& f : paths)
-        parser.parse_file(f.c_str(), [&](const char* buf, size_t n) { ary->count_sequence(buf, n); });
-    } else {
-      device_sequence_parser parser(mer_len, device);
-      for(const auto& f : paths)
-        parser.parse_file(f.c_str(), [&](const char* d_buf, size_t n) { ary->count_sequence_dev(d_buf, n); },
-                          [&](const char* buf, size_t n) { ary->count_sequence(buf, n); }, [&]() { ary->wait_consumed(); });
-      parse_ms += parser.device_ms(); fallback_bytes += parser.host_fallback_bytes();
-    }
-    ary->done();
-  };
-  try {
-    if(!if_files.empty()) {   // count_main.cc:289-295: prime the hash with the --if mers, then only update
-      ary->set_operation(mer_hash::PRIME);
-      feed(if_files);
-      ary->set_operation(mer_hash::UPDATE);
-    }
-    feed(files);
-    if(!generator.empty()) {
-      feed_generators(generator, shell, mer_len, [&](const char* buf, size_t n) { ary->count_sequence(buf, n); });
-      ary->done();
-    }
-  } catch(std::exception& e) { die(e.what()); }
-  const double count_s = seconds_since(count_start);
-
-  auto write_start = std::chrono::steady_clock::now();
-  if(!no_write) {
-    try {
-      dumper->one_file(true);
-      if(lower_given) dumper->min(lower);
-      if(upper_given) dumper->max(upper);
-      dumper->dump(ary->ary());
-    } catch(std::exception& e) { die(e.what()); }
-  }
-  const double write_s = seconds_since(write_start);
-
-  if(bc) { jfgpu_attach_bloom(ary->handle(), nullptr); jfgpu_bc_destroy(bc); }
-
-  if(!timing.empty()) {   // count_main.cc:375-382
-    std::ofstream tf(timing);
-    tf << "Init     " << init_s << "\n"
-       << "Counting " << count_s << "\n"
-       << "Writing  " << write_s << "\n";
-    if(!host_parse && getenv("JFGPU_TIMING_DETAIL"))     // extra lines only on request: the file keeps the reference's three
-      tf << "DeviceParse " << parse_ms / 1e3 << "\n" << "HostParsedBytes " << fallback_bytes << "\n";
-  }
-  return 0;
-}
-
-
-// ---------------------------------------------------------------- bc  (sub_commands/bc_main.cc:84-161)
-int bc_main(int argc, char* argv[]) {
-  auto start_time = std::chrono::steady_clock::now();
-  file_header header;
-  header.fill_standard();
-  header.set_cmdline(argc, argv);
-  unsigned mer_len = 0; uint64_t size = 0; double fpr = 0.001; bool canonical = false, size_given = false, host_parse = false;
-  int device = -1;
-  std::string output = "mer_bloom_filter", timing, generator, shell;
-  std::vector<std::string> files;
-  ArgCursor a{argc, argv};
-  for(; a.more(); ++a.i) {
-    if(a.is("-m", "--mer-len")) mer_len = (unsigned)strtoul(a.value("-m", "--mer-len").c_str(), 0, 10);
-    else if(a.is("-s", "--size")) { size = parse_suffix(a.value("-s", "--size"), "-s"); size_given = true; }
-    else if(a.is("-f", "--fpr")) fpr = atof(a.value("-f", "--fpr").c_str());
-    else if(a.is("-t", "--threads")) (void)a.value("-t", "--threads");
-    else if(a.is("-F", "--Files")) (void)a.value("-F", "--Files");
-    else if(a.is("-o", "--output")) output = a.value("-o", "--output");
-    else if(a.is("", "--timing")) timing = a.value("", "--timing");
-    else if(a.is("", "--device")) device = atoi(a.value("", "--device").c_str());
-    else if(a.cur() == "-C" || a.cur() == "--canonical") canonical = true;
-    else if(a.cur() == "--host-parse") host_parse = true;
-    else if(a.is("-g", "--generator")) generator = a.value("-g", "--generator");
-    else if(a.is("-G", "--Generators")) (void)a.value("-G", "--Generators");
-    else if(a.is("-S", "--shell")) shell = a.value("-S", "--shell");
-    else if(a.cur().size() > 1 && a.cur()[0] == '-') die("Unknown option '" + a.cur() + "'");
-    else files.push_back(a.cur());
-  }
-  if(!mer_len) die("Error: mandatory switch missing: -m, --mer-len");
-  if(!size_given) die("Error: mandatory switch missing: -s, --size");
-  if(files.empty() && generator.empty()) die("Error: at least 1 file argument is required");
-  if(mer_len > 64) die("jellyfish-amd: mer length > 64 is not built yet");
-  mer_dna::k(mer_len);
-  header.canonical(canonical);
-  std::ofstream out(output, std::ios::binary | std::ios::trunc);
-  if(!out.good()) die("Can't open output file '" + output + "'");
-  jfgpu_bloom_params bp;
-  memset(&bp, 0, sizeof bp);
-  bp.k = mer_len; bp.canonical = canonical; bp.device = device;
-  bp.m = jfgpu_bc_opt_m(fpr, size); bp.nb_hashes = jfgpu_bc_opt_k(fpr);
-  jfgpu_bloom* bc = nullptr;
-  if(jfgpu_bc_create(&bp, &bc)) die(std::string("Failed to create the bloom filter: ") + jfgpu_last_error());
-  uint64_t m = 0, nbytes = 0; uint32_t nh = 0;
-  header_matrix m1, m2;
-  m1.r = m2.r = 64; m1.c = m2.c = 2 * mer_len; m1.columns.assign(m1.c, 0); m2.columns.assign(m2.c, 0);
-  jfgpu_bc_get_info(bc, &m, &nh, &nbytes, m1.columns.data(), m2.columns.data());
-  header.format("bloomcounter");
-  header.key_len(mer_len * 2);
-  header.matrix(m1, 1);
-  header.matrix(m2, 2);
-  header.size(m);
-  header.nb_hashes(nh);
-  header.write(out);
-  const double init_s = seconds_since(start_time);
-  auto count_start = std::chrono::steady_clock::now();
-  try {
-    auto host_sink = [&](const char* buf, size_t n) { if(jfgpu_bc_insert_ascii(bc, buf, n)) throw std::runtime_error(jfgpu_last_error()); };
-    if(host_parse) {
-      sequence_parser parser(mer_len);
-      for(const auto& f : files) parser.parse_file(f.c_str(), host_sink);
-    } else {
-      device_sequence_parser parser(mer_len, device);
-      for(const auto& f : files)
-        parser.parse_file(f.c_str(),
-                          [&](const char* d_buf, size_t n) { if(jfgpu_bc_insert_ascii_dev(bc, d_buf, n)) throw std::runtime_error(jfgpu_last_error()); },
-                          host_sink, [&]() { if(jfgpu_bc_sync(bc, nullptr)) throw std::runtime_error(jfgpu_last_error()); });
-    }
-    if(!generator.empty()) feed_generators(generator, shell, mer_len, host_sink);
-    if(jfgpu_bc_sync(bc, nullptr)) throw std::runtime_error(jfgpu_last_error());
-  } catch(std::exception& e) { die(e.what()); }
-  const double count_s = seconds_since(count_start);
-  auto write_start = std::chrono::steady_clock::now();
-  std::vector<uint8_t> body(nbytes);
-  if(jfgpu_bc_read(bc, body.data())) die(jfgpu_last_error());
-  out.write((const char*)body.data(), body.size());
-  out.close();
-  jfgpu_bc_destroy(bc);
-  if(!timing.empty()) {
-    std::ofstream tf(timing);
-    tf << "Init     " << init_s << "\n" << "Counting " << count_s << "\n" << "Writing  " << seconds_since(write_start) << "\n";
-  }
-  return 0;
-}
-
 // ---------------------------------------------------------------- readers
 struct db_file {
   std::ifstream is;
@@ -493,6 +210,304 @@ int merge_main(int argc, char* argv[]) {
   const uint64_t max = upper_given ? upper : std::numeric_limits<uint64_t>::max();
   const int op = jaccard ? 3 : max_flag ? 2 : min_flag ? 1 : 0;
   try { merge_files(inputs, output, out_header, min, max, op); } catch(MergeError& e) { die(e.what()); }
+  return 0;
+}
+
+// -g / -S: every line of the file is a shell command whose standard output is a fasta / fastq stream
+// (lib/generator_manager.cc runs them through named pipes; here each is read through a pipe in turn).  Blank
+// lines and # comments are skipped (:223-226); a command that fails is an error.
+static void feed_generators(const std::string& generator, std::string shell, unsigned mer_len, const sequence_parser::sink_type& sink) {
+  std::ifstream gf(generator);
+  if(!gf.good()) die("Can't open generator file '" + generator + "'");
+  if(shell.empty()) { const char* e = getenv("SHELL"); shell = e && *e ? e : "/bin/sh"; }
+  sequence_parser parser(mer_len);
+  std::string cmd, data;
+  while(std::getline(gf, cmd)) {
+    const size_t first = cmd.find_first_not_of(" \t\n\v\f\r");
+    if(first == std::string::npos || cmd[first] == '#') continue;
+    int fds[2];
+    if(pipe(fds) != 0) die("pipe() failed");
+    const pid_t pid = fork();
+    if(pid < 0) die("fork() failed");
+    if(pid == 0) {
+      close(fds[0]); dup2(fds[1], 1); close(fds[1]);
+      execl(shell.c_str(), shell.c_str(), "-c", cmd.c_str(), (char*)0);
+      _exit(127);
+    }
+    close(fds[1]);
+    data.clear();
+    char tmp[1 << 16]; ssize_t r;
+    while((r = read(fds[0], tmp, sizeof tmp)) > 0) data.append(tmp, (size_t)r);
+    close(fds[0]);
+    int status = 0;
+    waitpid(pid, &status, 0);
+    if(!WIFEXITED(status) || WEXITSTATUS(status) != 0) die("Generator command failed: " + cmd);
+    parser.parse_memory(data.data(), data.size(), sink);
+  }
+}
+
+// ---------------------------------------------------------------- count
+int count_main(int argc, char* argv[]) {
+  auto start_time = std::chrono::steady_clock::now();
+  file_header header;
+  header.fill_standard();
+  header.set_cmdline(argc, argv);
+
+  unsigned mer_len = 0, threads = 1, counter_len = 7, out_counter_len = 4, reprobes = 126, Files = 1;
+  uint64_t size = 0, lower = 0, upper = std::numeric_limits<uint64_t>::max();
+  bool size_given = false, lower_given = false, upper_given = false, canonical = false, text = false, no_write = false, disk = false, host_parse = false, no_merge = false, no_unlink = false;
+  int device = -1;
+  std::string output = "mer_counts.jf", timing, bc_path, generator, shell;
+  std::vector<std::string> files, if_files;
+  ArgCursor a{argc, argv};
+  for(; a.more(); ++a.i) {
+    if(a.is("-m", "--mer-len")) mer_len = (unsigned)strtoul(a.value("-m", "--mer-len").c_str(), 0, 10);
+    else if(a.is("-s", "--size")) { size = parse_suffix(a.value("-s", "--size"), "-s"); size_given = true; }
+    else if(a.is("-t", "--threads")) threads = (unsigned)strtoul(a.value("-t", "--threads").c_str(), 0, 10);
+    else if(a.is("", "--if")) if_files.push_back(a.value("", "--if"));
+    else if(a.is("-g", "--generator")) generator = a.value("-g", "--generator");
+    else if(a.is("-G", "--Generators")) (void)a.value("-G", "--Generators");     // generators run one after the other here
+    else if(a.is("-S", "--shell")) shell = a.value("-S", "--shell");
+    else if(a.is("-F", "--Files")) Files = (unsigned)strtoul(a.value("-F", "--Files").c_str(), 0, 10);
+    else if(a.is("-c", "--counter-len")) counter_len = (unsigned)strtoul(a.value("-c", "--counter-len").c_str(), 0, 10);
+    else if(a.is("", "--out-counter-len")) out_counter_len = (unsigned)strtoul(a.value("", "--out-counter-len").c_str(), 0, 10);
+    else if(a.is("-p", "--reprobes")) reprobes = (unsigned)strtoul(a.value("-p", "--reprobes").c_str(), 0, 10);
+    else if(a.is("-o", "--output")) output = a.value("-o", "--output");
+    else if(a.is("-L", "--lower-count")) { lower = strtoull(a.value("-L", "--lower-count").c_str(), 0, 10); lower_given = true; }
+    else if(a.is("-U", "--upper-count")) { upper = strtoull(a.value("-U", "--upper-count").c_str(), 0, 10); upper_given = true; }
+    else if(a.is("", "--timing")) timing = a.value("", "--timing");
+    else if(a.is("", "--device")) device = atoi(a.value("", "--device").c_str());
+    else if(a.is("", "--bc")) bc_path = a.value("", "--bc");
+    else if(a.cur() == "-C" || a.cur() == "--canonical") canonical = true;
+    else if(a.cur() == "--text") text = true;
+    else if(a.cur() == "--no-write") no_write = true;
+    else if(a.cur() == "--host-parse") host_parse = true;   // read the files with the host reader instead of the device parser
+    else if(a.cur() == "--disk") disk = true;   // do_size_doubling(false) (count_main.cc:276-277): a full table is written out as a sorted run
+    else if(a.cur() == "--no-merge") no_merge = true;
+    else if(a.cur() == "--no-unlink") no_unlink = true;
+    else if(a.is("", "--bf-size") || a.is("", "--bf-fp") || a.is("-Q", "--min-qual-char") ||
+            a.is("-q", "--min-quality") || a.is("", "--sam"))
+      die("Option '" + a.cur() + "' is not supported by jellyfish-amd yet");
+    else if(a.cur() == "-h" || a.cur() == "--help") {
+      std::cout << "Usage: jellyfish-amd count [options] file:path+\n\n"
+                   "Count k-mers in fasta or fastq files on an MI355X\n\n"
+                   " -m, --mer-len=uint32       *Length of mer\n"
+                   " -s, --size=uint64          *Initial hash size\n"
+                   " -t, --threads=uint32        Number of threads (1)\n"
+                   " -o, --output=string         Output file (mer_counts.jf)\n"
+                   " -c, --counter-len=Length    Length bits of counting field (7)\n"
+                   "     --out-counter-len=bytes Length in bytes of counter field in output (4)\n"
+                   " -C, --canonical             Count both strand, canonical representation (false)\n"
+                   " -p, --reprobes=uint32       Maximum number of reprobes (126)\n"
+                   " -L, --lower-count=uint64    Don't output k-mer with count < lower-count\n"
+                   " -U, --upper-count=uint64    Don't output k-mer with count > upper-count\n"
+                   "     --if=path               Count only the k-mers of these fasta / fastq files (repeatable)\n"
+                   " -g, --generator=path        File of commands generating fast[aq] (one per line, e.g. zcat reads.fa.gz)\n"
+                   " -S, --shell=string          Shell used to run generator commands ($SHELL or /bin/sh)\n"
+                   "     --text                  Dump in text format (false)\n"
+                   "     --timing=Timing file    Print timing information\n"
+                   "     --device=int            HIP device ordinal (current)\n"
+                   "     --host-parse            Parse the sequence files on the host (default: on the device)\n";
+      return 0;
+    } else if(a.cur().size() > 1 && a.cur()[0] == '-' && a.cur() != "-") die("Unknown option '" + a.cur() + "'");
+    else files.push_back(a.cur());
+  }
+  if(!mer_len) die("Error: mandatory switch missing: -m, --mer-len");
+  if(!size_given) die("Error: mandatory switch missing: -s, --size");
+  if(files.empty() && generator.empty()) die("Error: at least 1 file argument is required");
+  (void)threads; (void)counter_len; (void)reprobes; (void)Files;
+  if(mer_len > 64) die("jellyfish-amd: mer length > 64 is not built yet");
+  if(text) out_counter_len = 8;   // text counts are not saturated (text_dumper.hpp:18-20)
+
+  mer_dna::k(mer_len);
+  header.canonical(canonical);
+  std::unique_ptr<mer_hash> ary;
+  try {
+    ary.reset(new mer_hash(size, mer_len * 2, counter_len, threads, reprobes, canonical, device, out_counter_len));
+  } catch(std::exception& e) { die(std::string("Failed to allocate the hash: ") + e.what()); }
+  if(disk) ary->do_size_doubling(false);
+
+  // Bloom counter read from file to filter out low frequency k-mers, two pass algorithm
+  // (load_bloom_filter, count_main.cc:191-206,313-316)
+  jfgpu_bloom* bc = nullptr;
+  if(!bc_path.empty()) {
+    std::ifstream in(bc_path, std::ios::in | std::ios::binary);
+    file_header bh(in);
+    if(!in.good()) die("Failed to parse bloom filter file '" + bc_path + "'");
+    if(bh.format() != "bloomcounter") die("Invalid format '" + bh.format() + "'. Expected 'bloomcounter'");
+    if(bh.key_len() != mer_len * 2) die("Invalid mer length in bloom filter");
+    header_matrix m1 = bh.matrix(1), m2 = bh.matrix(2);
+    jfgpu_bloom_params bp;
+    memset(&bp, 0, sizeof bp);
+    bp.k = mer_len; bp.canonical = canonical; bp.m = bh.size(); bp.nb_hashes = (uint32_t)bh.nb_hashes(); bp.device = device;
+    bp.matrix1 = m1.columns.data(); bp.matrix2 = m2.columns.data();
+    if(jfgpu_bc_create(&bp, &bc)) die(std::string("Failed to create the bloom filter: ") + jfgpu_last_error());
+    std::vector<uint8_t> body(bh.size() / 5 + (bh.size() % 5 != 0));
+    in.read((char*)body.data(), body.size());
+    if(!in.good()) die("Bloom filter file is truncated");
+    if(jfgpu_bc_load(bc, body.data()) || jfgpu_attach_bloom(ary->handle(), bc)) die(jfgpu_last_error());
+  }
+
+  std::unique_ptr<dumper_base> dumper;
+  if(text) dumper.reset(new text_dumper(threads, output.c_str(), &header));
+  else dumper.reset(new binary_dumper(out_counter_len, ary->key_len(), threads, output.c_str(), &header));
+  if(disk && !no_write) {      // intermediate sorted runs <output>0, <output>1, ... (dumper.hpp:45-61), merged at the end
+    dumper->one_file(false);
+    ary->on_full([&]() { dumper->dump(ary->ary()); });
+  }
+  const double init_s = seconds_since(start_time);
+
+  auto count_start = std::chrono::steady_clock::now();
+  double parse_ms = 0; size_t fallback_bytes = 0;
+  {   // size the device workspace for the whole input up front (file sizes are an upper bound of the sequence)
+    uint64_t total = 0;
+    for(const auto& f : files) { struct stat st; if(stat(f.c_str(), &st) == 0 && S_ISREG(st.st_mode)) total += (uint64_t)st.st_size; }
+    if(!host_parse && total > ((uint64_t)64 << 20)) ary->expect_input(std::min<uint64_t>(total, (uint64_t)12 << 30));
+  }
+  auto feed = [&](const std::vector<std::string>& paths) {
+    if(host_parse) {
+      sequence_parser parser(mer_len);
+      for(const auto& f : paths)
+        parser.parse_file(f.c_str(), [&](const char* buf, size_t n) { ary->count_sequence(buf, n); });
+    } else {
+      device_sequence_parser parser(mer_len, device);
+      for(const auto& f : paths)
+        parser.parse_file(f.c_str(), [&](const char* d_buf, size_t n) { ary->count_sequence_dev(d_buf, n); },
+                          [&](const char* buf, size_t n) { ary->count_sequence(buf, n); }, [&]() { ary->wait_consumed(); });
+      parse_ms += parser.device_ms(); fallback_bytes += parser.host_fallback_bytes();
+    }
+    ary->done();
+  };
+  try {
+    if(!if_files.empty()) {   // count_main.cc:289-295: prime the hash with the --if mers, then only update
+      ary->set_operation(mer_hash::PRIME);
+      feed(if_files);
+      ary->set_operation(mer_hash::UPDATE);
+    }
+    feed(files);
+    if(!generator.empty()) {
+      feed_generators(generator, shell, mer_len, [&](const char* buf, size_t n) { ary->count_sequence(buf, n); });
+      ary->done();
+    }
+  } catch(std::exception& e) { die(e.what()); }
+  const double count_s = seconds_since(count_start);
+
+  auto write_start = std::chrono::steady_clock::now();
+  if(!no_write) {
+    try {
+      if(dumper->nb_files() == 0) {      // no intermediate files: dump directly into the output file (count_main.cc:348-355)
+        dumper->one_file(true);
+        if(lower_given) dumper->min(lower);
+        if(upper_given) dumper->max(upper);
+        dumper->dump(ary->ary());
+      } else {                           // a last run, then one round of merging (:356-371)
+        dumper->dump(ary->ary());
+        if(!no_merge) {
+          const std::vector<std::string> parts = dumper->file_names();
+          try { merge_files(parts, output, header, lower_given ? lower : 0, upper_given ? upper : std::numeric_limits<uint64_t>::max(), 0); }
+          catch(MergeError& e) { die(e.what()); }
+          if(!no_unlink) for(const auto& f : parts) unlink(f.c_str());
+        }
+      }
+    } catch(std::exception& e) { die(e.what()); }
+  }
+  const double write_s = seconds_since(write_start);
+
+  if(bc) { jfgpu_attach_bloom(ary->handle(), nullptr); jfgpu_bc_destroy(bc); }
+
+  if(!timing.empty()) {   // count_main.cc:375-382
+    std::ofstream tf(timing);
+    tf << "Init     " << init_s << "\n"
+       << "Counting " << count_s << "\n"
+       << "Writing  " << write_s << "\n";
+    if(!host_parse && getenv("JFGPU_TIMING_DETAIL"))     // extra lines only on request: the file keeps the reference's three
+      tf << "DeviceParse " << parse_ms / 1e3 << "\n" << "HostParsedBytes " << fallback_bytes << "\n";
+  }
+  return 0;
+}
+
+
+// ---------------------------------------------------------------- bc  (sub_commands/bc_main.cc:84-161)
+int bc_main(int argc, char* argv[]) {
+  auto start_time = std::chrono::steady_clock::now();
+  file_header header;
+  header.fill_standard();
+  header.set_cmdline(argc, argv);
+  unsigned mer_len = 0; uint64_t size = 0; double fpr = 0.001; bool canonical = false, size_given = false, host_parse = false;
+  int device = -1;
+  std::string output = "mer_bloom_filter", timing, generator, shell;
+  std::vector<std::string> files;
+  ArgCursor a{argc, argv};
+  for(; a.more(); ++a.i) {
+    if(a.is("-m", "--mer-len")) mer_len = (unsigned)strtoul(a.value("-m", "--mer-len").c_str(), 0, 10);
+    else if(a.is("-s", "--size")) { size = parse_suffix(a.value("-s", "--size"), "-s"); size_given = true; }
+    else if(a.is("-f", "--fpr")) fpr = atof(a.value("-f", "--fpr").c_str());
+    else if(a.is("-t", "--threads")) (void)a.value("-t", "--threads");
+    else if(a.is("-F", "--Files")) (void)a.value("-F", "--Files");
+    else if(a.is("-o", "--output")) output = a.value("-o", "--output");
+    else if(a.is("", "--timing")) timing = a.value("", "--timing");
+    else if(a.is("", "--device")) device = atoi(a.value("", "--device").c_str());
+    else if(a.cur() == "-C" || a.cur() == "--canonical") canonical = true;
+    else if(a.cur() == "--host-parse") host_parse = true;
+    else if(a.is("-g", "--generator")) generator = a.value("-g", "--generator");
+    else if(a.is("-G", "--Generators")) (void)a.value("-G", "--Generators");
+    else if(a.is("-S", "--shell")) shell = a.value("-S", "--shell");
+    else if(a.cur().size() > 1 && a.cur()[0] == '-') die("Unknown option '" + a.cur() + "'");
+    else files.push_back(a.cur());
+  }
+  if(!mer_len) die("Error: mandatory switch missing: -m, --mer-len");
+  if(!size_given) die("Error: mandatory switch missing: -s, --size");
+  if(files.empty() && generator.empty()) die("Error: at least 1 file argument is required");
+  if(mer_len > 64) die("jellyfish-amd: mer length > 64 is not built yet");
+  mer_dna::k(mer_len);
+  header.canonical(canonical);
+  std::ofstream out(output, std::ios::binary | std::ios::trunc);
+  if(!out.good()) die("Can't open output file '" + output + "'");
+  jfgpu_bloom_params bp;
+  memset(&bp, 0, sizeof bp);
+  bp.k = mer_len; bp.canonical = canonical; bp.device = device;
+  bp.m = jfgpu_bc_opt_m(fpr, size); bp.nb_hashes = jfgpu_bc_opt_k(fpr);
+  jfgpu_bloom* bc = nullptr;
+  if(jfgpu_bc_create(&bp, &bc)) die(std::string("Failed to create the bloom filter: ") + jfgpu_last_error());
+  uint64_t m = 0, nbytes = 0; uint32_t nh = 0;
+  header_matrix m1, m2;
+  m1.r = m2.r = 64; m1.c = m2.c = 2 * mer_len; m1.columns.assign(m1.c, 0); m2.columns.assign(m2.c, 0);
+  jfgpu_bc_get_info(bc, &m, &nh, &nbytes, m1.columns.data(), m2.columns.data());
+  header.format("bloomcounter");
+  header.key_len(mer_len * 2);
+  header.matrix(m1, 1);
+  header.matrix(m2, 2);
+  header.size(m);
+  header.nb_hashes(nh);
+  header.write(out);
+  const double init_s = seconds_since(start_time);
+  auto count_start = std::chrono::steady_clock::now();
+  try {
+    auto host_sink = [&](const char* buf, size_t n) { if(jfgpu_bc_insert_ascii(bc, buf, n)) throw std::runtime_error(jfgpu_last_error()); };
+    if(host_parse) {
+      sequence_parser parser(mer_len);
+      for(const auto& f : files) parser.parse_file(f.c_str(), host_sink);
+    } else {
+      device_sequence_parser parser(mer_len, device);
+      for(const auto& f : files)
+        parser.parse_file(f.c_str(),
+                          [&](const char* d_buf, size_t n) { if(jfgpu_bc_insert_ascii_dev(bc, d_buf, n)) throw std::runtime_error(jfgpu_last_error()); },
+                          host_sink, [&]() { if(jfgpu_bc_sync(bc, nullptr)) throw std::runtime_error(jfgpu_last_error()); });
+    }
+    if(!generator.empty()) feed_generators(generator, shell, mer_len, host_sink);
+    if(jfgpu_bc_sync(bc, nullptr)) throw std::runtime_error(jfgpu_last_error());
+  } catch(std::exception& e) { die(e.what()); }
+  const double count_s = seconds_since(count_start);
+  auto write_start = std::chrono::steady_clock::now();
+  std::vector<uint8_t> body(nbytes);
+  if(jfgpu_bc_read(bc, body.data())) die(jfgpu_last_error());
+  out.write((const char*)body.data(), body.size());
+  out.close();
+  jfgpu_bc_destroy(bc);
+  if(!timing.empty()) {
+    std::ofstream tf(timing);
+    tf << "Init     " << init_s << "\n" << "Counting " << count_s << "\n" << "Writing  " << seconds_since(write_start) << "\n";
+  }
   return 0;
 }
 

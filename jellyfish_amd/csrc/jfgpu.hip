@@ -95,6 +95,7 @@ struct jfgpu_table {
   uint64_t pending_bytes = 0;
   bool ref_matrix = false;       // default matrix family: the reference's (glibc random() stream kept in `glibc`)
   GlibcRandom glibc;
+  int (*spill_fn)(void*) = nullptr; void* spill_user = nullptr;     // jfgpu_set_spill
   int operation = 0;             // what count_ascii does with a k-mer: 0 add, 1 set (prime), 2 update_add (jfgpu_set_operation)
   int flush_groups = 1;          // P2 / tile-insert pipeline depth of a flush (JFGPU_FLUSH_GROUPS).  Measured: 8 groups on two
                                  // streams run P2 and T concurrently but no faster (both are LDS-bound), so one launch each is the default
@@ -223,13 +224,14 @@ int launch_count_chunk(jfgpu_table* t, const char* d_bases, size_t n) {
 // How many more k-mers may be enqueued before the table could exceed 80 % load, assuming every one
 // of them is new (an upper bound: duplicates are only discovered by inserting).
 uint64_t capacity_limit(const jfgpu_table* t) { return ((1ull << t->g.lsize_l) / 10) * 8; }
-bool capacity_managed(const jfgpu_table* t) { return t->grow_on && t->g.shard_bits == 0 && t->g.lsize_g < t->g.key_bits && (!t->wide || t->g.lsize_g < 48); }
+bool capacity_managed(const jfgpu_table* t) { return (t->grow_on || t->spill_fn) && t->g.shard_bits == 0 && t->g.lsize_g < t->g.key_bits && (!t->wide || t->g.lsize_g < 48); }
 
 // The size passed at creation is a hint (doc/Readme.md:67-72; hash_counter::handle_full_ary,
 // hash_counter.hpp:178-198): before enqueuing `incoming` potential new keys make sure they cannot
 // overflow the table -- measure the true occupancy when the running upper bound runs out, double the
 // table (cooperative rehash on the device) when it is really more than half full.  Returns the
 // number of k-mers that may be enqueued now (<= incoming, > 0).
+extern "C" int jfgpu_clear(jfgpu_table* t);
 int ensure_capacity(jfgpu_table* t, uint64_t incoming, uint64_t* allowed) {
   *allowed = incoming;
   if(!capacity_managed(t)) return JFGPU_OK;
@@ -243,6 +245,15 @@ int ensure_capacity(jfgpu_table* t, uint64_t incoming, uint64_t* allowed) {
     const bool really_full = t->occ_known > (1ull << t->g.lsize_l) / 2;
     if(!really_full && headroom >= min_piece) break;
     if(t->g.lsize_g >= t->g.key_bits) break;                             // 4^k positions: cannot fill up
+    if(!t->grow_on) {
+      // --disk (count_main.cc:276-277, hash_counter.hpp:178-198 with a dumper): the caller writes the table out
+      // as one sorted run, then it is emptied and counting goes on; the runs are merged at the end
+      rc = part_flush(t); if(rc) return rc;
+      rc = check_deferred(t); if(rc) return rc;
+      if(t->spill_fn(t->spill_user) != 0) return fail(JFGPU_E_INVALID, "the spill callback failed");
+      rc = jfgpu_clear(t); if(rc) return rc;
+      continue;
+    }
     rc = table_grow(t);
     if(rc < 0) break;            // no memory for a bigger table: carry on, "Hash full" if it really overflows
     if(rc) return rc;
@@ -928,6 +939,12 @@ int jfgpu_reserve(jfgpu_table* t, uint64_t input_bytes) {
   HIP_TRY(hipMemsetAsync(t->ws, 0, t->ws_cap, t->stream));
   if(!t->d_M1) { t->g1 = 2 * t->n_cu; HIP_TRY(hipMalloc((void**)&t->d_M1, (size_t)t->g1 * kMaxBuckets * sizeof(uint32_t))); }
   if(t->pg.b2 && !t->d_M2) HIP_TRY(hipMalloc((void**)&t->d_M2, (size_t)nb1 * 32 * nb2 * sizeof(uint32_t)));
+  return JFGPU_OK;
+}
+
+int jfgpu_set_spill(jfgpu_table* t, int (*fn)(void*), void* user) {
+  int rc = use(t); if(rc) return rc;
+  t->spill_fn = fn; t->spill_user = user;
   return JFGPU_OK;
 }
 

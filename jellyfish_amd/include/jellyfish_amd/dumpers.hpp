@@ -35,6 +35,7 @@ public:
   void min(uint64_t m) { min_ = m; }
   void max(uint64_t m) { max_ = m; }
   int nb_files() const { return nb_files_; }
+  const std::vector<std::string>& file_names() const { return file_names_; }    // dumper_t::file_names, dumper.hpp:80-87
   virtual void dump(hash_counter* ary) = 0;
 
 protected:
@@ -43,10 +44,12 @@ protected:
   uint64_t min_, max_;
   bool one_file_ = true;
   int nb_files_ = 0;
+  std::vector<std::string> file_names_;
   std::string next_path() {   // dumper.hpp:45-61: prefix itself when one_file, else prefix + index
     std::string p = prefix_;
     if(!one_file_) p += std::to_string(nb_files_);
     ++nb_files_;
+    file_names_.push_back(p);
     return p;
   }
 };

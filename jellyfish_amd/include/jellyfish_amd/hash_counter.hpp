@@ -9,6 +9,7 @@
 // (std::runtime_error("Hash full"), hash_counter.hpp:194-195; allocation failure,
 // large_hash_array.hpp:169-172).
 #pragma once
+#include <functional>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -79,6 +80,12 @@ public:
   void refresh_info() { jf_check(jfgpu_get_info(t_, &info_)); }
   // hash_counter::do_size_doubling (hash_counter.hpp:78-79)
   void do_size_doubling(bool v) { jf_check(jfgpu_set_growth(t_, v ? 1 : 0)); }
+  // hash_counter::dumper(d) (hash_counter.hpp:81): with doubling off, a table that fills up is handed to `spill`
+  // (which writes it out as one sorted run) and emptied, instead of failing with "Hash full".
+  void on_full(std::function<void()> spill) {
+    spill_ = std::move(spill);
+    jf_check(jfgpu_set_spill(t_, spill_ ? &hash_counter::spill_trampoline : nullptr, this));
+  }
 
   // file_header::update_from_ary (file_header.hpp:25-33)
   void update_header(file_header& h) {
@@ -156,6 +163,11 @@ public:
   void flush() { std::lock_guard<std::mutex> lock(mu_); flush_locked(); }
 
 private:
+  std::function<void()> spill_;
+  static int spill_trampoline(void* self) {
+    try { static_cast<hash_counter*>(self)->spill_(); return 0; } catch(std::exception& e) { fprintf(stderr, "%s\n", e.what()); return 1; }
+  }
+
   static constexpr size_t kBatch = 1 << 20;
   jfgpu_table* t_ = nullptr;
   jfgpu_info info_;

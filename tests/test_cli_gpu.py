@@ -357,3 +357,38 @@ def test_bloom_counter_two_word_keys_and_reference_golden(cli, tmp_path):
     subprocess.check_call([O.REF_JF, "count", "-m", "40", "-s", "1000000", "-C", "--bc", "none.bc", "-o", "ref_none.jf", "seq1m_0.fa"], cwd=d)
     assert sorted(subprocess.check_output([cli, "dump", "-c", "none.jf"], cwd=d).splitlines()) == \
         sorted(subprocess.check_output([O.REF_JF, "dump", "-c", "ref_none.jf"], cwd=d).splitlines())
+
+
+def test_disk_spill_and_merge_reproduce_reference_goldens(cli, tmp_path):
+    """tests/merge.sh:21-37: with --disk a table that fills up is written out as sorted runs <output>0, <output>1, ...
+    which are merged at the end (or left alone with --no-merge and merged by the `merge` verb); binary and text;
+    every route gives the histogram of the in-memory count (md5 72f1913b...).  tests/large_key.sh's --disk idea for
+    one-word keys too: -s 2k --disk equals a big table."""
+    import glob
+    import hashlib
+    if not os.access(O.REF_GEN, os.X_OK):
+        pytest.skip("oracle/_ref not built")
+    g = MANIFEST["reference_md5"]
+    d = str(tmp_path)
+    subprocess.check_call([O.REF_GEN, "-o", "seq1m"] + g["seq1m"], cwd=d)
+    files = ["seq1m_0.fa", "seq1m_1.fa", "seq1m_0.fa", "seq1m_2.fa", "seq1m_2.fa"]
+    histo_md5 = lambda jf: hashlib.md5(subprocess.check_output([cli, "histo", jf], cwd=d)).hexdigest()
+    gold = "72f1913b3503114c7df7a4dcc68ce867"
+    subprocess.check_call([cli, "count", "-t", "4", "-o", "parts", "-s", "1M", "--disk", "--no-merge", "-C", "-m", "40"] + files, cwd=d)
+    parts = sorted(glob.glob(os.path.join(d, "parts[0-9]*")))
+    assert len(parts) >= 3                                                     # 3 M distinct k-mers through a 1 M table
+    subprocess.check_call([cli, "merge", "-o", "merged.jf"] + parts, cwd=d)
+    assert histo_md5("merged.jf") == gold
+    subprocess.check_call([cli, "count", "-t", "4", "-o", "auto.jf", "-s", "1M", "--disk", "-C", "-m", "40"] + files, cwd=d)
+    assert histo_md5("auto.jf") == gold and not glob.glob(os.path.join(d, "auto.jf[0-9]*"))   # runs merged and unlinked
+    subprocess.check_call([cli, "count", "-t", "4", "-o", "text.jf", "-s", "1M", "--text", "--disk", "-C", "-m", "40"] + files, cwd=d)
+    assert histo_md5("text.jf") == gold
+    if O.have_ref():                                                           # the reference reads the merged file
+        assert hashlib.md5(subprocess.check_output([O.REF_JF, "histo", "auto.jf"], cwd=d)).hexdigest() == gold
+        assert subprocess.check_output([O.REF_JF, "dump", "--check-order", "auto.jf"], cwd=d).decode().startswith("ORDER OK")
+    # one-word keys, -L/-U applied at merge time (count_main.cc:360-363)
+    subprocess.check_call([cli, "count", "-o", "big.jf", "-s", "8M", "-C", "-m", "21", "-L", "2"] + files, cwd=d)
+    subprocess.check_call([cli, "count", "-o", "small.jf", "-s", "20k", "--disk", "-C", "-m", "21", "-L", "2"] + files, cwd=d)
+    a = sorted(subprocess.check_output([cli, "dump", "-c", "big.jf"], cwd=d).splitlines())
+    b = sorted(subprocess.check_output([cli, "dump", "-c", "small.jf"], cwd=d).splitlines())
+    assert a == b and len(a) > 0
