@@ -238,6 +238,21 @@ int ensure_capacity(jfgpu_table* t, uint64_t incoming, uint64_t* allowed) {
   uint64_t limit = capacity_limit(t);
   if(t->occ_known + t->fed_since + incoming <= limit) { t->fed_since += incoming; return JFGPU_OK; }
   int rc = measure_occupancy(t); if(rc) return rc;
+  if(!t->grow_on) {
+    // --disk (count_main.cc:276-277, hash_counter.hpp:178-198 with a dumper): when what is left would not take a
+    // useful piece, the caller writes the table out as one sorted run, the table is emptied and counting goes on
+    // (the runs are merged at the end).  Pieces never exceed the room left, so nothing is ever dropped.
+    uint64_t room = limit > t->occ_known ? limit - t->occ_known : 0;
+    if(room < std::min<uint64_t>(incoming, std::max<uint64_t>(limit / 8, 1))) {
+      rc = check_deferred(t); if(rc) return rc;
+      if(t->spill_fn(t->spill_user) != 0) return fail(JFGPU_E_INVALID, "the spill callback failed");
+      rc = jfgpu_clear(t); if(rc) return rc;
+      room = capacity_limit(t);
+    }
+    *allowed = std::max<uint64_t>(1, std::min<uint64_t>(incoming, room));
+    t->fed_since += *allowed;
+    return JFGPU_OK;
+  }
   const uint64_t min_piece = std::min<uint64_t>(incoming, 65536);      // never enqueue less than this at a time
   while(true) {
     limit = capacity_limit(t);
@@ -245,15 +260,6 @@ int ensure_capacity(jfgpu_table* t, uint64_t incoming, uint64_t* allowed) {
     const bool really_full = t->occ_known > (1ull << t->g.lsize_l) / 2;
     if(!really_full && headroom >= min_piece) break;
     if(t->g.lsize_g >= t->g.key_bits) break;                             // 4^k positions: cannot fill up
-    if(!t->grow_on) {
-      // --disk (count_main.cc:276-277, hash_counter.hpp:178-198 with a dumper): the caller writes the table out
-      // as one sorted run, then it is emptied and counting goes on; the runs are merged at the end
-      rc = part_flush(t); if(rc) return rc;
-      rc = check_deferred(t); if(rc) return rc;
-      if(t->spill_fn(t->spill_user) != 0) return fail(JFGPU_E_INVALID, "the spill callback failed");
-      rc = jfgpu_clear(t); if(rc) return rc;
-      continue;
-    }
     rc = table_grow(t);
     if(rc < 0) break;            // no memory for a bigger table: carry on, "Hash full" if it really overflows
     if(rc) return rc;

@@ -86,8 +86,12 @@ def test_count_multiple_files_and_hash_full(cli, tmp_path):
     assert dict((a, int(c)) for a, c in (l.split() for l in subprocess.check_output([cli, "dump", "-c", small]).decode().splitlines())) == exp
     if O.have_ref():
         assert subprocess.check_output([O.REF_JF, "dump", "--check-order", small]).decode().startswith("ORDER OK %d" % len(exp))
-    # ... unless doubling is switched off (--disk, count_main.cc:276-277): then "Hash full" (hash_counter.hpp:194-195), exit code 1
-    r = subprocess.run([cli, "count", "-m", "21", "-C", "-s", "1k", "--disk", "-o", str(tmp_path / "full.jf"), fa], capture_output=True)
+    # ... and with doubling switched off (--disk, count_main.cc:276-277) it is written out in sorted runs that are merged at the end
+    disk = str(tmp_path / "disk.jf")
+    subprocess.run([cli, "count", "-m", "21", "-C", "-s", "1k", "--disk", "-o", disk, fa, fq], check=True, timeout=120)
+    assert dict((a, int(c)) for a, c in (l.split() for l in subprocess.check_output([cli, "dump", "-c", disk]).decode().splitlines())) == exp
+    # nowhere to spill to (--no-write): "Hash full" (hash_counter.hpp:194-195), exit code 1
+    r = subprocess.run([cli, "count", "-m", "21", "-C", "-s", "1k", "--disk", "--no-write", "-o", str(tmp_path / "full.jf"), fa], capture_output=True, timeout=120)
     assert r.returncode == 1 and b"Hash full" in r.stderr
     r = subprocess.run([cli, "count", "-m", "21", "-s", "64k", "-o", str(tmp_path / "bad.jf"), os.path.join(GOLD, "manifest.json")],
                        capture_output=True)
