@@ -619,11 +619,21 @@ int query_main(int argc, char* argv[]) {
   file_header header(in);
   if(!in.good()) die("Failed to parse header of file '" + db + "'");
   mer_dna::k(header.key_len() / 2);
-  if(header.format() != binary_dumper::format)
+  if(header.format() != binary_dumper::format && header.format() != "bloomcounter")
     die("Unsupported format '" + header.format() + "'. Must be a bloom counter or binary list.");
   mapped_file map(db.c_str());
-  binary_query bq(map.base() + header.offset(), header.key_len(), header.counter_len(), header.matrix(), header.size() - 1,
-                  map.length() - header.offset());
+  // the two kinds of database answer the same question, "check(mer)" (query_main.cc:99-117)
+  std::unique_ptr<binary_query> bin;
+  std::unique_ptr<bloom_query> bloom;
+  try {
+    if(header.format() == "bloomcounter")
+      bloom.reset(new bloom_query(map.base() + header.offset(), map.length() - header.offset(), header.size(), (unsigned)header.nb_hashes(),
+                                  header.matrix(1), header.matrix(2)));
+    else
+      bin.reset(new binary_query(map.base() + header.offset(), header.key_len(), header.counter_len(), header.matrix(), header.size() - 1,
+                                 map.length() - header.offset()));
+  } catch(std::exception& e) { die(e.what()); }
+  struct { binary_query* b; bloom_query* f; uint64_t check(const mer_dna& m) const { return b ? b->check(m) : f->check(m); } } bq{bin.get(), bloom.get()};
   const bool canonical = header.canonical();
   const unsigned k = mer_dna::k();
   // query_from_sequence (query_main.cc:44-51): every (canonical) k-mer of the files, in order

@@ -273,4 +273,32 @@ private:
   uint64_t key_pos(const mer_dna& key) const { return m_.times(key.data()) & mask_; }
 };
 
+// Read-only view of a bloomcounter file body (bloom_counter2::check__, bloom_counter2.hpp:109-142, with the
+// hash pair of mer_dna_bloom_counter.hpp:19-34): cell_i = (h0 % m + i * (h1 % m)) % m, base-3 digit (p % 5) of
+// byte (p / 5), result = the minimum digit over the nb_hashes cells (0, 1 or 2).
+class bloom_query {
+public:
+  bloom_query(const char* data, size_t nbytes, uint64_t m, unsigned nb_hashes, const header_matrix& m1, const header_matrix& m2)
+      : data_((const unsigned char*)data), m_(m), k_(nb_hashes), m1_(m1), m2_(m2) {
+    if(nbytes < m / 5 + (m % 5 != 0)) throw std::length_error("Bloom counter file is truncated");
+  }
+  unsigned check(const mer_dna& key) const {
+    static const unsigned pow3[5] = {1, 3, 9, 27, 81};
+    const uint64_t base = m1_.times(key.data()) % m_, inc = m2_.times(key.data()) % m_;
+    uint64_t p = base;
+    unsigned res = 2;
+    for(unsigned i = 0; i < k_; ++i) {
+      const unsigned d = (data_[p / 5] / pow3[p % 5]) % 3;
+      res = std::min(res, d);
+      p += inc; if(p >= m_) p -= m_;
+    }
+    return res;
+  }
+private:
+  const unsigned char* data_;
+  uint64_t m_;
+  unsigned k_;
+  header_matrix m1_, m2_;
+};
+
 }  // namespace jellyfish_amd

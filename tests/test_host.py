@@ -207,3 +207,28 @@ def test_merge_verb_reproduces_reference_goldens(cli, tmp_path):
     assert lines and all(l.endswith(" 2") for l in lines)
     r = subprocess.run([cli, "merge", "-o", "bad.jf", "m9_2.jf", "p0.jf"], cwd=d, capture_output=True)
     assert r.returncode != 0 and b"different key lengths" in r.stderr
+
+
+@pytest.mark.parametrize("name", ["bc_k21C", "bc_k31"])
+def test_query_on_bloomcounter_files(cli, name):
+    """`query` on a bloomcounter file written by the reference (query_main.cc:99-104): per k-mer the minimum
+    base-3 digit of its cells, as the oracle's restatement of bloom_counter2::check computes it."""
+    gold = os.path.join(ROOT, "tests", "golden")
+    case = next(c for c in json.load(open(os.path.join(gold, "manifest.json")))["bloom"] if c["name"] == name)
+    bc = os.path.join(gold, case["ref_bc"])
+    hdr, off = _header_of(bc)
+    body = np.frombuffer(open(bc, "rb").read()[off:], dtype=np.uint8)
+    k, can = case["k"], case["canonical"]
+    assert hdr["canonical"] == can
+    seq = O.parse_file(open(os.path.join(gold, case["input"]), "rb").read())
+    kmers = O.extract(seq, k, can)[:3000]
+    m1 = np.array(hdr["matrix1"]["columns"], dtype=np.uint64)
+    m2 = np.array(hdr["matrix2"]["columns"], dtype=np.uint64)
+    h0, h1 = O.matrix_times(m1, 64, 2 * k, kmers), O.matrix_times(m2, 64, 2 * k, kmers)
+    L = O.lib()
+    want = ["%s %d" % (O.to_str(kmers[i], k), L.jfo_bc_check(body.ctypes.data, hdr["size"], hdr["nb_hashes"], int(h0[i]), int(h1[i])))
+            for i in range(len(kmers))]
+    got = subprocess.check_output([cli, "query", bc] + [w.split()[0] for w in want[:200]]).decode().splitlines()
+    assert got == want[:200]
+    got = subprocess.check_output([cli, "query", "-s", os.path.join(gold, case["input"]), bc]).decode().splitlines()
+    assert got[:3000] == want and {l.split()[1] for l in got} <= {"0", "1", "2"}
