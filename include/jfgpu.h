@@ -219,6 +219,12 @@ int  jfgpu_reference_matrix(uint32_t lsize, uint32_t key_len, uint64_t* columns)
 #define JFGPU_OP_UPDATE 2
 int  jfgpu_set_operation(jfgpu_table* t, int op);
 
+/* Device memory a table created with (k, size) occupies, and the number of positions it really gets (the size is
+ * rounded up to a power of two and to the engine's minimum for that k; large_hash::array::usage_info::mem,
+ * sub_commands/mem_main.cc).  Host only.  The partitioned insert path additionally needs its workspace
+ * (jfgpu_reserve: about 8 bytes per k-mer fed between two syncs). */
+int  jfgpu_table_bytes(uint32_t k, uint64_t size, uint64_t* slots, uint64_t* bytes);
+
 /* Spill instead of "Hash full" when the table may not double (jfgpu_set_growth(t, 0), i.e. `count --disk`):
  * before the table would pass 80 % load the engine applies everything pending and calls fn(user); the callback
  * writes the table out as one sorted run (jfgpu_dump_begin / _next / _end -- what the reference's dumper does

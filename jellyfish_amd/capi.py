@@ -98,6 +98,7 @@ SIGNATURES = {
     "jfgpu_parser_last_ms": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "jfgpu_set_growth": (C.c_int, [_P, C.c_int]),
     "jfgpu_reference_matrix": (C.c_int, [C.c_uint32, C.c_uint32, _P]),
+    "jfgpu_table_bytes": (C.c_int, [C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "jfgpu_set_spill": (C.c_int, [_P, _P, _P]),
     "jfgpu_set_operation": (C.c_int, [_P, C.c_int]),
     "jfgpu_set_mode": (C.c_int, [_P, C.c_int]),

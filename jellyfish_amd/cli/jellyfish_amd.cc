@@ -668,6 +668,42 @@ int query_main(int argc, char* argv[]) {
   return 0;
 }
 
+// ---------------------------------------------------------------- mem  (sub_commands/mem_main.cc)
+// Device memory of the table for a size hint, or the largest size hint that fits a memory budget.
+static std::string add_suffix(uint64_t x, uint64_t unit) {
+  static const char suffixes[] = "kMGTPE";
+  int i = 0;
+  while(x >= unit && i <= 5) { x /= unit; ++i; }
+  return std::to_string(x) + (i > 0 ? std::string(1, suffixes[i - 1]) : std::string());
+}
+int mem_main(int argc, char* argv[]) {
+  unsigned mer_len = 0; uint64_t size = 0, mem = 0; bool size_given = false, mem_given = false;
+  ArgCursor a{argc, argv};
+  for(; a.more(); ++a.i) {
+    if(a.is("-m", "--mer-len")) mer_len = (unsigned)strtoul(a.value("-m", "--mer-len").c_str(), 0, 10);
+    else if(a.is("-s", "--size")) { size = parse_suffix(a.value("-s", "--size"), "-s"); size_given = true; }
+    else if(a.is("", "--mem")) { mem = parse_suffix(a.value("", "--mem"), "--mem"); mem_given = true; }
+    else if(a.is("-c", "--counter-len")) (void)a.value("-c", "--counter-len");
+    else if(a.is("-p", "--reprobes")) (void)a.value("-p", "--reprobes");
+    else die("Unknown option '" + a.cur() + "'");
+  }
+  if(!mer_len) die("Error: mandatory switch missing: -m, --mer-len");
+  if(size_given == mem_given) die("Error: exactly one of -s, --size and --mem is required");
+  uint64_t slots = 0, bytes = 0;
+  if(size_given) {
+    if(jfgpu_table_bytes(mer_len, size, &slots, &bytes)) die(jfgpu_last_error());
+    std::cout << bytes << " (" << add_suffix(bytes, 1024) << ")\n";
+  } else {
+    uint64_t best = 0;
+    for(unsigned l = 1; l < 63; ++l) {
+      if(jfgpu_table_bytes(mer_len, (uint64_t)1 << l, &slots, &bytes)) die(jfgpu_last_error());
+      if(bytes <= mem && slots == ((uint64_t)1 << l)) best = slots;
+    }
+    std::cout << best << " (" << add_suffix(best, 1000) << ")\n";
+  }
+  return 0;
+}
+
 int info_main(int argc, char* argv[]) {
   bool json = false, skip = false, cmd = false;
   std::string db;
@@ -695,7 +731,7 @@ int info_main(int argc, char* argv[]) {
 int main(int argc, char* argv[]) {
   const char* usage =
       "Usage: jellyfish-amd <cmd> [options] arg...\n"
-      "Where <cmd> is one of: count, bc, stats, histo, dump, query, info.\n"
+      "Where <cmd> is one of: count, bc, merge, stats, histo, dump, query, mem, info.\n"
       "Options:\n  --version        Display version\n  --help           Display this message\n";
   if(argc < 2) { std::cerr << "Too few arguments\n" << usage; return 1; }
   const std::string cmd = argv[1];
@@ -709,6 +745,7 @@ int main(int argc, char* argv[]) {
     if(cmd == "stats") return stats_main(argc - 1, argv + 1);
     if(cmd == "query") return query_main(argc - 1, argv + 1);
     if(cmd == "merge") return merge_main(argc - 1, argv + 1);
+    if(cmd == "mem") return mem_main(argc - 1, argv + 1);
     if(cmd == "info") return info_main(argc - 1, argv + 1);
   } catch(std::exception& e) { die(e.what()); }
   std::cerr << "Unknown command '" << cmd << "'\n" << usage;

@@ -948,6 +948,21 @@ int jfgpu_reserve(jfgpu_table* t, uint64_t input_bytes) {
   return JFGPU_OK;
 }
 
+int jfgpu_table_bytes(uint32_t k, uint64_t size, uint64_t* slots, uint64_t* bytes) {
+  if(k < 1 || k > 64) return fail(JFGPU_E_UNSUPPORTED, "mer length must be in [1, 64]");
+  uint32_t lsize = 0;
+  while(lsize < 63 && (1ull << lsize) < size) ++lsize;
+  const bool wide = k > 32;
+  if(wide) { lsize = std::max(lsize, wide_min_lsize(k)); lsize = std::min<uint32_t>(lsize, 48); }
+  else { lsize = std::max(lsize, geom_min_lsize(k, 0)); lsize = std::max<uint32_t>(lsize, 1); lsize = std::min<uint32_t>(lsize, 2 * k); }
+  const uint64_t n = 1ull << lsize;
+  uint64_t ovf = std::max<uint64_t>(1ull << 12, std::min<uint64_t>(n / 256, 1ull << 26));
+  { uint64_t c = 1; while(c < ovf) c <<= 1; ovf = c; }
+  if(slots) *slots = n;
+  if(bytes) *bytes = n * (wide ? 16 : 8) + ovf * 16 + (n >> std::min<uint32_t>(lsize, kMaxTileBits)) + (size_t)(2 * k + 7) / 8 * 256 * 8 * 2;
+  return JFGPU_OK;
+}
+
 int jfgpu_set_spill(jfgpu_table* t, int (*fn)(void*), void* user) {
   int rc = use(t); if(rc) return rc;
   t->spill_fn = fn; t->spill_user = user;

@@ -232,3 +232,18 @@ def test_query_on_bloomcounter_files(cli, name):
     assert got == want[:200]
     got = subprocess.check_output([cli, "query", "-s", os.path.join(gold, case["input"]), bc]).decode().splitlines()
     assert got[:3000] == want and {l.split()[1] for l in got} <= {"0", "1", "2"}
+
+
+def test_mem_verb_and_table_bytes(cli):
+    """`mem` (sub_commands/mem_main.cc): bytes of device memory for a size hint, and the inverse."""
+    from jellyfish_amd import capi
+    import ctypes as C
+    slots, nbytes = C.c_uint64(), C.c_uint64()
+    assert capi.load().jfgpu_table_bytes(21, 10 ** 10, C.byref(slots), C.byref(nbytes)) == 0
+    assert slots.value == 1 << 34 and (1 << 37) <= nbytes.value < (1 << 37) * 1.02          # 8-byte slots + side tables
+    out = subprocess.check_output([cli, "mem", "-m", "21", "-s", "10G"]).decode().split()
+    assert int(out[0]) == nbytes.value and out[1] == "(129G)"
+    assert capi.load().jfgpu_table_bytes(40, 1 << 20, C.byref(slots), C.byref(nbytes)) == 0
+    assert nbytes.value >= 16 * slots.value                                                  # two-word keys: 16-byte slots
+    inv = subprocess.check_output([cli, "mem", "-m", "21", "--mem", "200G"]).decode().split()
+    assert int(inv[0]) == 1 << 34
