@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--lsize", type=int, default=34, help="log2 slots per GPU")
     ap.add_argument("--cpu-sample-reads", type=int, default=666667)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist", choices=["U", "G"], default="U",
+                    help="U: iid uniform reads (the metric's configuration); G: BASELINE.md's secondary distribution, reads sampled from a "
+                         "100 Mbp random genome with 1 %% substitutions (about 100x coverage at 10 Gbp: most k-mers repeat)")
     args = ap.parse_args()
 
     import numpy as np
@@ -112,7 +115,10 @@ def main():
     t = capi.Table(K, 1 << (args.lsize + sb), canonical=True, device=local_rank, shard_bits=sb, shard_id=rank)
     buf = torch.empty(n_reads * stride + 16, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
-    t.gen_reads_dev(buf.data_ptr(), rank * n_reads, n_reads, READ_LEN, 42)
+    if args.dist == "G":
+        t.gen_genome_reads_dev(buf.data_ptr(), rank * n_reads, n_reads, READ_LEN, 100_000_000, 0.01, 42)
+    else:
+        t.gen_reads_dev(buf.data_ptr(), rank * n_reads, n_reads, READ_LEN, 42)
     t.sync()
 
     bounds = [n_reads * i // steps for i in range(steps + 1)]
@@ -200,7 +206,7 @@ def main():
         # (profiles/r01_traffic.json); only quoted when the run matches that configuration.
         traffic, traffic_src = None, None
         tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tj) and world == 1 and not force_dist and abs(args.gbp - 10.0) < 1e-9 and args.lsize == 34 and steps == 10:
+        if os.path.exists(tj) and world == 1 and not force_dist and args.dist == "U" and abs(args.gbp - 10.0) < 1e-9 and args.lsize == 34 and steps == 10:
             traffic = json.load(open(tj)).get("per_timed_launch_bytes", {}).get(slot_names[which])
             traffic_src = None if traffic is None else "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, same command)"
         out = {
@@ -208,8 +214,9 @@ def main():
             "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: k=21 -C, %.1f Gbp of 150 bp reads per GPU, 2^%d-slot "
-                                   "64-bit table per GPU in HBM" % (args.gbp, args.lsize),
+            "config": {"workload": ("BASELINE configs[1]: k=21 -C, %.1f Gbp of 150 bp reads per GPU, 2^%d-slot "
+                                    "64-bit table per GPU in HBM" % (args.gbp, args.lsize)) +
+                                   ("" if args.dist == "U" else "; SECONDARY distribution G (reads from a 100 Mbp random genome, 1 % substitutions)"),
                        "k": K, "read_len": READ_LEN, "reads_per_gpu": n_reads, "table_slots_per_gpu": 1 << args.lsize,
                        "load_factor": float(tot[1]) / float(world << args.lsize),
                        "distinct": int(tot[1]), "total_kmers": total_kmers,

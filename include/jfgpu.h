@@ -291,6 +291,12 @@ int  jfgpu_profile_reset(jfgpu_table* t);
  * such reads); counter-based RNG so any slice is reproducible.  d_out needs
  * n_reads * (read_len + 1) bytes.  first_read offsets the read index. */
 int  jfgpu_gen_reads_dev(jfgpu_table* t, char* d_out, uint64_t first_read, uint64_t n_reads, uint32_t read_len, uint64_t seed);
+/* Synthetic reads of the secondary distribution "G" (BASELINE.md section 3): read_len-base windows at uniform
+ * positions and strands of a uniform random genome of genome_len bases (a pure function of the seed, never stored),
+ * each base substituted with probability substitution_rate; same layout and slicing rules as jfgpu_gen_reads_dev.
+ * High coverage means most k-mers repeat: the case where duplicates aggregate in the LDS tiles. */
+int  jfgpu_gen_genome_reads_dev(jfgpu_table* t, char* d_out, uint64_t first_read, uint64_t n_reads, uint32_t read_len,
+                                uint64_t genome_len, double substitution_rate, uint64_t seed);
 /* Random-access roofline denominator: n independent 64-bit atomicAdds
  * at uniformly random slots of this table's own memory (table must be cleared
  * afterwards).  Returns updates per second. */

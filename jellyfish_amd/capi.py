@@ -107,6 +107,7 @@ SIGNATURES = {
     "jfgpu_profile_get": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "jfgpu_profile_reset": (C.c_int, [_P]),
     "jfgpu_gen_reads_dev": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64]),
+    "jfgpu_gen_genome_reads_dev": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_double, C.c_uint64]),
     "jfgpu_gups": (C.c_int, [_P, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
     "jfgpu_malloc_dev": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "jfgpu_free_dev": (C.c_int, [_P, _P]),
@@ -316,6 +317,9 @@ class Table:
 
     def gen_reads_dev(self, d_out, first_read, n_reads, read_len, seed):
         _check(self._lib.jfgpu_gen_reads_dev(self._h, _ptr(d_out), first_read, n_reads, read_len, seed))
+
+    def gen_genome_reads_dev(self, d_out, first_read, n_reads, read_len, genome_len, substitution_rate, seed):
+        _check(self._lib.jfgpu_gen_genome_reads_dev(self._h, _ptr(d_out), first_read, n_reads, read_len, genome_len, substitution_rate, seed))
 
     def gups(self, n_updates, mode=0):
         v = C.c_double()

@@ -1032,6 +1032,21 @@ int jfgpu_gen_reads_dev(jfgpu_table* t, char* d_out, uint64_t first_read, uint64
   return JFGPU_OK;
 }
 
+int jfgpu_gen_genome_reads_dev(jfgpu_table* t, char* d_out, uint64_t first_read, uint64_t n_reads, uint32_t read_len,
+                               uint64_t genome_len, double substitution_rate, uint64_t seed) {
+  int rc = use(t); if(rc) return rc;
+  if(!n_reads) return JFGPU_OK;
+  if(!d_out) return fail(JFGPU_E_INVALID, "null buffer");
+  if(read_len < 1 || read_len > 2048 || genome_len < read_len) return fail(JFGPU_E_INVALID, "read_len must be in [1, 2048] and <= genome_len");
+  if(substitution_rate < 0 || substitution_rate > 0.5) return fail(JFGPU_E_INVALID, "substitution rate must be in [0, 0.5]");
+  if(((uintptr_t)d_out & 15) != 0) return fail(JFGPU_E_INVALID, "gen_genome_reads: output must be 16-byte aligned");
+  const uint64_t vecs = (n_reads * ((uint64_t)read_len + 1) + 15) / 16;
+  hipLaunchKernelGGL(gen_genome_reads_kernel, dim3(grid_for(t, (vecs + kBlock - 1) / kBlock)), dim3(kBlock), 0, t->stream,
+                     (uint8_t*)d_out, first_read, n_reads, read_len, genome_len, (uint32_t)lrint(substitution_rate * 65536.0), seed);
+  HIP_TRY(hipGetLastError());
+  return JFGPU_OK;
+}
+
 int jfgpu_gups(jfgpu_table* t, uint64_t n_updates, int mode, double* ups) {
   int rc = use(t); if(rc) return rc;
   if(!ups) return fail(JFGPU_E_INVALID, "null out");

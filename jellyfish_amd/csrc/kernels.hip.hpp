@@ -617,6 +617,48 @@ __global__ __launch_bounds__(kBlock) void gen_reads_kernel(uint8_t* __restrict__
   }
 }
 
+// Distribution "G" of BASELINE.md section 3: reads sampled at uniform positions and strands from a uniform random
+// genome (never materialised: base g of the genome is a pure function of (seed, g)), with iid substitutions.
+// Same output layout as gen_reads_kernel (read_len bases + one 'N' per read), counter-based, any slice reproducible.
+__device__ inline uint32_t genome_base(uint64_t gseed, uint64_t g) {
+  const uint64_t d = mix64(mix64(gseed + 0x9E3779B97F4A7C15ull * ((g >> 5) + 1)));
+  return (uint32_t)(d >> (2 * (g & 31))) & 3u;
+}
+__global__ __launch_bounds__(kBlock) void gen_genome_reads_kernel(uint8_t* __restrict__ out, uint64_t first_read, uint64_t n_reads,
+                                                                  uint32_t read_len, uint64_t genome_len, uint32_t sub_per_64k,
+                                                                  uint64_t seed) {
+  const uint64_t stride = (uint64_t)read_len + 1;
+  const uint64_t total = n_reads * stride;
+  const uint64_t gseed = mix64(seed ^ 0x67656E6F6D65ull);
+  for(uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v * 16 < total; v += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t p0 = v * 16;
+    uint64_t r = p0 / stride; uint32_t off = (uint32_t)(p0 - r * stride);
+    uint32_t w[4] = {0, 0, 0, 0};
+    uint64_t rid = ~0ull, pos = 0; bool rev = false;
+    for(int i = 0; i < 16; ++i) {
+      uint32_t ch = 0;
+      if(p0 + i < total) {
+        if(off == read_len) ch = 'N';
+        else {
+          if(r != rid) {
+            rid = r;
+            const uint64_t h = mix64(mix64(seed + 0xD1B54A32D192ED03ull * (first_read + r + 1)));
+            pos = (h >> 1) % (genome_len - read_len + 1); rev = (h & 1) != 0;
+          }
+          uint32_t b = rev ? 3u - genome_base(gseed, pos + (read_len - 1 - off)) : genome_base(gseed, pos + off);
+          const uint64_t e = mix64(seed + 0xA24BAED4963EE407ull * ((first_read + r) * 4096 + off + 1));   // substitution draw of this base
+          if((uint32_t)(e & 0xFFFFu) < sub_per_64k) b = (b + 1 + (uint32_t)((e >> 16) % 3)) & 3u;
+          ch = (uint32_t)("ACGT"[b]);
+        }
+      }
+      w[i >> 2] |= ch << (8 * (i & 3));
+      if(++off == stride) { off = 0; ++r; }
+    }
+    if(p0 + 16 <= total) *reinterpret_cast<uint4*>(out + p0) = make_uint4(w[0], w[1], w[2], w[3]);
+    else for(int i = 0; i < 16 && p0 + i < total; ++i) out[p0 + i] = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
+  }
+}
+
 // ---- random-access roofline probes (R_gups) ------------------------------------
 // mode 0: fire-and-forget atomicAdd   mode 1: returning atomicAdd   mode 2: atomicCAS(0 -> x)
 // mode 3: plain load + dependent fire-and-forget atomicAdd

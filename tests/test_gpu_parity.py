@@ -621,3 +621,25 @@ def test_prime_and_update_operations(gpu):
         for key, c in exp_r.items():
             exp[key] = exp.get(key, 0) + c
         assert got == exp
+
+
+def test_genome_read_generator(gpu):
+    """The secondary benchmark distribution: reads from a random genome with substitutions.  Reproducible, sliceable,
+    only ACGT + one N per read, every window counted once, and coverage makes k-mers repeat."""
+    k, L, n = 21, 150, 20000
+    with gpu.Table(k, 1 << 22) as t:
+        nb = n * (L + 1)
+        d = t.malloc(nb + 16)
+        t.gen_genome_reads_dev(d, 0, n, L, 100000, 0.01, 7)         # 30x coverage of a 100 kbp genome
+        a = t.d2h(d, nb).reshape(n, L + 1)
+        assert (a[:, L] == ord("N")).all() and np.isin(a[:, :L], np.frombuffer(b"ACGT", dtype=np.uint8)).all()
+        t.gen_genome_reads_dev(d, 5000, 1000, L, 100000, 0.01, 7)   # a slice of the same stream
+        assert (t.d2h(d, 1000 * (L + 1)).reshape(1000, L + 1) == a[5000:6000]).all()
+        t.gen_genome_reads_dev(d, 0, n, L, 100000, 0.01, 7)
+        t.count_ascii_dev(d, nb)
+        st = t.stats()
+        assert st.total == n * (L - k + 1)
+        assert 2 * 100000 * 0.9 < st.distinct < st.total // 3        # about both strands of the genome + error k-mers, far fewer than the windows
+        exp = oracle_map(bytes(a.reshape(-1)), k, True)
+        assert st.distinct == len(exp) and st.max_count == max(exp.values())
+        t.free(d)
