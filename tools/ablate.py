@@ -1,3 +1,6 @@
+"""Driver for experimental builds of the engine (JFGPU_LIB=/path/to/lib.so): the 10 Gbp bench flow without the
+bench harness, printing the per-stage HIP-event times.  Used with -DJFGPU_TILE_PROF builds (phase clocks of the
+tile insert go to stderr at every sync)."""
 import sys, os, json
 sys.path.insert(0, ".")
 from jellyfish_amd import capi
