@@ -19,6 +19,7 @@
 #include <iostream>
 #include <limits>
 #include <memory>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -540,16 +541,51 @@ int dump_main(int argc, char* argv[]) {
   return 0;
 }
 
+// histo / stats need only the counts: for binary/sorted files the fixed-width records are split between a few threads
+// over a read-only mapping (histo_main.cc runs -t threads over the file the same way); text files are read serially.
+// make() builds one accumulator per thread, visit(acc, count) feeds it; the accumulators are returned for reduction.
+template <typename Acc, typename Make, typename Visit>
+static std::vector<Acc> scan_counts(const std::string& path, unsigned threads, Make make, Visit visit) {
+  db_file f(path);
+  std::vector<Acc> accs;
+  if(f.header.format() != binary_dumper::format) {
+    accs.push_back(make());
+    for_each_record(f, [&](const mer_dna&, uint64_t v) { visit(accs[0], v); });
+    return accs;
+  }
+  mapped_file map(path.c_str());
+  const size_t off = f.header.offset(), kb = (f.header.key_len() + 7) / 8, vb = f.header.counter_len(), rec = kb + vb;
+  const size_t n = map.length() > off ? (map.length() - off) / rec : 0;
+  const unsigned char* base = (const unsigned char*)map.base() + off;
+  const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, n >> 16));
+  for(unsigned i = 0; i < nt; ++i) accs.push_back(make());
+  auto work = [&](unsigned i) {
+    const size_t a = n * i / nt, b = n * (i + 1) / nt;
+    for(size_t r = a; r < b; ++r) {
+      uint64_t v = 0;
+      memcpy(&v, base + r * rec + kb, vb);
+      visit(accs[i], v);
+    }
+  };
+  std::vector<std::thread> th;
+  for(unsigned i = 1; i < nt; ++i) th.emplace_back(work, i);
+  work(0);
+  for(auto& t : th) t.join();
+  return accs;
+}
+static unsigned default_threads() { return std::max(1u, std::min(16u, std::thread::hardware_concurrency())); }
+
 int histo_main(int argc, char* argv[]) {
   uint64_t low = 1, high = 10000, inc = 1;
   bool full = false;
+  unsigned threads = default_threads();
   std::string output, db;
   ArgCursor a{argc, argv};
   for(; a.more(); ++a.i) {
     if(a.is("-l", "--low")) low = strtoull(a.value("-l", "--low").c_str(), 0, 10);
     else if(a.is("-h", "--high")) high = strtoull(a.value("-h", "--high").c_str(), 0, 10);
     else if(a.is("-i", "--increment")) inc = strtoull(a.value("-i", "--increment").c_str(), 0, 10);
-    else if(a.is("-t", "--threads")) (void)a.value("-t", "--threads");
+    else if(a.is("-t", "--threads")) threads = std::max(1u, (unsigned)strtoul(a.value("-t", "--threads").c_str(), 0, 10));
     else if(a.cur() == "-f" || a.cur() == "--full") full = true;
     else if(a.is("-o", "--output")) output = a.value("-o", "--output");
     else db = a.cur();
@@ -560,13 +596,14 @@ int histo_main(int argc, char* argv[]) {
   std::ofstream fout;
   if(!output.empty()) { fout.open(output); if(!fout.good()) die("Error opening output file '" + output + "'"); }
   std::ostream& out = output.empty() ? std::cout : fout;
-  db_file f(db);
   const uint64_t base = inc >= low ? 0 : low - inc, ceil = high + inc;
   const uint64_t nb = (ceil + inc - base) / inc;
-  std::vector<uint64_t> histo(nb, 0);
-  for_each_record(f, [&](const mer_dna&, uint64_t v) {
-    if(v < base) ++histo[0]; else if(v > ceil) ++histo[nb - 1]; else ++histo[(v - base) / inc];
+  typedef std::vector<uint64_t> hist_t;
+  std::vector<hist_t> parts = scan_counts<hist_t>(db, threads, [&]() { return hist_t(nb, 0); }, [&](hist_t& h, uint64_t v) {
+    if(v < base) ++h[0]; else if(v > ceil) ++h[nb - 1]; else ++h[(v - base) / inc];
   });
+  hist_t histo(nb, 0);
+  for(const auto& h : parts) for(uint64_t i = 0; i < nb; ++i) histo[i] += h[i];
   uint64_t col = base;
   for(uint64_t i = 0; i < nb; ++i, col += inc)
     if(histo[i] > 0 || full) out << col << " " << histo[i] << "\n";
@@ -587,12 +624,13 @@ int stats_main(int argc, char* argv[]) {
   std::ofstream fout;
   if(!output.empty()) { fout.open(output); if(!fout.good()) die("Error opening output file '" + output + "'"); }
   std::ostream& out = output.empty() ? std::cout : fout;
-  db_file f(db);
-  uint64_t uniq = 0, distinct = 0, total = 0, max = 0;
-  for_each_record(f, [&](const mer_dna&, uint64_t v) {
+  struct acc_t { uint64_t uniq = 0, distinct = 0, total = 0, max = 0; };
+  std::vector<acc_t> parts = scan_counts<acc_t>(db, default_threads(), []() { return acc_t(); }, [&](acc_t& x, uint64_t v) {
     if(v < lower || v > upper) return;
-    uniq += v == 1; total += v; max = std::max(max, v); ++distinct;
+    x.uniq += v == 1; x.total += v; x.max = std::max(x.max, v); ++x.distinct;
   });
+  uint64_t uniq = 0, distinct = 0, total = 0, max = 0;
+  for(const auto& x : parts) { uniq += x.uniq; distinct += x.distinct; total += x.total; max = std::max(max, x.max); }
   out << "Unique:    " << uniq << "\n" << "Distinct:  " << distinct << "\n"
       << "Total:     " << total << "\n" << "Max_count: " << max << "\n";
   return 0;
