@@ -160,12 +160,18 @@ public:
   }
   bool has_key(const mer_dna& k) { return get_val_for_key(k, nullptr); }
 
-  void flush() { std::lock_guard<std::mutex> lock(mu_); flush_locked(); }
+  void flush() { if(in_spill_) return; std::lock_guard<std::mutex> lock(mu_); flush_locked(); }   // (a spill runs inside an engine call)
 
 private:
   std::function<void()> spill_;
+  bool in_spill_ = false;
   static int spill_trampoline(void* self) {
-    try { static_cast<hash_counter*>(self)->spill_(); return 0; } catch(std::exception& e) { fprintf(stderr, "%s\n", e.what()); return 1; }
+    hash_counter* h = static_cast<hash_counter*>(self);
+    h->in_spill_ = true;
+    int rc = 0;
+    try { h->spill_(); } catch(std::exception& e) { fprintf(stderr, "%s\n", e.what()); rc = 1; }
+    h->in_spill_ = false;
+    return rc;
   }
 
   static constexpr size_t kBatch = 1 << 20;
