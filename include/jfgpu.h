@@ -301,6 +301,10 @@ int  jfgpu_gen_genome_reads_dev(jfgpu_table* t, char* d_out, uint64_t first_read
  * at uniformly random slots of this table's own memory (table must be cleared
  * afterwards).  Returns updates per second. */
 int  jfgpu_gups(jfgpu_table* t, uint64_t n_updates, int mode, double* updates_per_s);
+/* Pinned host memory: buffers handed to jfgpu_dump_next / jfgpu_count_ascii / jfgpu_memcpy_* move at PCIe speed
+ * when they come from here (pageable memory goes through the runtime's staging at a fraction of it). */
+int  jfgpu_malloc_host(size_t bytes, void** out);
+int  jfgpu_free_host(void* p);
 /* Raw device memory for callers without torch. */
 int  jfgpu_malloc_dev(jfgpu_table* t, size_t bytes, void** out);
 int  jfgpu_free_dev(jfgpu_table* t, void* p);

@@ -109,6 +109,8 @@ SIGNATURES = {
     "jfgpu_gen_reads_dev": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64]),
     "jfgpu_gen_genome_reads_dev": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_double, C.c_uint64]),
     "jfgpu_gups": (C.c_int, [_P, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
+    "jfgpu_malloc_host": (C.c_int, [C.c_size_t, C.POINTER(_P)]),
+    "jfgpu_free_host": (C.c_int, [_P]),
     "jfgpu_malloc_dev": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "jfgpu_free_dev": (C.c_int, [_P, _P]),
     "jfgpu_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_size_t]),

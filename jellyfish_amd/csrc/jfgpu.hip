@@ -1071,6 +1071,16 @@ int jfgpu_gups(jfgpu_table* t, uint64_t n_updates, int mode, double* ups) {
   return JFGPU_OK;
 }
 
+int jfgpu_malloc_host(size_t bytes, void** out) {       // pinned: device copies to / from it run at PCIe speed
+  if(!out) return fail(JFGPU_E_INVALID, "null out");
+  *out = nullptr;
+  HIP_TRY(hipHostMalloc(out, bytes ? bytes : 16, hipHostMallocDefault));
+  return JFGPU_OK;
+}
+int jfgpu_free_host(void* p) {
+  if(p) HIP_TRY(hipHostFree(p));
+  return JFGPU_OK;
+}
 int jfgpu_malloc_dev(jfgpu_table* t, size_t bytes, void** out) {
   int rc = use(t); if(rc) return rc;
   if(!out) return fail(JFGPU_E_INVALID, "null out");

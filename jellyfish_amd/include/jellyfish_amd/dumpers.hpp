@@ -86,8 +86,13 @@ public:
     // Records have a fixed width and arrive in file order, so every chunk's place in the file is known: while
     // the device sorts and ships chunk i+1 into one buffer, a few threads pwrite() the slices of chunk i from
     // the other (a single write() stream copies into the page cache at 2-3 GB/s; the device delivers faster).
-    const uint64_t cap = std::max<uint64_t>((uint64_t)4 << 20, ary->info().tile_slots);
-    std::vector<char> bufs[2] = {std::vector<char>(cap * rec), std::vector<char>(cap * rec)};
+    const uint64_t cap = std::max<uint64_t>(std::min<uint64_t>((uint64_t)16 << 20, std::max<uint64_t>(n, (uint64_t)1 << 16)), ary->info().tile_slots);
+    struct pinned {                                            // device -> host at PCIe speed needs pinned memory
+      char* p = nullptr; std::vector<char> fallback;
+      explicit pinned(size_t n) { void* q = nullptr; if(jfgpu_malloc_host(n, &q) == JFGPU_OK) p = (char*)q; else { fallback.resize(n); p = fallback.data(); } }
+      ~pinned() { if(fallback.empty()) jfgpu_free_host(p); }
+      char* data() { return p; }
+    } bufs[2] = {pinned(cap * rec), pinned(cap * rec)};
     const int fd = ::open(path.c_str(), O_WRONLY);
     if(fd < 0) { jfgpu_dump_end(ary->handle()); throw ErrorWriting("Can't reopen '" + path + "' for writing"); }
     std::vector<std::future<bool>> pending[2];
