@@ -93,16 +93,8 @@ public:
       ~pinned() { if(fallback.empty()) jfgpu_free_host(p); }
       char* data() { return p; }
     } bufs[2] = {pinned(cap * rec), pinned(cap * rec)};
-    const int fd = ::open(path.c_str(), O_RDWR);
+    const int fd = ::open(path.c_str(), O_WRONLY);
     if(fd < 0) { jfgpu_dump_end(ary->handle()); throw ErrorWriting("Can't reopen '" + path + "' for writing"); }
-    // The final size is known (n records): the file is sized and mapped, and the slices are memcpy'd into the mapping --
-    // page-cache writes through one descriptor serialise on the inode lock, page faults on a mapping do not.
-    char* map = nullptr;
-    const size_t map_len = (size_t)body + (size_t)n * rec;
-    if(n && ::ftruncate(fd, (off_t)map_len) == 0) {
-      void* m = ::mmap(nullptr, map_len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-      if(m != MAP_FAILED) map = (char*)m;
-    }
     std::vector<std::future<bool>> pending[2];
     auto drain = [&](int b) { bool ok = true; for(auto& f : pending[b]) ok = f.get() && ok; pending[b].clear(); return ok; };
     const unsigned nw = std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2));
@@ -119,8 +111,7 @@ public:
           const char* src = bufs[b].data() + o;
           const size_t len = std::min(per, bytes - o);
           const off_t at = body + (off_t)(written * rec + o);
-          pending[b].push_back(std::async(std::launch::async, [fd, src, len, at, map, map_len]() {
-            if(map && (size_t)at + len <= map_len) { memcpy(map + at, src, len); return true; }
+          pending[b].push_back(std::async(std::launch::async, [fd, src, len, at]() {
             size_t done = 0;
             while(done < len) {
               const ssize_t w = ::pwrite(fd, src + done, len - done, at + (off_t)done);
@@ -133,11 +124,7 @@ public:
         written += got;
       }
       ok = drain(0) && ok; ok = drain(1) && ok;
-    } catch(...) { drain(0); drain(1); if(map) ::munmap(map, map_len); ::close(fd); jfgpu_dump_end(ary->handle()); throw; }
-    if(map) {
-      ::munmap(map, map_len);
-      if(written != n && ::ftruncate(fd, body + (off_t)(written * rec)) != 0) ok = false;    // cannot happen: n is exact
-    }
+    } catch(...) { drain(0); drain(1); ::close(fd); jfgpu_dump_end(ary->handle()); throw; }
     ::close(fd);
     jf_check(jfgpu_dump_end(ary->handle()));
     if(!ok) throw ErrorWriting("Error while writing '" + path + "'");
