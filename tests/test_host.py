@@ -247,3 +247,61 @@ def test_mem_verb_and_table_bytes(cli):
     assert nbytes.value >= 16 * slots.value                                                  # two-word keys: 16-byte slots
     inv = subprocess.check_output([cli, "mem", "-m", "21", "--mem", "200G"]).decode().split()
     assert int(inv[0]) == 1 << 34
+
+
+@pytest.fixture(scope="module")
+def parser_emu(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("pemu") / "parser_emu")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "jellyfish_amd", "include"), "-o", exe,
+                           os.path.join(ROOT, "tests", "host", "parser_emu.cc")])
+    return exe
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_host_sequence_parser_matches_oracle(parser_emu, tmp_path, seed):
+    """The host reader (fallback for pipes, --host-parse and FASTQ the device parser refuses) against the oracle's
+    restatement of mer_overlap_sequence_parser: CRLF, blank lines, wrapped FASTQ, quality lines starting with '@' or
+    '+', no final newline -- with buffers small enough that records straddle many of them."""
+    rng = random.Random(300 + seed)
+    rnd = lambda n, alpha="ACGTACGTacgtNnR": "".join(rng.choice(alpha) for _ in range(n))
+    eol = "\r\n" if seed & 1 else "\n"
+    txt = ""
+    if seed % 4 < 2:
+        for r in range(60):
+            txt += ">r%d desc > x%s" % (r, eol)
+            s = rnd(rng.choice([0, 1, 20, 21, 60, 61, 500, 3000]))
+            w = rng.choice([1, 7, 60, 10 ** 6])
+            for i in range(0, len(s), w):
+                txt += s[i:i + w] + eol
+            if rng.random() < 0.15:
+                txt += eol
+    else:
+        for r in range(80):
+            s = rnd(rng.choice([0, 1, 21, 100, 151, 400]), "ACGTN")
+            q = "".join(rng.choice("@+IIFF#>5") for _ in s)
+            w = rng.choice([10 ** 6, 10 ** 6, 50])                      # sometimes wrapped over several lines
+            wrap = lambda x: eol.join(x[i:i + w] for i in range(0, max(len(x), 1), w))
+            txt += "@r%d%s%s%s+%s%s%s" % (r, eol, wrap(s), eol, eol, wrap(q), eol)
+    if seed & 2:
+        txt = txt.rstrip("\r\n")
+    data = txt.encode()
+    path = tmp_path / "in.txt"
+    path.write_bytes(data)
+    want = O.parse_file(data)
+    for buf in (64, 4096, 1 << 20):
+        got = subprocess.check_output([parser_emu, "21", str(buf), str(path)])
+        assert got == want, buf
+
+
+def test_host_sequence_parser_errors(parser_emu, tmp_path):
+    bad = tmp_path / "bad.fq"
+    bad.write_bytes(b"@r\nACGTACGTACGTACGTACGTACGT\n+\nIIII\n")
+    r = subprocess.run([parser_emu, "21", "4096", str(bad)], capture_output=True)
+    assert r.returncode == 1 and b"Invalid fastq sequence" in r.stderr          # mer_overlap_sequence_parser.hpp:308
+    other = tmp_path / "x.txt"
+    other.write_bytes(b"hello\n")
+    r = subprocess.run([parser_emu, "21", "4096", str(other)], capture_output=True)
+    assert r.returncode == 1 and b"Unsupported format" in r.stderr              # :146-147
+    empty = tmp_path / "empty.fa"
+    empty.write_bytes(b"")
+    assert subprocess.check_output([parser_emu, "21", "4096", str(empty)]) == b""
