@@ -63,7 +63,14 @@ struct DevTable {
 // Workgroup barrier that orders LDS only.  __syncthreads() also waits for every outstanding
 // global store of the wave (s_waitcnt vmcnt(0)), which serialises "write a chunk to HBM" with
 // "start the next chunk" in the streaming kernels; here the only cross-wave traffic is LDS.
+// (JFGPU_EMU: the same sources compiled for the host by tests/host/hip_emu, where a barrier is a fiber rendezvous.)
+#if defined(JFGPU_EMU)
+__device__ __forceinline__ void lds_barrier() { __syncthreads(); }
+#define JF_DYN_LDS(name) unsigned char* name = ::hip_emu::dyn_lds()
+#else
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#define JF_DYN_LDS(name) extern __shared__ __align__(16) unsigned char name[]
+#endif
 
 __device__ inline bool bloom_admits(const DevBloom& B, uint64_t key);   // kernels_bloom.hip.hpp
 
@@ -528,7 +535,7 @@ __global__ __launch_bounds__(kBlock) void dump_tiles_kernel(DevTable T, uint64_t
                                                             uint64_t tile0, uint64_t n_tiles,
                                                             const uint64_t* __restrict__ tile_offsets,  // record offset of tile (relative to tile0's)
                                                             uint8_t* __restrict__ out, uint32_t key_bytes, uint32_t val_bytes) {
-  extern __shared__ __align__(16) unsigned char s_raw[];
+  JF_DYN_LDS(s_raw);
   const uint32_t tsz = 1u << T.g.tile_bits;
   uint64_t* s_w = reinterpret_cast<uint64_t*>(s_raw);
   uint64_t* s_invt = s_w + tsz;

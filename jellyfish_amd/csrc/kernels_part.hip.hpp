@@ -286,7 +286,7 @@ __global__ __launch_bounds__(kPBlock) void p1_scatter_sorted_kernel(DevTable T, 
                                                                     int64_t lo, int64_t hi, const uint32_t* __restrict__ M,
                                                                     const uint64_t* __restrict__ bucket_off,
                                                                     uint32_t* __restrict__ out) {
-  extern __shared__ __align__(16) unsigned char s_dyn[];
+  JF_DYN_LDS(s_dyn);
   uint32_t* s_item = reinterpret_cast<uint32_t*>(s_dyn);                          // [kPTilePos]
   uint16_t* s_bkt = reinterpret_cast<uint16_t*>(s_dyn + (size_t)kPTilePos * 4);   // [kPTilePos]
   __shared__ uint64_t s_fwd[8 * 256];
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(kPBlock) void p1_keys_scatter_sorted_kernel(DevTabl
                                                                          int64_t n, const uint32_t* __restrict__ M,
                                                                          const uint64_t* __restrict__ bucket_off,
                                                                          uint32_t* __restrict__ out) {
-  extern __shared__ __align__(16) unsigned char s_dyn[];
+  JF_DYN_LDS(s_dyn);
   uint32_t* s_item = reinterpret_cast<uint32_t*>(s_dyn);                          // [kPTilePos]
   uint16_t* s_bkt = reinterpret_cast<uint16_t*>(s_dyn + (size_t)kPTilePos * 4);   // [kPTilePos]
   __shared__ uint64_t s_fwd[8 * 256];
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(kPBlock) void p2_scatter_sorted_kernel(PartGeom P, 
                                                                     const uint32_t* __restrict__ M,
                                                                     const uint64_t* __restrict__ goff, ITEM* __restrict__ out, uint32_t bucket0) {
   constexpr int kChunk = kPBlock * PER_THREAD;
-  extern __shared__ __align__(16) unsigned char s_dyn[];
+  JF_DYN_LDS(s_dyn);
   ITEM* s_item = reinterpret_cast<ITEM*>(s_dyn);                       // [kChunk]
   __shared__ uint32_t s_delta[kMaxBuckets];     // write cursor of sub-bucket d (relative to the bucket's first item) minus its start in the sorted chunk, mod 2^32
   __shared__ uint32_t s_hist[kMaxBuckets];
@@ -520,7 +520,7 @@ __device__ inline void tile_insert_one(const DevTable& T, unsigned long long* s_
 
 template <typename ITEM, bool RETURNING, bool LOAD>
 __global__ __launch_bounds__(kPBlock) void tile_insert_kernel(DevTable T, SegList S, uint64_t tile0, uint32_t n_tiles) {
-  extern __shared__ __align__(16) unsigned char s_raw[];
+  JF_DYN_LDS(s_raw);
   unsigned long long* s_tile = reinterpret_cast<unsigned long long*>(s_raw);
   const TableGeom& g = T.g;
   const uint32_t tsz = 1u << g.tile_bits;
@@ -773,7 +773,7 @@ __global__ __launch_bounds__(kPBlock) void p1_scatter_granule_kernel(DevTable T,
                                                                      unsigned int* __restrict__ gcur,
                                                                      unsigned long long* __restrict__ tot,
                                                                      uint32_t* __restrict__ out) {
-  extern __shared__ __align__(16) unsigned char s_dyn[];
+  JF_DYN_LDS(s_dyn);
   uint32_t* s_item = reinterpret_cast<uint32_t*>(s_dyn);                          // [kPTilePos]
   uint16_t* s_bkt = reinterpret_cast<uint16_t*>(s_dyn + (size_t)kPTilePos * 4);   // [kPTilePos]
   __shared__ uint64_t s_fwd[8 * 256];
@@ -829,7 +829,7 @@ template <bool RETURNING, int NB>
 __global__ __launch_bounds__(kPBlock) void p1_keys_granule_kernel(DevTable T, PartGeom P, const uint64_t* __restrict__ keys, int64_t n,
                                                                   uint32_t cap, unsigned int* __restrict__ gcur,
                                                                   unsigned long long* __restrict__ tot, uint32_t* __restrict__ out) {
-  extern __shared__ __align__(16) unsigned char s_dyn[];
+  JF_DYN_LDS(s_dyn);
   uint32_t* s_item = reinterpret_cast<uint32_t*>(s_dyn);
   uint16_t* s_bkt = reinterpret_cast<uint16_t*>(s_dyn + (size_t)kPTilePos * 4);
   __shared__ uint64_t s_fwd[8 * 256];

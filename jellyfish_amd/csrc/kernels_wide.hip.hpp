@@ -409,7 +409,7 @@ __global__ __launch_bounds__(kBlock) void dump_tiles_wide_kernel(WideTable T, ui
                                                                  uint64_t tile0, uint64_t n_tiles,
                                                                  const uint64_t* __restrict__ tile_offsets,
                                                                  uint8_t* __restrict__ out, uint32_t key_bytes, uint32_t val_bytes) {
-  extern __shared__ __align__(16) unsigned char s_raw[];
+  JF_DYN_LDS(s_raw);
   const TableGeom& g = T.W.g;
   const uint32_t tsz = 1u << g.tile_bits;
   uint64_t* s_hi = reinterpret_cast<uint64_t*>(s_raw);

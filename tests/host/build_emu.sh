@@ -1,0 +1,9 @@
+#!/bin/bash
+# Builds the host-emulated engine (tests/host/hip_emu): the kernels' sources compiled by g++ for CPU debugging.
+# TEST INFRASTRUCTURE: loaded only when a test run sets JFGPU_EMU=1 (tests/conftest.py); never measured, never shipped.
+set -e
+cd "$(dirname "$0")/../.."
+mkdir -p tests/host/_build
+g++ -std=c++17 -O2 -g -x c++ -DJFGPU_EMU -Itests/host/hip_emu -fPIC -shared -pthread \
+    -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result -Wno-unknown-pragmas -Wno-sign-compare -Wno-unused-but-set-variable -Wno-unused-variable \
+    -o tests/host/_build/libjfgpu_emu.so jellyfish_amd/csrc/jfgpu.hip
