@@ -149,6 +149,12 @@ int  jfgpu_partition_ascii_dev(jfgpu_table* t, const char* d_bases, size_t n,
 
 /* ---- results path ------------------------------------------------------ */
 int  jfgpu_stats_compute(jfgpu_table* t, uint64_t lower, uint64_t upper, jfgpu_stats* out);
+/* Order-independent checksum of the {k-mer -> count} content restricted to lower <= count <= upper:
+ * out4 = { records, sum of counts, sum of h, xor of h } (mod 2^64) with h = mix(..mix(mix(S ^ w0) ^ w1).. ^ count),
+ * mix = the splitmix64 finaliser, S = 0x9E3779B97F4A7C15, w = the key's little-endian words (mer_dna::data()).
+ * No reference counterpart: it exists so that a 10 Gbp run is compared with the reference's table (the oracle driver
+ * computes the same numbers from large_hash_array's iterators) without writing and sorting ~86 GB of records. */
+int  jfgpu_digest(jfgpu_table* t, uint64_t lower, uint64_t upper, uint64_t* out4);
 /* histo_main.cc:34-45: histo[0] counts vals < base, histo[n-1] vals > ceil,
  * else histo[(val-base)/inc]. */
 int  jfgpu_histo(jfgpu_table* t, uint64_t base, uint64_t ceil, uint64_t inc, uint64_t* histo, uint64_t nb_buckets);

@@ -74,6 +74,7 @@ SIGNATURES = {
     "jfgpu_lookup": (C.c_int, [_P, _P, C.c_size_t, _P, _P]),
     "jfgpu_partition_ascii_dev": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, _P]),
     "jfgpu_stats_compute": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.POINTER(Stats)]),
+    "jfgpu_digest": (C.c_int, [_P, C.c_uint64, C.c_uint64, _P]),
     "jfgpu_histo": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64, _P, C.c_uint64]),
     "jfgpu_dump_begin": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "jfgpu_dump_next": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
@@ -251,6 +252,12 @@ class Table:
         _check(self._lib.jfgpu_stats_compute(self._h, lower, upper, C.byref(s)))
         return s
 
+    def digest(self, lower=0, upper=2 ** 64 - 1):
+        """(records, sum of counts, sum of h, xor of h): order-independent checksum of the table's content."""
+        out = np.zeros(4, dtype=np.uint64)
+        _check(self._lib.jfgpu_digest(self._h, lower, upper, out.ctypes.data))
+        return tuple(int(x) for x in out)
+
     def histo(self, low=1, high=10000, inc=1):
         """Same bucket arithmetic as histo_main.cc:60-66; returns (first_col, inc, counts)."""
         base = 0 if inc >= low else low - inc
@@ -289,6 +296,11 @@ class Table:
 
     def set_growth(self, on):
         _check(self._lib.jfgpu_set_growth(self._h, int(bool(on))))
+
+    def set_spill(self, fn):
+        """jfgpu_set_spill: fn() is called (table full, growth off) to write the table out; return 0 on success."""
+        self._spill_cb = C.CFUNCTYPE(C.c_int, C.c_void_p)(lambda _u: int(fn() or 0)) if fn is not None else None
+        _check(self._lib.jfgpu_set_spill(self._h, C.cast(self._spill_cb, C.c_void_p) if self._spill_cb else None, None))
 
     def refresh_info(self):
         _check(self._lib.jfgpu_get_info(self._h, C.byref(self.info)))
@@ -417,6 +429,25 @@ def opt_m(fp, n):
 
 def opt_k(fp):
     return load().jfgpu_bc_opt_k(fp)
+
+
+def digest_of(keys, counts):
+    """The same checksum from decoded records (keys: (n,) or (n, words) uint64, counts: (n,) uint64), in numpy."""
+    def mix(z):
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    if keys.ndim == 1:
+        keys = keys.reshape(-1, 1)
+    counts = np.ascontiguousarray(counts, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        h = np.full(len(keys), 0x9E3779B97F4A7C15, dtype=np.uint64)
+        for w in range(keys.shape[1]):
+            h = mix(h ^ keys[:, w])
+        h = mix(h ^ counts)
+        return (len(keys), int(counts.sum(dtype=np.uint64)), int(h.sum(dtype=np.uint64)),
+                int(np.bitwise_xor.reduce(h)) if len(h) else 0)
 
 
 def decode_records(recs: np.ndarray, k: int, counter_len: int):

@@ -74,6 +74,13 @@ struct ArgCursor {
   }
 };
 
+// A positional argument, or an error for anything that looks like an option the verb does not know (yaggo does the same).
+std::string positional(const ArgCursor& a) {
+  const std::string c = a.cur();
+  if(c.size() > 1 && c[0] == '-') die("Unknown option '" + c + "'");
+  return c;
+}
+
 double seconds_since(std::chrono::steady_clock::time_point t0) {
   return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
@@ -256,9 +263,10 @@ int count_main(int argc, char* argv[]) {
 
   unsigned mer_len = 0, threads = 1, counter_len = 7, out_counter_len = 4, reprobes = 126, Files = 1;
   uint64_t size = 0, lower = 0, upper = std::numeric_limits<uint64_t>::max();
+  bool counter_len_given = false, reprobes_given = false, generators_given = false;
   bool size_given = false, lower_given = false, upper_given = false, canonical = false, text = false, no_write = false, disk = false, host_parse = false, no_merge = false, no_unlink = false;
   int device = -1;
-  std::string output = "mer_counts.jf", timing, bc_path, generator, shell;
+  std::string output = "mer_counts.jf", timing, bc_path, generator, shell, digest_path;
   std::vector<std::string> files, if_files;
   ArgCursor a{argc, argv};
   for(; a.more(); ++a.i) {
@@ -267,18 +275,19 @@ int count_main(int argc, char* argv[]) {
     else if(a.is("-t", "--threads")) threads = (unsigned)strtoul(a.value("-t", "--threads").c_str(), 0, 10);
     else if(a.is("", "--if")) if_files.push_back(a.value("", "--if"));
     else if(a.is("-g", "--generator")) generator = a.value("-g", "--generator");
-    else if(a.is("-G", "--Generators")) (void)a.value("-G", "--Generators");     // generators run one after the other here
+    else if(a.is("-G", "--Generators")) { (void)a.value("-G", "--Generators"); generators_given = true; }   // generators run one after the other here
     else if(a.is("-S", "--shell")) shell = a.value("-S", "--shell");
     else if(a.is("-F", "--Files")) Files = (unsigned)strtoul(a.value("-F", "--Files").c_str(), 0, 10);
-    else if(a.is("-c", "--counter-len")) counter_len = (unsigned)strtoul(a.value("-c", "--counter-len").c_str(), 0, 10);
+    else if(a.is("-c", "--counter-len")) { counter_len = (unsigned)strtoul(a.value("-c", "--counter-len").c_str(), 0, 10); counter_len_given = true; }
     else if(a.is("", "--out-counter-len")) out_counter_len = (unsigned)strtoul(a.value("", "--out-counter-len").c_str(), 0, 10);
-    else if(a.is("-p", "--reprobes")) reprobes = (unsigned)strtoul(a.value("-p", "--reprobes").c_str(), 0, 10);
+    else if(a.is("-p", "--reprobes")) { reprobes = (unsigned)strtoul(a.value("-p", "--reprobes").c_str(), 0, 10); reprobes_given = true; }
     else if(a.is("-o", "--output")) output = a.value("-o", "--output");
     else if(a.is("-L", "--lower-count")) { lower = strtoull(a.value("-L", "--lower-count").c_str(), 0, 10); lower_given = true; }
     else if(a.is("-U", "--upper-count")) { upper = strtoull(a.value("-U", "--upper-count").c_str(), 0, 10); upper_given = true; }
     else if(a.is("", "--timing")) timing = a.value("", "--timing");
     else if(a.is("", "--device")) device = atoi(a.value("", "--device").c_str());
     else if(a.is("", "--bc")) bc_path = a.value("", "--bc");
+    else if(a.is("", "--digest")) digest_path = a.value("", "--digest");   // content checksum of the table (jfgpu_digest), for at-scale parity checks
     else if(a.cur() == "-C" || a.cur() == "--canonical") canonical = true;
     else if(a.cur() == "--text") text = true;
     else if(a.cur() == "--no-write") no_write = true;
@@ -317,6 +326,14 @@ int count_main(int argc, char* argv[]) {
   if(!size_given) die("Error: mandatory switch missing: -s, --size");
   if(files.empty() && generator.empty()) die("Error: at least 1 file argument is required");
   (void)threads; (void)counter_len; (void)reprobes; (void)Files;
+  // Accepted for script compatibility but meaningless on this engine: say so once instead of silently ignoring them.
+  // (-t: the device has its own parallelism; -c / -p: the in-memory slot format and probing are the engine's own and never
+  // reach the file -- the header's val_len / max_reprobe / reprobes[] are the values readers and `merge` need to agree on.)
+  if(!getenv("JFGPU_QUIET")) {
+    if(counter_len_given) std::cerr << "jellyfish-amd: note: -c/--counter-len has no effect (in-memory counts are exact 64-bit)\n";
+    if(reprobes_given) std::cerr << "jellyfish-amd: note: -p/--reprobes has no effect (tile-local probing on the device)\n";
+    if(generators_given) std::cerr << "jellyfish-amd: note: -G/--Generators has no effect (generator commands run one after the other)\n";
+  }
   if(mer_len > 64) die("jellyfish-amd: mer length > 64 is not built yet");
   if(text) out_counter_len = 8;   // text counts are not saturated (text_dumper.hpp:18-20)
 
@@ -393,6 +410,12 @@ int count_main(int argc, char* argv[]) {
   } catch(std::exception& e) { die(e.what()); }
   const double count_s = seconds_since(count_start);
 
+  if(!digest_path.empty()) {
+    uint64_t d[4];
+    if(jfgpu_digest(ary->handle(), lower_given ? lower : 0, upper_given ? upper : std::numeric_limits<uint64_t>::max(), d)) die(jfgpu_last_error());
+    std::ofstream df(digest_path);
+    df << "records " << d[0] << "\ntotal " << d[1] << "\nsum " << d[2] << "\nxor " << d[3] << "\n";
+  }
   auto write_start = std::chrono::steady_clock::now();
   if(!no_write) {
     try {
@@ -524,7 +547,7 @@ int dump_main(int argc, char* argv[]) {
     else if(a.is("-L", "--lower-count")) lower = strtoull(a.value("-L", "--lower-count").c_str(), 0, 10);
     else if(a.is("-U", "--upper-count")) upper = strtoull(a.value("-U", "--upper-count").c_str(), 0, 10);
     else if(a.is("-o", "--output")) output = a.value("-o", "--output");
-    else db = a.cur();
+    else db = positional(a);
   }
   if(db.empty()) die("Usage: jellyfish-amd dump [-c] [-t] [-L l] [-U u] [-o out] db:path");
   std::ios::sync_with_stdio(false);
@@ -588,7 +611,7 @@ int histo_main(int argc, char* argv[]) {
     else if(a.is("-t", "--threads")) threads = std::max(1u, (unsigned)strtoul(a.value("-t", "--threads").c_str(), 0, 10));
     else if(a.cur() == "-f" || a.cur() == "--full") full = true;
     else if(a.is("-o", "--output")) output = a.value("-o", "--output");
-    else db = a.cur();
+    else db = positional(a);
   }
   if(db.empty()) die("Usage: jellyfish-amd histo [-l low] [-h high] [-i inc] [-f] [-o out] db:path");
   if(high < low) die("High count value must be >= to low count value");
@@ -610,6 +633,31 @@ int histo_main(int argc, char* argv[]) {
   return 0;
 }
 
+// digest db: the content checksum documented with jfgpu_digest (include/jfgpu.h), from a file (host scan)
+int digest_main(int argc, char* argv[]) {
+  uint64_t lower = 0, upper = std::numeric_limits<uint64_t>::max();
+  std::string db;
+  ArgCursor a{argc, argv};
+  for(; a.more(); ++a.i) {
+    if(a.is("-L", "--lower-count")) lower = strtoull(a.value("-L", "--lower-count").c_str(), 0, 10);
+    else if(a.is("-U", "--upper-count")) upper = strtoull(a.value("-U", "--upper-count").c_str(), 0, 10);
+    else db = positional(a);
+  }
+  if(db.empty()) die("Usage: jellyfish-amd digest [-L l] [-U u] db:path");
+  auto mix = [](uint64_t z) { z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
+  db_file f(db);
+  uint64_t n = 0, total = 0, sum = 0, x = 0;
+  for_each_record(f, [&](const mer_dna& m, uint64_t v) {
+    if(v < lower || v > upper) return;
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    for(unsigned w = 0; w < m.nb_words(); ++w) h = mix(h ^ m.word(w));
+    h = mix(h ^ v);
+    ++n; total += v; sum += h; x ^= h;
+  });
+  std::cout << "records " << n << "\ntotal " << total << "\nsum " << sum << "\nxor " << x << "\n";
+  return 0;
+}
+
 int stats_main(int argc, char* argv[]) {
   uint64_t lower = 0, upper = std::numeric_limits<uint64_t>::max();
   std::string output, db;
@@ -618,7 +666,7 @@ int stats_main(int argc, char* argv[]) {
     if(a.is("-L", "--lower-count")) lower = strtoull(a.value("-L", "--lower-count").c_str(), 0, 10);
     else if(a.is("-U", "--upper-count")) upper = strtoull(a.value("-U", "--upper-count").c_str(), 0, 10);
     else if(a.is("-o", "--output")) output = a.value("-o", "--output");
-    else db = a.cur();
+    else db = positional(a);
   }
   if(db.empty()) die("Usage: jellyfish-amd stats [-L l] [-U u] [-o out] db:path");
   std::ofstream fout;
@@ -646,8 +694,8 @@ int query_main(int argc, char* argv[]) {
     else if(a.is("-o", "--output")) output = a.value("-o", "--output");
     else if(a.cur() == "-i" || a.cur() == "--interactive") interactive = true;
     else if(a.cur() == "-l" || a.cur() == "--load" || a.cur() == "-L" || a.cur() == "--no-load") {}
-    else if(db.empty()) db = a.cur();
-    else mers.push_back(a.cur());
+    else if(db.empty()) db = positional(a);
+    else mers.push_back(positional(a));
   }
   if(db.empty()) die("Usage: jellyfish-amd query [-s file] [-i] [-o out] db:path [mers...]");
   std::ofstream fout;
@@ -748,7 +796,9 @@ int info_main(int argc, char* argv[]) {
   for(int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     if(a == "-j" || a == "--json") json = true; else if(a == "-s" || a == "--skip") skip = true;
-    else if(a == "-c" || a == "--cmd") cmd = true; else db = a;
+    else if(a == "-c" || a == "--cmd") cmd = true;
+    else if(a.size() > 1 && a[0] == '-') die("Unknown option '" + a + "'");
+    else db = a;
   }
   if(db.empty()) die("Usage: jellyfish-amd info [-j] [-c] [-s] db:path");
   std::ifstream is(db, std::ios::binary);
@@ -781,6 +831,7 @@ int main(int argc, char* argv[]) {
     if(cmd == "dump") return dump_main(argc - 1, argv + 1);
     if(cmd == "histo") return histo_main(argc - 1, argv + 1);
     if(cmd == "stats") return stats_main(argc - 1, argv + 1);
+    if(cmd == "digest") return digest_main(argc - 1, argv + 1);
     if(cmd == "query") return query_main(argc - 1, argv + 1);
     if(cmd == "merge") return merge_main(argc - 1, argv + 1);
     if(cmd == "mem") return mem_main(argc - 1, argv + 1);

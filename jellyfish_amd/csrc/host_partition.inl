@@ -306,7 +306,12 @@ int part_flush_t(jfgpu_table* t) {
 
 int part_flush(jfgpu_table* t) {
   if(t->pending.empty()) return JFGPU_OK;
-  return t->item32 ? part_flush_t<uint32_t>(t) : part_flush_t<uint64_t>(t);
+  const int rc = t->item32 ? part_flush_t<uint32_t>(t) : part_flush_t<uint64_t>(t);
+  if(rc) {      // report the failure once: what was pending is lost with it, the handle stays usable (jfgpu_clear not needed)
+    if(t->stream) hipStreamSynchronize(t->stream);
+    t->pending.clear(); t->pending_bytes = 0; t->ws_used = 0;
+  }
+  return rc;
 }
 
 void part_discard(jfgpu_table* t) {

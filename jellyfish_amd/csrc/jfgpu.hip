@@ -278,6 +278,9 @@ int launch_count(jfgpu_table* t, const char* d_bases, size_t n) {
   while(true) {
     uint64_t take = 0;
     int rc = ensure_capacity(t, n - off, &take); if(rc) return rc;
+    // a piece holds at least one window and moves forward (spill mode may grant less than k characters of room; the few
+    // extra k-mers cannot take the table past its 80 % bound by more than 2k)
+    if(take < 2 * (uint64_t)t->g.k) take = std::min<uint64_t>(n - off, 2 * (uint64_t)t->g.k);
     rc = launch_count_chunk(t, d_bases + off, (size_t)take); if(rc) return rc;
     if(off + take >= n) return JFGPU_OK;
     off += take - (t->g.k - 1);          // next piece re-reads the last k-1 characters: every window exactly once
@@ -660,18 +663,10 @@ int jfgpu_count_ascii(jfgpu_table* t, const char* bases, size_t n) {
   return JFGPU_OK;
 }
 
-int jfgpu_add_keys_dev(jfgpu_table* t, const uint64_t* d_keys, size_t n, uint64_t val, uint8_t* d_is_new) {
-  int rc = use(t); if(rc) return rc;
+// One piece of an add_keys batch that is known to fit (the capacity check was made by the caller).
+static int add_keys_piece(jfgpu_table* t, const uint64_t* d_keys, size_t n, uint64_t val, uint8_t* d_is_new) {
+  int rc = JFGPU_OK;
   if(!n) return JFGPU_OK;
-  if(!d_keys) return fail(JFGPU_E_INVALID, "null keys");
-  if(capacity_managed(t)) {
-    uint64_t take = 0;
-    rc = ensure_capacity(t, n, &take); if(rc) return rc;
-    if(take < n) {                       // feed the rest in further pieces (each re-checks the occupancy)
-      rc = jfgpu_add_keys_dev(t, d_keys + take * t->key_words, n - take, val, d_is_new ? d_is_new + take : nullptr); if(rc) return rc;
-      n = take;
-    }
-  }
   if(t->wide) {
     ProfScope ps(t, 1, n);
     hipLaunchKernelGGL(add_keys_wide_kernel, dim3(grid_for(t, (n + kBlock - 1) / kBlock)), dim3(kBlock), 0, t->stream, t->wt, d_keys, (uint64_t)n, val, d_is_new);
@@ -693,6 +688,23 @@ int jfgpu_add_keys_dev(jfgpu_table* t, const uint64_t* d_keys, size_t n, uint64_
     hipLaunchKernelGGL(add_keys_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, d_keys, (uint64_t)n, val, d_is_new);
   }
   HIP_TRY(hipGetLastError());
+  return JFGPU_OK;
+}
+
+int jfgpu_add_keys_dev(jfgpu_table* t, const uint64_t* d_keys, size_t n, uint64_t val, uint8_t* d_is_new) {
+  int rc = use(t); if(rc) return rc;
+  if(!n) return JFGPU_OK;
+  if(!d_keys) return fail(JFGPU_E_INVALID, "null keys");
+  if(!capacity_managed(t)) return add_keys_piece(t, d_keys, n, val, d_is_new);
+  // In order, piece by piece: each piece is enqueued before the occupancy is looked at again, so a batch several
+  // times the table's size doubles (or spills) the table as often as it has to (hash_counter::add, hash_counter.hpp:91-115)
+  size_t off = 0;
+  while(off < n) {
+    uint64_t take = 0;
+    rc = ensure_capacity(t, n - off, &take); if(rc) return rc;
+    rc = add_keys_piece(t, d_keys + off * t->key_words, (size_t)take, val, d_is_new ? d_is_new + off : nullptr); if(rc) return rc;
+    off += (size_t)take;
+  }
   return JFGPU_OK;
 }
 
@@ -810,6 +822,25 @@ int jfgpu_stats_compute(jfgpu_table* t, uint64_t lower, uint64_t upper, jfgpu_st
   if(e != hipSuccess) return fail(JFGPU_E_HIP, hipGetErrorString(e));
   out->unique = h[0]; out->distinct = h[1]; out->total = h[2]; out->max_count = h[3];
   out->occupied = h[1]; out->mers_fed = c[CTR_MERS];
+  return JFGPU_OK;
+}
+
+int jfgpu_digest(jfgpu_table* t, uint64_t lower, uint64_t upper, uint64_t* out4) {
+  int rc = use(t); if(rc) return rc;
+  rc = part_flush(t); if(rc) return rc;
+  if(!out4) return fail(JFGPU_E_INVALID, "null out");
+  uint64_t c[CTR_COUNT];
+  rc = check_deferred(t, c); if(rc) return rc;
+  unsigned long long* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, 4 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), t->stream));
+  const int grid = grid_for(t, (1ull << t->g.lsize_l) / kBlock + 1);
+  if(t->wide) hipLaunchKernelGGL(digest_wide_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->wt, lower, upper, (int)(c[CTR_OVF_USED] != 0), d);
+  else hipLaunchKernelGGL(digest_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, lower, upper, (int)(c[CTR_OVF_USED] != 0), d);
+  hipError_t e = hipMemcpyAsync(out4, d, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, t->stream);
+  if(e == hipSuccess) e = hipStreamSynchronize(t->stream);
+  hipFree(d);
+  if(e != hipSuccess) return fail(JFGPU_E_HIP, hipGetErrorString(e));
   return JFGPU_OK;
 }
 

@@ -482,6 +482,47 @@ __global__ __launch_bounds__(kBlock) void stats_kernel(DevTable T, uint64_t lowe
   }
 }
 
+// ---- content digest (at-scale parity) -----------------------------------------
+// An order-independent checksum of the {k-mer -> count} multiset: per entry h = mix(..mix(mix(seed ^ w0) ^ w1).. ^ count)
+// over the key's little-endian 64-bit words, then out[0] += 1, out[1] += count, out[2] += h, out[3] ^= h (all mod 2^64).
+// The reference driver (oracle/ref_drivers/ref_jf.cc, `count --digest` / `digest`) computes the same four numbers from the
+// reference's own table, so two runs over 10 Gbp are compared without writing or sorting 86 GB of records.
+__device__ __host__ inline uint64_t digest_mix(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+constexpr uint64_t kDigestSeed = 0x9E3779B97F4A7C15ull;
+
+__device__ inline void digest_reduce(uint64_t n, uint64_t tot, uint64_t sum, uint64_t x, unsigned long long* __restrict__ out) {
+  for(int o = 32; o > 0; o >>= 1) {
+    n += __shfl_down(n, o, 64); tot += __shfl_down(tot, o, 64); sum += __shfl_down(sum, o, 64); x ^= __shfl_down(x, o, 64);
+  }
+  if((threadIdx.x & 63) == 0 && n) {
+    atomicAdd(&out[0], (unsigned long long)n); atomicAdd(&out[1], (unsigned long long)tot);
+    atomicAdd(&out[2], (unsigned long long)sum); atomicXor(&out[3], (unsigned long long)x);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void digest_kernel(DevTable T, uint64_t lower, uint64_t upper, int have_ovf,
+                                                        unsigned long long* __restrict__ out) {
+  __shared__ uint64_t s_inv[8 * 256];
+  load_tables_lds(s_inv, T.inv_tbl, T.g.nbytes);
+  __syncthreads();
+  const uint64_t n = 1ull << T.g.lsize_l;
+  uint64_t cnt = 0, tot = 0, sum = 0, x = 0;
+  for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t w = T.slots[i];
+    if(!w) continue;
+    const uint64_t c = full_count(T, w, i, have_ovf);
+    if(c < lower || c > upper) continue;
+    const uint64_t key = slot_key(T.g, s_inv, w, i & ~T.g.tile_mask);
+    const uint64_t h = digest_mix(digest_mix(kDigestSeed ^ key) ^ c);
+    ++cnt; tot += c; sum += h; x ^= h;
+  }
+  digest_reduce(cnt, tot, sum, x, out);
+}
+
 // ---- histo (histo_main.cc:34-45) -----------------------------------------------------
 constexpr uint32_t kHistoLds = 8192;  // buckets privatised per block
 __global__ __launch_bounds__(kBlock) void histo_kernel(DevTable T, uint64_t hbase, uint64_t hceil, uint64_t inc,

@@ -403,6 +403,28 @@ __global__ __launch_bounds__(kBlock) void scan_wide_kernel(WideTable T, int what
   }
 }
 
+// Content digest of a two-word-key table (see digest_kernel in kernels.hip.hpp).
+__global__ __launch_bounds__(kBlock) void digest_wide_kernel(WideTable T, uint64_t lower, uint64_t upper, int have_ovf,
+                                                             unsigned long long* __restrict__ out) {
+  const TableGeom& g = T.W.g;
+  const DevTable d = ovf_view(T);
+  const uint64_t n = 1ull << g.lsize_l;
+  uint64_t cnt = 0, tot = 0, sum = 0, x = 0;
+  for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t hi = T.slots[2 * i + 1];
+    if(!hi) continue;
+    const uint64_t lo = T.slots[2 * i];
+    if(!lo) continue;
+    uint64_t c = slot_count(g, hi);
+    if(have_ovf) c += ovf_get(d, i) << g.cnt_bits;
+    if(c < lower || c > upper) continue;
+    const u128 key = wide_slot_key(T, T.inv_tbl, lo, hi, i & ~g.tile_mask);
+    const uint64_t h = digest_mix(digest_mix(digest_mix(kDigestSeed ^ (uint64_t)key) ^ (uint64_t)(key >> 64)) ^ c);
+    ++cnt; tot += c; sum += h; x ^= h;
+  }
+  digest_reduce(cnt, tot, sum, x, out);
+}
+
 // Sorted dump of 128-bit slots: one block per tile, bitonic sort on (tag_hi, tag_lo) in LDS
 // (8192 x 16 B = 128 KiB + 16 KiB of slot indices), inverse tables through the caches.
 __global__ __launch_bounds__(kBlock) void dump_tiles_wide_kernel(WideTable T, uint64_t lower, uint64_t upper, int have_ovf,

@@ -77,6 +77,39 @@ public:
   }
 };
 
+// ---- content digest: the checksum include/jfgpu.h documents for jfgpu_digest, computed from the REFERENCE's table
+// (large_hash_array's own iterators) or from a reference-readable file.  { records, sum counts, sum h, xor h }.
+static inline uint64_t digest_mix(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+struct digest_t {
+  uint64_t n, total, sum, x;
+  digest_t() : n(0), total(0), sum(0), x(0) { }
+  void add(const mer_dna& m, uint64_t val) {
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    const unsigned words = (mer_dna::k() + 31) / 32;
+    for(unsigned w = 0; w < words; ++w) h = digest_mix(h ^ m.word(w));
+    h = digest_mix(h ^ val);
+    ++n; total += val; sum += h; x ^= h;
+  }
+  void merge(const digest_t& o) { n += o.n; total += o.total; sum += o.sum; x ^= o.x; }
+  void print(std::ostream& os) const { os << "records " << n << "\ntotal " << total << "\nsum " << sum << "\nxor " << x << "\n"; }
+};
+class ref_digester : public jellyfish::thread_exec {
+  mer_array* ary_; int nb_; uint64_t lower_, upper_;
+public:
+  std::vector<digest_t> parts_;
+  ref_digester(mer_array* ary, int nb_threads, uint64_t lower, uint64_t upper) : ary_(ary), nb_(nb_threads), lower_(lower), upper_(upper), parts_(nb_threads) { }
+  virtual void start(int thid) {
+    digest_t d;
+    mer_array::eager_iterator it = ary_->eager_slice(thid, nb_);
+    while(it.next()) if(it.val() >= lower_ && it.val() <= upper_) d.add(it.key(), it.val());
+    parts_[thid] = d;
+  }
+};
+
 static uint64_t parse_size(const char* s) {  // yaggo "suffix": k/M/G/T = powers of 1000
   char* end;
   double v = strtod(s, &end);
@@ -95,6 +128,7 @@ static int do_count(int argc, char* argv[]) {
   const char* output = "mer_counts.jf";
   const char* timing = 0;
   const char* bc_path = 0;
+  const char* digest_path = 0;
   file_vector files, if_files;
   for(int i = 1; i < argc; ++i) {
     std::string a(argv[i]);
@@ -115,6 +149,7 @@ static int do_count(int argc, char* argv[]) {
     else if(a == "--no-write") no_write = true;
     else if(a == "--timing") timing = next();
     else if(a == "--bc") bc_path = next();
+    else if(a == "--digest") digest_path = next();
     else files.push_back(argv[i]);
   }
   if(!k || !size || files.empty()) {
@@ -158,6 +193,14 @@ static int do_count(int argc, char* argv[]) {
   size_t total = 0;
   for(size_t c : counter.counts_) total += c;
 
+  if(digest_path) {     // before the dump: the sorted dumper zeroes the table behind itself
+    ref_digester dg(ary.ary(), threads, lower_given ? lower : 0, upper_given ? upper : std::numeric_limits<uint64_t>::max());
+    dg.exec_join(threads);
+    digest_t d;
+    for(size_t i = 0; i < dg.parts_.size(); ++i) d.merge(dg.parts_[i]);
+    std::ofstream df(digest_path);
+    d.print(df);
+  }
   if(!no_write) {
     dumper->one_file(true);
     if(lower_given) dumper->min(lower);
@@ -346,6 +389,25 @@ static int do_stats(int argc, char* argv[]) {
   return 0;
 }
 
+// digest db : the content checksum of a binary/sorted or text/sorted file
+static int do_digest(int argc, char* argv[]) {
+  uint64_t low = 0, high = std::numeric_limits<uint64_t>::max(); const char* db = 0;
+  for(int i = 1; i < argc; ++i) {
+    std::string a(argv[i]);
+    if(a == "-L") low = strtoull(argv[++i], 0, 10);
+    else if(a == "-U") high = strtoull(argv[++i], 0, 10);
+    else db = argv[i];
+  }
+  if(!db) return 1;
+  std::ifstream is; jellyfish::file_header header;
+  if(!open_db(db, is, header)) return 1;
+  digest_t d;
+  if(header.format() == binary_dumper::format) { binary_reader r(is, &header); while(r.next()) if(r.val() >= low && r.val() <= high) d.add(r.key(), r.val()); }
+  else                                         { text_reader r(is, &header);   while(r.next()) if(r.val() >= low && r.val() <= high) d.add(r.key(), r.val()); }
+  d.print(std::cout);
+  return 0;
+}
+
 // query db mer...   (query_main.cc:56-70,104-115) -- random access through the
 // reference's binary_query (interpolation search on the header's matrix).
 static int do_query(int argc, char* argv[]) {
@@ -381,7 +443,7 @@ static int do_header(int argc, char* argv[]) {
 }
 
 int main(int argc, char* argv[]) {
-  if(argc < 2) { std::cerr << "usage: ref_jf <count|bc|dump|histo|stats|query|header> ...\n"; return 1; }
+  if(argc < 2) { std::cerr << "usage: ref_jf <count|bc|dump|histo|stats|query|header|digest> ...\n"; return 1; }
   std::string cmd(argv[1]);
   try {
     if(cmd == "count")  return do_count(argc - 1, argv + 1);
@@ -391,6 +453,7 @@ int main(int argc, char* argv[]) {
     if(cmd == "query")  return do_query(argc - 1, argv + 1);
     if(cmd == "header") return do_header(argc - 1, argv + 1);
     if(cmd == "bc")     return do_bc(argc - 1, argv + 1);
+    if(cmd == "digest") return do_digest(argc - 1, argv + 1);
   } catch(std::exception& e) {
     std::cerr << "ref_jf: " << e.what() << "\n";
     return 1;

@@ -1,8 +1,10 @@
 /* Hand-written config.h used ONLY to compile the read-only reference tree
  * (/root/reference) as the parity oracle `oracle/_ref/*`.  The reference's
  * autotools build is not runnable here (no autoreconf/yaggo); see
- * oracle/README.md.  HAVE_SSE is left undefined => the portable times_128 hash
- * (identical results, see unit_tests/test_rectangular_binary_matrix.cc:153-177). */
+ * oracle/README.md.  HAVE_SSE comes from oracle/Makefile (-DHAVE_SSE=1 -msse2), as the reference's own
+ * configure turns it on for x86 (m4/m4-ax_ext.m4:221,303, configure.ac:62-67): the SSE2 hash is what a user's
+ * build runs, so it is the CPU baseline of record (results identical to the portable path,
+ * unit_tests/test_rectangular_binary_matrix.cc:153-177). */
 #ifndef ORACLE_REF_CONFIG_H
 #define ORACLE_REF_CONFIG_H
 #define HAVE_INT128 1

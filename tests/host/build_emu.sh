@@ -7,3 +7,6 @@ mkdir -p tests/host/_build
 g++ -std=c++17 -O2 -g -x c++ -DJFGPU_EMU -Itests/host/hip_emu -fPIC -shared -pthread \
     -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result -Wno-unknown-pragmas -Wno-sign-compare -Wno-unused-but-set-variable -Wno-unused-variable \
     -o tests/host/_build/libjfgpu_emu.so jellyfish_amd/csrc/jfgpu.hip
+# the CLI against the emulated engine (JFGPU_CLI=tests/host/_build/jellyfish-amd-emu for tests/test_cli_gpu.py)
+g++ -O2 -std=c++17 -Iinclude -Ijellyfish_amd/include -o tests/host/_build/jellyfish-amd-emu jellyfish_amd/cli/jellyfish_amd.cc \
+    -Ltests/host/_build -ljfgpu_emu -Wl,-rpath,'$ORIGIN' -pthread

@@ -396,6 +396,7 @@ template <typename T, typename U> static inline void __hip_atomic_store(T* p, U 
 template <typename T, typename U> static inline T atomicAdd(T* p, U v) { return __atomic_fetch_add(p, (T)v, __ATOMIC_RELAXED); }
 template <typename T, typename U> static inline T atomicSub(T* p, U v) { return __atomic_fetch_sub(p, (T)v, __ATOMIC_RELAXED); }
 template <typename T, typename U> static inline T atomicOr(T* p, U v) { return __atomic_fetch_or(p, (T)v, __ATOMIC_RELAXED); }
+template <typename T, typename U> static inline T atomicXor(T* p, U v) { return __atomic_fetch_xor(p, (T)v, __ATOMIC_RELAXED); }
 template <typename T, typename U> static inline T atomicAnd(T* p, U v) { return __atomic_fetch_and(p, (T)v, __ATOMIC_RELAXED); }
 template <typename T, typename U> static inline T atomicExch(T* p, U v) { return __atomic_exchange_n(p, (T)v, __ATOMIC_RELAXED); }
 template <typename T, typename U> static inline T atomicMax(T* p, U v) { return __hip_atomic_fetch_max(p, v, 0, 0); }

@@ -15,12 +15,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 MANIFEST = json.load(open(os.path.join(GOLD, "manifest.json")))
-CLI = os.path.join(ROOT, "bin", "jellyfish-amd")
+CLI = os.environ.get("JFGPU_CLI") or os.path.join(ROOT, "bin", "jellyfish-amd")    # JFGPU_CLI: tests/host/build_emu.sh debugging build
 
 
 @pytest.fixture(scope="module")
 def cli(gpu):
-    subprocess.check_call(["make", "-s", "cli"], cwd=ROOT)
+    if not os.environ.get("JFGPU_CLI"):
+        subprocess.check_call(["make", "-s", "cli"], cwd=ROOT)
     return CLI
 
 
@@ -49,6 +50,27 @@ def test_count_file_matches_reference_golden(cli, case, tmp_path):
         sample = golden[:: max(1, len(golden) // 100)]
         q = subprocess.check_output([O.REF_JF, "query", out] + [l.split()[0] for l in sample]).decode().splitlines()
         assert q == sample
+
+
+@pytest.mark.parametrize("name", ["reads150_k21C", "reads150_k63C", "reads150_k32"])
+def test_count_digest_equals_the_reference_tables_digest(cli, name, tmp_path):
+    """The at-scale parity instrument (tools/at_scale_parity.sh) on a small case: `jellyfish-amd count --digest`
+    (jfgpu_digest over the device table) == `ref_jf count --digest` (the reference's in-memory table) == the digest
+    of the written file."""
+    from jellyfish_amd import capi
+    case = next(c for c in MANIFEST["cases"] if c["name"] == name)
+    inp, k = os.path.join(GOLD, case["input"]), case["k"]
+    can = ["-C"] if case["canonical"] else []
+    out, dg = str(tmp_path / "o.jf"), str(tmp_path / "d.txt")
+    subprocess.check_call([cli, "count", "-m", str(k), "-s", case["size"], "-o", out, "--digest", dg] + can + [inp])
+    mine = open(dg).read()
+    assert subprocess.check_output([cli, "digest", out]).decode() == mine
+    keys, cnt = O.count(O.parse_file(open(inp, "rb").read()), k, case["canonical"])
+    assert tuple(int(l.split()[1]) for l in mine.splitlines()) == capi.digest_of(keys, cnt)
+    if O.have_ref():
+        subprocess.check_call([O.REF_JF, "count", "-m", str(k), "-s", case["size"], "-t", "2", "--no-write", "--digest", str(tmp_path / "r.txt")] + can + [inp])
+        assert open(tmp_path / "r.txt").read() == mine
+        assert subprocess.check_output([O.REF_JF, "digest", out]).decode() == mine
 
 
 def test_count_text_format_and_bounds(cli, tmp_path):

@@ -187,6 +187,24 @@ def test_lower_upper_and_histo(gpu):
         assert st.distinct == sum(1 for v in exp.values() if lo <= v <= hi)
 
 
+def test_content_digest_matches_dump(gpu):
+    """jfgpu_digest (order-independent checksum used for the 10 Gbp parity runs) == the same checksum of the decoded dump,
+    with and without a count filter, through both insert strategies."""
+    rng = random.Random(5)
+    seq = rnd_seq(rng, 120000, "ACGTN") + rnd_seq(rng, 20000, "AC")
+    for k, mode in ((21, 1), (21, 2), (31, 0), (5, 0)):
+        with gpu.Table(k, 1 << 18) as t:
+            if mode:
+                t.set_mode(mode)
+            t.count_ascii(seq)
+            t.sync()
+            recs = t.dump_records()
+            keys, cnts = gpu.decode_records(recs, k, t.info.out_counter_len)
+            assert t.digest() == gpu.digest_of(keys, cnts)
+            sel = (cnts >= 2) & (cnts <= 40)
+            assert t.digest(2, 40) == gpu.digest_of(keys[sel], cnts[sel])
+
+
 def test_hash_full_is_reported(gpu):
     """More distinct k-mers than slots: the reference throws 'Hash full'
     (hash_counter.hpp:194-195); the engine must fail loudly too, never drop silently."""
@@ -452,6 +470,52 @@ def test_table_grows_like_the_reference(gpu, mode, k, size, n):
         vals, found = t.lookup(keys[:10])
         assert vals.tolist() == [exp[x] + 2 ** 45 for x in keys[:10].tolist()]
         t.free(d)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_add_keys_batch_larger_than_the_table_grows_in_order(gpu, mode):
+    """hash_counter::add on a batch several times the table's size (the facade flushes 2^20 keys at a time): the pieces
+    are enqueued in order, the occupancy is re-measured between them and the table doubles as often as needed."""
+    k, n = 21, 300000
+    rng = np.random.default_rng(7)
+    keys = rng.integers(0, 1 << (2 * k), size=n, dtype=np.uint64)
+    keys[::7] = keys[0]                                       # some duplicates
+    uk, uc = np.unique(keys, return_counts=True)
+    with gpu.Table(k, 1 << 14) as t:                          # 16 K slots for ~257 K distinct keys
+        t.set_mode(mode)
+        first = t.info.lsize
+        t.add_keys(keys, val=1)
+        t.sync()
+        assert t.info.lsize >= first + 4
+        got = table_map(gpu, t)
+        assert got == dict(zip(uk.tolist(), uc.tolist()))
+
+
+def test_spill_mode_add_keys_and_tiny_pieces(gpu):
+    """do_size_doubling(false) with a spill callback (count --disk): batches larger than the table are cut into pieces
+    no larger than the room left, the table is handed to the callback whenever it fills, nothing is lost; a table with
+    less room than k characters still makes progress (pieces hold at least one window)."""
+    k = 10
+    rng = random.Random(99)
+    seq = rnd_seq(rng, 60000)
+    exp = oracle_map(seq, k, True)
+    for size, feed_keys in ((64, False), (16, False), (4096, True)):
+        runs = []
+        with gpu.Table(k, size) as t:
+            t.set_growth(False)
+            t.set_spill(lambda: runs.append(table_map(gpu, t, check_order=False)) or 0)
+            if feed_keys:
+                okeys, ocnt = O.count(seq, k, True)
+                t.add_keys(np.repeat(okeys[:, 0], ocnt.astype(np.int64)), val=1)
+            else:
+                t.count_ascii(seq)
+            t.sync()
+            runs.append(table_map(gpu, t, check_order=False))
+        tot = {}
+        for r in runs:
+            for key, c in r.items():
+                tot[key] = tot.get(key, 0) + c
+        assert len(runs) > 1 and tot == exp, (size, feed_keys, len(runs))
 
 
 # ---- single-pass P1 (p1_scatter_granule_kernel): fixed bucket regions, reservations of 64 items ----------

@@ -67,6 +67,17 @@ def test_wide_count_matches_oracle(gpu, k, canonical, n, alphabet):
         assert {base + i * inc: int(c) for i, c in enumerate(h) if c} == ref
 
 
+def test_wide_content_digest(gpu):
+    rng = random.Random(11)
+    seq = "".join(rng.choice("ACGTN") for _ in range(60000)).encode()
+    for k in (33, 63):
+        with gpu.Table(k, 1 << 16) as t:
+            t.count_ascii(seq)
+            t.sync()
+            keys, cnts = gpu.decode_records(t.dump_records(), k, t.info.out_counter_len)
+            assert t.digest() == gpu.digest_of(keys, cnts)
+
+
 def test_wide_add_keys_and_overflow(gpu):
     k = 63
     rng = random.Random(3)

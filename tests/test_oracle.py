@@ -212,3 +212,32 @@ def test_bloom_restatement_reproduces_reference_file(case):
     kept = sorted("%s %d" % (O.to_str(keys[i], k), cnt[i]) for i in range(len(keys))
                   if L.jfo_bc_check(data.ctypes.data, m, nh, int(kh0[i]), int(kh1[i])) > 1)
     assert kept == open(os.path.join(GOLD, case["name"] + ".filtered.dump")).read().splitlines()
+
+
+def _digest_lines(txt):
+    return tuple(int(l.split()[1]) for l in txt.strip().splitlines())
+
+
+@needs_ref
+@pytest.mark.parametrize("k,can", [(21, True), (40, False), (63, True), (100, True)])
+def test_content_digest_three_ways(tmp_path, k, can):
+    """The at-scale parity checksum (include/jfgpu.h, jfgpu_digest): the reference driver computes it from the reference's
+    in-memory table (`count --digest`, large_hash_array iterators) and from a file (`digest`); both equal the numpy
+    restatement applied to the oracle's own counts.  One-, two- and four-word keys."""
+    from jellyfish_amd import capi
+    fa = os.path.join(GOLD, "reads150_s42.fa")
+    d = str(tmp_path)
+    args = [O.REF_JF, "count", "-m", str(k), "-s", "64k", "-t", "3", "-o", "x.jf", "--digest", "mem.txt", fa]
+    if can:
+        args.insert(2, "-C")
+    subprocess.check_call(args, cwd=d)
+    mem = _digest_lines(open(os.path.join(d, "mem.txt")).read())
+    fil = _digest_lines(subprocess.check_output([O.REF_JF, "digest", "x.jf"], cwd=d).decode())
+    keys, cnt = O.count(O.parse_file(open(fa, "rb").read()), k, can)
+    mine = capi.digest_of(keys, cnt)
+    assert mem == fil == mine
+    # with a count filter
+    args[args.index("mem.txt")] = "lu.txt"
+    subprocess.check_call(args[:2] + ["-L", "2", "-U", "3"] + args[2:], cwd=d)
+    sel = (cnt >= 2) & (cnt <= 3)
+    assert _digest_lines(open(os.path.join(d, "lu.txt")).read()) == capi.digest_of(keys[sel], cnt[sel])
