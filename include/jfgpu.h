@@ -197,6 +197,16 @@ int  jfgpu_bc_read(jfgpu_bloom* b, uint8_t* out);
 int  jfgpu_bc_load(jfgpu_bloom* b, const uint8_t* data);
 /* bloom_base::check / insert on encoded k-mers (query_main.cc Bloom branch); out[i] = 0, 1 or 2 */
 int  jfgpu_bc_keys(jfgpu_bloom* b, const uint64_t* keys, size_t n, uint8_t* out, int do_insert);
+/* How jfgpu_bc_insert_* applies the increments (no reference counterpart; the array is the same either way because the
+ * increments saturate and commute): 0 auto, 1 direct (one global compare-and-swap per cell), 2 partitioned (cell updates
+ * routed to 64 KiB segments of the array and applied in LDS at the next jfgpu_bc_sync / _read / _keys / attach).
+ * jfgpu_bc_reserve sizes the routing workspace up front (default: taken from free memory at the first large batch). */
+int  jfgpu_bc_set_mode(jfgpu_bloom* b, int mode);
+int  jfgpu_bc_reserve(jfgpu_bloom* b, uint64_t workspace_bytes);
+/* per-stage device time on the counter's stream (bench.py): which = 0 direct, 1 route (P1), 2 partition (P2), 3 segments */
+int  jfgpu_bc_profile_enable(jfgpu_bloom* b, int on);
+int  jfgpu_bc_profile_get(jfgpu_bloom* b, int which, double* ms, uint64_t* launches, uint64_t* units);
+int  jfgpu_bc_profile_reset(jfgpu_bloom* b);
 /* count --bc: from now on jfgpu_count_* admits a k-mer only if check(m) > 1 (count_main.cc:115-118).
  * b == NULL detaches.  The Bloom counter must outlive its use. */
 int  jfgpu_attach_bloom(jfgpu_table* t, jfgpu_bloom* b);

@@ -90,6 +90,11 @@ SIGNATURES = {
     "jfgpu_bc_read": (C.c_int, [_P, _P]),
     "jfgpu_bc_load": (C.c_int, [_P, _P]),
     "jfgpu_bc_keys": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_int]),
+    "jfgpu_bc_set_mode": (C.c_int, [_P, C.c_int]),
+    "jfgpu_bc_reserve": (C.c_int, [_P, C.c_uint64]),
+    "jfgpu_bc_profile_enable": (C.c_int, [_P, C.c_int]),
+    "jfgpu_bc_profile_get": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "jfgpu_bc_profile_reset": (C.c_int, [_P]),
     "jfgpu_attach_bloom": (C.c_int, [_P, _P]),
     "jfgpu_parser_create": (C.c_int, [C.c_int, C.c_uint32, C.POINTER(_P)]),
     "jfgpu_parser_destroy": (None, [_P]),
@@ -415,6 +420,24 @@ class Bloom:
         data = np.ascontiguousarray(data, dtype=np.uint8)
         assert len(data) == self.nb_bytes
         _check(self._lib.jfgpu_bc_load(self._h, data.ctypes.data))
+
+    def set_mode(self, mode):
+        """0 auto, 1 direct (global compare-and-swap per cell), 2 partitioned (cell updates applied per 64 KiB segment in LDS)."""
+        _check(self._lib.jfgpu_bc_set_mode(self._h, mode))
+
+    def reserve(self, workspace_bytes):
+        _check(self._lib.jfgpu_bc_reserve(self._h, int(workspace_bytes)))
+
+    def profile_enable(self, on=True):
+        _check(self._lib.jfgpu_bc_profile_enable(self._h, int(on)))
+
+    def profile_get(self, which):
+        ms, ln, un = C.c_double(), C.c_uint64(), C.c_uint64()
+        _check(self._lib.jfgpu_bc_profile_get(self._h, which, C.byref(ms), C.byref(ln), C.byref(un)))
+        return ms.value, ln.value, un.value
+
+    def profile_reset(self):
+        _check(self._lib.jfgpu_bc_profile_reset(self._h))
 
     def keys(self, keys, insert=False):
         keys = np.ascontiguousarray(keys, dtype=np.uint64)

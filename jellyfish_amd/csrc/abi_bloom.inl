@@ -11,7 +11,19 @@ struct jfgpu_bloom {
   uint32_t* d_data = nullptr; size_t data_bytes = 0, alloc_bytes = 0;
   unsigned long long* d_mers = nullptr;
   uint8_t* d_stage = nullptr;
-  DevBloom view() const { DevBloom b; b.data = d_data; b.m = m; b.nh = nh; b.nbytes = g.nbytes; b.tbl1 = d_t1; b.tbl2 = d_t2; return b; }
+  // partitioned insert (kernels_bloom_part.hip.hpp, bloom_partition.inl)
+  BloomPart bp{}; bool part_ok = false;
+  int mode = 0;                    // 0 auto, 1 direct (global CAS), 2 partitioned (JFGPU_BLOOM_MODE / jfgpu_bc_set_mode)
+  double slack = 0.03;             // head-room of a bucket region over the mean
+  int g1 = 0;
+  uint8_t* ws = nullptr; size_t ws_cap = 0, ws_used = 0;
+  struct Pending { uint32_t* items; uint64_t* off; unsigned long long* tot; uint32_t cap; };
+  std::vector<Pending> pending;
+  uint32_t* d_M2 = nullptr;
+  bool prof_on = false;
+  std::vector<ProfSpan> spans;
+  double prof_ms[4] = {}; uint64_t prof_launches[4] = {}, prof_units[4] = {};
+  DevBloom view() const { DevBloom b; b.data = d_data; b.m = m; b.recip = bloom_recip(m); b.nh = nh; b.nbytes = g.nbytes; b.tbl1 = d_t1; b.tbl2 = d_t2; return b; }
 };
 
 namespace {
@@ -30,6 +42,8 @@ void plain_tables(const Gf2Matrix& m, std::vector<uint64_t>& tbl) {
   for(uint32_t j = 0; j < m.c; ++j) img[j] = m.col_for_bit(j);
   gf2_byte_tables(img, (m.c + 7) / 8, tbl);
 }
+typedef jfgpu_bloom::Pending BloomPending;
+#include "bloom_partition.inl"
 }  // namespace
 
 extern "C" {
@@ -83,6 +97,20 @@ int jfgpu_bc_create(const jfgpu_bloom_params* p, jfgpu_bloom** out) {
   HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
   b->data_bytes = b->m / 5 + (b->m % 5 != 0);                    // bloom_counter2.hpp:40-42
   b->alloc_bytes = (b->data_bytes + 3) / 4 * 4 + 4;
+  bloom_part_init(b.get());
+  if(b->part_ok) b->alloc_bytes = ((size_t)b->bp.n_seg << kBloomSegBits) + 4;      // whole segments are loaded and stored
+  if(const char* e = getenv("JFGPU_BLOOM_MODE")) {
+    if(!strcmp(e, "direct")) b->mode = 1;
+    else if(!strcmp(e, "partitioned") && b->part_ok) b->mode = 2;
+  }
+  {
+    const int pl = (int)((size_t)kBloomChunk * 6 + (size_t)2 * 8 * 2048);
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_bloom_granule_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, pl));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_bloom_granule_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, pl));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_bloom_granule_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, pl));
+    HIP_TRY(hipFuncSetAttribute((const void*)bloom_segment_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 1 << kBloomSegBits));
+    HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint32_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * 16 * 4));
+  }
   HIP_TRY(hipMalloc((void**)&b->d_data, b->alloc_bytes));
   HIP_TRY(hipMemsetAsync(b->d_data, 0, b->alloc_bytes, b->stream));
   HIP_TRY(hipMalloc((void**)&b->d_t1, t1.size() * 8)); HIP_TRY(hipMalloc((void**)&b->d_t2, t2.size() * 8));
@@ -99,8 +127,11 @@ void jfgpu_bc_destroy(jfgpu_bloom* b) {
   if(!b) return;
   hipSetDevice(b->device);
   if(b->stream) hipStreamSynchronize(b->stream);
+  bloom_prof_collect(b);
   hipFree(b->d_data); hipFree(b->d_t1); hipFree(b->d_t2); hipFree(b->d_mers);
   if(b->d_stage) hipFree(b->d_stage);
+  if(b->ws) hipFree(b->ws);
+  if(b->d_M2) hipFree(b->d_M2);
   if(b->stream) hipStreamDestroy(b->stream);
   delete b;
 }
@@ -111,12 +142,10 @@ int jfgpu_bc_insert_ascii_dev(jfgpu_bloom* b, const char* d_bases, size_t n) {
   if(!d_bases) return fail(JFGPU_E_INVALID, "null buffer");
   const uint8_t* base; int64_t lo, hi;
   align_buffer(d_bases, n, base, lo, hi);
-  const int64_t n_tiles = (hi + kTilePos - 1) / kTilePos;
-  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(n_tiles, (int64_t)b->n_cu * 8));
-  if(b->wide) hipLaunchKernelGGL(bloom_insert_ascii_wide_kernel, dim3(grid), dim3(kBlock), 0, b->stream, b->view(), b->wg, base, lo, hi, b->d_mers);
-  else hipLaunchKernelGGL(bloom_insert_ascii_kernel, dim3(grid), dim3(kBlock), 0, b->stream, b->view(), b->g, base, lo, hi, b->d_mers);
-  HIP_TRY(hipGetLastError());
-  return JFGPU_OK;
+  // the increments saturate and commute, so batches may be applied in any order: large ones are buffered as routed cell
+  // updates and applied segment by segment at the next flush (sync / read / attach), small ones go straight to the array
+  if(bloom_use_partitioned(b, n)) return bloom_ingest(b, base, lo, hi);
+  return bloom_launch_direct(b, base, lo, hi);
 }
 
 int jfgpu_bc_insert_ascii(jfgpu_bloom* b, const char* bases, size_t n) {
@@ -137,6 +166,7 @@ int jfgpu_bc_insert_ascii(jfgpu_bloom* b, const char* bases, size_t n) {
 
 int jfgpu_bc_sync(jfgpu_bloom* b, uint64_t* mers_fed) {
   int rc = use_b(b); if(rc) return rc;
+  rc = bloom_flush(b); if(rc) return rc;
   unsigned long long m = 0;
   HIP_TRY(hipMemcpyAsync(&m, b->d_mers, sizeof m, hipMemcpyDeviceToHost, b->stream));
   HIP_TRY(hipStreamSynchronize(b->stream));
@@ -156,6 +186,7 @@ int jfgpu_bc_get_info(const jfgpu_bloom* b, uint64_t* m, uint32_t* nb_hashes, ui
 
 int jfgpu_bc_read(jfgpu_bloom* b, uint8_t* out) {          // bloom_base::write_bits (bloom_common.hpp)
   int rc = use_b(b); if(rc) return rc;
+  rc = bloom_flush(b); if(rc) return rc;
   HIP_TRY(hipMemcpyAsync(out, b->d_data, b->data_bytes, hipMemcpyDeviceToHost, b->stream));
   HIP_TRY(hipStreamSynchronize(b->stream));
   return JFGPU_OK;
@@ -163,6 +194,7 @@ int jfgpu_bc_read(jfgpu_bloom* b, uint8_t* out) {          // bloom_base::write_
 
 int jfgpu_bc_load(jfgpu_bloom* b, const uint8_t* data) {   // bloom_counter2(m, k, istream&, fns)
   int rc = use_b(b); if(rc) return rc;
+  rc = bloom_flush(b); if(rc) return rc;
   HIP_TRY(hipMemcpyAsync(b->d_data, data, b->data_bytes, hipMemcpyHostToDevice, b->stream));
   HIP_TRY(hipStreamSynchronize(b->stream));
   return JFGPU_OK;
@@ -170,6 +202,7 @@ int jfgpu_bc_load(jfgpu_bloom* b, const uint8_t* data) {   // bloom_counter2(m, 
 
 int jfgpu_bc_keys(jfgpu_bloom* b, const uint64_t* keys, size_t n, uint8_t* out, int do_insert) {
   int rc = use_b(b); if(rc) return rc;
+  rc = bloom_flush(b); if(rc) return rc;
   if(!n) return JFGPU_OK;
   uint64_t* d_k = nullptr; uint8_t* d_o = nullptr;
   const size_t kw = b->wide ? 2 : 1;                       // words per key (little-endian words, like jfgpu_add_keys)
@@ -190,6 +223,51 @@ int jfgpu_bc_keys(jfgpu_bloom* b, const uint64_t* keys, size_t n, uint8_t* out, 
   return JFGPU_OK;
 }
 
+int jfgpu_bc_set_mode(jfgpu_bloom* b, int mode) {
+  int rc = use_b(b); if(rc) return rc;
+  if(mode < 0 || mode > 2) return fail(JFGPU_E_INVALID, "mode must be 0 (auto), 1 (direct) or 2 (partitioned)");
+  if(mode == 2 && !b->part_ok) return fail(JFGPU_E_UNSUPPORTED, "this Bloom counter has no partitioned insert path");
+  rc = bloom_flush(b); if(rc) return rc;
+  b->mode = mode;
+  return JFGPU_OK;
+}
+
+int jfgpu_bc_reserve(jfgpu_bloom* b, uint64_t workspace_bytes) {
+  int rc = use_b(b); if(rc) return rc;
+  if(!b->part_ok || b->mode == 1) return JFGPU_OK;
+  rc = bloom_flush(b); if(rc) return rc;
+  rc = bloom_ws_ensure(b, std::max<uint64_t>(workspace_bytes, (uint64_t)64 << 20));
+  if(rc < 0) return fail(JFGPU_E_ALLOC, "not enough device memory for the Bloom partition workspace");
+  if(rc) return rc;
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  return JFGPU_OK;
+}
+
+int jfgpu_bc_profile_enable(jfgpu_bloom* b, int on) {
+  int rc = use_b(b); if(rc) return rc;
+  b->prof_on = on != 0;
+  return JFGPU_OK;
+}
+
+int jfgpu_bc_profile_get(jfgpu_bloom* b, int which, double* ms, uint64_t* launches, uint64_t* units) {
+  int rc = use_b(b); if(rc) return rc;
+  if(which < 0 || which >= BS_COUNT) return fail(JFGPU_E_INVALID, "bad profile slot");
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  bloom_prof_collect(b);
+  if(ms) *ms = b->prof_ms[which];
+  if(launches) *launches = b->prof_launches[which];
+  if(units) *units = b->prof_units[which];
+  return JFGPU_OK;
+}
+
+int jfgpu_bc_profile_reset(jfgpu_bloom* b) {
+  int rc = use_b(b); if(rc) return rc;
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  bloom_prof_collect(b);
+  for(int i = 0; i < BS_COUNT; ++i) { b->prof_ms[i] = 0; b->prof_launches[i] = 0; b->prof_units[i] = 0; }
+  return JFGPU_OK;
+}
+
 int jfgpu_attach_bloom(jfgpu_table* t, jfgpu_bloom* b) {   // count --bc (count_main.cc:191-206,313-316)
   int rc = use(t); if(rc) return rc;
   rc = part_flush(t); if(rc) return rc;
@@ -197,6 +275,7 @@ int jfgpu_attach_bloom(jfgpu_table* t, jfgpu_bloom* b) {   // count --bc (count_
   if(b->device != t->device) return fail(JFGPU_E_INVALID, "Bloom counter lives on another device");
   if(b->g.k != t->g.k) return fail(JFGPU_E_INVALID, "Invalid mer length in bloom filter");
   if(t->g.shard_bits) return fail(JFGPU_E_UNSUPPORTED, "count --bc on a sharded table is not built yet");
+  rc = bloom_flush(b); if(rc) return rc;
   HIP_TRY(hipStreamSynchronize(b->stream));
   if(t->wide) t->wt.bloom = b->view(); else t->dt.bloom = b->view();
   return JFGPU_OK;

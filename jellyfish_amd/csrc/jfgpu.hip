@@ -19,6 +19,7 @@
 #include "kernels.hip.hpp"
 #include "kernels_part.hip.hpp"
 #include "kernels_bloom.hip.hpp"
+#include "kernels_bloom_part.hip.hpp"
 #include "kernels_wide.hip.hpp"
 #include "kernels_parse.hip.hpp"
 

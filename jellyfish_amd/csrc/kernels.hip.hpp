@@ -40,6 +40,7 @@ enum Counter : int { CTR_FULL = 0, CTR_MERS = 1, CTR_OVF_FULL = 2, CTR_OVF_USED 
 struct DevBloom {
   uint32_t* data;             // ceil(m/5) bytes, addressed as dwords
   uint64_t m;                 // number of base-3 cells
+  uint64_t recip;             // floor(2^64 / m): x % m without a 64-bit divide (the reference's divisor64, divisor.hpp:64-109)
   uint32_t nh;                // hash functions per key
   uint32_t nbytes;            // key bytes fed to the tables
   const uint64_t* tbl1;       // byte tables of the two 64-row matrices

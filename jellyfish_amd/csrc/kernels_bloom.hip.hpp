@@ -15,13 +15,18 @@
 
 namespace jfgpu {
 
-__device__ __constant__ const uint32_t kPow3[5] = {1, 3, 9, 27, 81};
-
 // p / 5 and p % 5 without a 64-bit divide.
 __device__ inline void divmod5(uint64_t p, uint64_t& q, uint32_t& r) {
   q = __umul64hi(p, 0xCCCCCCCCCCCCCCCDull) >> 2;
   r = (uint32_t)(p - q * 5);
 }
+
+// digit j (0..4) of a byte holding five base-3 cells, and 3^j, without tables or variable divisors
+__device__ inline uint32_t bloom_digit(uint32_t v, uint32_t j) {
+  const uint32_t q = j == 0 ? v : j == 1 ? v / 3u : j == 2 ? v / 9u : j == 3 ? v / 27u : v / 81u;
+  return q % 3u;
+}
+__device__ inline uint32_t bloom_pow3(uint32_t j) { return j == 0 ? 1u : j == 1 ? 3u : j == 2 ? 9u : j == 3 ? 27u : 81u; }
 
 // Increment digit `boff` of the byte at byte index `byte` unless it is already 2.  Returns the previous digit.
 __device__ inline uint32_t bloom_bump(uint32_t* words, uint64_t byte, uint32_t boff) {
@@ -30,17 +35,32 @@ __device__ inline uint32_t bloom_bump(uint32_t* words, uint64_t byte, uint32_t b
   uint32_t old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   while(true) {
     const uint32_t v = (old >> sh) & 0xFFu;
-    const uint32_t d = (v / kPow3[boff]) % 3;
+    const uint32_t d = bloom_digit(v, boff);
     if(d == 2) return 2;
-    const uint32_t nw = old + (kPow3[boff] << sh);      // v + 3^boff <= 242: never carries out of the byte
+    const uint32_t nw = old + (bloom_pow3(boff) << sh);  // v + 3^boff <= 242: never carries out of the byte
     const uint32_t seen = atomicCAS(w, old, nw);
     if(seen == old) return d;
     old = seen;
   }
 }
 
+// x % m by a precomputed reciprocal (bloom_counter2.hpp:60-64 uses divisor64 for the same reason): the estimate
+// floor(x * floor(2^64 / m) / 2^64) is the quotient or one less, so at most one correction is needed (two are allowed).
+__device__ __host__ inline uint64_t bloom_mod(uint64_t x, uint64_t m, uint64_t recip) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint64_t q = __umul64hi(x, recip);
+#else
+  const uint64_t q = (uint64_t)(((unsigned __int128)x * recip) >> 64);
+#endif
+  uint64_t r = x - q * m;
+  if(r >= m) r -= m;
+  if(r >= m) r -= m;
+  return r;
+}
+inline uint64_t bloom_recip(uint64_t m) { return m <= 1 ? ~0ull : (uint64_t)((((unsigned __int128)1) << 64) / m); }
+
 __device__ inline uint32_t bloom_insert(const DevBloom& B, uint64_t h0, uint64_t h1) {
-  const uint64_t base = h0 % B.m, inc = h1 % B.m;
+  const uint64_t base = bloom_mod(h0, B.m, B.recip), inc = bloom_mod(h1, B.m, B.recip);
   uint64_t p = base;
   uint32_t res = 2;
   for(uint32_t i = 0; i < B.nh; ++i) {
@@ -54,24 +74,45 @@ __device__ inline uint32_t bloom_insert(const DevBloom& B, uint64_t h0, uint64_t
 }
 
 __device__ inline uint32_t bloom_check(const DevBloom& B, uint64_t h0, uint64_t h1) {
-  const uint64_t base = h0 % B.m, inc = h1 % B.m;
+  const uint64_t base = bloom_mod(h0, B.m, B.recip), inc = bloom_mod(h1, B.m, B.recip);
   uint64_t p = base;
   uint32_t res = 2;
   for(uint32_t i = 0; i < B.nh; ++i) {
     uint64_t byte; uint32_t boff;
     divmod5(p, byte, boff);
     const uint32_t v = (B.data[byte >> 2] >> (8 * (uint32_t)(byte & 3))) & 0xFFu;
-    const uint32_t d = (v / kPow3[boff]) % 3;
+    const uint32_t d = bloom_digit(v, boff);
     res = d < res ? d : res;
     p += inc; if(p >= B.m) p -= B.m;
   }
   return res;
 }
 
+// check(m) > 1, i.e. every one of the nh cells holds 2, decided as early as possible: the first cell below 2 ends the
+// search (same answer as bloom_check() > 1).  A k-mer seen once fails at its first or second cell with high
+// probability, so the filter pass of `count --bc` costs ~1.2 random reads per singleton instead of nh; cells are
+// read two at a time so that a k-mer that passes does not pay nh dependent round trips.
+__device__ inline bool bloom_all_two(const DevBloom& B, uint64_t h0, uint64_t h1) {
+  const uint64_t base = bloom_mod(h0, B.m, B.recip), inc = bloom_mod(h1, B.m, B.recip);
+  uint64_t p = base;
+  for(uint32_t i = 0; i < B.nh; i += 2) {
+    uint64_t p2 = p + inc; if(p2 >= B.m) p2 -= B.m;
+    uint64_t b0, b1; uint32_t o0, o1;
+    divmod5(p, b0, o0); divmod5(p2, b1, o1);
+    const bool two = i + 1 < B.nh;
+    const uint32_t w0 = B.data[b0 >> 2];
+    const uint32_t w1 = two ? B.data[b1 >> 2] : 0u;
+    if(bloom_digit((w0 >> (8 * (uint32_t)(b0 & 3))) & 0xFFu, o0) < 2) return false;
+    if(two && bloom_digit((w1 >> (8 * (uint32_t)(b1 & 3))) & 0xFFu, o1) < 2) return false;
+    p = p2 + inc; if(p >= B.m) p -= B.m;
+  }
+  return true;
+}
+
 // count --bc filter (count_main.cc:115-118); tables read through the caches (12-16 KiB hot set).
 __device__ inline bool bloom_admits(const DevBloom& B, uint64_t key) {
   const uint64_t h0 = hash_tables(B.tbl1, key, B.nbytes), h1 = hash_tables(B.tbl2, key, B.nbytes);
-  return bloom_check(B, h0, h1) > 1;
+  return bloom_all_two(B, h0, h1);
 }
 
 // K4: insert every (canonical) k-mer of a contract buffer into the Bloom counter.

@@ -705,10 +705,12 @@ __device__ inline void granule_init(GranuleLds& G, uint32_t nb) {
   for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) { G.cur[j] = 0; G.room[j] = 0; G.cnt[j] = 0; }
 }
 
-template <bool RETURNING, int N>
-__device__ inline uint32_t granule_emit(GranuleLds& G, const DevTable& T, const PartGeom& P, uint32_t nb, uint32_t cap,
+// direct(b, item): what to do with an item that cannot be stored in bucket b's region (region exhausted, or the item
+// equals the hole marker) -- the count path inserts it with global atomics, the Bloom path bumps its cell.
+template <int N, typename DIRECT>
+__device__ inline uint32_t granule_emit(GranuleLds& G, uint32_t nb, uint32_t cap,
                                         unsigned int* __restrict__ gcur, uint32_t* __restrict__ out, uint32_t* s_item, uint16_t* s_bkt,
-                                        const uint32_t (&it)[N], const uint32_t (&dr)[N]) {
+                                        const uint32_t (&it)[N], const uint32_t (&dr)[N], DIRECT&& direct_fn) {
   lds_barrier();
   block_excl_scan_2048(G.hist, G.lstart, nb, G.wave);
   lds_barrier();
@@ -752,7 +754,7 @@ __device__ inline uint32_t granule_emit(GranuleLds& G, const DevTable& T, const 
       out[(uint64_t)b * cap + rel] = v;
       if(v == 0xFFFFFFFFu) { direct = true; atomicSub(&G.cnt[b], 1u); }   // its slot now reads as a hole
     }
-    if(direct) { item_direct_insert<RETURNING>(T, P, b, (uint64_t)v); ++direct_n; }
+    if(direct) { direct_fn(b, v); ++direct_n; }
   }
   return direct_n;
 }
@@ -814,7 +816,8 @@ __global__ __launch_bounds__(kPBlock) void p1_scatter_granule_kernel(DevTable T,
     });
     flush_run(kPerLane);
     if(long_runs) my_direct += apply_runs<RETURNING, BLOOM>(T, s_fwd, L);
-    my_direct += granule_emit<RETURNING>(G, T, P, nb, cap, gcur, out, s_item, s_bkt, it, dr);
+    my_direct += granule_emit(G, nb, cap, gcur, out, s_item, s_bkt, it, dr,
+                              [&](uint32_t b, uint32_t v) { item_direct_insert<RETURNING>(T, P, b, (uint64_t)v); });
   }
   granule_finish(G, nb, cap, tot, out);
   if(my_direct) atomicAdd((unsigned long long*)&T.counters[CTR_DIRECT], (unsigned long long)my_direct);
@@ -870,7 +873,8 @@ __global__ __launch_bounds__(kPBlock) void p1_keys_granule_kernel(DevTable T, Pa
       }
     }
     fetch(c0 + kPTilePos);                                 // next chunk's keys travel during the sort and the write-out
-    my_direct += granule_emit<RETURNING>(G, T, P, nb, cap, gcur, out, s_item, s_bkt, it, dr);
+    my_direct += granule_emit(G, nb, cap, gcur, out, s_item, s_bkt, it, dr,
+                              [&](uint32_t b, uint32_t v) { item_direct_insert<RETURNING>(T, P, b, (uint64_t)v); });
   }
   granule_finish(G, nb, cap, tot, out);
   if(my_direct) atomicAdd((unsigned long long*)&T.counters[CTR_DIRECT], (unsigned long long)my_direct);

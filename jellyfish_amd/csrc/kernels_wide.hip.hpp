@@ -237,7 +237,7 @@ __device__ inline void for_each_kmer_wide(const WideGeom& W, const LaneWordsW& L
 // Bloom counter on two-word keys: h0 = M1 * key, h1 = M2 * key with 64 x 2k matrices (mer_dna_bloom_counter.hpp:19-34);
 // the byte tables (16 x 256 entries each) are read through the caches.
 __device__ inline bool bloom_admits_wide(const DevBloom& B, u128 key) {
-  return bloom_check(B, hash_tables_wide(B.tbl1, key, B.nbytes), hash_tables_wide(B.tbl2, key, B.nbytes)) > 1;
+  return bloom_all_two(B, hash_tables_wide(B.tbl1, key, B.nbytes), hash_tables_wide(B.tbl2, key, B.nbytes));
 }
 
 __global__ __launch_bounds__(kBlock) void bloom_insert_ascii_wide_kernel(DevBloom B, WideGeom W, const uint8_t* __restrict__ base,

@@ -145,3 +145,43 @@ def test_count_bc_single_pass_partition_equals_direct(gpu, monkeypatch):
         assert all(got.get(key, 0) == c for key, c in exact.items() if c >= 2)          # nothing seen twice is lost
         singles = [key for key, c in exact.items() if c == 1]
         assert sum(1 for key in singles if key in got) < 0.01 * len(singles)            # only false positives survive
+
+
+@pytest.mark.parametrize("n_cells,two_level", [(14 * 150000, False), (14 * 30_000_000, True)])
+def test_partitioned_insert_equals_direct_and_oracle(gpu, n_cells, two_level):
+    """The partitioned insert (cell updates routed to 64 KiB segments, applied in LDS: kernels_bloom_part.hip.hpp) leaves
+    the same bytes as one global compare-and-swap per cell and as the oracle's bloom_counter2 restatement; with more
+    than 1024 segments the second partition level (P2) is on the path.  Several batches per flush, saturation at 2,
+    a flush in the middle (check on encoded keys), inserts after it."""
+    rng = random.Random(17)
+    k, nh = 31, 10
+    seq = ("".join(rng.choice("ACGT") for _ in range(90000)) + "N" + "".join(rng.choice("ACGTacgtN") for _ in range(30000))).encode()
+    seq = seq + seq[:50000] + seq[:20000]                      # parts of it two and three times: cells saturate
+    out = {}
+    for mode in (1, 2):
+        with gpu.Bloom(k, n_cells, nh, canonical=True, seed=9) as b:
+            b.set_mode(mode)
+            b.profile_enable(True)
+            third = len(seq) // 3
+            b.insert_ascii(seq[:third])
+            b.insert_ascii(seq[third - (k - 1): 2 * third])
+            kmers = O.extract(seq[:third], k, True)
+            assert (b.keys(kmers[::501, 0]) >= 1).all()          # flushes what is pending
+            b.insert_ascii(seq[2 * third - (k - 1):])
+            assert b.sync() == len(O.extract(seq, k, True))
+            out[mode] = b.read()
+            used = [b.profile_get(i)[1] for i in range(4)]
+            if mode == 2:
+                assert used[1] > 0 and used[3] > 0 and (used[2] > 0) == two_level, used
+            else:
+                assert used[1] == 0 and used[0] > 0
+            m1, m2 = b.matrix1, b.matrix2
+    assert (out[1] == out[2]).all()
+    if not two_level:
+        kmers = O.extract(seq, k, True)
+        h0, h1 = O.matrix_times(m1, 64, 2 * k, kmers), O.matrix_times(m2, 64, 2 * k, kmers)
+        data = np.zeros(len(out[1]), dtype=np.uint8)
+        L = O.lib()
+        for x, y in zip(h0.tolist(), h1.tolist()):
+            L.jfo_bc_insert(data.ctypes.data, n_cells, nh, x, y)
+        assert (out[2] == data).all()
