@@ -6,21 +6,23 @@ constexpr uint64_t kPartMinBytes = 1u << 20;   // AUTO: smaller device batches t
 
 void part_geom_init(jfgpu_table* t) {
   const uint32_t bits = t->g.lsize_l - t->g.tile_bits;   // tile-index bits to resolve
-  t->part_ok = false;
+  t->part_ok = false; t->item32 = false; t->item128 = false;
   if(t->g.tile_bits < kMaxTileBits) return;               // tiny table: one partial tile
   uint32_t b1, b2;
-  if(bits <= 11) { b1 = bits; b2 = 0; }
+  const uint32_t one_level = t->wide ? 10 : 11;           // two-word keys only have the single-pass P1 (<= 1024 buckets)
+  if(bits <= one_level) { b1 = bits; b2 = 0; }
   else { b2 = std::min<uint32_t>(11, (bits + 1) / 2); b1 = bits - b2; }
-  if(b1 > 11) return;
+  if(b1 > one_level) return;
   t->pg.b1 = b1; t->pg.b2 = b2;
   t->pg.rest_shift = t->g.lsize_l - b1;
   t->pg.item_bits = t->pg.rest_shift + t->g.rem_bits;
+  if(t->wide) { t->item128 = true; t->part_ok = t->pg.item_bits <= 128; return; }
   if(t->pg.item_bits > 64) return;
   t->item32 = t->pg.item_bits <= 32;
   t->part_ok = true;
 }
 
-size_t item_size(const jfgpu_table* t) { return t->item32 ? 4 : 8; }
+size_t item_size(const jfgpu_table* t) { return t->item128 ? 16 : t->item32 ? 4 : 8; }
 
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -77,10 +79,11 @@ int part_flush(jfgpu_table* t);
 // mostly holes: auto mode wants the mean bucket load to be at least 4x that.
 uint32_t granule_cap(const jfgpu_table* t, bool from_keys, uint64_t max_items) {
   (void)from_keys;
-  if(!t->item32 || t->pg.b2 == 0 || t->pg.b1 > 10 || t->p1_single == 0 || !t->g1) return 0;
+  if(t->item128) { if(t->pg.b1 > 10 || !t->g1) return 0; }              // the only P1 two-word keys have
+  else if(!t->item32 || t->pg.b2 == 0 || t->pg.b1 > 10 || t->p1_single == 0 || !t->g1) return 0;
   const uint64_t nb = 1ull << t->pg.b1, strand = (uint64_t)t->g1 * kGran;
   const uint64_t mean = (max_items + nb - 1) / nb;
-  if(t->p1_single < 0 && mean < 4 * strand) return 0;
+  if(t->p1_single < 0 && mean < 4 * strand && !(t->item128 && t->mode == MODE_PARTITIONED)) return 0;
   const double want = (double)mean * (1.0 + t->p1_slack) + (double)strand;
   uint64_t cap = want < (double)kGran ? kGran : (uint64_t)want;
   cap = (cap + kGran - 1) / kGran * kGran;
@@ -98,8 +101,12 @@ int part_ingest(jfgpu_table* t, const uint8_t* base, int64_t lo, int64_t hi, boo
   }
   if(t->pending.size() >= kMaxSeg) { int rc = part_flush(t); if(rc) return rc; }
   const uint32_t gcap = granule_cap(t, from_keys, max_items);
-  const size_t bytes = gcap ? (size_t)nb * gcap * sizeof(uint32_t) : max_items * item_size(t);
+  if(t->item128 && (!gcap || from_keys)) return -1;       // two-word keys: single-pass P1 from sequence or the direct kernel
+  const size_t bytes = gcap ? (size_t)nb * gcap * item_size(t) : max_items * item_size(t);
   const size_t need = align_up(bytes, 256) + align_up((2 * nb + 1) * sizeof(uint64_t), 256) + (gcap ? align_up(nb * 16, 256) : 0) + 1024;
+  // 16-byte items: the arena may be smaller than what the whole input needs, so keep half of it for the flush's P2 output
+  const size_t ws_limit = t->item128 && t->pg.b2 ? t->ws_cap / 2 : t->ws_cap;
+  if(t->item128 && !t->pending.empty() && t->ws_used + need > ws_limit) { int rc = part_flush(t); if(rc) return rc; }
   if(t->ws_used + need > t->ws_cap) {
     if(!t->pending.empty()) { int rc = part_flush(t); if(rc) return rc; }   // apply what is pending, arena is empty again
     if(need > t->ws_cap) { int rc = ws_grow(t, need); if(rc) return rc; }     // rc < 0: no memory -> caller goes direct
@@ -116,7 +123,13 @@ int part_ingest(jfgpu_table* t, const uint8_t* base, int64_t lo, int64_t hi, boo
     HIP_TRY(hipMemsetAsync(gcur, 0, nb * 16, t->stream));
     ProfScope ps(t, 4, (uint64_t)(from_keys ? hi : hi - lo));
     const size_t lds = (size_t)kPTilePos * 6;
-    const bool bl = t->dt.bloom.data != nullptr && !from_keys;
+    const bool bl = (t->wide ? t->wt.bloom.data : t->dt.bloom.data) != nullptr && !from_keys;
+    if(t->item128) {
+      const size_t wlds = (size_t)kWideChunk * 18 + (size_t)t->g.nbytes * 2048;
+#define PW(RT, BL) hipLaunchKernelGGL((p1_wide_granule_kernel<RT, BL>), dim3(t->g1), dim3(kPBlock), wlds, t->stream, t->wt, t->pg, base, lo, hi, gcap, gcur, b.tot, (u128*)b.items)
+      if(t->returning) { if(bl) PW(true, true); else PW(true, false); } else { if(bl) PW(false, true); else PW(false, false); }
+#undef PW
+    } else
 #define PK(RT, N) hipLaunchKernelGGL((p1_keys_granule_kernel<RT, N>), dim3(t->g1), dim3(kPBlock), lds, t->stream, t->dt, t->pg, (const uint64_t*)base, hi, gcap, gcur, b.tot, (uint32_t*)b.items)
     if(from_keys) {
       if(t->returning) PK(true, 0);
@@ -198,15 +211,27 @@ int part_flush_t(jfgpu_table* t) {
   SegList S1; memset(&S1, 0, sizeof S1);
   S1.n = (uint32_t)nbatch;
   for(size_t s = 0; s < nbatch; ++s) { S1.items[s] = t->pending[s].items; S1.off[s] = t->pending[s].off; S1.sh[s] = t->pending[s].gran_cap ? 1 : 0; }
-  const size_t tile_lds = (size_t)8 << t->g.tile_bits;
+  constexpr bool kWideItems = sizeof(ITEM) == 16;         // two-word keys: 128-bit items, 128-bit slots
+  const size_t tile_lds = (size_t)(kWideItems ? 16 : 8) << t->g.tile_bits;
   // always LOAD-capable: a tile is read only if its dirty byte is set (clean after jfgpu_clear)
   const bool rt = t->returning, load = true;
+  // the tile insert of one item array (or of the pending batches themselves), on stream `ts`
+  auto launch_tile_kernel = [&](const SegList& S, uint64_t tile0, uint32_t ntile, hipStream_t ts) {
+    const dim3 block(kPBlock);
+    if constexpr(kWideItems) {
+      const dim3 grid((unsigned)std::min<uint64_t>(ntile, (uint64_t)t->n_cu * 4));     // 128 KiB of LDS: one block per CU
+      if(rt) hipLaunchKernelGGL(tile_insert_wide_kernel<true>, grid, block, tile_lds, ts, t->wt, S, tile0, ntile);
+      else   hipLaunchKernelGGL(tile_insert_wide_kernel<false>, grid, block, tile_lds, ts, t->wt, S, tile0, ntile);
+    } else {
+      const dim3 grid((unsigned)std::min<uint64_t>(ntile, (uint64_t)t->n_cu * 16));
+#define TI(RT, LD) hipLaunchKernelGGL((tile_insert_kernel<ITEM, RT, LD>), grid, block, tile_lds, ts, t->dt, S, tile0, ntile)
+      if(rt) { if(load) TI(true, true); else TI(true, false); } else { if(load) TI(false, true); else TI(false, false); }
+#undef TI
+    }
+  };
   auto launch_tiles = [&](const SegList& S, uint64_t tile0, uint32_t ntile, uint64_t units) {
     ProfScope ps(t, 6, units);
-    const dim3 grid((unsigned)std::min<uint64_t>(ntile, (uint64_t)t->n_cu * 16)), block(kPBlock);
-#define TI(RT, LD) hipLaunchKernelGGL((tile_insert_kernel<ITEM, RT, LD>), grid, block, tile_lds, t->stream, t->dt, S, tile0, ntile)
-    if(rt) { if(load) TI(true, true); else TI(true, false); } else { if(load) TI(false, true); else TI(false, false); }
-#undef TI
+    launch_tile_kernel(S, tile0, ntile, t->stream);
   };
   if(total == 0) {
     // nothing to insert
@@ -219,8 +244,13 @@ int part_flush_t(jfgpu_table* t) {
       const uint64_t span = t->pending[s].gran_cap ? (uint64_t)nb1 * t->pending[s].gran_cap : n;
       const dim3 grid((unsigned)grid_for(t, (span + kBlock - 1) / kBlock)), block(kBlock);
       const uint64_t gc = t->pending[s].gran_cap;
-      if(rt) hipLaunchKernelGGL((items_direct_kernel<ITEM, true>), grid, block, 0, t->stream, t->dt, t->pg, (const ITEM*)t->pending[s].items, (const uint64_t*)t->pending[s].off, gc);
-      else   hipLaunchKernelGGL((items_direct_kernel<ITEM, false>), grid, block, 0, t->stream, t->dt, t->pg, (const ITEM*)t->pending[s].items, (const uint64_t*)t->pending[s].off, gc);
+      if constexpr(kWideItems) {
+        if(rt) hipLaunchKernelGGL(items_direct_wide_kernel<true>, grid, block, 0, t->stream, t->wt, t->pg, (const u128*)t->pending[s].items, (const uint64_t*)t->pending[s].off, gc);
+        else   hipLaunchKernelGGL(items_direct_wide_kernel<false>, grid, block, 0, t->stream, t->wt, t->pg, (const u128*)t->pending[s].items, (const uint64_t*)t->pending[s].off, gc);
+      } else {
+        if(rt) hipLaunchKernelGGL((items_direct_kernel<ITEM, true>), grid, block, 0, t->stream, t->dt, t->pg, (const ITEM*)t->pending[s].items, (const uint64_t*)t->pending[s].off, gc);
+        else   hipLaunchKernelGGL((items_direct_kernel<ITEM, false>), grid, block, 0, t->stream, t->dt, t->pg, (const ITEM*)t->pending[s].items, (const uint64_t*)t->pending[s].off, gc);
+      }
     }
   } else if(t->pg.b2 == 0) {
     launch_tiles(S1, 0, nb1, total);
@@ -258,14 +288,15 @@ int part_flush_t(jfgpu_table* t) {
     }
     hipEvent_t p2a = nullptr, p2b = nullptr, ta = nullptr, tb = nullptr;
     if(t->prof_on) { p2a = get_event(t); p2b = get_event(t); ta = get_event(t); tb = get_event(t); hipEventRecord(p2a, t->stream); }
-    constexpr int per_thread = sizeof(ITEM) == 4 ? 16 : 8;
+    constexpr int per_thread = sizeof(ITEM) == 4 ? 16 : sizeof(ITEM) == 8 ? 8 : 4;
+    const uint32_t p2_tag_bits = kWideItems ? t->wt.W.tag_full : t->g.tag_bits;      // where an item's P2 sub-bucket starts
     for(uint32_t g = 0; g < n_groups; ++g) {
       const uint32_t b0 = g * gsz, nbk = g + 1 == n_groups ? nb1 - b0 : gsz;
       const dim3 grid(g2, nbk), block(kPBlock);
-      hipLaunchKernelGGL((p2_kernel<ITEM, false>), grid, block, 0, t->stream, t->pg, t->g.tag_bits, S1, t->d_M2, (const uint64_t*)d_goff, tmp, b0);
+      hipLaunchKernelGGL((p2_kernel<ITEM, false>), grid, block, 0, t->stream, t->pg, p2_tag_bits, S1, t->d_M2, (const uint64_t*)d_goff, tmp, b0);
       hipLaunchKernelGGL(scan_matrix_kernel, dim3(nbk), dim3(1024), 0, t->stream, t->d_M2, (uint32_t)g2, nb2, (const uint64_t*)d_base, d_goff, b0);
       hipLaunchKernelGGL((p2_scatter_sorted_kernel<ITEM, per_thread>), grid, block, (size_t)kPBlock * per_thread * sizeof(ITEM), t->stream,
-                         t->pg, t->g.tag_bits, S1, (const uint32_t*)t->d_M2, (const uint64_t*)d_goff, tmp, b0);
+                         t->pg, p2_tag_bits, S1, (const uint32_t*)t->d_M2, (const uint64_t*)d_goff, tmp, b0);
       if(t->prof_on && g + 1 == n_groups) hipEventRecord(p2b, t->stream);
       const uint64_t tile_start = (uint64_t)b0 << t->pg.b2;
       const uint32_t ntile = nbk << t->pg.b2;
@@ -278,10 +309,7 @@ int part_flush_t(jfgpu_table* t) {
         ts = t->stream2;
       }
       if(t->prof_on && g == 0) hipEventRecord(ta, ts);
-      const dim3 tgrid((unsigned)std::min<uint64_t>(ntile, (uint64_t)t->n_cu * 16));
-#define TI(RT, LD) hipLaunchKernelGGL((tile_insert_kernel<ITEM, RT, LD>), tgrid, block, tile_lds, ts, t->dt, S2, tile_start, ntile)
-      if(rt) TI(true, true); else TI(false, true);
-#undef TI
+      launch_tile_kernel(S2, tile_start, ntile, ts);
       if(t->prof_on && g + 1 == n_groups) hipEventRecord(tb, ts);
     }
     if(t->prof_on) {
@@ -306,7 +334,7 @@ int part_flush_t(jfgpu_table* t) {
 
 int part_flush(jfgpu_table* t) {
   if(t->pending.empty()) return JFGPU_OK;
-  const int rc = t->item32 ? part_flush_t<uint32_t>(t) : part_flush_t<uint64_t>(t);
+  const int rc = t->item128 ? part_flush_t<u128>(t) : t->item32 ? part_flush_t<uint32_t>(t) : part_flush_t<uint64_t>(t);
   if(rc) {      // report the failure once: what was pending is lost with it, the handle stays usable (jfgpu_clear not needed)
     if(t->stream) hipStreamSynchronize(t->stream);
     t->pending.clear(); t->pending_bytes = 0; t->ws_used = 0;

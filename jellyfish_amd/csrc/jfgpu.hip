@@ -21,6 +21,7 @@
 #include "kernels_bloom.hip.hpp"
 #include "kernels_bloom_part.hip.hpp"
 #include "kernels_wide.hip.hpp"
+#include "kernels_wide_part.hip.hpp"
 #include "kernels_parse.hip.hpp"
 
 using namespace jfgpu;
@@ -91,6 +92,7 @@ struct jfgpu_table {
   bool part_ok = false;          // geometry admits the partitioned path
   PartGeom pg{};
   bool item32 = false;
+  bool item128 = false;          // two-word keys: 128-bit items (kernels_wide_part.hip.hpp)
   bool pristine = true;          // table known all-zero: tile_insert may skip the tile read
   std::vector<PendingBatch> pending;
   uint64_t pending_bytes = 0;
@@ -198,6 +200,11 @@ int launch_count_chunk(jfgpu_table* t, const char* d_bases, size_t n) {
   const uint8_t* base; int64_t lo, hi;
   align_buffer(d_bases, n, base, lo, hi);
   if(t->wide) {
+    if(t->operation == 0 && use_partitioned(t, n)) {
+      const int rc = part_ingest(t, base, lo, hi, false, n);
+      if(rc >= 0) return rc;        // < 0: batch too small for the single-pass partition / no memory -> direct kernel
+    }
+    t->pristine = false;
     const int64_t nt = (hi + kTilePos - 1) / kTilePos;
     ProfScope ps(t, 0, n);
     if(t->returning) hipLaunchKernelGGL(count_ascii_wide_kernel<true>, dim3(grid_for(t, (uint64_t)nt)), dim3(kBlock), 0, t->stream, t->wt, base, lo, hi, t->operation);
@@ -377,7 +384,7 @@ int table_grow(jfgpu_table* t) {
   WideTable nw = t->wt;
   if(t->wide) {
     nw.W = w2; nw.slots = nd.slots; nw.fwd_tbl = nf; nw.inv_tbl = ni; nw.ovf_key = nd.ovf_key; nw.ovf_cnt = nd.ovf_cnt;
-    nw.ovf_mask = nd.ovf_mask; nw.counters = nd.counters; nw.max_probe = nd.max_probe;
+    nw.ovf_mask = nd.ovf_mask; nw.counters = nd.counters; nw.max_probe = nd.max_probe; nw.dirty = nd.dirty;
     hipLaunchKernelGGL(rehash_wide_kernel, dim3(grid_for(t, (1ull << t->g.lsize_l) / kBlock + 1)), dim3(kBlock), 0, t->stream, t->wt, nw,
                        (int)(ctr[CTR_OVF_USED] != 0));
   } else
@@ -394,6 +401,8 @@ int table_grow(jfgpu_table* t) {
     t->wt = nw;
     const int wl = (int)(((size_t)16 << t->g.tile_bits) + ((size_t)2 << t->g.tile_bits));
     HIP_TRY(hipFuncSetAttribute((const void*)dump_tiles_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
+    part_geom_init(t);
+    if(t->mode == MODE_PARTITIONED && !t->part_ok) t->mode = MODE_AUTO;
     t->pristine = false;
     ++t->grow_seed;
     return check_deferred(t);
@@ -517,15 +526,15 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
   if(wide) {
     WideTable& w = t->wt;
     w.slots = d.slots; w.fwd_tbl = d.fwd_tbl; w.inv_tbl = d.inv_tbl; w.ovf_key = d.ovf_key; w.ovf_cnt = d.ovf_cnt;
-    w.ovf_mask = d.ovf_mask; w.counters = d.counters; w.max_probe = d.max_probe;
+    w.ovf_mask = d.ovf_mask; w.counters = d.counters; w.max_probe = d.max_probe; w.dirty = d.dirty;
     memset(&w.bloom, 0, sizeof w.bloom);
-    t->part_ok = false; t->mode = MODE_DIRECT;
+    part_geom_init(t.get());
     const int wl = (int)(((size_t)16 << t->g.tile_bits) + ((size_t)2 << t->g.tile_bits));
     HIP_TRY(hipFuncSetAttribute((const void*)dump_tiles_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
   } else part_geom_init(t.get());
-  if(!wide) if(const char* m = getenv("JFGPU_MODE")) {
+  if(const char* m = getenv("JFGPU_MODE")) {
     if(!strcmp(m, "direct")) t->mode = MODE_DIRECT;
-    else if(!strcmp(m, "partitioned")) t->mode = MODE_PARTITIONED;
+    else if(!strcmp(m, "partitioned") && t->part_ok) t->mode = MODE_PARTITIONED;
   }
   if(const char* m = getenv("JFGPU_P1_SINGLE")) t->p1_single = atoi(m) ? 1 : 0;     // tuning / test knobs of the single-pass P1
   if(const char* m = getenv("JFGPU_P1_SLACK")) t->p1_slack = atof(m);
@@ -555,6 +564,14 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_granule_kernel<true, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint32_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * 16 * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint64_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * 8 * 8));
+    HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<u128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * 4 * 16));
+    const int wl = kWideChunk * 18 + 16 * 2048, wt = 16 << kMaxTileBits;
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_wide_granule_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_wide_granule_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_wide_granule_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_wide_granule_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
+    HIP_TRY(hipFuncSetAttribute((const void*)tile_insert_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, wt));
+    HIP_TRY(hipFuncSetAttribute((const void*)tile_insert_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, wt));
   }
   jfgpu_table* raw = t.release();
   int rc = jfgpu_clear(raw);
@@ -970,7 +987,14 @@ int jfgpu_reserve(jfgpu_table* t, uint64_t input_bytes) {
   const size_t headroom = t->item32 && t->pg.b2 ? (size_t)(pend * ((t->p1_slack > 0 ? t->p1_slack : 0.0) + 0.05)) + 2 * strand : 0;
   const size_t need = 2 * pend + headroom + (n_tiles_of(t) + 1 + nb1) * sizeof(uint64_t) +
                       (size_t)kMaxSeg * (align_up((2 * nb1 + 1) * sizeof(uint64_t), 256) + align_up(nb1 * 16, 256) + 1280) + ((size_t)1 << 20);
-  rc = ws_grow(t, need);
+  size_t want = need;
+  if(t->item128) {      // 16-byte items: what a whole input would need may exceed the device; the arena is then flushed more than once
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    const size_t avail = free_b + t->ws_cap > ((size_t)8 << 30) ? free_b + t->ws_cap - ((size_t)8 << 30) : 0;
+    want = std::min(want, avail);
+  }
+  rc = ws_grow(t, want);
   if(rc < 0) return fail(JFGPU_E_ALLOC, "not enough device memory to reserve the partition workspace");
   if(rc) return rc;
   // touch every page once now: first-touch of fresh device pages costs ~40% on the first pass over them

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(kPBlock) void p2_kernel(PartGeom P, uint32_t tag_bi
     for(uint64_t v = a + threadIdx.x; v < b; v += blockDim.x) {
       const ITEM it = src[v];
       if(holes && it == (ITEM)~(ITEM)0) continue;
-      const uint32_t d = (uint32_t)((uint64_t)it >> tag_bits) & (nb - 1);
+      const uint32_t d = (uint32_t)(it >> tag_bits) & (nb - 1);
       const unsigned long long at = atomicAdd(&s_cur[d], 1ull);
       if(SCATTER) out[at] = it;
     }
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(kPBlock) void p2_scatter_sorted_kernel(PartGeom P, 
     for(int r = 0; r < PER_THREAD; ++r)
       if(dr[r] != 0xFFFFFFFFu) {
         if(((hm >> r) & 1) && it[r] == (ITEM)~(ITEM)0) { dr[r] = 0xFFFFFFFFu; continue; }   // a hole
-        const uint32_t d = (uint32_t)((uint64_t)it[r] >> tag_bits) & (nb - 1);
+        const uint32_t d = (uint32_t)(it[r] >> tag_bits) & (nb - 1);
         dr[r] = (d << 16) | atomicAdd(&s_hist[d], 1u);
       }
     lds_barrier();
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(kPBlock) void p2_scatter_sorted_kernel(PartGeom P, 
     const uint32_t cn = s_lstart[nb - 1] + s_hist[nb - 1];       // items of this chunk that are not holes
     for(uint32_t i = threadIdx.x; i < cn; i += blockDim.x) {
       const ITEM v = s_item[i];
-      const uint32_t d = (uint32_t)((uint64_t)v >> tag_bits) & (nb - 1);
+      const uint32_t d = (uint32_t)(v >> tag_bits) & (nb - 1);
       out[base0 + (uint32_t)(s_delta[d] + i)] = v;     // run of bucket d: consecutive lanes, consecutive addresses
     }
   }
@@ -707,10 +707,11 @@ __device__ inline void granule_init(GranuleLds& G, uint32_t nb) {
 
 // direct(b, item): what to do with an item that cannot be stored in bucket b's region (region exhausted, or the item
 // equals the hole marker) -- the count path inserts it with global atomics, the Bloom path bumps its cell.
-template <int N, typename DIRECT>
+// ITEM: uint32_t (one-word keys, Bloom cell updates) or unsigned __int128 (two-word keys); the hole marker is all ones.
+template <typename ITEM, int N, typename DIRECT>
 __device__ inline uint32_t granule_emit(GranuleLds& G, uint32_t nb, uint32_t cap,
-                                        unsigned int* __restrict__ gcur, uint32_t* __restrict__ out, uint32_t* s_item, uint16_t* s_bkt,
-                                        const uint32_t (&it)[N], const uint32_t (&dr)[N], DIRECT&& direct_fn) {
+                                        unsigned int* __restrict__ gcur, ITEM* __restrict__ out, ITEM* s_item, uint16_t* s_bkt,
+                                        const ITEM (&it)[N], const uint32_t (&dr)[N], DIRECT&& direct_fn) {
   lds_barrier();
   block_excl_scan_2048(G.hist, G.lstart, nb, G.wave);
   lds_barrier();
@@ -744,15 +745,16 @@ __device__ inline uint32_t granule_emit(GranuleLds& G, uint32_t nb, uint32_t cap
   lds_barrier();
   uint32_t direct_n = 0;
   const uint32_t cn = G.lstart[nb - 1] + G.hist[nb - 1];
+  const ITEM hole = (ITEM)~(ITEM)0;
   for(uint32_t i = threadIdx.x; i < cn; i += blockDim.x) {
     const uint32_t b = s_bkt[i], r = i - G.lstart[b], sp = G.split[b];
-    const uint32_t v = s_item[i];
+    const ITEM v = s_item[i];
     uint32_t rel = G.pos0[b] + r;
     bool direct = false;
     if(r >= sp) { const uint32_t p1 = G.pos1[b]; if(p1 == kNoRoom) direct = true; else rel = p1 + (r - sp); }
     if(!direct) {
       out[(uint64_t)b * cap + rel] = v;
-      if(v == 0xFFFFFFFFu) { direct = true; atomicSub(&G.cnt[b], 1u); }   // its slot now reads as a hole
+      if(v == hole) { direct = true; atomicSub(&G.cnt[b], 1u); }   // its slot now reads as a hole
     }
     if(direct) { direct_fn(b, v); ++direct_n; }
   }
@@ -760,11 +762,12 @@ __device__ inline uint32_t granule_emit(GranuleLds& G, uint32_t nb, uint32_t cap
 }
 
 // Kernel end: unused tails of the last reservations become holes, exact per-bucket counts go to tot.
-__device__ inline void granule_finish(GranuleLds& G, uint32_t nb, uint32_t cap, unsigned long long* __restrict__ tot, uint32_t* __restrict__ out) {
+template <typename ITEM>
+__device__ inline void granule_finish(GranuleLds& G, uint32_t nb, uint32_t cap, unsigned long long* __restrict__ tot, ITEM* __restrict__ out) {
   lds_barrier();
   for(uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {
     const uint32_t room = G.room[b], cur = G.cur[b];
-    for(uint32_t r = 0; r < room; ++r) out[(uint64_t)b * cap + cur + r] = 0xFFFFFFFFu;
+    for(uint32_t r = 0; r < room; ++r) out[(uint64_t)b * cap + cur + r] = (ITEM)~(ITEM)0;
     if(G.cnt[b]) atomicAdd(&tot[b], (unsigned long long)G.cnt[b]);
   }
 }

@@ -66,6 +66,7 @@ struct WideTable {
   uint64_t* counters;
   uint32_t max_probe;
   DevBloom bloom;             // count --bc filter (data == nullptr: none)
+  uint8_t* dirty;             // one byte per tile: something was ever inserted (the LDS tile insert skips reading clean tiles)
 };
 
 __device__ inline DevTable ovf_view(const WideTable& T) {     // reuse ovf_add / ovf_get of the one-word code
@@ -121,6 +122,7 @@ __device__ inline bool wide_add(const WideTable& T, const uint64_t* fwd_lds, u12
   const WideSlot w = wide_words(T.W, key, a.idx0);
   const uint64_t add = cnt << (g.tag_bits + 1);
   const uint32_t tmask = (uint32_t)g.tile_mask;
+  if(T.dirty) { uint8_t* d = &T.dirty[a.tile_base >> g.tile_bits]; if(!*d) *d = 1; }
   for(uint32_t p = 0; p <= T.max_probe; ++p) {
     const uint64_t slot = a.tile_base + probe_slot(a.idx0, p, tmask);
     unsigned long long* hi = (unsigned long long*)&T.slots[2 * slot + 1];

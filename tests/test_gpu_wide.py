@@ -156,3 +156,74 @@ def test_wide_table_grows_like_the_reference(gpu, k, canonical, n):
         assert found.all() and vals.tolist() == [want[tuple(x)] for x in some.tolist()]
         st = t.stats()
         assert (st.distinct, st.total) == (len(exp), sum(want.values()))
+
+
+@pytest.mark.parametrize("k,size", [(33, 1 << 16), (40, 1 << 20), (63, 1 << 16)])
+def test_wide_partitioned_path_equals_direct_and_oracle(gpu, k, size):
+    """Two-word keys through the partitioned insert (kernels_wide_part.hip.hpp: 128-bit items, 128 KiB tiles in LDS, the
+    two-word claim on LDS words) against the oracle and against the global-atomic path, in the same table format:
+    several batches per flush, duplicates far apart, low-complexity stretches that overflow a bucket region, a flush in
+    the middle, direct inserts on top of tiles written by the tile kernel.  k = 63 starts at 2^29 slots, i.e. with the
+    second partition level; the small tables are single-level."""
+    rng = random.Random(k)
+    seq = rnd_seq(rng, 70000, "ACGT") + b"N" + rnd_seq(rng, 20000, "ACGTacgtN") + b"A" * 3000 + rnd_seq(rng, 5000, "AC")
+    seq = seq + seq[:30000]
+    exp = oracle_map(seq, k, True)
+    dumps = {}
+    for mode in (1, 2):
+        with gpu.Table(k, size, canonical=True) as t:
+            t.set_mode(mode)
+            t.profile_enable(True)
+            half = len(seq) // 2
+            t.count_ascii(seq[:half])
+            sample = np.array(list(exp.keys())[:200], dtype=np.uint64)
+            t.lookup(sample)                                   # flush + read in the middle
+            t.count_ascii(seq[half - (k - 1):])
+            t.sync()
+            used = [t.profile_get(i)[1] for i in range(8)]
+            if mode == 2:
+                assert used[4] > 0 and (used[6] > 0 or used[7] > 0) and used[0] == 0, used
+            else:
+                assert used[0] > 0 and used[4] == 0, used
+            assert table_map(gpu, t) == exp
+            st = t.stats()
+            assert (st.distinct, st.total, st.mers_fed) == (len(exp), sum(exp.values()), sum(exp.values()))
+            t.add_keys(sample[:50], val=3)                     # global two-word claim on top of LDS-written tiles
+            vals, found = t.lookup(sample[:50])
+            assert found.all() and vals.tolist() == [exp[tuple(r)] + 3 for r in sample[:50].tolist()]
+            dumps[mode] = t.digest()
+    assert dumps[1] == dumps[2]
+
+
+def test_wide_partitioned_grows_and_filters(gpu):
+    """A tiny size hint with two-word keys in partitioned mode: the table doubles itself between flushes; and count --bc
+    (Bloom filter attached) admits the same k-mers through both insert strategies."""
+    rng = random.Random(3)
+    k = 40
+    seq = rnd_seq(rng, 150000, "ACGT")
+    seq = seq + seq[:50000]
+    exp = oracle_map(seq, k, True)
+    with gpu.Table(k, 1 << 13) as t:
+        t.set_mode(2)
+        first = t.info.lsize
+        for a in range(0, len(seq), 40000):
+            t.count_ascii(seq[max(0, a - (k - 1)): a + 40000])
+        t.sync()
+        assert t.info.lsize > first
+        assert table_map(gpu, t) == exp
+    n = len(exp)
+    with gpu.Bloom(k, gpu.opt_m(0.001, n), gpu.opt_k(0.001)) as b:
+        b.insert_ascii(seq)
+        b.sync()
+        got = {}
+        for mode in (1, 2):
+            with gpu.Table(k, 1 << 18) as t:
+                t.set_mode(mode)
+                t.attach_bloom(b)
+                t.count_ascii(seq)
+                t.sync()
+                got[mode] = table_map(gpu, t)
+                t.attach_bloom(None)
+        assert got[1] == got[2]
+        twice = {key: c for key, c in exp.items() if c >= 2}
+        assert all(got[2].get(key) == c for key, c in twice.items())          # no false negatives
