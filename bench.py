@@ -1,29 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- k-mers/s of the `jellyfish count` hot path on MI355X (BASELINE.json metric).
 
-Workload (BASELINE.json configs[1]): k=21 canonical, 10 Gbp of synthetic 150 bp reads per
-GPU (uniform iid bases, the distribution of the reference's generate_sequence), table of
-2^34 64-bit slots per GPU resident in HBM.  The reads are generated on the device before
-the timed region, so `value` is throughput with the input already resident in HBM.
+  --config C2 (default; the metric's configuration, BASELINE configs[1]): k=21 canonical, 10 Gbp of synthetic 150 bp
+           reads per GPU (iid uniform bases, the distribution of the reference's generate_sequence), 2^34-slot table.
+  --config C3 (configs[2]): k=31, Bloom-counter pass (`jellyfish bc -s 10G -f 0.001`: m = 14e10 cells = 28 GB, 10
+           hashes) followed by the filtered count (`count --bc`) over the same reads, 2^33-slot table.
+  --config C5 (configs[4]): k=63 (two-word keys, 128-bit slots), 2^33-slot table.
+The reads are generated on the device before the timed region: `value` is throughput with the input resident in HBM.
 
-  step   = one batch (1/K of the 10 Gbp) through encode -> canonical -> GF(2) hash -> insert
-  N = 1  : per step the batch is encoded, hashed and radix-partitioned on the device (P1); the
-           last step's sync applies everything pending (P2 partition + LDS-resident tile insert),
-           all inside the timed region.  JFGPU_MODE=direct selects the one-kernel atomic path.
-  N > 1  : one process per GPU, table sharded by the top hash bits; per step
-           partition (HIP) -> all-to-all-v of routed k-mers (RCCL over xGMI) -> insert (HIP).
-           Weak scaling: every rank brings its own 10 Gbp.
+  step   = one batch (1/K of the reads) through encode -> canonical -> GF(2) hash -> route/insert
+  N = 1  : per step the batch is encoded, hashed and radix-partitioned on the device (P1); the last step's sync applies
+           everything pending (P2 partition + LDS-resident tile insert), all inside the timed region.  C3 runs K steps of
+           the Bloom pass, its flush, then K steps of the filtered count and its flush.
+  N > 1  : (C2) one process per GPU, table sharded by the top hash bits; per step partition (HIP) -> all-to-all of routed
+           k-mers (RCCL over xGMI) -> insert (HIP).  Weak scaling: every rank brings its own reads.
 
-Prints ONE JSON line (rank 0).  Extra objects: "roofline" (HBM; algorithmic bytes per k-mer
-from SURVEY 8(d): 150/130 B of sequence + 16 B slot read-modify-write = 17.15 B) and
-"cpu_baseline" (the reference's own CPU path, oracle/_ref, timed on this box's host cores on
-a bounded sample of the same reads; falls back to the single-core C restatement when the
-reference build is absent).  The oracle is only the baseline / checker here, never the
-thing measured.
+Prints ONE JSON line (rank 0).  `value` comes from the contract's timed region (K steps, once); `repeats` re-runs the
+same job a few more times (median/min/max), `flush_sweep` forces 1/2/4/8 flushes per job, `end_to_end` is the Counting
+phase of `jellyfish-amd count` from a FASTA file of the same reads (host read + H2D + device parse included), `roofline`
+and `cpu_baseline` are the contract's extra objects (algorithmic bytes per k-mer from SURVEY 8(d); the reference's own
+CPU path, oracle/_ref, timed on this box's host cores on a bounded sample).  The oracle is only baseline / checker here.
 """
 import argparse
 import json
 import os
+import statistics
 import subprocess
 import sys
 import tempfile
@@ -32,47 +33,109 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-K = 21
 READ_LEN = 150
-B_ALG = READ_LEN / (READ_LEN - K + 1) + 16.0     # bytes per k-mer occurrence
 HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: 8 TB/s spec
+CONFIGS = {
+    #        k   lsize  slot B  algorithmic bytes per k-mer occurrence
+    "C2": dict(k=21, lsize=34, slot=8, name="BASELINE configs[1]: k=21 -C, {gbp:.1f} Gbp of 150 bp reads per GPU, 2^{lsize}-slot 64-bit table per GPU in HBM"),
+    "C3": dict(k=31, lsize=33, slot=8, name="BASELINE configs[2]: k=31 -C, Bloom-counter pass (m = 14 x {gbp:.0f}e9 cells, 10 hashes) then count --bc, {gbp:.1f} Gbp of 150 bp reads, 2^{lsize}-slot table"),
+    "C5": dict(k=63, lsize=33, slot=16, name="BASELINE configs[4]: k=63 -C (two-word keys), {gbp:.1f} Gbp of 150 bp reads, 2^{lsize}-slot 128-bit table in HBM"),
+}
 
 
-def cpu_baseline(sample_bytes, n_reads, k, tmpdir):
-    """Reference CPU path on a bounded sample.  Returns (dict for the JSON line, stats text)."""
+def b_alg(cfg, k):
+    seq = READ_LEN / (READ_LEN - k + 1)
+    if cfg == "C3":      # Bloom pass: input + 10 cells x (1 B read + 1 B write); count pass: input + slot RMW
+        return {"bc": seq + 20.0, "count": seq + 16.0}
+    return {"count": seq + 2.0 * CONFIGS[cfg]["slot"]}
+
+
+def write_fasta(arr, path):
+    """(n_reads, READ_LEN + 1) uint8 device-layout reads (bases + one 'N') -> FASTA with one-line records."""
+    import numpy as np
+    n = arr.shape[0]
+    hdr = np.tile(np.frombuffer(b">r\n", dtype=np.uint8), (n, 1))
+    body = arr.copy()
+    body[:, READ_LEN] = ord("\n")
+    np.concatenate([hdr, body], axis=1).tofile(path)
+
+
+def ref_count(ref, fa_list, k, size, threads, tmpdir, extra=()):
+    out, timing = os.path.join(tmpdir, "ref.jf"), os.path.join(tmpdir, "timing")
+    subprocess.check_call([ref, "count", "-m", str(k), "-C", "-s", str(size), "-t", str(threads), "-o", out, "--timing", timing] + list(extra) + fa_list)
+    t = dict(l.split() for l in open(timing).read().splitlines())
+    return float(t["Counting"]), int(t["Mers"]), out
+
+
+def cpu_baseline(cfg, sample, k, tmpdir):
+    """Reference CPU path (oracle/_ref: the reference's own classes, SSE2 hash like its configure enables) on a bounded
+    sample of the same reads.  Returns (dict for the JSON line, reference `stats` text of the sample or None)."""
     import numpy as np
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_jf")
+    n_reads = sample.shape[0]
     kmers = n_reads * (READ_LEN - k + 1)
-    arr = np.frombuffer(sample_bytes, dtype=np.uint8).reshape(n_reads, READ_LEN + 1).copy()
-    if os.access(ref, os.X_OK):
-        arr[:, READ_LEN] = ord("\n")
-        hdr = np.tile(np.frombuffer(b">r\n", dtype=np.uint8), (n_reads, 1))
-        fa = os.path.join(tmpdir, "sample.fa")
-        np.concatenate([hdr, arr], axis=1).tofile(fa)
-        cores = min(os.cpu_count() or 1, 64)
-        out, timing = os.path.join(tmpdir, "ref.jf"), os.path.join(tmpdir, "timing")
-        size = 1
-        while size < 3 * kmers:
-            size <<= 1
-        subprocess.check_call([ref, "count", "-m", str(k), "-C", "-s", str(size), "-t", str(cores), "-o", out,
-                               "--timing", timing, fa])
-        t = dict(l.split() for l in open(timing).read().splitlines())
-        assert int(t["Mers"]) == kmers
+    if not os.access(ref, os.X_OK):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        n_small = min(n_reads, 100000)
+        t0 = time.time()
+        O.count(sample[:n_small].tobytes(), k, True)
+        dt = time.time() - t0
+        return ({"value": n_small * (READ_LEN - k + 1) / dt, "unit": "k-mers/s", "cores": 1, "kind": "port",
+                 "sample": "first %d reads through oracle/jf_oracle.c (sort+count restatement)" % n_small}, None)
+    fa = os.path.join(tmpdir, "sample.fa")
+    write_fasta(sample, fa)
+    ncpu = os.cpu_count() or 1
+    best_t = min(ncpu, 64)                       # measured on 2 x EPYC 9575F: -t 64 beats -t 256 (profiles/r02_call2_*.log)
+    size = 1
+    while size < 2 * kmers:                      # presized, load ~0.5 like the full job's table
+        size <<= 1
+    res = {"unit": "k-mers/s", "kind": "reference"}
+    if cfg == "C3":
+        bc = os.path.join(tmpdir, "ref.bc")
+        t0 = time.time()
+        subprocess.check_call([ref, "bc", "-m", str(k), "-C", "-s", str(n_reads * READ_LEN), "-t", str(best_t), "-o", bc, fa])
+        t_bc = time.time() - t0
+        t_cnt, mers, out = ref_count(ref, [fa], k, size, best_t, tmpdir, ["--bc", bc])
+        assert mers == kmers
         stats = subprocess.check_output([ref, "stats", out]).decode()
-        os.unlink(out); os.unlink(fa)
-        return ({"value": kmers / float(t["Counting"]), "unit": "k-mers/s", "cores": cores, "kind": "reference",
-                 "sample": "first %d reads (%.0f Mbp) of the same synthetic input, jellyfish 2.3.1 classes "
-                           "(oracle/_ref), -t %d, table presized 2^%d, Counting phase only"
-                           % (n_reads, n_reads * READ_LEN / 1e6, cores, size.bit_length() - 1)}, stats)
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as O
-    n_small = min(n_reads, 100000)
-    seq = arr[:n_small].tobytes()
-    t0 = time.time()
-    keys, cnt = O.count(seq, k, True)
-    dt = time.time() - t0
-    return ({"value": n_small * (READ_LEN - k + 1) / dt, "unit": "k-mers/s", "cores": 1, "kind": "port",
-             "sample": "first %d reads through oracle/jf_oracle.c (sort+count restatement)" % n_small}, None)
+        res.update({"value": kmers / (t_bc + t_cnt), "cores": best_t, "bc_pass_kmers_per_s": kmers / t_bc, "count_bc_pass_kmers_per_s": kmers / t_cnt,
+                    "sample": "first %d reads (%.0f Mbp) of the same input: jellyfish 2.3.1 classes (oracle/_ref, SSE2 hash), bc (whole command, "
+                              "-s %d -f 0.001) then count --bc (Counting phase), -t %d" % (n_reads, n_reads * READ_LEN / 1e6, n_reads * READ_LEN, best_t)})
+        return res, stats
+    t_best, mers, out = ref_count(ref, [fa], k, size, best_t, tmpdir)
+    assert mers == kmers
+    stats = subprocess.check_output([ref, "stats", out]).decode()
+    os.unlink(out)
+    res.update({"value": kmers / t_best, "cores": best_t,
+                "sample": "first %d reads (%.0f Mbp) of the same synthetic input, jellyfish 2.3.1 classes (oracle/_ref, -DHAVE_SSE -msse2), "
+                          "-t %d, table presized 2^%d (load %.2f), Counting phase only" % (n_reads, n_reads * READ_LEN / 1e6, best_t, size.bit_length() - 1, kmers / size)})
+    if cfg == "C2":
+        variants = {}
+        # one thread, on a tenth of the sample (same table, so the load factor is lower: stated)
+        n1 = max(1, n_reads // 10)
+        fa1 = os.path.join(tmpdir, "s1.fa")
+        write_fasta(sample[:n1], fa1)
+        t1, m1, o1 = ref_count(ref, [fa1], k, size // 8, 1, tmpdir)
+        variants["t1"] = {"kmers_per_s": m1 / t1, "threads": 1, "sample_reads": n1}
+        os.unlink(o1)
+        if ncpu > best_t:
+            ta, ma, oa = ref_count(ref, [fa], k, size, ncpu, tmpdir)
+            variants["t_nproc"] = {"kmers_per_s": ma / ta, "threads": ncpu}
+            os.unlink(oa)
+        # -F 4: the single serial parser is the reference's bottleneck at high thread counts; four files, four parsers
+        parts = []
+        for i in range(4):
+            p = os.path.join(tmpdir, "q%d.fa" % i)
+            write_fasta(sample[n_reads * i // 4: n_reads * (i + 1) // 4], p)
+            parts.append(p)
+        tf, mf, of = ref_count(ref, parts, k, size, best_t, tmpdir, ["-F", "4"])
+        variants["F4"] = {"kmers_per_s": mf / tf, "threads": best_t, "files": 4}
+        os.unlink(of)
+        res["variants"] = variants
+        res["value"] = max([res["value"]] + [v["kmers_per_s"] for v in variants.values()])     # the reference at its best on this box
+        res["value_is"] = "best of: -t %d one file; %s" % (best_t, ", ".join(sorted(variants)))
+    return res, stats
 
 
 def main():
@@ -80,176 +143,334 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="C2")
     ap.add_argument("--gbp", type=float, default=10.0, help="giga-bases of reads per GPU")
-    ap.add_argument("--lsize", type=int, default=34, help="log2 slots per GPU")
-    ap.add_argument("--cpu-sample-reads", type=int, default=666667)
+    ap.add_argument("--lsize", type=int, default=0, help="log2 slots per GPU (default: the configuration's)")
+    ap.add_argument("--cpu-sample-reads", type=int, default=1033000, help="reads of the CPU-baseline sample (155 Mbp: load 0.50 in its 2^28 table)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--repeats", type=int, default=5, help="how many times the whole job is run in all (first = the contract's timed region)")
+    ap.add_argument("--no-extras", action="store_true", help="skip flush sweep and end-to-end (quick runs, profiling)")
     ap.add_argument("--dist", choices=["U", "G"], default="U",
                     help="U: iid uniform reads (the metric's configuration); G: BASELINE.md's secondary distribution, reads sampled from a "
                          "100 Mbp random genome with 1 %% substitutions (about 100x coverage at 10 Gbp: most k-mers repeat)")
     args = ap.parse_args()
 
     import numpy as np
-    import torch
     from jellyfish_amd import capi
-    from jellyfish_amd import dist as jd
 
+    # JFGPU_EMU_BENCH=1: dry run of this script against the host-emulated engine (tests/host/run_emu.sh, tiny --gbp/--lsize):
+    # a debugging aid for the script itself; its numbers mean nothing and it refuses the default sizes.
+    emu = os.environ.get("JFGPU_EMU_BENCH") == "1"
+    if emu:
+        assert args.gbp <= 0.01 and args.gpus == 1, "emulated dry run: tiny single-process runs only"
+        torch = None
+    else:
+        import torch
+        assert torch.cuda.is_available(), "bench.py needs a GPU: there is no CPU path to measure"
+
+    cfg = args.config
+    K = CONFIGS[cfg]["k"]
+    lsize = args.lsize or CONFIGS[cfg]["lsize"]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
-    assert torch.cuda.is_available(), "bench.py needs a GPU: there is no CPU path to measure"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if world > 1 and cfg != "C2":
+        raise SystemExit("--config %s is a single-GPU configuration (BASELINE.json)" % cfg)
+    dev = None
+    if not emu:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
-    sb = jd.shard_bits_for(world)
+    sb = (world - 1).bit_length()
+    assert 1 << sb == world, "the number of GPUs must be a power of two (shards = top hash bits)"
+
+    def device_sync():
+        if not emu:
+            torch.cuda.synchronize()
 
     n_reads = int(round(args.gbp * 1e9 / READ_LEN))
     steps, warmup = args.steps, args.warmup
     stride = READ_LEN + 1
     kmers_per_read = READ_LEN - K + 1
-    t = capi.Table(K, 1 << (args.lsize + sb), canonical=True, device=local_rank, shard_bits=sb, shard_id=rank)
-    buf = torch.empty(n_reads * stride + 16, dtype=torch.uint8, device=dev)
-    torch.cuda.synchronize()
+    t = capi.Table(K, 1 << (lsize + sb), canonical=True, device=local_rank, shard_bits=sb, shard_id=rank)
+    lsize = t.info.lsize - sb                        # the engine may raise a size below the slot format's minimum
+    buf = t.malloc(n_reads * stride + 16)            # plain device memory through the C ABI
+    device_sync()
     if args.dist == "G":
-        t.gen_genome_reads_dev(buf.data_ptr(), rank * n_reads, n_reads, READ_LEN, 100_000_000, 0.01, 42)
+        t.gen_genome_reads_dev(buf, rank * n_reads, n_reads, READ_LEN, 100_000_000, 0.01, 42)
     else:
-        t.gen_reads_dev(buf.data_ptr(), rank * n_reads, n_reads, READ_LEN, 42)
+        t.gen_reads_dev(buf, rank * n_reads, n_reads, READ_LEN, 42)
     t.sync()
+
+    def reads_to_host(a, b):                         # reads [a, b) as a (b - a, stride) uint8 array
+        return t.d2h(buf + a * stride, (b - a) * stride).reshape(b - a, stride)
+    ns = min(args.cpu_sample_reads, n_reads)
+    sample = reads_to_host(0, ns) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
 
     bounds = [n_reads * i // steps for i in range(steps + 1)]
 
     def batch(i):
         i %= steps
-        return buf.data_ptr() + bounds[i] * stride, (bounds[i + 1] - bounds[i]) * stride
+        return buf + bounds[i] * stride, (bounds[i + 1] - bounds[i]) * stride
 
     # random-access roofline denominator on this very table (dirty afterwards -> cleared)
     gups = {}
-    if rank == 0:
+    if rank == 0 and cfg != "C5":
         for mode, name in ((0, "atomic_add"), (2, "atomic_cas")):
             gups[name] = t.gups(1 << 28, mode)
     t.clear()
     force_dist = os.environ.get("JFGPU_BENCH_FORCE_DIST") == "1"     # exercise the N>1 code path on one GPU
-    if world > 1 or force_dist:
+    sharded = world > 1 or force_dist
+    if sharded:
         import torch.distributed as dist
+        from jellyfish_amd import dist as jd
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    # Init phase: workspace for one sync-to-sync span (like -s presizes the table)
-    t.reserve(n_reads * stride if world == 1 and not force_dist else int(n_reads * kmers_per_read * 1.02) + (1 << 20))
-
-    if world == 1 and not force_dist:
-        def run_step(i):
-            p, n = batch(i)
-            t.count_ascii_dev(p, n)
+    bloom = None
+    if cfg == "C3":
+        bloom = capi.Bloom(K, capi.opt_m(0.001, int(args.gbp * 1e9)), capi.opt_k(0.001), canonical=True, device=local_rank)
+        bloom.reserve(100 << 30)
+    # Init phase: workspace for one sync-to-sync span (like -s presizes the table).  C3: the filtered pass admits next to
+    # nothing of a uniform input, and the Bloom pass needs the memory: two batches' worth, flushed as it fills
+    if cfg == "C3":
+        t.reserve(2 * ((n_reads + steps - 1) // steps) * stride)
     else:
+        t.reserve(n_reads * stride if not sharded else int(n_reads * kmers_per_read * 1.02) + (1 << 20))
+
+    sc = None
+    if sharded:
         max_batch = max(bounds[i + 1] - bounds[i] for i in range(steps))
         be = jd.GpuBackend(t, max_batch * kmers_per_read, dev)
         sc = jd.ShardedCounter(be)
 
-        def run_step(i):
-            sc.step(batch(i))
-
     def fence():
-        if world > 1 or force_dist:
+        if sharded:
             sc.finish()                  # last step's exchange + insert
         t.sync()
-        torch.cuda.synchronize()
-        if world > 1 or force_dist:
+        device_sync()
+        if sharded:
             dist.barrier()
 
-    for i in range(warmup):
-        run_step(i)
-    fence()
-    t.clear()
-    t.profile_enable(True)
-    t.profile_reset()
+    def job(n_steps, flushes=1):
+        """n_steps batches through the whole path of this configuration (both passes for C3), applied and synchronised."""
+        if cfg == "C3":
+            t.attach_bloom(None)
+            for i in range(n_steps):
+                p, n = batch(i)
+                bloom.insert_ascii_dev(p, n)
+            bloom.sync()                 # flush of the Bloom pass: end of `jellyfish bc`
+            t.attach_bloom(bloom)
+        for i in range(n_steps):
+            if sharded:
+                sc.step(batch(i))
+            else:
+                p, n = batch(i)
+                t.count_ascii_dev(p, n)
+            if flushes > 1 and i + 1 < n_steps and (i + 1) * flushes // n_steps > i * flushes // n_steps:
+                t.sync()
+        fence()
+
+    def reset():
+        t.clear()
+        if bloom is not None:
+            t.attach_bloom(None)
+            bloom.clear()
+
+    job(warmup)
+    reset()
+    t.profile_enable(True); t.profile_reset()
+    if bloom is not None:
+        bloom.profile_enable(True); bloom.profile_reset()
     fence()
     t0 = time.perf_counter()
-    for i in range(steps):
-        run_step(i)
-    fence()
+    job(steps)
     elapsed = time.perf_counter() - t0
     t.profile_enable(False)
+    if bloom is not None:
+        bloom.profile_enable(False)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # every window of every read was counted exactly once (size-independent invariant)
+    # size-independent invariants of the timed job: every window was seen exactly once; unfiltered runs counted them all
     st = t.stats()
-    tot = torch.tensor([st.total, st.distinct], dtype=torch.int64, device=dev)
+    tot = [st.total, st.distinct, st.mers_fed]
     if world > 1:
-        dist.all_reduce(tot)
+        tt = torch.tensor(tot, dtype=torch.int64, device=dev)
+        dist.all_reduce(tt)
+        tot = [int(x) for x in tt.tolist()]
     total_kmers = n_reads * kmers_per_read * world
-    assert int(tot[0]) == total_kmers, "counted %d k-mers, expected %d" % (int(tot[0]), total_kmers)
+    if cfg == "C3":
+        assert bloom.sync() == total_kmers and int(tot[2]) == total_kmers, "k-mers fed: bc %d, count %d, expected %d" % (bloom.sync(), int(tot[2]), total_kmers)
+    else:
+        assert int(tot[0]) == total_kmers, "counted %d k-mers, expected %d" % (int(tot[0]), total_kmers)
+    digest = t.digest() if world == 1 else None
 
+    out = None
     if rank == 0:
         slot_names = ["count_direct", "add_keys", "shard_partition", "lookup", "p1_partition", "p2_partition", "tile_insert", "items_direct"]
+        B = b_alg(cfg, K)
         kernels = {}
         for i, nm in enumerate(slot_names):
             kms, kl, ku = t.profile_get(i)
             if kl:
-                kernels[nm] = {"ms": round(kms, 3), "launches": kl, "units": ku}
-        which = max(range(len(slot_names)), key=lambda i: t.profile_get(i)[0])
-        ms, launches, _ = t.profile_get(which)
-        per_launch_kmers = int(st.total) / max(launches, 1)
+                kernels[nm] = {"ms": round(kms, 3), "launches": kl, "units": ku, "bytes_per_kmer": B["count"]}
+        if bloom is not None:
+            for i, nm in enumerate(("bc_direct", "bc_p1_route", "bc_p2_partition", "bc_segments")):
+                kms, kl, ku = bloom.profile_get(i)
+                if kl:
+                    kernels[nm] = {"ms": round(kms, 3), "launches": kl, "units": ku, "bytes_per_kmer": B["bc"]}
+        dom = max(kernels, key=lambda nm: kernels[nm]["ms"])
+        ms, launches = kernels[dom]["ms"], kernels[dom]["launches"]
+        per_launch_kmers = total_kmers / world / max(launches, 1)
         avg_ms = ms / max(launches, 1)
-        achieved = per_launch_kmers * B_ALG / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        bpk = kernels[dom]["bytes_per_kmer"]
+        achieved = per_launch_kmers * bpk / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         value = total_kmers / elapsed
-        # HBM bytes per launch of the named kernel: PMC counters cannot be read from inside this process, so
-        # the figure comes from the committed rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this same command
-        # (profiles/r01_traffic.json); only quoted when the run matches that configuration.
+        whole_bpk = sum(B.values())          # C3: both passes touch every k-mer
+        # HBM bytes per launch of the named kernel: PMC counters cannot be read from inside this process, so the figure
+        # comes from the committed rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this same command (profiles/r02_traffic_<cfg>.json,
+        # made by tools/profile_bench.sh); quoted whenever workload and kernel match, whatever --steps is (traffic per
+        # job does not depend on how the input is cut into batches -- it is scaled to this run's launch count)
         traffic, traffic_src = None, None
-        tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tj) and world == 1 and not force_dist and args.dist == "U" and abs(args.gbp - 10.0) < 1e-9 and args.lsize == 34 and steps == 10:
-            traffic = json.load(open(tj)).get("per_timed_launch_bytes", {}).get(slot_names[which])
-            traffic_src = None if traffic is None else "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, same command)"
+        tj = os.path.join(ROOT, "profiles", "r02_traffic_%s.json" % cfg)
+        if os.path.exists(tj) and world == 1 and not force_dist and args.dist == "U":
+            rec = json.load(open(tj))
+            if abs(rec.get("gbp", 0) - args.gbp) < 1e-9 and rec.get("lsize") == lsize and dom in rec.get("per_job_bytes", {}):
+                traffic = rec["per_job_bytes"][dom] / max(launches, 1)
+                traffic_src = "profiles/r02_traffic_%s.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, same command): bytes per job / %d launches" % (cfg, launches)
         out = {
-            "metric": "k-mers/sec at k=21 canonical, 150 bp synthetic reads, bit-exact counts",
+            "metric": "k-mers/sec at k=%d canonical, 150 bp synthetic reads, bit-exact counts" % K,
             "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": ("BASELINE configs[1]: k=21 -C, %.1f Gbp of 150 bp reads per GPU, 2^%d-slot "
-                                    "64-bit table per GPU in HBM" % (args.gbp, args.lsize)) +
+            "vs_baseline": None, "dtype": "u64" if CONFIGS[cfg]["slot"] == 8 else "u128", "data": "synthetic",
+            "config": {"workload": CONFIGS[cfg]["name"].format(gbp=args.gbp, lsize=lsize) +
                                    ("" if args.dist == "U" else "; SECONDARY distribution G (reads from a 100 Mbp random genome, 1 % substitutions)"),
-                       "k": K, "read_len": READ_LEN, "reads_per_gpu": n_reads, "table_slots_per_gpu": 1 << args.lsize,
-                       "load_factor": float(tot[1]) / float(world << args.lsize),
+                       "id": cfg, "k": K, "read_len": READ_LEN, "reads_per_gpu": n_reads, "table_slots_per_gpu": 1 << lsize,
+                       "load_factor": float(tot[1]) / float(world << lsize),
                        "distinct": int(tot[1]), "total_kmers": total_kmers,
                        "parallelism": ("single GPU" if not force_dist else "single GPU through the sharded code path") if world == 1 else "hash-prefix shard x%d + all-to-all" % world},
             "kernels": kernels,
-            "roofline": {"bound": "hbm", "kernel": slot_names[which],
+            "content_digest": digest,
+            "roofline": {"bound": "hbm", "kernel": dom,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "bytes_per_kmer": B_ALG, "kmers_per_launch": per_launch_kmers,
+                         "traffic": traffic, "traffic_source": traffic_src, "bytes_per_kmer": bpk, "kmers_per_launch": per_launch_kmers,
                          "avg_launch_ms": avg_ms, "launches": launches,
-                         "whole_path_achieved": value * B_ALG / 1e9, "whole_path_frac": value * B_ALG / 1e9 / HBM_PEAK_GBS,
-                         "note": "achieved/frac follow the contract: the named (largest-total-time) kernel's k-mers per launch x 17.15 B / its "
-                                 "average launch time; that kernel is one stage of a multi-kernel path, so whole_path_* (k-mers/s of the "
-                                 "whole job x 17.15 B) is the number to compare with the 8 TB/s peak",
+                         "whole_path_achieved": value * whole_bpk / 1e9, "whole_path_frac": value * whole_bpk / 1e9 / HBM_PEAK_GBS,
+                         "note": "achieved/frac follow the contract: the named (largest-total-time) kernel's k-mers per launch x its algorithmic "
+                                 "bytes per k-mer / its average launch time; that kernel is one stage of a multi-kernel path, so whole_path_* "
+                                 "(k-mers/s of the whole job x the path's algorithmic bytes) is the number to compare with the 8 TB/s peak",
                          "gups_atomic_add": gups.get("atomic_add"), "gups_atomic_cas": gups.get("atomic_cas"),
                          "value_over_gups": value / world / gups["atomic_cas"] if gups.get("atomic_cas") else None},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            ns = min(args.cpu_sample_reads, n_reads)
-            sample = bytes(buf[: ns * stride].cpu().numpy())
-            with tempfile.TemporaryDirectory() as td:
-                base, ref_stats = cpu_baseline(sample, ns, K, td)
-            out["cpu_baseline"] = base
-            if ref_stats is not None:       # bit-exactness spot check on the very sample the CPU counted
-                with capi.Table(K, 1 << 28, canonical=True, device=local_rank) as t2:
-                    t2.count_ascii_dev(buf.data_ptr(), ns * stride)
-                    t2.sync()
-                    s2 = t2.stats()
-                mine = "Unique:    %d\nDistinct:  %d\nTotal:     %d\nMax_count: %d\n" % (s2.unique, s2.distinct, s2.total, s2.max_count)
-                out["cpu_baseline"]["stats_equal_on_sample"] = (mine == ref_stats)
-                assert mine == ref_stats, "GPU and reference disagree on the sample:\n%s\n%s" % (mine, ref_stats)
+        if cfg == "C3":
+            bc_ms = sum(v["ms"] for nm, v in kernels.items() if nm.startswith("bc_"))
+            cnt_ms = sum(v["ms"] for nm, v in kernels.items() if not nm.startswith("bc_"))
+            out["passes"] = {"bc_device_ms": bc_ms, "count_bc_device_ms": cnt_ms, "admitted_kmers": int(tot[0]),
+                             "bc_kmers_per_s_device": total_kmers / (bc_ms * 1e-3) if bc_ms else None,
+                             "count_bc_kmers_per_s_device": total_kmers / (cnt_ms * 1e-3) if cnt_ms else None}
+
+    # ---- repeats of the whole job (outside the contract's region; same work, same checks) ----
+    vals = [total_kmers / elapsed]
+    for r in range(max(0, args.repeats - 1)):
+        reset(); fence()
+        t1 = time.perf_counter()
+        job(steps)
+        dt = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        vals.append(total_kmers / dt)
+        if world == 1 and digest is not None:
+            assert t.digest() == digest, "repeat %d produced a different table" % (r + 1)
+    if rank == 0:
+        out["repeats"] = {"n": len(vals), "kmers_per_s": vals, "median": statistics.median(vals), "min": min(vals), "max": max(vals),
+                          "note": "first entry = the contract's timed region (value); the others re-run the identical job after a clear, table digest equal every time"}
+
+    if rank == 0 and world == 1 and not force_dist and not args.no_extras and cfg == "C2":
+        # ---- how much of the rate depends on flushing once: forced flushes inside the job ----
+        sweep = {}
+        for f in (1, 2, 4, 8):
+            if f > steps:
+                break
+            reset(); fence()
+            t1 = time.perf_counter()
+            job(steps, flushes=f)
+            sweep[str(f)] = total_kmers / (time.perf_counter() - t1)
+            assert t.digest() == digest
+        out["flush_sweep"] = {"kmers_per_s_by_flushes_per_job": sweep,
+                              "note": "a flush streams every dirty tile of the table once, so its cost is O(table), not O(batch)"}
+        # ---- end to end: `jellyfish-amd count` from a FASTA file of the same reads (page cache warm, /dev/shm) ----
+        cli = (os.environ.get("JFGPU_CLI") if emu else None) or os.path.join(ROOT, "bin", "jellyfish-amd")
+        shm = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+        if os.access(cli, os.X_OK):
+            reset()
+            with tempfile.TemporaryDirectory(dir=shm) as td:
+                fa = os.path.join(td, "reads.fa")
+                chunk = 8_000_000
+                with open(fa, "wb") as fh:                       # the same reads, one-line FASTA records (">r\n" + 150 bases + "\n")
+                    for a in range(0, n_reads, chunk):
+                        b = min(n_reads, a + chunk)
+                        arr = reads_to_host(a, b)
+                        hdr = np.tile(np.frombuffer(b">r\n", dtype=np.uint8), (b - a, 1))
+                        arr[:, READ_LEN] = ord("\n")
+                        np.concatenate([hdr, arr], axis=1).tofile(fh)
+                fbytes = os.path.getsize(fa)
+                t.close()                                         # the CLI needs the device memory
+                tim, dg = os.path.join(td, "timing"), os.path.join(td, "digest")
+                env = dict(os.environ, JFGPU_QUIET="1")
+                t1 = time.perf_counter()
+                subprocess.check_call([cli, "count", "-m", str(K), "-C", "-s", str(1 << lsize), "--no-write", "--timing", tim, "--digest", dg,
+                                       "--device", str(local_rank), fa], env=env)
+                wall = time.perf_counter() - t1
+                tm = dict(l.split() for l in open(tim).read().splitlines())
+                dgl = tuple(int(l.split()[1]) for l in open(dg).read().splitlines())
+                assert dgl == digest, "CLI run and HBM-resident run disagree: %r vs %r" % (dgl, digest)
+                cs = float(tm["Counting"])
+                out["end_to_end"] = {"counting_s": cs, "init_s": float(tm["Init"]), "process_wall_s": wall, "file_bytes": fbytes,
+                                     "file_GB_per_s": fbytes / cs / 1e9, "kmers_per_s": total_kmers / cs, "digest_equal_to_resident_run": True,
+                                     "what": "Counting phase (count_main.cc:286->345 equivalent) of `jellyfish-amd count --no-write` on a %.1f GB FASTA file of "
+                                             "the same reads in /dev/shm: host read, host->device copy, device parse, count; PCIe-inclusive, never `value`" % (fbytes / 1e9)}
+            t = None
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        with tempfile.TemporaryDirectory() as td:
+            base, ref_stats = cpu_baseline(cfg, sample, K, td)
+        out["cpu_baseline"] = base
+        if ref_stats is not None:       # bit-exactness spot check on the very sample the CPU counted
+            if t is not None:
+                t.close(); t = None
+            b2 = None
+            with capi.Table(K, 1 << 28, canonical=True, device=local_rank) as t2:
+                if cfg == "C3":
+                    b2 = capi.Bloom(K, capi.opt_m(0.001, ns * READ_LEN), capi.opt_k(0.001), canonical=True, device=local_rank)
+                    b2.insert_ascii_dev(buf, ns * stride)
+                    b2.sync()
+                    t2.attach_bloom(b2)
+                t2.count_ascii_dev(buf, ns * stride)
+                t2.sync()
+                s2 = t2.stats()
+                t2.attach_bloom(None)
+            if b2 is not None:
+                b2.close()
+            mine = "Unique:    %d\nDistinct:  %d\nTotal:     %d\nMax_count: %d\n" % (s2.unique, s2.distinct, s2.total, s2.max_count)
+            out["cpu_baseline"]["stats_equal_on_sample"] = (mine == ref_stats)
+            assert mine == ref_stats, "GPU and reference disagree on the sample:\n%s\n%s" % (mine, ref_stats)
+    if rank == 0:
         print(json.dumps(out), flush=True)
-    t.close()
-    if world > 1 or force_dist:
+    if bloom is not None:
+        bloom.close()
+    if t is not None:
+        t.close()
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
 

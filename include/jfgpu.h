@@ -190,6 +190,7 @@ void jfgpu_bc_destroy(jfgpu_bloom* b);
 int  jfgpu_bc_insert_ascii_dev(jfgpu_bloom* b, const char* d_bases, size_t n);
 int  jfgpu_bc_insert_ascii(jfgpu_bloom* b, const char* bases, size_t n);
 int  jfgpu_bc_sync(jfgpu_bloom* b, uint64_t* mers_fed);
+int  jfgpu_bc_clear(jfgpu_bloom* b);      /* all cells back to 0 (a fresh mer_dna_bloom_counter), k-mer tally reset */
 int  jfgpu_bc_get_info(const jfgpu_bloom* b, uint64_t* m, uint32_t* nb_hashes, uint64_t* nb_bytes,
                        uint64_t* matrix1 /* [2k] or NULL */, uint64_t* matrix2);
 /* write_bits / the istream ctor: the raw ceil(m/5) bytes of a "bloomcounter" file body */

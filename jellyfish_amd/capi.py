@@ -86,6 +86,7 @@ SIGNATURES = {
     "jfgpu_bc_insert_ascii_dev": (C.c_int, [_P, _P, C.c_size_t]),
     "jfgpu_bc_insert_ascii": (C.c_int, [_P, _P, C.c_size_t]),
     "jfgpu_bc_sync": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "jfgpu_bc_clear": (C.c_int, [_P]),
     "jfgpu_bc_get_info": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), _P, _P]),
     "jfgpu_bc_read": (C.c_int, [_P, _P]),
     "jfgpu_bc_load": (C.c_int, [_P, _P]),
@@ -410,6 +411,9 @@ class Bloom:
         n = C.c_uint64()
         _check(self._lib.jfgpu_bc_sync(self._h, C.byref(n)))
         return n.value
+
+    def clear(self):
+        _check(self._lib.jfgpu_bc_clear(self._h))
 
     def read(self):
         out = np.zeros(self.nb_bytes, dtype=np.uint8)

@@ -164,6 +164,16 @@ int jfgpu_bc_insert_ascii(jfgpu_bloom* b, const char* bases, size_t n) {
   return JFGPU_OK;
 }
 
+int jfgpu_bc_clear(jfgpu_bloom* b) {
+  int rc = use_b(b); if(rc) return rc;
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  b->pending.clear(); b->ws_used = 0;                       // pending cell updates are dropped with the rest
+  HIP_TRY(hipMemsetAsync(b->d_data, 0, b->alloc_bytes, b->stream));
+  HIP_TRY(hipMemsetAsync(b->d_mers, 0, sizeof(unsigned long long), b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  return JFGPU_OK;
+}
+
 int jfgpu_bc_sync(jfgpu_bloom* b, uint64_t* mers_fed) {
   int rc = use_b(b); if(rc) return rc;
   rc = bloom_flush(b); if(rc) return rc;
