@@ -80,7 +80,8 @@ int part_flush(jfgpu_table* t);
 uint32_t granule_cap(const jfgpu_table* t, bool from_keys, uint64_t max_items) {
   (void)from_keys;
   if(t->item128) { if(t->pg.b1 > 10 || !t->g1) return 0; }              // the only P1 two-word keys have
-  else if(!t->item32 || t->pg.b2 == 0 || t->pg.b1 > 10 || t->p1_single == 0 || !t->g1) return 0;
+  else if(t->pg.b2 == 0 || t->pg.b1 > 10 || t->p1_single == 0 || !t->g1) return 0;
+  else if(!t->item32 && from_keys) return 0;                             // 64-bit items: single-pass from sequence only
   const uint64_t nb = 1ull << t->pg.b1, strand = (uint64_t)t->g1 * kGran;
   const uint64_t mean = (max_items + nb - 1) / nb;
   if(t->p1_single < 0 && mean < 4 * strand && !(t->item128 && t->mode == MODE_PARTITIONED)) return 0;
@@ -129,6 +130,15 @@ int part_ingest(jfgpu_table* t, const uint8_t* base, int64_t lo, int64_t hi, boo
 #define PW(RT, BL) hipLaunchKernelGGL((p1_wide_granule_kernel<RT, BL>), dim3(t->g1), dim3(kPBlock), wlds, t->stream, t->wt, t->pg, base, lo, hi, gcap, gcur, b.tot, (u128*)b.items)
       if(t->returning) { if(bl) PW(true, true); else PW(true, false); } else { if(bl) PW(false, true); else PW(false, false); }
 #undef PW
+    } else if(!t->item32) {
+      const size_t glds = (size_t)kG64Chunk * 10;
+#define P64(RT, BL, N) hipLaunchKernelGGL((p1_granule64_kernel<RT, BL, N>), dim3(t->g1), dim3(kPBlock), glds, t->stream, t->dt, t->pg, base, lo, hi, gcap, gcur, b.tot, (uint64_t*)b.items)
+      if(bl) { if(t->returning) P64(true, true, 0); else P64(false, true, 0); }
+      else if(t->returning) P64(true, false, 0);
+      else if(t->g.nbytes == 8) P64(false, false, 8);
+      else if(t->g.nbytes == 7) P64(false, false, 7);
+      else P64(false, false, 0);
+#undef P64
     } else
 #define PK(RT, N) hipLaunchKernelGGL((p1_keys_granule_kernel<RT, N>), dim3(t->g1), dim3(kPBlock), lds, t->stream, t->dt, t->pg, (const uint64_t*)base, hi, gcap, gcur, b.tot, (uint32_t*)b.items)
     if(from_keys) {

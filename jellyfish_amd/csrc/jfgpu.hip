@@ -564,6 +564,13 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_granule_kernel<true, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint32_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * 16 * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint64_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * 8 * 8));
+    const int gl = kG64Chunk * 10;
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_granule64_kernel<true, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, gl));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_granule64_kernel<false, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, gl));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_granule64_kernel<true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, gl));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_granule64_kernel<false, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, gl));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_granule64_kernel<false, false, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, gl));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_granule64_kernel<false, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, gl));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<u128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * 4 * 16));
     const int wl = kWideChunk * 18 + 16 * 2048, wt = 16 << kMaxTileBits;
     HIP_TRY(hipFuncSetAttribute((const void*)p1_wide_granule_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
@@ -983,8 +990,8 @@ int jfgpu_reserve(jfgpu_table* t, uint64_t input_bytes) {
   // pending items (upper bound: one per input byte) + the P2 output of the same size + offsets
   // (single-pass P1 batches are regions with head-room: slack + one stranded reservation per block and bucket)
   const size_t pend = align_up(input_bytes * item_size(t), 256);
-  const size_t strand = (size_t)nb1 * (2 * (size_t)t->n_cu) * kGran * sizeof(uint32_t);          // per batch
-  const size_t headroom = t->item32 && t->pg.b2 ? (size_t)(pend * ((t->p1_slack > 0 ? t->p1_slack : 0.0) + 0.05)) + 2 * strand : 0;
+  const size_t strand = (size_t)nb1 * (2 * (size_t)t->n_cu) * kGran * item_size(t);              // per batch
+  const size_t headroom = t->pg.b2 ? (size_t)(pend * ((t->p1_slack > 0 ? t->p1_slack : 0.0) + 0.05)) + 2 * strand : 0;
   const size_t need = 2 * pend + headroom + (n_tiles_of(t) + 1 + nb1) * sizeof(uint64_t) +
                       (size_t)kMaxSeg * (align_up((2 * nb1 + 1) * sizeof(uint64_t), 256) + align_up(nb1 * 16, 256) + 1280) + ((size_t)1 << 20);
   size_t want = need;

@@ -74,6 +74,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 #endif
 
 __device__ inline bool bloom_admits(const DevBloom& B, uint64_t key);   // kernels_bloom.hip.hpp
+__device__ inline uint32_t bloom_admit_mask(const DevBloom& B, const TableGeom& g, const LaneWords& L);   // kernels_bloom.hip.hpp
 
 // ---- overflow side table ----------------------------------------------------
 // A slot's count field wrapped: remember `units` x 2^cnt_bits for that slot.  Keyed by
@@ -315,9 +316,10 @@ __global__ __launch_bounds__(kBlock) void count_ascii_kernel(DevTable T, const u
       else if(op == 1) table_add<RETURNING>(T, s_fwd, key, 0);
       else table_update_add<RETURNING>(T, s_fwd, key, n);
     };
-    for_each_kmer(T.g, L, [&](int, uint64_t key) {
+    const uint32_t adm = BLOOM ? bloom_admit_mask(T.bloom, T.g, L) : 0xFFFFu;   // count --bc (count_main.cc:115-118); compiled out otherwise
+    for_each_kmer(T.g, L, [&](int j, uint64_t key) {
       ++my_mers;
-      if(BLOOM && !bloom_admits(T.bloom, key)) return;            // count --bc (count_main.cc:115-118); compiled out otherwise
+      if(BLOOM && !((adm >> j) & 1u)) return;
       if(run && key == prev) { ++run; return; }
       if(run) apply(prev, run);
       prev = key; run = 1;

@@ -109,6 +109,59 @@ __device__ inline bool bloom_all_two(const DevBloom& B, uint64_t h0, uint64_t h1
   return true;
 }
 
+// The filter for the 16 windows of one lane: bit j of the result = the window ending at the lane's position j is valid
+// and check(m) > 1.  The cells are read in rounds: round r reads cell r of every window still undecided (all of a
+// lane's loads of a round are in flight together), a window drops out at its first cell below 2.  With one decision
+// loop per window a wave paid up to 16 x nh dependent memory round trips per tile; here it pays at most 2 x nh,
+// usually 6-10 (a window survives a round with probability ~0.16 on a filter at its design load, unless its k-mer
+// really was seen twice).  Eight windows at a time: sixteen would not fit the registers of a 1024-thread block.
+template <int J0>
+__device__ inline uint32_t bloom_admit_half(const DevBloom& B, const TableGeom& g, const LaneWords& L, uint64_t& fw, uint64_t& rc) {
+  constexpr int H = kPerLane / 2;
+  const uint32_t k = g.k;
+  const uint64_t kwin = k >= 64 ? ~0ull : ((1ull << k) - 1);
+  const uint32_t rc_shift = 2 * (k - 1);
+  uint64_t p[H], inc[H];
+  uint32_t alive = 0;
+#pragma unroll
+  for(int e = 0; e < H; ++e) {
+    const int j = J0 + e;
+    const uint64_t c = (L.cur >> (2 * (15 - j))) & 3u;
+    fw = ((fw << 2) | c) & g.key_mask;
+    rc = (rc >> 2) | ((3ull - c) << rc_shift);
+    p[e] = 0; inc[e] = 0;
+    if(((L.inv48 >> (15 - j)) & kwin) == 0) {
+      const uint64_t key = (g.canonical && rc < fw) ? rc : fw;
+      p[e] = bloom_mod(hash_tables(B.tbl1, key, B.nbytes), B.m, B.recip);
+      inc[e] = bloom_mod(hash_tables(B.tbl2, key, B.nbytes), B.m, B.recip);
+      alive |= 1u << e;
+    }
+  }
+  for(uint32_t r = 0; r < B.nh && alive; ++r) {
+    uint32_t wv[H];
+#pragma unroll
+    for(int e = 0; e < H; ++e) {
+      wv[e] = 0;
+      if((alive >> e) & 1u) { uint64_t byte; uint32_t dig; divmod5(p[e], byte, dig); wv[e] = B.data[byte >> 2]; }
+    }
+#pragma unroll
+    for(int e = 0; e < H; ++e)
+      if((alive >> e) & 1u) {
+        uint64_t byte; uint32_t dig;
+        divmod5(p[e], byte, dig);
+        if(bloom_digit((wv[e] >> (8 * (uint32_t)(byte & 3))) & 0xFFu, dig) < 2) alive &= ~(1u << e);
+        else { p[e] += inc[e]; if(p[e] >= B.m) p[e] -= B.m; }
+      }
+  }
+  return alive << J0;
+}
+__device__ inline uint32_t bloom_admit_mask(const DevBloom& B, const TableGeom& g, const LaneWords& L) {
+  uint64_t fw = (((uint64_t)L.p2 << 32) | L.p1) & g.key_mask;
+  uint64_t rc = revcomp64(fw, g.k);
+  const uint32_t lo = bloom_admit_half<0>(B, g, L, fw, rc);
+  return lo | bloom_admit_half<kPerLane / 2>(B, g, L, fw, rc);
+}
+
 // count --bc filter (count_main.cc:115-118); tables read through the caches (12-16 KiB hot set).
 __device__ inline bool bloom_admits(const DevBloom& B, uint64_t key) {
   const uint64_t h0 = hash_tables(B.tbl1, key, B.nbytes), h1 = hash_tables(B.tbl2, key, B.nbytes);

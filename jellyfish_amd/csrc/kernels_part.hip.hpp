@@ -147,9 +147,10 @@ __global__ __launch_bounds__(kPBlock) void p1_kernel(DevTable T, PartGeom P, con
         if(run == 1) emit(prev);
         else if(run > 1) long_runs = true;
       };
-      for_each_kmer(T.g, L, [&](int, uint64_t key) {
+      const uint32_t adm = BLOOM ? bloom_admit_mask(T.bloom, T.g, L) : 0xFFFFu;   // count --bc; read-only, so both passes agree
+      for_each_kmer(T.g, L, [&](int j, uint64_t key) {
         ++my_mers;
-        if(BLOOM && !bloom_admits(T.bloom, key)) return;          // count --bc; read-only, so both passes agree
+        if(BLOOM && !((adm >> j) & 1u)) return;
         if(run && key == prev) { ++run; return; }
         flush_run();
         prev = key; run = 1;
@@ -319,8 +320,9 @@ __global__ __launch_bounds__(kPBlock) void p1_scatter_sorted_kernel(DevTable T, 
         dr[site] = (b << 16) | atomicAdd(&s_hist[b], 1u);
       } else if(run > 1) long_runs = true;
     };
+    const uint32_t adm = BLOOM ? bloom_admit_mask(T.bloom, T.g, L) : 0xFFFFu;
     for_each_kmer(T.g, L, [&](int j, uint64_t key) {
-      if(BLOOM && !bloom_admits(T.bloom, key)) return;
+      if(BLOOM && !((adm >> j) & 1u)) return;
       if(run && key == prev) { ++run; return; }
       flush_run(j);
       prev = key; run = 1;
@@ -810,9 +812,10 @@ __global__ __launch_bounds__(kPBlock) void p1_scatter_granule_kernel(DevTable T,
         dr[site] = (b << 16) | atomicAdd(&G.hist[b], 1u);
       } else if(run > 1) long_runs = true;
     };
+    const uint32_t adm = BLOOM ? bloom_admit_mask(T.bloom, T.g, L) : 0xFFFFu;
     for_each_kmer(T.g, L, [&](int j, uint64_t key) {
       ++my_mers;
-      if(BLOOM && !bloom_admits(T.bloom, key)) return;
+      if(BLOOM && !((adm >> j) & 1u)) return;
       if(run && key == prev) { ++run; return; }
       flush_run(j);
       prev = key; run = 1;
@@ -821,6 +824,76 @@ __global__ __launch_bounds__(kPBlock) void p1_scatter_granule_kernel(DevTable T,
     if(long_runs) my_direct += apply_runs<RETURNING, BLOOM>(T, s_fwd, L);
     my_direct += granule_emit(G, nb, cap, gcur, out, s_item, s_bkt, it, dr,
                               [&](uint32_t b, uint32_t v) { item_direct_insert<RETURNING>(T, P, b, (uint64_t)v); });
+  }
+  granule_finish(G, nb, cap, tot, out);
+  if(my_direct) atomicAdd((unsigned long long*)&T.counters[CTR_DIRECT], (unsigned long long)my_direct);
+  uint64_t w = my_mers;
+  for(int o = 32; o > 0; o >>= 1) w += __shfl_down(w, o, 64);
+  if((threadIdx.x & 63) == 0 && w) atomicAdd((unsigned long long*)&T.counters[CTR_MERS], (unsigned long long)w);
+}
+
+// Single-pass P1 with 64-bit items (one-word keys whose item does not fit 32 bits, e.g. k = 31 at 2^33 slots): the
+// block's 16384 positions go through the sort in two rounds of 8 positions per lane (8192 items of 8 bytes = 64 KiB of
+// LDS per round).  Consecutive identical k-mers are not merged here: they meet in the LDS tile like any other duplicate.
+constexpr int kG64Per = 8;
+constexpr int kG64Chunk = kPBlock * kG64Per;
+template <bool RETURNING, bool BLOOM, int NB>
+__global__ __launch_bounds__(kPBlock) void p1_granule64_kernel(DevTable T, PartGeom P, const uint8_t* __restrict__ base,
+                                                               int64_t lo, int64_t hi, uint32_t cap,
+                                                               unsigned int* __restrict__ gcur, unsigned long long* __restrict__ tot,
+                                                               uint64_t* __restrict__ out) {
+  JF_DYN_LDS(s_dyn);
+  uint64_t* s_item = reinterpret_cast<uint64_t*>(s_dyn);                               // [kG64Chunk]
+  uint16_t* s_bkt = reinterpret_cast<uint16_t*>(s_dyn + (size_t)kG64Chunk * 8);        // [kG64Chunk]
+  __shared__ uint64_t s_fwd[8 * 256];
+  __shared__ uint32_t s_codes[kPBlock + 2];
+  __shared__ uint32_t s_inv[kPBlock + 2];
+  __shared__ GranuleLds G;
+  const TableGeom& g = T.g;
+  const uint32_t nb = 1u << P.b1;
+  load_tables_lds(s_fwd, T.fwd_tbl, g.nbytes);
+  granule_init(G, nb);
+  const uint32_t k = g.k, bshift = g.lsize_l - P.b1;
+  const uint64_t kwin = k >= 64 ? ~0ull : ((1ull << k) - 1);
+  const uint32_t rc_shift = 2 * (k - 1);
+  uint32_t my_direct = 0, my_mers = 0;
+  const int64_t n_tiles = (hi + kPTilePos - 1) / kPTilePos;
+  TileRaw R = tile_fetch(base, (int64_t)blockIdx.x * kPTilePos, lo, hi);
+  for(int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    lds_barrier();
+    const LaneWords L = tile_stage(R, tile * kPTilePos, lo, hi, s_codes, s_inv);      // barrier inside
+    R = tile_fetch(base, (tile + gridDim.x) * kPTilePos, lo, hi);
+    const uint32_t adm = BLOOM ? bloom_admit_mask(T.bloom, g, L) : 0xFFFFu;
+    uint64_t fw = (((uint64_t)L.p2 << 32) | L.p1) & g.key_mask;
+    uint64_t rc = revcomp64(fw, k);
+#pragma unroll 1
+    for(int j0 = 0; j0 < kPerLane; j0 += kG64Per) {
+      lds_barrier();
+      for(uint32_t q = threadIdx.x; q < nb; q += blockDim.x) G.hist[q] = 0;
+      lds_barrier();
+      uint64_t it[kG64Per]; uint32_t dr[kG64Per];
+#pragma unroll
+      for(int e = 0; e < kG64Per; ++e) {
+        const int j = j0 + e;
+        dr[e] = 0xFFFFFFFFu; it[e] = 0;
+        const uint64_t c = (L.cur >> (2 * (15 - j))) & 3u;
+        fw = ((fw << 2) | c) & g.key_mask;
+        rc = (rc >> 2) | ((3ull - c) << rc_shift);
+        if(((L.inv48 >> (15 - j)) & kwin) == 0) {
+          ++my_mers;
+          if(!BLOOM || ((adm >> j) & 1u)) {
+            const uint64_t key = (g.canonical && rc < fw) ? rc : fw;
+            const uint64_t pos = hash_tables_t<NB>(s_fwd, key, g.nbytes);
+            const uint64_t local = pos & g.local_mask;
+            it[e] = make_item<uint64_t>(g, P, key, local);
+            const uint32_t b = (uint32_t)(local >> bshift);
+            dr[e] = (b << 16) | atomicAdd(&G.hist[b], 1u);
+          }
+        }
+      }
+      my_direct += granule_emit(G, nb, cap, gcur, out, s_item, s_bkt, it, dr,
+                                [&](uint32_t b, uint64_t v) { item_direct_insert<RETURNING>(T, P, b, v); });
+    }
   }
   granule_finish(G, nb, cap, tot, out);
   if(my_direct) atomicAdd((unsigned long long*)&T.counters[CTR_DIRECT], (unsigned long long)my_direct);

@@ -185,3 +185,34 @@ def test_partitioned_insert_equals_direct_and_oracle(gpu, n_cells, two_level):
         for x, y in zip(h0.tolist(), h1.tolist()):
             L.jfo_bc_insert(data.ctypes.data, n_cells, nh, x, y)
         assert (out[2] == data).all()
+
+
+@pytest.mark.parametrize("k,single", [(31, "1"), (31, "0"), (21, "1"), (16, "1")])
+def test_count_bc_through_every_p1_variant(gpu, monkeypatch, k, single):
+    """count --bc with the filter evaluated as a per-lane mask in rounds (bloom_admit_mask): the single-pass P1 with 64-bit
+    items (k = 31 here), the exact two-pass P1, the 32-bit single-pass P1 and the direct kernel admit exactly the k-mers
+    the oracle's check() > 1 admits -- on a filter that holds more than the k-mers counted, so false positives exist."""
+    monkeypatch.setenv("JFGPU_P1_SINGLE", single)
+    rng = random.Random(k)
+    seq = "".join(rng.choice("ACGT") for _ in range(250000)).encode()
+    seq = seq + b"N" + seq[:80000] + b"N" + "".join(rng.choice("ACGTN") for _ in range(50000)).encode()
+    n = 40000                                                  # undersized on purpose: fp rate far above 0.001
+    m, nh = gpu.opt_m(0.01, n), gpu.opt_k(0.01)
+    with gpu.Bloom(k, m, nh, canonical=True, seed=3) as b:
+        b.insert_ascii(seq)
+        b.sync()
+        kmers = O.extract(seq, k, True)
+        keys, cnt = O.count(seq, k, True)
+        chk = b.keys(keys[:, 0])
+        exp = {int(a): int(c) for a, c, ok in zip(keys[:, 0], cnt, chk == 2) if ok}
+        assert len(exp) > int((cnt >= 2).sum())                # some singletons pass: the mask is not trivially right
+        for mode in (1, 2):
+            with gpu.Table(k, 1 << 25, canonical=True) as t:
+                t.set_mode(mode)
+                t.attach_bloom(b)
+                t.count_ascii(seq)
+                t.sync()
+                kk, cc = gpu.decode_records(t.dump_records(), k, 4)
+                assert dict(zip(kk.tolist(), cc.tolist())) == exp, (k, single, mode)
+                assert t.stats().mers_fed == len(kmers)
+                t.attach_bloom(None)

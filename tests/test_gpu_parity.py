@@ -555,6 +555,8 @@ def _solve_key_for_item(cols, lsize, k, pos_target, top_bits):
     (16, True, 600000, "ACGTN", "-0.95"),      # regions far too small: most items take the exhausted-region path
     (15, True, 500000, "AT", "0.03"),          # duplicates and homopolymer runs
     (19, False, 400000, "ACGT", "0.03"),       # 2k - b1 = 32: every 32-bit value is a real item, the all-ones one is planted
+    (24, True, 400000, "ACGTN", "0.03"),       # 64-bit items: the rounds-of-8 single-pass kernel (p1_granule64_kernel)
+    (24, True, 300000, "AC", "-0.9"),          # ... with low complexity and regions far too small
 ])
 def test_single_pass_p1_matches_oracle(gpu, monkeypatch, k, canonical, n, alphabet, slack):
     monkeypatch.setenv("JFGPU_P1_SINGLE", "1")

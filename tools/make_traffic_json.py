@@ -1,48 +1,54 @@
 #!/usr/bin/env python3
-"""profiles/<tag>_{fetch,write}.csv (tools/rocpd_pmc.py output of the FETCH_SIZE / WRITE_SIZE passes of
-tools/profile_bench.sh) -> profiles/r01_traffic.json, the HBM-traffic figures bench.py quotes.
-Corrections per MI355X_MICROARCH.md: counters are KB; FETCH_SIZE is doubled for wide coalesced reads."""
-import csv, json, sys
+"""<tag>_{fetch,write}.csv (tools/rocpd_pmc.py output of the FETCH_SIZE / WRITE_SIZE passes of tools/profile_bench.sh)
+-> profiles/r02_traffic_<cfg>.json: HBM bytes per job of every stage bench.py names, the figures its `roofline.traffic`
+quotes.  The profiled command runs exactly one job (--warmup 0 --repeats 1), so sums over the run are per-job sums.
+Corrections per MI355X_MICROARCH.md: counters are KB; FETCH_SIZE is doubled for wide coalesced reads; WRITE_SIZE as is.
+usage: make_traffic_json.py <tag path prefix> <C2|C3|C5> <gbp> <lsize> [out.json]"""
+import csv
+import json
+import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "profiles/r01_single"
-out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01_traffic.json"
+tag, cfg, gbp, lsize = sys.argv[1], sys.argv[2], float(sys.argv[3]), int(sys.argv[4])
+out = sys.argv[5] if len(sys.argv) > 5 else "profiles/r02_traffic_%s.json" % cfg
 
 
 def load(path, col):
     d = {}
     for row in csv.DictReader(open(path)):
-        d[row["Kernel"]] = (int(row["Dispatches"]), float(row[col]) * 1024.0)
+        d[row["Kernel"]] = (int(row["Dispatches"]), float(row[col] or 0) * 1024.0)
     return d
 
 
+def stage_of(kernel):
+    k = kernel
+    if "p1_bloom" in k: return "bc_p1_route"
+    if "bloom_segment" in k: return "bc_segments"
+    if "bloom_insert" in k or "bloom_items" in k: return "bc_direct"
+    if "tile_insert" in k: return "tile_insert"
+    if "items_direct" in k: return "items_direct"
+    if "jfgpu::p2_" in k or "scan_matrix" in k: return "bc_p2_partition" if cfg == "C3" else "p2_partition"
+    if "jfgpu::p1_" in k or "granule_finish" in k: return "p1_partition"
+    if "count_ascii" in k: return "count_direct"
+    return None
+
+
 f, w = load(tag + "_fetch.csv", "FETCH_SIZE"), load(tag + "_write.csv", "WRITE_SIZE")
-kernels = {}
+kernels, stages = {}, {}
 for k in f:
-    if "jfgpu::p1_" in k or "jfgpu::p2_" in k or "tile_insert" in k or "granule" in k:
-        kernels[k] = {"dispatches": f[k][0], "fetch_bytes": 2.0 * f[k][1], "write_bytes": w.get(k, (0, 0.0))[1]}
-
-
-def tot(sub):
-    return sum(v["fetch_bytes"] + v["write_bytes"] for k, v in kernels.items() if sub in k)
-
-
-n_batches = max(v["dispatches"] for k, v in kernels.items() if "jfgpu::p1_" in k)      # 1 warm-up + 10 timed, equal size
+    st = stage_of(k)
+    if st is None:
+        continue
+    rec = {"stage": st, "dispatches": f[k][0], "fetch_bytes": 2.0 * f[k][1], "write_bytes": w.get(k, (0, 0.0))[1]}
+    kernels[k] = rec
+    stages[st] = stages.get(st, 0.0) + rec["fetch_bytes"] + rec["write_bytes"]
 res = {
-    "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `python bench.py --no-cpu-baseline` "
-              "(tools/profile_bench.sh), sums over all dispatches of the run: 1 warm-up batch + 10 timed batches, flush kernels: "
-              "1 Gbp warm-up flush + 10 Gbp timed flush; KB -> bytes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes; "
-              "WRITE_SIZE as reported",
+    "config": cfg, "gbp": gbp, "lsize": lsize,
+    "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `python bench.py --config %s --warmup 0 --repeats 1 "
+              "--no-extras --no-cpu-baseline` (tools/profile_bench.sh): one job, sums over all its dispatches; KB -> bytes; FETCH_SIZE doubled as "
+              "MI355X_MICROARCH.md prescribes for wide coalesced reads; WRITE_SIZE as reported" % cfg,
     "kernels": kernels,
-    "per_timed_launch_bytes": {
-        "p1_partition": tot("jfgpu::p1_") / n_batches,
-        "p2_partition": tot("jfgpu::p2_") * 10.0 / 11.0,
-        # tile insert: table writes are the same in both flushes, item reads scale 1:10
-        "tile_insert": sum(v["write_bytes"] / 2.0 + v["fetch_bytes"] * 10.0 / 11.0 for k, v in kernels.items() if "tile_insert" in k),
-    },
-    "per_timed_launch_note": "p1: per batch (all P1 kernels / batches); p2: 10/11 of the two flushes; tile_insert: half of the table "
-                             "writes + 10/11 of the item reads",
+    "per_job_bytes": stages,
+    "whole_job_bytes": sum(stages.values()),
 }
-res["whole_run_timed_bytes"] = res["per_timed_launch_bytes"]["p1_partition"] * 10 + res["per_timed_launch_bytes"]["p2_partition"] + \
-    res["per_timed_launch_bytes"]["tile_insert"]
 json.dump(res, open(out, "w"), indent=1)
-print(json.dumps(res["per_timed_launch_bytes"]), res["whole_run_timed_bytes"] / 1e9, "GB")
+print(json.dumps(stages), res["whole_job_bytes"] / 1e9, "GB")

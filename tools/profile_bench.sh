@@ -6,7 +6,7 @@ set -u
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --no-cpu-baseline $*"
+B="python $R/bench.py --no-cpu-baseline --no-extras --warmup 0 --repeats 1 $*"
 O=$R/gpurun_out
 rm -rf $O/${TAG}_p1 $O/${TAG}_p2 $O/${TAG}_p3
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_p1 -o p -- $B 2>/dev/null | grep '^{' | tail -1 > $O/${TAG}_bench.json
