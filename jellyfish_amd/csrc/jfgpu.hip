@@ -22,6 +22,7 @@
 #include "kernels_bloom_part.hip.hpp"
 #include "kernels_wide.hip.hpp"
 #include "kernels_wide_part.hip.hpp"
+#include "kernels_nword.hip.hpp"
 #include "kernels_parse.hip.hpp"
 
 using namespace jfgpu;
@@ -74,6 +75,9 @@ struct jfgpu_table {
   uint64_t grow_seed = 0;
   // two-word keys (33 <= k <= 64): 128-bit slots, kernels_wide.hip.hpp
   bool wide = false;
+  // keys of three or four words (65 <= k <= 128): 256-bit slots, kernels_nword.hip.hpp (direct path only)
+  bool nword = false;
+  NTable nt{};
   WideTable wt{};
   uint32_t key_words = 1;
   // staging for host buffers
@@ -199,6 +203,15 @@ int launch_count_chunk(jfgpu_table* t, const char* d_bases, size_t n) {
   if(n < t->g.k) return JFGPU_OK;
   const uint8_t* base; int64_t lo, hi;
   align_buffer(d_bases, n, base, lo, hi);
+  if(t->nword) {
+    t->pristine = false;
+    const int64_t nt = (hi + kTilePos - 1) / kTilePos;
+    ProfScope ps(t, 0, n);
+    if(t->returning) hipLaunchKernelGGL(count_ascii_nword_kernel<true>, dim3(grid_for(t, (uint64_t)nt)), dim3(kBlock), 0, t->stream, t->nt, base, lo, hi, t->operation);
+    else             hipLaunchKernelGGL(count_ascii_nword_kernel<false>, dim3(grid_for(t, (uint64_t)nt)), dim3(kBlock), 0, t->stream, t->nt, base, lo, hi, t->operation);
+    HIP_TRY(hipGetLastError());
+    return JFGPU_OK;
+  }
   if(t->wide) {
     if(t->operation == 0 && use_partitioned(t, n)) {
       const int rc = part_ingest(t, base, lo, hi, false, n);
@@ -232,7 +245,7 @@ int launch_count_chunk(jfgpu_table* t, const char* d_bases, size_t n) {
 // How many more k-mers may be enqueued before the table could exceed 80 % load, assuming every one
 // of them is new (an upper bound: duplicates are only discovered by inserting).
 uint64_t capacity_limit(const jfgpu_table* t) { return ((1ull << t->g.lsize_l) / 10) * 8; }
-bool capacity_managed(const jfgpu_table* t) { return (t->grow_on || t->spill_fn) && t->g.shard_bits == 0 && t->g.lsize_g < t->g.key_bits && (!t->wide || t->g.lsize_g < 48); }
+bool capacity_managed(const jfgpu_table* t) { return (t->grow_on || t->spill_fn) && t->g.shard_bits == 0 && t->g.lsize_g < t->g.key_bits && (!(t->wide || t->nword) || t->g.lsize_g < 48); }
 
 // The size passed at creation is a hint (doc/Readme.md:67-72; hash_counter::handle_full_ary,
 // hash_counter.hpp:178-198): before enqueuing `incoming` potential new keys make sure they cannot
@@ -314,7 +327,8 @@ int measure_occupancy(jfgpu_table* t) {
   HIP_TRY(hipMalloc((void**)&d, 4 * sizeof(unsigned long long)));
   HIP_TRY(hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), t->stream));
   const int grid = grid_for(t, (1ull << t->g.lsize_l) / kBlock + 1);
-  if(t->wide) hipLaunchKernelGGL(scan_wide_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->wt, 0, 0ull, ~0ull, 0, 0ull, 0ull, 1ull, 1ull, d, (uint32_t*)nullptr);
+  if(t->nword) hipLaunchKernelGGL(scan_nword_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->nt, 0, 0ull, ~0ull, 0, 0ull, 0ull, 1ull, 1ull, d, (uint32_t*)nullptr);
+  else if(t->wide) hipLaunchKernelGGL(scan_wide_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->wt, 0, 0ull, ~0ull, 0, 0ull, 0ull, 1ull, 1ull, d, (uint32_t*)nullptr);
   else hipLaunchKernelGGL(stats_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, 0ull, ~0ull, 0, d);
   unsigned long long h[4];
   hipError_t e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, t->stream);
@@ -353,7 +367,9 @@ int table_grow(jfgpu_table* t) {
   }
   TableGeom g2;
   WideGeom w2;
-  if(t->wide) { if(!wide_geom_init(w2, t->g.k, r + 1, t->g.canonical)) return -1; g2 = w2.g; }
+  NGeom ng2;
+  if(t->nword) { if(!nword_geom_init(ng2, t->g.k, r + 1, t->g.canonical)) return -1; g2 = ng2.g; }
+  else if(t->wide) { if(!wide_geom_init(w2, t->g.k, r + 1, t->g.canonical)) return -1; g2 = w2.g; }
   else if(!geom_init(g2, t->g.k, r + 1, 0, 0, t->g.canonical)) return -1;
   const uint64_t n2 = 1ull << g2.lsize_l;
   const size_t slot_bytes = 8 * (size_t)t->key_words;
@@ -382,7 +398,13 @@ int table_grow(jfgpu_table* t) {
   HIP_TRY(hipMemcpyAsync(nf, fwd.data(), fwd.size() * 8, hipMemcpyHostToDevice, t->stream));
   HIP_TRY(hipMemcpyAsync(ni, inv.data(), inv.size() * 8, hipMemcpyHostToDevice, t->stream));
   WideTable nw = t->wt;
-  if(t->wide) {
+  NTable nn = t->nt;
+  if(t->nword) {
+    nn.N = ng2; nn.slots = nd.slots; nn.fwd_tbl = nf; nn.inv_tbl = ni; nn.ovf_key = nd.ovf_key; nn.ovf_cnt = nd.ovf_cnt;
+    nn.ovf_mask = nd.ovf_mask; nn.counters = nd.counters; nn.max_probe = nd.max_probe;
+    hipLaunchKernelGGL(rehash_nword_kernel, dim3(grid_for(t, (1ull << t->g.lsize_l) / kBlock + 1)), dim3(kBlock), 0, t->stream, t->nt, nn,
+                       (int)(ctr[CTR_OVF_USED] != 0));
+  } else if(t->wide) {
     nw.W = w2; nw.slots = nd.slots; nw.fwd_tbl = nf; nw.inv_tbl = ni; nw.ovf_key = nd.ovf_key; nw.ovf_cnt = nd.ovf_cnt;
     nw.ovf_mask = nd.ovf_mask; nw.counters = nd.counters; nw.max_probe = nd.max_probe; nw.dirty = nd.dirty;
     hipLaunchKernelGGL(rehash_wide_kernel, dim3(grid_for(t, (1ull << t->g.lsize_l) / kBlock + 1)), dim3(kBlock), 0, t->stream, t->wt, nw,
@@ -397,6 +419,12 @@ int table_grow(jfgpu_table* t) {
   t->dt = nd; t->g = g2; t->matrix = m2; t->d_fwd = nf; t->d_inv = ni; t->ovf_cap = cap2;
   t->returning = t->g.cnt_bits < 40;
   if(t->d_M2) { hipFree(t->d_M2); t->d_M2 = nullptr; }
+  if(t->nword) {
+    t->nt = nn;
+    t->pristine = false;
+    ++t->grow_seed;
+    return check_deferred(t);
+  }
   if(t->wide) {
     t->wt = nw;
     const int wl = (int)(((size_t)16 << t->g.tile_bits) + ((size_t)2 << t->g.tile_bits));
@@ -437,7 +465,7 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
   if(!p || !out) return fail(JFGPU_E_INVALID, "null argument");
   *out = nullptr;
   if(p->k < 1) return fail(JFGPU_E_INVALID, "mer length must be >= 1");
-  if(p->k > 64) return fail(JFGPU_E_UNSUPPORTED, "mer length > 64 (more than two key words) is not built yet");
+  if(p->k > 128) return fail(JFGPU_E_UNSUPPORTED, "mer length > 128 (more than four key words) is not built");
   if(p->k > 32 && p->shard_bits) return fail(JFGPU_E_UNSUPPORTED, "sharded tables with mer length > 32 are not built yet");
   if(p->shard_bits > 8) return fail(JFGPU_E_INVALID, "at most 256 shards");
   if(p->shard_id >= (1u << p->shard_bits)) return fail(JFGPU_E_INVALID, "shard_id out of range");
@@ -450,10 +478,13 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
   HIP_TRY(hipSetDevice(dev));
 
   // size -> lsize (large_hash_array.hpp:156-157 rounds up to a power of two, :997-1000 caps at 4^k)
-  const bool wide = p->k > 32;
+  const bool nword = p->k > 64, wide = p->k > 32 && !nword;
   uint32_t lsize = 0;
   while(lsize < 63 && (1ull << lsize) < p->size) ++lsize;
-  if(wide) {
+  if(nword) {
+    lsize = std::max(lsize, nword_min_lsize(p->k));
+    lsize = std::min<uint32_t>(lsize, 48);
+  } else if(wide) {
     lsize = std::max(lsize, wide_min_lsize(p->k));
     lsize = std::min<uint32_t>(lsize, 48);
   } else {
@@ -469,8 +500,11 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
   t->device = dev;
   t->out_counter_len = p->out_counter_len ? p->out_counter_len : 4;
   if(t->out_counter_len > 8) return fail(JFGPU_E_INVALID, "out_counter_len must be <= 8");
-  t->wide = wide; t->key_words = wide ? 2 : 1;
-  if(wide) {
+  t->wide = wide; t->nword = nword; t->key_words = nword ? kNWords : wide ? 2 : 1;
+  if(nword) {
+    if(!nword_geom_init(t->nt.N, p->k, lsize, p->canonical ? 1 : 0)) return fail(JFGPU_E_INVALID, "table geometry does not fit a 256-bit slot");
+    t->g = t->nt.N.g;
+  } else if(wide) {
     if(!wide_geom_init(t->wt.W, p->k, lsize, p->canonical ? 1 : 0)) return fail(JFGPU_E_INVALID, "table geometry does not fit a 128-bit slot");
     t->g = t->wt.W.g;
   } else if(!geom_init(t->g, p->k, lsize, p->shard_bits, p->shard_id, p->canonical ? 1 : 0))
@@ -523,7 +557,14 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
   // dump kernel needs > 64 KiB of dynamic LDS
   const size_t dump_lds = ((size_t)8 << t->g.tile_bits) + ((size_t)2 << t->g.tile_bits) + (size_t)t->g.nbytes * 2048;
   HIP_TRY(hipFuncSetAttribute((const void*)dump_tiles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dump_lds));
-  if(wide) {
+  if(nword) {
+    NTable& w = t->nt;
+    w.slots = d.slots; w.fwd_tbl = d.fwd_tbl; w.inv_tbl = d.inv_tbl; w.ovf_key = d.ovf_key; w.ovf_cnt = d.ovf_cnt;
+    w.ovf_mask = d.ovf_mask; w.counters = d.counters; w.max_probe = d.max_probe;
+    t->part_ok = false; t->mode = MODE_DIRECT;
+    const int nl = (int)(((size_t)32 << kNTileBits) + ((size_t)2 << kNTileBits));
+    HIP_TRY(hipFuncSetAttribute((const void*)dump_tiles_nword_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, nl));
+  } else if(wide) {
     WideTable& w = t->wt;
     w.slots = d.slots; w.fwd_tbl = d.fwd_tbl; w.inv_tbl = d.inv_tbl; w.ovf_key = d.ovf_key; w.ovf_cnt = d.ovf_cnt;
     w.ovf_mask = d.ovf_mask; w.counters = d.counters; w.max_probe = d.max_probe; w.dirty = d.dirty;
@@ -532,7 +573,7 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     const int wl = (int)(((size_t)16 << t->g.tile_bits) + ((size_t)2 << t->g.tile_bits));
     HIP_TRY(hipFuncSetAttribute((const void*)dump_tiles_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
   } else part_geom_init(t.get());
-  if(const char* m = getenv("JFGPU_MODE")) {
+  if(!nword) if(const char* m = getenv("JFGPU_MODE")) {
     if(!strcmp(m, "direct")) t->mode = MODE_DIRECT;
     else if(!strcmp(m, "partitioned") && t->part_ok) t->mode = MODE_PARTITIONED;
   }
@@ -692,6 +733,13 @@ int jfgpu_count_ascii(jfgpu_table* t, const char* bases, size_t n) {
 static int add_keys_piece(jfgpu_table* t, const uint64_t* d_keys, size_t n, uint64_t val, uint8_t* d_is_new) {
   int rc = JFGPU_OK;
   if(!n) return JFGPU_OK;
+  if(t->nword) {
+    ProfScope ps(t, 1, n);
+    t->pristine = false;
+    hipLaunchKernelGGL(add_keys_nword_kernel, dim3(grid_for(t, (n + kBlock - 1) / kBlock)), dim3(kBlock), 0, t->stream, t->nt, d_keys, (uint64_t)n, val, d_is_new);
+    HIP_TRY(hipGetLastError());
+    return JFGPU_OK;
+  }
   if(t->wide) {
     ProfScope ps(t, 1, n);
     hipLaunchKernelGGL(add_keys_wide_kernel, dim3(grid_for(t, (n + kBlock - 1) / kBlock)), dim3(kBlock), 0, t->stream, t->wt, d_keys, (uint64_t)n, val, d_is_new);
@@ -758,6 +806,11 @@ int jfgpu_lookup_dev(jfgpu_table* t, const uint64_t* d_keys, size_t n, uint64_t*
   rc = check_deferred(t, c); if(rc) return rc;
   const int grid = grid_for(t, (n + kBlock - 1) / kBlock);
   ProfScope ps(t, 3, n);
+  if(t->nword) {
+    hipLaunchKernelGGL(lookup_nword_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->nt, d_keys, (uint64_t)n, d_vals, d_found, (int)(c[CTR_OVF_USED] != 0));
+    HIP_TRY(hipGetLastError());
+    return JFGPU_OK;
+  }
   if(t->wide) {
     hipLaunchKernelGGL(lookup_wide_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->wt, d_keys, (uint64_t)n, d_vals, d_found, (int)(c[CTR_OVF_USED] != 0));
     HIP_TRY(hipGetLastError());
@@ -792,7 +845,7 @@ int jfgpu_partition_ascii_dev(jfgpu_table* t, const char* d_bases, size_t n, uin
                               uint64_t* counts_out) {
   int rc = use(t); if(rc) return rc;
   if(!counts_out) return fail(JFGPU_E_INVALID, "null counts_out");
-  if(t->wide) return fail(JFGPU_E_UNSUPPORTED, "hash-prefix partition with mer length > 32 is not built yet");
+  if(t->wide || t->nword) return fail(JFGPU_E_UNSUPPORTED, "hash-prefix partition with mer length > 32 is not built yet");
   const uint32_t n_shards = 1u << t->g.shard_bits;
   for(uint32_t i = 0; i < n_shards; ++i) counts_out[i] = 0;
   if(n < t->g.k) return JFGPU_OK;
@@ -838,7 +891,8 @@ int jfgpu_stats_compute(jfgpu_table* t, uint64_t lower, uint64_t upper, jfgpu_st
   HIP_TRY(hipMalloc((void**)&d, 4 * sizeof(unsigned long long)));
   HIP_TRY(hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), t->stream));
   const int grid = grid_for(t, (1ull << t->g.lsize_l) / kBlock + 1);
-  if(t->wide) hipLaunchKernelGGL(scan_wide_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->wt, 0, lower, upper, (int)(c[CTR_OVF_USED] != 0), 0ull, 0ull, 1ull, 1ull, d, (uint32_t*)nullptr);
+  if(t->nword) hipLaunchKernelGGL(scan_nword_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->nt, 0, lower, upper, (int)(c[CTR_OVF_USED] != 0), 0ull, 0ull, 1ull, 1ull, d, (uint32_t*)nullptr);
+  else if(t->wide) hipLaunchKernelGGL(scan_wide_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->wt, 0, lower, upper, (int)(c[CTR_OVF_USED] != 0), 0ull, 0ull, 1ull, 1ull, d, (uint32_t*)nullptr);
   else hipLaunchKernelGGL(stats_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, lower, upper, (int)(c[CTR_OVF_USED] != 0), d);
   unsigned long long h[4];
   hipError_t e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, t->stream);
@@ -860,7 +914,8 @@ int jfgpu_digest(jfgpu_table* t, uint64_t lower, uint64_t upper, uint64_t* out4)
   HIP_TRY(hipMalloc((void**)&d, 4 * sizeof(unsigned long long)));
   HIP_TRY(hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), t->stream));
   const int grid = grid_for(t, (1ull << t->g.lsize_l) / kBlock + 1);
-  if(t->wide) hipLaunchKernelGGL(digest_wide_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->wt, lower, upper, (int)(c[CTR_OVF_USED] != 0), d);
+  if(t->nword) hipLaunchKernelGGL(scan_nword_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->nt, 3, lower, upper, (int)(c[CTR_OVF_USED] != 0), 0ull, 0ull, 1ull, 1ull, d, (uint32_t*)nullptr);
+  else if(t->wide) hipLaunchKernelGGL(digest_wide_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->wt, lower, upper, (int)(c[CTR_OVF_USED] != 0), d);
   else hipLaunchKernelGGL(digest_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, lower, upper, (int)(c[CTR_OVF_USED] != 0), d);
   hipError_t e = hipMemcpyAsync(out4, d, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, t->stream);
   if(e == hipSuccess) e = hipStreamSynchronize(t->stream);
@@ -879,7 +934,8 @@ int jfgpu_histo(jfgpu_table* t, uint64_t base, uint64_t ceil, uint64_t inc, uint
   HIP_TRY(hipMalloc((void**)&d, nb * sizeof(unsigned long long)));
   HIP_TRY(hipMemsetAsync(d, 0, nb * sizeof(unsigned long long), t->stream));
   const int grid = grid_for(t, (1ull << t->g.lsize_l) / kBlock + 1);
-  if(t->wide) hipLaunchKernelGGL(scan_wide_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->wt, 1, 0ull, ~0ull, (int)(c[CTR_OVF_USED] != 0), base, ceil, inc, nb, d, (uint32_t*)nullptr);
+  if(t->nword) hipLaunchKernelGGL(scan_nword_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->nt, 1, 0ull, ~0ull, (int)(c[CTR_OVF_USED] != 0), base, ceil, inc, nb, d, (uint32_t*)nullptr);
+  else if(t->wide) hipLaunchKernelGGL(scan_wide_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->wt, 1, 0ull, ~0ull, (int)(c[CTR_OVF_USED] != 0), base, ceil, inc, nb, d, (uint32_t*)nullptr);
   else hipLaunchKernelGGL(histo_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, base, ceil, inc, nb, (int)(c[CTR_OVF_USED] != 0), d);
   hipError_t e = hipMemcpyAsync(histo, d, nb * sizeof(uint64_t), hipMemcpyDeviceToHost, t->stream);
   if(e == hipSuccess) e = hipStreamSynchronize(t->stream);
@@ -897,7 +953,11 @@ int jfgpu_dump_begin(jfgpu_table* t, uint64_t lower, uint64_t upper, uint64_t* n
   uint32_t* d_cnt = nullptr;
   HIP_TRY(hipMalloc((void**)&d_cnt, nt * sizeof(uint32_t)));
   t->dump_have_ovf = c[CTR_OVF_USED] != 0;
-  if(t->wide) {
+  if(t->nword) {
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, nt * sizeof(uint32_t), t->stream));
+    hipLaunchKernelGGL(scan_nword_kernel, dim3(grid_for(t, (1ull << t->g.lsize_l) / kBlock + 1)), dim3(kBlock), 0, t->stream, t->nt, 2, lower, upper,
+                       t->dump_have_ovf, 0ull, 0ull, 1ull, 1ull, (unsigned long long*)nullptr, d_cnt);
+  } else if(t->wide) {
     HIP_TRY(hipMemsetAsync(d_cnt, 0, nt * sizeof(uint32_t), t->stream));
     hipLaunchKernelGGL(scan_wide_kernel, dim3(grid_for(t, (1ull << t->g.lsize_l) / kBlock + 1)), dim3(kBlock), 0, t->stream, t->wt, 2, lower, upper,
                        t->dump_have_ovf, 0ull, 0ull, 1ull, 1ull, (unsigned long long*)nullptr, d_cnt);
@@ -949,7 +1009,11 @@ int jfgpu_dump_next(jfgpu_table* t, void* out, uint64_t capacity_records, uint64
   std::vector<uint64_t> offs(ntile);
   for(uint64_t i = 0; i < ntile; ++i) offs[i] = t->dump_prefix[t0 + i] - t->dump_prefix[t0];
   HIP_TRY(hipMemcpyAsync(t->d_tile_off, offs.data(), ntile * sizeof(uint64_t), hipMemcpyHostToDevice, t->stream));
-  if(t->wide) {
+  if(t->nword) {
+    const size_t nl = ((size_t)32 << t->g.tile_bits) + ((size_t)2 << t->g.tile_bits);
+    hipLaunchKernelGGL(dump_tiles_nword_kernel, dim3(grid_for(t, ntile)), dim3(kBlock), nl, t->stream, t->nt, t->dump_lower, t->dump_upper,
+                       t->dump_have_ovf, t0, ntile, (const uint64_t*)t->d_tile_off, t->d_dump, key_bytes, t->out_counter_len);
+  } else if(t->wide) {
     const size_t wl = ((size_t)16 << t->g.tile_bits) + ((size_t)2 << t->g.tile_bits);
     hipLaunchKernelGGL(dump_tiles_wide_kernel, dim3(grid_for(t, ntile)), dim3(kBlock), wl, t->stream, t->wt, t->dump_lower, t->dump_upper,
                        t->dump_have_ovf, t0, ntile, (const uint64_t*)t->d_tile_off, t->d_dump, key_bytes, t->out_counter_len);
@@ -1012,17 +1076,18 @@ int jfgpu_reserve(jfgpu_table* t, uint64_t input_bytes) {
 }
 
 int jfgpu_table_bytes(uint32_t k, uint64_t size, uint64_t* slots, uint64_t* bytes) {
-  if(k < 1 || k > 64) return fail(JFGPU_E_UNSUPPORTED, "mer length must be in [1, 64]");
+  if(k < 1 || k > 128) return fail(JFGPU_E_UNSUPPORTED, "mer length must be in [1, 128]");
   uint32_t lsize = 0;
   while(lsize < 63 && (1ull << lsize) < size) ++lsize;
-  const bool wide = k > 32;
-  if(wide) { lsize = std::max(lsize, wide_min_lsize(k)); lsize = std::min<uint32_t>(lsize, 48); }
+  const bool nword = k > 64, wide = k > 32 && !nword;
+  if(nword) { lsize = std::max(lsize, nword_min_lsize(k)); lsize = std::min<uint32_t>(lsize, 48); }
+  else if(wide) { lsize = std::max(lsize, wide_min_lsize(k)); lsize = std::min<uint32_t>(lsize, 48); }
   else { lsize = std::max(lsize, geom_min_lsize(k, 0)); lsize = std::max<uint32_t>(lsize, 1); lsize = std::min<uint32_t>(lsize, 2 * k); }
   const uint64_t n = 1ull << lsize;
   uint64_t ovf = std::max<uint64_t>(1ull << 12, std::min<uint64_t>(n / 256, 1ull << 26));
   { uint64_t c = 1; while(c < ovf) c <<= 1; ovf = c; }
   if(slots) *slots = n;
-  if(bytes) *bytes = n * (wide ? 16 : 8) + ovf * 16 + (n >> std::min<uint32_t>(lsize, kMaxTileBits)) + (size_t)(2 * k + 7) / 8 * 256 * 8 * 2;
+  if(bytes) *bytes = n * (nword ? 32 : wide ? 16 : 8) + ovf * 16 + (n >> std::min<uint32_t>(lsize, kMaxTileBits)) + (size_t)(2 * k + 7) / 8 * 256 * 8 * 2;
   return JFGPU_OK;
 }
 
@@ -1033,7 +1098,7 @@ int jfgpu_set_spill(jfgpu_table* t, int (*fn)(void*), void* user) {
 }
 
 int jfgpu_reference_matrix(uint32_t lsize, uint32_t key_len, uint64_t* columns) {
-  if(!columns || lsize < 1 || lsize > 64 || key_len < 2 || key_len > 128) return fail(JFGPU_E_INVALID, "bad matrix dimensions");
+  if(!columns || lsize < 1 || lsize > 64 || key_len < 2 || key_len > 256) return fail(JFGPU_E_INVALID, "bad matrix dimensions");
   GlibcRandom rng;
   const Gf2Matrix m = lsize >= key_len ? gf2_identity(lsize, key_len) : gf2_reference_matrix(lsize, key_len, rng);
   for(uint32_t i = 0; i < key_len; ++i) columns[i] = m.columns[i];
