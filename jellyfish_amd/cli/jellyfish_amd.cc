@@ -334,7 +334,7 @@ int count_main(int argc, char* argv[]) {
     if(reprobes_given) std::cerr << "jellyfish-amd: note: -p/--reprobes has no effect (tile-local probing on the device)\n";
     if(generators_given) std::cerr << "jellyfish-amd: note: -G/--Generators has no effect (generator commands run one after the other)\n";
   }
-  if(mer_len > 64) die("jellyfish-amd: mer length > 64 is not built yet");
+  if(mer_len > 128) die("jellyfish-amd: mer length > 128 (more than four key words) is not built");
   if(text) out_counter_len = 8;   // text counts are not saturated (text_dumper.hpp:18-20)
 
   mer_dna::k(mer_len);
@@ -482,7 +482,7 @@ int bc_main(int argc, char* argv[]) {
   if(!mer_len) die("Error: mandatory switch missing: -m, --mer-len");
   if(!size_given) die("Error: mandatory switch missing: -s, --size");
   if(files.empty() && generator.empty()) die("Error: at least 1 file argument is required");
-  if(mer_len > 64) die("jellyfish-amd: mer length > 64 is not built yet");
+  if(mer_len > 64) die("jellyfish-amd: Bloom counters for mer length > 64 are not built");
   mer_dna::k(mer_len);
   header.canonical(canonical);
   std::ofstream out(output, std::ios::binary | std::ios::trunc);

@@ -79,7 +79,8 @@ struct jfgpu_table {
   bool nword = false;
   NTable nt{};
   WideTable wt{};
-  uint32_t key_words = 1;
+  uint32_t key_words = 1;        // 64-bit words of a key in the API (mer_dna::data(): ceil(2k / 64))
+  uint32_t slot_words = 1;       // 64-bit words of a table slot (1, 2 or 4)
   // staging for host buffers
   uint8_t* d_stage[2] = {nullptr, nullptr};
   hipEvent_t stage_done[2] = {nullptr, nullptr};
@@ -372,7 +373,7 @@ int table_grow(jfgpu_table* t) {
   else if(t->wide) { if(!wide_geom_init(w2, t->g.k, r + 1, t->g.canonical)) return -1; g2 = w2.g; }
   else if(!geom_init(g2, t->g.k, r + 1, 0, 0, t->g.canonical)) return -1;
   const uint64_t n2 = 1ull << g2.lsize_l;
-  const size_t slot_bytes = 8 * (size_t)t->key_words;
+  const size_t slot_bytes = 8 * (size_t)t->slot_words;
   uint64_t cap2 = std::max<uint64_t>(1ull << 12, std::min<uint64_t>(n2 / 256, 1ull << 26));
   { uint64_t x = 1; while(x < cap2) x <<= 1; cap2 = x; }
   DevTable nd = t->dt;
@@ -500,7 +501,7 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
   t->device = dev;
   t->out_counter_len = p->out_counter_len ? p->out_counter_len : 4;
   if(t->out_counter_len > 8) return fail(JFGPU_E_INVALID, "out_counter_len must be <= 8");
-  t->wide = wide; t->nword = nword; t->key_words = nword ? kNWords : wide ? 2 : 1;
+  t->wide = wide; t->nword = nword; t->key_words = (2 * p->k + 63) / 64; t->slot_words = nword ? kNWords : wide ? 2 : 1;
   if(nword) {
     if(!nword_geom_init(t->nt.N, p->k, lsize, p->canonical ? 1 : 0)) return fail(JFGPU_E_INVALID, "table geometry does not fit a 256-bit slot");
     t->g = t->nt.N.g;
@@ -541,7 +542,7 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
 
   DevTable& d = t->dt;
   d.g = t->g;
-  HIP_TRY(hipMalloc((void**)&d.slots, n_slots * sizeof(uint64_t) * t->key_words));
+  HIP_TRY(hipMalloc((void**)&d.slots, n_slots * sizeof(uint64_t) * t->slot_words));
   HIP_TRY(hipMalloc((void**)&t->d_fwd, fwd.size() * sizeof(uint64_t)));
   HIP_TRY(hipMalloc((void**)&t->d_inv, inv.size() * sizeof(uint64_t)));
   HIP_TRY(hipMalloc((void**)&d.ovf_key, t->ovf_cap * sizeof(uint64_t)));
@@ -656,11 +657,11 @@ int jfgpu_get_info(const jfgpu_table* t, jfgpu_info* o) {
   o->k = t->g.k; o->key_len = t->g.key_bits; o->canonical = t->g.canonical;
   o->lsize = t->g.lsize_g; o->size = 1ull << t->g.lsize_g; o->local_size = 1ull << t->g.lsize_l;
   o->shard_bits = t->g.shard_bits; o->shard_id = t->g.shard_id;
-  o->val_len = t->g.cnt_bits; o->slot_bytes = 8 * t->key_words; o->tile_slots = 1u << t->g.tile_bits;
+  o->val_len = t->g.cnt_bits; o->slot_bytes = 8 * t->slot_words; o->tile_slots = 1u << t->g.tile_bits;
   o->matrix_identity = t->matrix.identity ? 1 : 0;
   o->out_counter_len = t->out_counter_len;
   o->max_reprobe = t->dt.max_probe;
-  o->table_bytes = (1ull << t->g.lsize_l) * 8 * t->key_words;
+  o->table_bytes = (1ull << t->g.lsize_l) * 8 * t->slot_words;
   return JFGPU_OK;
 }
 
@@ -673,7 +674,7 @@ int jfgpu_get_matrix(const jfgpu_table* t, uint64_t* columns) {
 int jfgpu_clear(jfgpu_table* t) {
   int rc = use(t); if(rc) return rc;
   part_discard(t);
-  HIP_TRY(hipMemsetAsync(t->dt.slots, 0, (1ull << t->g.lsize_l) * sizeof(uint64_t) * t->key_words, t->stream));
+  HIP_TRY(hipMemsetAsync(t->dt.slots, 0, (1ull << t->g.lsize_l) * sizeof(uint64_t) * t->slot_words, t->stream));
   HIP_TRY(hipMemsetAsync(t->dt.ovf_key, 0, t->ovf_cap * sizeof(uint64_t), t->stream));
   HIP_TRY(hipMemsetAsync(t->dt.ovf_cnt, 0, t->ovf_cap * sizeof(uint64_t), t->stream));
   HIP_TRY(hipMemsetAsync(t->dt.counters, 0, CTR_COUNT * sizeof(uint64_t), t->stream));
@@ -736,7 +737,7 @@ static int add_keys_piece(jfgpu_table* t, const uint64_t* d_keys, size_t n, uint
   if(t->nword) {
     ProfScope ps(t, 1, n);
     t->pristine = false;
-    hipLaunchKernelGGL(add_keys_nword_kernel, dim3(grid_for(t, (n + kBlock - 1) / kBlock)), dim3(kBlock), 0, t->stream, t->nt, d_keys, (uint64_t)n, val, d_is_new);
+    hipLaunchKernelGGL(add_keys_nword_kernel, dim3(grid_for(t, (n + kBlock - 1) / kBlock)), dim3(kBlock), 0, t->stream, t->nt, d_keys, (uint64_t)n, t->key_words, val, d_is_new);
     HIP_TRY(hipGetLastError());
     return JFGPU_OK;
   }
@@ -807,7 +808,7 @@ int jfgpu_lookup_dev(jfgpu_table* t, const uint64_t* d_keys, size_t n, uint64_t*
   const int grid = grid_for(t, (n + kBlock - 1) / kBlock);
   ProfScope ps(t, 3, n);
   if(t->nword) {
-    hipLaunchKernelGGL(lookup_nword_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->nt, d_keys, (uint64_t)n, d_vals, d_found, (int)(c[CTR_OVF_USED] != 0));
+    hipLaunchKernelGGL(lookup_nword_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->nt, d_keys, (uint64_t)n, t->key_words, d_vals, d_found, (int)(c[CTR_OVF_USED] != 0));
     HIP_TRY(hipGetLastError());
     return JFGPU_OK;
   }

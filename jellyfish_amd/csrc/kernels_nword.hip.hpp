@@ -295,24 +295,26 @@ __global__ __launch_bounds__(kBlock) void count_ascii_nword_kernel(NTable T, con
   if((threadIdx.x & 63) == 0 && w) atomicAdd((unsigned long long*)&T.counters[CTR_MERS], (unsigned long long)w);
 }
 
-__device__ inline K256 load_key4(const uint64_t* keys, uint64_t i, const K256& mask) {
-  K256 r; for(int q = 0; q < 4; ++q) r.w[q] = keys[4 * i + q];
+// keys come as ceil(2k / 64) words each (3 for k <= 96), the reference's mer_dna::data() layout
+__device__ inline K256 load_key4(const uint64_t* keys, uint64_t i, uint32_t kw, const K256& mask) {
+  K256 r = k256_zero();
+  for(uint32_t q = 0; q < kw; ++q) r.w[q] = keys[(uint64_t)kw * i + q];
   return k256_and(r, mask);
 }
 
-__global__ __launch_bounds__(kBlock) void add_keys_nword_kernel(NTable T, const uint64_t* __restrict__ keys, uint64_t n, uint64_t val,
+__global__ __launch_bounds__(kBlock) void add_keys_nword_kernel(NTable T, const uint64_t* __restrict__ keys, uint64_t n, uint32_t kw, uint64_t val,
                                                                 uint8_t* __restrict__ is_new) {
   for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-    const bool nw = nword_add_val(T, load_key4(keys, i, T.N.key_mask), val);
+    const bool nw = nword_add_val(T, load_key4(keys, i, kw, T.N.key_mask), val);
     if(is_new) is_new[i] = nw ? 1 : 0;
   }
 }
 
-__global__ __launch_bounds__(kBlock) void lookup_nword_kernel(NTable T, const uint64_t* __restrict__ keys, uint64_t n,
+__global__ __launch_bounds__(kBlock) void lookup_nword_kernel(NTable T, const uint64_t* __restrict__ keys, uint64_t n, uint32_t kw,
                                                               uint64_t* __restrict__ vals, uint8_t* __restrict__ found, int have_ovf) {
   const DevTable d = ovf_view(T);
   for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-    const uint64_t s = nword_find(T, load_key4(keys, i, T.N.key_mask));
+    const uint64_t s = nword_find(T, load_key4(keys, i, kw, T.N.key_mask));
     vals[i] = s == ~0ull ? 0 : nword_count_at(T, d, s, T.slots[4 * s + 3], have_ovf);
     if(found) found[i] = s != ~0ull;
   }

@@ -418,3 +418,29 @@ def test_disk_spill_and_merge_reproduce_reference_goldens(cli, tmp_path):
     a = sorted(subprocess.check_output([cli, "dump", "-c", "big.jf"], cwd=d).splitlines())
     b = sorted(subprocess.check_output([cli, "dump", "-c", "small.jf"], cwd=d).splitlines())
     assert a == b and len(a) > 0
+
+
+def test_large_key_golden_k100(cli, tmp_path):
+    """tests/large_key.sh:7-18, the reference's own test of keys longer than two words: 100-mers of the first 10001 lines
+    of seq1m_0.fa read from a pipe (/dev/fd/0), with a table that fits (-s 2M), a size hint 1000 times too small (-s 2k:
+    the 256-bit-slot table doubles itself ten times) and -s 2k --disk (sorted runs merged at the end): the sorted k-mer
+    list has the reference's golden md5 every time, and the reference's reader decodes our 25-byte keys."""
+    import hashlib
+    if not os.access(O.REF_GEN, os.X_OK):
+        pytest.skip("oracle/_ref not built")
+    g = MANIFEST["reference_md5"]
+    d = str(tmp_path)
+    subprocess.check_call([O.REF_GEN, "-o", "seq1m"] + g["seq1m"], cwd=d)
+    head = b"".join(open(os.path.join(d, "seq1m_0.fa"), "rb").readlines()[:10001])
+
+    def ordered_md5(jf, reader):
+        out = subprocess.check_output([reader, "dump", "-c", jf], cwd=d)
+        return hashlib.md5(b"".join(sorted(l.split(b" ")[0] + b"\n" for l in out.splitlines()))).hexdigest()
+    for name, extra in (("m100_2M.jf", ["-s", "2M"]), ("m100_2k.jf", ["-s", "2k"]), ("m100_2k_disk.jf", ["-s", "2k", "--disk"])):
+        subprocess.run([cli, "count", "-t", "4", "-o", name, "-m", "100"] + extra + ["/dev/fd/0"], input=head, cwd=d, check=True)
+        assert ordered_md5(name, cli) == g["large_key_m100.ordered"], name
+    if O.have_ref():
+        assert ordered_md5("m100_2k.jf", O.REF_JF) == g["large_key_m100.ordered"]
+        assert subprocess.check_output([O.REF_JF, "dump", "--check-order", "m100_2M.jf"], cwd=d).decode().startswith("ORDER OK")
+        ref = subprocess.run([O.REF_JF, "count", "-m", "100", "-s", "2M", "-t", "2", "--no-write", "--digest", "r.txt", "/dev/fd/0"], input=head, cwd=d, check=True)
+        assert subprocess.check_output([cli, "digest", "m100_2M.jf"], cwd=d).decode() == open(os.path.join(d, "r.txt")).read()

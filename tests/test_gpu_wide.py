@@ -227,3 +227,41 @@ def test_wide_partitioned_grows_and_filters(gpu):
         assert got[1] == got[2]
         twice = {key: c for key, c in exp.items() if c >= 2}
         assert all(got[2].get(key) == c for key, c in twice.items())          # no false negatives
+
+
+@pytest.mark.parametrize("k,canonical,n,alphabet", [
+    (100, False, 20000, "ACGT"), (65, True, 15000, "ACGT"), (96, False, 9000, "ACGTacgt"), (97, True, 30000, "AC"),
+    (120, True, 40000, "ACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTN"), (80, True, 79, "ACGT"), (80, True, 80, "ACGT"),
+])
+def test_keys_of_three_and_four_words(gpu, k, canonical, n, alphabet):
+    """65 <= k <= 128 (kernels_nword.hip.hpp; the reference's tests/large_key.sh range): 256-bit keys in four-word slots
+    claimed word by word, a size hint far too small (the table doubles itself), counts, (pos, key) order of the dump
+    under the final matrix, look-ups with keys of ceil(2k/64) words, the content digest, hash_counter::add."""
+    rng = random.Random(k + n)
+    seq = rnd_seq(rng, n, alphabet)
+    keys, cnt = O.count(seq, k, canonical)
+    exp = {tuple(r): c for r, c in zip(keys.tolist(), cnt.tolist())}
+    with gpu.Table(k, 1 << 12, canonical=canonical) as t:
+        assert t.info.slot_bytes == 32 and t.key_words == (2 * k + 63) // 64
+        t.count_ascii(seq[: n // 2])
+        t.count_ascii(seq[max(0, n // 2 - (k - 1)):])
+        t.sync()
+        st = t.stats()
+        assert (st.distinct, st.total, st.mers_fed) == (len(exp), sum(exp.values()), sum(exp.values()))
+        kk, cc = gpu.decode_records(t.dump_records(chunk_records=1 << 16), k, t.info.out_counter_len)
+        assert {tuple(r): c for r, c in zip(kk.tolist(), cc.tolist())} == exp
+        assert t.digest() == gpu.digest_of(keys, cnt)
+        if len(kk) > 1:
+            pos = O.matrix_times(t.matrix(), t.info.lsize, 2 * k, kk[:4000])
+            pk = [(p,) + tuple(reversed(r)) for p, r in zip(pos.tolist(), kk[:4000].tolist())]
+            assert pk == sorted(pk)
+            vals, found = t.lookup(kk[:300])
+            assert found.all() and vals.tolist() == cc[:300].tolist()
+            absent = kk[:50].copy(); absent[:, 0] ^= np.uint64(0x5555)
+            absent = np.array([r for r in absent.tolist() if tuple(r) not in exp], dtype=np.uint64).reshape(-1, kk.shape[1])
+            vals, found = t.lookup(absent)
+            assert not found.any()
+            new = t.add_keys(np.concatenate([kk[:20], absent[:5]]), val=2 ** 40 + 1, want_new=True)
+            assert new.tolist() == [0] * 20 + [1] * len(absent[:5])
+            vals, found = t.lookup(kk[:20])
+            assert vals.tolist() == [int(c) + 2 ** 40 + 1 for c in cc[:20]]
