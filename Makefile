@@ -14,7 +14,7 @@ engine: $(LIBDIR)/libjfgpu.so
 
 $(LIBDIR)/libjfgpu.so: $(wildcard $(CSRC)/*.hip) $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.inl) include/jfgpu.h
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/jfgpu.hip
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/jfgpu.hip -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 
 cli: bin/jellyfish-amd
 

@@ -12,8 +12,10 @@ The reads are generated on the device before the timed region: `value` is throug
   N = 1  : per step the batch is encoded, hashed and radix-partitioned on the device (P1); the last step's sync applies
            everything pending (P2 partition + LDS-resident tile insert), all inside the timed region.  C3 runs K steps of
            the Bloom pass, its flush, then K steps of the filtered count and its flush.
-  N > 1  : (C2) one process per GPU, table sharded by the top hash bits; per step partition (HIP) -> all-to-all of routed
-           k-mers (RCCL over xGMI) -> insert (HIP).  Weak scaling: every rank brings its own reads.
+  N > 1  : (C2) one process per GPU, table sharded by the top hash bits; per step route by owner (HIP) -> exchange of the
+           routed k-mers (RCCL ncclSend/ncclRecv over xGMI, under the C ABI: jfgpu_comm_*) -> insert (HIP), pipelined by
+           one step.  torch.distributed (gloo) only hands out the RCCL id and reduces the timings.  Weak scaling: every
+           rank brings its own reads.
 
 Prints ONE JSON line (rank 0).  `value` comes from the contract's timed region (K steps, once); `repeats` re-runs the
 same job a few more times (median/min/max), `flush_sweep` forces 1/2/4/8 flushes per job, `end_to_end` is the Counting
@@ -185,7 +187,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group("gloo")          # control plane only; the data path is the engine's own RCCL communicator
     sb = (world - 1).bit_length()
     assert 1 << sb == world, "the number of GPUs must be a power of two (shards = top hash bits)"
 
@@ -226,12 +228,12 @@ def main():
     t.clear()
     force_dist = os.environ.get("JFGPU_BENCH_FORCE_DIST") == "1"     # exercise the N>1 code path on one GPU
     sharded = world > 1 or force_dist
+    comm = None
     if sharded:
-        import torch.distributed as dist
-        from jellyfish_amd import dist as jd
-        if not dist.is_initialized():
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        ids = [capi.comm_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(ids, src=0)
+        comm = capi.Comm(world, rank, ids[0], device=local_rank)
     bloom = None
     if cfg == "C3":
         bloom = capi.Bloom(K, capi.opt_m(0.001, int(args.gbp * 1e9)), capi.opt_k(0.001), canonical=True, device=local_rank)
@@ -243,18 +245,14 @@ def main():
     else:
         t.reserve(n_reads * stride if not sharded else int(n_reads * kmers_per_read * 1.02) + (1 << 20))
 
-    sc = None
-    if sharded:
-        max_batch = max(bounds[i + 1] - bounds[i] for i in range(steps))
-        be = jd.GpuBackend(t, max_batch * kmers_per_read, dev)
-        sc = jd.ShardedCounter(be)
+    exchanged = [0, 0]
 
     def fence():
         if sharded:
-            sc.finish()                  # last step's exchange + insert
+            exchanged[0], exchanged[1] = comm.finish()     # last step's exchange + insert; running totals sent / received
         t.sync()
         device_sync()
-        if sharded:
+        if world > 1:
             dist.barrier()
 
     def job(n_steps, flushes=1):
@@ -268,7 +266,8 @@ def main():
             t.attach_bloom(bloom)
         for i in range(n_steps):
             if sharded:
-                sc.step(batch(i))
+                p, n = batch(i)
+                comm.step(t, p, n)
             else:
                 p, n = batch(i)
                 t.count_ascii_dev(p, n)
@@ -295,7 +294,7 @@ def main():
     if bloom is not None:
         bloom.profile_enable(False)
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -303,9 +302,10 @@ def main():
     st = t.stats()
     tot = [st.total, st.distinct, st.mers_fed]
     if world > 1:
-        tt = torch.tensor(tot, dtype=torch.int64, device=dev)
+        tt = torch.tensor(tot + exchanged, dtype=torch.int64)
         dist.all_reduce(tt)
         tot = [int(x) for x in tt.tolist()]
+        assert tot[3] == tot[4], "k-mers lost or duplicated in the exchange: sent %d, received %d" % (tot[3], tot[4])
     total_kmers = n_reads * kmers_per_read * world
     if cfg == "C3":
         assert bloom.sync() == total_kmers and int(tot[2]) == total_kmers, "k-mers fed: bc %d, count %d, expected %d" % (bloom.sync(), int(tot[2]), total_kmers)
@@ -385,7 +385,7 @@ def main():
         job(steps)
         dt = time.perf_counter() - t1
         if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            tt = torch.tensor([dt], dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         vals.append(total_kmers / dt)
@@ -470,7 +470,9 @@ def main():
         bloom.close()
     if t is not None:
         t.close()
-    if sharded:
+    if comm is not None:
+        comm.close()
+    if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -147,6 +147,24 @@ int  jfgpu_lookup(jfgpu_table* t, const uint64_t* keys, size_t n, uint64_t* vals
 int  jfgpu_partition_ascii_dev(jfgpu_table* t, const char* d_bases, size_t n,
                                uint64_t* d_keys_out, size_t capacity, uint64_t* counts_out);
 
+/* The exchange itself: one process per GPU, shard r = the table positions whose top shard_bits bits are
+ * r.  jfgpu_comm_count_ascii_dev is one step of a rank: route this rank's contract buffer by owner, exchange (RCCL
+ * ncclSend / ncclRecv over xGMI, one group per round of at most 1 GiB per peer), insert what arrived -- pipelined by
+ * one step, so the keys of step i travel while step i+1 is routed and step i-1 is inserted.  Collective: every rank
+ * calls it the same number of times (n may be 0), then jfgpu_comm_finish, then reads its table (jfgpu_sync, dump...);
+ * the shards' sorted dumps concatenated in rank order are the globally (pos, key)-sorted file body.
+ *   id128: from jfgpu_comm_unique_id on one rank, handed to the others by whatever launched them.
+ * jfgpu_comm_create_local: the same code with all `world` shards in ONE process on one device and device copies as
+ * the transport (no RCCL): exists so that the sharded path can be tested on a single GPU. */
+typedef struct jfgpu_comm jfgpu_comm;
+int  jfgpu_comm_unique_id(uint8_t* id128);
+int  jfgpu_comm_create(int world, int rank, const uint8_t* id128, int device, jfgpu_comm** out);
+int  jfgpu_comm_create_local(int world, int device, jfgpu_comm** out);
+void jfgpu_comm_destroy(jfgpu_comm* c);
+int  jfgpu_comm_count_ascii_dev(jfgpu_comm* c, jfgpu_table* t, const char* d_bases, size_t n);
+int  jfgpu_comm_local_step(jfgpu_comm* c, jfgpu_table** tables, const char* const* d_bases, const size_t* n);
+int  jfgpu_comm_finish(jfgpu_comm* c, uint64_t* sent, uint64_t* received);
+
 /* ---- results path ------------------------------------------------------ */
 int  jfgpu_stats_compute(jfgpu_table* t, uint64_t lower, uint64_t upper, jfgpu_stats* out);
 /* Order-independent checksum of the {k-mer -> count} content restricted to lower <= count <= upper:

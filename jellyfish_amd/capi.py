@@ -73,6 +73,13 @@ SIGNATURES = {
     "jfgpu_lookup_dev": (C.c_int, [_P, _P, C.c_size_t, _P, _P]),
     "jfgpu_lookup": (C.c_int, [_P, _P, C.c_size_t, _P, _P]),
     "jfgpu_partition_ascii_dev": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, _P]),
+    "jfgpu_comm_unique_id": (C.c_int, [_P]),
+    "jfgpu_comm_create": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, C.POINTER(_P)]),
+    "jfgpu_comm_create_local": (C.c_int, [C.c_int, C.c_int, C.POINTER(_P)]),
+    "jfgpu_comm_destroy": (None, [_P]),
+    "jfgpu_comm_count_ascii_dev": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "jfgpu_comm_local_step": (C.c_int, [_P, _P, _P, _P]),
+    "jfgpu_comm_finish": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "jfgpu_stats_compute": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.POINTER(Stats)]),
     "jfgpu_digest": (C.c_int, [_P, C.c_uint64, C.c_uint64, _P]),
     "jfgpu_histo": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64, _P, C.c_uint64]),
@@ -362,6 +369,52 @@ class Table:
         out = np.zeros(nbytes, dtype=np.uint8)
         _check(self._lib.jfgpu_memcpy_d2h(self._h, out.ctypes.data, d_src, nbytes))
         return out
+
+
+def comm_unique_id():
+    """128 opaque bytes (ncclUniqueId) made on one rank and handed to the others before Comm(...)."""
+    buf = np.zeros(128, dtype=np.uint8)
+    _check(load().jfgpu_comm_unique_id(buf.ctypes.data))
+    return bytes(buf)
+
+
+class Comm:
+    """The multi-GPU exchange (jfgpu_comm*): RCCL between one process per GPU, or `local=True`: all shards in this process."""
+
+    def __init__(self, world, rank=0, unique_id=None, device=-1, local=False):
+        self._lib = load()
+        self.world, self.rank, self.local = world, rank, local
+        h = _P()
+        if local:
+            _check(self._lib.jfgpu_comm_create_local(world, device, C.byref(h)))
+        else:
+            idb = np.frombuffer(unique_id, dtype=np.uint8).copy()
+            assert len(idb) == 128
+            _check(self._lib.jfgpu_comm_create(world, rank, idb.ctypes.data, device, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.jfgpu_comm_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def step(self, table, d_ptr, n):
+        """One collective step of this rank: route, exchange, insert what arrived for the previous step."""
+        _check(self._lib.jfgpu_comm_count_ascii_dev(self._h, table._h, _ptr(d_ptr), n))
+
+    def local_step(self, tables, d_ptrs, ns):
+        w = self.world
+        th = (_P * w)(*[t._h for t in tables])
+        dp = (_P * w)(*[_ptr(p) for p in d_ptrs])
+        nn = (C.c_size_t * w)(*ns)
+        _check(self._lib.jfgpu_comm_local_step(self._h, th, dp, nn))
+
+    def finish(self):
+        s, r = C.c_uint64(), C.c_uint64()
+        _check(self._lib.jfgpu_comm_finish(self._h, C.byref(s), C.byref(r)))
+        return s.value, r.value
 
 
 class Bloom:

@@ -83,6 +83,10 @@ uint32_t granule_cap(const jfgpu_table* t, bool from_keys, uint64_t max_items) {
   else if(t->pg.b2 == 0 || t->pg.b1 > 10 || t->p1_single == 0 || !t->g1) return 0;
   else if(!t->item32 && from_keys) return 0;                             // 64-bit items: single-pass from sequence only
   const uint64_t nb = 1ull << t->pg.b1, strand = (uint64_t)t->g1 * kGran;
+  // Sequence input: one item per byte is the upper bound, what earlier flushes saw per byte (+10 %) the estimate -- reads
+  // of length L give (L - k + 1) / (L + 1) items per byte, 0.58 at k = 63.  An underestimate is safe: what does not fit
+  // a region is inserted directly (granule_emit), it only costs speed.
+  if(!from_keys && t->items_per_byte > 0) max_items = std::min<uint64_t>(max_items, (uint64_t)((double)max_items * (t->items_per_byte * 1.10 + 0.005)) + 4096);
   const uint64_t mean = (max_items + nb - 1) / nb;
   if(t->p1_single < 0 && mean < 4 * strand && !(t->item128 && t->mode == MODE_PARTITIONED)) return 0;
   const double want = (double)mean * (1.0 + t->p1_slack) + (double)strand;
@@ -113,6 +117,7 @@ int part_ingest(jfgpu_table* t, const uint8_t* base, int64_t lo, int64_t hi, boo
     if(need > t->ws_cap) { int rc = ws_grow(t, need); if(rc) return rc; }     // rc < 0: no memory -> caller goes direct
   }
   PendingBatch b{nullptr, nullptr, max_items};
+  b.input_bytes = from_keys ? 0 : (uint64_t)(hi - lo);
   b.items = ws_alloc(t, bytes);
   b.off = (uint64_t*)ws_alloc(t, (2 * nb + 1) * sizeof(uint64_t));
   if(!b.items || !b.off) return fail(JFGPU_E_ALLOC, "partition workspace exhausted");
@@ -217,6 +222,12 @@ int part_flush_t(jfgpu_table* t) {
     for(uint32_t j = 0; j < nb1; ++j) bucket_tot[j] += offs[s * (nb1 + 1) + j + 1] - offs[s * (nb1 + 1) + j];
   for(uint32_t j = 0; j < nb1; ++j) { total += bucket_tot[j]; max_bucket = std::max(max_bucket, bucket_tot[j]); }
   if(max_bucket > 0xF0000000ull) return fail(JFGPU_E_UNSUPPORTED, "more than 2^32 pending k-mers in one partition bucket: sync more often");
+  {   // items per input byte of what is being flushed (sequence batches only): sizes the next batches' bucket regions
+    uint64_t in_bytes = 0, in_items = 0;
+    for(size_t s = 0; s < nbatch; ++s)
+      if(t->pending[s].input_bytes) { in_bytes += t->pending[s].input_bytes; in_items += offs[s * (nb1 + 1) + nb1]; }
+    if(in_bytes >= (1u << 20)) t->items_per_byte = (double)in_items / (double)in_bytes;
+  }
   const uint64_t n_tiles = n_tiles_of(t);
   SegList S1; memset(&S1, 0, sizeof S1);
   S1.n = (uint32_t)nbatch;

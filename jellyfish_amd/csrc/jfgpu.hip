@@ -50,6 +50,7 @@ struct PendingBatch {
   void* items; uint64_t* off; uint64_t cap_items;
   uint32_t gran_cap = 0;                      // > 0: single-pass ("granule") batch, items per bucket region; off is in pair format
   unsigned long long* tot = nullptr;          // granule batch: exact items per bucket
+  uint64_t input_bytes = 0;                   // sequence bytes this batch was made from (0: encoded keys)
 };
 
 struct ProfSpan { hipEvent_t a, b; int which; uint64_t units; };
@@ -109,6 +110,7 @@ struct jfgpu_table {
                                  // streams run P2 and T concurrently but no faster (both are LDS-bound), so one launch each is the default
   hipStream_t stream2 = nullptr; hipEvent_t flush_ev[2] = {nullptr, nullptr}; hipEvent_t flush_done = nullptr;
   int p1_single = -1;            // single-pass P1: -1 auto (large batches), 0 never, 1 whenever the geometry allows (JFGPU_P1_SINGLE)
+  double items_per_byte = 0;     // k-mers per sequence byte seen by the last flush (0: unknown yet)
   double p1_slack = 0.03;        // head-room of a bucket region over the mean (JFGPU_P1_SLACK; negative forces the exhausted path)
   uint32_t* d_M1 = nullptr; int g1 = 0;
   uint32_t* d_M2 = nullptr; int g2 = 0;
@@ -1239,3 +1241,4 @@ int jfgpu_memcpy_d2h(jfgpu_table* t, void* dst, const void* d_src, size_t bytes)
 
 #include "abi_bloom.inl"
 #include "abi_parser.inl"
+#include "abi_comm.inl"

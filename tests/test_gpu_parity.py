@@ -292,6 +292,92 @@ def test_sharded_partition_equals_single_table(gpu):
             t.close()
 
 
+@pytest.mark.parametrize("world,max_msg,mode", [(2, None, 0), (4, "997", 2), (1, None, 2)])
+def test_comm_local_transport_equals_single_table(gpu, monkeypatch, world, max_msg, mode):
+    """The multi-GPU exchange under the C ABI (jfgpu_comm_*, abi_comm.inl) with its in-process transport: `world` shards
+    on this one device, every rank routes its own input by owner, messages move as device copies (in rounds of max_msg
+    keys when set), receivers insert; the step pipeline (route i+1 / exchange i / insert i-1), empty steps and ranks with
+    nothing to send included.  The shards' dumps concatenated in rank order are byte-identical to the dump of one table
+    of the global size, nothing is lost or duplicated, and the exchange code is the one the RCCL transport runs."""
+    if max_msg:
+        monkeypatch.setenv("JFGPU_COMM_MAX_MSG", max_msg)
+    rng = random.Random(31 + world)
+    k, lsize_g = 21, 20
+    inputs = [[rnd_seq(rng, rng.choice([0, 5, 30000, 50000]), "ACGTN") for _ in range(world)] for _step in range(4)]
+    inputs[1][0] = b""
+    whole_seq = b"N".join(b"N".join(step) for step in inputs)
+    exp = oracle_map(whole_seq, k, True)
+    with gpu.Table(k, 1 << lsize_g) as single:
+        single.count_ascii(whole_seq); single.sync()
+        whole = single.dump_records()
+        cols = single.matrix()
+    sb = world.bit_length() - 1
+    shards = [gpu.Table(k, 1 << lsize_g, shard_bits=sb, shard_id=r, matrix_columns=cols) for r in range(world)]
+    comm = gpu.Comm(world, local=True)
+    try:
+        bufs = []
+        for t in shards:
+            if mode:
+                t.set_mode(mode)
+        for step in inputs:
+            ptrs, ns = [], []
+            for r, seq in enumerate(step):
+                d = shards[r].malloc(len(seq) + 64)
+                if seq:
+                    shards[r].h2d(d, np.frombuffer(seq, dtype=np.uint8))
+                bufs.append((shards[r], d)); ptrs.append(d); ns.append(len(seq))
+            comm.local_step(shards, ptrs, ns)
+        sent, received = comm.finish()
+        assert sent == received == sum(exp.values())
+        for t in shards:
+            t.sync()
+        parts = [t.dump_records() for t in shards]
+        assert (np.concatenate(parts) == whole).all()
+        assert sum(t.stats().total for t in shards) == sum(exp.values())
+        for t, d in bufs:
+            t.free(d)
+    finally:
+        comm.close()
+        for t in shards:
+            t.close()
+
+
+def test_comm_rccl_transport_world_one(gpu, monkeypatch):
+    """The RCCL transport of the same exchange with a world of one rank (what a single-GPU box can run): ncclSend / ncclRecv
+    to self inside one group per round, rounds of 4096 keys, the one-step pipeline; the table equals a plain count."""
+    monkeypatch.setenv("JFGPU_COMM_MAX_MSG", "4096")
+    rng = random.Random(77)
+    k = 21
+    steps = [rnd_seq(rng, n, "ACGTN") for n in (60000, 0, 30, 90000, 20000)]
+    whole_seq = b"N".join(steps)
+    exp = oracle_map(whole_seq, k, True)
+    try:
+        comm = gpu.Comm(1, 0, gpu.comm_unique_id())
+    except gpu.JfgpuError as e:
+        if "emulated" in e.msg:
+            pytest.skip("no RCCL in the emulated engine")
+        raise
+    try:
+        with gpu.Table(k, 1 << 20) as t, gpu.Table(k, 1 << 20) as plain:
+            plain.count_ascii(whole_seq); plain.sync()
+            bufs = []
+            for seq in steps:
+                d = t.malloc(len(seq) + 64)
+                if seq:
+                    t.h2d(d, np.frombuffer(seq, dtype=np.uint8))
+                bufs.append(d)
+                comm.step(t, d, len(seq))
+            sent, received = comm.finish()
+            assert sent == received == sum(exp.values())
+            t.sync()
+            assert (t.dump_records() == plain.dump_records()).all()
+            assert table_map(gpu, t) == exp
+            for d in bufs:
+                t.free(d)
+    finally:
+        comm.close()
+
+
 def test_device_generator_is_reproducible_and_counts_match(gpu):
     """bench.py's synthetic reads: any slice regenerates identically; GPU counts on the
     device-resident buffer equal the oracle's on the same bytes."""
