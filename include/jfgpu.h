@@ -312,6 +312,18 @@ int  jfgpu_parser_parse(jfgpu_parser* p, const char* bytes, size_t n, unsigned f
  * at PCIe speed, that of pageable memory (an mmap'ed file) at a fraction of it. */
 int  jfgpu_parser_host_buffer(jfgpu_parser* p, int which, size_t bytes, char** out);
 /* Milliseconds the parse kernels of the last call took on the device (HIP events). */
+/* The same in pipeline form: _upload(which) starts the copy of a (pinned) host buffer to device buffer `which` on a copy
+ * stream and returns; _upload_wait(which) says when that host buffer may be refilled; _parse_uploaded(which) parses what
+ * was uploaded (waiting for that copy only).  Two buffers each side: the copy of chunk i+1 overlaps parse and count of
+ * chunk i while the host reads chunk i+2. */
+int  jfgpu_parser_upload(jfgpu_parser* p, int which, const char* bytes, size_t n);
+int  jfgpu_parser_upload_wait(jfgpu_parser* p, int which);
+int  jfgpu_parser_parse_uploaded(jfgpu_parser* p, int which, unsigned flags,
+                                 const char** d_out, size_t* n_out, uint64_t* n_records);
+/* count -Q / --min-quality (mer_qual_iterator.hpp:75-84, count_main.cc:234-256): from now on a FASTQ base whose quality
+ * character is below min_qual_char reaches the contract buffer as 'N'.  0 switches it off.  The raw chunk given to
+ * jfgpu_parser_parse_dev is edited in place when this is on.  FASTA input has no qualities: unaffected, as in the reference. */
+int  jfgpu_parser_set_min_quality(jfgpu_parser* p, int min_qual_char);
 int  jfgpu_parser_last_ms(jfgpu_parser* p, double* ms);
 
 /* ---- measurement helpers (bench.py; not part of the reference surface) -- */

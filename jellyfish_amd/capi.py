@@ -108,7 +108,11 @@ SIGNATURES = {
     "jfgpu_parser_destroy": (None, [_P]),
     "jfgpu_parser_parse_dev": (C.c_int, [_P, _P, C.c_size_t, C.c_uint, C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
     "jfgpu_parser_parse": (C.c_int, [_P, _P, C.c_size_t, C.c_uint, C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
+    "jfgpu_parser_upload": (C.c_int, [_P, C.c_int, _P, C.c_size_t]),
+    "jfgpu_parser_upload_wait": (C.c_int, [_P, C.c_int]),
+    "jfgpu_parser_parse_uploaded": (C.c_int, [_P, C.c_int, C.c_uint, C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
     "jfgpu_parser_host_buffer": (C.c_int, [_P, C.c_int, C.c_size_t, C.POINTER(_P)]),
+    "jfgpu_parser_set_min_quality": (C.c_int, [_P, C.c_int]),
     "jfgpu_parser_last_ms": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "jfgpu_set_growth": (C.c_int, [_P, C.c_int]),
     "jfgpu_reference_matrix": (C.c_int, [C.c_uint32, C.c_uint32, _P]),
@@ -575,6 +579,9 @@ class Parser:
 
     def parse_dev(self, d_ptr, n, flags):
         return self._call(self._lib.jfgpu_parser_parse_dev, _ptr(d_ptr), n, flags)
+
+    def set_min_quality(self, ch):
+        _check(self._lib.jfgpu_parser_set_min_quality(self._h, int(ch)))
 
     def last_ms(self):
         ms = C.c_double()

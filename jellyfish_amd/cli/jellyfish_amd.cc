@@ -265,7 +265,8 @@ int count_main(int argc, char* argv[]) {
   uint64_t size = 0, lower = 0, upper = std::numeric_limits<uint64_t>::max();
   bool counter_len_given = false, reprobes_given = false, generators_given = false;
   bool size_given = false, lower_given = false, upper_given = false, canonical = false, text = false, no_write = false, disk = false, host_parse = false, no_merge = false, no_unlink = false;
-  int device = -1;
+  int device = -1, min_qual = 0, quality_start = 64, min_quality = 0;
+  bool min_qual_char_given = false, min_quality_given = false;
   std::string output = "mer_counts.jf", timing, bc_path, generator, shell, digest_path;
   std::vector<std::string> files, if_files;
   ArgCursor a{argc, argv};
@@ -295,8 +296,15 @@ int count_main(int argc, char* argv[]) {
     else if(a.cur() == "--disk") disk = true;   // do_size_doubling(false) (count_main.cc:276-277): a full table is written out as a sorted run
     else if(a.cur() == "--no-merge") no_merge = true;
     else if(a.cur() == "--no-unlink") no_unlink = true;
-    else if(a.is("", "--bf-size") || a.is("", "--bf-fp") || a.is("-Q", "--min-qual-char") ||
-            a.is("-q", "--min-quality") || a.is("", "--sam"))
+    else if(a.is("-Q", "--min-qual-char")) {             // count_main.cc:234-244
+      const std::string v = a.value("-Q", "--min-qual-char");
+      if(v.size() != 1) die("[-Q, --min-qual-char] must be one character.");
+      if(v[0] < '!' || v[0] > '~') die(std::string("Quality character '") + v + "' is outside of the range [!, ~]");
+      min_qual = v[0]; min_qual_char_given = true;
+    }
+    else if(a.is("", "--quality-start")) quality_start = atoi(a.value("", "--quality-start").c_str());
+    else if(a.is("", "--min-quality")) { min_quality = atoi(a.value("", "--min-quality").c_str()); min_quality_given = true; }
+    else if(a.is("", "--bf-size") || a.is("", "--bf-fp") || a.is("", "--sam"))
       die("Option '" + a.cur() + "' is not supported by jellyfish-amd yet");
     else if(a.cur() == "-h" || a.cur() == "--help") {
       std::cout << "Usage: jellyfish-amd count [options] file:path+\n\n"
@@ -325,6 +333,12 @@ int count_main(int argc, char* argv[]) {
   if(!mer_len) die("Error: mandatory switch missing: -m, --mer-len");
   if(!size_given) die("Error: mandatory switch missing: -s, --size");
   if(files.empty() && generator.empty()) die("Error: at least 1 file argument is required");
+  if(min_quality_given) {                                   // count_main.cc:245-256
+    if(min_qual_char_given) die("Switches --min-quality and -Q, --min-qual-char conflict");
+    if(quality_start < '!' || quality_start > '~') die("Quality start " + std::to_string(quality_start) + " is outside the range [33, 126]");
+    min_qual = quality_start + min_quality;
+    if(min_qual < '!' || min_qual > '~') die("Min quality " + std::to_string(min_quality) + " is outside the range [0, " + std::to_string((int)'~' - quality_start) + "]");
+  }
   (void)threads; (void)counter_len; (void)reprobes; (void)Files;
   // Accepted for script compatibility but meaningless on this engine: say so once instead of silently ignoring them.
   // (-t: the device has its own parallelism; -c / -p: the in-memory slot format and probing are the engine's own and never
@@ -385,10 +399,12 @@ int count_main(int argc, char* argv[]) {
   auto feed = [&](const std::vector<std::string>& paths) {
     if(host_parse) {
       sequence_parser parser(mer_len);
+      parser.min_quality(min_qual);
       for(const auto& f : paths)
         parser.parse_file(f.c_str(), [&](const char* buf, size_t n) { ary->count_sequence(buf, n); });
     } else {
       device_sequence_parser parser(mer_len, device);
+      parser.min_quality(min_qual);
       for(const auto& f : paths)
         parser.parse_file(f.c_str(), [&](const char* d_buf, size_t n) { ary->count_sequence_dev(d_buf, n); },
                           [&](const char* buf, size_t n) { ary->count_sequence(buf, n); }, [&]() { ary->wait_consumed(); });

@@ -6,6 +6,9 @@ struct jfgpu_parser {
   hipStream_t stream = nullptr;
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
   uint8_t* d_raw = nullptr; size_t raw_cap = 0;            // host-fed chunks land here
+  // pipelined feed (jfgpu_parser_upload / _parse_uploaded): chunk i+1 travels on the copy stream while chunk i is parsed
+  uint8_t* d_up[2] = {nullptr, nullptr}; size_t up_cap[2] = {0, 0}; size_t up_len[2] = {0, 0};
+  hipStream_t copy_stream = nullptr; hipEvent_t up_done[2] = {nullptr, nullptr};
   uint8_t* d_out[2] = {nullptr, nullptr}; size_t out_cap[2] = {0, 0};
   int cur = 0;
   ParseAgg* d_agg = nullptr; ParseStart* d_start = nullptr; size_t tiles_cap = 0;
@@ -14,6 +17,7 @@ struct jfgpu_parser {
   uint8_t* d_carry = nullptr; uint32_t carry_len = 0;      // last k-1 characters of the previous chunk's output
   char* h_pin[2] = {nullptr, nullptr}; size_t pin_cap[2] = {0, 0};   // pinned host staging for callers that read files
   double last_ms = 0;
+  uint32_t min_qual = 0;                                   // > 0: FASTQ bases with a lower quality character become 'N'
 };
 
 namespace {
@@ -62,6 +66,8 @@ void jfgpu_parser_destroy(jfgpu_parser* p) {
   if(p->stream) hipStreamSynchronize(p->stream);
   hipFree(p->d_raw); hipFree(p->d_out[0]); hipFree(p->d_out[1]); hipFree(p->d_agg); hipFree(p->d_start);
   hipFree(p->d_nlpos); hipFree(p->d_res); hipFree(p->d_carry);
+  if(p->copy_stream) { hipStreamSynchronize(p->copy_stream); hipStreamDestroy(p->copy_stream); }
+  for(int i = 0; i < 2; ++i) { if(p->d_up[i]) hipFree(p->d_up[i]); if(p->up_done[i]) hipEventDestroy(p->up_done[i]); }
   for(int i = 0; i < 2; ++i) if(p->h_pin[i]) hipHostFree(p->h_pin[i]);
   if(p->ev_a) hipEventDestroy(p->ev_a);
   if(p->ev_b) hipEventDestroy(p->ev_b);
@@ -141,6 +147,15 @@ int jfgpu_parser_parse_dev(jfgpu_parser* p, const char* d_bytes, size_t n, unsig
       return fail(JFGPU_E_FORMAT, "not a strict 4-line FASTQ chunk:" + why);
     }
   }
+  if(fmt == JFGPU_PARSE_FASTQ && p->min_qual) {
+    // quality masking (mer_qual_iterator.hpp:75-84): edit the raw chunk in place, emit again
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((records + 3) / 4, 8192));
+    hipLaunchKernelGGL(fastq_qual_mask_kernel, dim3(grid), dim3(256), 0, p->stream, const_cast<uint8_t*>(base), lo, hi, p->d_nlpos, res.lines, records, p->min_qual);
+    HIP_TRY(hipMemsetAsync(p->d_res, 0, sizeof(ParseResult), p->stream));
+    hipLaunchKernelGGL(parse_emit_kernel<PARSE_FASTQ>, dim3((unsigned)nt), dim3(kParseBlock), 0, p->stream, base, lo, hi, (int64_t)0,
+                       p->d_start, out0, p->d_nlpos, (uint64_t)max_lines, p->d_res);
+    HIP_TRY(hipGetLastError());
+  }
   HIP_TRY(hipEventRecord(p->ev_b, p->stream));
   // seam: the previous chunk's last k-1 characters in front, then remember this chunk's
   uint8_t* start = out0 - p->carry_len;
@@ -171,6 +186,42 @@ int jfgpu_parser_parse(jfgpu_parser* p, const char* bytes, size_t n, unsigned fl
   return jfgpu_parser_parse_dev(p, (const char*)p->d_raw, n, flags, d_out, n_out, n_records);
 }
 
+// Pipelined form of jfgpu_parser_parse for callers that read files: upload(which) enqueues the host-to-device copy of
+// a pinned buffer on the parser's copy stream and returns at once; parse_uploaded(which) waits for that copy only and
+// parses.  With two host buffers and two device buffers the copy of chunk i+1 overlaps the parse (and the counting)
+// of chunk i while the caller reads chunk i+2 from the file.
+int jfgpu_parser_upload(jfgpu_parser* p, int which, const char* bytes, size_t n) {
+  int rc = use_p(p); if(rc) return rc;
+  if(which < 0 || which > 1 || (n && !bytes)) return fail(JFGPU_E_INVALID, "bad argument");
+  if(n > ((size_t)1 << 31)) return fail(JFGPU_E_INVALID, "chunk larger than 2^31 bytes");
+  if(!p->copy_stream) {
+    HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+    for(int i = 0; i < 2; ++i) HIP_TRY(hipEventCreateWithFlags(&p->up_done[i], hipEventDisableTiming));
+  }
+  if(n + 64 > p->up_cap[which]) {
+    HIP_TRY(hipStreamSynchronize(p->copy_stream)); HIP_TRY(hipStreamSynchronize(p->stream));
+    rc = grow_buf(p->d_up[which], p->up_cap[which], n + 64); if(rc) return rc;
+  }
+  if(n) HIP_TRY(hipMemcpyAsync(p->d_up[which], bytes, n, hipMemcpyHostToDevice, p->copy_stream));
+  HIP_TRY(hipEventRecord(p->up_done[which], p->copy_stream));
+  p->up_len[which] = n;
+  return JFGPU_OK;
+}
+
+int jfgpu_parser_upload_wait(jfgpu_parser* p, int which) {      // the host buffer given to upload(which) may be refilled
+  int rc = use_p(p); if(rc) return rc;
+  if(which < 0 || which > 1 || !p->copy_stream) return fail(JFGPU_E_INVALID, "nothing was uploaded");
+  HIP_TRY(hipEventSynchronize(p->up_done[which]));
+  return JFGPU_OK;
+}
+
+int jfgpu_parser_parse_uploaded(jfgpu_parser* p, int which, unsigned flags, const char** d_out, size_t* n_out, uint64_t* n_records) {
+  int rc = use_p(p); if(rc) return rc;
+  if(which < 0 || which > 1 || !p->copy_stream) return fail(JFGPU_E_INVALID, "nothing was uploaded");
+  HIP_TRY(hipStreamWaitEvent(p->stream, p->up_done[which], 0));
+  return jfgpu_parser_parse_dev(p, (const char*)p->d_up[which], p->up_len[which], flags, d_out, n_out, n_records);
+}
+
 int jfgpu_parser_host_buffer(jfgpu_parser* p, int which, size_t bytes, char** out) {
   int rc = use_p(p); if(rc) return rc;
   if(!out || which < 0 || which > 1) return fail(JFGPU_E_INVALID, "bad argument");
@@ -181,6 +232,13 @@ int jfgpu_parser_host_buffer(jfgpu_parser* p, int which, size_t bytes, char** ou
     p->pin_cap[which] = bytes;
   }
   *out = p->h_pin[which];
+  return JFGPU_OK;
+}
+
+int jfgpu_parser_set_min_quality(jfgpu_parser* p, int min_qual_char) {
+  int rc = use_p(p); if(rc) return rc;
+  if(min_qual_char < 0 || min_qual_char > 126) return fail(JFGPU_E_INVALID, "quality character outside [0, '~']");
+  p->min_qual = (uint32_t)min_qual_char;
   return JFGPU_OK;
 }
 

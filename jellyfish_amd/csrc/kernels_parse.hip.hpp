@@ -328,4 +328,28 @@ __global__ void fastq_check_kernel(const uint8_t* __restrict__ b, int64_t lo, in
   if(bad) atomicOr((unsigned long long*)&res->flags, (unsigned long long)bad);
 }
 
+// ---- E: quality masking (-Q / --min-quality) ---------------------------------------------------
+// mer_qual_iterator (/root/reference/include/jellyfish/mer_qual_iterator.hpp:75-84): a base whose quality character is
+// below min_qual counts as an invalid character.  On a chunk that passed the record check (strict 4-line records, equal
+// sequence and quality lengths) that is: sequence byte i of a record becomes 'N' when quality byte i < min_qual.  The
+// raw chunk is edited in place, then the emit pass is run again (the layout of kept bytes does not change).
+__global__ void fastq_qual_mask_kernel(uint8_t* __restrict__ b, int64_t lo, int64_t hi, const uint32_t* __restrict__ nlpos,
+                                       uint64_t n_newlines, uint64_t n_records, uint32_t min_qual) {
+  // one wave per record, lanes stride over its bases
+  const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  const uint32_t lane = threadIdx.x & 63;
+  for(uint64_t r = wave; r < n_records; r += n_waves) {
+    const uint64_t l1 = 4 * r + 1, l3 = 4 * r + 3;
+    const int64_t s1 = lo + (int64_t)nlpos[l1 - 1] + 1, e1 = lo + (int64_t)nlpos[l1];
+    const int64_t s3 = lo + (int64_t)nlpos[l3 - 1] + 1;
+    const int64_t e3 = l3 < n_newlines ? lo + (int64_t)nlpos[l3] : hi;
+    int64_t len = e1 - s1;
+    if(e3 - s3 < len) len = e3 - s3;
+    for(int64_t i = lane; i < len; i += 64) {
+      const uint32_t q = b[s3 + i];
+      if(q != '\r' && q < min_qual) b[s1 + i] = 'N';
+    }
+  }
+}
+
 }  // namespace jfgpu

@@ -38,6 +38,11 @@ public:
 
   size_t nb_files() const { return files_read_; }
   size_t nb_reads() const { return reads_read_ + host_.nb_reads(); }
+  // count -Q / --min-quality: FASTQ bases below this quality character count as 'N' (device parser and host fallback alike)
+  void min_quality(int c) {
+    host_.min_quality(c);
+    if(jfgpu_parser_set_min_quality(p_, c)) throw std::runtime_error(jfgpu_last_error());
+  }
   size_t host_fallback_bytes() const { return fallback_bytes_; }
   double device_ms() const { return device_ms_; }
 
@@ -50,7 +55,7 @@ public:
       host_.parse_file(path, host_sink);
       return;
     }
-    const bool pinned = pinned_ < 0 ? (size_t)st.st_size >= ((size_t)16 << 30) : pinned_ != 0;
+    const bool pinned = pinned_ < 0 ? (size_t)st.st_size >= ((size_t)64 << 20) : pinned_ != 0;
     if(pinned) {
       try { parse_fd_pinned(fd, (size_t)st.st_size, dev_sink, host_sink, fence); } catch(...) { close(fd); throw; }
       close(fd);
@@ -98,7 +103,7 @@ private:
   }
 
   static constexpr size_t npos = ~(size_t)0;
-  int pinned_ = -1;             // JFGPU_FEED_PINNED: -1 auto (files >= 16 GiB), 0 never, 1 always
+  int pinned_ = -1;             // JFGPU_FEED_PINNED: -1 auto (files >= 64 MiB), 0 never (pageable copy of the mapping), 1 always
   unsigned k_;
   size_t chunk_;
   jfgpu_parser* p_ = nullptr;
@@ -133,11 +138,11 @@ private:
     return true;
   }
 
-  // Large regular files: two pinned buffers of chunk_ bytes.  Buffer w holds [carried tail of the previous
-  // buffer][fresh bytes]; the part up to the last line / record boundary is parsed on the device while a
-  // background task moves the tail to the other buffer and reads on.  Pinning the two buffers costs ~0.2 s
-  // and the gain over the pageable mmap copy is modest (measured 15 vs 11.6 GB/s from the page cache), which
-  // is why only very large files take this path.
+  // Regular files: two pinned buffers of chunk_ bytes, three overlapping stages.  Buffer w holds [carried tail of the
+  // previous buffer][fresh bytes]; the part up to the last line / record boundary is uploaded on the parser's copy
+  // stream (jfgpu_parser_upload) and parsed + counted on the device, while a background task moves the tail to the
+  // other buffer and reads the next chunk with a few dozen parallel pread()s (one stream copies out of the page cache
+  // at ~2-3 GB/s; a pageable copy of the mapping measured 2.9 GB/s end to end on a 10 GB file, profiles/r02_*).
   void parse_fd_pinned(int fd, size_t n, const dev_sink_type& dev_sink, const host_sink_type& host_sink, const fence_type& fence) {
     ++files_read_;
     const size_t cap = chunk_ + (chunk_ >> 2);
@@ -179,16 +184,18 @@ private:
       std::future<bool> next_ready;
       const size_t tail = len - cut;
       const bool more = !last || tail;
+      if(jfgpu_parser_upload(p_, w, buf, cut)) throw std::runtime_error(jfgpu_last_error());   // asynchronous, copy stream
       if(more) {
         const int o = w ^ 1;
         next_ready = std::async(std::launch::async, [&, o, tail, cut, buf]() {
-          memcpy(pin_[o], buf + cut, tail);
+          memcpy(pin_[o], buf + cut, tail);       // pin_[o]'s own upload finished before its parse returned (previous turn)
           return fill(o, tail);
         });
       }
+      // (the upload of this buffer was enqueued before the background task started: see below)
       fence();
       const char* d_out = nullptr; size_t n_out = 0; uint64_t recs = 0;
-      const int rc = jfgpu_parser_parse(p_, buf, cut, fmt | (first ? 0u : JFGPU_PARSE_CONTINUE), &d_out, &n_out, &recs);
+      const int rc = jfgpu_parser_parse_uploaded(p_, w, fmt | (first ? 0u : JFGPU_PARSE_CONTINUE), &d_out, &n_out, &recs);
       if(next_ready.valid() && !next_ready.get()) throw std::runtime_error("Error reading the sequence file");
       if(rc == JFGPU_E_FORMAT) {
         void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
@@ -225,7 +232,7 @@ private:
     return npos;
   }
 
-  unsigned copy_threads_ = std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 4));
+  unsigned copy_threads_ = std::max(1u, std::min(32u, std::thread::hardware_concurrency() / 4));
   sequence_parser host_;
   size_t files_read_ = 0, reads_read_ = 0, fallback_bytes_ = 0;
   double device_ms_ = 0;

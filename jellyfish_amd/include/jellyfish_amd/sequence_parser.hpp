@@ -38,6 +38,8 @@ public:
 
   size_t nb_files() const { return files_read_; }
   size_t nb_reads() const { return reads_read_; }
+  // count -Q / --min-quality (mer_qual_iterator.hpp:75-84): FASTQ bases with a lower quality character become 'N'; 0 = off
+  void min_quality(int c) { min_qual_ = c; }
 
   void parse_file(const char* path, const sink_type& sink) {
     int fd = open(path, O_RDONLY);
@@ -79,6 +81,7 @@ private:
   size_t buf_size_;
   std::string buf_;
   size_t files_read_ = 0, reads_read_ = 0;
+  int min_qual_ = 0;
 
   static const char* line_end(const char* p, const char* end) {
     const char* nl = (const char*)memchr(p, '\n', end - p);
@@ -128,6 +131,7 @@ private:
     while(p < end) {
       // sequence lines until a line starting with '+'
       size_t seq_len = 0;
+      const size_t rec_start = buf_.size();                  // this record's bases are buf_[rec_start, rec_start + seq_len)
       while(true) {
         p = skip_newlines(p, end);
         if(p >= end || *p == '+') break;
@@ -146,6 +150,9 @@ private:
         const char* e = line_end(p, end);
         const char* le = e;
         while(le > p && le[-1] == '\r') --le;
+        if(min_qual_)
+          for(const char* q = p; q < le && quals + (size_t)(q - p) < seq_len; ++q)
+            if(*q < min_qual_) buf_[rec_start + quals + (size_t)(q - p)] = 'N';
         quals += le - p;
         p = e < end ? e + 1 : end;
       }
