@@ -216,6 +216,11 @@ int  jfgpu_bc_read(jfgpu_bloom* b, uint8_t* out);
 int  jfgpu_bc_load(jfgpu_bloom* b, const uint8_t* data);
 /* bloom_base::check / insert on encoded k-mers (query_main.cc Bloom branch); out[i] = 0, 1 or 2 */
 int  jfgpu_bc_keys(jfgpu_bloom* b, const uint64_t* keys, size_t n, uint8_t* out, int do_insert);
+/* count --bf-size N --bf-fp F (count_main.cc:121-131,321-323; bloom_filter.hpp:44-68): a Bloom filter of m = opt_m(F, N)
+ * BITS with opt_k(F) hashes, filled by the count itself -- attached with jfgpu_attach_bloom, every k-mer sets its bits
+ * and is counted only if all of them were set before (its first sighting only marks it).  Same params struct; the
+ * result is order dependent in the reference too (tests/bloom_filter.sh bounds it statistically). */
+int  jfgpu_bf_create(const jfgpu_bloom_params* p, jfgpu_bloom** out);
 /* How jfgpu_bc_insert_* applies the increments (no reference counterpart; the array is the same either way because the
  * increments saturate and commute): 0 auto, 1 direct (one global compare-and-swap per cell), 2 partitioned (cell updates
  * routed to 64 KiB segments of the array and applied in LDS at the next jfgpu_bc_sync / _read / _keys / attach).

@@ -89,6 +89,7 @@ SIGNATURES = {
     "jfgpu_bc_opt_m": (C.c_uint64, [C.c_double, C.c_uint64]),
     "jfgpu_bc_opt_k": (C.c_uint32, [C.c_double]),
     "jfgpu_bc_create": (C.c_int, [C.POINTER(BloomParams), C.POINTER(_P)]),
+    "jfgpu_bf_create": (C.c_int, [C.POINTER(BloomParams), C.POINTER(_P)]),
     "jfgpu_bc_destroy": (None, [_P]),
     "jfgpu_bc_insert_ascii_dev": (C.c_int, [_P, _P, C.c_size_t]),
     "jfgpu_bc_insert_ascii": (C.c_int, [_P, _P, C.c_size_t]),
@@ -424,7 +425,7 @@ class Comm:
 class Bloom:
     """Bloom counter of `jellyfish bc` in HBM (jfgpu_bloom*)."""
 
-    def __init__(self, k, m, nb_hashes, canonical=True, device=-1, seed=0, matrix1=None, matrix2=None):
+    def __init__(self, k, m, nb_hashes, canonical=True, device=-1, seed=0, matrix1=None, matrix2=None, one_pass_filter=False):
         self._lib = load()
         p = BloomParams()
         p.k, p.canonical, p.m, p.nb_hashes, p.device, p.seed = k, int(bool(canonical)), int(m), int(nb_hashes), device, seed
@@ -435,7 +436,7 @@ class Bloom:
             p.matrix1 = self._m1.ctypes.data_as(C.POINTER(C.c_uint64))
             p.matrix2 = self._m2.ctypes.data_as(C.POINTER(C.c_uint64))
         h = _P()
-        _check(self._lib.jfgpu_bc_create(C.byref(p), C.byref(h)))
+        _check((self._lib.jfgpu_bf_create if one_pass_filter else self._lib.jfgpu_bc_create)(C.byref(p), C.byref(h)))
         self._h = h
         self.k = k
         m_, nh, nbytes = C.c_uint64(), C.c_uint32(), C.c_uint64()

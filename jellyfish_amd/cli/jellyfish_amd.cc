@@ -265,6 +265,7 @@ int count_main(int argc, char* argv[]) {
   uint64_t size = 0, lower = 0, upper = std::numeric_limits<uint64_t>::max();
   bool counter_len_given = false, reprobes_given = false, generators_given = false;
   bool size_given = false, lower_given = false, upper_given = false, canonical = false, text = false, no_write = false, disk = false, host_parse = false, no_merge = false, no_unlink = false;
+  uint64_t bf_size = 0; double bf_fp = 0.01; bool bf_size_given = false;
   int device = -1, min_qual = 0, quality_start = 64, min_quality = 0;
   bool min_qual_char_given = false, min_quality_given = false;
   std::string output = "mer_counts.jf", timing, bc_path, generator, shell, digest_path;
@@ -304,8 +305,10 @@ int count_main(int argc, char* argv[]) {
     }
     else if(a.is("", "--quality-start")) quality_start = atoi(a.value("", "--quality-start").c_str());
     else if(a.is("", "--min-quality")) { min_quality = atoi(a.value("", "--min-quality").c_str()); min_quality_given = true; }
-    else if(a.is("", "--bf-size") || a.is("", "--bf-fp") || a.is("", "--sam"))
-      die("Option '" + a.cur() + "' is not supported by jellyfish-amd yet");
+    else if(a.is("", "--bf-size")) { bf_size = parse_suffix(a.value("", "--bf-size"), "--bf-size"); bf_size_given = true; }
+    else if(a.is("", "--bf-fp")) bf_fp = atof(a.value("", "--bf-fp").c_str());
+    else if(a.is("", "--sam"))
+      die("SAM/BAM/CRAM not supported (missing htslib).");
     else if(a.cur() == "-h" || a.cur() == "--help") {
       std::cout << "Usage: jellyfish-amd count [options] file:path+\n\n"
                    "Count k-mers in fasta or fastq files on an MI355X\n\n"
@@ -333,6 +336,7 @@ int count_main(int argc, char* argv[]) {
   if(!mer_len) die("Error: mandatory switch missing: -m, --mer-len");
   if(!size_given) die("Error: mandatory switch missing: -s, --size");
   if(files.empty() && generator.empty()) die("Error: at least 1 file argument is required");
+  if(bf_size_given && !bc_path.empty()) die("Switches --bf-size and --bc conflict");
   if(min_quality_given) {                                   // count_main.cc:245-256
     if(min_qual_char_given) die("Switches --min-quality and -Q, --min-qual-char conflict");
     if(quality_start < '!' || quality_start > '~') die("Quality start " + std::to_string(quality_start) + " is outside the range [33, 126]");
@@ -378,6 +382,17 @@ int count_main(int argc, char* argv[]) {
     in.read((char*)body.data(), body.size());
     if(!in.good()) die("Bloom filter file is truncated");
     if(jfgpu_bc_load(bc, body.data()) || jfgpu_attach_bloom(ary->handle(), bc)) die(jfgpu_last_error());
+  }
+
+  // Bloom filter to filter out low frequency k-mers, one pass algorithm (count_main.cc:318-324): the first sighting of
+  // a k-mer only marks it in the filter, later ones are counted
+  if(bf_size_given) {
+    jfgpu_bloom_params bp;
+    memset(&bp, 0, sizeof bp);
+    bp.k = mer_len; bp.canonical = canonical; bp.device = device;
+    bp.m = jfgpu_bc_opt_m(bf_fp, bf_size); bp.nb_hashes = jfgpu_bc_opt_k(bf_fp);
+    if(jfgpu_bf_create(&bp, &bc)) die(std::string("Failed to create the bloom filter: ") + jfgpu_last_error());
+    if(jfgpu_attach_bloom(ary->handle(), bc)) die(jfgpu_last_error());
   }
 
   std::unique_ptr<dumper_base> dumper;

@@ -13,6 +13,7 @@ struct jfgpu_bloom {
   uint8_t* d_stage = nullptr;
   // partitioned insert (kernels_bloom_part.hip.hpp, bloom_partition.inl)
   BloomPart bp{}; bool part_ok = false;
+  uint32_t kind = 0;               // 0: Bloom counter (bc / count --bc); 1: one-pass Bloom filter of bits (count --bf-size)
   int mode = 0;                    // 0 auto, 1 direct (global CAS), 2 partitioned (JFGPU_BLOOM_MODE / jfgpu_bc_set_mode)
   double slack = 0.03;             // head-room of a bucket region over the mean
   int g1 = 0;
@@ -23,7 +24,7 @@ struct jfgpu_bloom {
   bool prof_on = false;
   std::vector<ProfSpan> spans;
   double prof_ms[4] = {}; uint64_t prof_launches[4] = {}, prof_units[4] = {};
-  DevBloom view() const { DevBloom b; b.data = d_data; b.m = m; b.recip = bloom_recip(m); b.nh = nh; b.nbytes = g.nbytes; b.tbl1 = d_t1; b.tbl2 = d_t2; return b; }
+  DevBloom view() const { DevBloom b; b.data = d_data; b.m = m; b.recip = bloom_recip(m); b.nh = nh; b.kind = kind; b.pad_ = 0; b.nbytes = g.nbytes; b.tbl1 = d_t1; b.tbl2 = d_t2; return b; }
 };
 
 namespace {
@@ -51,7 +52,11 @@ extern "C" {
 uint64_t jfgpu_bc_opt_m(double fp, uint64_t n) { return n * (uint64_t)lrint(-log(fp) / 0.4804530139182014); }   // bloom_common.hpp:61-63
 uint32_t jfgpu_bc_opt_k(double fp) { return (uint32_t)lrint(-log(fp) / 0.6931471805599453); }                     // :64-66
 
-int jfgpu_bc_create(const jfgpu_bloom_params* p, jfgpu_bloom** out) {
+static int bloom_create(const jfgpu_bloom_params* p, jfgpu_bloom** out, uint32_t kind);
+int jfgpu_bc_create(const jfgpu_bloom_params* p, jfgpu_bloom** out) { return bloom_create(p, out, 0); }
+int jfgpu_bf_create(const jfgpu_bloom_params* p, jfgpu_bloom** out) { return bloom_create(p, out, 1); }
+
+static int bloom_create(const jfgpu_bloom_params* p, jfgpu_bloom** out, uint32_t kind) {
   if(!p || !out) return fail(JFGPU_E_INVALID, "null argument");
   *out = nullptr;
   if(p->k < 1) return fail(JFGPU_E_INVALID, "mer length must be >= 1");
@@ -64,7 +69,7 @@ int jfgpu_bc_create(const jfgpu_bloom_params* p, jfgpu_bloom** out) {
   if(dev >= ndev) return fail(JFGPU_E_NO_DEVICE, "device ordinal out of range");
   HIP_TRY(hipSetDevice(dev));
   std::unique_ptr<jfgpu_bloom> b(new jfgpu_bloom);
-  b->device = dev; b->m = p->m; b->nh = p->nb_hashes;
+  b->device = dev; b->m = p->m; b->nh = p->nb_hashes; b->kind = kind;
   if(p->k > 32) {
     b->wide = true;
     if(!wide_geom_init(b->wg, p->k, std::max<uint32_t>(kMaxTileBits, wide_min_lsize(p->k)), p->canonical ? 1 : 0)) return fail(JFGPU_E_INVALID, "bad mer length");
@@ -95,9 +100,10 @@ int jfgpu_bc_create(const jfgpu_bloom_params* p, jfgpu_bloom** out) {
   HIP_TRY(hipGetDeviceProperties(&prop, dev));
   b->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
-  b->data_bytes = b->m / 5 + (b->m % 5 != 0);                    // bloom_counter2.hpp:40-42
+  b->data_bytes = kind == 1 ? b->m / 8 + (b->m % 8 != 0)         // bloom_filter.hpp:25-27
+                            : b->m / 5 + (b->m % 5 != 0);        // bloom_counter2.hpp:40-42
   b->alloc_bytes = (b->data_bytes + 3) / 4 * 4 + 4;
-  bloom_part_init(b.get());
+  if(kind == 0) bloom_part_init(b.get());
   if(b->part_ok) b->alloc_bytes = ((size_t)b->bp.n_seg << kBloomSegBits) + 4;      // whole segments are loaded and stored
   if(const char* e = getenv("JFGPU_BLOOM_MODE")) {
     if(!strcmp(e, "direct")) b->mode = 1;
@@ -138,6 +144,7 @@ void jfgpu_bc_destroy(jfgpu_bloom* b) {
 
 int jfgpu_bc_insert_ascii_dev(jfgpu_bloom* b, const char* d_bases, size_t n) {
   int rc = use_b(b); if(rc) return rc;
+  if(b->kind != 0) return fail(JFGPU_E_INVALID, "a one-pass Bloom filter is fed by the count it is attached to");
   if(n < b->g.k) return JFGPU_OK;
   if(!d_bases) return fail(JFGPU_E_INVALID, "null buffer");
   const uint8_t* base; int64_t lo, hi;
@@ -212,6 +219,7 @@ int jfgpu_bc_load(jfgpu_bloom* b, const uint8_t* data) {   // bloom_counter2(m, 
 
 int jfgpu_bc_keys(jfgpu_bloom* b, const uint64_t* keys, size_t n, uint8_t* out, int do_insert) {
   int rc = use_b(b); if(rc) return rc;
+  if(b->kind != 0) return fail(JFGPU_E_UNSUPPORTED, "check / insert on encoded k-mers is built for Bloom counters only");
   rc = bloom_flush(b); if(rc) return rc;
   if(!n) return JFGPU_OK;
   uint64_t* d_k = nullptr; uint8_t* d_o = nullptr;
@@ -285,6 +293,7 @@ int jfgpu_attach_bloom(jfgpu_table* t, jfgpu_bloom* b) {   // count --bc (count_
   if(b->device != t->device) return fail(JFGPU_E_INVALID, "Bloom counter lives on another device");
   if(b->g.k != t->g.k) return fail(JFGPU_E_INVALID, "Invalid mer length in bloom filter");
   if(t->g.shard_bits) return fail(JFGPU_E_UNSUPPORTED, "count --bc on a sharded table is not built yet");
+  if(t->nword) return fail(JFGPU_E_UNSUPPORTED, "Bloom filters for mer length > 64 are not built");
   rc = bloom_flush(b); if(rc) return rc;
   HIP_TRY(hipStreamSynchronize(b->stream));
   if(t->wide) t->wt.bloom = b->view(); else t->dt.bloom = b->view();

@@ -107,6 +107,8 @@ int part_ingest(jfgpu_table* t, const uint8_t* base, int64_t lo, int64_t hi, boo
   if(t->pending.size() >= kMaxSeg) { int rc = part_flush(t); if(rc) return rc; }
   const uint32_t gcap = granule_cap(t, from_keys, max_items);
   if(t->item128 && (!gcap || from_keys)) return -1;       // two-word keys: single-pass P1 from sequence or the direct kernel
+  // a one-pass Bloom filter (count --bf-size) changes as it is asked: the two-pass P1 would ask it twice per k-mer
+  if(!gcap && !from_keys && (t->wide ? t->wt.bloom : t->dt.bloom).data && (t->wide ? t->wt.bloom : t->dt.bloom).kind == 1) return -1;
   const size_t bytes = gcap ? (size_t)nb * gcap * item_size(t) : max_items * item_size(t);
   const size_t need = align_up(bytes, 256) + align_up((2 * nb + 1) * sizeof(uint64_t), 256) + (gcap ? align_up(nb * 16, 256) : 0) + 1024;
   // 16-byte items: the arena may be smaller than what the whole input needs, so keep half of it for the flush's P2 output

@@ -43,6 +43,8 @@ struct DevBloom {
   uint64_t recip;             // floor(2^64 / m): x % m without a 64-bit divide (the reference's divisor64, divisor.hpp:64-109)
   uint32_t nh;                // hash functions per key
   uint32_t nbytes;            // key bytes fed to the tables
+  uint32_t kind;              // 0: Bloom counter, admit iff check() > 1 (count --bc); 1: one-pass Bloom filter, insert and admit iff
+  uint32_t pad_;              //    every bit was already set (count --bf-size, count_main.cc:121-131)
   const uint64_t* tbl1;       // byte tables of the two 64-row matrices
   const uint64_t* tbl2;
 };

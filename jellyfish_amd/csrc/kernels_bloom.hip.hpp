@@ -109,6 +109,23 @@ __device__ inline bool bloom_all_two(const DevBloom& B, uint64_t h0, uint64_t h1
   return true;
 }
 
+// count --bf-size (bloom_filter.hpp:44-68, filter_bf count_main.cc:121-131): set the nh bits of the key, admit it iff all of
+// them were set already -- the first sighting of a k-mer only marks it, later ones are counted.  One atomic OR per bit,
+// like the reference's __sync_fetch_and_or; concurrent first sightings of one k-mer can both come out "new" there and
+// here alike, which is why the reference only bounds the result statistically (tests/bloom_filter.sh).
+__device__ inline bool bloom_filter_insert(const DevBloom& B, uint64_t h0, uint64_t h1) {
+  const uint64_t base = bloom_mod(h0, B.m, B.recip), inc = bloom_mod(h1, B.m, B.recip);
+  uint64_t p = base;
+  bool present = true;
+  for(uint32_t i = 0; i < B.nh; ++i) {
+    const uint32_t bit = 1u << (uint32_t)(p & 31);
+    const uint32_t old = atomicOr(&B.data[p >> 5], bit);
+    present = present && (old & bit);
+    p += inc; if(p >= B.m) p -= B.m;
+  }
+  return present;
+}
+
 // The filter for the 16 windows of one lane: bit j of the result = the window ending at the lane's position j is valid
 // and check(m) > 1.  The cells are read in rounds: round r reads cell r of every window still undecided (all of a
 // lane's loads of a round are in flight together), a window drops out at its first cell below 2.  With one decision
@@ -158,6 +175,21 @@ __device__ inline uint32_t bloom_admit_half(const DevBloom& B, const TableGeom& 
 __device__ inline uint32_t bloom_admit_mask(const DevBloom& B, const TableGeom& g, const LaneWords& L) {
   uint64_t fw = (((uint64_t)L.p2 << 32) | L.p1) & g.key_mask;
   uint64_t rc = revcomp64(fw, g.k);
+  if(B.kind == 1) {                      // one-pass Bloom filter: every window inserts, in order
+    const uint64_t kwin = g.k >= 64 ? ~0ull : ((1ull << g.k) - 1);
+    const uint32_t rc_shift = 2 * (g.k - 1);
+    uint32_t adm = 0;
+#pragma unroll 1
+    for(int j = 0; j < kPerLane; ++j) {
+      const uint64_t c = (L.cur >> (2 * (15 - j))) & 3u;
+      fw = ((fw << 2) | c) & g.key_mask;
+      rc = (rc >> 2) | ((3ull - c) << rc_shift);
+      if(((L.inv48 >> (15 - j)) & kwin) != 0) continue;
+      const uint64_t key = (g.canonical && rc < fw) ? rc : fw;
+      if(bloom_filter_insert(B, hash_tables(B.tbl1, key, B.nbytes), hash_tables(B.tbl2, key, B.nbytes))) adm |= 1u << j;
+    }
+    return adm;
+  }
   const uint32_t lo = bloom_admit_half<0>(B, g, L, fw, rc);
   return lo | bloom_admit_half<kPerLane / 2>(B, g, L, fw, rc);
 }
@@ -165,6 +197,7 @@ __device__ inline uint32_t bloom_admit_mask(const DevBloom& B, const TableGeom& 
 // count --bc filter (count_main.cc:115-118); tables read through the caches (12-16 KiB hot set).
 __device__ inline bool bloom_admits(const DevBloom& B, uint64_t key) {
   const uint64_t h0 = hash_tables(B.tbl1, key, B.nbytes), h1 = hash_tables(B.tbl2, key, B.nbytes);
+  if(B.kind == 1) return bloom_filter_insert(B, h0, h1);
   return bloom_all_two(B, h0, h1);
 }
 

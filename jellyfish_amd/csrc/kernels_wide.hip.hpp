@@ -239,7 +239,8 @@ __device__ inline void for_each_kmer_wide(const WideGeom& W, const LaneWordsW& L
 // Bloom counter on two-word keys: h0 = M1 * key, h1 = M2 * key with 64 x 2k matrices (mer_dna_bloom_counter.hpp:19-34);
 // the byte tables (16 x 256 entries each) are read through the caches.
 __device__ inline bool bloom_admits_wide(const DevBloom& B, u128 key) {
-  return bloom_all_two(B, hash_tables_wide(B.tbl1, key, B.nbytes), hash_tables_wide(B.tbl2, key, B.nbytes));
+  const uint64_t h0 = hash_tables_wide(B.tbl1, key, B.nbytes), h1 = hash_tables_wide(B.tbl2, key, B.nbytes);
+  return B.kind == 1 ? bloom_filter_insert(B, h0, h1) : bloom_all_two(B, h0, h1);
 }
 
 __global__ __launch_bounds__(kBlock) void bloom_insert_ascii_wide_kernel(DevBloom B, WideGeom W, const uint8_t* __restrict__ base,

@@ -31,6 +31,8 @@
 #include <jellyfish/stream_manager.hpp>
 #include <jellyfish/mer_overlap_sequence_parser.hpp>
 #include <jellyfish/mer_iterator.hpp>
+#include <jellyfish/whole_sequence_parser.hpp>
+#include <jellyfish/mer_qual_iterator.hpp>
 #include <jellyfish/mapped_file.hpp>
 #include <jellyfish/mer_dna_bloom_counter.hpp>
 #include <jellyfish/jellyfish.hpp>
@@ -40,6 +42,9 @@ typedef std::vector<const char*>                                         file_ve
 typedef jellyfish::stream_manager<file_vector::const_iterator>           stream_manager_type;
 typedef jellyfish::mer_overlap_sequence_parser<stream_manager_type>      sequence_parser;
 typedef jellyfish::mer_iterator<sequence_parser, mer_dna>                mer_iterator_type;
+
+typedef jellyfish::whole_sequence_parser<stream_manager_type>            read_parser;
+typedef jellyfish::mer_qual_iterator<read_parser, mer_dna>               mer_qual_iterator_type;
 
 static double now_s() {
   using namespace std::chrono;
@@ -110,6 +115,24 @@ public:
   }
 };
 
+// count -Q / --min-quality: the quality-aware loop of count_main.cc:86-92,326-329 (whole_sequence_parser + mer_qual_iterator)
+class ref_qual_counter : public jellyfish::thread_exec {
+  mer_hash&   ary_;
+  read_parser parser_;
+  bool        canonical_;
+  char        min_qual_;
+public:
+  std::vector<size_t> counts_;
+  ref_qual_counter(int nb_threads, mer_hash& ary, stream_manager_type& streams, bool canonical, char min_qual)
+    : ary_(ary), parser_(4 * nb_threads, 100, streams.nb_streams(), streams), canonical_(canonical), min_qual_(min_qual), counts_(nb_threads, 0) { ary_.reset_done(); }
+  virtual void start(int thid) {
+    size_t count = 0;
+    for(mer_qual_iterator_type mers(parser_, min_qual_, canonical_); mers; ++mers) { ary_.add(*mers, 1); ++count; }
+    counts_[thid] = count;
+    ary_.done();
+  }
+};
+
 static uint64_t parse_size(const char* s) {  // yaggo "suffix": k/M/G/T = powers of 1000
   char* end;
   double v = strtod(s, &end);
@@ -129,6 +152,7 @@ static int do_count(int argc, char* argv[]) {
   const char* timing = 0;
   const char* bc_path = 0;
   const char* digest_path = 0;
+  int min_qual = 0;
   file_vector files, if_files;
   for(int i = 1; i < argc; ++i) {
     std::string a(argv[i]);
@@ -150,6 +174,7 @@ static int do_count(int argc, char* argv[]) {
     else if(a == "--timing") timing = next();
     else if(a == "--bc") bc_path = next();
     else if(a == "--digest") digest_path = next();
+    else if(a == "-Q") min_qual = next()[0];
     else files.push_back(argv[i]);
   }
   if(!k || !size || files.empty()) {
@@ -187,11 +212,17 @@ static int do_count(int argc, char* argv[]) {
   }
   stream_manager_type streams(Files);
   streams.paths(files.begin(), files.end());
-  ref_counter counter(threads, ary, streams, canonical, bc.get(), op);
-  counter.exec_join(threads);
-  double t2 = now_s();
   size_t total = 0;
-  for(size_t c : counter.counts_) total += c;
+  if(min_qual) {
+    ref_qual_counter counter(threads, ary, streams, canonical, (char)min_qual);
+    counter.exec_join(threads);
+    for(size_t c : counter.counts_) total += c;
+  } else {
+    ref_counter counter(threads, ary, streams, canonical, bc.get(), op);
+    counter.exec_join(threads);
+    for(size_t c : counter.counts_) total += c;
+  }
+  double t2 = now_s();
 
   if(digest_path) {     // before the dump: the sorted dumper zeroes the table behind itself
     ref_digester dg(ary.ary(), threads, lower_given ? lower : 0, upper_given ? upper : std::numeric_limits<uint64_t>::max());

@@ -444,3 +444,67 @@ def test_large_key_golden_k100(cli, tmp_path):
         assert subprocess.check_output([O.REF_JF, "dump", "--check-order", "m100_2M.jf"], cwd=d).decode().startswith("ORDER OK")
         ref = subprocess.run([O.REF_JF, "count", "-m", "100", "-s", "2M", "-t", "2", "--no-write", "--digest", "r.txt", "/dev/fd/0"], input=head, cwd=d, check=True)
         assert subprocess.check_output([cli, "digest", "m100_2M.jf"], cwd=d).decode() == open(os.path.join(d, "r.txt")).read()
+
+
+@pytest.mark.parametrize("flags", [["-Q", "5"], ["-Q", "P"], ["-Q", "Z"], ["-Q", "!"], ["--min-quality", "20"], ["-Q", "V", "--host-parse"]])
+def test_min_quality_equals_the_reference(cli, flags, tmp_path):
+    """count -Q / --min-quality (count_main.cc:234-256, mer_qual_iterator.hpp:75-84): bases whose quality character is below
+    the threshold break k-mers like an N.  jellyfish-amd (device FASTQ parser with the masking kernel; host reader with
+    --host-parse) against the reference driver running the reference's own whole_sequence_parser + mer_qual_iterator, on
+    the reference generator's FASTQ (qualities uniform over the printable range) and on a wrapped (multi-line) copy that
+    the device parser hands to the host reader; FASTA input is unaffected."""
+    if not O.have_ref():
+        pytest.skip("oracle/_ref not built")
+    fq = os.path.join(GOLD, "reads_fq_s1473540700.fq")
+    d = str(tmp_path)
+    # a wrapped copy: sequence and quality lines cut at 40 columns (legal FASTQ, not the strict 4-line layout)
+    lines = open(fq).read().splitlines()
+    wrapped = []
+    for i in range(0, len(lines) - 3, 4):
+        wrapped.append(lines[i])
+        wrapped += [lines[i + 1][j:j + 40] for j in range(0, len(lines[i + 1]), 40)]
+        wrapped.append(lines[i + 2])
+        wrapped += [lines[i + 3][j:j + 40] for j in range(0, len(lines[i + 3]), 40)]
+    open(os.path.join(d, "wrapped.fq"), "w").write("\n".join(wrapped) + "\n")
+    qchar = flags[1] if flags[0] == "-Q" else chr(64 + 20)       # --quality-start defaults to 64 (count_main_cmdline.yaggo)
+    for name, path in (("strict", fq), ("wrapped", os.path.join(d, "wrapped.fq"))):
+        subprocess.check_call([cli, "count", "-m", "4", "-C", "-s", "64k", "-o", name + ".jf"] + flags + [path], cwd=d)
+        subprocess.check_call([O.REF_JF, "count", "-m", "4", "-C", "-s", "64k", "-t", "2", "-o", name + ".ref.jf", "-Q", qchar, path], cwd=d)
+        mine = sorted(subprocess.check_output([cli, "dump", "-c", name + ".jf"], cwd=d).splitlines())
+        ref = sorted(subprocess.check_output([O.REF_JF, "dump", "-c", name + ".ref.jf"], cwd=d).splitlines())
+        assert mine == ref and len(ref) > 0, (name, flags)
+    subprocess.check_call([O.REF_JF, "count", "-m", "4", "-C", "-s", "64k", "-o", "all.ref.jf", fq], cwd=d)
+    unfiltered = sorted(subprocess.check_output([O.REF_JF, "dump", "-c", "all.ref.jf"], cwd=d).splitlines())
+    if qchar <= "B":
+        assert mine == unfiltered                               # the generator's qualities start at 'B': nothing is masked
+    else:
+        assert mine != unfiltered
+    fa = os.path.join(GOLD, "reads150_s42.fa")
+    subprocess.check_call([cli, "count", "-m", "21", "-C", "-s", "64k", "-o", "fa.jf"] + flags + [fa], cwd=d)
+    assert sorted(subprocess.check_output([cli, "dump", "-c", "fa.jf"], cwd=d).decode().splitlines()) == \
+        open(os.path.join(GOLD, "reads150_k21C.dump")).read().splitlines()
+
+
+def test_bf_size_one_pass_filter_bound(cli, tmp_path):
+    """tests/bloom_filter.sh:21-33 in small: files a b a c, `count --bf-size N --bf-fp 0.001`: the k-mers of a are seen twice
+    and counted once, everything else only marks the filter; the sum of the histogram is |a| within the script's 2 % bound.
+    (The reference's result is order- and thread-timing dependent too; the script only bounds it.)"""
+    import random
+    rng = random.Random(5)
+    d = str(tmp_path)
+    n = 100000
+    for name in "abc":
+        with open(os.path.join(d, name + ".fa"), "w") as fh:
+            fh.write(">%s\n" % name)
+            s = "".join(rng.choice("ACGT") for _ in range(n))
+            fh.write("\n".join(s[i:i + 70] for i in range(0, n, 70)) + "\n")
+    files = ["a.fa", "b.fa", "a.fa", "c.fa"]
+    subprocess.check_call([cli, "count", "--bf-size", "300k", "--bf-fp", "0.001", "-t", "2", "-o", "bf.jf", "-s", "1M", "-m", "40"] + files, cwd=d)
+    histo = subprocess.check_output([cli, "histo", "bf.jf"], cwd=d).decode().split()
+    total = sum(int(x) for x in histo[1::2])
+    expected = n - 39
+    assert 0 <= total - expected <= 0.02 * expected, (total, expected)
+    if O.have_ref():
+        assert subprocess.check_output([O.REF_JF, "histo", "bf.jf"], cwd=d).decode().split() == histo
+    r = subprocess.run([cli, "count", "--bf-size", "1M", "--bc", "x", "-m", "21", "-s", "1M", "a.fa"], cwd=d, capture_output=True)
+    assert r.returncode == 1 and b"conflict" in r.stderr

@@ -216,3 +216,43 @@ def test_count_bc_through_every_p1_variant(gpu, monkeypatch, k, single):
                 assert dict(zip(kk.tolist(), cc.tolist())) == exp, (k, single, mode)
                 assert t.stats().mers_fed == len(kmers)
                 t.attach_bloom(None)
+
+
+@pytest.mark.parametrize("k,mode", [(21, 1), (21, 2), (40, 1), (40, 2), (31, 2)])
+def test_one_pass_bloom_filter(gpu, monkeypatch, k, mode):
+    """count --bf-size (count_main.cc:121-131, bloom_filter.hpp:44-68): the first sighting of a k-mer only marks it in a
+    Bloom filter of bits, later sightings are counted.  With the second copy of the input fed in a later call the
+    semantics are exact up to false positives: every k-mer of the repeated part is counted once (twice if its first
+    sighting was a false positive), k-mers seen once are absent but for false positives -- the bound of the reference's
+    tests/bloom_filter.sh.  Direct kernel and single-pass partition (the two-pass P1 would ask the filter twice)."""
+    monkeypatch.setenv("JFGPU_P1_SINGLE", "1")
+    rng = random.Random(k * 7 + mode)
+    twice = "".join(rng.choice("ACGT") for _ in range(120000)).encode()
+    once = "".join(rng.choice("ACGT") for _ in range(60000)).encode()
+    kt, _ = O.count(twice, k, True)
+    ko, _ = O.count(once, k, True)
+    rep = {tuple(r) for r in kt.tolist()}
+    single = {tuple(r) for r in ko.tolist()} - rep
+    n = len(rep) + len(single)
+    with gpu.Bloom(k, gpu.opt_m(0.01, n), gpu.opt_k(0.01), canonical=True, one_pass_filter=True) as bf, \
+            gpu.Table(k, 1 << 25, canonical=True) as t:
+        assert bf.nb_bytes == (gpu.opt_m(0.01, n) + 7) // 8 and bf.nb_hashes == 7
+        t.set_mode(mode)
+        t.attach_bloom(bf)
+        t.count_ascii(twice + b"N" + once)
+        t.sync()                                               # first sightings are in the filter now
+        t.count_ascii(twice)
+        t.sync()
+        kk, cc = gpu.decode_records(t.dump_records(), k, 4)
+        got = {(tuple(r) if kk.ndim == 2 else (r,)): c for r, c in zip(kk.tolist(), cc.tolist())}
+        t.attach_bloom(None)
+    mult = {}
+    kt_all = O.extract(twice, k, True)
+    for r in kt_all.tolist():
+        mult[tuple(r)] = mult.get(tuple(r), 0) + 1
+    # every repeated k-mer is there: all its sightings of the second feed, plus those of the first feed that were false positives
+    assert all(mult[key] <= got.get(key, 0) <= 2 * mult[key] for key in rep)
+    extra = sum(got[key] - mult[key] for key in rep)
+    fp_single = sum(1 for key in single if key in got)
+    assert extra <= 0.03 * len(kt_all) and fp_single <= 0.03 * len(single)
+    assert set(got) <= rep | single
