@@ -22,6 +22,8 @@ struct jfgpu_comm {
 #endif
   hipStream_t xstream = nullptr;                 // exchange stream
   uint64_t max_msg_keys = (uint64_t)1 << 27;     // 1 GiB per peer per round (a 6.9 GB self-message was dropped by RCCL 2.26)
+  bool self_rccl = false;                        // JFGPU_COMM_SELF_RCCL=1: a rank's own share travels through ncclSend/ncclRecv as
+                                                 // well (default: a device copy) -- lets a single-GPU box exercise every RCCL call
   struct Rank {
     jfgpu_table* t = nullptr;
     uint64_t* send[2] = {nullptr, nullptr}; size_t send_cap[2] = {0, 0};
@@ -127,16 +129,24 @@ int comm_exchange_rccl(jfgpu_comm* c) {
 #else
   jfgpu_comm::Rank& R = c->ranks[0];
   const int cur = R.turn, W = c->world;
-  // counts: W words out, W words in
-  HIP_TRY(hipMemcpyAsync(R.d_xc, R.scount[cur].data(), sizeof(uint64_t) * W, hipMemcpyHostToDevice, c->xstream));
-  NCCL_TRY(ncclGroupStart());
-  for(int p = 0; p < W; ++p) {
-    NCCL_TRY(ncclSend(R.d_xc + p, 1, ncclUint64, p, c->nccl, c->xstream));
-    NCCL_TRY(ncclRecv(R.d_xc + W + p, 1, ncclUint64, p, c->nccl, c->xstream));
+  // counts: W words out, W words in (what a rank keeps for itself never leaves the device: plain copies below)
+  const bool via_rccl = W > 1 || c->self_rccl;
+  const int skip = c->self_rccl ? -1 : c->rank;          // the peer served by a plain device copy
+  R.rcount[cur][c->rank] = R.scount[cur][c->rank];
+  if(via_rccl) {
+    HIP_TRY(hipMemcpyAsync(R.d_xc, R.scount[cur].data(), sizeof(uint64_t) * W, hipMemcpyHostToDevice, c->xstream));
+    NCCL_TRY(ncclGroupStart());
+    for(int p = 0; p < W; ++p) {
+      if(p == skip) continue;
+      NCCL_TRY(ncclSend(R.d_xc + p, 1, ncclUint64, p, c->nccl, c->xstream));
+      NCCL_TRY(ncclRecv(R.d_xc + W + p, 1, ncclUint64, p, c->nccl, c->xstream));
+    }
+    NCCL_TRY(ncclGroupEnd());
+    std::vector<uint64_t> got(W);
+    HIP_TRY(hipMemcpyAsync(got.data(), R.d_xc + W, sizeof(uint64_t) * W, hipMemcpyDeviceToHost, c->xstream));
+    HIP_TRY(hipStreamSynchronize(c->xstream));
+    for(int p = 0; p < W; ++p) if(p != skip) R.rcount[cur][p] = got[p];
   }
-  NCCL_TRY(ncclGroupEnd());
-  HIP_TRY(hipMemcpyAsync(R.rcount[cur].data(), R.d_xc + W, sizeof(uint64_t) * W, hipMemcpyDeviceToHost, c->xstream));
-  HIP_TRY(hipStreamSynchronize(c->xstream));
   uint64_t total = 0, gmax = 0;
   for(int p = 0; p < W; ++p) { R.roff[cur][p] = total; total += R.rcount[cur][p]; gmax = std::max(gmax, std::max(R.rcount[cur][p], R.scount[cur][p])); }
   R.roff[cur][W] = total;
@@ -144,23 +154,31 @@ int comm_exchange_rccl(jfgpu_comm* c) {
   int rc = comm_reserve(R.recv[cur], R.recv_cap[cur], total, R.t->stream, c->xstream); if(rc) return rc;
   HIP_TRY(hipEventRecord(R.routed[cur], R.t->stream));
   HIP_TRY(hipStreamWaitEvent(c->xstream, R.routed[cur], 0));
-  // every rank runs the same number of rounds: the largest message of the whole job decides
-  unsigned long long lmax = gmax, *d_m = (unsigned long long*)R.d_xc;
-  HIP_TRY(hipMemcpyAsync(d_m, &lmax, sizeof lmax, hipMemcpyHostToDevice, c->xstream));
-  NCCL_TRY(ncclAllReduce(d_m, d_m, 1, ncclUint64, ncclMax, c->nccl, c->xstream));
-  HIP_TRY(hipMemcpyAsync(&lmax, d_m, sizeof lmax, hipMemcpyDeviceToHost, c->xstream));
-  HIP_TRY(hipStreamSynchronize(c->xstream));
-  const uint64_t rounds = std::max<uint64_t>(1, (lmax + c->max_msg_keys - 1) / c->max_msg_keys);
-  for(uint64_t r = 0; r < rounds; ++r) {
-    const uint64_t lo = r * c->max_msg_keys;
-    NCCL_TRY(ncclGroupStart());
-    for(int p = 0; p < W; ++p) {
-      const uint64_t sc = R.scount[cur][p] > lo ? std::min(R.scount[cur][p] - lo, c->max_msg_keys) : 0;
-      const uint64_t rcn = R.rcount[cur][p] > lo ? std::min(R.rcount[cur][p] - lo, c->max_msg_keys) : 0;
-      if(sc) NCCL_TRY(ncclSend(R.send[cur] + R.soff[cur][p] + lo, sc, ncclUint64, p, c->nccl, c->xstream));
-      if(rcn) NCCL_TRY(ncclRecv(R.recv[cur] + R.roff[cur][p] + lo, rcn, ncclUint64, p, c->nccl, c->xstream));
+  // this rank's own share: a device copy (1/W of the keys; everything, for a world of one)
+  if(skip >= 0 && R.scount[cur][c->rank])
+    HIP_TRY(hipMemcpyAsync(R.recv[cur] + R.roff[cur][c->rank], R.send[cur] + R.soff[cur][c->rank], R.scount[cur][c->rank] * sizeof(uint64_t),
+                           hipMemcpyDeviceToDevice, c->xstream));
+  if(via_rccl) {
+    // every rank runs the same number of rounds: the largest peer-to-peer message of this step decides
+    unsigned long long lmax = 0, *d_m = (unsigned long long*)R.d_xc;
+    for(int p = 0; p < W; ++p) if(p != skip) lmax = std::max<unsigned long long>(lmax, std::max(R.rcount[cur][p], R.scount[cur][p]));
+    HIP_TRY(hipMemcpyAsync(d_m, &lmax, sizeof lmax, hipMemcpyHostToDevice, c->xstream));
+    NCCL_TRY(ncclAllReduce(d_m, d_m, 1, ncclUint64, ncclMax, c->nccl, c->xstream));
+    HIP_TRY(hipMemcpyAsync(&lmax, d_m, sizeof lmax, hipMemcpyDeviceToHost, c->xstream));
+    HIP_TRY(hipStreamSynchronize(c->xstream));
+    const uint64_t rounds = std::max<uint64_t>(1, (lmax + c->max_msg_keys - 1) / c->max_msg_keys);
+    for(uint64_t r = 0; r < rounds; ++r) {
+      const uint64_t lo = r * c->max_msg_keys;
+      NCCL_TRY(ncclGroupStart());
+      for(int p = 0; p < W; ++p) {
+        if(p == skip) continue;
+        const uint64_t sc = R.scount[cur][p] > lo ? std::min(R.scount[cur][p] - lo, c->max_msg_keys) : 0;
+        const uint64_t rcn = R.rcount[cur][p] > lo ? std::min(R.rcount[cur][p] - lo, c->max_msg_keys) : 0;
+        if(sc) NCCL_TRY(ncclSend(R.send[cur] + R.soff[cur][p] + lo, sc, ncclUint64, p, c->nccl, c->xstream));
+        if(rcn) NCCL_TRY(ncclRecv(R.recv[cur] + R.roff[cur][p] + lo, rcn, ncclUint64, p, c->nccl, c->xstream));
+      }
+      NCCL_TRY(ncclGroupEnd());
     }
-    NCCL_TRY(ncclGroupEnd());
   }
   HIP_TRY(hipEventRecord(R.exchanged[cur], c->xstream));
   R.used[cur] = true;
@@ -255,6 +273,7 @@ int jfgpu_comm_create(int world, int rank, const uint8_t* id128, int device, jfg
   c->ranks.resize(1);
   int rc = comm_init_rank(c.get(), c->ranks[0]); if(rc) return rc;
   if(const char* e = getenv("JFGPU_COMM_MAX_MSG")) c->max_msg_keys = std::max<uint64_t>(1, strtoull(e, 0, 10));
+  if(const char* e = getenv("JFGPU_COMM_SELF_RCCL")) c->self_rccl = atoi(e) != 0;
   *out = c.release();
   return JFGPU_OK;
 #endif

@@ -9,6 +9,8 @@
 // and the "Invalid fastq sequence" error behave as in the reference (:292-309).
 #pragma once
 #include <jfgpu.h>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <future>
 #include <thread>
@@ -45,6 +47,15 @@ public:
   }
   size_t host_fallback_bytes() const { return fallback_bytes_; }
   double device_ms() const { return device_ms_; }
+
+  // Allocate the pinned staging buffers now if a file of this size will take the pinned path (an Init-phase cost).
+  void prepare(size_t largest_file_bytes) {
+    const bool pinned = pinned_ < 0 ? largest_file_bytes >= ((size_t)64 << 20) : pinned_ != 0;
+    if(!pinned) return;
+    const size_t cap = chunk_ + (chunk_ >> 2);
+    for(int w = 0; w < 2; ++w)
+      if(jfgpu_parser_host_buffer(p_, w, cap, &pin_[w])) throw std::runtime_error(jfgpu_last_error());
+  }
 
   void parse_file(const char* path, const dev_sink_type& dev_sink, const host_sink_type& host_sink, const fence_type& fence) {
     int fd = open(path, O_RDONLY);
@@ -145,9 +156,16 @@ private:
   // at ~2-3 GB/s; a pageable copy of the mapping measured 2.9 GB/s end to end on a 10 GB file, profiles/r02_*).
   void parse_fd_pinned(int fd, size_t n, const dev_sink_type& dev_sink, const host_sink_type& host_sink, const fence_type& fence) {
     ++files_read_;
+    // JFGPU_FEED_TRACE=1: where the wall time of the feed goes (stderr), for tools/cli_feed_bench.py
+    const bool trace = getenv("JFGPU_FEED_TRACE") != nullptr;
+    typedef std::chrono::steady_clock clk;
+    double t_alloc = 0, t_fill0 = 0, t_fence = 0, t_parse = 0, t_sink = 0, t_wait_fill = 0, t_bg_fill = 0;
+    auto since = [](clk::time_point a) { return std::chrono::duration<double>(clk::now() - a).count(); };
+    auto ta = clk::now();
     const size_t cap = chunk_ + (chunk_ >> 2);
     for(int w = 0; w < 2; ++w)
       if(jfgpu_parser_host_buffer(p_, w, cap, &pin_[w])) throw std::runtime_error(jfgpu_last_error());
+    t_alloc = since(ta);
     size_t pos = 0;                 // file offset of the first byte not yet read
     size_t have[2] = {0, 0};        // valid bytes in each buffer
     auto fill = [&](int w, size_t carried) -> bool {      // append fresh bytes behind `carried`
@@ -156,7 +174,9 @@ private:
       pos += want; have[w] = carried + want;
       return true;
     };
+    ta = clk::now();
     if(!fill(0, 0)) throw std::runtime_error("Error reading the sequence file");
+    t_fill0 = since(ta);
     unsigned fmt;
     if(pin_[0][0] == '>') fmt = JFGPU_PARSE_FASTA;
     else if(pin_[0][0] == '@') fmt = JFGPU_PARSE_FASTQ;
@@ -188,15 +208,22 @@ private:
       if(more) {
         const int o = w ^ 1;
         next_ready = std::async(std::launch::async, [&, o, tail, cut, buf]() {
+          const auto tb = clk::now();
           memcpy(pin_[o], buf + cut, tail);       // pin_[o]'s own upload finished before its parse returned (previous turn)
-          return fill(o, tail);
+          const bool ok = fill(o, tail);
+          t_bg_fill += since(tb);
+          return ok;
         });
       }
       // (the upload of this buffer was enqueued before the background task started: see below)
+      ta = clk::now();
       fence();
+      t_fence += since(ta); ta = clk::now();
       const char* d_out = nullptr; size_t n_out = 0; uint64_t recs = 0;
       const int rc = jfgpu_parser_parse_uploaded(p_, w, fmt | (first ? 0u : JFGPU_PARSE_CONTINUE), &d_out, &n_out, &recs);
+      t_parse += since(ta); ta = clk::now();
       if(next_ready.valid() && !next_ready.get()) throw std::runtime_error("Error reading the sequence file");
+      t_wait_fill += since(ta);
       if(rc == JFGPU_E_FORMAT) {
         void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
         if(m == MAP_FAILED) throw std::runtime_error("Can't mmap file");
@@ -208,9 +235,16 @@ private:
       if(rc) throw std::runtime_error(jfgpu_last_error());
       double ms = 0; jfgpu_parser_last_ms(p_, &ms); device_ms_ += ms;
       reads_read_ += recs;
+      ta = clk::now();
       if(n_out) dev_sink(d_out, n_out);
+      t_sink += since(ta);
       consumed += cut; first = false;
-      if(!more) break;                        // that was the last buffer and nothing is left over
+      if(!more) {                             // that was the last buffer and nothing is left over
+        if(trace) fprintf(stderr, "[feed] %.2f GB: pinned buffers %.3f s, first fill %.3f, fence %.3f, upload+parse %.3f, wait for next fill %.3f "
+                                  "(background fills %.3f, %u threads), sink %.3f\n", n / 1e9, t_alloc, t_fill0, t_fence, t_parse, t_wait_fill, t_bg_fill,
+                          copy_threads_, t_sink);
+        break;
+      }
     }
   }
 

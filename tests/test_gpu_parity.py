@@ -342,10 +342,14 @@ def test_comm_local_transport_equals_single_table(gpu, monkeypatch, world, max_m
             t.close()
 
 
-def test_comm_rccl_transport_world_one(gpu, monkeypatch):
-    """The RCCL transport of the same exchange with a world of one rank (what a single-GPU box can run): ncclSend / ncclRecv
-    to self inside one group per round, rounds of 4096 keys, the one-step pipeline; the table equals a plain count."""
+@pytest.mark.parametrize("self_rccl", ["1", "0"])
+def test_comm_rccl_transport_world_one(gpu, monkeypatch, self_rccl):
+    """The RCCL transport of the same exchange with a world of one rank (what a single-GPU box can run).  With
+    JFGPU_COMM_SELF_RCCL=1 the rank's own share goes through every RCCL call an N > 1 run makes -- counts exchange,
+    max-reduce of the round count, ncclSend / ncclRecv inside one group per round of 4096 keys; by default it is a device
+    copy.  The one-step pipeline either way; the table equals a plain count."""
     monkeypatch.setenv("JFGPU_COMM_MAX_MSG", "4096")
+    monkeypatch.setenv("JFGPU_COMM_SELF_RCCL", self_rccl)
     rng = random.Random(77)
     k = 21
     steps = [rnd_seq(rng, n, "ACGTN") for n in (60000, 0, 30, 90000, 20000)]
