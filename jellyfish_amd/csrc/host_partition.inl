@@ -158,7 +158,9 @@ int part_ingest(jfgpu_table* t, const uint8_t* base, int64_t lo, int64_t hi, boo
 #define PG(RT, BL, N) hipLaunchKernelGGL((p1_scatter_granule_kernel<RT, BL, N>), dim3(t->g1), dim3(kPBlock), lds, t->stream, t->dt, t->pg, base, lo, hi, gcap, gcur, b.tot, (uint32_t*)b.items)
     {
       if(bl) { if(t->returning) PG(true, true, 0); else PG(false, true, 0); }
-      else if(t->returning) PG(true, false, 0);
+      else if(t->returning) {       // narrow count fields (32-bit slots among them): same kernels, overflow-aware direct inserts
+        if(t->g.nbytes == 6) PG(true, false, 6); else if(t->g.nbytes == 7) PG(true, false, 7); else if(t->g.nbytes == 8) PG(true, false, 8); else PG(true, false, 0);
+      }
       else if(t->g.nbytes == 6) PG(false, false, 6);
       else if(t->g.nbytes == 7) PG(false, false, 7);
       else if(t->g.nbytes == 8) PG(false, false, 8);
@@ -235,7 +237,7 @@ int part_flush_t(jfgpu_table* t) {
   S1.n = (uint32_t)nbatch;
   for(size_t s = 0; s < nbatch; ++s) { S1.items[s] = t->pending[s].items; S1.off[s] = t->pending[s].off; S1.sh[s] = t->pending[s].gran_cap ? 1 : 0; }
   constexpr bool kWideItems = sizeof(ITEM) == 16;         // two-word keys: 128-bit items, 128-bit slots
-  const size_t tile_lds = (size_t)(kWideItems ? 16 : 8) << t->g.tile_bits;
+  const size_t tile_lds = (size_t)(kWideItems ? 16 : t->g.slot32 ? 4 : 8) << t->g.tile_bits;
   // always LOAD-capable: a tile is read only if its dirty byte is set (clean after jfgpu_clear)
   const bool rt = t->returning, load = true;
   // the tile insert of one item array (or of the pending batches themselves), on stream `ts`
@@ -247,7 +249,20 @@ int part_flush_t(jfgpu_table* t) {
       else   hipLaunchKernelGGL(tile_insert_wide_kernel<false>, grid, block, tile_lds, ts, t->wt, S, tile0, ntile);
     } else {
       const dim3 grid((unsigned)std::min<uint64_t>(ntile, (uint64_t)t->n_cu * 16));
-#define TI(RT, LD) hipLaunchKernelGGL((tile_insert_kernel<ITEM, RT, LD>), grid, block, tile_lds, ts, t->dt, S, tile0, ntile)
+      if constexpr(sizeof(ITEM) == 4) {
+        if(t->g.slot32) {           // 32 KiB tiles: four workgroups of 512 per CU
+          const dim3 b512(512);
+          if(rt) hipLaunchKernelGGL((tile_insert_kernel<ITEM, true, true, unsigned int, 512>), grid, b512, tile_lds, ts, t->dt, S, tile0, ntile);
+          else   hipLaunchKernelGGL((tile_insert_kernel<ITEM, false, true, unsigned int, 512>), grid, b512, tile_lds, ts, t->dt, S, tile0, ntile);
+          return;
+        }
+      }
+      if(t->g.slot32) {             // (64-bit items into 32-bit slots: small k in a huge table; same kernel, 1024 threads)
+        if(rt) hipLaunchKernelGGL((tile_insert_kernel<ITEM, true, true, unsigned int, kPBlock>), grid, block, tile_lds, ts, t->dt, S, tile0, ntile);
+        else   hipLaunchKernelGGL((tile_insert_kernel<ITEM, false, true, unsigned int, kPBlock>), grid, block, tile_lds, ts, t->dt, S, tile0, ntile);
+        return;
+      }
+#define TI(RT, LD) hipLaunchKernelGGL((tile_insert_kernel<ITEM, RT, LD, unsigned long long, kPBlock>), grid, block, tile_lds, ts, t->dt, S, tile0, ntile)
       if(rt) { if(load) TI(true, true); else TI(true, false); } else { if(load) TI(false, true); else TI(false, false); }
 #undef TI
     }

@@ -135,6 +135,8 @@ int use(const jfgpu_table* t) {
   return JFGPU_OK;
 }
 
+bool allow_slot32() { const char* e = getenv("JFGPU_SLOT64"); return !(e && atoi(e)); }     // JFGPU_SLOT64=1: never use 32-bit slots (A/B)
+size_t slot_bytes_of(const jfgpu_table* t) { return t->g.slot32 ? 4 : 8 * (size_t)t->slot_words; }
 uint64_t n_tiles_of(const jfgpu_table* t) { return 1ull << (t->g.lsize_l - t->g.tile_bits); }
 
 int grid_for(const jfgpu_table* t, uint64_t work_items) {
@@ -373,9 +375,9 @@ int table_grow(jfgpu_table* t) {
   NGeom ng2;
   if(t->nword) { if(!nword_geom_init(ng2, t->g.k, r + 1, t->g.canonical)) return -1; g2 = ng2.g; }
   else if(t->wide) { if(!wide_geom_init(w2, t->g.k, r + 1, t->g.canonical)) return -1; g2 = w2.g; }
-  else if(!geom_init(g2, t->g.k, r + 1, 0, 0, t->g.canonical)) return -1;
+  else if(!geom_init(g2, t->g.k, r + 1, 0, 0, t->g.canonical, allow_slot32())) return -1;
   const uint64_t n2 = 1ull << g2.lsize_l;
-  const size_t slot_bytes = 8 * (size_t)t->slot_words;
+  const size_t slot_bytes = g2.slot32 ? 4 : 8 * (size_t)t->slot_words;
   uint64_t cap2 = std::max<uint64_t>(1ull << 12, std::min<uint64_t>(n2 / 256, 1ull << 26));
   { uint64_t x = 1; while(x < cap2) x <<= 1; cap2 = x; }
   DevTable nd = t->dt;
@@ -510,7 +512,7 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
   } else if(wide) {
     if(!wide_geom_init(t->wt.W, p->k, lsize, p->canonical ? 1 : 0)) return fail(JFGPU_E_INVALID, "table geometry does not fit a 128-bit slot");
     t->g = t->wt.W.g;
-  } else if(!geom_init(t->g, p->k, lsize, p->shard_bits, p->shard_id, p->canonical ? 1 : 0))
+  } else if(!geom_init(t->g, p->k, lsize, p->shard_bits, p->shard_id, p->canonical ? 1 : 0, allow_slot32()))
     return fail(JFGPU_E_INVALID, "table geometry does not fit a 64-bit slot");
 
   // hash matrix (large_hash_array.hpp:992-1001)
@@ -544,7 +546,7 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
 
   DevTable& d = t->dt;
   d.g = t->g;
-  HIP_TRY(hipMalloc((void**)&d.slots, n_slots * sizeof(uint64_t) * t->slot_words));
+  HIP_TRY(hipMalloc((void**)&d.slots, n_slots * slot_bytes_of(t.get())));
   HIP_TRY(hipMalloc((void**)&t->d_fwd, fwd.size() * sizeof(uint64_t)));
   HIP_TRY(hipMalloc((void**)&t->d_inv, inv.size() * sizeof(uint64_t)));
   HIP_TRY(hipMalloc((void**)&d.ovf_key, t->ovf_cap * sizeof(uint64_t)));
@@ -585,10 +587,11 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
   if(const char* m = getenv("JFGPU_FLUSH_GROUPS")) t->flush_groups = std::max(1, atoi(m));
   {
     const int tl = (int)((size_t)8 << t->g.tile_bits);
-#define TATTR(I, R, L) HIP_TRY(hipFuncSetAttribute((const void*)tile_insert_kernel<I, R, L>, hipFuncAttributeMaxDynamicSharedMemorySize, tl))
+#define TATTR(I, R, L) HIP_TRY(hipFuncSetAttribute((const void*)tile_insert_kernel<I, R, L, unsigned long long, kPBlock>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 << kMaxTileBits))
     TATTR(uint32_t, true, true); TATTR(uint32_t, true, false); TATTR(uint32_t, false, true); TATTR(uint32_t, false, false);
     TATTR(uint64_t, true, true); TATTR(uint64_t, true, false); TATTR(uint64_t, false, true); TATTR(uint64_t, false, false);
 #undef TATTR
+    (void)tl;
     HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_sorted_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_sorted_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_sorted_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
@@ -604,6 +607,9 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     HIP_TRY(hipFuncSetAttribute((const void*)p1_keys_granule_kernel<false, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_keys_granule_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_granule_kernel<true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_granule_kernel<true, false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_granule_kernel<true, false, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_granule_kernel<true, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_granule_kernel<false, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_granule_kernel<true, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint32_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * 16 * 4));
@@ -659,11 +665,11 @@ int jfgpu_get_info(const jfgpu_table* t, jfgpu_info* o) {
   o->k = t->g.k; o->key_len = t->g.key_bits; o->canonical = t->g.canonical;
   o->lsize = t->g.lsize_g; o->size = 1ull << t->g.lsize_g; o->local_size = 1ull << t->g.lsize_l;
   o->shard_bits = t->g.shard_bits; o->shard_id = t->g.shard_id;
-  o->val_len = t->g.cnt_bits; o->slot_bytes = 8 * t->slot_words; o->tile_slots = 1u << t->g.tile_bits;
+  o->val_len = t->g.cnt_bits; o->slot_bytes = (uint32_t)slot_bytes_of(t); o->tile_slots = 1u << t->g.tile_bits;
   o->matrix_identity = t->matrix.identity ? 1 : 0;
   o->out_counter_len = t->out_counter_len;
   o->max_reprobe = t->dt.max_probe;
-  o->table_bytes = (1ull << t->g.lsize_l) * 8 * t->slot_words;
+  o->table_bytes = (1ull << t->g.lsize_l) * slot_bytes_of(t);
   return JFGPU_OK;
 }
 
@@ -676,7 +682,7 @@ int jfgpu_get_matrix(const jfgpu_table* t, uint64_t* columns) {
 int jfgpu_clear(jfgpu_table* t) {
   int rc = use(t); if(rc) return rc;
   part_discard(t);
-  HIP_TRY(hipMemsetAsync(t->dt.slots, 0, (1ull << t->g.lsize_l) * sizeof(uint64_t) * t->slot_words, t->stream));
+  HIP_TRY(hipMemsetAsync(t->dt.slots, 0, (1ull << t->g.lsize_l) * slot_bytes_of(t), t->stream));
   HIP_TRY(hipMemsetAsync(t->dt.ovf_key, 0, t->ovf_cap * sizeof(uint64_t), t->stream));
   HIP_TRY(hipMemsetAsync(t->dt.ovf_cnt, 0, t->ovf_cap * sizeof(uint64_t), t->stream));
   HIP_TRY(hipMemsetAsync(t->dt.counters, 0, CTR_COUNT * sizeof(uint64_t), t->stream));
@@ -1090,7 +1096,9 @@ int jfgpu_table_bytes(uint32_t k, uint64_t size, uint64_t* slots, uint64_t* byte
   uint64_t ovf = std::max<uint64_t>(1ull << 12, std::min<uint64_t>(n / 256, 1ull << 26));
   { uint64_t c = 1; while(c < ovf) c <<= 1; ovf = c; }
   if(slots) *slots = n;
-  if(bytes) *bytes = n * (nword ? 32 : wide ? 16 : 8) + ovf * 16 + (n >> std::min<uint32_t>(lsize, kMaxTileBits)) + (size_t)(2 * k + 7) / 8 * 256 * 8 * 2;
+  TableGeom gg;
+  const bool s32 = !nword && !wide && geom_init(gg, k, lsize, 0, 0, 1, allow_slot32()) && gg.slot32;
+  if(bytes) *bytes = n * (nword ? 32 : wide ? 16 : s32 ? 4 : 8) + ovf * 16 + (n >> std::min<uint32_t>(lsize, kMaxTileBits)) + (size_t)(2 * k + 7) / 8 * 256 * 8 * 2;
   return JFGPU_OK;
 }
 
@@ -1186,7 +1194,7 @@ int jfgpu_gups(jfgpu_table* t, uint64_t n_updates, int mode, double* ups) {
   HIP_TRY(hipMemsetAsync(d_sink, 0, sizeof(unsigned long long), t->stream));
   hipEvent_t a, b;
   HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
-  const uint64_t mask = (1ull << t->g.lsize_l) - 1;
+  const uint64_t mask = (((1ull << t->g.lsize_l) * slot_bytes_of(t)) >> 3) - 1;    // 64-bit words of the table's allocation
   t->pristine = false;
   HIP_TRY(hipMemsetAsync(t->dt.dirty, 1, (size_t)1 << (t->g.lsize_l - t->g.tile_bits), t->stream));
   const int grid = grid_for(t, (n_updates + kBlock - 1) / kBlock);

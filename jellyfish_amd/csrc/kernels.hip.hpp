@@ -114,6 +114,29 @@ __device__ inline uint64_t full_count(const DevTable& T, uint64_t word, uint64_t
   return c;
 }
 
+// ---- slot access ------------------------------------------------------------------
+// 64-bit slots, or 32-bit slots holding the same [count | occ | tag] fields (TableGeom::slot32).  The branch is
+// uniform over the whole grid (a scalar branch); slot words travel as uint64_t either way.
+__device__ __forceinline__ uint64_t slot_ld(const DevTable& T, uint64_t i) {
+  return T.g.slot32 ? (uint64_t)reinterpret_cast<const uint32_t*>(T.slots)[i] : T.slots[i];
+}
+__device__ __forceinline__ uint64_t slot_ld_relaxed(const DevTable& T, uint64_t i) {
+  if(T.g.slot32) return __hip_atomic_load(reinterpret_cast<const uint32_t*>(T.slots) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __hip_atomic_load(&T.slots[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t slot_cas(const DevTable& T, uint64_t i, uint64_t cmp, uint64_t val) {
+  if(T.g.slot32) return atomicCAS(reinterpret_cast<unsigned int*>(T.slots) + i, (unsigned int)cmp, (unsigned int)val);
+  return atomicCAS((unsigned long long*)&T.slots[i], (unsigned long long)cmp, (unsigned long long)val);
+}
+__device__ __forceinline__ uint64_t slot_add_rtn(const DevTable& T, uint64_t i, uint64_t add) {
+  if(T.g.slot32) return atomicAdd(reinterpret_cast<unsigned int*>(T.slots) + i, (unsigned int)add);
+  return atomicAdd((unsigned long long*)&T.slots[i], (unsigned long long)add);
+}
+__device__ __forceinline__ void slot_add(const DevTable& T, uint64_t i, uint64_t add) {
+  if(T.g.slot32) __hip_atomic_fetch_add(reinterpret_cast<unsigned int*>(T.slots) + i, (unsigned int)add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else __hip_atomic_fetch_add((unsigned long long*)&T.slots[i], (unsigned long long)add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- insert / increment -------------------------------------------------------
 // large_hash_array.hpp:509-597 (claim_key) + :741-752 (add_val), restated for a
 // 64-bit [count|occ|tag] slot: CAS the whole word from 0 to claim, atomicAdd on
@@ -137,15 +160,14 @@ __device__ inline bool table_add(const DevTable& T, const uint64_t* fwd_lds, uin
   const uint32_t tmask = (uint32_t)g.tile_mask;
   for(uint32_t p = 0; p <= T.max_probe; ++p) {
     const uint64_t slot = a.tile_base + probe_slot(a.idx0, p, tmask);
-    unsigned long long* addr = (unsigned long long*)&T.slots[slot];
-    const unsigned long long old = atomicCAS(addr, 0ull, (unsigned long long)neww);
+    const uint64_t old = slot_cas(T, slot, 0, neww);
     if(old == 0ull) return true;
     if((old & g.low_mask) == low) {
       if(RETURNING) {
-        const unsigned long long prev = atomicAdd(addr, (unsigned long long)add);
+        const uint64_t prev = slot_add_rtn(T, slot, add);
         if((prev >> (g.tag_bits + 1)) + cnt > g.cnt_max) ovf_add(T, slot, 1);
       } else {
-        __hip_atomic_fetch_add(addr, (unsigned long long)add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        slot_add(T, slot, add);
       }
       return false;
     }
@@ -168,15 +190,14 @@ __device__ inline bool table_update_add(const DevTable& T, const uint64_t* fwd_l
   const uint32_t tmask = (uint32_t)g.tile_mask;
   for(uint32_t p = 0; p <= T.max_probe; ++p) {
     const uint64_t slot = a.tile_base + probe_slot(a.idx0, p, tmask);
-    unsigned long long* addr = (unsigned long long*)&T.slots[slot];
-    const unsigned long long old = __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t old = slot_ld_relaxed(T, slot);
     if(old == 0ull) return false;
     if((old & g.low_mask) == low) {
       if(RETURNING) {
-        const unsigned long long prev = atomicAdd(addr, (unsigned long long)add);
+        const uint64_t prev = slot_add_rtn(T, slot, add);
         if((prev >> (g.tag_bits + 1)) + cnt > g.cnt_max) ovf_add(T, slot, 1);
       } else {
-        __hip_atomic_fetch_add(addr, (unsigned long long)add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        slot_add(T, slot, add);
       }
       return true;
     }
@@ -203,14 +224,13 @@ __device__ inline bool table_add_val(const DevTable& T, const uint64_t* fwd_lds,
   const uint32_t tmask = (uint32_t)g.tile_mask;
   for(uint32_t p = 0; p <= T.max_probe; ++p) {
     const uint64_t slot = a.tile_base + probe_slot(a.idx0, p, tmask);
-    unsigned long long* addr = (unsigned long long*)&T.slots[slot];
-    const unsigned long long old = atomicCAS(addr, 0ull, (unsigned long long)(add | low));
+    const uint64_t old = slot_cas(T, slot, 0, add | low);
     bool mine = false, is_new = false;
     if(old == 0ull) { mine = true; is_new = true; }
     else if((old & g.low_mask) == low) {
       mine = true;
       if(add) {
-        const unsigned long long prev = atomicAdd(addr, (unsigned long long)add);
+        const uint64_t prev = slot_add_rtn(T, slot, add);
         if((prev >> (g.tag_bits + 1)) + lowpart > g.cnt_max) ovf_add(T, slot, 1);
       }
     }
@@ -375,7 +395,7 @@ __global__ __launch_bounds__(kBlock) void lookup_kernel(DevTable T, const uint64
       const uint64_t low = g.occ_bit | make_tag(g, key, a.idx0);
       for(uint32_t p = 0; p <= T.max_probe; ++p) {
         const uint64_t slot = a.tile_base + probe_slot(a.idx0, p, tmask);
-        const uint64_t w = T.slots[slot];
+        const uint64_t w = slot_ld(T, slot);
         if(w == 0) break;
         if((w & g.low_mask) == low) { val = full_count(T, w, slot, have_ovf); fnd = 1; break; }
       }
@@ -455,7 +475,7 @@ __global__ __launch_bounds__(kBlock) void partition_scatter_kernel(DevTable T, c
 __global__ __launch_bounds__(kBlock) void rehash_kernel(DevTable old, DevTable neu, int have_ovf) {
   const uint64_t n = 1ull << old.g.lsize_l;
   for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-    const uint64_t w = old.slots[i];
+    const uint64_t w = slot_ld(old, i);
     if(!w) continue;
     const uint64_t key = slot_key(old.g, old.inv_tbl, w, i & ~old.g.tile_mask);
     table_add_val(neu, neu.fwd_tbl, key, full_count(old, w, i, have_ovf));
@@ -469,7 +489,7 @@ __global__ __launch_bounds__(kBlock) void stats_kernel(DevTable T, uint64_t lowe
   const uint64_t n = 1ull << T.g.lsize_l;
   uint64_t uniq = 0, dist = 0, tot = 0, mx = 0;
   for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-    const uint64_t w = T.slots[i];
+    const uint64_t w = slot_ld(T, i);
     if(!w) continue;
     const uint64_t c = full_count(T, w, i, have_ovf);
     if(c < lower || c > upper) continue;
@@ -517,7 +537,7 @@ __global__ __launch_bounds__(kBlock) void digest_kernel(DevTable T, uint64_t low
   const uint64_t n = 1ull << T.g.lsize_l;
   uint64_t cnt = 0, tot = 0, sum = 0, x = 0;
   for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-    const uint64_t w = T.slots[i];
+    const uint64_t w = slot_ld(T, i);
     if(!w) continue;
     const uint64_t c = full_count(T, w, i, have_ovf);
     if(c < lower || c > upper) continue;
@@ -538,7 +558,7 @@ __global__ __launch_bounds__(kBlock) void histo_kernel(DevTable T, uint64_t hbas
   __syncthreads();
   const uint64_t n = 1ull << T.g.lsize_l;
   for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-    const uint64_t w = T.slots[i];
+    const uint64_t w = slot_ld(T, i);
     if(!w) continue;
     const uint64_t c = full_count(T, w, i, have_ovf);
     uint64_t b;
@@ -560,7 +580,7 @@ __global__ __launch_bounds__(kBlock) void tile_count_kernel(DevTable T, uint64_t
     const uint64_t tb = tile << T.g.tile_bits;
     uint32_t c = 0;
     for(uint32_t i = threadIdx.x; i < tsz; i += blockDim.x) {
-      const uint64_t w = T.slots[tb + i];
+      const uint64_t w = slot_ld(T, tb + i);
       if(!w) continue;
       const uint64_t cnt = full_count(T, w, tb + i, have_ovf);
       c += (cnt >= lower && cnt <= upper);
@@ -596,7 +616,7 @@ __global__ __launch_bounds__(kBlock) void dump_tiles_kernel(DevTable T, uint64_t
     const uint64_t tb = tile << T.g.tile_bits;
     __syncthreads();
     for(uint32_t i = threadIdx.x; i < tsz; i += blockDim.x) {
-      uint64_t w = T.slots[tb + i];
+      uint64_t w = slot_ld(T, tb + i);
       uint64_t sk = SENT;
       if(w) {
         const uint64_t cnt = full_count(T, w, tb + i, have_ovf);

@@ -495,24 +495,25 @@ __global__ __launch_bounds__(kPBlock) void p2_scatter_sorted_kernel(PartGeom P, 
 // LOAD == false: the whole table is known to be all-zero (fresh / cleared): never read tiles.
 // LOAD == true : read a tile only if its dirty byte says something was ever inserted into it.
 // Same claim-or-increment protocol as table_add, on LDS words (ds_cmpst_rtn_b64 / ds_add_u64).
-template <typename ITEM, bool RETURNING>
-__device__ inline void tile_insert_one(const DevTable& T, unsigned long long* s_tile, uint64_t item, uint64_t tile_index) {
+// SLOT: unsigned long long (64-bit slots) or unsigned int (32-bit slots, TableGeom::slot32): the LDS word of one slot.
+template <typename ITEM, bool RETURNING, typename SLOT>
+__device__ inline void tile_insert_one(const DevTable& T, SLOT* s_tile, uint64_t item, uint64_t tile_index) {
   const TableGeom& g = T.g;
   const uint32_t tmask = (1u << g.tile_bits) - 1;
   const uint64_t tag = item & (g.occ_bit - 1);
   const uint32_t idx0 = (uint32_t)(tag >> g.rem_bits);
-  const uint64_t low = g.occ_bit | tag;
-  const uint64_t neww = g.inc | low;
+  const SLOT low = (SLOT)(g.occ_bit | tag), lmask = (SLOT)g.low_mask, inc = (SLOT)g.inc;
+  const SLOT neww = inc | low;
   for(uint32_t p = 0; p <= T.max_probe; ++p) {
     const uint32_t slot = probe_slot(idx0, p, tmask);
-    const unsigned long long old = atomicCAS(&s_tile[slot], 0ull, (unsigned long long)neww);
-    if(old == 0ull) return;
-    if((old & g.low_mask) == low) {
+    const SLOT old = atomicCAS(&s_tile[slot], (SLOT)0, neww);
+    if(old == 0) return;
+    if((old & lmask) == low) {
       if(RETURNING) {
-        const unsigned long long prev = atomicAdd(&s_tile[slot], (unsigned long long)g.inc);
-        if((prev >> (g.tag_bits + 1)) + 1 > g.cnt_max) ovf_add(T, (tile_index << g.tile_bits) + slot, 1);
+        const SLOT prev = atomicAdd(&s_tile[slot], inc);
+        if(((uint64_t)prev >> (g.tag_bits + 1)) + 1 > g.cnt_max) ovf_add(T, (tile_index << g.tile_bits) + slot, 1);
       } else {
-        atomicAdd(&s_tile[slot], (unsigned long long)g.inc);
+        atomicAdd(&s_tile[slot], inc);
       }
       return;
     }
@@ -520,17 +521,22 @@ __device__ inline void tile_insert_one(const DevTable& T, unsigned long long* s_
   atomicAdd((unsigned long long*)&T.counters[CTR_FULL], 1ull);
 }
 
-template <typename ITEM, bool RETURNING, bool LOAD>
-__global__ __launch_bounds__(kPBlock) void tile_insert_kernel(DevTable T, SegList S, uint64_t tile0, uint32_t n_tiles) {
+// SLOT: the LDS word of one slot (see tile_insert_one); BLOCK: threads per workgroup.  64-bit slots: 64 KiB tiles, two
+// workgroups of 1024 per CU.  32-bit slots: 32 KiB tiles, four workgroups of 512 per CU -- the insert phase is a chain
+// of dependent LDS atomics per lane, and more tiles in flight per CU is what hides it behind the tile loads and stores.
+template <typename ITEM, bool RETURNING, bool LOAD, typename SLOT, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void tile_insert_kernel(DevTable T, SegList S, uint64_t tile0, uint32_t n_tiles) {
   JF_DYN_LDS(s_raw);
-  unsigned long long* s_tile = reinterpret_cast<unsigned long long*>(s_raw);
+  SLOT* s_tile = reinterpret_cast<SLOT*>(s_raw);
   const TableGeom& g = T.g;
   const uint32_t tsz = 1u << g.tile_bits;
-  if(S.n == 1) {
+  constexpr uint32_t kVec = 16 / sizeof(SLOT);                          // slots per 16-byte vector
+  SLOT* const gslots = reinterpret_cast<SLOT*>(T.slots);
+  if(S.n == 1 && S.sh[0] == 0) {
     // Fast path (one packed item array, e.g. the P2 output).  Software pipeline over this block's
     // tiles: offsets are fetched two tiles ahead and the items one tile ahead into registers, so the
     // dependent global loads (offset -> items) never sit on the critical path of a tile.
-    constexpr int NP = 6;                                   // register-prefetched items per lane (6144 per tile)
+    constexpr int NP = 6144 / BLOCK;                        // register-prefetched items per lane (6144 per tile)
     const uint64_t* off = S.off[0];
     const ITEM* src = reinterpret_cast<const ITEM*>(S.items[0]);
     const uint32_t G = gridDim.x;
@@ -540,7 +546,7 @@ __global__ __launch_bounds__(kPBlock) void tile_insert_kernel(DevTable T, SegLis
     if(t < n_tiles) { a0 = off[t]; b0 = off[t + 1]; d0 = LOAD ? T.dirty[tile0 + t] : 0; }
     if(t + G < n_tiles) { a1 = off[t + G]; b1 = off[t + G + 1]; d1 = LOAD ? T.dirty[tile0 + t + G] : 0; }
 #pragma unroll
-    for(int r = 0; r < NP; ++r) { const uint64_t v = a0 + (uint64_t)r * kPBlock + threadIdx.x; cur[r] = v < b0 ? src[v] : (ITEM)0; }
+    for(int r = 0; r < NP; ++r) { const uint64_t v = a0 + (uint64_t)r * BLOCK + threadIdx.x; cur[r] = v < b0 ? src[v] : (ITEM)0; }
 #ifdef JFGPU_TILE_PROF
     long long pc0 = 0, pc1 = 0, pc2 = 0, pc3 = 0, pt = clock64();
 #define TP(acc) do { const long long n_ = clock64(); acc += n_ - pt; pt = n_; } while(0)
@@ -553,27 +559,27 @@ __global__ __launch_bounds__(kPBlock) void tile_insert_kernel(DevTable T, SegLis
       if(t + 2 * G < n_tiles) { a2 = off[t + 2 * G]; b2 = off[t + 2 * G + 1]; d2 = LOAD ? T.dirty[tile0 + t + 2 * G] : 0; }
       ITEM nxt[NP];
 #pragma unroll
-      for(int r = 0; r < NP; ++r) { const uint64_t v = a1 + (uint64_t)r * kPBlock + threadIdx.x; nxt[r] = v < b1 ? src[v] : (ITEM)0; }
+      for(int r = 0; r < NP; ++r) { const uint64_t v = a1 + (uint64_t)r * BLOCK + threadIdx.x; nxt[r] = v < b1 ? src[v] : (ITEM)0; }
       TP(pc0);
       if(b0 > a0) {                                          // block-uniform
-        uint64_t* gt = T.slots + ((tile0 + t) << g.tile_bits);
+        SLOT* gt = gslots + ((tile0 + t) << g.tile_bits);
         const bool load = LOAD && d0 != 0;
-        for(uint32_t i = threadIdx.x * 2; i < tsz; i += blockDim.x * 2) {
-          ulonglong2 v = make_ulonglong2(0ull, 0ull);
-          if(load) v = *reinterpret_cast<const ulonglong2*>(gt + i);
-          *reinterpret_cast<ulonglong2*>(s_tile + i) = v;
+        for(uint32_t i = threadIdx.x * kVec; i < tsz; i += BLOCK * kVec) {
+          uint4 v = make_uint4(0, 0, 0, 0);
+          if(load) v = *reinterpret_cast<const uint4*>(gt + i);
+          *reinterpret_cast<uint4*>(s_tile + i) = v;
         }
         lds_barrier();
         TP(pc1);
 #pragma unroll
         for(int r = 0; r < NP; ++r)
-          if(a0 + (uint64_t)r * kPBlock + threadIdx.x < b0) tile_insert_one<ITEM, RETURNING>(T, s_tile, (uint64_t)cur[r], tile0 + t);
-        for(uint64_t v = a0 + (uint64_t)NP * kPBlock + threadIdx.x; v < b0; v += kPBlock)   // rare: an over-full tile
+          if(a0 + (uint64_t)r * BLOCK + threadIdx.x < b0) tile_insert_one<ITEM, RETURNING>(T, s_tile, (uint64_t)cur[r], tile0 + t);
+        for(uint64_t v = a0 + (uint64_t)NP * BLOCK + threadIdx.x; v < b0; v += BLOCK)   // rare: an over-full tile
           tile_insert_one<ITEM, RETURNING>(T, s_tile, (uint64_t)src[v], tile0 + t);
         lds_barrier();
         TP(pc2);
-        for(uint32_t i = threadIdx.x * 2; i < tsz; i += blockDim.x * 2)
-          *reinterpret_cast<ulonglong2*>(gt + i) = *reinterpret_cast<const ulonglong2*>(s_tile + i);
+        for(uint32_t i = threadIdx.x * kVec; i < tsz; i += BLOCK * kVec)
+          *reinterpret_cast<uint4*>(gt + i) = *reinterpret_cast<const uint4*>(s_tile + i);
         if(threadIdx.x == 0) T.dirty[tile0 + t] = 1;
         lds_barrier();
         TP(pc3);
@@ -598,26 +604,26 @@ __global__ __launch_bounds__(kPBlock) void tile_insert_kernel(DevTable T, SegLis
     uint64_t n_items = 0;
     for(uint32_t s = 0; s < S.n; ++s) n_items += seg_hi(S, s, t) - seg_lo(S, s, t);
     if(n_items == 0) continue;                                   // block-uniform
-    uint64_t* gt = T.slots + ((tile0 + t) << g.tile_bits);
+    SLOT* gt = gslots + ((tile0 + t) << g.tile_bits);
     const bool load = LOAD && T.dirty[tile0 + t] != 0;              // block-uniform
-    for(uint32_t i = threadIdx.x * 2; i < tsz; i += blockDim.x * 2) {   // tile -> LDS, 16 B per lane per step
-      ulonglong2 v = make_ulonglong2(0ull, 0ull);
-      if(load) v = *reinterpret_cast<const ulonglong2*>(gt + i);
-      *reinterpret_cast<ulonglong2*>(s_tile + i) = v;
+    for(uint32_t i = threadIdx.x * kVec; i < tsz; i += BLOCK * kVec) {   // tile -> LDS, 16 B per lane per step
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if(load) v = *reinterpret_cast<const uint4*>(gt + i);
+      *reinterpret_cast<uint4*>(s_tile + i) = v;
     }
     lds_barrier();
     for(uint32_t s = 0; s < S.n; ++s) {
       const uint64_t a = seg_lo(S, s, t), b = seg_hi(S, s, t);
       const ITEM* src = reinterpret_cast<const ITEM*>(S.items[s]);
       const bool holes = S.sh[s] != 0;
-      for(uint64_t v = a + threadIdx.x; v < b; v += blockDim.x) {
+      for(uint64_t v = a + threadIdx.x; v < b; v += BLOCK) {
         const ITEM x = src[v];
         if(!(holes && x == (ITEM)~(ITEM)0)) tile_insert_one<ITEM, RETURNING>(T, s_tile, (uint64_t)x, tile0 + t);
       }
     }
     lds_barrier();
-    for(uint32_t i = threadIdx.x * 2; i < tsz; i += blockDim.x * 2)
-      *reinterpret_cast<ulonglong2*>(gt + i) = *reinterpret_cast<const ulonglong2*>(s_tile + i);
+    for(uint32_t i = threadIdx.x * kVec; i < tsz; i += BLOCK * kVec)
+      *reinterpret_cast<uint4*>(gt + i) = *reinterpret_cast<const uint4*>(s_tile + i);
     if(threadIdx.x == 0) T.dirty[tile0 + t] = 1;
     lds_barrier();
   }
@@ -637,15 +643,14 @@ __device__ inline void item_direct_insert(const DevTable& T, const PartGeom& P, 
   const uint64_t low = g.occ_bit | tag, neww = g.inc | low;
   for(uint32_t p = 0; p <= T.max_probe; ++p) {
     const uint64_t slot = tile_base + probe_slot(idx0, p, tmask);
-    unsigned long long* addr = (unsigned long long*)&T.slots[slot];
-    const unsigned long long old = atomicCAS(addr, 0ull, (unsigned long long)neww);
+    const uint64_t old = slot_cas(T, slot, 0, neww);
     if(old == 0ull) return;
     if((old & g.low_mask) == low) {
       if(RETURNING) {
-        const unsigned long long prev = atomicAdd(addr, (unsigned long long)g.inc);
+        const uint64_t prev = slot_add_rtn(T, slot, g.inc);
         if((prev >> (g.tag_bits + 1)) + 1 > g.cnt_max) ovf_add(T, slot, 1);
       } else {
-        __hip_atomic_fetch_add(addr, (unsigned long long)g.inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        slot_add(T, slot, g.inc);
       }
       return;
     }

@@ -22,7 +22,8 @@
 namespace jfgpu {
 
 constexpr uint32_t kMaxTileBits = 13;   // probe domain = 8192 slots = 64 KiB: fits LDS, see DESIGN.md
-constexpr uint32_t kMinCountBits = 16;  // in-slot count field never narrower than this
+constexpr uint32_t kMinCountBits = 16;  // in-slot count field never narrower than this (64-bit slots)
+constexpr uint32_t kMinCountBits32 = 8; // ... and in a 32-bit slot
 
 // ---- character classes ----------------------------------------------------
 // A a->0, C c->1, G g->2, T t->3; everything else (N, IUPAC, '\n', ...) -> 4 = reset.
@@ -68,6 +69,10 @@ JF_HD uint64_t revcomp64(uint64_t x, uint32_t k) {
 
 // ---- table geometry ---------------------------------------------------------
 // One slot = one 64-bit word:   [ count : cnt_bits | occupied : 1 | tag : tag_bits ]
+// -- or the same three fields in ONE 32-bit word when the tag is short enough (tag_bits <= 23, i.e. at most ten key bits
+// left to store: k = 21 at 2^32 slots and up), which halves the table and what every flush of the partitioned path
+// streams.  The reference packs entries at bit granularity for the same reason (offsets_key_value.hpp:87-106: 23.4 bits
+// per entry at k = 21 / 2^34); here the unit stays a naturally aligned word so that one atomic claims a slot.
 //   tag = (idx0 << rem_bits) | rem
 //   rem  = key >> lsize_g              (key bits the hash position does not determine)
 //   idx0 = position inside the tile    (low tile_bits bits of the hash position)
@@ -86,6 +91,8 @@ struct TableGeom {
   uint32_t tile_bits, rem_bits, tag_bits, cnt_bits;
   uint32_t nbytes;                // bytes of a key fed to the hash tables = ceil(2k/8)
   uint32_t canonical;
+  uint32_t slot32;                // 1: slots are 32-bit words (same fields, cnt_bits = 31 - tag_bits)
+  uint32_t pad_;
   uint64_t key_mask, tile_mask, rem_mask, local_mask;
   uint64_t occ_bit, low_mask, inc, cnt_max;
 };
@@ -93,15 +100,16 @@ struct TableGeom {
 // Fills every derived field from (k, lsize_g, shard_bits, shard_id, canonical).
 // Returns false when the combination cannot be packed into a 64-bit slot.
 inline bool geom_init(TableGeom& g, uint32_t k, uint32_t lsize_g, uint32_t shard_bits, uint32_t shard_id,
-                      uint32_t canonical) {
+                      uint32_t canonical, bool allow32 = true) {
   if(k < 1 || k > 32 || lsize_g > 2 * k || shard_bits > lsize_g) return false;
   g.k = k; g.key_bits = 2 * k; g.lsize_g = lsize_g; g.shard_bits = shard_bits; g.shard_id = shard_id;
   g.lsize_l = lsize_g - shard_bits;
   g.tile_bits = g.lsize_l < kMaxTileBits ? g.lsize_l : kMaxTileBits;
   g.rem_bits = g.key_bits - lsize_g;
   g.tag_bits = g.tile_bits + g.rem_bits;
-  if(g.tag_bits + 1 + kMinCountBits > 64) return false;
-  g.cnt_bits = 63 - g.tag_bits;
+  g.slot32 = allow32 && g.tag_bits + 1 + kMinCountBits32 <= 32; g.pad_ = 0;
+  if(!g.slot32 && g.tag_bits + 1 + kMinCountBits > 64) return false;
+  g.cnt_bits = (g.slot32 ? 31 : 63) - g.tag_bits;
   g.nbytes = (g.key_bits + 7) / 8;
   g.canonical = canonical;
   g.key_mask = g.key_bits == 64 ? ~0ull : ((1ull << g.key_bits) - 1);

@@ -205,6 +205,76 @@ def test_content_digest_matches_dump(gpu):
             assert t.digest(2, 40) == gpu.digest_of(keys[sel], cnts[sel])
 
 
+@pytest.mark.parametrize("k,lsize,mode", [(14, 20, 1), (14, 20, 2), (16, 25, 2), (12, 14, 0), (13, 26, 2)])
+def test_slot32_equals_slot64_and_oracle(gpu, monkeypatch, k, lsize, mode):
+    """32-bit slots (kmer_core.hpp: count | occ | tag in one dword when at most ten key bits are left to store) against
+    64-bit slots of the same geometry (JFGPU_SLOT64=1) and the oracle: both insert strategies, duplicates, a k-mer counted
+    far beyond the narrow count field (the overflow side table), a flush in the middle, look-ups, hash_counter::add with
+    large values, stats / histo / digest, and the sorted dump -- whose bytes must not depend on the slot width."""
+    rng = random.Random(k * 100 + lsize)
+    seq = rnd_seq(rng, 150000, "ACGTN") + b"N" + b"A" * 9000 + b"N" + rnd_seq(rng, 40000, "AC") + b"N" + b"ACGT" * 3000
+    exp = oracle_map(seq, k, True)
+    assert max(exp.values()) > 5000
+    out = {}
+    for slot64 in ("0", "1"):
+        monkeypatch.setenv("JFGPU_SLOT64", slot64)
+        with gpu.Table(k, 1 << lsize) as t:
+            assert t.info.slot_bytes == (8 if slot64 == "1" else 4), (t.info.slot_bytes, t.info.val_len)
+            if mode:
+                t.set_mode(mode)
+            half = len(seq) // 2
+            t.count_ascii(seq[:half])
+            sample = np.array(list(exp.keys())[:300], dtype=np.uint64)
+            t.lookup(sample)
+            t.count_ascii(seq[half - (k - 1):])
+            t.sync()
+            assert table_map(gpu, t) == exp
+            st = t.stats()
+            assert (st.distinct, st.total, st.max_count) == (len(exp), sum(exp.values()), max(exp.values()))
+            vals, found = t.lookup(sample)
+            assert found.all() and vals.tolist() == [exp[x] for x in sample.tolist()]
+            t.add_keys(sample[:20], val=2 ** 33 + 7)
+            vals, _ = t.lookup(sample[:20])
+            assert vals.tolist() == [exp[x] + 2 ** 33 + 7 for x in sample[:20].tolist()]
+            base, inc, h = t.histo(1, 20000, 1)
+            out[slot64] = (t.dump_records().tobytes(), t.digest(), h.tobytes())
+    assert out["0"] == out["1"]
+
+
+def test_slot32_grows_and_shards(gpu):
+    """A 32-bit-slot table that doubles itself (the new geometry may or may not stay 32-bit) and 32-bit shards fed through
+    the local exchange give the oracle's counts."""
+    rng = random.Random(9)
+    k = 12
+    seq = rnd_seq(rng, 400000, "ACGT")
+    exp = oracle_map(seq, k, True)
+    with gpu.Table(k, 1 << 14) as t:                           # rem_bits = 10: 32-bit slots, far too small
+        assert t.info.slot_bytes == 4
+        t.count_ascii(seq)
+        t.sync()
+        assert t.info.lsize > 14 and table_map(gpu, t) == exp
+    shards = [gpu.Table(k, 1 << 20, shard_bits=1, shard_id=r) for r in range(2)]
+    comm = gpu.Comm(2, local=True)
+    try:
+        assert all(s.info.slot_bytes == 4 for s in shards)
+        bufs = [s.malloc(len(seq) + 64) for s in shards]
+        half = len(seq) // 2
+        parts = [seq[:half], seq[half - (k - 1):]]
+        for s, d, p in zip(shards, bufs, parts):
+            s.h2d(d, np.frombuffer(p, dtype=np.uint8))
+        comm.local_step(shards, bufs, [len(p) for p in parts])
+        comm.finish()
+        got = {}
+        for s in shards:
+            s.sync()
+            got.update(table_map(gpu, s, check_order=False))
+        assert got == exp
+    finally:
+        comm.close()
+        for s in shards:
+            s.close()
+
+
 def test_hash_full_is_reported(gpu):
     """More distinct k-mers than slots: the reference throws 'Hash full'
     (hash_counter.hpp:194-195); the engine must fail loudly too, never drop silently."""
