@@ -39,7 +39,7 @@ READ_LEN = 150
 HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: 8 TB/s spec
 CONFIGS = {
     #        k   lsize  slot B  algorithmic bytes per k-mer occurrence
-    "C2": dict(k=21, lsize=34, slot=8, name="BASELINE configs[1]: k=21 -C, {gbp:.1f} Gbp of 150 bp reads per GPU, 2^{lsize}-slot 64-bit table per GPU in HBM"),
+    "C2": dict(k=21, lsize=34, slot=8, name="BASELINE configs[1]: k=21 -C, {gbp:.1f} Gbp of 150 bp reads per GPU, 2^{lsize}-slot table per GPU in HBM ({slot_bytes}-byte slots)"),
     "C3": dict(k=31, lsize=33, slot=8, name="BASELINE configs[2]: k=31 -C, Bloom-counter pass (m = 14 x {gbp:.0f}e9 cells, 10 hashes) then count --bc, {gbp:.1f} Gbp of 150 bp reads, 2^{lsize}-slot table"),
     "C5": dict(k=63, lsize=33, slot=16, name="BASELINE configs[4]: k=63 -C (two-word keys), {gbp:.1f} Gbp of 150 bp reads, 2^{lsize}-slot 128-bit table in HBM"),
 }
@@ -201,6 +201,7 @@ def main():
     kmers_per_read = READ_LEN - K + 1
     t = capi.Table(K, 1 << (lsize + sb), canonical=True, device=local_rank, shard_bits=sb, shard_id=rank)
     lsize = t.info.lsize - sb                        # the engine may raise a size below the slot format's minimum
+    slot_bytes = t.info.slot_bytes
     buf = t.malloc(n_reads * stride + 16)            # plain device memory through the C ABI
     device_sync()
     if args.dist == "G":
@@ -351,9 +352,9 @@ def main():
             "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64" if CONFIGS[cfg]["slot"] == 8 else "u128", "data": "synthetic",
-            "config": {"workload": CONFIGS[cfg]["name"].format(gbp=args.gbp, lsize=lsize) +
+            "config": {"workload": CONFIGS[cfg]["name"].format(gbp=args.gbp, lsize=lsize, slot_bytes=slot_bytes) +
                                    ("" if args.dist == "U" else "; SECONDARY distribution G (reads from a 100 Mbp random genome, 1 % substitutions)"),
-                       "id": cfg, "k": K, "read_len": READ_LEN, "reads_per_gpu": n_reads, "table_slots_per_gpu": 1 << lsize,
+                       "id": cfg, "k": K, "read_len": READ_LEN, "reads_per_gpu": n_reads, "table_slots_per_gpu": 1 << lsize, "slot_bytes": slot_bytes,
                        "load_factor": float(tot[1]) / float(world << lsize),
                        "distinct": int(tot[1]), "total_kmers": total_kmers,
                        "parallelism": ("single GPU" if not force_dist else "single GPU through the sharded code path") if world == 1 else "hash-prefix shard x%d + all-to-all" % world},

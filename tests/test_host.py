@@ -240,12 +240,14 @@ def test_mem_verb_and_table_bytes(cli):
     import ctypes as C
     slots, nbytes = C.c_uint64(), C.c_uint64()
     assert capi.load().jfgpu_table_bytes(21, 10 ** 10, C.byref(slots), C.byref(nbytes)) == 0
-    assert slots.value == 1 << 34 and (1 << 37) <= nbytes.value < (1 << 37) * 1.02          # 8-byte slots + side tables
+    assert slots.value == 1 << 34 and (1 << 36) <= nbytes.value < (1 << 36) * 1.03          # 4-byte slots (k = 21 at 2^34: 8 key bits to store) + side tables
     out = subprocess.check_output([cli, "mem", "-m", "21", "-s", "10G"]).decode().split()
-    assert int(out[0]) == nbytes.value and out[1] == "(129G)"
+    assert int(out[0]) == nbytes.value and out[1] == "(65G)"
+    assert capi.load().jfgpu_table_bytes(31, 1 << 33, C.byref(slots), C.byref(nbytes)) == 0
+    assert slots.value == 1 << 33 and (1 << 36) <= nbytes.value < (1 << 36) * 1.03          # k = 31: 29 key bits to store, 8-byte slots
     assert capi.load().jfgpu_table_bytes(40, 1 << 20, C.byref(slots), C.byref(nbytes)) == 0
     assert nbytes.value >= 16 * slots.value                                                  # two-word keys: 16-byte slots
-    inv = subprocess.check_output([cli, "mem", "-m", "21", "--mem", "200G"]).decode().split()
+    inv = subprocess.check_output([cli, "mem", "-m", "21", "--mem", "100G"]).decode().split()
     assert int(inv[0]) == 1 << 34
 
 
