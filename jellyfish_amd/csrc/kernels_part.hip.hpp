@@ -525,7 +525,7 @@ __device__ inline void tile_insert_one(const DevTable& T, SLOT* s_tile, uint64_t
 // workgroups of 1024 per CU.  32-bit slots: 32 KiB tiles, four workgroups of 512 per CU -- the insert phase is a chain
 // of dependent LDS atomics per lane, and more tiles in flight per CU is what hides it behind the tile loads and stores.
 template <typename ITEM, bool RETURNING, bool LOAD, typename SLOT, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void tile_insert_kernel(DevTable T, SegList S, uint64_t tile0, uint32_t n_tiles) {
+__global__ __launch_bounds__(BLOCK, 2048 / 256) void tile_insert_kernel(DevTable T, SegList S, uint64_t tile0, uint32_t n_tiles) {
   JF_DYN_LDS(s_raw);
   SLOT* s_tile = reinterpret_cast<SLOT*>(s_raw);
   const TableGeom& g = T.g;
