@@ -78,7 +78,6 @@ int part_flush(jfgpu_table* t);
 // two-pass scheme.  Every block may strand part of one reservation per bucket, so small batches would be
 // mostly holes: auto mode wants the mean bucket load to be at least 4x that.
 uint32_t granule_cap(const jfgpu_table* t, bool from_keys, uint64_t max_items) {
-  (void)from_keys;
   if(t->item128) { if(t->pg.b1 > 10 || !t->g1) return 0; }              // the only P1 two-word keys have
   else if(t->pg.b2 == 0 || t->pg.b1 > 10 || t->p1_single == 0 || !t->g1) return 0;
   else if(!t->item32 && from_keys) return 0;                             // 64-bit items: single-pass from sequence only
@@ -88,7 +87,10 @@ uint32_t granule_cap(const jfgpu_table* t, bool from_keys, uint64_t max_items) {
   // a region is inserted directly (granule_emit), it only costs speed.
   if(!from_keys && t->items_per_byte > 0) max_items = std::min<uint64_t>(max_items, (uint64_t)((double)max_items * (t->items_per_byte * 1.10 + 0.005)) + 4096);
   const uint64_t mean = (max_items + nb - 1) / nb;
-  if(t->p1_single < 0 && mean < 4 * strand && !(t->item128 && t->mode == MODE_PARTITIONED)) return 0;
+  // a filtered pass (count --bc) stores few items, but the exact two-pass scheme would ask the filter twice per k-mer
+  // (random reads: what the pass costs); stranded reservations are at most g1 * nb * kGran items per batch
+  const bool filtered = !from_keys && (t->wide ? t->wt.bloom.data : t->dt.bloom.data) != nullptr;
+  if(t->p1_single < 0 && mean < 4 * strand && !filtered && !(t->item128 && t->mode == MODE_PARTITIONED)) return 0;
   const double want = (double)mean * (1.0 + t->p1_slack) + (double)strand;
   uint64_t cap = want < (double)kGran ? kGran : (uint64_t)want;
   cap = (cap + kGran - 1) / kGran * kGran;

@@ -696,6 +696,16 @@ int jfgpu_sync(jfgpu_table* t) {
   int rc = use(t); if(rc) return rc;
   rc = part_flush(t); if(rc) return rc;
   HIP_TRY(hipStreamSynchronize(t->stream));
+#ifdef JFGPU_PHASE_PROF
+  { unsigned long long c[16], z[16] = {0};
+    if(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_phase_prof), sizeof c) == hipSuccess) {
+      fprintf(stderr, "[phase prof] P1: stage %llu  encode+hash+hist %llu  scan %llu  place+lds-scatter %llu  (barrier) %llu  write-out %llu  finish %llu\n",
+              c[0], c[1], c[2], c[3], c[4], c[5], c[6]);
+      fprintf(stderr, "[phase prof] P2: (barrier) %llu  load %llu  hist %llu  scan %llu  lds-scatter %llu  write-out %llu\n",
+              c[8], c[9], c[10], c[11], c[12], c[13]);
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_prof), z, sizeof z);
+    } }
+#endif
 #ifdef JFGPU_TILE_PROF
   { uint64_t c[CTR_COUNT]; if(read_counters(t, c) == JFGPU_OK)
       fprintf(stderr, "[tile prof] wait+prefetch %llu  fill %llu  insert %llu  store %llu (shader clocks, summed over blocks)\n",

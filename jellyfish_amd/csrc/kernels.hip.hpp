@@ -36,6 +36,24 @@ constexpr int kTilePos = kBlock * kPerThread;  // 4096 sequence positions per bl
 enum Counter : int { CTR_FULL = 0, CTR_MERS = 1, CTR_OVF_FULL = 2, CTR_OVF_USED = 3, CTR_MISROUTED = 4, CTR_DIRECT = 5,
                      CTR_PROF0 = 8 /* .. 11: phase clocks of a -DJFGPU_TILE_PROF build */, CTR_COUNT = 12 };
 
+// -DJFGPU_PHASE_PROF builds: shader clocks per phase of the partition kernels, as wave 0 of every block sees them,
+// summed over blocks into a device array the host prints at jfgpu_sync (tools/ablate.py).  Slots 0-7 P1, 8-15 P2.
+#ifdef JFGPU_PHASE_PROF
+__device__ unsigned long long g_phase_prof[16];
+struct PhaseClk {
+  long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long t;
+  __device__ PhaseClk() { t = clock64(); }
+  __device__ void mark(int i) { const long long n = clock64(); acc[i] += n - t; t = n; }
+  __device__ void flush(int base) { if(threadIdx.x == 0) for(int i = 0; i < 8; ++i) if(acc[i]) atomicAdd(&g_phase_prof[base + i], (unsigned long long)acc[i]); }
+};
+#define JF_PHASE(pc, i) (pc).mark(i)
+#define JF_PHASE_FLUSH(pc, base) (pc).flush(base)
+#else
+struct PhaseClk {};
+#define JF_PHASE(pc, i) do {} while(0)
+#define JF_PHASE_FLUSH(pc, base) do {} while(0)
+#endif
+
 // Bloom counter view (kernels_bloom.hip.hpp); data == nullptr: no filter attached.
 struct DevBloom {
   uint32_t* data;             // ceil(m/5) bytes, addressed as dwords

@@ -442,9 +442,11 @@ __global__ __launch_bounds__(kPBlock) void p2_scatter_sorted_kernel(PartGeom P, 
   for(uint32_t s = 0; s < S.n; ++s) n += seg_hi(S, s, bucket) - seg_lo(S, s, bucket);
   const uint64_t per = (n + gridDim.x - 1) / gridDim.x;
   const uint64_t my_lo = (uint64_t)blockIdx.x * per, my_hi = my_lo + per < n ? my_lo + per : n;
+  PhaseClk pc;
   for(uint64_t c0 = my_lo; c0 < my_hi; c0 += kChunk) {
     const uint64_t c1 = c0 + kChunk < my_hi ? c0 + kChunk : my_hi;
     lds_barrier();                                      // previous chunk's readers of s_hist/s_lstart/s_item are done
+    JF_PHASE(pc, 0);
     // the cursor of bucket d advances by what the previous chunk wrote; delta is re-based on the new lstart below
     for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) { s_delta[j] += s_hist[j] + s_lstart[j]; s_hist[j] = 0; }
     ITEM it[PER_THREAD]; uint32_t dr[PER_THREAD];       // digit << 16 | rank inside the chunk
@@ -466,6 +468,7 @@ __global__ __launch_bounds__(kPBlock) void p2_scatter_sorted_kernel(PartGeom P, 
       slo = shi;
     }
     lds_barrier();
+    JF_PHASE(pc, 1);
 #pragma unroll
     for(int r = 0; r < PER_THREAD; ++r)
       if(dr[r] != 0xFFFFFFFFu) {
@@ -474,20 +477,25 @@ __global__ __launch_bounds__(kPBlock) void p2_scatter_sorted_kernel(PartGeom P, 
         dr[r] = (d << 16) | atomicAdd(&s_hist[d], 1u);
       }
     lds_barrier();
+    JF_PHASE(pc, 2);
     block_excl_scan_2048(s_hist, s_lstart, nb, s_wave);
     lds_barrier();
+    JF_PHASE(pc, 3);
     for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) s_delta[j] -= s_lstart[j];
 #pragma unroll
     for(int r = 0; r < PER_THREAD; ++r)
       if(dr[r] != 0xFFFFFFFFu) s_item[s_lstart[dr[r] >> 16] + (dr[r] & 0xFFFFu)] = it[r];
     lds_barrier();
+    JF_PHASE(pc, 4);
     const uint32_t cn = s_lstart[nb - 1] + s_hist[nb - 1];       // items of this chunk that are not holes
     for(uint32_t i = threadIdx.x; i < cn; i += blockDim.x) {
       const ITEM v = s_item[i];
       const uint32_t d = (uint32_t)(v >> tag_bits) & (nb - 1);
       out[base0 + (uint32_t)(s_delta[d] + i)] = v;     // run of bucket d: consecutive lanes, consecutive addresses
     }
+    JF_PHASE(pc, 5);
   }
+  JF_PHASE_FLUSH(pc, 8);
 }
 
 // ---- T: one workgroup owns one tile in LDS --------------------------------------------------
@@ -718,10 +726,12 @@ __device__ inline void granule_init(GranuleLds& G, uint32_t nb) {
 template <typename ITEM, int N, typename DIRECT>
 __device__ inline uint32_t granule_emit(GranuleLds& G, uint32_t nb, uint32_t cap,
                                         unsigned int* __restrict__ gcur, ITEM* __restrict__ out, ITEM* s_item, uint16_t* s_bkt,
-                                        const ITEM (&it)[N], const uint32_t (&dr)[N], DIRECT&& direct_fn) {
+                                        const ITEM (&it)[N], const uint32_t (&dr)[N], DIRECT&& direct_fn, PhaseClk* pc = nullptr) {
   lds_barrier();
+  if(pc) JF_PHASE(*pc, 2);
   block_excl_scan_2048(G.hist, G.lstart, nb, G.wave);
   lds_barrier();
+  if(pc) JF_PHASE(*pc, 3);
   // Placement of every bucket's run (nb <= blockDim: one bucket per thread): what fits the current
   // reservation stays there, the rest goes to a new one.  The reservation (a global atomic) is issued
   // first, its round trip overlaps the LDS scatter, its answer is used afterwards.
@@ -750,6 +760,7 @@ __device__ inline uint32_t granule_emit(GranuleLds& G, uint32_t nb, uint32_t cap
     }
   }
   lds_barrier();
+  if(pc) JF_PHASE(*pc, 4);
   uint32_t direct_n = 0;
   const uint32_t cn = G.lstart[nb - 1] + G.hist[nb - 1];
   const ITEM hole = (ITEM)~(ITEM)0;
@@ -765,6 +776,7 @@ __device__ inline uint32_t granule_emit(GranuleLds& G, uint32_t nb, uint32_t cap
     }
     if(direct) { direct_fn(b, v); ++direct_n; }
   }
+  if(pc) JF_PHASE(*pc, 5);
   return direct_n;
 }
 
@@ -799,10 +811,12 @@ __global__ __launch_bounds__(kPBlock) void p1_scatter_granule_kernel(DevTable T,
   uint32_t my_direct = 0, my_mers = 0;
   const int64_t n_tiles = (hi + kPTilePos - 1) / kPTilePos;
   TileRaw R = tile_fetch(base, (int64_t)blockIdx.x * kPTilePos, lo, hi);
+  PhaseClk pc;
   for(int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     lds_barrier();
     for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) G.hist[j] = 0;
     const LaneWords L = tile_stage(R, tile * kPTilePos, lo, hi, s_codes, s_inv);      // barrier inside
+    JF_PHASE(pc, 0);
     R = tile_fetch(base, (tile + gridDim.x) * kPTilePos, lo, hi);                      // next tile's bytes travel while this one is worked on
     uint32_t it[kPerLane + 1], dr[kPerLane + 1];
 #pragma unroll
@@ -827,10 +841,13 @@ __global__ __launch_bounds__(kPBlock) void p1_scatter_granule_kernel(DevTable T,
     });
     flush_run(kPerLane);
     if(long_runs) my_direct += apply_runs<RETURNING, BLOOM>(T, s_fwd, L);
+    JF_PHASE(pc, 1);
     my_direct += granule_emit(G, nb, cap, gcur, out, s_item, s_bkt, it, dr,
-                              [&](uint32_t b, uint32_t v) { item_direct_insert<RETURNING>(T, P, b, (uint64_t)v); });
+                              [&](uint32_t b, uint32_t v) { item_direct_insert<RETURNING>(T, P, b, (uint64_t)v); }, &pc);
   }
   granule_finish(G, nb, cap, tot, out);
+  JF_PHASE(pc, 6);
+  JF_PHASE_FLUSH(pc, 0);
   if(my_direct) atomicAdd((unsigned long long*)&T.counters[CTR_DIRECT], (unsigned long long)my_direct);
   uint64_t w = my_mers;
   for(int o = 32; o > 0; o >>= 1) w += __shfl_down(w, o, 64);
