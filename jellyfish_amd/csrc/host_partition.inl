@@ -243,8 +243,16 @@ int part_flush_t(jfgpu_table* t) {
   // always LOAD-capable: a tile is read only if its dirty byte is set (clean after jfgpu_clear)
   const bool rt = t->returning, load = true;
   // the tile insert of one item array (or of the pending batches themselves), on stream `ts`
-  auto launch_tile_kernel = [&](const SegList& S, uint64_t tile0, uint32_t ntile, hipStream_t ts) {
+  auto launch_tile_kernel = [&](const SegList& S, uint64_t tile0, uint32_t ntile, hipStream_t ts, bool pair = false) {
     const dim3 block(kPBlock);
+    if constexpr(sizeof(ITEM) == 4) {
+      if(pair) {                    // ntile counts pairs of 32 KiB tiles: 64 KiB of LDS, two workgroups of 1024 per CU
+        const dim3 grid((unsigned)std::min<uint64_t>(ntile, (uint64_t)t->n_cu * 16));
+        if(rt) hipLaunchKernelGGL((tile_insert_kernel<ITEM, true, true, unsigned int, kPBlock, 2>), grid, block, 2 * tile_lds, ts, t->dt, S, tile0, ntile);
+        else   hipLaunchKernelGGL((tile_insert_kernel<ITEM, false, true, unsigned int, kPBlock, 2>), grid, block, 2 * tile_lds, ts, t->dt, S, tile0, ntile);
+        return;
+      }
+    }
     if constexpr(kWideItems) {
       const dim3 grid((unsigned)std::min<uint64_t>(ntile, (uint64_t)t->n_cu * 4));     // 128 KiB of LDS: one block per CU
       if(rt) hipLaunchKernelGGL(tile_insert_wide_kernel<true>, grid, block, tile_lds, ts, t->wt, S, tile0, ntile);
@@ -300,22 +308,55 @@ int part_flush_t(jfgpu_table* t) {
     if(!t->d_M2) HIP_TRY(hipMalloc((void**)&t->d_M2, (size_t)nb1 * g2 * nb2 * sizeof(uint32_t)));
     ITEM* tmp = nullptr; uint64_t *d_goff = nullptr, *d_base = nullptr;
     bool tmp_owned = false;
-    d_goff = (uint64_t*)ws_alloc(t, (n_tiles + 1) * sizeof(uint64_t));
-    d_base = (uint64_t*)ws_alloc(t, nb1 * sizeof(uint64_t));
-    tmp = (ITEM*)ws_alloc(t, std::max<uint64_t>(total, 1) * sizeof(ITEM));
-    if(!d_goff || !d_base || !tmp) {     // arena too small for the flush temporaries: one-off allocation
-      tmp_owned = true;
-      tmp = nullptr; d_goff = nullptr; d_base = nullptr;
-      HIP_TRY(hipMalloc((void**)&tmp, std::max<uint64_t>(total, 1) * sizeof(ITEM)));
-      if(hipMalloc((void**)&d_goff, (n_tiles + 1) * sizeof(uint64_t)) != hipSuccess ||
-         hipMalloc((void**)&d_base, nb1 * sizeof(uint64_t)) != hipSuccess) {
-        hipFree(tmp); if(d_goff) hipFree(d_goff);
-        return fail(JFGPU_E_ALLOC, "hipMalloc partition offsets");
+    // 32-bit items into 32-bit slots: P2 routes to pairs of adjacent tiles (half as many destinations, and chunks of 28 Ki
+    // items), so the runs it writes are ~112 bytes on average instead of 32; the tile kernel owns a pair (64 KiB) in LDS
+    const bool pair = sizeof(ITEM) == 4 && t->g.slot32 && t->pg.b2 >= 1 && t->tile_pair;
+    // Single-pass P2 (pairs only): fixed regions of cap2 items per pair, reservations of kGran items (p2_granule_kernel).
+    // Worth it when the regions are mostly items: every block may strand one reservation per destination.
+    constexpr uint32_t kG2Single = 4;                       // blocks per P1 bucket
+    uint32_t cap2 = 0; unsigned int* d_gcur2 = nullptr; uint64_t* d_off2 = nullptr; ITEM* out2 = nullptr; bool own2 = false;
+    const uint64_t n_dest = n_tiles >> 1;
+    if(pair && t->p2_single) {
+      const uint64_t mean = total / n_dest, strand = (uint64_t)kG2Single * kGran;
+      if(mean >= 8 * strand || t->p2_single > 1) {
+        cap2 = (uint32_t)(((uint64_t)((double)mean * (1.0 + t->p2_slack)) + strand + 2 * kGran - 1) / kGran * kGran);
+        if(t->p2_cap) cap2 = t->p2_cap;
+        const size_t mark = t->ws_used;
+        d_gcur2 = (unsigned int*)ws_alloc(t, 2 * n_dest * sizeof(unsigned int));
+        d_off2 = (uint64_t*)ws_alloc(t, 2 * n_dest * sizeof(uint64_t));
+        out2 = (ITEM*)ws_alloc(t, n_dest * cap2 * sizeof(ITEM));
+        if(!d_gcur2 || !d_off2 || !out2) {       // no room for the regions in the arena: exact P2 (forced: one-off allocations)
+          t->ws_used = mark;
+          d_gcur2 = nullptr; d_off2 = nullptr; out2 = nullptr;
+          if(t->p2_single > 1 && hipMalloc((void**)&d_gcur2, 2 * n_dest * sizeof(unsigned int)) == hipSuccess &&
+             hipMalloc((void**)&d_off2, 2 * n_dest * sizeof(uint64_t)) == hipSuccess &&
+             hipMalloc((void**)&out2, n_dest * cap2 * sizeof(ITEM)) == hipSuccess) own2 = true;
+          else { if(d_gcur2) hipFree(d_gcur2); if(d_off2) hipFree(d_off2); if(out2) hipFree(out2); cap2 = 0; }
+        }
+        if(cap2) HIP_TRY(hipMemsetAsync(d_gcur2, 0, 2 * n_dest * sizeof(unsigned int), t->stream));
       }
     }
-    std::vector<uint64_t> base(nb1);
-    { uint64_t run = 0; for(uint32_t j = 0; j < nb1; ++j) { base[j] = run; run += bucket_tot[j]; } }
-    HIP_TRY(hipMemcpyAsync(d_base, base.data(), nb1 * sizeof(uint64_t), hipMemcpyHostToDevice, t->stream));
+    if(getenv("JFGPU_FLUSH_TRACE"))
+      fprintf(stderr, "[flush] %llu items in %zu batches, %llu tiles, pairs %d, single-pass P2 regions of %u items (0: exact P2)\n",
+              (unsigned long long)total, nbatch, (unsigned long long)n_tiles, (int)pair, cap2);
+    if(!cap2) {
+      d_goff = (uint64_t*)ws_alloc(t, (n_tiles + 1) * sizeof(uint64_t));
+      d_base = (uint64_t*)ws_alloc(t, nb1 * sizeof(uint64_t));
+      tmp = (ITEM*)ws_alloc(t, std::max<uint64_t>(total, 1) * sizeof(ITEM));
+      if(!d_goff || !d_base || !tmp) {     // arena too small for the flush temporaries: one-off allocation
+        tmp_owned = true;
+        tmp = nullptr; d_goff = nullptr; d_base = nullptr;
+        HIP_TRY(hipMalloc((void**)&tmp, std::max<uint64_t>(total, 1) * sizeof(ITEM)));
+        if(hipMalloc((void**)&d_goff, (n_tiles + 1) * sizeof(uint64_t)) != hipSuccess ||
+           hipMalloc((void**)&d_base, nb1 * sizeof(uint64_t)) != hipSuccess) {
+          hipFree(tmp); if(d_goff) hipFree(d_goff);
+          return fail(JFGPU_E_ALLOC, "hipMalloc partition offsets");
+        }
+      }
+      std::vector<uint64_t> base(nb1);
+      { uint64_t run = 0; for(uint32_t j = 0; j < nb1; ++j) { base[j] = run; run += bucket_tot[j]; } }
+      HIP_TRY(hipMemcpyAsync(d_base, base.data(), nb1 * sizeof(uint64_t), hipMemcpyHostToDevice, t->stream));
+    }
     // Optionally (JFGPU_FLUSH_GROUPS > 1) the P1 buckets go through P2 and the tile insert in groups, P2 on the
     // table's stream and the tile insert on a second one, so that group g's tiles are inserted while group g+1
     // is partitioned (one P2-scatter block, 88 KB LDS, and one tile block, 64 KB, fit a CU together).
@@ -329,19 +370,57 @@ int part_flush_t(jfgpu_table* t) {
     hipEvent_t p2a = nullptr, p2b = nullptr, ta = nullptr, tb = nullptr;
     if(t->prof_on) { p2a = get_event(t); p2b = get_event(t); ta = get_event(t); tb = get_event(t); hipEventRecord(p2a, t->stream); }
     constexpr int per_thread = sizeof(ITEM) == 4 ? 16 : sizeof(ITEM) == 8 ? 8 : 4;
-    const uint32_t p2_tag_bits = kWideItems ? t->wt.W.tag_full : t->g.tag_bits;      // where an item's P2 sub-bucket starts
+    PartGeom pg2 = t->pg;
+    if(pair) pg2.b2 -= 1;
+    const uint32_t nb2e = 1u << pg2.b2;
+    const uint32_t p2_tag_bits = (kWideItems ? t->wt.W.tag_full : t->g.tag_bits) + (pair ? 1 : 0);      // where an item's P2 sub-bucket starts
     for(uint32_t g = 0; g < n_groups; ++g) {
       const uint32_t b0 = g * gsz, nbk = g + 1 == n_groups ? nb1 - b0 : gsz;
       const dim3 grid(g2, nbk), block(kPBlock);
-      hipLaunchKernelGGL((p2_kernel<ITEM, false>), grid, block, 0, t->stream, t->pg, p2_tag_bits, S1, t->d_M2, (const uint64_t*)d_goff, tmp, b0);
-      hipLaunchKernelGGL(scan_matrix_kernel, dim3(nbk), dim3(1024), 0, t->stream, t->d_M2, (uint32_t)g2, nb2, (const uint64_t*)d_base, d_goff, b0);
-      hipLaunchKernelGGL((p2_scatter_sorted_kernel<ITEM, per_thread>), grid, block, (size_t)kPBlock * per_thread * sizeof(ITEM), t->stream,
-                         t->pg, p2_tag_bits, S1, (const uint32_t*)t->d_M2, (const uint64_t*)d_goff, tmp, b0);
+      if constexpr(sizeof(ITEM) == 4) {
+        if(cap2) {
+          const dim3 g1p(kG2Single, nbk);
+          const size_t lds = (size_t)kPBlock * kP2PairPer * sizeof(ITEM);
+          if(rt) hipLaunchKernelGGL((p2_granule_kernel<true, kP2PairPer>), g1p, block, lds, t->stream, t->dt, t->pg, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest, out2, b0);
+          else   hipLaunchKernelGGL((p2_granule_kernel<false, kP2PairPer>), g1p, block, lds, t->stream, t->dt, t->pg, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest, out2, b0);
+          const uint64_t d0 = (uint64_t)b0 << pg2.b2, nd = (uint64_t)nbk << pg2.b2;
+          // (granule_finish_kernel reads gcur[nb + j] as destination j's overflow note: the two halves of d_gcur2)
+          if(n_groups == 1) hipLaunchKernelGGL(granule_finish_kernel, dim3(1024), dim3(256), 0, t->stream, d_gcur2, cap2, (uint32_t)n_dest, d_off2);
+          else hipLaunchKernelGGL(granule_finish_range_kernel, dim3(256), dim3(256), 0, t->stream, d_gcur2, cap2, (uint32_t)n_dest, d_off2, (uint32_t)d0, (uint32_t)nd);
+          if(t->prof_on && g + 1 == n_groups) hipEventRecord(p2b, t->stream);
+          SegList S2; memset(&S2, 0, sizeof S2);
+          S2.n = 1; S2.items[0] = out2; S2.off[0] = d_off2 + 2 * d0; S2.sh[0] = 1;
+          hipStream_t ts = t->stream;
+          if(n_groups > 1) {
+            HIP_TRY(hipEventRecord(t->flush_ev[g & 1], t->stream));
+            HIP_TRY(hipStreamWaitEvent(t->stream2, t->flush_ev[g & 1], 0));
+            ts = t->stream2;
+          }
+          if(t->prof_on && g == 0) hipEventRecord(ta, ts);
+          // S2.off is relative to the group, the items are not: pair d of the whole table sits at d * cap2
+          launch_tile_kernel(S2, (uint64_t)b0 << t->pg.b2, (uint32_t)nd, ts, true);
+          if(t->prof_on && g + 1 == n_groups) hipEventRecord(tb, ts);
+          continue;
+        }
+      }
+      hipLaunchKernelGGL((p2_kernel<ITEM, false>), grid, block, 0, t->stream, pg2, p2_tag_bits, S1, t->d_M2, (const uint64_t*)d_goff, tmp, b0);
+      hipLaunchKernelGGL(scan_matrix_kernel, dim3(nbk), dim3(1024), 0, t->stream, t->d_M2, (uint32_t)g2, nb2e, (const uint64_t*)d_base, d_goff, b0);
+      bool launched = false;
+      if constexpr(sizeof(ITEM) == 4) {
+        if(pair) {
+          hipLaunchKernelGGL((p2_scatter_sorted_kernel<ITEM, kP2PairPer>), grid, block, (size_t)kPBlock * kP2PairPer * sizeof(ITEM), t->stream,
+                             pg2, p2_tag_bits, S1, (const uint32_t*)t->d_M2, (const uint64_t*)d_goff, tmp, b0);
+          launched = true;
+        }
+      }
+      if(!launched)
+        hipLaunchKernelGGL((p2_scatter_sorted_kernel<ITEM, per_thread>), grid, block, (size_t)kPBlock * per_thread * sizeof(ITEM), t->stream,
+                           pg2, p2_tag_bits, S1, (const uint32_t*)t->d_M2, (const uint64_t*)d_goff, tmp, b0);
       if(t->prof_on && g + 1 == n_groups) hipEventRecord(p2b, t->stream);
       const uint64_t tile_start = (uint64_t)b0 << t->pg.b2;
-      const uint32_t ntile = nbk << t->pg.b2;
+      const uint32_t ntile = nbk << pg2.b2;                 // units of the tile kernel: tiles, or pairs of tiles
       SegList S2; memset(&S2, 0, sizeof S2);
-      S2.n = 1; S2.items[0] = tmp; S2.off[0] = d_goff + tile_start;
+      S2.n = 1; S2.items[0] = tmp; S2.off[0] = d_goff + ((uint64_t)b0 << pg2.b2);
       hipStream_t ts = t->stream;
       if(n_groups > 1) {
         HIP_TRY(hipEventRecord(t->flush_ev[g & 1], t->stream));
@@ -349,7 +428,7 @@ int part_flush_t(jfgpu_table* t) {
         ts = t->stream2;
       }
       if(t->prof_on && g == 0) hipEventRecord(ta, ts);
-      launch_tile_kernel(S2, tile_start, ntile, ts);
+      launch_tile_kernel(S2, tile_start, ntile, ts, pair);
       if(t->prof_on && g + 1 == n_groups) hipEventRecord(tb, ts);
     }
     if(t->prof_on) {
@@ -362,6 +441,7 @@ int part_flush_t(jfgpu_table* t) {
     }
     hipError_t e = hipStreamSynchronize(t->stream);
     if(tmp_owned) { hipFree(tmp); hipFree(d_goff); hipFree(d_base); }
+    if(own2) { hipFree(d_gcur2); hipFree(d_off2); hipFree(out2); }
     if(e != hipSuccess) return fail(JFGPU_E_HIP, hipGetErrorString(e));
   }
   hipError_t e = hipGetLastError();

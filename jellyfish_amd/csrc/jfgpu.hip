@@ -106,6 +106,11 @@ struct jfgpu_table {
   GlibcRandom glibc;
   int (*spill_fn)(void*) = nullptr; void* spill_user = nullptr;     // jfgpu_set_spill
   int operation = 0;             // what count_ascii does with a k-mer: 0 add, 1 set (prime), 2 update_add (jfgpu_set_operation)
+  int p2_single = 1;             // ... and in one pass, reservations inside fixed regions (JFGPU_P2_SINGLE: 0 exact count + scatter, 1 when the
+                                 // regions would be mostly items, 2 always); p2_cap: test knob, items per region
+  uint32_t p2_cap = 0;
+  double p2_slack = 0.08;        // head-room of those regions over the mean load of a pair (JFGPU_P2_SLACK)
+  bool tile_pair = true;         // 32-bit slots: P2 routes to pairs of tiles (JFGPU_TILE_PAIR=0: single tiles, for A/B)
   int flush_groups = 1;          // P2 / tile-insert pipeline depth of a flush (JFGPU_FLUSH_GROUPS).  Measured: 8 groups on two
                                  // streams run P2 and T concurrently but no faster (both are LDS-bound), so one launch each is the default
   hipStream_t stream2 = nullptr; hipEvent_t flush_ev[2] = {nullptr, nullptr}; hipEvent_t flush_done = nullptr;
@@ -585,6 +590,10 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
   if(const char* m = getenv("JFGPU_P1_SINGLE")) t->p1_single = atoi(m) ? 1 : 0;     // tuning / test knobs of the single-pass P1
   if(const char* m = getenv("JFGPU_P1_SLACK")) t->p1_slack = atof(m);
   if(const char* m = getenv("JFGPU_FLUSH_GROUPS")) t->flush_groups = std::max(1, atoi(m));
+  if(const char* m = getenv("JFGPU_TILE_PAIR")) t->tile_pair = atoi(m) != 0;
+  if(const char* m = getenv("JFGPU_P2_SINGLE")) t->p2_single = atoi(m);
+  if(const char* m = getenv("JFGPU_P2_CAP")) t->p2_cap = (uint32_t)atoi(m) / kGran * kGran;
+  if(const char* m = getenv("JFGPU_P2_SLACK")) t->p2_slack = atof(m);
   {
     const int tl = (int)((size_t)8 << t->g.tile_bits);
 #define TATTR(I, R, L) HIP_TRY(hipFuncSetAttribute((const void*)tile_insert_kernel<I, R, L, unsigned long long, kPBlock>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 << kMaxTileBits))
@@ -613,6 +622,11 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_granule_kernel<false, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_granule_kernel<true, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint32_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * 16 * 4));
+    HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<true, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
+    HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<false, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
+    HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint32_t, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
+    HIP_TRY(hipFuncSetAttribute((const void*)tile_insert_kernel<uint32_t, true, true, unsigned int, kPBlock, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 << kMaxTileBits));
+    HIP_TRY(hipFuncSetAttribute((const void*)tile_insert_kernel<uint32_t, false, true, unsigned int, kPBlock, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 << kMaxTileBits));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint64_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * 8 * 8));
     const int gl = kG64Chunk * 10;
     HIP_TRY(hipFuncSetAttribute((const void*)p1_granule64_kernel<true, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, gl));
@@ -701,8 +715,8 @@ int jfgpu_sync(jfgpu_table* t) {
     if(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_phase_prof), sizeof c) == hipSuccess) {
       fprintf(stderr, "[phase prof] P1: stage %llu  encode+hash+hist %llu  scan %llu  place+lds-scatter %llu  (barrier) %llu  write-out %llu  finish %llu\n",
               c[0], c[1], c[2], c[3], c[4], c[5], c[6]);
-      fprintf(stderr, "[phase prof] P2: (barrier) %llu  load %llu  hist %llu  scan %llu  lds-scatter %llu  write-out %llu\n",
-              c[8], c[9], c[10], c[11], c[12], c[13]);
+      fprintf(stderr, "[phase prof] P2: (barrier) %llu  load %llu  hist %llu  scan %llu  lds-scatter %llu  write-out %llu  finish %llu\n",
+              c[8], c[9], c[10], c[11], c[12], c[13], c[14]);
       (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_prof), z, sizeof z);
     } }
 #endif

@@ -245,12 +245,20 @@ __global__ __launch_bounds__(kPBlock) void p2_kernel(PartGeom P, uint32_t tag_bi
     if(a >= b) continue;
     const ITEM* src = reinterpret_cast<const ITEM*>(S.items[s]) + seg_lo(S, s, bucket) - slo;
     const bool holes = S.sh[s] != 0;                      // block-uniform
-    for(uint64_t v = a + threadIdx.x; v < b; v += blockDim.x) {
-      const ITEM it = src[v];
-      if(holes && it == (ITEM)~(ITEM)0) continue;
-      const uint32_t d = (uint32_t)(it >> tag_bits) & (nb - 1);
-      const unsigned long long at = atomicAdd(&s_cur[d], 1ull);
-      if(SCATTER) out[at] = it;
+    constexpr int U = sizeof(ITEM) >= 16 ? 4 : 8;          // loads in flight per lane
+    for(uint64_t v0 = a + threadIdx.x; v0 < b; v0 += (uint64_t)blockDim.x * U) {
+      ITEM x[U];
+#pragma unroll
+      for(int r = 0; r < U; ++r) { const uint64_t v = v0 + (uint64_t)r * blockDim.x; x[r] = v < b ? src[v] : (ITEM)0; }
+#pragma unroll
+      for(int r = 0; r < U; ++r) {
+        if(v0 + (uint64_t)r * blockDim.x >= b) break;
+        const ITEM it = x[r];
+        if(holes && it == (ITEM)~(ITEM)0) continue;
+        const uint32_t d = (uint32_t)(it >> tag_bits) & (nb - 1);
+        const unsigned long long at = atomicAdd(&s_cur[d], 1ull);
+        if(SCATTER) out[at] = it;
+      }
     }
   }
   if(!SCATTER) {
@@ -421,6 +429,7 @@ __global__ __launch_bounds__(kPBlock) void p1_keys_scatter_sorted_kernel(DevTabl
 // items by destination bucket in LDS and then writes whole runs (consecutive lanes ->
 // consecutive addresses).  Same block->slice assignment and per-(block, bucket) cursors as
 // p2_kernel<.., false> counted, so positions are exact and no global atomic is needed.
+constexpr int kP2PairPer = 28;      // items per lane and chunk when P2 routes to pairs of tiles (28 Ki items = 112 KiB of LDS; 32 would spill registers)
 template <typename ITEM, int PER_THREAD>
 __global__ __launch_bounds__(kPBlock) void p2_scatter_sorted_kernel(PartGeom P, uint32_t tag_bits, SegList S,
                                                                     const uint32_t* __restrict__ M,
@@ -443,39 +452,59 @@ __global__ __launch_bounds__(kPBlock) void p2_scatter_sorted_kernel(PartGeom P, 
   const uint64_t per = (n + gridDim.x - 1) / gridDim.x;
   const uint64_t my_lo = (uint64_t)blockIdx.x * per, my_hi = my_lo + per < n ? my_lo + per : n;
   PhaseClk pc;
-  for(uint64_t c0 = my_lo; c0 < my_hi; c0 += kChunk) {
-    const uint64_t c1 = c0 + kChunk < my_hi ? c0 + kChunk : my_hi;
-    lds_barrier();                                      // previous chunk's readers of s_hist/s_lstart/s_item are done
-    JF_PHASE(pc, 0);
-    // the cursor of bucket d advances by what the previous chunk wrote; delta is re-based on the new lstart below
-    for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) { s_delta[j] += s_hist[j] + s_lstart[j]; s_hist[j] = 0; }
-    ITEM it[PER_THREAD]; uint32_t dr[PER_THREAD];       // digit << 16 | rank inside the chunk
+  // One chunk's items into registers (vm: which of the lane's PER_THREAD positions hold an item, hm: which of those came
+  // from a batch with holes).  No use of the loaded values here, so all the loads of a chunk are in flight together --
+  // and the next chunk's are issued before the current one is sorted, so their latency hides behind the LDS work.
+  // Addresses are a block-uniform base (the chunk's first item inside the batch) plus a 32-bit lane offset, so the loads
+  // of a chunk share one offset register instead of carrying a 64-bit address each.
+  auto load_chunk = [&](uint64_t c0, ITEM (&it)[PER_THREAD], uint32_t& vm, uint32_t& hm) {
+    vm = 0; hm = 0;
 #pragma unroll
-    for(int r = 0; r < PER_THREAD; ++r) { dr[r] = 0xFFFFFFFFu; it[r] = 0; }
+    for(int r = 0; r < PER_THREAD; ++r) it[r] = 0;
+    if(c0 >= my_hi) return;                             // block-uniform
+    const uint32_t cn = my_hi - c0 < (uint64_t)kChunk ? (uint32_t)(my_hi - c0) : (uint32_t)kChunk;
     uint64_t slo = 0;
-    uint32_t hm = 0;                                    // items that came from a batch with holes
     for(uint32_t s = 0; s < S.n; ++s) {                 // uniform loop: usually one or two batches overlap a chunk
       const uint64_t o0 = seg_lo(S, s, bucket), len = seg_hi(S, s, bucket) - o0, shi = slo + len;
-      if(shi > c0 && slo < c1) {
-        const ITEM* src = reinterpret_cast<const ITEM*>(S.items[s]) + o0;
+      if(shi > c0 && slo < c0 + cn) {
+        const uint32_t lo_rel = slo > c0 ? (uint32_t)(slo - c0) : 0u;                 // the batch's part of this chunk,
+        const uint32_t hi_rel = shi < c0 + cn ? (uint32_t)(shi - c0) : cn;            // in chunk-relative positions
+        const ITEM* src = reinterpret_cast<const ITEM*>(S.items[s]) + (int64_t)o0 + ((int64_t)c0 - (int64_t)slo);
         const bool holes = S.sh[s] != 0;
 #pragma unroll
         for(int r = 0; r < PER_THREAD; ++r) {
-          const uint64_t v = c0 + (uint64_t)r * kPBlock + threadIdx.x;
-          if(v < c1 && v >= slo && v < shi) { it[r] = src[v - slo]; dr[r] = 0; if(holes) hm |= 1u << r; }   // no use of the loaded value here: 16 loads in flight
+          const uint32_t rel = (uint32_t)r * kPBlock + threadIdx.x;
+          if(rel >= lo_rel && rel < hi_rel) { it[r] = src[rel]; vm |= 1u << r; if(holes) hm |= 1u << r; }
         }
       }
       slo = shi;
     }
+  };
+  ITEM nxt[PER_THREAD]; uint32_t nvm = 0, nhm = 0;
+  load_chunk(my_lo, nxt, nvm, nhm);
+  for(uint64_t c0 = my_lo; c0 < my_hi; c0 += kChunk) {
+    lds_barrier();                                      // previous chunk's readers of s_hist/s_lstart/s_item are done
+    JF_PHASE(pc, 0);
+    // the cursor of bucket d advances by what the previous chunk wrote; delta is re-based on the new lstart below
+    for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) { s_delta[j] += s_hist[j] + s_lstart[j]; s_hist[j] = 0; }
+    ITEM it[PER_THREAD];
+    uint32_t rk[(PER_THREAD + 1) / 2];                  // rank inside the chunk's bucket, 16 bits each (a chunk holds <= 32768 items)
+    const uint32_t hm = nhm;
+    uint32_t vm = nvm;
+#pragma unroll
+    for(int r = 0; r < PER_THREAD; ++r) it[r] = nxt[r];
+    load_chunk(c0 + kChunk, nxt, nvm, nhm);
     lds_barrier();
     JF_PHASE(pc, 1);
 #pragma unroll
-    for(int r = 0; r < PER_THREAD; ++r)
-      if(dr[r] != 0xFFFFFFFFu) {
-        if(((hm >> r) & 1) && it[r] == (ITEM)~(ITEM)0) { dr[r] = 0xFFFFFFFFu; continue; }   // a hole
-        const uint32_t d = (uint32_t)(it[r] >> tag_bits) & (nb - 1);
-        dr[r] = (d << 16) | atomicAdd(&s_hist[d], 1u);
+    for(int r = 0; r < PER_THREAD; ++r) {
+      uint32_t rank = 0;
+      if((vm >> r) & 1) {
+        if(((hm >> r) & 1) && it[r] == (ITEM)~(ITEM)0) vm &= ~(1u << r);   // a hole
+        else rank = atomicAdd(&s_hist[(uint32_t)(it[r] >> tag_bits) & (nb - 1)], 1u);
       }
+      if(r & 1) rk[r >> 1] |= rank << 16; else rk[r >> 1] = rank;
+    }
     lds_barrier();
     JF_PHASE(pc, 2);
     block_excl_scan_2048(s_hist, s_lstart, nb, s_wave);
@@ -484,7 +513,7 @@ __global__ __launch_bounds__(kPBlock) void p2_scatter_sorted_kernel(PartGeom P, 
     for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) s_delta[j] -= s_lstart[j];
 #pragma unroll
     for(int r = 0; r < PER_THREAD; ++r)
-      if(dr[r] != 0xFFFFFFFFu) s_item[s_lstart[dr[r] >> 16] + (dr[r] & 0xFFFFu)] = it[r];
+      if((vm >> r) & 1) s_item[s_lstart[(uint32_t)(it[r] >> tag_bits) & (nb - 1)] + ((rk[r >> 1] >> ((r & 1) * 16)) & 0xFFFFu)] = it[r];
     lds_barrier();
     JF_PHASE(pc, 4);
     const uint32_t cn = s_lstart[nb - 1] + s_hist[nb - 1];       // items of this chunk that are not holes
@@ -532,27 +561,58 @@ __device__ inline void tile_insert_one(const DevTable& T, SLOT* s_tile, uint64_t
 // SLOT: the LDS word of one slot (see tile_insert_one); BLOCK: threads per workgroup.  64-bit slots: 64 KiB tiles, two
 // workgroups of 1024 per CU.  32-bit slots: 32 KiB tiles, four workgroups of 512 per CU -- the insert phase is a chain
 // of dependent LDS atomics per lane, and more tiles in flight per CU is what hides it behind the tile loads and stores.
-template <typename ITEM, bool RETURNING, bool LOAD, typename SLOT, int BLOCK>
+// TPB = 2 (32-bit slots): the workgroup owns two adjacent tiles (one contiguous 64 KiB range of the table) and the
+// offsets index such pairs; an item's tile inside the pair is the lowest bit of its tile field.  P2 then has half as many
+// destinations, so the runs it writes are twice as long (what P2 costs is set by the length of those runs:
+// tools/probes/scatter_write_probe.hip).
+template <typename ITEM, bool RETURNING, bool LOAD, typename SLOT, int BLOCK, int TPB = 1>
 __global__ __launch_bounds__(BLOCK, 2048 / 256) void tile_insert_kernel(DevTable T, SegList S, uint64_t tile0, uint32_t n_tiles) {
   JF_DYN_LDS(s_raw);
   SLOT* s_tile = reinterpret_cast<SLOT*>(s_raw);
   const TableGeom& g = T.g;
-  const uint32_t tsz = 1u << g.tile_bits;
+  const uint32_t tsz = 1u << g.tile_bits;                               // slots of one tile
   constexpr uint32_t kVec = 16 / sizeof(SLOT);                          // slots per 16-byte vector
   SLOT* const gslots = reinterpret_cast<SLOT*>(T.slots);
-  if(S.n == 1 && S.sh[0] == 0) {
+  // n_tiles counts units of TPB tiles; unit t = tiles tile0 + TPB * t ..  (tile0 is a multiple of TPB)
+  auto unit_dirty = [&](uint32_t t) -> uint32_t {
+    if(!LOAD) return 0u;
+    if(TPB == 2) return *reinterpret_cast<const uint16_t*>(T.dirty + tile0 + 2 * (uint64_t)t);
+    return T.dirty[tile0 + t];
+  };
+  auto fill = [&](SLOT* gt, uint32_t d) {
+    for(uint32_t i = threadIdx.x * kVec; i < TPB * tsz; i += BLOCK * kVec) {   // tile(s) -> LDS, 16 B per lane per step
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if(LOAD && ((d >> (8 * (i >> g.tile_bits))) & 0xFFu)) v = *reinterpret_cast<const uint4*>(gt + i);
+      *reinterpret_cast<uint4*>(s_tile + i) = v;
+    }
+  };
+  auto store = [&](SLOT* gt, uint32_t t) {
+    for(uint32_t i = threadIdx.x * kVec; i < TPB * tsz; i += BLOCK * kVec)
+      *reinterpret_cast<uint4*>(gt + i) = *reinterpret_cast<const uint4*>(s_tile + i);
+    if(threadIdx.x == 0) {
+      if(TPB == 2) *reinterpret_cast<uint16_t*>(T.dirty + tile0 + 2 * (uint64_t)t) = 0x0101;
+      else T.dirty[tile0 + t] = 1;
+    }
+  };
+  auto insert = [&](ITEM x, uint32_t t) {
+    const uint32_t half = TPB == 2 ? (uint32_t)((uint64_t)x >> g.tag_bits) & 1u : 0u;
+    tile_insert_one<ITEM, RETURNING>(T, s_tile + half * tsz, (uint64_t)x, tile0 + (uint64_t)TPB * t + half);
+  };
+  if(S.n == 1) {
     // Fast path (one packed item array, e.g. the P2 output).  Software pipeline over this block's
     // tiles: offsets are fetched two tiles ahead and the items one tile ahead into registers, so the
     // dependent global loads (offset -> items) never sit on the critical path of a tile.
-    constexpr int NP = 6144 / BLOCK;                        // register-prefetched items per lane (6144 per tile)
+    constexpr int NP = TPB == 2 ? 9 : 6144 / BLOCK;         // register-prefetched items per lane (6144 per tile; 9216 per pair: 64 VGPRs)
     const uint64_t* off = S.off[0];
+    const uint32_t sh = S.sh[0];                            // 0: packed offsets off[t], off[t + 1]; 1: pairs (begin, end), items may be holes
+    const bool holes = sh != 0;
     const ITEM* src = reinterpret_cast<const ITEM*>(S.items[0]);
     const uint32_t G = gridDim.x;
     uint32_t t = blockIdx.x;
-    uint64_t a0 = 0, b0 = 0, a1 = 0, b1 = 0; uint8_t d0 = 0, d1 = 0;
+    uint64_t a0 = 0, b0 = 0, a1 = 0, b1 = 0; uint32_t d0 = 0, d1 = 0;
     ITEM cur[NP];
-    if(t < n_tiles) { a0 = off[t]; b0 = off[t + 1]; d0 = LOAD ? T.dirty[tile0 + t] : 0; }
-    if(t + G < n_tiles) { a1 = off[t + G]; b1 = off[t + G + 1]; d1 = LOAD ? T.dirty[tile0 + t + G] : 0; }
+    if(t < n_tiles) { a0 = off[(size_t)t << sh]; b0 = off[((size_t)t << sh) + 1]; d0 = unit_dirty(t); }
+    if(t + G < n_tiles) { a1 = off[(size_t)(t + G) << sh]; b1 = off[((size_t)(t + G) << sh) + 1]; d1 = unit_dirty(t + G); }
 #pragma unroll
     for(int r = 0; r < NP; ++r) { const uint64_t v = a0 + (uint64_t)r * BLOCK + threadIdx.x; cur[r] = v < b0 ? src[v] : (ITEM)0; }
 #ifdef JFGPU_TILE_PROF
@@ -563,32 +623,27 @@ __global__ __launch_bounds__(BLOCK, 2048 / 256) void tile_insert_kernel(DevTable
 #endif
     for(; t < n_tiles; t += G) {
       // issue the loads of the following tiles first
-      uint64_t a2 = 0, b2 = 0; uint8_t d2 = 0;
-      if(t + 2 * G < n_tiles) { a2 = off[t + 2 * G]; b2 = off[t + 2 * G + 1]; d2 = LOAD ? T.dirty[tile0 + t + 2 * G] : 0; }
+      uint64_t a2 = 0, b2 = 0; uint32_t d2 = 0;
+      if(t + 2 * G < n_tiles) { a2 = off[(size_t)(t + 2 * G) << sh]; b2 = off[((size_t)(t + 2 * G) << sh) + 1]; d2 = unit_dirty(t + 2 * G); }
       ITEM nxt[NP];
 #pragma unroll
       for(int r = 0; r < NP; ++r) { const uint64_t v = a1 + (uint64_t)r * BLOCK + threadIdx.x; nxt[r] = v < b1 ? src[v] : (ITEM)0; }
       TP(pc0);
       if(b0 > a0) {                                          // block-uniform
-        SLOT* gt = gslots + ((tile0 + t) << g.tile_bits);
-        const bool load = LOAD && d0 != 0;
-        for(uint32_t i = threadIdx.x * kVec; i < tsz; i += BLOCK * kVec) {
-          uint4 v = make_uint4(0, 0, 0, 0);
-          if(load) v = *reinterpret_cast<const uint4*>(gt + i);
-          *reinterpret_cast<uint4*>(s_tile + i) = v;
-        }
+        SLOT* gt = gslots + ((tile0 + (uint64_t)TPB * t) << g.tile_bits);
+        fill(gt, d0);
         lds_barrier();
         TP(pc1);
 #pragma unroll
         for(int r = 0; r < NP; ++r)
-          if(a0 + (uint64_t)r * BLOCK + threadIdx.x < b0) tile_insert_one<ITEM, RETURNING>(T, s_tile, (uint64_t)cur[r], tile0 + t);
-        for(uint64_t v = a0 + (uint64_t)NP * BLOCK + threadIdx.x; v < b0; v += BLOCK)   // rare: an over-full tile
-          tile_insert_one<ITEM, RETURNING>(T, s_tile, (uint64_t)src[v], tile0 + t);
+          if(a0 + (uint64_t)r * BLOCK + threadIdx.x < b0 && !(holes && cur[r] == (ITEM)~(ITEM)0)) insert(cur[r], t);
+        for(uint64_t v = a0 + (uint64_t)NP * BLOCK + threadIdx.x; v < b0; v += BLOCK) {   // rare: an over-full tile
+          const ITEM x = src[v];
+          if(!(holes && x == (ITEM)~(ITEM)0)) insert(x, t);
+        }
         lds_barrier();
         TP(pc2);
-        for(uint32_t i = threadIdx.x * kVec; i < tsz; i += BLOCK * kVec)
-          *reinterpret_cast<uint4*>(gt + i) = *reinterpret_cast<const uint4*>(s_tile + i);
-        if(threadIdx.x == 0) T.dirty[tile0 + t] = 1;
+        store(gt, t);
         lds_barrier();
         TP(pc3);
       }
@@ -612,13 +667,8 @@ __global__ __launch_bounds__(BLOCK, 2048 / 256) void tile_insert_kernel(DevTable
     uint64_t n_items = 0;
     for(uint32_t s = 0; s < S.n; ++s) n_items += seg_hi(S, s, t) - seg_lo(S, s, t);
     if(n_items == 0) continue;                                   // block-uniform
-    SLOT* gt = gslots + ((tile0 + t) << g.tile_bits);
-    const bool load = LOAD && T.dirty[tile0 + t] != 0;              // block-uniform
-    for(uint32_t i = threadIdx.x * kVec; i < tsz; i += BLOCK * kVec) {   // tile -> LDS, 16 B per lane per step
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if(load) v = *reinterpret_cast<const uint4*>(gt + i);
-      *reinterpret_cast<uint4*>(s_tile + i) = v;
-    }
+    SLOT* gt = gslots + ((tile0 + (uint64_t)TPB * t) << g.tile_bits);
+    fill(gt, unit_dirty(t));
     lds_barrier();
     for(uint32_t s = 0; s < S.n; ++s) {
       const uint64_t a = seg_lo(S, s, t), b = seg_hi(S, s, t);
@@ -626,13 +676,11 @@ __global__ __launch_bounds__(BLOCK, 2048 / 256) void tile_insert_kernel(DevTable
       const bool holes = S.sh[s] != 0;
       for(uint64_t v = a + threadIdx.x; v < b; v += BLOCK) {
         const ITEM x = src[v];
-        if(!(holes && x == (ITEM)~(ITEM)0)) tile_insert_one<ITEM, RETURNING>(T, s_tile, (uint64_t)x, tile0 + t);
+        if(!(holes && x == (ITEM)~(ITEM)0)) insert(x, t);
       }
     }
     lds_barrier();
-    for(uint32_t i = threadIdx.x * kVec; i < tsz; i += BLOCK * kVec)
-      *reinterpret_cast<uint4*>(gt + i) = *reinterpret_cast<const uint4*>(s_tile + i);
-    if(threadIdx.x == 0) T.dirty[tile0 + t] = 1;
+    store(gt, t);
     lds_barrier();
   }
 }
@@ -708,9 +756,9 @@ struct GranuleLds {
   uint16_t room[kGranMaxB];     // items left in the current reservation
   uint32_t hist[kGranMaxB];
   uint32_t lstart[kGranMaxB];
-  uint32_t pos0[kGranMaxB];     // where this chunk's run of bucket b starts ...
-  uint16_t split[kGranMaxB];    // ... how many of its items fit there ...
-  uint32_t pos1[kGranMaxB];     // ... and where the rest goes (kNoRoom: region exhausted)
+  uint4 place[kGranMaxB];       // this chunk's run of bucket b, in terms of the item's index i in the sorted chunk:
+                                //   x: i < x goes to region position i + y (the current reservation), the rest to i + z (a new one)
+                                //   w != 0: there is no new one (region exhausted), the rest is inserted directly
   uint32_t cnt[kGranMaxB];      // items this block stored per bucket
   uint32_t wave[16];
 };
@@ -723,10 +771,13 @@ __device__ inline void granule_init(GranuleLds& G, uint32_t nb) {
 // direct(b, item): what to do with an item that cannot be stored in bucket b's region (region exhausted, or the item
 // equals the hole marker) -- the count path inserts it with global atomics, the Bloom path bumps its cell.
 // ITEM: uint32_t (one-word keys, Bloom cell updates) or unsigned __int128 (two-word keys); the hole marker is all ones.
-template <typename ITEM, int N, typename DIRECT>
-__device__ inline uint32_t granule_emit(GranuleLds& G, uint32_t nb, uint32_t cap,
-                                        unsigned int* __restrict__ gcur, ITEM* __restrict__ out, ITEM* s_item, uint16_t* s_bkt,
-                                        const ITEM (&it)[N], const uint32_t (&dr)[N], DIRECT&& direct_fn, PhaseClk* pc = nullptr) {
+// gshort[b]: the overflow note of bucket b (see granule_finish_kernel).  bkt_of(i, v): bucket of the i-th item of the
+// sorted chunk -- read back from s_bkt (P1: the bucket is not part of the item) or recomputed from the item (P2).
+// scatter_fn(): the caller's items into the sorted chunk s_item (and s_bkt), item of bucket b with rank r at G.lstart[b] + r.
+template <typename ITEM, typename DIRECT, typename BKTOF, typename SCATTER>
+__device__ inline uint32_t granule_emit_x(GranuleLds& G, uint32_t nb, uint32_t cap, unsigned int* __restrict__ gcur, unsigned int* __restrict__ gshort,
+                                          ITEM* __restrict__ out, const ITEM* s_item,
+                                          SCATTER&& scatter_fn, DIRECT&& direct_fn, BKTOF&& bkt_of, PhaseClk* pc = nullptr) {
   lds_barrier();
   if(pc) JF_PHASE(*pc, 2);
   block_excl_scan_2048(G.hist, G.lstart, nb, G.wave);
@@ -741,22 +792,17 @@ __device__ inline uint32_t granule_emit(GranuleLds& G, uint32_t nb, uint32_t cap
     ph = G.hist[pb]; proom = G.room[pb]; pcur = G.cur[pb];
     if(ph > proom) { need = ph - proom; take = (need + kGran - 1) / kGran * kGran; g0 = atomicAdd(&gcur[pb], take); }
   }
-#pragma unroll
-  for(int e = 0; e < N; ++e)
-    if(dr[e] != 0xFFFFFFFFu) {
-      const uint32_t at = G.lstart[dr[e] >> 16] + (dr[e] & 0xFFFFu);
-      s_item[at] = it[e]; s_bkt[at] = (uint16_t)(dr[e] >> 16);
-    }
+  scatter_fn();
   if(pb < nb) {
-    G.pos0[pb] = pcur;
-    if(!take) { G.split[pb] = (uint16_t)ph; G.cur[pb] = pcur + ph; G.room[pb] = (uint16_t)(proom - ph); G.cnt[pb] += ph; }
-    else {
-      G.split[pb] = (uint16_t)proom;
-      if((uint64_t)g0 + take <= cap) { G.pos1[pb] = g0; G.cur[pb] = g0 + need; G.room[pb] = (uint16_t)(take - need); G.cnt[pb] += ph; }
-      else {                                                                                 // region exhausted
-        G.pos1[pb] = kNoRoom; G.cur[pb] = pcur + proom; G.room[pb] = 0; G.cnt[pb] += proom;
-        if(g0 < cap) atomicMax(&gcur[nb + pb], cap - g0);       // everything below g0 was handed out successfully
-      }
+    const uint32_t ls = G.lstart[pb];
+    if(!take) { G.place[pb] = make_uint4(ls + ph, pcur - ls, 0u, 0u); G.cur[pb] = pcur + ph; G.room[pb] = (uint16_t)(proom - ph); G.cnt[pb] += ph; }
+    else if((uint64_t)g0 + take <= cap) {
+      G.place[pb] = make_uint4(ls + proom, pcur - ls, g0 - ls - proom, 0u);
+      G.cur[pb] = g0 + need; G.room[pb] = (uint16_t)(take - need); G.cnt[pb] += ph;
+    } else {                                                                                 // region exhausted
+      G.place[pb] = make_uint4(ls + proom, pcur - ls, 0u, 1u);
+      G.cur[pb] = pcur + proom; G.room[pb] = 0; G.cnt[pb] += proom;
+      if(g0 < cap) atomicMax(&gshort[pb], cap - g0);          // everything below g0 was handed out successfully
     }
   }
   lds_barrier();
@@ -765,11 +811,12 @@ __device__ inline uint32_t granule_emit(GranuleLds& G, uint32_t nb, uint32_t cap
   const uint32_t cn = G.lstart[nb - 1] + G.hist[nb - 1];
   const ITEM hole = (ITEM)~(ITEM)0;
   for(uint32_t i = threadIdx.x; i < cn; i += blockDim.x) {
-    const uint32_t b = s_bkt[i], r = i - G.lstart[b], sp = G.split[b];
     const ITEM v = s_item[i];
-    uint32_t rel = G.pos0[b] + r;
+    const uint32_t b = bkt_of(i, v);
+    const uint4 w = G.place[b];
+    uint32_t rel = i + w.y;
     bool direct = false;
-    if(r >= sp) { const uint32_t p1 = G.pos1[b]; if(p1 == kNoRoom) direct = true; else rel = p1 + (r - sp); }
+    if(i >= w.x) { if(w.w) direct = true; else rel = i + w.z; }
     if(!direct) {
       out[(uint64_t)b * cap + rel] = v;
       if(v == hole) { direct = true; atomicSub(&G.cnt[b], 1u); }   // its slot now reads as a hole
@@ -780,6 +827,22 @@ __device__ inline uint32_t granule_emit(GranuleLds& G, uint32_t nb, uint32_t cap
   return direct_n;
 }
 
+template <typename ITEM, int N, typename DIRECT>
+__device__ inline uint32_t granule_emit(GranuleLds& G, uint32_t nb, uint32_t cap,
+                                        unsigned int* __restrict__ gcur, ITEM* __restrict__ out, ITEM* s_item, uint16_t* s_bkt,
+                                        const ITEM (&it)[N], const uint32_t (&dr)[N], DIRECT&& direct_fn, PhaseClk* pc = nullptr) {
+  return granule_emit_x<ITEM>(G, nb, cap, gcur, gcur + nb, out, s_item,
+                              [&]() {
+#pragma unroll
+                                for(int e = 0; e < N; ++e)
+                                  if(dr[e] != 0xFFFFFFFFu) {
+                                    const uint32_t at = G.lstart[dr[e] >> 16] + (dr[e] & 0xFFFFu);
+                                    s_item[at] = it[e]; s_bkt[at] = (uint16_t)(dr[e] >> 16);
+                                  }
+                              },
+                              direct_fn, [&](uint32_t i, ITEM) -> uint32_t { return s_bkt[i]; }, pc);
+}
+
 // Kernel end: unused tails of the last reservations become holes, exact per-bucket counts go to tot.
 template <typename ITEM>
 __device__ inline void granule_finish(GranuleLds& G, uint32_t nb, uint32_t cap, unsigned long long* __restrict__ tot, ITEM* __restrict__ out) {
@@ -787,7 +850,7 @@ __device__ inline void granule_finish(GranuleLds& G, uint32_t nb, uint32_t cap, 
   for(uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {
     const uint32_t room = G.room[b], cur = G.cur[b];
     for(uint32_t r = 0; r < room; ++r) out[(uint64_t)b * cap + cur + r] = (ITEM)~(ITEM)0;
-    if(G.cnt[b]) atomicAdd(&tot[b], (unsigned long long)G.cnt[b]);
+    if(tot && G.cnt[b]) atomicAdd(&tot[b], (unsigned long long)G.cnt[b]);
   }
 }
 
@@ -979,10 +1042,103 @@ __global__ __launch_bounds__(kPBlock) void p1_keys_granule_kernel(DevTable T, Pa
   if(misrouted) atomicAdd((unsigned long long*)&T.counters[CTR_MISROUTED], (unsigned long long)misrouted);
 }
 
+// ---- P2 in one pass (32-bit items routed to pairs of tiles) ------------------------------------------------------
+// The count pass of the exact P2 reads every item once more just to size the destinations.  Here every destination (a pair
+// of tiles) owns a fixed region of `cap` items and blocks reserve space in it kGran items at a time, exactly like the
+// single-pass P1: same LDS counting sort per chunk, same holes, and what does not fit a region goes straight to the table.
+// grid = (G2, buckets): blockIdx.y is the P1 bucket, blockIdx.x a contiguous slice of its items.  gcur / gshort / out are
+// indexed by destination = bucket * 2^b2e + sub-bucket.
+template <bool RETURNING, int PER_THREAD>
+__global__ __launch_bounds__(kPBlock) void p2_granule_kernel(DevTable T, PartGeom P, uint32_t b2e, uint32_t tag_bits, SegList S, uint32_t cap,
+                                                             unsigned int* __restrict__ gcur, unsigned int* __restrict__ gshort,
+                                                             uint32_t* __restrict__ out, uint32_t bucket0) {
+  typedef uint32_t ITEM;
+  constexpr int kChunk = kPBlock * PER_THREAD;
+  JF_DYN_LDS(s_dyn);
+  ITEM* s_item = reinterpret_cast<ITEM*>(s_dyn);                       // [kChunk]
+  __shared__ GranuleLds G;
+  const uint32_t nb = 1u << b2e;
+  const uint32_t bucket = bucket0 + blockIdx.y;
+  unsigned int* gc = gcur + (size_t)bucket * nb;
+  unsigned int* gs = gshort + (size_t)bucket * nb;
+  ITEM* o = out + (size_t)bucket * nb * cap;
+  granule_init(G, nb);
+  uint64_t n = 0;
+  for(uint32_t s = 0; s < S.n; ++s) n += seg_hi(S, s, bucket) - seg_lo(S, s, bucket);
+  const uint64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const uint64_t my_lo = (uint64_t)blockIdx.x * per, my_hi = my_lo + per < n ? my_lo + per : n;
+  uint32_t my_direct = 0;
+  PhaseClk pc;
+  for(uint64_t c0 = my_lo; c0 < my_hi; c0 += kChunk) {
+    lds_barrier();                                      // previous chunk's readers are done
+    JF_PHASE(pc, 0);
+    for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) G.hist[j] = 0;
+    ITEM it[PER_THREAD];
+    uint32_t rk[(PER_THREAD + 1) / 2];                  // rank inside the chunk's bucket, 16 bits each
+    uint32_t hm = 0, vm = 0;
+#pragma unroll
+    for(int r = 0; r < PER_THREAD; ++r) it[r] = 0;
+    const uint32_t cn = my_hi - c0 < (uint64_t)kChunk ? (uint32_t)(my_hi - c0) : (uint32_t)kChunk;
+    uint64_t slo = 0;
+    for(uint32_t s = 0; s < S.n; ++s) {                 // uniform loop: usually one or two batches overlap a chunk
+      const uint64_t o0 = seg_lo(S, s, bucket), len = seg_hi(S, s, bucket) - o0, shi = slo + len;
+      if(shi > c0 && slo < c0 + cn) {
+        const uint32_t lo_rel = slo > c0 ? (uint32_t)(slo - c0) : 0u;
+        const uint32_t hi_rel = shi < c0 + cn ? (uint32_t)(shi - c0) : cn;
+        const ITEM* src = reinterpret_cast<const ITEM*>(S.items[s]) + (int64_t)o0 + ((int64_t)c0 - (int64_t)slo);
+        const bool holes = S.sh[s] != 0;
+#pragma unroll
+        for(int r = 0; r < PER_THREAD; ++r) {
+          const uint32_t rel = (uint32_t)r * kPBlock + threadIdx.x;
+          if(rel >= lo_rel && rel < hi_rel) { it[r] = src[rel]; vm |= 1u << r; if(holes) hm |= 1u << r; }
+        }
+      }
+      slo = shi;
+    }
+    lds_barrier();
+    JF_PHASE(pc, 1);
+#pragma unroll
+    for(int r = 0; r < PER_THREAD; ++r) {
+      uint32_t rank = 0;
+      if((vm >> r) & 1) {
+        if(((hm >> r) & 1) && it[r] == (ITEM)~(ITEM)0) vm &= ~(1u << r);   // a hole
+        else rank = atomicAdd(&G.hist[(uint32_t)(it[r] >> tag_bits) & (nb - 1)], 1u);
+      }
+      if(r & 1) rk[r >> 1] |= rank << 16; else rk[r >> 1] = rank;
+    }
+    my_direct += granule_emit_x<ITEM>(G, nb, cap, gc, gs, o, s_item,
+                   [&]() {
+#pragma unroll
+                     for(int r = 0; r < PER_THREAD; ++r)
+                       if((vm >> r) & 1) s_item[G.lstart[(uint32_t)(it[r] >> tag_bits) & (nb - 1)] + ((rk[r >> 1] >> ((r & 1) * 16)) & 0xFFFFu)] = it[r];
+                   },
+                   [&](uint32_t, ITEM v) { item_direct_insert<RETURNING>(T, P, bucket, (uint64_t)v); },
+                   [&](uint32_t, ITEM v) -> uint32_t { return (uint32_t)(v >> tag_bits) & (nb - 1); }, &pc);
+  }
+  granule_finish<ITEM>(G, nb, cap, nullptr, o);
+  JF_PHASE(pc, 6);
+  JF_PHASE_FLUSH(pc, 8);
+  if(my_direct) atomicAdd((unsigned long long*)&T.counters[CTR_DIRECT], (unsigned long long)my_direct);
+}
+
 // After the granule pass: bucket bounds in the pair format of SegList (sh == 1).
 __global__ void granule_finish_kernel(const unsigned int* __restrict__ gcur, uint32_t cap, uint32_t nb, uint64_t* __restrict__ off2) {
   for(uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nb; j += gridDim.x * blockDim.x) {
     const uint32_t shortfall = gcur[nb + j];                     // > 0: some reservation did not fit
+    uint64_t used = gcur[j];
+    if(shortfall) used = shortfall <= cap ? cap - shortfall : 0;
+    else if(used > cap) used = cap;
+    off2[2 * (size_t)j] = (uint64_t)j * cap;
+    off2[2 * (size_t)j + 1] = (uint64_t)j * cap + used;
+  }
+}
+
+// The same for destinations d0 .. d0 + nd of nb (a flush in groups).
+__global__ void granule_finish_range_kernel(const unsigned int* __restrict__ gcur, uint32_t cap, uint32_t nb, uint64_t* __restrict__ off2,
+                                            uint32_t d0, uint32_t nd) {
+  for(uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nd; i += gridDim.x * blockDim.x) {
+    const uint32_t j = d0 + i;
+    const uint32_t shortfall = gcur[nb + j];
     uint64_t used = gcur[j];
     if(shortfall) used = shortfall <= cap ? cap - shortfall : 0;
     else if(used > cap) used = cap;

@@ -869,3 +869,37 @@ def test_genome_read_generator(gpu):
         exp = oracle_map(bytes(a.reshape(-1)), k, True)
         assert st.distinct == len(exp) and st.max_count == max(exp.values())
         t.free(d)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["pair_exact", "single_pass", "single_pass_overflow", "tiles"])
+def test_p2_variants_of_32bit_slots_give_the_same_table(gpu, monkeypatch, variant):
+    """32-bit items into 32-bit slots have three P2 forms: exact count + scatter to single tiles, the same to pairs of tiles
+    (the tile kernel then owns two tiles), and the single-pass P2 (reservations inside fixed regions per pair, holes,
+    overflow straight to the table).  Same input, two flushes (the second one loads dirty tiles), several pending batches
+    per flush: dump bytes and digest must equal the oracle's for each."""
+    env = {"tiles": {"JFGPU_TILE_PAIR": "0"}, "pair_exact": {"JFGPU_P2_SINGLE": "0"},
+           "single_pass": {"JFGPU_P2_SINGLE": "2"}, "single_pass_overflow": {"JFGPU_P2_SINGLE": "2", "JFGPU_P2_CAP": "64"}}[variant]
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
+    rng = random.Random(77)
+    k, lsize = 16, 26
+    seq = rnd_seq(rng, 700000, "ACGT") + b"N" + b"A" * 3000 + b"N" + rnd_seq(rng, 100000, "AC")
+    exp = oracle_map(seq, k, True)
+    with gpu.Table(k, 1 << lsize) as t:
+        assert t.info.slot_bytes == 4
+        t.set_mode(2)
+        t.reserve(len(seq))
+        d = t.malloc(len(seq) + 64)
+        t.h2d(d, np.frombuffer(seq, dtype=np.uint8))
+        third = len(seq) // 3
+        t.count_ascii_dev(d, third)
+        t.count_ascii_dev(d + third - (k - 1), third + (k - 1))
+        t.sync()
+        t.count_ascii_dev(d + 2 * third - (k - 1), len(seq) - 2 * third + (k - 1))
+        t.sync()
+        assert table_map(gpu, t) == exp
+        keys = np.array(list(exp.keys()), dtype=np.uint64)
+        cnts = np.array(list(exp.values()), dtype=np.uint64)
+        assert t.digest() == gpu.digest_of(keys, cnts)
+        t.free(d)
