@@ -203,7 +203,8 @@ int bloom_flush_inner(jfgpu_bloom* b) {
       const dim3 grid(g2, nb1), block(kPBlock);
       hipLaunchKernelGGL((p2_kernel<uint32_t, false>), grid, block, 0, b->stream, P, kBloomItemLow, S1, b->d_M2, (const uint64_t*)d_goff, tmp, 0u);
       hipLaunchKernelGGL(scan_matrix_kernel, dim3(nb1), dim3(1024), 0, b->stream, b->d_M2, (uint32_t)g2, nb2, (const uint64_t*)d_base, d_goff, 0u);
-      hipLaunchKernelGGL((p2_scatter_sorted_kernel<uint32_t, 16>), grid, block, (size_t)kPBlock * 16 * sizeof(uint32_t), b->stream,
+      // chunks of 28 Ki cell updates: the runs written per destination are what this pass costs (scatter_write_probe)
+      hipLaunchKernelGGL((p2_scatter_sorted_kernel<uint32_t, kP2PairPer>), grid, block, (size_t)kPBlock * kP2PairPer * sizeof(uint32_t), b->stream,
                          P, kBloomItemLow, S1, (const uint32_t*)b->d_M2, (const uint64_t*)d_goff, tmp, 0u);
     }
     SegList S2; memset(&S2, 0, sizeof S2);

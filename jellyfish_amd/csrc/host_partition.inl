@@ -107,6 +107,19 @@ int part_ingest(jfgpu_table* t, const uint8_t* base, int64_t lo, int64_t hi, boo
     HIP_TRY(hipMalloc((void**)&t->d_M1, (size_t)t->g1 * kMaxBuckets * sizeof(uint32_t)));
   }
   if(t->pending.size() >= kMaxSeg) { int rc = part_flush(t); if(rc) return rc; }
+  // 16-byte items: the arena is what limits the k-mers per flush, and every flush streams the whole table.  Before the
+  // first flush the bucket regions are sized for one item per input byte; reads of length L give (L - k + 1) / (L + 1)
+  // (0.58 at k = 63), so the first batch's exact count is read back once (one early wait for its P1) to size the others.
+  if(t->item128 && !from_keys && t->items_per_byte <= 0 && !t->pending.empty()) {
+    const PendingBatch& pb = t->pending.front();
+    if(pb.gran_cap && pb.input_bytes >= (1u << 20)) {
+      std::vector<uint64_t> tot(nb);
+      HIP_TRY(hipMemcpyAsync(tot.data(), pb.tot, nb * sizeof(uint64_t), hipMemcpyDeviceToHost, t->stream));
+      HIP_TRY(hipStreamSynchronize(t->stream));
+      uint64_t n = 0; for(uint64_t v : tot) n += v;
+      t->items_per_byte = std::max(0.01, (double)n / (double)pb.input_bytes);
+    }
+  }
   const uint32_t gcap = granule_cap(t, from_keys, max_items);
   if(t->item128 && (!gcap || from_keys)) return -1;       // two-word keys: single-pass P1 from sequence or the direct kernel
   // a one-pass Bloom filter (count --bf-size) changes as it is asked: the two-pass P1 would ask it twice per k-mer
@@ -116,12 +129,24 @@ int part_ingest(jfgpu_table* t, const uint8_t* base, int64_t lo, int64_t hi, boo
   // 16-byte items: the arena may be smaller than what the whole input needs, so keep half of it for the flush's P2 output
   const size_t ws_limit = t->item128 && t->pg.b2 ? t->ws_cap / 2 : t->ws_cap;
   if(t->item128 && !t->pending.empty() && t->ws_used + need > ws_limit) { int rc = part_flush(t); if(rc) return rc; }
+  // ... and every flush streams the whole table, so when the announced input (jfgpu_reserve) needs n of them, make them
+  // n equal ones: 6 + 3 + 1 batches cost a third more table traffic than 5 + 5
+  if(t->item128 && !from_keys && t->reserved_input && !t->pending.empty() && need > 0) {
+    const double per_flush = (double)ws_limit / (double)need * (double)(hi - lo);       // input bytes one flush can hold
+    if(per_flush > 0 && (double)t->reserved_input > per_flush) {
+      const double n = std::ceil((double)t->reserved_input / per_flush);
+      uint64_t pend_in = 0;
+      for(const PendingBatch& pb : t->pending) pend_in += pb.input_bytes;
+      if((double)pend_in + (double)(hi - lo) > (double)t->reserved_input / n * 1.02) { int rc = part_flush(t); if(rc) return rc; }
+    }
+  }
   if(t->ws_used + need > t->ws_cap) {
     if(!t->pending.empty()) { int rc = part_flush(t); if(rc) return rc; }   // apply what is pending, arena is empty again
     if(need > t->ws_cap) { int rc = ws_grow(t, need); if(rc) return rc; }     // rc < 0: no memory -> caller goes direct
   }
   PendingBatch b{nullptr, nullptr, max_items};
   b.input_bytes = from_keys ? 0 : (uint64_t)(hi - lo);
+  b.bound = t->cur_bound;
   b.items = ws_alloc(t, bytes);
   b.off = (uint64_t*)ws_alloc(t, (2 * nb + 1) * sizeof(uint64_t));
   if(!b.items || !b.off) return fail(JFGPU_E_ALLOC, "partition workspace exhausted");
@@ -228,6 +253,14 @@ int part_flush_t(jfgpu_table* t) {
     for(uint32_t j = 0; j < nb1; ++j) bucket_tot[j] += offs[s * (nb1 + 1) + j + 1] - offs[s * (nb1 + 1) + j];
   for(uint32_t j = 0; j < nb1; ++j) { total += bucket_tot[j]; max_bucket = std::max(max_bucket, bucket_tot[j]); }
   if(max_bucket > 0xF0000000ull) return fail(JFGPU_E_UNSUPPORTED, "more than 2^32 pending k-mers in one partition bucket: sync more often");
+  {   // capacity accounting (ensure_capacity): these batches were charged one k-mer per input byte, now their exact item
+      // counts are known -- plus whatever went straight to the table since the last look
+    uint64_t charged = 0, exact = 0;
+    for(size_t s = 0; s < nbatch; ++s) if(t->pending[s].bound) { charged += t->pending[s].bound; exact += offs[s * (nb1 + 1) + nb1]; }
+    const uint64_t dd = ctr[CTR_DIRECT] >= t->direct_seen ? ctr[CTR_DIRECT] - t->direct_seen : 0;
+    t->direct_seen = ctr[CTR_DIRECT];
+    if(charged && exact + dd < charged) t->fed_since -= std::min(t->fed_since, charged - (exact + dd));
+  }
   {   // items per input byte of what is being flushed (sequence batches only): sizes the next batches' bucket regions
     uint64_t in_bytes = 0, in_items = 0;
     for(size_t s = 0; s < nbatch; ++s)
@@ -369,7 +402,7 @@ int part_flush_t(jfgpu_table* t) {
     }
     hipEvent_t p2a = nullptr, p2b = nullptr, ta = nullptr, tb = nullptr;
     if(t->prof_on) { p2a = get_event(t); p2b = get_event(t); ta = get_event(t); tb = get_event(t); hipEventRecord(p2a, t->stream); }
-    constexpr int per_thread = sizeof(ITEM) == 4 ? 16 : sizeof(ITEM) == 8 ? 8 : 4;
+    constexpr int per_thread = sizeof(ITEM) == 4 ? 16 : sizeof(ITEM) == 8 ? 14 : 7;     // 8- and 16-byte items: chunks of 112 KiB (longer runs per destination)
     PartGeom pg2 = t->pg;
     if(pair) pg2.b2 -= 1;
     const uint32_t nb2e = 1u << pg2.b2;
@@ -460,6 +493,38 @@ int part_flush(jfgpu_table* t) {
     t->pending.clear(); t->pending_bytes = 0; t->ws_used = 0;
   }
   return rc;
+}
+
+// Replace the charges of the pending batches (one k-mer per input byte) by their exact item counts: one wait for the P1
+// kernels already enqueued, no flush.  The batches keep the corrected charge, so the flush's own correction stays neutral.
+int refine_pending_charges(jfgpu_table* t) {
+  if(t->pending.empty()) return JFGPU_OK;
+  const uint32_t nb1 = 1u << t->pg.b1;
+  std::vector<size_t> idx;
+  for(size_t s = 0; s < t->pending.size(); ++s) if(t->pending[s].bound) idx.push_back(s);
+  if(idx.empty()) return JFGPU_OK;
+  std::vector<uint64_t> buf(idx.size() * nb1);
+  uint64_t ctr[CTR_COUNT];
+  for(size_t i = 0; i < idx.size(); ++i) {
+    const PendingBatch& pb = t->pending[idx[i]];
+    if(pb.gran_cap) HIP_TRY(hipMemcpyAsync(&buf[i * nb1], pb.tot, nb1 * sizeof(uint64_t), hipMemcpyDeviceToHost, t->stream));
+    else HIP_TRY(hipMemcpyAsync(&buf[i * nb1], pb.off + nb1, sizeof(uint64_t), hipMemcpyDeviceToHost, t->stream));
+  }
+  HIP_TRY(hipMemcpyAsync(ctr, t->dt.counters, sizeof(ctr), hipMemcpyDeviceToHost, t->stream));
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  uint64_t charged = 0, exact = 0;
+  for(size_t i = 0; i < idx.size(); ++i) {
+    PendingBatch& pb = t->pending[idx[i]];
+    uint64_t n = 0;
+    if(pb.gran_cap) for(uint32_t j = 0; j < nb1; ++j) n += buf[i * nb1 + j]; else n = buf[i * nb1];
+    charged += pb.bound; exact += std::min(n, pb.bound);
+    pb.bound = std::max<uint64_t>(std::min(n, pb.bound), 1);
+  }
+  const uint64_t dd = ctr[CTR_DIRECT] >= t->direct_seen ? ctr[CTR_DIRECT] - t->direct_seen : 0;
+  t->direct_seen = ctr[CTR_DIRECT];
+  if(exact + dd < charged) t->fed_since -= std::min(t->fed_since, charged - (exact + dd));
+  else t->fed_since += (exact + dd) - charged;
+  return JFGPU_OK;
 }
 
 void part_discard(jfgpu_table* t) {

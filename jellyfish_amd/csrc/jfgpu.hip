@@ -51,6 +51,7 @@ struct PendingBatch {
   uint32_t gran_cap = 0;                      // > 0: single-pass ("granule") batch, items per bucket region; off is in pair format
   unsigned long long* tot = nullptr;          // granule batch: exact items per bucket
   uint64_t input_bytes = 0;                   // sequence bytes this batch was made from (0: encoded keys)
+  uint64_t bound = 0;                         // what ensure_capacity charged for this batch (an upper bound on its k-mers; 0: not charged)
 };
 
 struct ProfSpan { hipEvent_t a, b; int which; uint64_t units; };
@@ -73,6 +74,8 @@ struct jfgpu_table {
   // size doubling (hash_counter::do_size_doubling): occupancy bookkeeping, see ensure_capacity()
   bool grow_on = true;
   uint64_t occ_known = 0, fed_since = 0;
+  uint64_t cur_bound = 0;        // the charge of the piece being ingested right now (launch_count -> part_ingest)
+  uint64_t direct_seen = 0;      // CTR_DIRECT when the charges were last corrected
   uint64_t grow_seed = 0;
   // two-word keys (33 <= k <= 64): 128-bit slots, kernels_wide.hip.hpp
   bool wide = false;
@@ -116,6 +119,7 @@ struct jfgpu_table {
   hipStream_t stream2 = nullptr; hipEvent_t flush_ev[2] = {nullptr, nullptr}; hipEvent_t flush_done = nullptr;
   int p1_single = -1;            // single-pass P1: -1 auto (large batches), 0 never, 1 whenever the geometry allows (JFGPU_P1_SINGLE)
   double items_per_byte = 0;     // k-mers per sequence byte seen by the last flush (0: unknown yet)
+  uint64_t reserved_input = 0;   // sequence bytes the caller announced (jfgpu_reserve): lets forced flushes be spaced evenly
   double p1_slack = 0.03;        // head-room of a bucket region over the mean (JFGPU_P1_SLACK; negative forces the exhausted path)
   uint32_t* d_M1 = nullptr; int g1 = 0;
   uint32_t* d_M2 = nullptr; int g2 = 0;
@@ -263,12 +267,16 @@ bool capacity_managed(const jfgpu_table* t) { return (t->grow_on || t->spill_fn)
 // table (cooperative rehash on the device) when it is really more than half full.  Returns the
 // number of k-mers that may be enqueued now (<= incoming, > 0).
 extern "C" int jfgpu_clear(jfgpu_table* t);
+int refine_pending_charges(jfgpu_table* t);
 int ensure_capacity(jfgpu_table* t, uint64_t incoming, uint64_t* allowed) {
   *allowed = incoming;
   if(!capacity_managed(t)) return JFGPU_OK;
   uint64_t limit = capacity_limit(t);
   if(t->occ_known + t->fed_since + incoming <= limit) { t->fed_since += incoming; return JFGPU_OK; }
-  int rc = measure_occupancy(t); if(rc) return rc;
+  // the charges are one k-mer per input byte; what is pending knows its exact item count (no flush needed to read it)
+  int rc = refine_pending_charges(t); if(rc) return rc;
+  if(t->occ_known + t->fed_since + incoming <= limit) { t->fed_since += incoming; return JFGPU_OK; }
+  rc = measure_occupancy(t); if(rc) return rc;
   if(!t->grow_on) {
     // --disk (count_main.cc:276-277, hash_counter.hpp:178-198 with a dumper): when what is left would not take a
     // useful piece, the caller writes the table out as one sorted run, the table is emptied and counting goes on
@@ -312,7 +320,10 @@ int launch_count(jfgpu_table* t, const char* d_bases, size_t n) {
     // a piece holds at least one window and moves forward (spill mode may grant less than k characters of room; the few
     // extra k-mers cannot take the table past its 80 % bound by more than 2k)
     if(take < 2 * (uint64_t)t->g.k) take = std::min<uint64_t>(n - off, 2 * (uint64_t)t->g.k);
-    rc = launch_count_chunk(t, d_bases + off, (size_t)take); if(rc) return rc;
+    t->cur_bound = take;
+    rc = launch_count_chunk(t, d_bases + off, (size_t)take);
+    t->cur_bound = 0;
+    if(rc) return rc;
     if(off + take >= n) return JFGPU_OK;
     off += take - (t->g.k - 1);          // next piece re-reads the last k-1 characters: every window exactly once
   }
@@ -627,7 +638,7 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint32_t, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)tile_insert_kernel<uint32_t, true, true, unsigned int, kPBlock, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 << kMaxTileBits));
     HIP_TRY(hipFuncSetAttribute((const void*)tile_insert_kernel<uint32_t, false, true, unsigned int, kPBlock, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 << kMaxTileBits));
-    HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint64_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * 8 * 8));
+    HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint64_t, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * 14 * 8));
     const int gl = kG64Chunk * 10;
     HIP_TRY(hipFuncSetAttribute((const void*)p1_granule64_kernel<true, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, gl));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_granule64_kernel<false, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, gl));
@@ -635,7 +646,7 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     HIP_TRY(hipFuncSetAttribute((const void*)p1_granule64_kernel<false, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, gl));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_granule64_kernel<false, false, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, gl));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_granule64_kernel<false, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, gl));
-    HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<u128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * 4 * 16));
+    HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<u128, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * 7 * 16));
     const int wl = kWideChunk * 18 + 16 * 2048, wt = 16 << kMaxTileBits;
     HIP_TRY(hipFuncSetAttribute((const void*)p1_wide_granule_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_wide_granule_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
@@ -702,7 +713,7 @@ int jfgpu_clear(jfgpu_table* t) {
   HIP_TRY(hipMemsetAsync(t->dt.counters, 0, CTR_COUNT * sizeof(uint64_t), t->stream));
   HIP_TRY(hipMemsetAsync(t->dt.dirty, 0, (size_t)1 << (t->g.lsize_l - t->g.tile_bits), t->stream));
   HIP_TRY(hipStreamSynchronize(t->stream));
-  t->pristine = true; t->occ_known = 0; t->fed_since = 0;
+  t->pristine = true; t->occ_known = 0; t->fed_since = 0; t->direct_seen = 0;
   return JFGPU_OK;
 }
 
@@ -1083,6 +1094,7 @@ int jfgpu_reserve(jfgpu_table* t, uint64_t input_bytes) {
   int rc = use(t); if(rc) return rc;
   if(!t->part_ok || t->mode == MODE_DIRECT) return JFGPU_OK;
   rc = part_flush(t); if(rc) return rc;
+  t->reserved_input = input_bytes;
   const uint32_t nb1 = 1u << t->pg.b1, nb2 = 1u << t->pg.b2;
   // pending items (upper bound: one per input byte) + the P2 output of the same size + offsets
   // (single-pass P1 batches are regions with head-room: slack + one stranded reservation per block and bucket)
