@@ -164,6 +164,13 @@ void jfgpu_comm_destroy(jfgpu_comm* c);
 int  jfgpu_comm_count_ascii_dev(jfgpu_comm* c, jfgpu_table* t, const char* d_bases, size_t n);
 int  jfgpu_comm_local_step(jfgpu_comm* c, jfgpu_table** tables, const char* const* d_bases, const size_t* n);
 int  jfgpu_comm_finish(jfgpu_comm* c, uint64_t* sent, uint64_t* received);
+/* What a launcher has to agree on around the steps (RCCL transport, synchronous, collective): values[n] (n <= 64) replaced
+ * by their sum (op 0) or maximum (op 1) over the ranks -- "does any rank still have input?", so that every rank makes the
+ * same number of steps; all[world] = every rank's `mine` -- the records each shard will write, i.e. a rank's offset in
+ * the common binary/sorted file (sorted_dumper.hpp:57-101 writes one file; here shard dumps are concatenated in rank order). */
+int  jfgpu_comm_allreduce_u64(jfgpu_comm* c, uint64_t* values, int n, int op);
+int  jfgpu_comm_allgather_u64(jfgpu_comm* c, uint64_t mine, uint64_t* all);
+int  jfgpu_comm_world(const jfgpu_comm* c, int* world, int* rank);
 
 /* ---- results path ------------------------------------------------------ */
 int  jfgpu_stats_compute(jfgpu_table* t, uint64_t lower, uint64_t upper, jfgpu_stats* out);

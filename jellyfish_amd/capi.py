@@ -80,6 +80,9 @@ SIGNATURES = {
     "jfgpu_comm_count_ascii_dev": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "jfgpu_comm_local_step": (C.c_int, [_P, _P, _P, _P]),
     "jfgpu_comm_finish": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "jfgpu_comm_allreduce_u64": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "jfgpu_comm_allgather_u64": (C.c_int, [_P, C.c_uint64, _P]),
+    "jfgpu_comm_world": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "jfgpu_stats_compute": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.POINTER(Stats)]),
     "jfgpu_digest": (C.c_int, [_P, C.c_uint64, C.c_uint64, _P]),
     "jfgpu_histo": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64, _P, C.c_uint64]),
@@ -420,6 +423,17 @@ class Comm:
         s, r = C.c_uint64(), C.c_uint64()
         _check(self._lib.jfgpu_comm_finish(self._h, C.byref(s), C.byref(r)))
         return s.value, r.value
+
+    def allreduce(self, values, op="sum"):
+        """values (<= 64 integers) replaced by their sum / max over the ranks (RCCL transport; collective, synchronous)."""
+        a = np.array(values, dtype=np.uint64)
+        _check(self._lib.jfgpu_comm_allreduce_u64(self._h, a.ctypes.data, len(a), {"sum": 0, "max": 1}[op]))
+        return a.tolist()
+
+    def allgather(self, mine):
+        a = np.zeros(self.world, dtype=np.uint64)
+        _check(self._lib.jfgpu_comm_allgather_u64(self._h, int(mine), a.ctypes.data))
+        return a.tolist()
 
 
 class Bloom:

@@ -255,6 +255,80 @@ static void feed_generators(const std::string& generator, std::string shell, uns
 }
 
 // ---------------------------------------------------------------- count
+// ---- count --gpus N: one process per GPU -----------------------------------------------------------
+// The command line that carries --gpus N starts N copies of itself (environment: JFGPU_RANK, JFGPU_WORLD,
+// JFGPU_RENDEZVOUS = a scratch directory) and waits for them; each copy opens GPU `rank`, holds shard `rank` of the table,
+// reads its part of every input file, routes its k-mers to the owning shards over RCCL (jfgpu_comm_*) and writes its records
+// at its own offset of the common output file.  A launcher that sets RANK / WORLD_SIZE / LOCAL_RANK itself (torchrun, mpirun
+// wrappers) and JFGPU_RENDEZVOUS is taken at its word: no copies are started.
+struct rank_env { int rank = 0, world = 1, local_rank = 0; std::string rendezvous; bool is_rank = false; };
+
+rank_env read_rank_env() {
+  rank_env e;
+  const char* r = getenv("JFGPU_RANK"); if(!r) r = getenv("RANK");
+  const char* w = getenv("JFGPU_WORLD"); if(!w) w = getenv("WORLD_SIZE");
+  if(!r || !w) return e;
+  e.is_rank = true; e.rank = atoi(r); e.world = atoi(w);
+  const char* l = getenv("JFGPU_LOCAL_RANK"); if(!l) l = getenv("LOCAL_RANK");
+  e.local_rank = l ? atoi(l) : e.rank;
+  if(const char* d = getenv("JFGPU_RENDEZVOUS")) e.rendezvous = d;
+  return e;
+}
+
+int spawn_ranks(unsigned n, char* argv[]) {
+  char tmpl[] = "/tmp/jfgpu_rdv_XXXXXX";
+  const char* dir = mkdtemp(tmpl);
+  if(!dir) die("Can't create the rendezvous directory under /tmp");
+  std::vector<pid_t> pids;
+  for(unsigned r = 0; r < n; ++r) {
+    const pid_t pid = fork();
+    if(pid < 0) die("fork failed");
+    if(pid == 0) {
+      setenv("JFGPU_RANK", std::to_string(r).c_str(), 1);
+      setenv("JFGPU_WORLD", std::to_string(n).c_str(), 1);
+      setenv("JFGPU_LOCAL_RANK", std::to_string(r).c_str(), 1);
+      setenv("JFGPU_RENDEZVOUS", dir, 1);
+      std::vector<char*> av;                       // argv here starts at the verb ("count", ...): put the program name back
+      av.push_back(const_cast<char*>("jellyfish-amd"));
+      for(char** a = argv; *a; ++a) av.push_back(*a);
+      av.push_back(nullptr);
+      execv("/proc/self/exe", av.data());
+      perror("execv");
+      _exit(127);
+    }
+    pids.push_back(pid);
+  }
+  int worst = 0;
+  for(pid_t pid : pids) {
+    int st = 0;
+    if(waitpid(pid, &st, 0) < 0) { worst = std::max(worst, 1); continue; }
+    const int rc = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
+    worst = std::max(worst, rc);
+  }
+  unlink((std::string(dir) + "/id").c_str());
+  rmdir(dir);
+  return worst;
+}
+
+// rank 0 makes the RCCL id and leaves it in the rendezvous directory; the others wait for it
+void exchange_unique_id(const rank_env& e, uint8_t* id128) {
+  const std::string path = e.rendezvous + "/id", tmp = path + ".tmp";
+  if(e.rank == 0) {
+    if(jfgpu_comm_unique_id(id128)) die(jfgpu_last_error());
+    std::ofstream out(tmp, std::ios::binary | std::ios::trunc);
+    out.write((const char*)id128, 128);
+    out.close();
+    if(!out.good() || rename(tmp.c_str(), path.c_str()) != 0) die("Can't write '" + path + "'");
+    return;
+  }
+  for(int tries = 0; tries < 6000; ++tries) {            // 10 minutes: rank 0 may still be paging its libraries in
+    std::ifstream in(path, std::ios::binary);
+    if(in.good()) { in.read((char*)id128, 128); if(in.gcount() == 128) return; }
+    std::this_thread::sleep_for(std::chrono::milliseconds(100));
+  }
+  die("Timed out waiting for rank 0 in '" + e.rendezvous + "'");
+}
+
 int count_main(int argc, char* argv[]) {
   auto start_time = std::chrono::steady_clock::now();
   file_header header;
@@ -267,6 +341,7 @@ int count_main(int argc, char* argv[]) {
   bool size_given = false, lower_given = false, upper_given = false, canonical = false, text = false, no_write = false, disk = false, host_parse = false, no_merge = false, no_unlink = false;
   uint64_t bf_size = 0; double bf_fp = 0.01; bool bf_size_given = false;
   int device = -1, min_qual = 0, quality_start = 64, min_quality = 0;
+  unsigned gpus = 1; bool gpus_given = false;
   bool min_qual_char_given = false, min_quality_given = false;
   std::string output = "mer_counts.jf", timing, bc_path, generator, shell, digest_path;
   std::vector<std::string> files, if_files;
@@ -288,6 +363,7 @@ int count_main(int argc, char* argv[]) {
     else if(a.is("-U", "--upper-count")) { upper = strtoull(a.value("-U", "--upper-count").c_str(), 0, 10); upper_given = true; }
     else if(a.is("", "--timing")) timing = a.value("", "--timing");
     else if(a.is("", "--device")) device = atoi(a.value("", "--device").c_str());
+    else if(a.is("", "--gpus")) { gpus = (unsigned)strtoul(a.value("", "--gpus").c_str(), 0, 10); gpus_given = true; }
     else if(a.is("", "--bc")) bc_path = a.value("", "--bc");
     else if(a.is("", "--digest")) digest_path = a.value("", "--digest");   // content checksum of the table (jfgpu_digest), for at-scale parity checks
     else if(a.cur() == "-C" || a.cur() == "--canonical") canonical = true;
@@ -328,6 +404,7 @@ int count_main(int argc, char* argv[]) {
                    "     --text                  Dump in text format (false)\n"
                    "     --timing=Timing file    Print timing information\n"
                    "     --device=int            HIP device ordinal (current)\n"
+                   "     --gpus=N                Spread the table over N GPUs (a power of two), one process each\n"
                    "     --host-parse            Parse the sequence files on the host (default: on the device)\n";
       return 0;
     } else if(a.cur().size() > 1 && a.cur()[0] == '-' && a.cur() != "-") die("Unknown option '" + a.cur() + "'");
@@ -355,13 +432,36 @@ int count_main(int argc, char* argv[]) {
   if(mer_len > 128) die("jellyfish-amd: mer length > 128 (more than four key words) is not built");
   if(text) out_counter_len = 8;   // text counts are not saturated (text_dumper.hpp:18-20)
 
+  // --gpus N: this process is either the one the user typed (it starts the ranks and waits) or one of the ranks
+  rank_env renv;
+  jfgpu_comm* comm = nullptr;
+  uint32_t shard_bits = 0;
+  if(gpus_given) {
+    if(gpus < 1 || (gpus & (gpus - 1)) || gpus > 256) die("--gpus must be a power of two");
+    if(mer_len > 32) die("--gpus: sharded tables for mer length > 32 are not built yet");
+    if(!if_files.empty() || !bc_path.empty() || bf_size_given || disk || text || host_parse || !generator.empty())
+      die("--gpus cannot be combined with --if, --bc, --bf-size, --disk, --text, --host-parse or -g yet");
+    renv = read_rank_env();
+    if(!renv.is_rank) return spawn_ranks(gpus, argv);
+    if(renv.world != (int)gpus || renv.rank < 0 || renv.rank >= renv.world) die("--gpus does not match the ranks' environment (WORLD_SIZE / RANK)");
+    if(renv.rendezvous.empty()) die("--gpus under an external launcher: set JFGPU_RENDEZVOUS to a directory all ranks see");
+    if(device < 0) device = renv.local_rank;
+    while((1u << shard_bits) < gpus) ++shard_bits;
+  }
+
   mer_dna::k(mer_len);
   header.canonical(canonical);
   std::unique_ptr<mer_hash> ary;
   try {
-    ary.reset(new mer_hash(size, mer_len * 2, counter_len, threads, reprobes, canonical, device, out_counter_len));
+    ary.reset(new mer_hash(size, mer_len * 2, counter_len, threads, reprobes, canonical, device, out_counter_len, 0, shard_bits, (uint32_t)renv.rank));
   } catch(std::exception& e) { die(std::string("Failed to allocate the hash: ") + e.what()); }
   if(disk) ary->do_size_doubling(false);
+  if(gpus_given) {
+    uint8_t id[128];
+    exchange_unique_id(renv, id);
+    if(jfgpu_comm_create(renv.world, renv.rank, id, device, &comm)) die(std::string("Failed to create the communicator: ") + jfgpu_last_error());
+    ary->attach_comm(comm);
+  }
 
   // Bloom counter read from file to filter out low frequency k-mers, two pass algorithm
   // (load_bloom_filter, count_main.cc:191-206,313-316)
@@ -409,7 +509,8 @@ int count_main(int argc, char* argv[]) {
   {
     uint64_t total = 0, largest = 0;
     for(const auto& f : files) { struct stat st; if(stat(f.c_str(), &st) == 0 && S_ISREG(st.st_mode)) { total += (uint64_t)st.st_size; largest = std::max<uint64_t>(largest, st.st_size); } }
-    if(!host_parse && total > ((uint64_t)64 << 20)) ary->expect_input(std::min<uint64_t>(total, (uint64_t)12 << 30));
+    if(gpus_given) { total = total / gpus + ((uint64_t)1 << 20); largest = largest / gpus + ((uint64_t)1 << 20); }   // this rank's part
+    if(!host_parse && total > ((uint64_t)64 << 20) && !gpus_given) ary->expect_input(std::min<uint64_t>(total, (uint64_t)12 << 30));
     if(!host_parse) {
       try { dev_parser.reset(new device_sequence_parser(mer_len, device)); dev_parser->min_quality(min_qual); dev_parser->prepare(largest); }
       catch(std::exception& e) { die(e.what()); }
@@ -428,9 +529,13 @@ int count_main(int argc, char* argv[]) {
     } else {
       device_sequence_parser& parser = *dev_parser;
       const double ms0 = parser.device_ms(); const size_t fb0 = parser.host_fallback_bytes();
+      // (JFGPU_TEST_PARTS=N: read every file as N parts, one after the other -- what N ranks would read between them)
+      const unsigned test_parts = !gpus_given && getenv("JFGPU_TEST_PARTS") ? std::max(1, atoi(getenv("JFGPU_TEST_PARTS"))) : 1u;
       for(const auto& f : paths)
-        parser.parse_file(f.c_str(), [&](const char* d_buf, size_t n) { ary->count_sequence_dev(d_buf, n); },
-                          [&](const char* buf, size_t n) { ary->count_sequence(buf, n); }, [&]() { ary->wait_consumed(); });
+        for(unsigned part = 0; part < test_parts; ++part)
+          parser.parse_file_part(f.c_str(), gpus_given ? (unsigned)renv.rank : part, gpus_given ? gpus : test_parts,
+                                 [&](const char* d_buf, size_t n) { ary->count_sequence_dev(d_buf, n); },
+                                 [&](const char* buf, size_t n) { ary->count_sequence(buf, n); }, [&]() { ary->wait_consumed(); });
       parse_ms += parser.device_ms() - ms0; fallback_bytes += parser.host_fallback_bytes() - fb0;
     }
     ary->done();
@@ -452,8 +557,19 @@ int count_main(int argc, char* argv[]) {
   if(!digest_path.empty()) {
     uint64_t d[4];
     if(jfgpu_digest(ary->handle(), lower_given ? lower : 0, upper_given ? upper : std::numeric_limits<uint64_t>::max(), d)) die(jfgpu_last_error());
-    std::ofstream df(digest_path);
-    df << "records " << d[0] << "\ntotal " << d[1] << "\nsum " << d[2] << "\nxor " << d[3] << "\n";
+    if(comm) {                                     // the digest of the whole table: records, totals and sums add up, the xor words xor
+      std::vector<uint64_t> all(renv.world);
+      for(int i = 0; i < 4; ++i) {
+        if(jfgpu_comm_allgather_u64(comm, d[i], all.data())) die(jfgpu_last_error());
+        uint64_t v = 0;
+        for(uint64_t x : all) v = i == 3 ? (v ^ x) : (v + x);
+        d[i] = v;
+      }
+    }
+    if(renv.rank == 0) {
+      std::ofstream df(digest_path);
+      df << "records " << d[0] << "\ntotal " << d[1] << "\nsum " << d[2] << "\nxor " << d[3] << "\n";
+    }
   }
   auto write_start = std::chrono::steady_clock::now();
   if(!no_write) {
@@ -477,8 +593,14 @@ int count_main(int argc, char* argv[]) {
   const double write_s = seconds_since(write_start);
 
   if(bc) { jfgpu_attach_bloom(ary->handle(), nullptr); jfgpu_bc_destroy(bc); }
+  if(comm) {
+    uint64_t done = 1;                             // every rank's records are in the file before anyone reports success
+    if(jfgpu_comm_allreduce_u64(comm, &done, 1, 0)) die(jfgpu_last_error());
+    ary->attach_comm(nullptr);
+    jfgpu_comm_destroy(comm);
+  }
 
-  if(!timing.empty()) {   // count_main.cc:375-382
+  if(!timing.empty() && renv.rank == 0) {   // count_main.cc:375-382
     std::ofstream tf(timing);
     tf << "Init     " << init_s << "\n"
        << "Counting " << count_s << "\n"

@@ -21,6 +21,7 @@ struct jfgpu_comm {
   ncclComm_t nccl = nullptr;
 #endif
   hipStream_t xstream = nullptr;                 // exchange stream
+  uint64_t* d_coll = nullptr;                    // [512] staging of the small host-level collectives
   uint64_t max_msg_keys = (uint64_t)1 << 27;     // 1 GiB per peer per round (a 6.9 GB self-message was dropped by RCCL 2.26)
   bool self_rccl = false;                        // JFGPU_COMM_SELF_RCCL=1: a rank's own share travels through ncclSend/ncclRecv as
                                                  // well (default: a device copy) -- lets a single-GPU box exercise every RCCL call
@@ -300,6 +301,7 @@ void jfgpu_comm_destroy(jfgpu_comm* c) {
   hipSetDevice(c->device);
   if(c->xstream) hipStreamSynchronize(c->xstream);
   for(auto& R : c->ranks) { if(R.t && R.t->stream) hipStreamSynchronize(R.t->stream); comm_free_rank(R); }
+  if(c->d_coll) hipFree(c->d_coll);
 #if !defined(JFGPU_EMU)
   if(c->nccl) ncclCommDestroy(c->nccl);
 #endif
@@ -336,6 +338,53 @@ int jfgpu_comm_local_step(jfgpu_comm* c, jfgpu_table** tables, const char* const
     rc = comm_insert_prev(c, c->ranks[r]); if(rc) return rc;
     c->ranks[r].inflight = true; c->ranks[r].turn ^= 1;
   }
+  return JFGPU_OK;
+}
+
+// Small host-level collectives of the RCCL transport, for what a launcher has to agree on around the steps: whether any
+// rank still has input (so that every rank makes the same number of steps), and how many records every shard will write
+// (a rank's offset in the common output file).  values: n words, replaced by the sum (op 0) or the maximum (op 1) over
+// the ranks.  all: [world] words, all[r] = rank r's `mine`.  Synchronous; collective.
+int jfgpu_comm_allreduce_u64(jfgpu_comm* c, uint64_t* values, int n, int op) {
+  if(!c || c->local) return fail(JFGPU_E_INVALID, "not an RCCL communicator");
+  if(!values || n < 1 || n > 64 || (op != 0 && op != 1)) return fail(JFGPU_E_INVALID, "allreduce: 1..64 words, op 0 (sum) or 1 (max)");
+#if defined(JFGPU_EMU)
+  return fail(JFGPU_E_UNSUPPORTED, "no RCCL in the emulated build");
+#else
+  HIP_TRY(hipSetDevice(c->device));
+  if(c->world == 1 && !c->self_rccl) return JFGPU_OK;
+  if(!c->d_coll) HIP_TRY(hipMalloc((void**)&c->d_coll, sizeof(uint64_t) * 512));
+  HIP_TRY(hipMemcpyAsync(c->d_coll, values, sizeof(uint64_t) * n, hipMemcpyHostToDevice, c->xstream));
+  NCCL_TRY(ncclAllReduce(c->d_coll, c->d_coll, n, ncclUint64, op == 0 ? ncclSum : ncclMax, c->nccl, c->xstream));
+  HIP_TRY(hipMemcpyAsync(values, c->d_coll, sizeof(uint64_t) * n, hipMemcpyDeviceToHost, c->xstream));
+  HIP_TRY(hipStreamSynchronize(c->xstream));
+  return JFGPU_OK;
+#endif
+}
+
+int jfgpu_comm_allgather_u64(jfgpu_comm* c, uint64_t mine, uint64_t* all) {
+  if(!c || c->local) return fail(JFGPU_E_INVALID, "not an RCCL communicator");
+  if(!all) return fail(JFGPU_E_INVALID, "null argument");
+#if defined(JFGPU_EMU)
+  (void)mine;
+  return fail(JFGPU_E_UNSUPPORTED, "no RCCL in the emulated build");
+#else
+  HIP_TRY(hipSetDevice(c->device));
+  if(c->world == 1 && !c->self_rccl) { all[0] = mine; return JFGPU_OK; }
+  if(c->world > 256) return fail(JFGPU_E_INVALID, "allgather: world too large");
+  if(!c->d_coll) HIP_TRY(hipMalloc((void**)&c->d_coll, sizeof(uint64_t) * 512));
+  HIP_TRY(hipMemcpyAsync(c->d_coll + 256, &mine, sizeof(uint64_t), hipMemcpyHostToDevice, c->xstream));
+  NCCL_TRY(ncclAllGather(c->d_coll + 256, c->d_coll, 1, ncclUint64, c->nccl, c->xstream));
+  HIP_TRY(hipMemcpyAsync(all, c->d_coll, sizeof(uint64_t) * c->world, hipMemcpyDeviceToHost, c->xstream));
+  HIP_TRY(hipStreamSynchronize(c->xstream));
+  return JFGPU_OK;
+#endif
+}
+
+int jfgpu_comm_world(const jfgpu_comm* c, int* world, int* rank) {
+  if(!c) return fail(JFGPU_E_INVALID, "null communicator");
+  if(world) *world = c->world;
+  if(rank) *rank = c->rank;
   return JFGPU_OK;
 }
 

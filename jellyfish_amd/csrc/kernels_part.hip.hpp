@@ -451,7 +451,7 @@ __global__ __launch_bounds__(kPBlock) void p2_scatter_sorted_kernel(PartGeom P, 
   for(uint32_t s = 0; s < S.n; ++s) n += seg_hi(S, s, bucket) - seg_lo(S, s, bucket);
   const uint64_t per = (n + gridDim.x - 1) / gridDim.x;
   const uint64_t my_lo = (uint64_t)blockIdx.x * per, my_hi = my_lo + per < n ? my_lo + per : n;
-  PhaseClk pc;
+  [[maybe_unused]] PhaseClk pc;
   // One chunk's items into registers (vm: which of the lane's PER_THREAD positions hold an item, hm: which of those came
   // from a batch with holes).  No use of the loaded values here, so all the loads of a chunk are in flight together --
   // and the next chunk's are issued before the current one is sorted, so their latency hides behind the LDS work.
@@ -874,7 +874,7 @@ __global__ __launch_bounds__(kPBlock) void p1_scatter_granule_kernel(DevTable T,
   uint32_t my_direct = 0, my_mers = 0;
   const int64_t n_tiles = (hi + kPTilePos - 1) / kPTilePos;
   TileRaw R = tile_fetch(base, (int64_t)blockIdx.x * kPTilePos, lo, hi);
-  PhaseClk pc;
+  [[maybe_unused]] PhaseClk pc;
   for(int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     lds_barrier();
     for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) G.hist[j] = 0;
@@ -1068,7 +1068,7 @@ __global__ __launch_bounds__(kPBlock) void p2_granule_kernel(DevTable T, PartGeo
   const uint64_t per = (n + gridDim.x - 1) / gridDim.x;
   const uint64_t my_lo = (uint64_t)blockIdx.x * per, my_hi = my_lo + per < n ? my_lo + per : n;
   uint32_t my_direct = 0;
-  PhaseClk pc;
+  [[maybe_unused]] PhaseClk pc;
   for(uint64_t c0 = my_lo; c0 < my_hi; c0 += kChunk) {
     lds_barrier();                                      // previous chunk's readers are done
     JF_PHASE(pc, 0);

@@ -58,26 +58,69 @@ public:
   }
 
   void parse_file(const char* path, const dev_sink_type& dev_sink, const host_sink_type& host_sink, const fence_type& fence) {
+    parse_file_part(path, 0, 1, dev_sink, host_sink, fence);
+  }
+
+  // Part `part` of `parts` of a regular file, cut at record boundaries (a line starting with '>'; for FASTQ a line starting
+  // with '@' whose second-next line starts with '+'): what one rank of a multi-GPU job reads.  Every rank finds the same
+  // cut points on its own, the parts are disjoint and cover the file.  Records are never split, so a file of a few long
+  // sequences divides unevenly.  Pipes cannot be divided: part 0 reads them whole.
+  void parse_file_part(const char* path, unsigned part, unsigned parts, const dev_sink_type& dev_sink, const host_sink_type& host_sink,
+                       const fence_type& fence) {
     int fd = open(path, O_RDONLY);
     if(fd < 0) throw std::runtime_error(std::string("Can't open file '") + path + "'");
     struct stat st;
     if(fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size == 0) {   // pipes, empty files: the host reader copes
       close(fd);
-      host_.parse_file(path, host_sink);
+      if(part == 0) host_.parse_file(path, host_sink);
       return;
     }
-    const bool pinned = pinned_ < 0 ? (size_t)st.st_size >= ((size_t)64 << 20) : pinned_ != 0;
+    const size_t size = (size_t)st.st_size;
+    size_t begin = 0, end = size;
+    if(parts > 1) {
+      char first = 0;
+      if(pread(fd, &first, 1, 0) != 1 || (first != '>' && first != '@')) { close(fd); throw std::runtime_error("Unsupported format"); }
+      try {
+        begin = part == 0 ? 0 : record_boundary(fd, size, (size_t)((unsigned __int128)size * part / parts), first);
+        end = part + 1 == parts ? size : record_boundary(fd, size, (size_t)((unsigned __int128)size * (part + 1) / parts), first);
+      } catch(...) { close(fd); throw; }
+      if(begin >= end) { close(fd); ++files_read_; return; }
+    }
+    const bool pinned = pinned_ < 0 ? end - begin >= ((size_t)64 << 20) : pinned_ != 0;
     if(pinned) {
-      try { parse_fd_pinned(fd, (size_t)st.st_size, dev_sink, host_sink, fence); } catch(...) { close(fd); throw; }
+      try { parse_fd_pinned(fd, end, dev_sink, host_sink, fence, begin); } catch(...) { close(fd); throw; }
       close(fd);
       return;
     }
-    void* m = mmap(nullptr, st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    void* m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
     close(fd);
-    if(m == MAP_FAILED) { host_.parse_file(path, host_sink); return; }
-    madvise(m, st.st_size, MADV_SEQUENTIAL);
-    try { parse_memory((const char*)m, st.st_size, dev_sink, host_sink, fence); } catch(...) { munmap(m, st.st_size); throw; }
-    munmap(m, st.st_size);
+    if(m == MAP_FAILED) {
+      if(parts > 1) throw std::runtime_error("Can't mmap file");
+      host_.parse_file(path, host_sink);
+      return;
+    }
+    madvise(m, size, MADV_SEQUENTIAL);
+    try { parse_memory((const char*)m + begin, end - begin, dev_sink, host_sink, fence); } catch(...) { munmap(m, size); throw; }
+    munmap(m, size);
+  }
+
+  // Offset of the first record that starts at or after `target` (size: none).
+  static size_t record_boundary(int fd, size_t size, size_t target, char marker) {
+    if(target == 0) return 0;
+    const size_t W = (size_t)4 << 20;
+    std::vector<char> buf(W + 1);
+    size_t pos = target - 1;                     // buf[0] is the character before the first candidate
+    while(pos + 1 < size) {
+      const size_t len = std::min(W + 1, size - pos);
+      if(!read_exact(fd, pos, buf.data(), len)) throw std::runtime_error("Error reading the sequence file");
+      for(const char* q = buf.data(); (q = (const char*)memchr(q, '\n', buf.data() + len - 1 - q)) != nullptr; ++q) {
+        if(q[1] != marker) continue;
+        const size_t at = pos + (size_t)(q - buf.data()) + 1;
+        if(marker == '>' || fastq_record_at(fd, size, at)) return at;
+      }
+      pos += len - 1;
+    }
+    return size;
   }
 
   void parse_memory(const char* data, size_t n, const dev_sink_type& dev_sink, const host_sink_type& host_sink, const fence_type& fence) {
@@ -111,6 +154,24 @@ private:
       if(n_out) dev_sink(d_out, n_out);
       a = b; first = false;
     }
+  }
+
+  static bool read_exact(int fd, size_t off, char* dst, size_t len) {
+    size_t done = 0;
+    while(done < len) {
+      const ssize_t r = pread(fd, dst + done, len - done, (off_t)(off + done));
+      if(r <= 0) return false;
+      done += (size_t)r;
+    }
+    return true;
+  }
+  // does a FASTQ record start at file offset `at` ('@' there, and the second-next line starts with '+')?
+  static bool fastq_record_at(int fd, size_t size, size_t at) {
+    std::vector<char> b(std::min<size_t>((size_t)1 << 20, size - at));
+    if(b.empty() || !read_exact(fd, at, b.data(), b.size()) || b[0] != '@') return false;
+    const char* e1 = (const char*)memchr(b.data(), '\n', b.size());
+    const char* e2 = e1 ? (const char*)memchr(e1 + 1, '\n', b.data() + b.size() - (e1 + 1)) : nullptr;
+    return e2 && e2 + 1 < b.data() + b.size() && e2[1] == '+';
   }
 
   static constexpr size_t npos = ~(size_t)0;
@@ -154,7 +215,7 @@ private:
   // stream (jfgpu_parser_upload) and parsed + counted on the device, while a background task moves the tail to the
   // other buffer and reads the next chunk with a few dozen parallel pread()s (one stream copies out of the page cache
   // at ~2-3 GB/s; a pageable copy of the mapping measured 2.9 GB/s end to end on a 10 GB file, profiles/r02_*).
-  void parse_fd_pinned(int fd, size_t n, const dev_sink_type& dev_sink, const host_sink_type& host_sink, const fence_type& fence) {
+  void parse_fd_pinned(int fd, size_t n, const dev_sink_type& dev_sink, const host_sink_type& host_sink, const fence_type& fence, size_t start = 0) {
     ++files_read_;
     // JFGPU_FEED_TRACE=1: where the wall time of the feed goes (stderr), for tools/cli_feed_bench.py
     const bool trace = getenv("JFGPU_FEED_TRACE") != nullptr;
@@ -166,7 +227,7 @@ private:
     for(int w = 0; w < 2; ++w)
       if(jfgpu_parser_host_buffer(p_, w, cap, &pin_[w])) throw std::runtime_error(jfgpu_last_error());
     t_alloc = since(ta);
-    size_t pos = 0;                 // file offset of the first byte not yet read
+    size_t pos = start;             // file offset of the first byte not yet read (the part read is [start, n))
     size_t have[2] = {0, 0};        // valid bytes in each buffer
     auto fill = [&](int w, size_t carried) -> bool {      // append fresh bytes behind `carried`
       const size_t want = std::min(n - pos, cap - carried > chunk_ ? chunk_ : cap - carried);
@@ -182,7 +243,7 @@ private:
     else if(pin_[0][0] == '@') fmt = JFGPU_PARSE_FASTQ;
     else throw std::runtime_error("Unsupported format");
     bool first = true;
-    size_t consumed = 0;            // file bytes handed to a parser so far (for the host fallback)
+    size_t consumed = start;        // file offset up to which a parser has taken the bytes (for the host fallback)
     for(int w = 0;; w ^= 1) {
       const char* buf = pin_[w];
       const size_t len = have[w];
@@ -195,7 +256,7 @@ private:
       if(cut == npos || cut == 0) {           // no boundary in a whole buffer: the general reader takes the rest of the file
         void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
         if(m == MAP_FAILED) throw std::runtime_error("Can't mmap file");
-        if(fmt == JFGPU_PARSE_FASTA && consumed) { munmap(m, n); throw std::runtime_error("FASTA line longer than the staging buffer"); }
+        if(fmt == JFGPU_PARSE_FASTA && consumed > start) { munmap(m, n); throw std::runtime_error("FASTA line longer than the staging buffer"); }
         fallback_bytes_ += n - consumed;
         try { host_.parse_memory((const char*)m + consumed, n - consumed, host_sink); } catch(...) { munmap(m, n); throw; }
         munmap(m, n);

@@ -69,20 +69,42 @@ public:
       throw std::length_error("binary_dumper: table was created with a different out_counter_len");
     ary->flush();                                              // pending adds first: they may still double the table
     const std::string path = next_path();
-    std::ofstream out(path, std::ios::binary | std::ios::trunc);
-    if(!out.good()) throw ErrorWriting("Can't open file '" + path + "'");
-    if(header_) {
-      ary->update_header(*header_);
-      header_->format(format);
-      header_->counter_len(val_len_);
-      header_->write(out);
-    }
-    out.flush();
-    if(!out.good()) throw ErrorWriting("Error while writing '" + path + "'");
-    const off_t body = (off_t)out.tellp();
-    out.close();
+    // One shard of a multi-GPU table (hash_counter::attach_comm): the shards' sorted dumps concatenated in rank order are
+    // the globally (pos, key)-sorted body, so every rank writes its records into the same file at the offset the record
+    // counts of the ranks before it give; rank 0 writes the header and sizes the file first.
+    jfgpu_comm* comm = ary->comm();
+    int world = 1, rank = 0;
+    if(comm) jf_check(jfgpu_comm_world(comm, &world, &rank));
     uint64_t n = 0; uint32_t rec = 0;
     jf_check(jfgpu_dump_begin(ary->handle(), min_, max_, &n, &rec));
+    uint64_t first_record = 0, all_records = n;
+    if(comm) {
+      std::vector<uint64_t> counts(world);
+      if(jfgpu_comm_allgather_u64(comm, n, counts.data())) { jfgpu_dump_end(ary->handle()); throw std::runtime_error(jfgpu_last_error()); }
+      all_records = 0;
+      for(int r = 0; r < world; ++r) { if(r < rank) first_record += counts[r]; all_records += counts[r]; }
+    }
+    off_t body = 0;
+    if(rank == 0) {
+      std::ofstream out(path, std::ios::binary | std::ios::trunc);
+      if(!out.good()) { jfgpu_dump_end(ary->handle()); throw ErrorWriting("Can't open file '" + path + "'"); }
+      if(header_) {
+        ary->update_header(*header_);
+        header_->format(format);
+        header_->counter_len(val_len_);
+        header_->write(out);
+      }
+      out.flush();
+      if(!out.good()) { jfgpu_dump_end(ary->handle()); throw ErrorWriting("Error while writing '" + path + "'"); }
+      body = (off_t)out.tellp();
+      out.close();
+      if(comm && ::truncate(path.c_str(), body + (off_t)(all_records * rec)) != 0) { jfgpu_dump_end(ary->handle()); throw ErrorWriting("Can't size '" + path + "'"); }
+    }
+    if(comm) {                                                 // where the body starts; also: the file exists from here on
+      std::vector<uint64_t> bodies(world);
+      if(jfgpu_comm_allgather_u64(comm, (uint64_t)body, bodies.data())) { jfgpu_dump_end(ary->handle()); throw std::runtime_error(jfgpu_last_error()); }
+      body = (off_t)bodies[0] + (off_t)(first_record * rec);
+    }
     // Records have a fixed width and arrive in file order, so every chunk's place in the file is known: while
     // the device sorts and ships chunk i+1 into one buffer, a few threads pwrite() the slices of chunk i from
     // the other (a single write() stream copies into the page cache at 2-3 GB/s; the device delivers faster).

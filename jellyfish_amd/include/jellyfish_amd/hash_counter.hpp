@@ -40,8 +40,11 @@ public:
   // hash_counter(size, key_len (bits), val_len (bits), nb_threads, reprobe_limit)
   // (hash_counter.hpp:56-64).  val_len / nb_threads / reprobe_limit are CPU-table
   // knobs: accepted for source compatibility, the device slot format fixes them.
+  // shard_bits / shard_id: this object is one shard of a table spread over 2^shard_bits GPUs (size stays the GLOBAL size);
+  // see attach_comm.
   hash_counter(size_t size, uint16_t key_len, uint16_t val_len, uint16_t nb_threads, uint16_t reprobe_limit = 126,
-               bool canonical = false, int device = -1, uint32_t out_counter_len = 4, uint64_t matrix_seed = 0)
+               bool canonical = false, int device = -1, uint32_t out_counter_len = 4, uint64_t matrix_seed = 0,
+               uint32_t shard_bits = 0, uint32_t shard_id = 0)
       : nb_threads_(nb_threads) {
     (void)val_len; (void)reprobe_limit;
     if(key_len == 0 || key_len % 2) throw std::length_error("key_len must be an even number of bits");
@@ -49,12 +52,20 @@ public:
     memset(&p, 0, sizeof p);
     p.k = key_len / 2; p.canonical = canonical; p.size = size; p.device = device;
     p.matrix_seed = matrix_seed; p.out_counter_len = out_counter_len;
+    p.shard_bits = shard_bits; p.shard_id = shard_id;
     jf_check(jfgpu_create(&p, &t_));
     jf_check(jfgpu_get_info(t_, &info_));
     kw_ = (key_len + 63) / 64;
     pending_.reserve(kBatch * kw_);
   }
-  ~hash_counter() { if(t_) jfgpu_destroy(t_); }
+  ~hash_counter() { if(stage_) jfgpu_free_dev(t_, stage_); if(t_) jfgpu_destroy(t_); }
+
+  // Multi-GPU (one process per GPU): with a communicator attached, every sequence buffer is one collective
+  // step -- this rank's k-mers are routed to the shards that own them and what arrives is inserted here.  Ranks read
+  // different amounts of input, so each step starts by agreeing that somebody still has some; done() keeps stepping with
+  // nothing until nobody has (every rank makes the same number of steps), then completes the exchange.
+  void attach_comm(jfgpu_comm* c) { comm_ = c; }
+  jfgpu_comm* comm() const { return comm_; }
   hash_counter(const hash_counter&) = delete;
   hash_counter& operator=(const hash_counter&) = delete;
 
@@ -106,10 +117,27 @@ public:
 
   // ---- hot path -----------------------------------------------------------
   // One parser-contract buffer (count_main.cc:152-163 loop body on the device).
-  void count_sequence(const char* bases, size_t n) { flush(); jf_check(jfgpu_count_ascii(t_, bases, n)); }
+  void count_sequence(const char* bases, size_t n) {
+    flush();
+    if(!comm_) { jf_check(jfgpu_count_ascii(t_, bases, n)); return; }
+    if(n > stage_cap_) {                           // sharded: the routing kernels read device memory
+      if(stage_) jf_check(jfgpu_free_dev(t_, stage_));
+      stage_ = nullptr; stage_cap_ = 0;
+      jf_check(jfgpu_malloc_dev(t_, n + (n >> 2) + 64, &stage_));
+      stage_cap_ = n + (n >> 2);
+    }
+    jf_check(jfgpu_memcpy_h2d(t_, stage_, bases, n));
+    count_sequence_dev((const char*)stage_, n);
+  }
   // The same for a buffer already in device memory (device_sequence_parser); wait_consumed() says
   // when buffers handed over so far may be overwritten.
-  void count_sequence_dev(const char* d_bases, size_t n) { flush(); jf_check(jfgpu_count_ascii_dev(t_, d_bases, n)); }
+  void count_sequence_dev(const char* d_bases, size_t n) {
+    flush();
+    if(!comm_) { jf_check(jfgpu_count_ascii_dev(t_, d_bases, n)); return; }
+    uint64_t any = 1;
+    jf_check(jfgpu_comm_allreduce_u64(comm_, &any, 1, 0));
+    jf_check(jfgpu_comm_count_ascii_dev(comm_, t_, d_bases, n));    // returns when the buffer has been read
+  }
   void wait_consumed() { jf_check(jfgpu_wait(t_)); }
   // What count_sequence does with a k-mer: COUNT add(m, 1), PRIME set(m), UPDATE update_add(m, 1)
   // (the OPERATION of mer_counter_base, count_main.cc:133,152-184).
@@ -146,7 +174,24 @@ public:
     return true;
   }
   // done() (hash_counter.hpp:169-172): everything retired; throws "Hash full" if it did not fit.
-  void done() { flush(); jf_check(jfgpu_sync(t_)); refresh_info(); }
+  void done() {
+    flush();
+    if(comm_) {
+      while(true) {                                // other ranks may still have input: step with nothing until nobody has
+        uint64_t any = 0;
+        jf_check(jfgpu_comm_allreduce_u64(comm_, &any, 1, 0));
+        if(!any) break;
+        jf_check(jfgpu_comm_count_ascii_dev(comm_, t_, nullptr, 0));
+      }
+      uint64_t sent = 0, received = 0;
+      jf_check(jfgpu_comm_finish(comm_, &sent, &received));
+      uint64_t v[2] = {sent, received};
+      jf_check(jfgpu_comm_allreduce_u64(comm_, v, 2, 0));
+      if(v[0] != v[1]) throw std::runtime_error("multi-GPU exchange lost k-mers: " + std::to_string(v[0]) + " sent, " + std::to_string(v[1]) + " received");
+    }
+    jf_check(jfgpu_sync(t_));
+    refresh_info();
+  }
   void clear() { std::lock_guard<std::mutex> lock(mu_); pending_.clear(); jf_check(jfgpu_clear(t_)); }
 
   // array::get_val_for_key (large_hash_array.hpp:354-372)
@@ -175,6 +220,8 @@ private:
   }
 
   static constexpr size_t kBatch = 1 << 20;
+  jfgpu_comm* comm_ = nullptr;
+  void* stage_ = nullptr; size_t stage_cap_ = 0;
   jfgpu_table* t_ = nullptr;
   jfgpu_info info_;
   uint16_t nb_threads_;

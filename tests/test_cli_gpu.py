@@ -508,3 +508,64 @@ def test_bf_size_one_pass_filter_bound(cli, tmp_path):
         assert subprocess.check_output([O.REF_JF, "histo", "bf.jf"], cwd=d).decode().split() == histo
     r = subprocess.run([cli, "count", "--bf-size", "1M", "--bc", "x", "-m", "21", "-s", "1M", "a.fa"], cwd=d, capture_output=True)
     assert r.returncode == 1 and b"conflict" in r.stderr
+
+
+def _tricky_fastq(path, rng, n):
+    """FASTQ whose quality lines often start with '@' and whose sequences have 'N's: the record-boundary test must not be
+    fooled by a quality line."""
+    with open(path, "wb") as f:
+        for r in range(n):
+            L = rng.choice([40, 75, 151])
+            seq = "".join(rng.choice("ACGTN" if rng.random() < 0.1 else "ACGT") for _ in range(L))
+            qual = "".join(rng.choice("@+IIIIHHGG#5") for _ in range(L))
+            if r % 3 == 0:
+                qual = "@" + qual[1:]
+            f.write(("@r%d\n%s\n+\n%s\n" % (r, seq, qual)).encode())
+
+
+def test_file_parts_cover_the_file_exactly_once(cli, tmp_path):
+    """What the ranks of `count --gpus N` read: part r of N of every file, cut at record boundaries found independently
+    (device_sequence_parser::parse_file_part).  JFGPU_TEST_PARTS=N makes one process read the N parts one after the other:
+    the output must be the plain run's, for multi-line FASTA (records of very different lengths: some parts are empty),
+    FASTQ with '@' quality lines, pinned and mapped feeds."""
+    import random
+    rng = random.Random(5)
+    fa = tmp_path / "multi.fa"
+    with open(fa, "wb") as f:
+        for r in range(120):
+            seq = "".join(rng.choice("ACGT") for _ in range(rng.choice([30, 500, 30000])))
+            f.write((">s%d\n" % r).encode())
+            for i in range(0, len(seq), 70):
+                f.write(seq[i:i + 70].encode() + b"\n")
+    fq = tmp_path / "tricky.fq"
+    _tricky_fastq(fq, rng, 4000)
+    for inp in (str(fa), str(fq)):
+        ref = str(tmp_path / "ref.jf")
+        subprocess.check_call([cli, "count", "-m", "22", "-C", "-s", "4M", "-o", ref, inp])
+        want = _body(ref)                     # (headers differ by the command line / time; bodies must not)
+        for parts, pinned in ((2, "0"), (3, "1"), (8, "0"), (64, "1")):
+            o = str(tmp_path / ("p%d.jf" % parts))
+            subprocess.check_call([cli, "count", "-m", "22", "-C", "-s", "4M", "-o", o, inp],
+                                  env=dict(os.environ, JFGPU_TEST_PARTS=str(parts), JFGPU_FEED_PINNED=pinned, JFGPU_PARSE_CHUNK="100000"))
+            assert _body(o) == want and len(want) > 0, (inp, parts)
+
+
+@pytest.mark.parametrize("self_rccl", ["0", "1"])
+def test_count_gpus_1_goes_through_the_ranks_machinery(cli, tmp_path, self_rccl):
+    """`count --gpus 1`: the command starts one rank process (rendezvous directory, RCCL id, communicator of world 1), the
+    rank routes every k-mer through the exchange (JFGPU_COMM_SELF_RCCL=1: through ncclSend / ncclRecv to itself), agrees on
+    the number of steps, and writes its records through the sharded writer.  File body and digest equal the plain run's."""
+    case = next(c for c in MANIFEST["cases"] if c["name"] == "reads150_k21C")
+    inp = os.path.join(GOLD, case["input"])
+    ref, out = str(tmp_path / "ref.jf"), str(tmp_path / "g1.jf")
+    dg0, dg1 = str(tmp_path / "d0.txt"), str(tmp_path / "d1.txt")
+    subprocess.check_call([cli, "count", "-m", "21", "-C", "-s", case["size"], "-o", ref, "--digest", dg0, inp])
+    subprocess.check_call([cli, "count", "-m", "21", "-C", "-s", case["size"], "-o", out, "--digest", dg1, "--gpus", "1", "--timing", str(tmp_path / "t"), inp],
+                          env=dict(os.environ, JFGPU_COMM_SELF_RCCL=self_rccl, JFGPU_PARSE_CHUNK="200000"), timeout=600)
+    assert open(dg0).read() == open(dg1).read()
+    assert _body(out) == _body(ref)
+    assert subprocess.check_output([cli, "stats", out]) == subprocess.check_output([cli, "stats", ref])
+    assert open(tmp_path / "t").read().split()[0::2] == ["Init", "Counting", "Writing"]
+    for bad in (["--gpus", "3"], ["--gpus", "2", "--text"]):
+        r = subprocess.run([cli, "count", "-m", "21", "-s", "1M", "-o", out] + bad + [inp], capture_output=True)
+        assert r.returncode != 0 and b"--gpus" in r.stderr
