@@ -36,11 +36,23 @@ struct jfgpu_comm {
     bool used[2] = {false, false};
     int turn = 0; bool inflight = false;
     uint64_t sent = 0, received = 0;
+    // item path (see comm_route_items): this step's region capacity (0: the step went as 8-byte keys), the P1 cursors,
+    // k-mers per input byte seen so far (sizes the regions)
+    uint32_t icap[2] = {0, 0};
+    unsigned int* d_gcur = nullptr;              // gcur[2 * 1024] (u32) then tot[1024] (u64)
+    std::vector<uint64_t> claims;
+    unsigned long long* d_claimed = nullptr;     // k-mers the senders said they sent here (item path), summed on the device
+    double ipb = 0;
+    uint64_t strag_seen = 0;
   };
+  bool items_on = true; int items_mode = 1;      // JFGPU_COMM_ITEMS: 0 always send 8-byte keys, 1 items when the step is large enough, 2 items always
+  uint32_t strag_cap = 1u << 16;                 // stragglers per rank and step (JFGPU_COMM_STRAG)
   std::vector<Rank> ranks;                       // RCCL transport: one; local transport: `world`
 };
 
 namespace {
+
+int comm_reserve(uint64_t*& buf, size_t& cap, size_t need, hipStream_t s1, hipStream_t s2);
 
 int comm_init_rank(jfgpu_comm* c, jfgpu_comm::Rank& R) {
   for(int i = 0; i < 2; ++i) {
@@ -51,6 +63,193 @@ int comm_init_rank(jfgpu_comm* c, jfgpu_comm::Rank& R) {
   }
   HIP_TRY(hipMalloc((void**)&R.d_cnt, sizeof(unsigned long long) * c->world));
   HIP_TRY(hipMalloc((void**)&R.d_xc, sizeof(uint64_t) * 2 * c->world));
+  HIP_TRY(hipMalloc((void**)&R.d_gcur, 1024 * 16));
+  HIP_TRY(hipMalloc((void**)&R.d_claimed, 8));
+  HIP_TRY(hipMemset(R.d_claimed, 0, 8));
+  return JFGPU_OK;
+}
+
+// ---- the item path: 4 bytes per k-mer, already grouped for the receiver ------------------------------------------
+// Sender: p1_route_granule_kernel = the single-pass P1 over the global table (1024 buckets = owner x coarse bucket), so
+// an owner's share is one contiguous run of regions -- equal-sized messages, no counts to exchange.  Receiver: the regions
+// of its coarse buckets from all W senders go through one more split (fan-out W, p2_granule_kernel) into the regions of
+// its own 1024 P1 buckets: a pending batch like any other, applied by the next flush.  Region capacity is agreed per
+// step (the maximum of what the ranks want); what cannot travel this way (a region overflows on skewed input, the item
+// that looks like a hole) goes on a short list every rank receives.  A step falls back to 8-byte keys on all ranks when
+// any rank says so: geometry (2k - 10 > 32 bits, fewer than 2^23 slots per shard), steps too small for fixed regions,
+// or more stragglers than the list holds.
+struct ItemLayout {
+  uint32_t cap, nbg, nbc, gbits, cbits, split_bits, S;
+  size_t items_bytes, offs_at, claims_at, strag_at, send_bytes;   // send buffer: items[nbg * cap] | offs[2 * nbg] | claims[W] | strag[1 + S]
+  size_t r_offs_at, r_claims_at, r_strag_at, recv_bytes;          // recv buffer: items[nbg * cap] | offs[2 * nbg] | claims[W] | W x strag[1 + S]
+};                                                                // (claims[p]: k-mers the sender says it sends to rank p: bookkeeping for sent == received)
+// nbg = 2^gbits sender buckets = W owners x nbc = 2^cbits coarse buckets each; the receiver splits a coarse bucket into
+// 2^split_bits of its own 2^b1 P1 buckets (b1 = cbits + split_bits).  gbits = min(10, shard_bits + b1).
+ItemLayout item_layout(const jfgpu_comm* c, const jfgpu_table* t, uint32_t cap) {
+  ItemLayout L;
+  uint32_t sb = 0; while((1 << sb) < c->world) ++sb;
+  L.gbits = std::min<uint32_t>(10, sb + t->pg.b1); L.cbits = L.gbits - sb; L.split_bits = t->pg.b1 - L.cbits;
+  L.cap = cap; L.nbg = 1u << L.gbits; L.nbc = 1u << L.cbits; L.S = c->strag_cap;
+  L.items_bytes = align_up((size_t)L.nbg * cap * 4, 256);
+  L.offs_at = L.items_bytes; L.claims_at = L.offs_at + (size_t)2 * L.nbg * 8; L.strag_at = L.claims_at + 1024 * 8;
+  L.send_bytes = L.strag_at + (size_t)(1 + L.S) * 8;
+  L.r_offs_at = L.items_bytes; L.r_claims_at = L.r_offs_at + (size_t)2 * L.nbg * 8; L.r_strag_at = L.r_claims_at + 1024 * 8;
+  L.recv_bytes = L.r_strag_at + (size_t)c->world * (1 + L.S) * 8;
+  return L;
+}
+
+bool items_geometry_ok(const jfgpu_comm* c, const jfgpu_table* t) {
+  if(!c->items_on || t->wide || t->nword || c->world > 512) return false;
+  if(!t->part_ok || !t->item32 || t->pg.b2 == 0) return false;              // the shard inserts through two partition levels, 32-bit items
+  uint32_t sb = 0; while((1 << sb) < c->world) ++sb;
+  const uint32_t gbits = std::min<uint32_t>(10, sb + t->pg.b1);
+  if(gbits < sb || t->g.key_bits < gbits || t->g.key_bits - gbits > 32) return false;   // the routed item is 2k - gbits bits
+  return t->g.lsize_g >= t->g.tile_bits + gbits;
+}
+
+// Region capacity this rank wants for a step of n bytes (0: it would rather send keys).
+uint32_t items_cap_wanted(const jfgpu_comm* c, const jfgpu_comm::Rank& R, size_t n) {
+  const jfgpu_table* t = R.t;
+  if(!items_geometry_ok(c, t)) return 0;
+  const ItemLayout L = item_layout(c, t, 64);
+  const double ipb = R.ipb > 0 ? std::min(1.0, R.ipb * 1.10 + 0.005) : 1.0;
+  const uint64_t items = (uint64_t)((double)n * ipb) + 4096;
+  const uint64_t strand = (uint64_t)(2 * t->n_cu) * kGran, mean = (items + L.nbg - 1) / L.nbg;
+  if(mean < 4 * strand && c->items_mode < 2) return 0;                      // regions would be mostly holes (2: forced, for tests)
+  const uint64_t cap = ((uint64_t)((double)mean * 1.10) + strand + kGran - 1) / kGran * kGran;
+  if(cap > 0x7FFF0000ull) return 0;
+  return (uint32_t)cap;
+}
+
+// P1 over the global table into send[cur]; the host waits once (stragglers, exact item count).  *overflow: more
+// stragglers than the list holds -- the step has to be redone with keys.
+int comm_route_items(jfgpu_comm* c, jfgpu_comm::Rank& R, const char* d_bases, size_t n, uint32_t cap, bool* overflow, uint64_t* routed) {
+  jfgpu_table* t = R.t;
+  const int cur = R.turn;
+  const ItemLayout L = item_layout(c, t, cap);
+  *overflow = false; *routed = 0;
+  if(R.used[cur]) HIP_TRY(hipEventSynchronize(R.exchanged[cur]));       // send[cur] has left (step - 2)
+  int rc = comm_reserve(R.send[cur], R.send_cap[cur], (L.send_bytes + 7) / 8, t->stream, c->xstream); if(rc) return rc;
+  if(!R.used[cur ^ 1]) { rc = comm_reserve(R.send[cur ^ 1], R.send_cap[cur ^ 1], (L.send_bytes + 7) / 8, t->stream, c->xstream); if(rc) return rc; }   // (both buffers of the pair at once)
+  uint8_t* sb = reinterpret_cast<uint8_t*>(R.send[cur]);
+  uint32_t* items = reinterpret_cast<uint32_t*>(sb);
+  uint64_t* offs = reinterpret_cast<uint64_t*>(sb + L.offs_at);
+  uint64_t* strag = reinterpret_cast<uint64_t*>(sb + L.strag_at);
+  unsigned long long* tot = reinterpret_cast<unsigned long long*>(R.d_gcur + 2 * L.nbg);
+  HIP_TRY(hipMemsetAsync(R.d_gcur, 0, 1024 * 16, t->stream));
+  HIP_TRY(hipMemsetAsync(strag, 0, 8, t->stream));
+  if(n >= t->g.k) {
+    DevTable gv = t->dt;                                   // the shard's table seen as one table of 2^lsize_g slots
+    gv.g.lsize_l = gv.g.lsize_g; gv.g.shard_bits = 0; gv.g.shard_id = 0;
+    gv.g.local_mask = gv.g.lsize_g >= 64 ? ~0ull : ((1ull << gv.g.lsize_g) - 1);
+    PartGeom pg; memset(&pg, 0, sizeof pg);
+    pg.b1 = L.gbits; pg.b2 = gv.g.lsize_g - gv.g.tile_bits - L.gbits; pg.rest_shift = gv.g.lsize_g - L.gbits; pg.item_bits = pg.rest_shift + gv.g.rem_bits;
+    const uint8_t* base; int64_t lo, hi;
+    align_buffer(d_bases, n, base, lo, hi);
+    const StragList SL{reinterpret_cast<unsigned long long*>(strag), strag + 1, L.S, 0};
+    const size_t lds = (size_t)kPTilePos * 6;
+    const dim3 grid(2 * t->n_cu), block(kPBlock);
+    ProfScope ps(t, 2, n);
+#define PR(N) hipLaunchKernelGGL(p1_route_granule_kernel<N>, grid, block, lds, t->stream, gv, pg, base, lo, hi, cap, R.d_gcur, tot, items, SL)
+    if(t->g.nbytes == 6) PR(6); else if(t->g.nbytes == 7) PR(7); else if(t->g.nbytes == 8) PR(8); else PR(0);
+#undef PR
+  }
+  hipLaunchKernelGGL(granule_finish_kernel, dim3(4), dim3(256), 0, t->stream, R.d_gcur, cap, L.nbg, offs);
+  HIP_TRY(hipGetLastError());
+  std::vector<uint64_t> h(1024 + 1, 0);
+  HIP_TRY(hipMemcpyAsync(h.data(), tot, (size_t)L.nbg * 8, hipMemcpyDeviceToHost, t->stream));
+  HIP_TRY(hipMemcpyAsync(h.data() + 1024, strag, 8, hipMemcpyDeviceToHost, t->stream));
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  uint64_t stored = 0; for(int j = 0; j < 1024; ++j) stored += h[j];
+  if(h[1024] > L.S) { *overflow = true; return JFGPU_OK; }
+  if(n >= ((size_t)1 << 20)) R.ipb = (double)(stored + h[1024]) / (double)n;
+  // what every owner is being sent (regions + its stragglers): travels with the regions, summed up by the receivers
+  R.claims.assign(c->world, 0);
+  for(uint32_t j = 0; j < L.nbg; ++j) R.claims[j / L.nbc] += h[j];
+  if(h[1024]) {
+    std::vector<uint64_t> lst(h[1024]);
+    HIP_TRY(hipMemcpyAsync(lst.data(), strag + 1, h[1024] * 8, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    for(uint64_t r : lst) R.claims[(uint32_t)(r >> 32) / L.nbc] += 1;
+  }
+  HIP_TRY(hipMemcpyAsync(sb + L.claims_at, R.claims.data(), (size_t)c->world * 8, hipMemcpyHostToDevice, t->stream));
+  HIP_TRY(hipStreamSynchronize(t->stream));                 // (R.claims is reused by the next step)
+  *routed = stored + h[1024];
+  if(getenv("JFGPU_FLUSH_TRACE"))
+    fprintf(stderr, "[comm] item path: %zu bytes -> %llu items in %u regions of %u, %llu stragglers\n", n, (unsigned long long)stored, L.nbg, cap, (unsigned long long)h[1024]);
+  return JFGPU_OK;
+}
+
+__global__ void comm_add_claims_kernel(const uint64_t* __restrict__ claims, int n, unsigned long long* __restrict__ total) {
+  if(blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long s = 0; for(int i = 0; i < n; ++i) s += claims[i]; *total += s; }
+}
+
+// What arrived for the previous step (item path): one split of every coarse bucket into the shard's own P1 buckets, then
+// the stragglers; the result is a pending batch.
+int comm_insert_prev_items(jfgpu_comm* c, jfgpu_comm::Rank& R, int rank) {
+  const int prev = R.turn ^ 1, W = c->world;
+  jfgpu_table* t = R.t;
+  const ItemLayout L = item_layout(c, t, R.icap[prev]);
+  const uint32_t sb = L.split_bits;                        // bits that finish the shard's own bucket index
+  const uint32_t nb = 1u << t->pg.b1;
+  constexpr uint32_t kBlocksPerBucket = 4;
+  const uint32_t cap2 = (uint32_t)(((uint64_t)L.cap + (uint64_t)kBlocksPerBucket * kGran + kGran - 1) / kGran * kGran);
+  const size_t bytes = (size_t)nb * cap2 * 4;
+  const size_t need = align_up(bytes, 256) + align_up((2 * nb + 1) * sizeof(uint64_t), 256) + align_up(nb * 16, 256) + 1024;
+  if(t->pending.size() >= kMaxSeg) { int rc = part_flush(t); if(rc) return rc; }
+  if(t->ws_used + need > t->ws_cap) {
+    if(!t->pending.empty()) { int rc = part_flush(t); if(rc) return rc; }
+    if(need > t->ws_cap) { int rc = ws_grow(t, need); if(rc) return rc < 0 ? fail(JFGPU_E_ALLOC, "no device memory for the partition workspace of a shard") : rc; }
+  }
+  HIP_TRY(hipStreamWaitEvent(t->stream, R.exchanged[prev], 0));
+  PendingBatch b{nullptr, nullptr, (uint64_t)nb * cap2};
+  b.items = ws_alloc(t, bytes);
+  b.off = (uint64_t*)ws_alloc(t, (2 * nb + 1) * sizeof(uint64_t));
+  unsigned int* gcur = (unsigned int*)ws_alloc(t, nb * 16);             // gcur[2 nb] (u32) then tot[nb] (u64)
+  if(!b.items || !b.off || !gcur) return fail(JFGPU_E_ALLOC, "partition workspace exhausted");
+  b.gran_cap = cap2; b.tot = (unsigned long long*)(gcur + 2 * nb);
+  HIP_TRY(hipMemsetAsync(gcur, 0, nb * 16, t->stream));
+  const uint8_t* rb = reinterpret_cast<const uint8_t*>(R.recv[prev]);
+  const uint32_t* r_items = reinterpret_cast<const uint32_t*>(rb);
+  const uint64_t* r_offs = reinterpret_cast<const uint64_t*>(rb + L.r_offs_at);
+  const uint64_t* r_strag = reinterpret_cast<const uint64_t*>(rb + L.r_strag_at);
+  hipLaunchKernelGGL(comm_add_claims_kernel, dim3(1), dim3(64), 0, t->stream, reinterpret_cast<const uint64_t*>(rb + L.r_claims_at), W, R.d_claimed);
+  // sender p's regions of my coarse buckets sit at r_items + p * nbc * cap, its offsets speak of its own whole output
+  // (bucket j of 1024 at j * cap): bases shifted so that "bucket = rank * nbc + coarse" finds both
+  SegList S; memset(&S, 0, sizeof S);
+  S.n = (uint32_t)W;
+  const int64_t first = (int64_t)rank * L.nbc;
+  for(int p = 0; p < W; ++p) {
+    S.items[p] = r_items + (int64_t)p * L.nbc * L.cap - first * (int64_t)L.cap;
+    S.off[p] = r_offs + (int64_t)p * 2 * L.nbc - 2 * first;
+    S.sh[p] = 1;
+  }
+  PartGeom pd = t->pg;                                     // direct inserts of (coarse bucket, item)
+  pd.b1 = L.cbits; pd.b2 = t->g.lsize_l - t->g.tile_bits - L.cbits;
+  const uint32_t split_at = t->g.key_bits - L.gbits - sb;  // where those bits sit in a routed item (its top bits)
+  const int64_t dshift = first * (int64_t)(1u << sb);      // destinations are numbered from this rank's first bucket
+  {
+    ProfScope ps(t, 1, 0);
+    const dim3 grid(kBlocksPerBucket, L.nbc), block(kPBlock);
+    const size_t lds = (size_t)kPBlock * kP2PairPer * 4;
+    unsigned int* gc_v = gcur - dshift; unsigned int* gs_v = gcur + nb - dshift;
+    uint32_t* out_v = reinterpret_cast<uint32_t*>(b.items) - dshift * (int64_t)cap2;
+    unsigned long long* tot_v = b.tot - dshift;
+    if(t->returning) hipLaunchKernelGGL((p2_granule_kernel<true, kP2PairPer, true>), grid, block, lds, t->stream, t->dt, pd, sb, split_at, S, cap2, gc_v, gs_v, out_v, (uint32_t)first, tot_v, L.nbc - 1);
+    else             hipLaunchKernelGGL((p2_granule_kernel<false, kP2PairPer, true>), grid, block, lds, t->stream, t->dt, pd, sb, split_at, S, cap2, gc_v, gs_v, out_v, (uint32_t)first, tot_v, L.nbc - 1);
+    hipLaunchKernelGGL(granule_finish_kernel, dim3(4), dim3(256), 0, t->stream, gcur, cap2, nb, b.off);
+    for(int p = 0; p < W; ++p) {
+      const uint64_t* lst = r_strag + (size_t)p * (1 + L.S);
+      if(t->returning) hipLaunchKernelGGL(straggler_insert_kernel<true>, dim3(64), dim3(kBlock), 0, t->stream, t->dt, pd, lst + 1, (const unsigned long long*)lst, L.S, (uint32_t)rank, L.cbits);
+      else             hipLaunchKernelGGL(straggler_insert_kernel<false>, dim3(64), dim3(kBlock), 0, t->stream, t->dt, pd, lst + 1, (const unsigned long long*)lst, L.S, (uint32_t)rank, L.cbits);
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  t->pending.push_back(b);
+  t->pending_bytes += bytes;
+  t->pristine = false;
+  HIP_TRY(hipEventRecord(R.consumed[prev], t->stream));
+  R.inflight = false;
   return JFGPU_OK;
 }
 
@@ -59,7 +258,7 @@ int comm_reserve(uint64_t*& buf, size_t& cap, size_t need, hipStream_t s1, hipSt
   HIP_TRY(hipStreamSynchronize(s1)); HIP_TRY(hipStreamSynchronize(s2));
   if(buf) hipFree(buf);
   buf = nullptr; cap = 0;
-  const size_t want = need + need / 16 + 1024;
+  const size_t want = need + need / 4 + 1024;      // steps differ in size: head-room, so that the buffers are not re-allocated mid-job
   HIP_TRY(hipMalloc((void**)&buf, want * sizeof(uint64_t)));
   cap = want;
   return JFGPU_OK;
@@ -77,6 +276,7 @@ int comm_route(jfgpu_comm* c, jfgpu_comm::Rank& R, const char* d_bases, size_t n
   std::fill(R.soff[cur].begin(), R.soff[cur].end(), 0);
   if(n < t->g.k) return JFGPU_OK;
   int rc = comm_reserve(R.send[cur], R.send_cap[cur], n, t->stream, c->xstream); if(rc) return rc;
+  if(!R.used[cur ^ 1]) { rc = comm_reserve(R.send[cur ^ 1], R.send_cap[cur ^ 1], n, t->stream, c->xstream); if(rc) return rc; }   // (both buffers of the pair at once)
   const uint8_t* base; int64_t lo, hi;
   align_buffer(d_bases, n, base, lo, hi);
   const int64_t n_tiles = (hi + kTilePos - 1) / kTilePos;
@@ -104,9 +304,11 @@ int comm_route(jfgpu_comm* c, jfgpu_comm::Rank& R, const char* d_bases, size_t n
 }
 
 // What arrived for the previous step goes into the table (P1 from keys: pending batch applied at the next flush).
+int comm_insert_prev_items(jfgpu_comm* c, jfgpu_comm::Rank& R, int rank);
 int comm_insert_prev(jfgpu_comm* c, jfgpu_comm::Rank& R) {
   if(!R.inflight) return JFGPU_OK;
   const int prev = R.turn ^ 1;
+  if(R.icap[prev]) return comm_insert_prev_items(c, R, c->local ? (int)(&R - c->ranks.data()) : c->rank);
   jfgpu_table* t = R.t;
   HIP_TRY(hipStreamWaitEvent(t->stream, R.exchanged[prev], 0));
   const uint64_t n = R.roff[prev][c->world];
@@ -153,6 +355,7 @@ int comm_exchange_rccl(jfgpu_comm* c) {
   R.roff[cur][W] = total;
   if(R.used[cur]) HIP_TRY(hipEventSynchronize(R.consumed[cur]));          // recv[cur] was read by the insert of step - 2
   int rc = comm_reserve(R.recv[cur], R.recv_cap[cur], total, R.t->stream, c->xstream); if(rc) return rc;
+  if(!R.used[cur ^ 1]) { rc = comm_reserve(R.recv[cur ^ 1], R.recv_cap[cur ^ 1], total, R.t->stream, c->xstream); if(rc) return rc; }
   HIP_TRY(hipEventRecord(R.routed[cur], R.t->stream));
   HIP_TRY(hipStreamWaitEvent(c->xstream, R.routed[cur], 0));
   // this rank's own share: a device copy (1/W of the keys; everything, for a world of one)
@@ -225,6 +428,104 @@ int comm_exchange_local(jfgpu_comm* c) {
   return JFGPU_OK;
 }
 
+// The exchange of an item-path step, RCCL transport: equal-sized messages, nothing to agree on.
+int comm_exchange_items_rccl(jfgpu_comm* c) {
+#if defined(JFGPU_EMU)
+  (void)c;
+  return fail(JFGPU_E_UNSUPPORTED, "no RCCL in the emulated build");
+#else
+  jfgpu_comm::Rank& R = c->ranks[0];
+  const int cur = R.turn, W = c->world;
+  const ItemLayout L = item_layout(c, R.t, R.icap[cur]);
+  if(R.used[cur]) HIP_TRY(hipEventSynchronize(R.consumed[cur]));          // recv[cur] was read by the insert of step - 2
+  int rc = comm_reserve(R.recv[cur], R.recv_cap[cur], (L.recv_bytes + 7) / 8, R.t->stream, c->xstream); if(rc) return rc;
+  if(!R.used[cur ^ 1]) { rc = comm_reserve(R.recv[cur ^ 1], R.recv_cap[cur ^ 1], (L.recv_bytes + 7) / 8, R.t->stream, c->xstream); if(rc) return rc; }
+  HIP_TRY(hipEventRecord(R.routed[cur], R.t->stream));
+  HIP_TRY(hipStreamWaitEvent(c->xstream, R.routed[cur], 0));
+  uint8_t* sb = reinterpret_cast<uint8_t*>(R.send[cur]);
+  uint8_t* rb = reinterpret_cast<uint8_t*>(R.recv[cur]);
+  const size_t blk = (size_t)L.nbc * L.cap;                               // items per (sender, receiver) message
+  const int skip = c->self_rccl ? -1 : c->rank;
+  auto s_items = [&](int p) { return reinterpret_cast<uint32_t*>(sb) + (size_t)p * blk; };
+  auto r_items = [&](int p) { return reinterpret_cast<uint32_t*>(rb) + (size_t)p * blk; };
+  auto s_offs = [&](int p) { return reinterpret_cast<uint64_t*>(sb + L.offs_at) + (size_t)p * 2 * L.nbc; };
+  auto r_offs = [&](int p) { return reinterpret_cast<uint64_t*>(rb + L.r_offs_at) + (size_t)p * 2 * L.nbc; };
+  uint64_t* s_claims = reinterpret_cast<uint64_t*>(sb + L.claims_at);
+  uint64_t* r_claims = reinterpret_cast<uint64_t*>(rb + L.r_claims_at);
+  uint64_t* s_strag = reinterpret_cast<uint64_t*>(sb + L.strag_at);
+  auto r_strag = [&](int p) { return reinterpret_cast<uint64_t*>(rb + L.r_strag_at) + (size_t)p * (1 + L.S); };
+  if(skip >= 0) {
+    const int p = c->rank;
+    HIP_TRY(hipMemcpyAsync(r_items(p), s_items(p), blk * 4, hipMemcpyDeviceToDevice, c->xstream));
+    HIP_TRY(hipMemcpyAsync(r_offs(p), s_offs(p), (size_t)2 * L.nbc * 8, hipMemcpyDeviceToDevice, c->xstream));
+    HIP_TRY(hipMemcpyAsync(r_claims + p, s_claims + p, 8, hipMemcpyDeviceToDevice, c->xstream));
+    HIP_TRY(hipMemcpyAsync(r_strag(p), s_strag, (size_t)(1 + L.S) * 8, hipMemcpyDeviceToDevice, c->xstream));
+  }
+  if(W > 1 || c->self_rccl) {
+    // the regions in rounds of at most max_msg_keys * 8 bytes per peer (sizes are the same everywhere: nothing to agree on)
+    const size_t per = std::max<size_t>(1, (size_t)c->max_msg_keys * 2);
+    for(size_t lo = per; lo < blk; lo += per) {
+      NCCL_TRY(ncclGroupStart());
+      for(int p = 0; p < W; ++p) {
+        if(p == skip) continue;
+        const size_t len = std::min(per, blk - lo);
+        NCCL_TRY(ncclSend(s_items(p) + lo, len, ncclUint32, p, c->nccl, c->xstream));
+        NCCL_TRY(ncclRecv(r_items(p) + lo, len, ncclUint32, p, c->nccl, c->xstream));
+      }
+      NCCL_TRY(ncclGroupEnd());
+    }
+    NCCL_TRY(ncclGroupStart());
+    for(int p = 0; p < W; ++p) {
+      if(p == skip) continue;
+      NCCL_TRY(ncclSend(s_items(p), std::min(per, blk), ncclUint32, p, c->nccl, c->xstream));
+      NCCL_TRY(ncclRecv(r_items(p), std::min(per, blk), ncclUint32, p, c->nccl, c->xstream));
+      NCCL_TRY(ncclSend(s_offs(p), (size_t)2 * L.nbc, ncclUint64, p, c->nccl, c->xstream));
+      NCCL_TRY(ncclRecv(r_offs(p), (size_t)2 * L.nbc, ncclUint64, p, c->nccl, c->xstream));
+      NCCL_TRY(ncclSend(s_claims + p, 1, ncclUint64, p, c->nccl, c->xstream));
+      NCCL_TRY(ncclRecv(r_claims + p, 1, ncclUint64, p, c->nccl, c->xstream));
+      NCCL_TRY(ncclSend(s_strag, (size_t)(1 + L.S), ncclUint64, p, c->nccl, c->xstream));
+      NCCL_TRY(ncclRecv(r_strag(p), (size_t)(1 + L.S), ncclUint64, p, c->nccl, c->xstream));
+    }
+    NCCL_TRY(ncclGroupEnd());
+  }
+  HIP_TRY(hipEventRecord(R.exchanged[cur], c->xstream));
+  R.used[cur] = true;
+  return JFGPU_OK;
+#endif
+}
+
+// The same for the local transport.
+int comm_exchange_items_local(jfgpu_comm* c) {
+  const int W = c->world;
+  const ItemLayout L = item_layout(c, c->ranks[0].t, c->ranks[0].icap[c->ranks[0].turn]);
+  for(int d = 0; d < W; ++d) {
+    jfgpu_comm::Rank& D = c->ranks[d];
+    if(D.used[D.turn]) HIP_TRY(hipEventSynchronize(D.consumed[D.turn]));
+    int rc = comm_reserve(D.recv[D.turn], D.recv_cap[D.turn], (L.recv_bytes + 7) / 8, D.t->stream, c->xstream); if(rc) return rc;
+  }
+  for(int s = 0; s < W; ++s) {
+    jfgpu_comm::Rank& S = c->ranks[s];
+    HIP_TRY(hipEventRecord(S.routed[S.turn], S.t->stream));
+    HIP_TRY(hipStreamWaitEvent(c->xstream, S.routed[S.turn], 0));
+  }
+  const size_t blk = (size_t)L.nbc * L.cap;
+  for(int s = 0; s < W; ++s)
+    for(int d = 0; d < W; ++d) {
+      const uint8_t* sb = reinterpret_cast<const uint8_t*>(c->ranks[s].send[c->ranks[s].turn]);
+      uint8_t* rb = reinterpret_cast<uint8_t*>(c->ranks[d].recv[c->ranks[d].turn]);
+      HIP_TRY(hipMemcpyAsync(rb + (size_t)s * blk * 4, sb + (size_t)d * blk * 4, blk * 4, hipMemcpyDeviceToDevice, c->xstream));
+      HIP_TRY(hipMemcpyAsync(rb + L.r_offs_at + (size_t)s * 2 * L.nbc * 8, sb + L.offs_at + (size_t)d * 2 * L.nbc * 8, (size_t)2 * L.nbc * 8, hipMemcpyDeviceToDevice, c->xstream));
+      HIP_TRY(hipMemcpyAsync(rb + L.r_claims_at + (size_t)s * 8, sb + L.claims_at + (size_t)d * 8, 8, hipMemcpyDeviceToDevice, c->xstream));
+      HIP_TRY(hipMemcpyAsync(rb + L.r_strag_at + (size_t)s * (1 + L.S) * 8, sb + L.strag_at, (size_t)(1 + L.S) * 8, hipMemcpyDeviceToDevice, c->xstream));
+    }
+  for(int d = 0; d < W; ++d) {
+    jfgpu_comm::Rank& D = c->ranks[d];
+    HIP_TRY(hipEventRecord(D.exchanged[D.turn], c->xstream));
+    D.used[D.turn] = true;
+  }
+  return JFGPU_OK;
+}
+
 void comm_free_rank(jfgpu_comm::Rank& R) {
   for(int i = 0; i < 2; ++i) {
     if(R.send[i]) hipFree(R.send[i]);
@@ -235,6 +536,8 @@ void comm_free_rank(jfgpu_comm::Rank& R) {
   }
   if(R.d_cnt) hipFree(R.d_cnt);
   if(R.d_xc) hipFree(R.d_xc);
+  if(R.d_gcur) hipFree(R.d_gcur);
+  if(R.d_claimed) hipFree(R.d_claimed);
 }
 
 }  // namespace
@@ -275,6 +578,8 @@ int jfgpu_comm_create(int world, int rank, const uint8_t* id128, int device, jfg
   int rc = comm_init_rank(c.get(), c->ranks[0]); if(rc) return rc;
   if(const char* e = getenv("JFGPU_COMM_MAX_MSG")) c->max_msg_keys = std::max<uint64_t>(1, strtoull(e, 0, 10));
   if(const char* e = getenv("JFGPU_COMM_SELF_RCCL")) c->self_rccl = atoi(e) != 0;
+  if(const char* e = getenv("JFGPU_COMM_ITEMS")) { c->items_mode = atoi(e); c->items_on = c->items_mode != 0; }
+  if(const char* e = getenv("JFGPU_COMM_STRAG")) c->strag_cap = (uint32_t)std::max(1, atoi(e));
   *out = c.release();
   return JFGPU_OK;
 #endif
@@ -292,6 +597,8 @@ int jfgpu_comm_create_local(int world, int device, jfgpu_comm** out) {
   c->ranks.resize(world);
   for(auto& R : c->ranks) { int rc = comm_init_rank(c.get(), R); if(rc) return rc; }
   if(const char* e = getenv("JFGPU_COMM_MAX_MSG")) c->max_msg_keys = std::max<uint64_t>(1, strtoull(e, 0, 10));
+  if(const char* e = getenv("JFGPU_COMM_ITEMS")) { c->items_mode = atoi(e); c->items_on = c->items_mode != 0; }
+  if(const char* e = getenv("JFGPU_COMM_STRAG")) c->strag_cap = (uint32_t)std::max(1, atoi(e));
   *out = c.release();
   return JFGPU_OK;
 }
@@ -316,8 +623,24 @@ int jfgpu_comm_count_ascii_dev(jfgpu_comm* c, jfgpu_table* t, const char* d_base
   if((int)t->g.shard_id != c->rank) return fail(JFGPU_E_INVALID, "table shard_id is not this communicator's rank");
   jfgpu_comm::Rank& R = c->ranks[0];
   R.t = t;
-  rc = comm_route(c, R, d_bases, n); if(rc) return rc;
-  rc = comm_exchange_rccl(c); if(rc) return rc;
+  // item path or keys?  every rank says what region capacity it wants (0: keys); one "keys" decides for all
+  uint64_t v[2] = {items_cap_wanted(c, R, n) == 0 ? 1ull : 0ull, items_cap_wanted(c, R, n)};
+  rc = jfgpu_comm_allreduce_u64(c, v, 2, 1); if(rc) return rc;
+  uint32_t cap = v[0] ? 0u : (uint32_t)v[1];
+  uint64_t routed = 0;
+  if(cap) {
+    bool overflow = false;
+    rc = comm_route_items(c, R, d_bases, n, cap, &overflow, &routed); if(rc) return rc;
+    uint64_t o = overflow ? 1 : 0;
+    rc = jfgpu_comm_allreduce_u64(c, &o, 1, 1); if(rc) return rc;
+    if(o) cap = 0;                                           // somebody has more stragglers than the list holds: this step goes as keys
+  }
+  R.icap[R.turn] = cap;
+  if(cap) { R.sent += routed; rc = comm_exchange_items_rccl(c); if(rc) return rc; }
+  else {
+    rc = comm_route(c, R, d_bases, n); if(rc) return rc;
+    rc = comm_exchange_rccl(c); if(rc) return rc;
+  }
   rc = comm_insert_prev(c, R); if(rc) return rc;            // overlaps with the exchange just enqueued
   R.inflight = true; R.turn ^= 1;
   return JFGPU_OK;
@@ -327,13 +650,35 @@ int jfgpu_comm_count_ascii_dev(jfgpu_comm* c, jfgpu_table* t, const char* d_base
 int jfgpu_comm_local_step(jfgpu_comm* c, jfgpu_table** tables, const char* const* d_bases, const size_t* n) {
   if(!c || !c->local) return fail(JFGPU_E_INVALID, "not a local communicator");
   if(!tables || !d_bases || !n) return fail(JFGPU_E_INVALID, "null argument");
+  uint32_t cap = 0xFFFFFFFFu, want_max = 0;
   for(int r = 0; r < c->world; ++r) {
     int rc = use(tables[r]); if(rc) return rc;
     if((int)tables[r]->g.shard_id != r) return fail(JFGPU_E_INVALID, "tables must be given in shard order");
     c->ranks[r].t = tables[r];
-    rc = comm_route(c, c->ranks[r], d_bases[r], n[r]); if(rc) return rc;
+    const uint32_t w = items_cap_wanted(c, c->ranks[r], n[r]);
+    if(!w) cap = 0;
+    want_max = std::max(want_max, w);
   }
-  int rc = comm_exchange_local(c); if(rc) return rc;
+  if(cap) cap = want_max;
+  if(cap) {
+    bool any_overflow = false;
+    std::vector<uint64_t> routed(c->world, 0);
+    for(int r = 0; r < c->world; ++r) {
+      bool overflow = false;
+      int rc = comm_route_items(c, c->ranks[r], d_bases[r], n[r], cap, &overflow, &routed[r]); if(rc) return rc;
+      any_overflow = any_overflow || overflow;
+    }
+    if(any_overflow) cap = 0;
+    else for(int r = 0; r < c->world; ++r) c->ranks[r].sent += routed[r];
+  }
+  for(int r = 0; r < c->world; ++r) c->ranks[r].icap[c->ranks[r].turn] = cap;
+  int rc = JFGPU_OK;
+  if(cap) rc = comm_exchange_items_local(c);
+  else {
+    for(int r = 0; r < c->world; ++r) { rc = comm_route(c, c->ranks[r], d_bases[r], n[r]); if(rc) return rc; }
+    rc = comm_exchange_local(c);
+  }
+  if(rc) return rc;
   for(int r = 0; r < c->world; ++r) {
     rc = comm_insert_prev(c, c->ranks[r]); if(rc) return rc;
     c->ranks[r].inflight = true; c->ranks[r].turn ^= 1;
@@ -396,7 +741,9 @@ int jfgpu_comm_finish(jfgpu_comm* c, uint64_t* sent, uint64_t* received) {
   uint64_t s = 0, r = 0;
   for(auto& R : c->ranks) {
     if(R.t) { int rc = comm_insert_prev(c, R); if(rc) return rc; HIP_TRY(hipStreamSynchronize(R.t->stream)); }
-    s += R.sent; r += R.received;
+    unsigned long long claimed = 0;                          // item-path steps: what the senders said they sent here
+    HIP_TRY(hipMemcpy(&claimed, R.d_claimed, 8, hipMemcpyDeviceToHost));
+    s += R.sent; r += R.received + claimed;
   }
   HIP_TRY(hipStreamSynchronize(c->xstream));
   if(sent) *sent = s;

@@ -633,6 +633,12 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_granule_kernel<false, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_granule_kernel<true, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint32_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * 16 * 4));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_route_granule_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_route_granule_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_route_granule_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_route_granule_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
+    HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<true, kP2PairPer, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
+    HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<false, kP2PairPer, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<true, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<false, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint32_t, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));

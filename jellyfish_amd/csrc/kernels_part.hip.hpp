@@ -1048,10 +1048,13 @@ __global__ __launch_bounds__(kPBlock) void p1_keys_granule_kernel(DevTable T, Pa
 // single-pass P1: same LDS counting sort per chunk, same holes, and what does not fit a region goes straight to the table.
 // grid = (G2, buckets): blockIdx.y is the P1 bucket, blockIdx.x a contiguous slice of its items.  gcur / gshort / out are
 // indexed by destination = bucket * 2^b2e + sub-bucket.
-template <bool RETURNING, int PER_THREAD>
+template <bool RETURNING, int PER_THREAD, bool SMALL = false>
 __global__ __launch_bounds__(kPBlock) void p2_granule_kernel(DevTable T, PartGeom P, uint32_t b2e, uint32_t tag_bits, SegList S, uint32_t cap,
                                                              unsigned int* __restrict__ gcur, unsigned int* __restrict__ gshort,
-                                                             uint32_t* __restrict__ out, uint32_t bucket0) {
+                                                             uint32_t* __restrict__ out, uint32_t bucket0,
+                                                             unsigned long long* __restrict__ tot = nullptr, uint32_t bucket_mask = 0xFFFFFFFFu) {
+  // tot (optional): exact items stored per destination.  bucket_mask: the part of the bucket index that P, the geometry
+  // of the direct inserts, knows about (the receive side of the multi-GPU exchange splits buckets numbered globally).
   typedef uint32_t ITEM;
   constexpr int kChunk = kPBlock * PER_THREAD;
   JF_DYN_LDS(s_dyn);
@@ -1097,14 +1100,38 @@ __global__ __launch_bounds__(kPBlock) void p2_granule_kernel(DevTable T, PartGeo
     }
     lds_barrier();
     JF_PHASE(pc, 1);
+    if(SMALL) {
+      // (SMALL: nb <= 16) a fan-out of a few destinations (the receive side of the multi-GPU exchange): thousands of lanes on a handful of
+      // LDS counters would serialise, so a wave ranks its lanes per destination itself and adds once per destination
+      const uint32_t lane = threadIdx.x & 63;
+      const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
 #pragma unroll
-    for(int r = 0; r < PER_THREAD; ++r) {
-      uint32_t rank = 0;
-      if((vm >> r) & 1) {
-        if(((hm >> r) & 1) && it[r] == (ITEM)~(ITEM)0) vm &= ~(1u << r);   // a hole
-        else rank = atomicAdd(&G.hist[(uint32_t)(it[r] >> tag_bits) & (nb - 1)], 1u);
+      for(int r = 0; r < PER_THREAD; ++r) {
+        bool valid = (vm >> r) & 1;
+        if(valid && ((hm >> r) & 1) && it[r] == (ITEM)~(ITEM)0) { vm &= ~(1u << r); valid = false; }   // a hole
+        const uint32_t d = (uint32_t)(it[r] >> tag_bits) & (nb - 1);
+        uint32_t rank = 0;
+        for(uint32_t v = 0; v < nb; ++v) {                 // block-uniform trip count
+          const unsigned long long m = __ballot(valid && d == v);
+          if(!m) continue;                                 // wave-uniform
+          const int leader = __ffsll((long long)m) - 1;
+          uint32_t base = 0;
+          if((int)lane == leader) base = atomicAdd(&G.hist[v], (uint32_t)__popcll(m));
+          base = __shfl(base, leader, 64);
+          if(valid && d == v) rank = base + (uint32_t)__popcll(m & below);
+        }
+        if(r & 1) rk[r >> 1] |= rank << 16; else rk[r >> 1] = rank;
       }
-      if(r & 1) rk[r >> 1] |= rank << 16; else rk[r >> 1] = rank;
+    } else {
+#pragma unroll
+      for(int r = 0; r < PER_THREAD; ++r) {
+        uint32_t rank = 0;
+        if((vm >> r) & 1) {
+          if(((hm >> r) & 1) && it[r] == (ITEM)~(ITEM)0) vm &= ~(1u << r);   // a hole
+          else rank = atomicAdd(&G.hist[(uint32_t)(it[r] >> tag_bits) & (nb - 1)], 1u);
+        }
+        if(r & 1) rk[r >> 1] |= rank << 16; else rk[r >> 1] = rank;
+      }
     }
     my_direct += granule_emit_x<ITEM>(G, nb, cap, gc, gs, o, s_item,
                    [&]() {
@@ -1112,13 +1139,83 @@ __global__ __launch_bounds__(kPBlock) void p2_granule_kernel(DevTable T, PartGeo
                      for(int r = 0; r < PER_THREAD; ++r)
                        if((vm >> r) & 1) s_item[G.lstart[(uint32_t)(it[r] >> tag_bits) & (nb - 1)] + ((rk[r >> 1] >> ((r & 1) * 16)) & 0xFFFFu)] = it[r];
                    },
-                   [&](uint32_t, ITEM v) { item_direct_insert<RETURNING>(T, P, bucket, (uint64_t)v); },
+                   [&](uint32_t, ITEM v) { item_direct_insert<RETURNING>(T, P, bucket & bucket_mask, (uint64_t)v); },
                    [&](uint32_t, ITEM v) -> uint32_t { return (uint32_t)(v >> tag_bits) & (nb - 1); }, &pc);
   }
-  granule_finish<ITEM>(G, nb, cap, nullptr, o);
+  granule_finish<ITEM>(G, nb, cap, tot ? tot + (size_t)bucket * nb : nullptr, o);
   JF_PHASE(pc, 6);
   JF_PHASE_FLUSH(pc, 8);
   if(my_direct) atomicAdd((unsigned long long*)&T.counters[CTR_DIRECT], (unsigned long long)my_direct);
+}
+
+// ---- multi-GPU: P1 on the sending side (abi_comm.inl) ------------------------------------------------------------
+// The single-pass P1 over the GLOBAL table: T is a view of the shard's table whose geometry says "one table of 2^lsize_g
+// slots" (same matrix, same tags), so bucket = top 10 bits of the global position = (owner rank, the owner's coarse
+// bucket) and the regions of one owner are contiguous: they are what travels, 4 bytes per k-mer, already grouped for the
+// receiver.  Nothing may be inserted here (the k-mers belong to other GPUs): runs of identical k-mers are not merged,
+// and what the local P1 would insert directly -- items that do not fit their region, the item that looks like a hole --
+// is appended to a list of stragglers (bucket << 32 | item) every rank receives.
+struct StragList { unsigned long long* n; uint64_t* rec; uint32_t cap; uint32_t pad_; };
+
+template <int NB>
+__global__ __launch_bounds__(kPBlock) void p1_route_granule_kernel(DevTable T, PartGeom P, const uint8_t* __restrict__ base,
+                                                                   int64_t lo, int64_t hi, uint32_t cap,
+                                                                   unsigned int* __restrict__ gcur, unsigned long long* __restrict__ tot,
+                                                                   uint32_t* __restrict__ out, StragList SL) {
+  JF_DYN_LDS(s_dyn);
+  uint32_t* s_item = reinterpret_cast<uint32_t*>(s_dyn);                          // [kPTilePos]
+  uint16_t* s_bkt = reinterpret_cast<uint16_t*>(s_dyn + (size_t)kPTilePos * 4);   // [kPTilePos]
+  __shared__ uint64_t s_fwd[8 * 256];
+  __shared__ uint32_t s_codes[kPBlock + 2];
+  __shared__ uint32_t s_inv[kPBlock + 2];
+  __shared__ GranuleLds G;
+  const uint32_t nb = 1u << P.b1;
+  load_tables_lds(s_fwd, T.fwd_tbl, T.g.nbytes);
+  granule_init(G, nb);
+  const uint32_t bshift = T.g.lsize_l - P.b1;
+  uint32_t my_mers = 0;
+  const int64_t n_tiles = (hi + kPTilePos - 1) / kPTilePos;
+  TileRaw R = tile_fetch(base, (int64_t)blockIdx.x * kPTilePos, lo, hi);
+  for(int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    lds_barrier();
+    for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) G.hist[j] = 0;
+    const LaneWords L = tile_stage(R, tile * kPTilePos, lo, hi, s_codes, s_inv);      // barrier inside
+    R = tile_fetch(base, (tile + gridDim.x) * kPTilePos, lo, hi);
+    uint32_t it[kPerLane], dr[kPerLane];
+#pragma unroll
+    for(int e = 0; e < kPerLane; ++e) dr[e] = 0xFFFFFFFFu;
+    for_each_kmer(T.g, L, [&](int j, uint64_t key) {
+      ++my_mers;
+      const uint64_t pos = hash_tables_t<NB>(s_fwd, key, T.g.nbytes);
+      const uint64_t local = pos & T.g.local_mask;
+      const uint32_t b = (uint32_t)(local >> bshift);
+      it[j] = make_item<uint32_t>(T.g, P, key, local);
+      dr[j] = (b << 16) | atomicAdd(&G.hist[b], 1u);
+    });
+    granule_emit(G, nb, cap, gcur, out, s_item, s_bkt, it, dr,
+                 [&](uint32_t b, uint32_t v) {
+                   const unsigned long long at = atomicAdd(SL.n, 1ull);
+                   if(at < SL.cap) SL.rec[at] = ((uint64_t)b << 32) | v;
+                 });
+  }
+  granule_finish(G, nb, cap, tot, out);
+  uint64_t w = my_mers;
+  for(int o = 32; o > 0; o >>= 1) w += __shfl_down(w, o, 64);
+  if((threadIdx.x & 63) == 0 && w) atomicAdd((unsigned long long*)&T.counters[CTR_MERS], (unsigned long long)w);
+}
+
+// The stragglers a rank received: those of its own buckets go straight to the table.  cbits: bits of the coarse bucket
+// index inside an owner; P: the geometry item_direct_insert needs for (coarse bucket, item).
+template <bool RETURNING>
+__global__ __launch_bounds__(kBlock) void straggler_insert_kernel(DevTable T, PartGeom P, const uint64_t* __restrict__ rec,
+                                                                  const unsigned long long* __restrict__ n_ptr, uint32_t cap,
+                                                                  uint32_t owner, uint32_t cbits) {
+  const unsigned long long n = *n_ptr < cap ? *n_ptr : cap;
+  for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t r = rec[i];
+    const uint32_t gb = (uint32_t)(r >> 32);
+    if((gb >> cbits) == owner) item_direct_insert<RETURNING>(T, P, gb & ((1u << cbits) - 1), r & 0xFFFFFFFFull);
+  }
 }
 
 // After the granule pass: bucket bounds in the pair format of SegList (sh == 1).

@@ -354,6 +354,34 @@ template <typename T> inline T lane_exchange(T v, int src_lane_delta_kind, unsig
   return out;
 }
 
+// __ballot: the predicate bits of the wave's live lanes; __shfl: the value of an absolute lane.
+inline unsigned long long wave_ballot(int pred) {
+  BlockRun* R = tls_run();
+  const unsigned me = R->cur->linear, base = me & ~63u;
+  const unsigned nthreads = R->block_dim.x * R->block_dim.y * R->block_dim.z;
+  const unsigned char p = pred ? 1 : 0;
+  memcpy(R->xch[me], &p, 1);
+  wave_barrier();
+  R = tls_run();
+  unsigned long long m = 0;
+  for(unsigned l = 0; l < 64 && base + l < nthreads; ++l)
+    if(R->fibers[base + l].state != F_DONE && *(unsigned char*)R->xch[base + l]) m |= 1ull << l;
+  wave_barrier();
+  return m;
+}
+template <typename T> inline T lane_read(T v, int src) {
+  BlockRun* R = tls_run();
+  const unsigned me = R->cur->linear, base = me & ~63u;
+  const unsigned nthreads = R->block_dim.x * R->block_dim.y * R->block_dim.z;
+  memcpy(R->xch[me], &v, sizeof(T));
+  wave_barrier();
+  R = tls_run();
+  T out = v;
+  if(src >= 0 && src < 64 && base + (unsigned)src < nthreads && R->fibers[base + src].state != F_DONE) memcpy(&out, R->xch[base + src], sizeof(T));
+  wave_barrier();
+  return out;
+}
+
 }  // namespace hip_emu
 
 #define threadIdx (::hip_emu::tls_run()->cur->thread_idx)
@@ -369,6 +397,8 @@ static inline void __syncthreads() { ::hip_emu::block_barrier(); }
 template <typename T> static inline T __shfl_down(T v, unsigned o, int = 64) { return ::hip_emu::lane_exchange(v, 0, o); }
 template <typename T> static inline T __shfl_up(T v, unsigned o, int = 64) { return ::hip_emu::lane_exchange(v, 1, o); }
 template <typename T> static inline T __shfl_xor(T v, unsigned o, int = 64) { return ::hip_emu::lane_exchange(v, 2, o); }
+static inline unsigned long long __ballot(int pred) { return ::hip_emu::wave_ballot(pred); }
+template <typename T> static inline T __shfl(T v, int src, int = 64) { return ::hip_emu::lane_read(v, src); }
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __ffs(int v) { return __builtin_ffs(v); }

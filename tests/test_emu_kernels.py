@@ -18,6 +18,9 @@ BUILD = os.path.join(ROOT, "tests", "host", "_build")
 
 SELECTION = [
     "tests/test_gpu_parity.py::test_comm_local_transport_equals_single_table",
+    "tests/test_gpu_parity.py::test_comm_item_path_equals_single_table",
+    "tests/test_gpu_parity.py::test_p2_variants_of_32bit_slots_give_the_same_table",
+    "tests/test_cli_gpu.py::test_file_parts_cover_the_file_exactly_once",
     "tests/test_gpu_parity.py::test_content_digest_matches_dump",
     "tests/test_gpu_parity.py::test_ragged_lengths",
     "tests/test_gpu_parity.py::test_spill_mode_add_keys_and_tiny_pieces",

@@ -412,8 +412,8 @@ def test_comm_local_transport_equals_single_table(gpu, monkeypatch, world, max_m
             t.close()
 
 
-@pytest.mark.parametrize("self_rccl", ["1", "0"])
-def test_comm_rccl_transport_world_one(gpu, monkeypatch, self_rccl):
+@pytest.mark.parametrize("self_rccl,items", [("1", False), ("0", False), ("1", True), ("0", True)])
+def test_comm_rccl_transport_world_one(gpu, monkeypatch, self_rccl, items):
     """The RCCL transport of the same exchange with a world of one rank (what a single-GPU box can run).  With
     JFGPU_COMM_SELF_RCCL=1 the rank's own share goes through every RCCL call an N > 1 run makes -- counts exchange,
     max-reduce of the round count, ncclSend / ncclRecv inside one group per round of 4096 keys; by default it is a device
@@ -421,8 +421,12 @@ def test_comm_rccl_transport_world_one(gpu, monkeypatch, self_rccl):
     monkeypatch.setenv("JFGPU_COMM_MAX_MSG", "4096")
     monkeypatch.setenv("JFGPU_COMM_SELF_RCCL", self_rccl)
     rng = random.Random(77)
-    k = 21
+    k, size = 21, 1 << 20
     steps = [rnd_seq(rng, n, "ACGTN") for n in (60000, 0, 30, 90000, 20000)]
+    if items:       # the item path (4-byte items in fixed regions + stragglers) through the same RCCL calls; a homopolymer overflows a region
+        monkeypatch.setenv("JFGPU_COMM_ITEMS", "2")
+        k, size = 16, 1 << 26
+        steps = [rnd_seq(rng, n, "ACGT" * 12 + "N") for n in (60000, 0, 30, 90000)] + [b"C" * 50000 + rnd_seq(rng, 20000, "ACGT")]
     whole_seq = b"N".join(steps)
     exp = oracle_map(whole_seq, k, True)
     try:
@@ -432,8 +436,10 @@ def test_comm_rccl_transport_world_one(gpu, monkeypatch, self_rccl):
             pytest.skip("no RCCL in the emulated engine")
         raise
     try:
-        with gpu.Table(k, 1 << 20) as t, gpu.Table(k, 1 << 20) as plain:
+        with gpu.Table(k, size) as t, gpu.Table(k, size) as plain:
             plain.count_ascii(whole_seq); plain.sync()
+            if items:
+                t.set_mode(2)
             bufs = []
             for seq in steps:
                 d = t.malloc(len(seq) + 64)
@@ -903,3 +909,56 @@ def test_p2_variants_of_32bit_slots_give_the_same_table(gpu, monkeypatch, varian
         cnts = np.array(list(exp.values()), dtype=np.uint64)
         assert t.digest() == gpu.digest_of(keys, cnts)
         t.free(d)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,strag", [(2, None), (4, None), (1, None), (2, "3")])
+def test_comm_item_path_equals_single_table(gpu, monkeypatch, world, strag):
+    """The exchange's item path (abi_comm.inl: the sender runs the single-pass P1 over the GLOBAL table, an owner's regions
+    travel as 4-byte items, the receiver splits them into its own P1 buckets) on the in-process transport, forced on
+    (JFGPU_COMM_ITEMS=2) because test-sized steps would otherwise go as keys.  Inputs with a long homopolymer (one bucket
+    overflows its region: stragglers) and steps of very different sizes; with a straggler list of 3 entries the overflowing
+    step must fall back to keys on all ranks.  Shard dumps concatenated in rank order == the dump of one table."""
+    monkeypatch.setenv("JFGPU_COMM_ITEMS", "2")
+    if strag:
+        monkeypatch.setenv("JFGPU_COMM_STRAG", strag)
+    rng = random.Random(7 + world)
+    k, lsize_g = 16, 26
+    inputs = [[rnd_seq(rng, rng.choice([0, 40000, 90000]), "ACGT" * 12 + "N") for _ in range(world)] for _step in range(4)]
+    inputs[2][0] = rnd_seq(rng, 30000, "ACGT") + b"A" * 60000 + b"N" + rnd_seq(rng, 20000, "ACGT")
+    inputs[1][world - 1] = b""
+    whole_seq = b"N".join(b"N".join(step) for step in inputs)
+    exp = oracle_map(whole_seq, k, True)
+    with gpu.Table(k, 1 << lsize_g) as single:
+        single.count_ascii(whole_seq); single.sync()
+        whole = single.dump_records()
+        cols = single.matrix()
+    sb = world.bit_length() - 1
+    shards = [gpu.Table(k, 1 << lsize_g, shard_bits=sb, shard_id=r, matrix_columns=cols) for r in range(world)]
+    comm = gpu.Comm(world, local=True)
+    try:
+        bufs = []
+        for t in shards:
+            assert t.info.slot_bytes == 4
+            t.set_mode(2)
+        for step in inputs:
+            ptrs, ns = [], []
+            for r, seq in enumerate(step):
+                d = shards[r].malloc(len(seq) + 64)
+                if seq:
+                    shards[r].h2d(d, np.frombuffer(seq, dtype=np.uint8))
+                bufs.append((shards[r], d)); ptrs.append(d); ns.append(len(seq))
+            comm.local_step(shards, ptrs, ns)
+        sent, received = comm.finish()
+        assert sent == received == sum(exp.values())
+        for t in shards:
+            t.sync()
+        assert sum(t.stats().total for t in shards) == sum(exp.values())
+        parts = [t.dump_records() for t in shards]
+        assert (np.concatenate(parts) == whole).all()
+        for t, d in bufs:
+            t.free(d)
+    finally:
+        comm.close()
+        for t in shards:
+            t.close()
