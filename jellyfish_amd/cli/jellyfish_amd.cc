@@ -510,7 +510,7 @@ int count_main(int argc, char* argv[]) {
     uint64_t total = 0, largest = 0;
     for(const auto& f : files) { struct stat st; if(stat(f.c_str(), &st) == 0 && S_ISREG(st.st_mode)) { total += (uint64_t)st.st_size; largest = std::max<uint64_t>(largest, st.st_size); } }
     if(gpus_given) { total = total / gpus + ((uint64_t)1 << 20); largest = largest / gpus + ((uint64_t)1 << 20); }   // this rank's part
-    if(!host_parse && total > ((uint64_t)64 << 20) && !gpus_given) ary->expect_input(std::min<uint64_t>(total, (uint64_t)12 << 30));
+    if(!host_parse && total > ((uint64_t)64 << 20)) ary->expect_input(std::min<uint64_t>(total, (uint64_t)12 << 30));
     if(!host_parse) {
       try { dev_parser.reset(new device_sequence_parser(mer_len, device)); dev_parser->min_quality(min_qual); dev_parser->prepare(largest); }
       catch(std::exception& e) { die(e.what()); }

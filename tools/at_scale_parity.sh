@@ -36,6 +36,31 @@ if [ $PHASE = start ] || [ $PHASE = both ]; then
   t=$(date +%s%N); $CLI count -m 31 -C -s $SIZE63 --bc gpu.bc --no-write --digest $OUT/gpu_c3.digest --timing $OUT/gpu_c3.timing reads.fa; echo "gpu_c3_count_wall_ms $(ms $t)" >> $OUT/timing.txt
 fi
 
+# recheck: the engine alone against the reference digests of an earlier full run (tests/golden/at_scale/: the generator's
+# file is a function of its arguments, so are the reference's digests) -- C2, C5, C3, and C2 again through `count --gpus 1`
+# (rank process, RCCL communicator, item exchange, sharded writer's digest)
+if [ $PHASE = recheck ]; then
+  t0=$(date +%s%N)
+  [ -f reads.fa ] || $GEN -s 42 -r 150 -o reads $BASES
+  echo "generator_ms $(ms $t0)" > $OUT/timing.txt
+  export JFGPU_QUIET=1
+  G=$R/tests/golden/at_scale
+  t=$(date +%s%N); $CLI count -m 21 -C -s $SIZE21 --no-write --digest $OUT/gpu_c2.digest --timing $OUT/gpu_c2.timing reads.fa; echo "gpu_c2_wall_ms $(ms $t)" >> $OUT/timing.txt
+  t=$(date +%s%N); $CLI count -m 21 -C -s $SIZE21 --no-write --digest $OUT/gpu_c2_gpus1.digest --timing $OUT/gpu_c2_gpus1.timing --gpus 1 reads.fa 2> $OUT/gpus1.err; echo "gpu_c2_gpus1_wall_ms $(ms $t)" >> $OUT/timing.txt
+  t=$(date +%s%N); $CLI count -m 63 -C -s $SIZE63 --no-write --digest $OUT/gpu_c5.digest --timing $OUT/gpu_c5.timing reads.fa; echo "gpu_c5_wall_ms $(ms $t)" >> $OUT/timing.txt
+  t=$(date +%s%N); $CLI bc -m 31 -C -s $BASES -o gpu.bc --timing $OUT/gpu_c3_bc.timing reads.fa; echo "gpu_c3_bc_wall_ms $(ms $t)" >> $OUT/timing.txt
+  t=$(date +%s%N); $CLI count -m 31 -C -s $SIZE63 --bc gpu.bc --no-write --digest $OUT/gpu_c3.digest --timing $OUT/gpu_c3.timing reads.fa; echo "gpu_c3_count_wall_ms $(ms $t)" >> $OUT/timing.txt
+  {
+    for c in c2 c5 c3; do
+      if cmp -s $G/ref_$c.digest $OUT/gpu_$c.digest; then echo "$c digest EQUAL to the reference's (tests/golden/at_scale): $(tr '\n' ' ' < $OUT/gpu_$c.digest)"; else echo "$c digest DIFFERENT"; echo " ref: $(tr '\n' ' ' < $G/ref_$c.digest)"; echo " gpu: $(tr '\n' ' ' < $OUT/gpu_$c.digest)"; fi
+    done
+    if cmp -s $G/ref_c2.digest $OUT/gpu_c2_gpus1.digest; then echo "c2 through count --gpus 1: digest EQUAL"; else echo "c2 through count --gpus 1: digest DIFFERENT: $(tr '\n' ' ' < $OUT/gpu_c2_gpus1.digest)"; grep -v "RCCL\|rccl" $OUT/gpus1.err | tail -5; fi
+    cat $OUT/timing.txt
+    for f in gpu_c2 gpu_c2_gpus1 gpu_c5 gpu_c3_bc gpu_c3; do echo "-- $f.timing"; cat $OUT/$f.timing 2>/dev/null; done
+  } | tee $OUT/summary_recheck.txt
+  rm -rf $W
+fi
+
 if [ $PHASE = finish ] || [ $PHASE = both ]; then
   wait
   # when sourced in two phases the background jobs belong to the first shell: wait for their outputs instead
