@@ -13,6 +13,7 @@
 #include <istream>
 #include <ostream>
 #include <stdexcept>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -131,6 +132,17 @@ public:
     return len >= 64 ? res : res & (((uint64_t)1 << len) - 1);
   }
 
+  // randomize() (mer_dna.hpp:344-352): every base uniform; one generator per thread
+  void randomize() {
+    static thread_local std::mt19937_64 gen(std::random_device{}());
+    for(auto& w : w_) w = gen();
+    clean_msw();
+  }
+  void randomize(uint64_t seed) {
+    std::mt19937_64 gen(seed);
+    for(auto& w : w_) w = gen();
+    clean_msw();
+  }
   void polyA() { std::fill(w_.begin(), w_.end(), 0); }
   void polyT() { std::fill(w_.begin(), w_.end(), ~(uint64_t)0); clean_msw(); }
   bool is_homopolymer() const {
