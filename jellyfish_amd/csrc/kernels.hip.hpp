@@ -626,7 +626,7 @@ __global__ __launch_bounds__(kBlock) void dump_tiles_kernel(DevTable T, uint64_t
   uint16_t* s_idx = reinterpret_cast<uint16_t*>(s_invt + T.g.nbytes * 256);
   load_tables_lds(s_invt, T.inv_tbl, T.g.nbytes);
   const uint64_t tagmask = T.g.occ_bit - 1;
-  const uint64_t SENT = ~0ull;
+  const uint64_t SENT = ~T.g.occ_bit;      // no stored slot equals it (they all have the occupied bit), and it sorts after every tag
   const uint64_t maxval = val_bytes >= 8 ? ~0ull : ((1ull << (8 * val_bytes)) - 1);
   const uint32_t rec = key_bytes + val_bytes;
   for(uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {

@@ -441,7 +441,7 @@ __global__ __launch_bounds__(kBlock) void dump_tiles_wide_kernel(WideTable T, ui
   uint64_t* s_lo = s_hi + tsz;
   uint16_t* s_idx = reinterpret_cast<uint16_t*>(s_lo + tsz);
   const DevTable d = ovf_view(T);
-  const uint64_t tagmask = g.occ_bit - 1, SENT = ~0ull;
+  const uint64_t tagmask = g.occ_bit - 1, SENT = ~g.occ_bit;     // (a stored hi word has the occupied bit: a saturated count field over an all-ones tag is not the sentinel)
   const uint64_t maxval = val_bytes >= 8 ? ~0ull : ((1ull << (8 * val_bytes)) - 1);
   const uint32_t rec = key_bytes + val_bytes;
   for(uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {

@@ -265,3 +265,21 @@ def test_keys_of_three_and_four_words(gpu, k, canonical, n, alphabet):
             assert new.tolist() == [0] * 20 + [1] * len(absent[:5])
             vals, found = t.lookup(kk[:20])
             assert vals.tolist() == [int(c) + 2 ** 40 + 1 for c in cc[:20]]
+
+
+@pytest.mark.parametrize("k", [35, 21, 100])
+def test_dump_of_saturated_count_fields_over_all_ones_tags(gpu, k):
+    """A slot whose count field is all ones (hash_counter::add(m, UINT64_MAX), what unit_tests/test_hash_counter.cc does)
+    over a tag whose stored bits are all ones is a word of all ones -- it must still come out of the sorted dump (the dump's
+    'empty' marker once was all ones: such records were counted, then skipped, and the output kept uninitialised bytes)."""
+    rng = random.Random(k)
+    kw = (2 * k + 63) // 64
+    top = 2 * k - 64 * (kw - 1)
+    keys = np.array([[rng.getrandbits(64) for _ in range(kw - 1)] + [rng.getrandbits(top)] for _ in range(600)], dtype=np.uint64)
+    with gpu.Table(k, 1 << 16, canonical=False, out_counter_len=8) as t:
+        t.add_keys(keys[:, 0].copy() if kw == 1 else keys, val=2 ** 64 - 1)
+        t.sync()
+        recs = t.dump_records()
+        kk, cc = gpu.decode_records(recs, k, 8)
+        assert sorted(map(tuple, np.asarray(kk).reshape(len(cc), -1).tolist())) == sorted(map(tuple, keys.tolist()))
+        assert set(cc.tolist()) == {2 ** 64 - 1}
