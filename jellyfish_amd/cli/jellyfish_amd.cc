@@ -229,7 +229,7 @@ static void feed_generators(const std::string& generator, std::string shell, uns
   if(!gf.good()) die("Can't open generator file '" + generator + "'");
   if(shell.empty()) { const char* e = getenv("SHELL"); shell = e && *e ? e : "/bin/sh"; }
   sequence_parser parser(mer_len);
-  std::string cmd, data;
+  std::string cmd;
   while(std::getline(gf, cmd)) {
     const size_t first = cmd.find_first_not_of(" \t\n\v\f\r");
     if(first == std::string::npos || cmd[first] == '#') continue;
@@ -243,14 +243,12 @@ static void feed_generators(const std::string& generator, std::string shell, uns
       _exit(127);
     }
     close(fds[1]);
-    data.clear();
-    char tmp[1 << 16]; ssize_t r;
-    while((r = read(fds[0], tmp, sizeof tmp)) > 0) data.append(tmp, (size_t)r);
+    try { parser.parse_stream(fds[0], sink); }          // as it arrives, in pieces of whole records
+    catch(std::exception& e) { close(fds[0]); waitpid(pid, nullptr, 0); throw; }
     close(fds[0]);
     int status = 0;
     waitpid(pid, &status, 0);
     if(!WIFEXITED(status) || WEXITSTATUS(status) != 0) die("Generator command failed: " + cmd);
-    parser.parse_memory(data.data(), data.size(), sink);
   }
 }
 

@@ -46,6 +46,10 @@ constexpr size_t kStageBytes = 64u << 20;                  // host->device stagi
 constexpr int kNumProf = 8;   // 0 count 1 add_keys 2 shard-partition 3 lookup 4 P1 5 P2 6 tile-insert 7 items-direct
 enum Mode { MODE_AUTO = 0, MODE_DIRECT = 1, MODE_PARTITIONED = 2 };
 
+// Entries of the count-overflow side table of a small table (1 MiB): counts beyond the in-slot field are rare in k-mer
+// counting, but hash_counter::add(key, huge value) -- what the reference's unit tests do -- needs one per key.
+constexpr uint64_t kMinOvf = 1ull << 16;
+
 struct PendingBatch {
   void* items; uint64_t* off; uint64_t cap_items;
   uint32_t gran_cap = 0;                      // > 0: single-pass ("granule") batch, items per bucket region; off is in pair format
@@ -394,7 +398,7 @@ int table_grow(jfgpu_table* t) {
   else if(!geom_init(g2, t->g.k, r + 1, 0, 0, t->g.canonical, allow_slot32())) return -1;
   const uint64_t n2 = 1ull << g2.lsize_l;
   const size_t slot_bytes = g2.slot32 ? 4 : 8 * (size_t)t->slot_words;
-  uint64_t cap2 = std::max<uint64_t>(1ull << 12, std::min<uint64_t>(n2 / 256, 1ull << 26));
+  uint64_t cap2 = std::max<uint64_t>(kMinOvf, std::min<uint64_t>(n2 / 256, 1ull << 26));
   { uint64_t x = 1; while(x < cap2) x <<= 1; cap2 = x; }
   DevTable nd = t->dt;
   nd.g = g2; nd.slots = nullptr; nd.ovf_key = nd.ovf_cnt = nullptr; nd.dirty = nullptr;
@@ -556,7 +560,7 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
   HIP_TRY(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
 
   const uint64_t n_slots = 1ull << t->g.lsize_l;
-  t->ovf_cap = std::max<uint64_t>(1ull << 12, std::min<uint64_t>(n_slots / 256, 1ull << 26));
+  t->ovf_cap = std::max<uint64_t>(kMinOvf, std::min<uint64_t>(n_slots / 256, 1ull << 26));
   { uint64_t c = 1; while(c < t->ovf_cap) c <<= 1; t->ovf_cap = c; }
   t->returning = t->g.cnt_bits < 40;
 
@@ -1135,7 +1139,7 @@ int jfgpu_table_bytes(uint32_t k, uint64_t size, uint64_t* slots, uint64_t* byte
   else if(wide) { lsize = std::max(lsize, wide_min_lsize(k)); lsize = std::min<uint32_t>(lsize, 48); }
   else { lsize = std::max(lsize, geom_min_lsize(k, 0)); lsize = std::max<uint32_t>(lsize, 1); lsize = std::min<uint32_t>(lsize, 2 * k); }
   const uint64_t n = 1ull << lsize;
-  uint64_t ovf = std::max<uint64_t>(1ull << 12, std::min<uint64_t>(n / 256, 1ull << 26));
+  uint64_t ovf = std::max<uint64_t>(kMinOvf, std::min<uint64_t>(n / 256, 1ull << 26));
   { uint64_t c = 1; while(c < ovf) c <<= 1; ovf = c; }
   if(slots) *slots = n;
   TableGeom gg;

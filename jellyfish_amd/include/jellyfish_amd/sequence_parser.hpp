@@ -20,6 +20,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <stdexcept>
@@ -55,13 +56,45 @@ public:
         return;
       }
     }
-    // pipes / stdin / zero-size special files: slurp
-    std::string all;
-    char tmp[1 << 16];
-    ssize_t n;
-    while((n = read(fd, tmp, sizeof tmp)) > 0) all.append(tmp, n);
+    // pipes / stdin / special files: in pieces of whole records
+    try { parse_stream(fd, sink); } catch(...) { close(fd); throw; }
     close(fd);
-    parse_memory(all.data(), all.size(), sink);
+  }
+
+  // A stream that cannot be mapped (a pipe, e.g. `zcat reads.fa.gz |`, generator commands): read about `piece` bytes at a
+  // time, hand the records that are complete to parse_memory, carry the rest.  Memory is bounded by the piece or by the
+  // longest record, not by the stream.  (Pieces end where a record starts: a line beginning with '>'; for FASTQ a line
+  // beginning with '@' whose second-next line begins with '+'.)
+  void parse_stream(int fd, const sink_type& sink, size_t piece = (size_t)64 << 20) {
+    if(const char* e = getenv("JFGPU_STREAM_PIECE")) piece = std::max<size_t>(1, strtoull(e, nullptr, 10));   // (tests: many small pieces)
+    std::string data;
+    data.reserve(piece + (piece >> 2));
+    const size_t files_before = files_read_;
+    bool eof = false, any = false;
+    while(!eof) {
+      const size_t goal = data.size() + piece;
+      while(data.size() < goal) {
+        const size_t old = data.size();
+        const size_t want = std::min<size_t>((size_t)1 << 20, goal - old);
+        data.resize(old + want);
+        const ssize_t r = read(fd, &data[old], want);
+        if(r < 0) { data.resize(old); throw std::runtime_error("Error reading the sequence stream"); }
+        data.resize(old + (size_t)r);
+        if(r == 0) { eof = true; break; }
+      }
+      if(data.empty()) break;
+      if(data[0] != '>' && data[0] != '@') throw std::runtime_error("Unsupported format");
+      size_t cut = data.size();
+      if(!eof) {
+        cut = data[0] == '>' ? last_fasta_record(data) : last_fastq_record(data);
+        if(cut == 0) continue;                      // one record longer than everything read so far: read on
+      }
+      parse_memory(data.data(), cut, sink);
+      any = true;
+      data.erase(0, cut);
+    }
+    (void)any;
+    files_read_ = files_before + 1;                 // one stream = one file, however many pieces
   }
 
   void parse_memory(const char* data, size_t n, const sink_type& sink) {
@@ -83,6 +116,33 @@ private:
   size_t files_read_ = 0, reads_read_ = 0;
   int min_qual_ = 0;
 
+  // start of the last record that begins inside d (0: none but the first)
+  static size_t last_fasta_record(const std::string& d) {
+    size_t end = d.size();
+    while(end > 0) {
+      const void* q = memrchr(d.data(), '\n', end);           // the last newline before `end`
+      if(!q) return 0;
+      const size_t nl = (size_t)((const char*)q - d.data());
+      if(nl + 1 < d.size() && d[nl + 1] == '>') return nl + 1;
+      end = nl;
+    }
+    return 0;
+  }
+  static size_t last_fastq_record(const std::string& d) {
+    size_t end = d.size();
+    while(end > 0) {
+      const void* q = memrchr(d.data(), '\n', end);
+      if(!q) return 0;
+      const size_t nl = (size_t)((const char*)q - d.data()), s = nl + 1;
+      if(s < d.size() && d[s] == '@') {                        // a header, unless it is a quality line: then the
+        const char* e1 = (const char*)memchr(d.data() + s, '\n', d.size() - s);                       // second-next line
+        const char* e2 = e1 ? (const char*)memchr(e1 + 1, '\n', d.data() + d.size() - (e1 + 1)) : nullptr;   // is a sequence,
+        if(e2 && e2 + 1 < d.data() + d.size() && e2[1] == '+') return s;                               // not the '+' line
+      }
+      end = nl;
+    }
+    return 0;
+  }
   static const char* line_end(const char* p, const char* end) {
     const char* nl = (const char*)memchr(p, '\n', end - p);
     return nl ? nl : end;
