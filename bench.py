@@ -317,6 +317,8 @@ def main():
     out = None
     if rank == 0:
         slot_names = ["count_direct", "add_keys", "shard_partition", "lookup", "p1_partition", "p2_partition", "tile_insert", "items_direct"]
+        if sharded:     # the exchange's item path: slot 2 = P1 over the global table (sender), slot 1 = split of what arrived (receiver)
+            slot_names[1], slot_names[2] = "exchange_receive_split", "exchange_route_p1"
         B = b_alg(cfg, K)
         kernels = {}
         for i, nm in enumerate(slot_names):
