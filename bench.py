@@ -62,9 +62,19 @@ def write_fasta(arr, path):
     np.concatenate([hdr, body], axis=1).tofile(path)
 
 
+def _all_cpus():
+    """preexec_fn for the child processes: numpy / torch may have narrowed this process's CPU affinity (their threading
+    runtimes pin the main thread on some builds) and children inherit it -- the CLI's 32 read streams or the reference's 64
+    worker threads would then share a few cores."""
+    try:
+        os.sched_setaffinity(0, range(os.cpu_count() or 1))
+    except OSError:
+        pass
+
+
 def ref_count(ref, fa_list, k, size, threads, tmpdir, extra=()):
     out, timing = os.path.join(tmpdir, "ref.jf"), os.path.join(tmpdir, "timing")
-    subprocess.check_call([ref, "count", "-m", str(k), "-C", "-s", str(size), "-t", str(threads), "-o", out, "--timing", timing] + list(extra) + fa_list)
+    subprocess.check_call([ref, "count", "-m", str(k), "-C", "-s", str(size), "-t", str(threads), "-o", out, "--timing", timing] + list(extra) + fa_list, preexec_fn=_all_cpus)
     t = dict(l.split() for l in open(timing).read().splitlines())
     return float(t["Counting"]), int(t["Mers"]), out
 
@@ -96,7 +106,7 @@ def cpu_baseline(cfg, sample, k, tmpdir):
     if cfg == "C3":
         bc = os.path.join(tmpdir, "ref.bc")
         t0 = time.time()
-        subprocess.check_call([ref, "bc", "-m", str(k), "-C", "-s", str(n_reads * READ_LEN), "-t", str(best_t), "-o", bc, fa])
+        subprocess.check_call([ref, "bc", "-m", str(k), "-C", "-s", str(n_reads * READ_LEN), "-t", str(best_t), "-o", bc, fa], preexec_fn=_all_cpus)
         t_bc = time.time() - t0
         t_cnt, mers, out = ref_count(ref, [fa], k, size, best_t, tmpdir, ["--bc", bc])
         assert mers == kmers
@@ -432,13 +442,13 @@ def main():
                 env = dict(os.environ, JFGPU_QUIET="1")
                 t1 = time.perf_counter()
                 subprocess.check_call([cli, "count", "-m", str(K), "-C", "-s", str(1 << lsize), "--no-write", "--timing", tim, "--digest", dg,
-                                       "--device", str(local_rank), fa], env=env)
+                                       "--device", str(local_rank), fa], env=env, preexec_fn=_all_cpus)
                 wall = time.perf_counter() - t1
                 tm = dict(l.split() for l in open(tim).read().splitlines())
                 dgl = tuple(int(l.split()[1]) for l in open(dg).read().splitlines())
                 assert dgl == digest, "CLI run and HBM-resident run disagree: %r vs %r" % (dgl, digest)
                 cs = float(tm["Counting"])
-                out["end_to_end"] = {"counting_s": cs, "init_s": float(tm["Init"]), "process_wall_s": wall, "file_bytes": fbytes,
+                out["end_to_end"] = {"parent_affinity_cpus": len(os.sched_getaffinity(0)), "counting_s": cs, "init_s": float(tm["Init"]), "process_wall_s": wall, "file_bytes": fbytes,
                                      "file_GB_per_s": fbytes / cs / 1e9, "kmers_per_s": total_kmers / cs, "digest_equal_to_resident_run": True,
                                      "what": "Counting phase (count_main.cc:286->345 equivalent) of `jellyfish-amd count --no-write` on a %.1f GB FASTA file of "
                                              "the same reads in /dev/shm: host read, host->device copy, device parse, count; PCIe-inclusive, never `value`" % (fbytes / 1e9)}

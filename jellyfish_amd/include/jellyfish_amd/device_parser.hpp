@@ -327,7 +327,21 @@ private:
     return npos;
   }
 
-  unsigned copy_threads_ = std::max(1u, std::min(32u, std::thread::hardware_concurrency() / 4));
+  unsigned copy_threads_ = feed_threads();
+  // pread streams per fill: a quarter of the hardware threads, at most 32 -- and no more than the CPU time the cgroup
+  // grants (cpu.max): the copy out of the page cache costs 0.3-0.7 CPU-seconds per GB (tools/probes/feed_probe.hip), so on
+  // a box limited to 16 CPUs the feed tops out near 20 GB/s whatever the thread count, and more threads only get throttled.
+  // JFGPU_FEED_THREADS overrides.
+  static unsigned feed_threads() {
+    if(const char* e = getenv("JFGPU_FEED_THREADS")) return (unsigned)std::max(1, atoi(e));
+    unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency() / 4));
+    if(FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      long long quota = 0, period = 0;
+      if(fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) nt = std::min<unsigned>(nt, (unsigned)std::max<long long>(1, quota / period));
+      fclose(f);
+    }
+    return nt;
+  }
   sequence_parser host_;
   size_t files_read_ = 0, reads_read_ = 0, fallback_bytes_ = 0;
   double device_ms_ = 0;
