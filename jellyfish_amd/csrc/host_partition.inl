@@ -127,7 +127,8 @@ int part_ingest(jfgpu_table* t, const uint8_t* base, int64_t lo, int64_t hi, boo
   const size_t bytes = gcap ? (size_t)nb * gcap * item_size(t) : max_items * item_size(t);
   const size_t need = align_up(bytes, 256) + align_up((2 * nb + 1) * sizeof(uint64_t), 256) + (gcap ? align_up(nb * 16, 256) : 0) + 1024;
   // 16-byte items: the arena may be smaller than what the whole input needs, so keep half of it for the flush's P2 output
-  const size_t ws_limit = t->item128 && t->pg.b2 ? t->ws_cap / 2 : t->ws_cap;
+  // (the flush's P2 output: an eighth of the arena is enough, P2 and the tile insert then go group by group: part_flush_t)
+  const size_t ws_limit = t->item128 && t->pg.b2 ? t->ws_cap - t->ws_cap / 8 : t->ws_cap;
   if(t->item128 && !t->pending.empty() && t->ws_used + need > ws_limit) { int rc = part_flush(t); if(rc) return rc; }
   // ... and every flush streams the whole table, so when the announced input (jfgpu_reserve) needs n of them, make them
   // n equal ones: 6 + 3 + 1 batches cost a third more table traffic than 5 + 5
@@ -372,36 +373,56 @@ int part_flush_t(jfgpu_table* t) {
     if(getenv("JFGPU_FLUSH_TRACE"))
       fprintf(stderr, "[flush] %llu items in %zu batches, %llu tiles, pairs %d, single-pass P2 regions of %u items (0: exact P2)\n",
               (unsigned long long)total, nbatch, (unsigned long long)n_tiles, (int)pair, cap2);
+    // When the arena cannot hold a P2 output of the whole flush beside what is pending, the P1 buckets go through P2 and
+    // the tile insert in groups that share one small output buffer (group g's tiles are inserted before group g+1 is
+    // partitioned): 16-byte items at 10 Gbp then need 104 GB (P1 regions) + 12 GB instead of 104 + 94, the whole job fits
+    // one flush, and the table is streamed once instead of twice.
+    uint32_t share_groups = 0;
+    uint64_t tmp_items = std::max<uint64_t>(total, 1);
     if(!cap2) {
+      const size_t fixed = align_up((n_tiles + 1) * sizeof(uint64_t), 256) + align_up(nb1 * sizeof(uint64_t), 256) + 1024;
+      const size_t used = align_up(t->ws_used, 256);
+      const size_t free_b = t->ws_cap > used + fixed ? t->ws_cap - used - fixed : 0;
+      const uint32_t forced = getenv("JFGPU_FLUSH_SHARE") ? (uint32_t)atoi(getenv("JFGPU_FLUSH_SHARE")) : 0;      // (tests)
+      if((total * sizeof(ITEM) > free_b || forced) && t->flush_groups <= 1) {
+        for(uint32_t G = 2; G <= nb1 / 8; G *= 2) {
+          uint64_t mx = 0;
+          for(uint32_t g = 0; g < G; ++g) { uint64_t sum = 0; for(uint32_t j = g * (nb1 / G); j < (g + 1) * (nb1 / G); ++j) sum += bucket_tot[j]; mx = std::max(mx, sum); }
+          if(forced ? G == forced : mx * sizeof(ITEM) <= free_b) { share_groups = G; tmp_items = std::max<uint64_t>(mx, 1); break; }
+        }
+      }
       d_goff = (uint64_t*)ws_alloc(t, (n_tiles + 1) * sizeof(uint64_t));
       d_base = (uint64_t*)ws_alloc(t, nb1 * sizeof(uint64_t));
-      tmp = (ITEM*)ws_alloc(t, std::max<uint64_t>(total, 1) * sizeof(ITEM));
+      tmp = (ITEM*)ws_alloc(t, tmp_items * sizeof(ITEM));
       if(!d_goff || !d_base || !tmp) {     // arena too small for the flush temporaries: one-off allocation
+        if(!forced) { share_groups = 0; tmp_items = std::max<uint64_t>(total, 1); }
         tmp_owned = true;
         tmp = nullptr; d_goff = nullptr; d_base = nullptr;
-        HIP_TRY(hipMalloc((void**)&tmp, std::max<uint64_t>(total, 1) * sizeof(ITEM)));
+        HIP_TRY(hipMalloc((void**)&tmp, tmp_items * sizeof(ITEM)));
         if(hipMalloc((void**)&d_goff, (n_tiles + 1) * sizeof(uint64_t)) != hipSuccess ||
            hipMalloc((void**)&d_base, nb1 * sizeof(uint64_t)) != hipSuccess) {
           hipFree(tmp); if(d_goff) hipFree(d_goff);
           return fail(JFGPU_E_ALLOC, "hipMalloc partition offsets");
         }
       }
-      std::vector<uint64_t> base(nb1);
-      { uint64_t run = 0; for(uint32_t j = 0; j < nb1; ++j) { base[j] = run; run += bucket_tot[j]; } }
+      std::vector<uint64_t> base(nb1);                     // where a bucket's tiles start in tmp (groups sharing tmp: from 0 again)
+      { uint64_t run = 0; for(uint32_t j = 0; j < nb1; ++j) { if(share_groups && j % (nb1 / share_groups) == 0) run = 0; base[j] = run; run += bucket_tot[j]; } }
       HIP_TRY(hipMemcpyAsync(d_base, base.data(), nb1 * sizeof(uint64_t), hipMemcpyHostToDevice, t->stream));
     }
+    if(getenv("JFGPU_FLUSH_TRACE") && share_groups) fprintf(stderr, "[flush] P2 + tile insert in %u groups sharing an output buffer of %llu items\n", share_groups, (unsigned long long)tmp_items);
     // Optionally (JFGPU_FLUSH_GROUPS > 1) the P1 buckets go through P2 and the tile insert in groups, P2 on the
     // table's stream and the tile insert on a second one, so that group g's tiles are inserted while group g+1
     // is partitioned (one P2-scatter block, 88 KB LDS, and one tile block, 64 KB, fit a CU together).
-    const uint32_t n_groups = t->flush_groups > 1 && nb1 >= (uint32_t)t->flush_groups * 8 ? (uint32_t)t->flush_groups : 1;
+    const uint32_t n_groups = share_groups ? share_groups : t->flush_groups > 1 && nb1 >= (uint32_t)t->flush_groups * 8 ? (uint32_t)t->flush_groups : 1;
+    const bool two_streams = n_groups > 1 && !share_groups;
     const uint32_t gsz = nb1 / n_groups;
-    if(n_groups > 1 && !t->stream2) {
+    if(two_streams && !t->stream2) {
       HIP_TRY(hipStreamCreateWithFlags(&t->stream2, hipStreamNonBlocking));
       for(auto& ev : t->flush_ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&t->flush_done, hipEventDisableTiming));
     }
     hipEvent_t p2a = nullptr, p2b = nullptr, ta = nullptr, tb = nullptr;
-    if(t->prof_on) { p2a = get_event(t); p2b = get_event(t); ta = get_event(t); tb = get_event(t); hipEventRecord(p2a, t->stream); }
+    if(t->prof_on && !share_groups) { p2a = get_event(t); p2b = get_event(t); ta = get_event(t); tb = get_event(t); hipEventRecord(p2a, t->stream); }
     constexpr int per_thread = sizeof(ITEM) == 4 ? 16 : sizeof(ITEM) == 8 ? 14 : 7;     // 8- and 16-byte items: chunks of 112 KiB (longer runs per destination)
     PartGeom pg2 = t->pg;
     if(pair) pg2.b2 -= 1;
@@ -410,6 +431,8 @@ int part_flush_t(jfgpu_table* t) {
     for(uint32_t g = 0; g < n_groups; ++g) {
       const uint32_t b0 = g * gsz, nbk = g + 1 == n_groups ? nb1 - b0 : gsz;
       const dim3 grid(g2, nbk), block(kPBlock);
+      hipEvent_t ga = nullptr;                              // groups sharing tmp: every group's two stages are timed on their own
+      if(t->prof_on && share_groups) { ga = get_event(t); hipEventRecord(ga, t->stream); }
       if constexpr(sizeof(ITEM) == 4) {
         if(cap2) {
           const dim3 g1p(kG2Single, nbk);
@@ -424,7 +447,7 @@ int part_flush_t(jfgpu_table* t) {
           SegList S2; memset(&S2, 0, sizeof S2);
           S2.n = 1; S2.items[0] = out2; S2.off[0] = d_off2 + 2 * d0; S2.sh[0] = 1;
           hipStream_t ts = t->stream;
-          if(n_groups > 1) {
+          if(two_streams) {
             HIP_TRY(hipEventRecord(t->flush_ev[g & 1], t->stream));
             HIP_TRY(hipStreamWaitEvent(t->stream2, t->flush_ev[g & 1], 0));
             ts = t->stream2;
@@ -449,26 +472,38 @@ int part_flush_t(jfgpu_table* t) {
       if(!launched)
         hipLaunchKernelGGL((p2_scatter_sorted_kernel<ITEM, per_thread>), grid, block, (size_t)kPBlock * per_thread * sizeof(ITEM), t->stream,
                            pg2, p2_tag_bits, S1, (const uint32_t*)t->d_M2, (const uint64_t*)d_goff, tmp, b0);
-      if(t->prof_on && g + 1 == n_groups) hipEventRecord(p2b, t->stream);
+      if(t->prof_on && g + 1 == n_groups && !share_groups) hipEventRecord(p2b, t->stream);
       const uint64_t tile_start = (uint64_t)b0 << t->pg.b2;
       const uint32_t ntile = nbk << pg2.b2;                 // units of the tile kernel: tiles, or pairs of tiles
       SegList S2; memset(&S2, 0, sizeof S2);
       S2.n = 1; S2.items[0] = tmp; S2.off[0] = d_goff + ((uint64_t)b0 << pg2.b2);
       hipStream_t ts = t->stream;
-      if(n_groups > 1) {
+      if(two_streams) {
         HIP_TRY(hipEventRecord(t->flush_ev[g & 1], t->stream));
         HIP_TRY(hipStreamWaitEvent(t->stream2, t->flush_ev[g & 1], 0));
         ts = t->stream2;
+      }
+      if(share_groups) {      // one stream, P2 and T alternate: time every group's two stages separately
+        uint64_t gtot = 0; for(uint32_t j = b0; j < b0 + nbk; ++j) gtot += bucket_tot[j];
+        if(t->prof_on) {
+          hipEvent_t gb = get_event(t), gc = get_event(t), gd = get_event(t);
+          hipEventRecord(gb, ts); hipEventRecord(gc, ts);
+          t->prof_pending.push_back({ga, gb, 5, gtot});
+          launch_tile_kernel(S2, tile_start, ntile, ts, pair);
+          hipEventRecord(gd, ts);
+          t->prof_pending.push_back({gc, gd, 6, gtot});
+        } else launch_tile_kernel(S2, tile_start, ntile, ts, pair);
+        continue;
       }
       if(t->prof_on && g == 0) hipEventRecord(ta, ts);
       launch_tile_kernel(S2, tile_start, ntile, ts, pair);
       if(t->prof_on && g + 1 == n_groups) hipEventRecord(tb, ts);
     }
-    if(t->prof_on) {
+    if(t->prof_on && !share_groups) {
       t->prof_pending.push_back({p2a, p2b, 5, total});
       t->prof_pending.push_back({ta, tb, 6, total});
     }
-    if(n_groups > 1) {        // the table's stream continues only after the last tiles are in
+    if(two_streams) {        // the table's stream continues only after the last tiles are in
       HIP_TRY(hipEventRecord(t->flush_done, t->stream2));
       HIP_TRY(hipStreamWaitEvent(t->stream, t->flush_done, 0));
     }

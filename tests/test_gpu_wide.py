@@ -283,3 +283,26 @@ def test_dump_of_saturated_count_fields_over_all_ones_tags(gpu, k):
         kk, cc = gpu.decode_records(recs, k, 8)
         assert sorted(map(tuple, np.asarray(kk).reshape(len(cc), -1).tolist())) == sorted(map(tuple, keys.tolist()))
         assert set(cc.tolist()) == {2 ** 64 - 1}
+
+
+def test_flush_in_groups_sharing_one_p2_buffer(gpu, monkeypatch):
+    """When the arena cannot hold a whole flush's P2 output the P1 buckets go through P2 and the tile insert in groups that
+    reuse one small buffer (what lets 10 Gbp of 63-mers flush once).  Forced here with 4 groups: two-word and one-word
+    keys, two flushes (the second one loads dirty tiles), per-stage timers on; the table equals the direct path's."""
+    rng = random.Random(12)
+    for k, size in ((40, 1 << 26), (21, 1 << 27)):
+        seq = rnd_seq(rng, 200000, "ACGT") + b"N" + rnd_seq(rng, 50000, "AC")
+        digests = {}
+        for share in ("4", "0"):
+            monkeypatch.setenv("JFGPU_FLUSH_SHARE", share)
+            with gpu.Table(k, size, canonical=True) as t:
+                t.set_mode(2 if share != "0" else 1)
+                t.profile_enable(True)
+                half = len(seq) // 2
+                t.count_ascii(seq[:half]); t.sync()
+                t.count_ascii(seq[half - (k - 1):]); t.sync()
+                if share != "0":
+                    assert t.profile_get(5)[1] >= 4 and t.profile_get(6)[1] >= 4        # P2 and T ran per group
+                st = t.stats()
+                digests[share] = (t.digest(), st.total, st.distinct)
+        assert digests["4"] == digests["0"]
