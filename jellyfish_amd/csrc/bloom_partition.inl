@@ -103,8 +103,10 @@ int bloom_ingest(jfgpu_bloom* b, const uint8_t* base, int64_t lo, int64_t hi) {
   const size_t lds = (size_t)kBloomChunk * 6 + (size_t)2 * b->g.nbytes * 2048;
   int64_t at = lo;
   while(hi - at >= (int64_t)k) {
-    // largest piece whose regions fit what is left of the first half of the arena
-    const size_t half = b->ws_cap / 2;
+    // largest piece whose regions fit what is left of the arena's pending part: 7/8 of it -- the flush's P2 output takes
+    // the rest, P1b bucket group by bucket group (bloom_flush_inner), so a flush holds twice the sequence it used to
+    // and the 28 GB array is streamed half as often
+    const size_t half = b->ws_cap - b->ws_cap / 8;
     const size_t room = half > align_up(b->ws_used, 256) ? half - align_up(b->ws_used, 256) : 0;
     uint64_t piece = (uint64_t)(hi - at);
     uint32_t cap = bloom_region_cap(b, piece);
@@ -168,10 +170,10 @@ int bloom_flush_inner(jfgpu_bloom* b) {
   for(size_t s = 0; s < nbatch; ++s) { S1.items[s] = b->pending[s].items; S1.off[s] = b->pending[s].off; S1.sh[s] = 1; }
   const DevBloom B = b->view();
   const size_t seg_lds = (size_t)1 << kBloomSegBits;
-  auto launch_segments = [&](const SegList& S, uint32_t nseg, uint64_t units) {
+  auto launch_segments = [&](const SegList& S, uint32_t nseg, uint64_t units, uint32_t seg0 = 0) {
     BloomProf ps(b, BS_SEG, units);
     const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nseg, (uint64_t)b->n_cu * 2)));
-    hipLaunchKernelGGL(bloom_segment_kernel, grid, dim3(kPBlock), seg_lds, b->stream, B, S, nseg);
+    hipLaunchKernelGGL(bloom_segment_kernel, grid, dim3(kPBlock), seg_lds, b->stream, B, S, nseg, seg0);
   };
   if(total == 0) {
     // nothing
@@ -191,25 +193,46 @@ int bloom_flush_inner(jfgpu_bloom* b) {
     const uint64_t n_tiles = (uint64_t)nb1 * nb2;
     uint64_t* d_goff = (uint64_t*)bloom_ws_alloc(b, (n_tiles + 1) * sizeof(uint64_t));
     uint64_t* d_base = (uint64_t*)bloom_ws_alloc(b, nb1 * sizeof(uint64_t));
-    uint32_t* tmp = (uint32_t*)bloom_ws_alloc(b, std::max<uint64_t>(total, 1) * sizeof(uint32_t));
+    // the P2 output of the whole flush, or -- when that does not fit beside what is pending -- of one group of P1b buckets
+    // at a time: the groups share the buffer, each group's segments are applied before the next group is partitioned
+    const size_t free_b = b->ws_cap > align_up(b->ws_used, 256) + 4096 ? b->ws_cap - align_up(b->ws_used, 256) - 4096 : 0;
+    uint32_t n_groups = 1;
+    uint64_t tmp_items = std::max<uint64_t>(total, 1);
+    const uint32_t forced = getenv("JFGPU_FLUSH_SHARE") ? (uint32_t)atoi(getenv("JFGPU_FLUSH_SHARE")) : 0;      // (tests)
+    if(total * sizeof(uint32_t) > free_b || forced)
+      for(uint32_t G = 2; G <= nb1 / 4; G *= 2) {
+        uint64_t mx = 0;
+        for(uint32_t g = 0; g < G; ++g) { uint64_t sum = 0; for(uint32_t j = g * (nb1 / G); j < (g + 1) * (nb1 / G); ++j) sum += bucket_tot[j]; mx = std::max(mx, sum); }
+        if(forced ? G == forced : mx * sizeof(uint32_t) <= free_b) { n_groups = G; tmp_items = std::max<uint64_t>(mx, 1); break; }
+      }
+    uint32_t* tmp = (uint32_t*)bloom_ws_alloc(b, tmp_items * sizeof(uint32_t));
     if(!d_goff || !d_base || !tmp) return fail(JFGPU_E_ALLOC, "Bloom partition workspace too small for the flush");
+    const uint32_t gsz = nb1 / n_groups;
     std::vector<uint64_t> basev(nb1);
-    { uint64_t run = 0; for(uint32_t j = 0; j < nb1; ++j) { basev[j] = run; run += bucket_tot[j]; } }
+    { uint64_t run = 0; for(uint32_t j = 0; j < nb1; ++j) { if(j % gsz == 0) run = 0; basev[j] = run; run += bucket_tot[j]; } }
     HIP_TRY(hipMemcpyAsync(d_base, basev.data(), nb1 * sizeof(uint64_t), hipMemcpyHostToDevice, b->stream));
     PartGeom P; memset(&P, 0, sizeof P);
     P.b1 = b->bp.b1; P.b2 = b->bp.b2;
-    {
-      BloomProf ps(b, BS_P2, total);
-      const dim3 grid(g2, nb1), block(kPBlock);
-      hipLaunchKernelGGL((p2_kernel<uint32_t, false>), grid, block, 0, b->stream, P, kBloomItemLow, S1, b->d_M2, (const uint64_t*)d_goff, tmp, 0u);
-      hipLaunchKernelGGL(scan_matrix_kernel, dim3(nb1), dim3(1024), 0, b->stream, b->d_M2, (uint32_t)g2, nb2, (const uint64_t*)d_base, d_goff, 0u);
-      // chunks of 28 Ki cell updates: the runs written per destination are what this pass costs (scatter_write_probe)
-      hipLaunchKernelGGL((p2_scatter_sorted_kernel<uint32_t, kP2PairPer>), grid, block, (size_t)kPBlock * kP2PairPer * sizeof(uint32_t), b->stream,
-                         P, kBloomItemLow, S1, (const uint32_t*)b->d_M2, (const uint64_t*)d_goff, tmp, 0u);
+    for(uint32_t g = 0; g < n_groups; ++g) {
+      const uint32_t b0 = g * gsz;
+      uint64_t gtot = 0; for(uint32_t j = b0; j < b0 + gsz; ++j) gtot += bucket_tot[j];
+      {
+        BloomProf ps(b, BS_P2, gtot);
+        const dim3 grid(g2, gsz), block(kPBlock);
+        hipLaunchKernelGGL((p2_kernel<uint32_t, false>), grid, block, 0, b->stream, P, kBloomItemLow, S1, b->d_M2, (const uint64_t*)d_goff, tmp, b0);
+        hipLaunchKernelGGL(scan_matrix_kernel, dim3(gsz), dim3(1024), 0, b->stream, b->d_M2, (uint32_t)g2, nb2, (const uint64_t*)d_base, d_goff, b0);
+        // chunks of 28 Ki cell updates: the runs written per destination are what this pass costs (scatter_write_probe)
+        hipLaunchKernelGGL((p2_scatter_sorted_kernel<uint32_t, kP2PairPer>), grid, block, (size_t)kPBlock * kP2PairPer * sizeof(uint32_t), b->stream,
+                           P, kBloomItemLow, S1, (const uint32_t*)b->d_M2, (const uint64_t*)d_goff, tmp, b0);
+      }
+      // this group's segments: numbers b0 * nb2 .. ; the last group stops at the array's last segment
+      const uint64_t seg0 = (uint64_t)b0 * nb2;
+      if(seg0 >= b->bp.n_seg) break;
+      const uint32_t nseg = (uint32_t)std::min<uint64_t>((uint64_t)gsz * nb2, b->bp.n_seg - seg0);
+      SegList S2; memset(&S2, 0, sizeof S2);
+      S2.n = 1; S2.items[0] = tmp; S2.off[0] = d_goff + seg0;
+      launch_segments(S2, nseg, gtot, (uint32_t)seg0);
     }
-    SegList S2; memset(&S2, 0, sizeof S2);
-    S2.n = 1; S2.items[0] = tmp; S2.off[0] = d_goff;
-    launch_segments(S2, b->bp.n_seg, total);
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(b->stream));

@@ -132,7 +132,7 @@ __device__ inline void bloom_lds_bump(uint32_t* s_seg, uint32_t item) {
 }
 
 // Segment index = seg0 + t; its items are, for each pending array s, items[s][off(s, t) .. ) as in tile_insert_kernel.
-__global__ __launch_bounds__(kPBlock) void bloom_segment_kernel(DevBloom B, SegList S, uint32_t n_seg) {
+__global__ __launch_bounds__(kPBlock) void bloom_segment_kernel(DevBloom B, SegList S, uint32_t n_seg, uint32_t seg0 = 0) {
   JF_DYN_LDS(s_raw);
   uint32_t* s_seg = reinterpret_cast<uint32_t*>(s_raw);
   constexpr uint32_t kWords = (1u << kBloomSegBits) / 4;
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(kPBlock) void bloom_segment_kernel(DevBloom B, SegL
     uint64_t n_items = 0;
     for(uint32_t s = 0; s < S.n; ++s) n_items += seg_hi(S, s, t) - seg_lo(S, s, t);
     if(n_items == 0) continue;                                      // block-uniform
-    uint32_t* gseg = B.data + (size_t)t * kWords;
+    uint32_t* gseg = B.data + ((size_t)seg0 + t) * kWords;             // (offsets are indexed from seg0: a group of buckets)
     for(uint32_t i = threadIdx.x * 4; i < kWords; i += blockDim.x * 4)
       *reinterpret_cast<uint4*>(s_seg + i) = *reinterpret_cast<const uint4*>(gseg + i);
     lds_barrier();
