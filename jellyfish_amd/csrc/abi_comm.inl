@@ -235,8 +235,8 @@ int comm_insert_prev_items(jfgpu_comm* c, jfgpu_comm::Rank& R, int rank) {
     unsigned int* gc_v = gcur - dshift; unsigned int* gs_v = gcur + nb - dshift;
     uint32_t* out_v = reinterpret_cast<uint32_t*>(b.items) - dshift * (int64_t)cap2;
     unsigned long long* tot_v = b.tot - dshift;
-    if(t->returning) hipLaunchKernelGGL((p2_granule_kernel<true, kP2PairPer, true>), grid, block, lds, t->stream, t->dt, pd, sb, split_at, S, cap2, gc_v, gs_v, out_v, (uint32_t)first, tot_v, L.nbc - 1);
-    else             hipLaunchKernelGGL((p2_granule_kernel<false, kP2PairPer, true>), grid, block, lds, t->stream, t->dt, pd, sb, split_at, S, cap2, gc_v, gs_v, out_v, (uint32_t)first, tot_v, L.nbc - 1);
+    if(t->returning) hipLaunchKernelGGL((p2_granule_kernel<uint32_t, TableDirect<true>, kP2PairPer, true>), grid, block, lds, t->stream, TableDirect<true>{t->dt, pd}, sb, split_at, S, cap2, gc_v, gs_v, out_v, (uint32_t)first, tot_v, L.nbc - 1);
+    else             hipLaunchKernelGGL((p2_granule_kernel<uint32_t, TableDirect<false>, kP2PairPer, true>), grid, block, lds, t->stream, TableDirect<false>{t->dt, pd}, sb, split_at, S, cap2, gc_v, gs_v, out_v, (uint32_t)first, tot_v, L.nbc - 1);
     hipLaunchKernelGGL(granule_finish_kernel, dim3(4), dim3(256), 0, t->stream, gcur, cap2, nb, b.off);
     for(int p = 0; p < W; ++p) {
       const uint64_t* lst = r_strag + (size_t)p * (1 + L.S);

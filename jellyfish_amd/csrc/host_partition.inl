@@ -345,12 +345,16 @@ int part_flush_t(jfgpu_table* t) {
     // 32-bit items into 32-bit slots: P2 routes to pairs of adjacent tiles (half as many destinations, and chunks of 28 Ki
     // items), so the runs it writes are ~112 bytes on average instead of 32; the tile kernel owns a pair (64 KiB) in LDS
     const bool pair = sizeof(ITEM) == 4 && t->g.slot32 && t->pg.b2 >= 1 && t->tile_pair;
-    // Single-pass P2 (pairs only): fixed regions of cap2 items per pair, reservations of kGran items (p2_granule_kernel).
-    // Worth it when the regions are mostly items: every block may strand one reservation per destination.
+    // Single-pass P2 (32-bit items into pairs of tiles; 16-byte items into tiles): fixed regions of cap2 items per
+    // destination, reservations of kGran items (p2_granule_kernel).  Worth it when the regions are mostly items: every
+    // block may strand one reservation per destination.  When the regions of the whole table do not fit the arena beside
+    // what is pending, the P1 buckets go through P2 and the tile insert in `single_groups` groups sharing one buffer.
     constexpr uint32_t kG2Single = 4;                       // blocks per P1 bucket
-    uint32_t cap2 = 0; unsigned int* d_gcur2 = nullptr; uint64_t* d_off2 = nullptr; ITEM* out2 = nullptr; bool own2 = false;
-    const uint64_t n_dest = n_tiles >> 1;
-    if(pair && t->p2_single) {
+    constexpr bool kSingleItems = sizeof(ITEM) == 4 || sizeof(ITEM) == 16;
+    uint32_t cap2 = 0, single_groups = 1; unsigned int* d_gcur2 = nullptr; uint64_t* d_off2 = nullptr; ITEM* out2 = nullptr; bool own2 = false;
+    const bool single_ok = kSingleItems && t->p2_single && (sizeof(ITEM) == 16 || pair) && t->flush_groups <= 1;
+    const uint64_t n_dest = pair ? n_tiles >> 1 : n_tiles;
+    if(single_ok) {
       const uint64_t mean = total / n_dest, strand = (uint64_t)kG2Single * kGran;
       if(mean >= 8 * strand || t->p2_single > 1) {
         cap2 = (uint32_t)(((uint64_t)((double)mean * (1.0 + t->p2_slack)) + strand + 2 * kGran - 1) / kGran * kGran);
@@ -358,21 +362,28 @@ int part_flush_t(jfgpu_table* t) {
         const size_t mark = t->ws_used;
         d_gcur2 = (unsigned int*)ws_alloc(t, 2 * n_dest * sizeof(unsigned int));
         d_off2 = (uint64_t*)ws_alloc(t, 2 * n_dest * sizeof(uint64_t));
-        out2 = (ITEM*)ws_alloc(t, n_dest * cap2 * sizeof(ITEM));
-        if(!d_gcur2 || !d_off2 || !out2) {       // no room for the regions in the arena: exact P2 (forced: one-off allocations)
+        const size_t used = align_up(t->ws_used, 256) + 4096;
+        const size_t free_b = t->ws_cap > used ? t->ws_cap - used : 0;
+        const uint32_t forced = getenv("JFGPU_FLUSH_SHARE") ? (uint32_t)atoi(getenv("JFGPU_FLUSH_SHARE")) : 0;      // (tests)
+        uint32_t G = forced && forced <= nb1 / 8 ? forced : 1;
+        while(!forced && G <= nb1 / 8 && (n_dest / G) * cap2 * sizeof(ITEM) > free_b) G *= 2;
+        if(d_gcur2 && d_off2 && G <= std::max<uint32_t>(1, nb1 / 8)) out2 = (ITEM*)ws_alloc(t, (n_dest / G) * cap2 * sizeof(ITEM));
+        if(out2) single_groups = G;
+        else {                                   // no room for the regions in the arena: exact P2 (forced: one-off allocations)
           t->ws_used = mark;
           d_gcur2 = nullptr; d_off2 = nullptr; out2 = nullptr;
+          single_groups = forced && forced <= nb1 / 8 ? forced : 1;
           if(t->p2_single > 1 && hipMalloc((void**)&d_gcur2, 2 * n_dest * sizeof(unsigned int)) == hipSuccess &&
              hipMalloc((void**)&d_off2, 2 * n_dest * sizeof(uint64_t)) == hipSuccess &&
-             hipMalloc((void**)&out2, n_dest * cap2 * sizeof(ITEM)) == hipSuccess) own2 = true;
-          else { if(d_gcur2) hipFree(d_gcur2); if(d_off2) hipFree(d_off2); if(out2) hipFree(out2); cap2 = 0; }
+             hipMalloc((void**)&out2, (n_dest / single_groups) * cap2 * sizeof(ITEM)) == hipSuccess) own2 = true;
+          else { if(d_gcur2) hipFree(d_gcur2); if(d_off2) hipFree(d_off2); if(out2) hipFree(out2); cap2 = 0; single_groups = 1; }
         }
         if(cap2) HIP_TRY(hipMemsetAsync(d_gcur2, 0, 2 * n_dest * sizeof(unsigned int), t->stream));
       }
     }
     if(getenv("JFGPU_FLUSH_TRACE"))
-      fprintf(stderr, "[flush] %llu items in %zu batches, %llu tiles, pairs %d, single-pass P2 regions of %u items (0: exact P2)\n",
-              (unsigned long long)total, nbatch, (unsigned long long)n_tiles, (int)pair, cap2);
+      fprintf(stderr, "[flush] %llu items in %zu batches, %llu tiles, pairs %d, single-pass P2 regions of %u items (0: exact P2) in %u group(s)\n",
+              (unsigned long long)total, nbatch, (unsigned long long)n_tiles, (int)pair, cap2, single_groups);
     // When the arena cannot hold a P2 output of the whole flush beside what is pending, the P1 buckets go through P2 and
     // the tile insert in groups that share one small output buffer (group g's tiles are inserted before group g+1 is
     // partitioned): 16-byte items at 10 Gbp then need 104 GB (P1 regions) + 12 GB instead of 104 + 94, the whole job fits
@@ -413,6 +424,7 @@ int part_flush_t(jfgpu_table* t) {
     // Optionally (JFGPU_FLUSH_GROUPS > 1) the P1 buckets go through P2 and the tile insert in groups, P2 on the
     // table's stream and the tile insert on a second one, so that group g's tiles are inserted while group g+1
     // is partitioned (one P2-scatter block, 88 KB LDS, and one tile block, 64 KB, fit a CU together).
+    if(cap2 && single_groups > 1) share_groups = single_groups;      // same loop, same per-group timers; the shared buffer holds regions
     const uint32_t n_groups = share_groups ? share_groups : t->flush_groups > 1 && nb1 >= (uint32_t)t->flush_groups * 8 ? (uint32_t)t->flush_groups : 1;
     const bool two_streams = n_groups > 1 && !share_groups;
     const uint32_t gsz = nb1 / n_groups;
@@ -433,28 +445,47 @@ int part_flush_t(jfgpu_table* t) {
       const dim3 grid(g2, nbk), block(kPBlock);
       hipEvent_t ga = nullptr;                              // groups sharing tmp: every group's two stages are timed on their own
       if(t->prof_on && share_groups) { ga = get_event(t); hipEventRecord(ga, t->stream); }
-      if constexpr(sizeof(ITEM) == 4) {
+      if constexpr(kSingleItems) {
         if(cap2) {
           const dim3 g1p(kG2Single, nbk);
-          const size_t lds = (size_t)kPBlock * kP2PairPer * sizeof(ITEM);
-          if(rt) hipLaunchKernelGGL((p2_granule_kernel<true, kP2PairPer>), g1p, block, lds, t->stream, t->dt, t->pg, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest, out2, b0);
-          else   hipLaunchKernelGGL((p2_granule_kernel<false, kP2PairPer>), g1p, block, lds, t->stream, t->dt, t->pg, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest, out2, b0);
           const uint64_t d0 = (uint64_t)b0 << pg2.b2, nd = (uint64_t)nbk << pg2.b2;
+          // destination d of the whole table sits at d * cap2 of a buffer that only holds this group's: shifted base
+          ITEM* out_v = out2 - (share_groups ? (int64_t)d0 * (int64_t)cap2 : 0);
+          if constexpr(sizeof(ITEM) == 4) {
+            const size_t lds = (size_t)kPBlock * kP2PairPer * sizeof(ITEM);
+            if(rt) hipLaunchKernelGGL((p2_granule_kernel<uint32_t, TableDirect<true>, kP2PairPer>), g1p, block, lds, t->stream, TableDirect<true>{t->dt, t->pg}, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest, (uint32_t*)out_v, b0);
+            else   hipLaunchKernelGGL((p2_granule_kernel<uint32_t, TableDirect<false>, kP2PairPer>), g1p, block, lds, t->stream, TableDirect<false>{t->dt, t->pg}, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest, (uint32_t*)out_v, b0);
+          } else {
+            const size_t lds = (size_t)kPBlock * kP2WidePer * sizeof(ITEM);
+            if(rt) hipLaunchKernelGGL((p2_granule_kernel<u128, WideDirect<true>, kP2WidePer>), g1p, block, lds, t->stream, WideDirect<true>{t->wt, t->pg}, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest, (u128*)out_v, b0);
+            else   hipLaunchKernelGGL((p2_granule_kernel<u128, WideDirect<false>, kP2WidePer>), g1p, block, lds, t->stream, WideDirect<false>{t->wt, t->pg}, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest, (u128*)out_v, b0);
+          }
           // (granule_finish_kernel reads gcur[nb + j] as destination j's overflow note: the two halves of d_gcur2)
           if(n_groups == 1) hipLaunchKernelGGL(granule_finish_kernel, dim3(1024), dim3(256), 0, t->stream, d_gcur2, cap2, (uint32_t)n_dest, d_off2);
           else hipLaunchKernelGGL(granule_finish_range_kernel, dim3(256), dim3(256), 0, t->stream, d_gcur2, cap2, (uint32_t)n_dest, d_off2, (uint32_t)d0, (uint32_t)nd);
-          if(t->prof_on && g + 1 == n_groups) hipEventRecord(p2b, t->stream);
           SegList S2; memset(&S2, 0, sizeof S2);
-          S2.n = 1; S2.items[0] = out2; S2.off[0] = d_off2 + 2 * d0; S2.sh[0] = 1;
+          S2.n = 1; S2.items[0] = out_v; S2.off[0] = d_off2 + 2 * d0; S2.sh[0] = 1;     // offsets from the group's first destination, items absolute
           hipStream_t ts = t->stream;
+          if(share_groups) {    // one stream, P2 and T alternate (the next group overwrites the regions): timed per group
+            uint64_t gtot = 0; for(uint32_t j = b0; j < b0 + nbk; ++j) gtot += bucket_tot[j];
+            if(t->prof_on) {
+              hipEvent_t gb = get_event(t), gc = get_event(t), gd = get_event(t);
+              hipEventRecord(gb, ts); hipEventRecord(gc, ts);
+              t->prof_pending.push_back({ga, gb, 5, gtot});
+              launch_tile_kernel(S2, (uint64_t)b0 << t->pg.b2, (uint32_t)nd, ts, pair);
+              hipEventRecord(gd, ts);
+              t->prof_pending.push_back({gc, gd, 6, gtot});
+            } else launch_tile_kernel(S2, (uint64_t)b0 << t->pg.b2, (uint32_t)nd, ts, pair);
+            continue;
+          }
+          if(t->prof_on && g + 1 == n_groups) hipEventRecord(p2b, t->stream);
           if(two_streams) {
             HIP_TRY(hipEventRecord(t->flush_ev[g & 1], t->stream));
             HIP_TRY(hipStreamWaitEvent(t->stream2, t->flush_ev[g & 1], 0));
             ts = t->stream2;
           }
           if(t->prof_on && g == 0) hipEventRecord(ta, ts);
-          // S2.off is relative to the group, the items are not: pair d of the whole table sits at d * cap2
-          launch_tile_kernel(S2, (uint64_t)b0 << t->pg.b2, (uint32_t)nd, ts, true);
+          launch_tile_kernel(S2, (uint64_t)b0 << t->pg.b2, (uint32_t)nd, ts, pair);
           if(t->prof_on && g + 1 == n_groups) hipEventRecord(tb, ts);
           continue;
         }

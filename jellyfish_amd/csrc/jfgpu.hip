@@ -641,10 +641,10 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     HIP_TRY(hipFuncSetAttribute((const void*)p1_route_granule_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_route_granule_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_route_granule_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
-    HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<true, kP2PairPer, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
-    HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<false, kP2PairPer, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
-    HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<true, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
-    HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<false, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
+    HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint32_t, TableDirect<true>, kP2PairPer, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
+    HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint32_t, TableDirect<false>, kP2PairPer, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
+    HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint32_t, TableDirect<true>, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
+    HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint32_t, TableDirect<false>, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint32_t, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)tile_insert_kernel<uint32_t, true, true, unsigned int, kPBlock, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 << kMaxTileBits));
     HIP_TRY(hipFuncSetAttribute((const void*)tile_insert_kernel<uint32_t, false, true, unsigned int, kPBlock, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 << kMaxTileBits));
@@ -656,6 +656,8 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     HIP_TRY(hipFuncSetAttribute((const void*)p1_granule64_kernel<false, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, gl));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_granule64_kernel<false, false, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, gl));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_granule64_kernel<false, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, gl));
+    HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<u128, WideDirect<true>, kP2WidePer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2WidePer * 16));
+    HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<u128, WideDirect<false>, kP2WidePer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2WidePer * 16));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<u128, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * 7 * 16));
     const int wl = kWideChunk * 18 + 16 * 2048, wt = 16 << kMaxTileBits;
     HIP_TRY(hipFuncSetAttribute((const void*)p1_wide_granule_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wl));

@@ -1048,14 +1048,22 @@ __global__ __launch_bounds__(kPBlock) void p1_keys_granule_kernel(DevTable T, Pa
 // single-pass P1: same LDS counting sort per chunk, same holes, and what does not fit a region goes straight to the table.
 // grid = (G2, buckets): blockIdx.y is the P1 bucket, blockIdx.x a contiguous slice of its items.  gcur / gshort / out are
 // indexed by destination = bucket * 2^b2e + sub-bucket.
-template <bool RETURNING, int PER_THREAD, bool SMALL = false>
-__global__ __launch_bounds__(kPBlock) void p2_granule_kernel(DevTable T, PartGeom P, uint32_t b2e, uint32_t tag_bits, SegList S, uint32_t cap,
+// What to do with an item that cannot be stored in its region: one-word keys (32-bit items) -- the table's global claim.
+template <bool RETURNING>
+struct TableDirect {
+  DevTable T; PartGeom P;
+  __device__ void operator()(uint32_t bucket, uint32_t item) const { item_direct_insert<RETURNING>(T, P, bucket, (uint64_t)item); }
+  __device__ unsigned long long* direct_counter() const { return (unsigned long long*)&T.counters[CTR_DIRECT]; }
+};
+
+// ITEM: uint32_t or unsigned __int128; DIRECT: see TableDirect (kernels_wide_part.hip.hpp has the two-word one).
+template <typename ITEM, typename DIRECT, int PER_THREAD, bool SMALL = false>
+__global__ __launch_bounds__(kPBlock) void p2_granule_kernel(DIRECT D, uint32_t b2e, uint32_t tag_bits, SegList S, uint32_t cap,
                                                              unsigned int* __restrict__ gcur, unsigned int* __restrict__ gshort,
-                                                             uint32_t* __restrict__ out, uint32_t bucket0,
+                                                             ITEM* __restrict__ out, uint32_t bucket0,
                                                              unsigned long long* __restrict__ tot = nullptr, uint32_t bucket_mask = 0xFFFFFFFFu) {
   // tot (optional): exact items stored per destination.  bucket_mask: the part of the bucket index that P, the geometry
   // of the direct inserts, knows about (the receive side of the multi-GPU exchange splits buckets numbered globally).
-  typedef uint32_t ITEM;
   constexpr int kChunk = kPBlock * PER_THREAD;
   JF_DYN_LDS(s_dyn);
   ITEM* s_item = reinterpret_cast<ITEM*>(s_dyn);                       // [kChunk]
@@ -1139,13 +1147,13 @@ __global__ __launch_bounds__(kPBlock) void p2_granule_kernel(DevTable T, PartGeo
                      for(int r = 0; r < PER_THREAD; ++r)
                        if((vm >> r) & 1) s_item[G.lstart[(uint32_t)(it[r] >> tag_bits) & (nb - 1)] + ((rk[r >> 1] >> ((r & 1) * 16)) & 0xFFFFu)] = it[r];
                    },
-                   [&](uint32_t, ITEM v) { item_direct_insert<RETURNING>(T, P, bucket & bucket_mask, (uint64_t)v); },
+                   [&](uint32_t, ITEM v) { D(bucket & bucket_mask, v); },
                    [&](uint32_t, ITEM v) -> uint32_t { return (uint32_t)(v >> tag_bits) & (nb - 1); }, &pc);
   }
   granule_finish<ITEM>(G, nb, cap, tot ? tot + (size_t)bucket * nb : nullptr, o);
   JF_PHASE(pc, 6);
   JF_PHASE_FLUSH(pc, 8);
-  if(my_direct) atomicAdd((unsigned long long*)&T.counters[CTR_DIRECT], (unsigned long long)my_direct);
+  if(my_direct) atomicAdd(D.direct_counter(), (unsigned long long)my_direct);
 }
 
 // ---- multi-GPU: P1 on the sending side (abi_comm.inl) ------------------------------------------------------------

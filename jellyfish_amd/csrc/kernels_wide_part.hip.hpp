@@ -54,6 +54,15 @@ __device__ inline void wide_item_direct(const WideTable& T, const PartGeom& P, u
   atomicAdd((unsigned long long*)&T.counters[CTR_FULL], 1ull);
 }
 
+// p2_granule_kernel's overflow policy for two-word keys, and its chunk (7 Ki items = 112 KiB of LDS)
+template <bool RETURNING>
+struct WideDirect {
+  WideTable T; PartGeom P;
+  __device__ void operator()(uint32_t bucket, u128 item) const { wide_item_direct<RETURNING>(T, P, bucket, item); }
+  __device__ unsigned long long* direct_counter() const { return (unsigned long long*)&T.counters[CTR_DIRECT]; }
+};
+constexpr int kP2WidePer = 7;
+
 // ---- P1w --------------------------------------------------------------------------------------------------
 // One block iteration = 16384 sequence positions, in rounds of kWidePer positions per lane (4096 items per round).
 template <bool RETURNING, bool BLOOM>

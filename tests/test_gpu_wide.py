@@ -293,8 +293,9 @@ def test_flush_in_groups_sharing_one_p2_buffer(gpu, monkeypatch):
     for k, size in ((40, 1 << 26), (21, 1 << 27)):
         seq = rnd_seq(rng, 200000, "ACGT") + b"N" + rnd_seq(rng, 50000, "AC")
         digests = {}
-        for share in ("4", "0"):
-            monkeypatch.setenv("JFGPU_FLUSH_SHARE", share)
+        for share in ("4", "4s", "0"):                       # 4s: the single-pass P2 (fixed regions), also in 4 groups
+            monkeypatch.setenv("JFGPU_FLUSH_SHARE", share[0])
+            monkeypatch.setenv("JFGPU_P2_SINGLE", "2" if share == "4s" else "0")
             with gpu.Table(k, size, canonical=True) as t:
                 t.set_mode(2 if share != "0" else 1)
                 t.profile_enable(True)
@@ -305,4 +306,4 @@ def test_flush_in_groups_sharing_one_p2_buffer(gpu, monkeypatch):
                     assert t.profile_get(5)[1] >= 4 and t.profile_get(6)[1] >= 4        # P2 and T ran per group
                 st = t.stats()
                 digests[share] = (t.digest(), st.total, st.distinct)
-        assert digests["4"] == digests["0"]
+        assert digests["4"] == digests["0"] == digests["4s"]
