@@ -116,6 +116,7 @@ static int bloom_create(const jfgpu_bloom_params* p, jfgpu_bloom** out, uint32_t
     HIP_TRY(hipFuncSetAttribute((const void*)p1_bloom_granule_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, pl));
     HIP_TRY(hipFuncSetAttribute((const void*)bloom_segment_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 1 << kBloomSegBits));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint32_t, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
+    HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint32_t, BloomDirect, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
   }
   HIP_TRY(hipMalloc((void**)&b->d_data, b->alloc_bytes));
   HIP_TRY(hipMemsetAsync(b->d_data, 0, b->alloc_bytes, b->stream));

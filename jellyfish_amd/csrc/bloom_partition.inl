@@ -205,7 +205,29 @@ int bloom_flush_inner(jfgpu_bloom* b) {
         for(uint32_t g = 0; g < G; ++g) { uint64_t sum = 0; for(uint32_t j = g * (nb1 / G); j < (g + 1) * (nb1 / G); ++j) sum += bucket_tot[j]; mx = std::max(mx, sum); }
         if(forced ? G == forced : mx * sizeof(uint32_t) <= free_b) { n_groups = G; tmp_items = std::max<uint64_t>(mx, 1); break; }
       }
-    uint32_t* tmp = (uint32_t*)bloom_ws_alloc(b, tmp_items * sizeof(uint32_t));
+    // Single-pass P2 (p2_granule_kernel, like the count path's): fixed regions of cap2 cell updates per segment instead of a
+    // count pass + exact placement -- the updates are read once instead of twice.  Regions of one bucket group at a time.
+    constexpr uint32_t kG2Single = 4;
+    uint32_t cap2 = 0;
+    unsigned int* d_gcur2 = nullptr; uint64_t* d_off2 = nullptr; uint32_t* out2 = nullptr;
+    const int p2_single = getenv("JFGPU_P2_SINGLE") ? atoi(getenv("JFGPU_P2_SINGLE")) : 1;
+    if(p2_single) {
+      const uint64_t mean = total / std::max<uint32_t>(1, b->bp.n_seg), strand = (uint64_t)kG2Single * kGran;   // (the array ends before the last bucket does)
+      if(mean >= 8 * strand || p2_single > 1) {
+        cap2 = (uint32_t)(((uint64_t)((double)mean * 1.08) + strand + 2 * kGran - 1) / kGran * kGran);
+        const size_t mark = b->ws_used;
+        d_gcur2 = (unsigned int*)bloom_ws_alloc(b, (2 * n_tiles + 2) * sizeof(unsigned int));
+        d_off2 = (uint64_t*)bloom_ws_alloc(b, 2 * n_tiles * sizeof(uint64_t));
+        const size_t used = align_up(b->ws_used, 256) + 4096;
+        const size_t fr = b->ws_cap > used ? b->ws_cap - used : 0;
+        uint32_t G = forced && forced <= nb1 / 4 ? forced : 1;
+        while(!forced && G <= nb1 / 4 && (n_tiles / G) * cap2 * sizeof(uint32_t) > fr) G *= 2;
+        if(d_gcur2 && d_off2 && G <= std::max<uint32_t>(1, nb1 / 4)) out2 = (uint32_t*)bloom_ws_alloc(b, (n_tiles / G) * cap2 * sizeof(uint32_t));
+        if(out2) { n_groups = G; HIP_TRY(hipMemsetAsync(d_gcur2, 0, (2 * n_tiles + 2) * sizeof(unsigned int), b->stream)); }
+        else { b->ws_used = mark; cap2 = 0; d_gcur2 = nullptr; d_off2 = nullptr; }
+      }
+    }
+    uint32_t* tmp = cap2 ? out2 : (uint32_t*)bloom_ws_alloc(b, tmp_items * sizeof(uint32_t));
     if(!d_goff || !d_base || !tmp) return fail(JFGPU_E_ALLOC, "Bloom partition workspace too small for the flush");
     const uint32_t gsz = nb1 / n_groups;
     std::vector<uint64_t> basev(nb1);
@@ -216,6 +238,24 @@ int bloom_flush_inner(jfgpu_bloom* b) {
     for(uint32_t g = 0; g < n_groups; ++g) {
       const uint32_t b0 = g * gsz;
       uint64_t gtot = 0; for(uint32_t j = b0; j < b0 + gsz; ++j) gtot += bucket_tot[j];
+      const uint64_t seg0 = (uint64_t)b0 * nb2;
+      if(cap2) {
+        uint32_t* out_v = out2 - (n_groups > 1 ? (int64_t)seg0 * (int64_t)cap2 : 0);      // segment d of the whole array sits at d * cap2
+        {
+          BloomProf ps(b, BS_P2, gtot);
+          const dim3 g1p(kG2Single, gsz), block(kPBlock);
+          const BloomDirect D{B, b->bp, reinterpret_cast<unsigned long long*>(d_gcur2 + 2 * n_tiles)};
+          hipLaunchKernelGGL((p2_granule_kernel<uint32_t, BloomDirect, kP2PairPer>), g1p, block, (size_t)kPBlock * kP2PairPer * sizeof(uint32_t), b->stream,
+                             D, b->bp.b2, kBloomItemLow, S1, cap2, d_gcur2, d_gcur2 + n_tiles, out_v, b0);
+          hipLaunchKernelGGL(granule_finish_range_kernel, dim3(256), dim3(256), 0, b->stream, d_gcur2, cap2, (uint32_t)n_tiles, d_off2, (uint32_t)seg0, gsz * nb2);
+        }
+        if(seg0 >= b->bp.n_seg) break;
+        const uint32_t nseg = (uint32_t)std::min<uint64_t>((uint64_t)gsz * nb2, b->bp.n_seg - seg0);
+        SegList S2; memset(&S2, 0, sizeof S2);
+        S2.n = 1; S2.items[0] = out_v; S2.off[0] = d_off2 + 2 * seg0; S2.sh[0] = 1;
+        launch_segments(S2, nseg, gtot, (uint32_t)seg0);
+        continue;
+      }
       {
         BloomProf ps(b, BS_P2, gtot);
         const dim3 grid(g2, gsz), block(kPBlock);
@@ -226,7 +266,6 @@ int bloom_flush_inner(jfgpu_bloom* b) {
                            P, kBloomItemLow, S1, (const uint32_t*)b->d_M2, (const uint64_t*)d_goff, tmp, b0);
       }
       // this group's segments: numbers b0 * nb2 .. ; the last group stops at the array's last segment
-      const uint64_t seg0 = (uint64_t)b0 * nb2;
       if(seg0 >= b->bp.n_seg) break;
       const uint32_t nseg = (uint32_t)std::min<uint64_t>((uint64_t)gsz * nb2, b->bp.n_seg - seg0);
       SegList S2; memset(&S2, 0, sizeof S2);

@@ -40,6 +40,14 @@ __device__ inline void bloom_item_direct(const DevBloom& B, const BloomPart& BP,
   bloom_bump(B.data, byte, item & 7u);
 }
 
+// p2_granule_kernel's overflow policy for cell updates: the cell is bumped in place.  counter: any device word (the
+// number of such updates, not read by anyone yet).
+struct BloomDirect {
+  DevBloom B; BloomPart BP; unsigned long long* counter;
+  __device__ void operator()(uint32_t bucket, uint32_t item) const { bloom_item_direct(B, BP, bucket, item); }
+  __device__ unsigned long long* direct_counter() const { return counter; }
+};
+
 // ---- P1b ----------------------------------------------------------------------------------------------------
 // One block iteration = 16384 sequence positions.  The lanes roll their 16 windows together, one position per round:
 // a round gives every lane at most kBloomPer items (nh > kBloomPer takes more rounds), 10240 per block, sorted and

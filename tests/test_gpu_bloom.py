@@ -147,14 +147,18 @@ def test_count_bc_single_pass_partition_equals_direct(gpu, monkeypatch):
         assert sum(1 for key in singles if key in got) < 0.01 * len(singles)            # only false positives survive
 
 
-@pytest.mark.parametrize("n_cells,two_level,share", [(14 * 150000, False, None), (14 * 30_000_000, True, None), (14 * 30_000_000, True, "4")])
+@pytest.mark.parametrize("n_cells,two_level,share", [(14 * 150000, False, None), (14 * 30_000_000, True, None), (14 * 30_000_000, True, "4"),
+                                                     (14 * 30_000_000, True, "single"), (14 * 30_000_000, True, "single4")])
 def test_partitioned_insert_equals_direct_and_oracle(gpu, monkeypatch, n_cells, two_level, share):
     """The partitioned insert (cell updates routed to 64 KiB segments, applied in LDS: kernels_bloom_part.hip.hpp) leaves
     the same bytes as one global compare-and-swap per cell and as the oracle's bloom_counter2 restatement; with more
     than 1024 segments the second partition level (P2) is on the path.  Several batches per flush, saturation at 2,
     a flush in the middle (check on encoded keys), inserts after it."""
-    if share:       # P2 and the segment kernel go through the P1b buckets in groups that share one output buffer
-        monkeypatch.setenv("JFGPU_FLUSH_SHARE", share)
+    # share: P2 and the segment kernel go through the P1b buckets in groups that share one output buffer; single: the
+    # single-pass P2 (fixed regions per segment, forced on: test-sized flushes would take the exact one)
+    monkeypatch.setenv("JFGPU_P2_SINGLE", "2" if share and share.startswith("single") else "0")
+    if share and share[-1] == "4":
+        monkeypatch.setenv("JFGPU_FLUSH_SHARE", "4")
     rng = random.Random(17)
     k, nh = 31, 10
     seq = ("".join(rng.choice("ACGT") for _ in range(90000)) + "N" + "".join(rng.choice("ACGTacgtN") for _ in range(30000))).encode()

@@ -4,7 +4,7 @@ mkdir -p gpurun_out
 {
   echo "== parity (wide, bloom)"
   timeout 900 python -m pytest tests/test_gpu_wide.py tests/test_gpu_bloom.py -m gpu -x -q 2>&1 | grep -E "passed|failed|rror" | tail -3
-  for c in C5 C2; do
+  for c in C3; do
     echo "== bench $c"
     JFGPU_FLUSH_TRACE=1 timeout 900 python bench.py --config $c --no-cpu-baseline --no-extras --repeats 2 2> gpurun_out/r02_c19_$c.err | grep '^{' > gpurun_out/r02_bench_${c}_c19.json; grep flush gpurun_out/r02_c19_$c.err | tail -4
     python - <<PY
