@@ -245,6 +245,11 @@ def main():
         if world > 1:
             dist.broadcast_object_list(ids, src=0)
         comm = capi.Comm(world, rank, ids[0], device=local_rank)
+        try:        # RCCL prints a version banner through C stdio: push it out now, so that the JSON line is the last thing on stdout
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
     bloom = None
     if cfg == "C3":
         bloom = capi.Bloom(K, capi.opt_m(0.001, int(args.gbp * 1e9)), capi.opt_k(0.001), canonical=True, device=local_rank)
