@@ -192,7 +192,8 @@ int comm_insert_prev_items(jfgpu_comm* c, jfgpu_comm::Rank& R, int rank) {
   const ItemLayout L = item_layout(c, t, R.icap[prev]);
   const uint32_t sb = L.split_bits;                        // bits that finish the shard's own bucket index
   const uint32_t nb = 1u << t->pg.b1;
-  constexpr uint32_t kBlocksPerBucket = 4;
+  // blocks per coarse bucket: about two workgroups per CU in all (world 8: 4 x 128 buckets; world 1: 1 x 1024)
+  const uint32_t kBlocksPerBucket = std::max<uint32_t>(1, std::min<uint32_t>(4, (2u * (uint32_t)t->n_cu) / std::max<uint32_t>(1, L.nbc)));
   const uint32_t cap2 = (uint32_t)(((uint64_t)L.cap + (uint64_t)kBlocksPerBucket * kGran + kGran - 1) / kGran * kGran);
   const size_t bytes = (size_t)nb * cap2 * 4;
   const size_t need = align_up(bytes, 256) + align_up((2 * nb + 1) * sizeof(uint64_t), 256) + align_up(nb * 16, 256) + 1024;
