@@ -274,41 +274,23 @@ int part_flush_t(jfgpu_table* t) {
   for(size_t s = 0; s < nbatch; ++s) { S1.items[s] = t->pending[s].items; S1.off[s] = t->pending[s].off; S1.sh[s] = t->pending[s].gran_cap ? 1 : 0; }
   constexpr bool kWideItems = sizeof(ITEM) == 16;         // two-word keys: 128-bit items, 128-bit slots
   const size_t tile_lds = (size_t)(kWideItems ? 16 : t->g.slot32 ? 4 : 8) << t->g.tile_bits;
-  // always LOAD-capable: a tile is read only if its dirty byte is set (clean after jfgpu_clear)
-  const bool rt = t->returning, load = true;
+  const bool rt = t->returning;      // a tile is read only if its dirty byte is set (clean after jfgpu_clear)
   // the tile insert of one item array (or of the pending batches themselves), on stream `ts`
   auto launch_tile_kernel = [&](const SegList& S, uint64_t tile0, uint32_t ntile, hipStream_t ts, bool pair = false) {
-    const dim3 block(kPBlock);
-    if constexpr(sizeof(ITEM) == 4) {
-      if(pair) {                    // ntile counts pairs of 32 KiB tiles: 64 KiB of LDS, two workgroups of 1024 per CU
-        const dim3 grid((unsigned)std::min<uint64_t>(ntile, (uint64_t)t->n_cu * 16));
-        if(rt) hipLaunchKernelGGL((tile_insert_kernel<ITEM, true, true, unsigned int, kPBlock, 2>), grid, block, 2 * tile_lds, ts, t->dt, S, tile0, ntile);
-        else   hipLaunchKernelGGL((tile_insert_kernel<ITEM, false, true, unsigned int, kPBlock, 2>), grid, block, 2 * tile_lds, ts, t->dt, S, tile0, ntile);
-        return;
-      }
-    }
+    const dim3 block(kPBlock), tblock(kTileBlock);
     if constexpr(kWideItems) {
       const dim3 grid((unsigned)std::min<uint64_t>(ntile, (uint64_t)t->n_cu * 4));     // 128 KiB of LDS: one block per CU
       if(rt) hipLaunchKernelGGL(tile_insert_wide_kernel<true>, grid, block, tile_lds, ts, t->wt, S, tile0, ntile);
       else   hipLaunchKernelGGL(tile_insert_wide_kernel<false>, grid, block, tile_lds, ts, t->wt, S, tile0, ntile);
     } else {
+      // one-word keys: placement by rank inside buckets of four (kernels_tile.hip.hpp); two workgroups per CU
       const dim3 grid((unsigned)std::min<uint64_t>(ntile, (uint64_t)t->n_cu * 16));
-      if constexpr(sizeof(ITEM) == 4) {
-        if(t->g.slot32) {           // 32 KiB tiles: four workgroups of 512 per CU
-          const dim3 b512(512);
-          if(rt) hipLaunchKernelGGL((tile_insert_kernel<ITEM, true, true, unsigned int, 512>), grid, b512, tile_lds, ts, t->dt, S, tile0, ntile);
-          else   hipLaunchKernelGGL((tile_insert_kernel<ITEM, false, true, unsigned int, 512>), grid, b512, tile_lds, ts, t->dt, S, tile0, ntile);
-          return;
-        }
-      }
-      if(t->g.slot32) {             // (64-bit items into 32-bit slots: small k in a huge table; same kernel, 1024 threads)
-        if(rt) hipLaunchKernelGGL((tile_insert_kernel<ITEM, true, true, unsigned int, kPBlock>), grid, block, tile_lds, ts, t->dt, S, tile0, ntile);
-        else   hipLaunchKernelGGL((tile_insert_kernel<ITEM, false, true, unsigned int, kPBlock>), grid, block, tile_lds, ts, t->dt, S, tile0, ntile);
-        return;
-      }
-#define TI(RT, LD) hipLaunchKernelGGL((tile_insert_kernel<ITEM, RT, LD, unsigned long long, kPBlock>), grid, block, tile_lds, ts, t->dt, S, tile0, ntile)
-      if(rt) { if(load) TI(true, true); else TI(true, false); } else { if(load) TI(false, true); else TI(false, false); }
-#undef TI
+#define TR(SLOT, TPB) do { const size_t lds = tile_rank_lds(sizeof(SLOT), t->g.tile_bits, TPB); \
+        if(rt) hipLaunchKernelGGL((tile_rank_insert_kernel<ITEM, true, SLOT, TPB>), grid, tblock, lds, ts, t->dt, S, tile0, ntile); \
+        else   hipLaunchKernelGGL((tile_rank_insert_kernel<ITEM, false, SLOT, TPB>), grid, tblock, lds, ts, t->dt, S, tile0, ntile); } while(0)
+      if(t->g.slot32) { if(pair) TR(unsigned int, 2); else TR(unsigned int, 1); }
+      else TR(unsigned long long, 1);
+#undef TR
     }
   };
   auto launch_tiles = [&](const SegList& S, uint64_t tile0, uint32_t ntile, uint64_t units) {

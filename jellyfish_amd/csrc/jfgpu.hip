@@ -18,6 +18,7 @@
 #include "gf2_matrix.hpp"
 #include "kernels.hip.hpp"
 #include "kernels_part.hip.hpp"
+#include "kernels_tile.hip.hpp"
 #include "kernels_bloom.hip.hpp"
 #include "kernels_bloom_part.hip.hpp"
 #include "kernels_wide.hip.hpp"
@@ -610,12 +611,11 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
   if(const char* m = getenv("JFGPU_P2_CAP")) t->p2_cap = (uint32_t)atoi(m) / kGran * kGran;
   if(const char* m = getenv("JFGPU_P2_SLACK")) t->p2_slack = atof(m);
   {
-    const int tl = (int)((size_t)8 << t->g.tile_bits);
-#define TATTR(I, R, L) HIP_TRY(hipFuncSetAttribute((const void*)tile_insert_kernel<I, R, L, unsigned long long, kPBlock>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 << kMaxTileBits))
-    TATTR(uint32_t, true, true); TATTR(uint32_t, true, false); TATTR(uint32_t, false, true); TATTR(uint32_t, false, false);
-    TATTR(uint64_t, true, true); TATTR(uint64_t, true, false); TATTR(uint64_t, false, true); TATTR(uint64_t, false, false);
+#define TATTR(I, S, P) HIP_TRY(hipFuncSetAttribute((const void*)tile_rank_insert_kernel<I, true, S, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_rank_lds(sizeof(S), kMaxTileBits, P))); \
+                       HIP_TRY(hipFuncSetAttribute((const void*)tile_rank_insert_kernel<I, false, S, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_rank_lds(sizeof(S), kMaxTileBits, P)))
+    TATTR(uint32_t, unsigned int, 1); TATTR(uint32_t, unsigned int, 2); TATTR(uint32_t, unsigned long long, 1);
+    TATTR(uint64_t, unsigned int, 1); TATTR(uint64_t, unsigned int, 2); TATTR(uint64_t, unsigned long long, 1);
 #undef TATTR
-    (void)tl;
     HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_sorted_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_sorted_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_sorted_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
@@ -646,8 +646,6 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint32_t, TableDirect<true>, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint32_t, TableDirect<false>, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint32_t, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
-    HIP_TRY(hipFuncSetAttribute((const void*)tile_insert_kernel<uint32_t, true, true, unsigned int, kPBlock, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 << kMaxTileBits));
-    HIP_TRY(hipFuncSetAttribute((const void*)tile_insert_kernel<uint32_t, false, true, unsigned int, kPBlock, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 << kMaxTileBits));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint64_t, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * 14 * 8));
     const int gl = kG64Chunk * 10;
     HIP_TRY(hipFuncSetAttribute((const void*)p1_granule64_kernel<true, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, gl));
@@ -734,12 +732,14 @@ int jfgpu_sync(jfgpu_table* t) {
   rc = part_flush(t); if(rc) return rc;
   HIP_TRY(hipStreamSynchronize(t->stream));
 #ifdef JFGPU_PHASE_PROF
-  { unsigned long long c[16], z[16] = {0};
+  { unsigned long long c[24], z[24] = {0};
     if(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_phase_prof), sizeof c) == hipSuccess) {
       fprintf(stderr, "[phase prof] P1: stage %llu  encode+hash+hist %llu  scan %llu  place+lds-scatter %llu  (barrier) %llu  write-out %llu  finish %llu\n",
               c[0], c[1], c[2], c[3], c[4], c[5], c[6]);
       fprintf(stderr, "[phase prof] P2: (barrier) %llu  load %llu  hist %llu  scan %llu  lds-scatter %llu  write-out %llu  finish %llu\n",
               c[8], c[9], c[10], c[11], c[12], c[13], c[14]);
+      fprintf(stderr, "[phase prof] T: loop+offsets %llu  rank adds + fill %llu  place %llu  queue %llu  merge + store %llu\n",
+              c[16], c[17], c[18], c[19], c[20]);
       (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_prof), z, sizeof z);
     } }
 #endif

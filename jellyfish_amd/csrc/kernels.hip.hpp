@@ -37,9 +37,9 @@ enum Counter : int { CTR_FULL = 0, CTR_MERS = 1, CTR_OVF_FULL = 2, CTR_OVF_USED 
                      CTR_PROF0 = 8 /* .. 11: phase clocks of a -DJFGPU_TILE_PROF build */, CTR_COUNT = 12 };
 
 // -DJFGPU_PHASE_PROF builds: shader clocks per phase of the partition kernels, as wave 0 of every block sees them,
-// summed over blocks into a device array the host prints at jfgpu_sync (tools/ablate.py).  Slots 0-7 P1, 8-15 P2.
+// summed over blocks into a device array the host prints at jfgpu_sync (tools/ablate.py).  Slots 0-7 P1, 8-15 P2, 16-23 T.
 #ifdef JFGPU_PHASE_PROF
-__device__ unsigned long long g_phase_prof[16];
+__device__ unsigned long long g_phase_prof[24];
 struct PhaseClk {
   long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long t;
   __device__ PhaseClk() { t = clock64(); }
@@ -177,7 +177,7 @@ __device__ inline bool table_add(const DevTable& T, const uint64_t* fwd_lds, uin
   const uint64_t neww = add | low;
   const uint32_t tmask = (uint32_t)g.tile_mask;
   for(uint32_t p = 0; p <= T.max_probe; ++p) {
-    const uint64_t slot = a.tile_base + probe_slot(a.idx0, p, tmask);
+    const uint64_t slot = a.tile_base + probe_lin(a.idx0, p, tmask);
     const uint64_t old = slot_cas(T, slot, 0, neww);
     if(old == 0ull) return true;
     if((old & g.low_mask) == low) {
@@ -207,7 +207,7 @@ __device__ inline bool table_update_add(const DevTable& T, const uint64_t* fwd_l
   const uint64_t add = cnt << (g.tag_bits + 1);
   const uint32_t tmask = (uint32_t)g.tile_mask;
   for(uint32_t p = 0; p <= T.max_probe; ++p) {
-    const uint64_t slot = a.tile_base + probe_slot(a.idx0, p, tmask);
+    const uint64_t slot = a.tile_base + probe_lin(a.idx0, p, tmask);
     const uint64_t old = slot_ld_relaxed(T, slot);
     if(old == 0ull) return false;
     if((old & g.low_mask) == low) {
@@ -241,7 +241,7 @@ __device__ inline bool table_add_val(const DevTable& T, const uint64_t* fwd_lds,
   const uint64_t add = lowpart << (g.tag_bits + 1);
   const uint32_t tmask = (uint32_t)g.tile_mask;
   for(uint32_t p = 0; p <= T.max_probe; ++p) {
-    const uint64_t slot = a.tile_base + probe_slot(a.idx0, p, tmask);
+    const uint64_t slot = a.tile_base + probe_lin(a.idx0, p, tmask);
     const uint64_t old = slot_cas(T, slot, 0, add | low);
     bool mine = false, is_new = false;
     if(old == 0ull) { mine = true; is_new = true; }
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(kBlock) void lookup_kernel(DevTable T, const uint64
     if(a.shard == g.shard_id) {
       const uint64_t low = g.occ_bit | make_tag(g, key, a.idx0);
       for(uint32_t p = 0; p <= T.max_probe; ++p) {
-        const uint64_t slot = a.tile_base + probe_slot(a.idx0, p, tmask);
+        const uint64_t slot = a.tile_base + probe_lin(a.idx0, p, tmask);
         const uint64_t w = slot_ld(T, slot);
         if(w == 0) break;
         if((w & g.low_mask) == low) { val = full_count(T, w, slot, have_ovf); fnd = 1; break; }

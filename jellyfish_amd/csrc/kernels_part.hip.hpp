@@ -527,164 +527,6 @@ __global__ __launch_bounds__(kPBlock) void p2_scatter_sorted_kernel(PartGeom P, 
   JF_PHASE_FLUSH(pc, 8);
 }
 
-// ---- T: one workgroup owns one tile in LDS --------------------------------------------------
-// Tile index = tile0 + t; its items are, for each segment s, items[s][off[s][t] .. off[s][t+1]).
-// LOAD == false: the whole table is known to be all-zero (fresh / cleared): never read tiles.
-// LOAD == true : read a tile only if its dirty byte says something was ever inserted into it.
-// Same claim-or-increment protocol as table_add, on LDS words (ds_cmpst_rtn_b64 / ds_add_u64).
-// SLOT: unsigned long long (64-bit slots) or unsigned int (32-bit slots, TableGeom::slot32): the LDS word of one slot.
-template <typename ITEM, bool RETURNING, typename SLOT>
-__device__ inline void tile_insert_one(const DevTable& T, SLOT* s_tile, uint64_t item, uint64_t tile_index) {
-  const TableGeom& g = T.g;
-  const uint32_t tmask = (1u << g.tile_bits) - 1;
-  const uint64_t tag = item & (g.occ_bit - 1);
-  const uint32_t idx0 = (uint32_t)(tag >> g.rem_bits);
-  const SLOT low = (SLOT)(g.occ_bit | tag), lmask = (SLOT)g.low_mask, inc = (SLOT)g.inc;
-  const SLOT neww = inc | low;
-  for(uint32_t p = 0; p <= T.max_probe; ++p) {
-    const uint32_t slot = probe_slot(idx0, p, tmask);
-    const SLOT old = atomicCAS(&s_tile[slot], (SLOT)0, neww);
-    if(old == 0) return;
-    if((old & lmask) == low) {
-      if(RETURNING) {
-        const SLOT prev = atomicAdd(&s_tile[slot], inc);
-        if(((uint64_t)prev >> (g.tag_bits + 1)) + 1 > g.cnt_max) ovf_add(T, (tile_index << g.tile_bits) + slot, 1);
-      } else {
-        atomicAdd(&s_tile[slot], inc);
-      }
-      return;
-    }
-  }
-  atomicAdd((unsigned long long*)&T.counters[CTR_FULL], 1ull);
-}
-
-// SLOT: the LDS word of one slot (see tile_insert_one); BLOCK: threads per workgroup.  64-bit slots: 64 KiB tiles, two
-// workgroups of 1024 per CU.  32-bit slots: 32 KiB tiles, four workgroups of 512 per CU -- the insert phase is a chain
-// of dependent LDS atomics per lane, and more tiles in flight per CU is what hides it behind the tile loads and stores.
-// TPB = 2 (32-bit slots): the workgroup owns two adjacent tiles (one contiguous 64 KiB range of the table) and the
-// offsets index such pairs; an item's tile inside the pair is the lowest bit of its tile field.  P2 then has half as many
-// destinations, so the runs it writes are twice as long (what P2 costs is set by the length of those runs:
-// tools/probes/scatter_write_probe.hip).
-template <typename ITEM, bool RETURNING, bool LOAD, typename SLOT, int BLOCK, int TPB = 1>
-__global__ __launch_bounds__(BLOCK, 2048 / 256) void tile_insert_kernel(DevTable T, SegList S, uint64_t tile0, uint32_t n_tiles) {
-  JF_DYN_LDS(s_raw);
-  SLOT* s_tile = reinterpret_cast<SLOT*>(s_raw);
-  const TableGeom& g = T.g;
-  const uint32_t tsz = 1u << g.tile_bits;                               // slots of one tile
-  constexpr uint32_t kVec = 16 / sizeof(SLOT);                          // slots per 16-byte vector
-  SLOT* const gslots = reinterpret_cast<SLOT*>(T.slots);
-  // n_tiles counts units of TPB tiles; unit t = tiles tile0 + TPB * t ..  (tile0 is a multiple of TPB)
-  auto unit_dirty = [&](uint32_t t) -> uint32_t {
-    if(!LOAD) return 0u;
-    if(TPB == 2) return *reinterpret_cast<const uint16_t*>(T.dirty + tile0 + 2 * (uint64_t)t);
-    return T.dirty[tile0 + t];
-  };
-  auto fill = [&](SLOT* gt, uint32_t d) {
-    for(uint32_t i = threadIdx.x * kVec; i < TPB * tsz; i += BLOCK * kVec) {   // tile(s) -> LDS, 16 B per lane per step
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if(LOAD && ((d >> (8 * (i >> g.tile_bits))) & 0xFFu)) v = *reinterpret_cast<const uint4*>(gt + i);
-      *reinterpret_cast<uint4*>(s_tile + i) = v;
-    }
-  };
-  auto store = [&](SLOT* gt, uint32_t t) {
-    for(uint32_t i = threadIdx.x * kVec; i < TPB * tsz; i += BLOCK * kVec)
-      *reinterpret_cast<uint4*>(gt + i) = *reinterpret_cast<const uint4*>(s_tile + i);
-    if(threadIdx.x == 0) {
-      if(TPB == 2) *reinterpret_cast<uint16_t*>(T.dirty + tile0 + 2 * (uint64_t)t) = 0x0101;
-      else T.dirty[tile0 + t] = 1;
-    }
-  };
-  auto insert = [&](ITEM x, uint32_t t) {
-    const uint32_t half = TPB == 2 ? (uint32_t)((uint64_t)x >> g.tag_bits) & 1u : 0u;
-    tile_insert_one<ITEM, RETURNING>(T, s_tile + half * tsz, (uint64_t)x, tile0 + (uint64_t)TPB * t + half);
-  };
-  if(S.n == 1) {
-    // Fast path (one packed item array, e.g. the P2 output).  Software pipeline over this block's
-    // tiles: offsets are fetched two tiles ahead and the items one tile ahead into registers, so the
-    // dependent global loads (offset -> items) never sit on the critical path of a tile.
-    constexpr int NP = TPB == 2 ? 9 : 6144 / BLOCK;         // register-prefetched items per lane (6144 per tile; 9216 per pair: 64 VGPRs)
-    const uint64_t* off = S.off[0];
-    const uint32_t sh = S.sh[0];                            // 0: packed offsets off[t], off[t + 1]; 1: pairs (begin, end), items may be holes
-    const bool holes = sh != 0;
-    const ITEM* src = reinterpret_cast<const ITEM*>(S.items[0]);
-    const uint32_t G = gridDim.x;
-    uint32_t t = blockIdx.x;
-    uint64_t a0 = 0, b0 = 0, a1 = 0, b1 = 0; uint32_t d0 = 0, d1 = 0;
-    ITEM cur[NP];
-    if(t < n_tiles) { a0 = off[(size_t)t << sh]; b0 = off[((size_t)t << sh) + 1]; d0 = unit_dirty(t); }
-    if(t + G < n_tiles) { a1 = off[(size_t)(t + G) << sh]; b1 = off[((size_t)(t + G) << sh) + 1]; d1 = unit_dirty(t + G); }
-#pragma unroll
-    for(int r = 0; r < NP; ++r) { const uint64_t v = a0 + (uint64_t)r * BLOCK + threadIdx.x; cur[r] = v < b0 ? src[v] : (ITEM)0; }
-#ifdef JFGPU_TILE_PROF
-    long long pc0 = 0, pc1 = 0, pc2 = 0, pc3 = 0, pt = clock64();
-#define TP(acc) do { const long long n_ = clock64(); acc += n_ - pt; pt = n_; } while(0)
-#else
-#define TP(acc) do {} while(0)
-#endif
-    for(; t < n_tiles; t += G) {
-      // issue the loads of the following tiles first
-      uint64_t a2 = 0, b2 = 0; uint32_t d2 = 0;
-      if(t + 2 * G < n_tiles) { a2 = off[(size_t)(t + 2 * G) << sh]; b2 = off[((size_t)(t + 2 * G) << sh) + 1]; d2 = unit_dirty(t + 2 * G); }
-      ITEM nxt[NP];
-#pragma unroll
-      for(int r = 0; r < NP; ++r) { const uint64_t v = a1 + (uint64_t)r * BLOCK + threadIdx.x; nxt[r] = v < b1 ? src[v] : (ITEM)0; }
-      TP(pc0);
-      if(b0 > a0) {                                          // block-uniform
-        SLOT* gt = gslots + ((tile0 + (uint64_t)TPB * t) << g.tile_bits);
-        fill(gt, d0);
-        lds_barrier();
-        TP(pc1);
-#pragma unroll
-        for(int r = 0; r < NP; ++r)
-          if(a0 + (uint64_t)r * BLOCK + threadIdx.x < b0 && !(holes && cur[r] == (ITEM)~(ITEM)0)) insert(cur[r], t);
-        for(uint64_t v = a0 + (uint64_t)NP * BLOCK + threadIdx.x; v < b0; v += BLOCK) {   // rare: an over-full tile
-          const ITEM x = src[v];
-          if(!(holes && x == (ITEM)~(ITEM)0)) insert(x, t);
-        }
-        lds_barrier();
-        TP(pc2);
-        store(gt, t);
-        lds_barrier();
-        TP(pc3);
-      }
-      a0 = a1; b0 = b1; d0 = d1; a1 = a2; b1 = b2; d1 = d2;
-#pragma unroll
-      for(int r = 0; r < NP; ++r) cur[r] = nxt[r];
-    }
-#ifdef JFGPU_TILE_PROF
-    if(threadIdx.x == 0) {      // wave 0's view: prefetch issue + waits / fill / insert / store, in shader clocks
-      atomicAdd((unsigned long long*)&T.counters[CTR_PROF0 + 0], (unsigned long long)pc0);
-      atomicAdd((unsigned long long*)&T.counters[CTR_PROF0 + 1], (unsigned long long)pc1);
-      atomicAdd((unsigned long long*)&T.counters[CTR_PROF0 + 2], (unsigned long long)pc2);
-      atomicAdd((unsigned long long*)&T.counters[CTR_PROF0 + 3], (unsigned long long)pc3);
-    }
-#endif
-#undef TP
-    return;
-  }
-  for(uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-    // general path (several pending batches, single-level tables): every lane reads the offsets itself
-    uint64_t n_items = 0;
-    for(uint32_t s = 0; s < S.n; ++s) n_items += seg_hi(S, s, t) - seg_lo(S, s, t);
-    if(n_items == 0) continue;                                   // block-uniform
-    SLOT* gt = gslots + ((tile0 + (uint64_t)TPB * t) << g.tile_bits);
-    fill(gt, unit_dirty(t));
-    lds_barrier();
-    for(uint32_t s = 0; s < S.n; ++s) {
-      const uint64_t a = seg_lo(S, s, t), b = seg_hi(S, s, t);
-      const ITEM* src = reinterpret_cast<const ITEM*>(S.items[s]);
-      const bool holes = S.sh[s] != 0;
-      for(uint64_t v = a + threadIdx.x; v < b; v += BLOCK) {
-        const ITEM x = src[v];
-        if(!(holes && x == (ITEM)~(ITEM)0)) insert(x, t);
-      }
-    }
-    lds_barrier();
-    store(gt, t);
-    lds_barrier();
-  }
-}
-
 // One item of P1 bucket `bucket` straight into the table with global atomics (same protocol as
 // table_add; tag and tile are already in the item).
 template <bool RETURNING>
@@ -698,7 +540,7 @@ __device__ inline void item_direct_insert(const DevTable& T, const PartGeom& P, 
   { uint8_t* d = &T.dirty[tile]; if(!*d) *d = 1; }
   const uint64_t low = g.occ_bit | tag, neww = g.inc | low;
   for(uint32_t p = 0; p <= T.max_probe; ++p) {
-    const uint64_t slot = tile_base + probe_slot(idx0, p, tmask);
+    const uint64_t slot = tile_base + probe_lin(idx0, p, tmask);
     const uint64_t old = slot_cas(T, slot, 0, neww);
     if(old == 0ull) return;
     if((old & g.low_mask) == low) {

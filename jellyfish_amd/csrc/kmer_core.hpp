@@ -212,6 +212,15 @@ JF_HD uint32_t probe_slot(uint32_t idx0, uint32_t p, uint32_t tile_mask) {
   return (idx0 + ((p * (p + 1)) >> 1)) & tile_mask;
 }
 
+// One-word keys (round 3): slots are grouped in buckets of four that fill front to back, and probing is linear from the
+// start of the home bucket (wrapping inside the tile).  That is what lets the LDS tile kernel place a flush's items by
+// rank instead of by compare-and-swap (kernels_tile.hip.hpp); the global-atomic path, look-ups and growth follow the same
+// sequence with one claim per probe as before.  Keys of two and more words keep the triangular sequence above.
+constexpr uint32_t kBucketBits = 2;
+JF_HD uint32_t probe_lin(uint32_t idx0, uint32_t p, uint32_t tile_mask) {
+  return ((idx0 & ~((1u << kBucketBits) - 1u)) + p) & tile_mask;
+}
+
 // One aligned 16-byte vector of sequence (global_load_dwordx4 on the device).
 JF_HD void load16(const uint8_t* p, uint32_t w[4]) {
 #if defined(__HIP_DEVICE_COMPILE__)
