@@ -317,7 +317,15 @@ int part_flush_t(jfgpu_table* t) {
       }
     }
   } else if(t->pg.b2 == 0) {
-    launch_tiles(S1, 0, nb1, total);
+    // single-level table (at most 2^11 tiles): the P1 buckets are the tiles; one pass over them per pending batch
+    if constexpr(kWideItems) launch_tiles(S1, 0, nb1, total);
+    else for(size_t s = 0; s < nbatch; ++s) {
+      const uint64_t n = offs[s * (nb1 + 1) + nb1];
+      if(!n) continue;
+      SegList Sb; memset(&Sb, 0, sizeof Sb);
+      Sb.n = 1; Sb.items[0] = S1.items[s]; Sb.off[0] = S1.off[s]; Sb.sh[0] = S1.sh[s];
+      launch_tiles(Sb, 0, nb1, n);
+    }
   } else {
     // breadth-first: every P1 bucket through P2 in one launch per pass, then every tile in one launch
     const int g2 = 32;

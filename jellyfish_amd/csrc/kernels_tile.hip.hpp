@@ -20,9 +20,8 @@
 //      empty slot, next bucket otherwise.
 //   M  on the way out (LDS -> table), one lane per bucket: equal tags among the bucket's (at most four) entries are
 //      merged into the first of them and the bucket is compacted -- the k-mers that occur several times in this flush or
-//      were already in the table.  A bucket that looks full but holds equal tags will have a free slot after M, so a
-//      queued item that meets one may not walk past it: it is deferred, and only then (rare: block-uniform flag) the
-//      merge is done in LDS first and the deferred items placed after it.
+//      were already in the table.  (A bucket that looks full in phase C but holds equal tags will have a free slot after
+//      M; an item that would walk past it folds the copies itself first, see slow_insert.)
 //
 // Same table format and count semantics as the global-atomic path (kernels.hip.hpp::table_add): (tile, tag) identifies
 // the key wherever in the tile it lands; large_hash_array.hpp:509-597,741-752 (claim_key / add_val) restated.
@@ -61,18 +60,22 @@ inline size_t tile_rank_lds(size_t slot_bytes, uint32_t tile_bits, int tpb) {
 
 template <typename ITEM, bool RETURNING, typename SLOT, int TPB, int BLOCK = kTileBlock>
 __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kernel(DevTable T, SegList S, uint64_t tile0, uint32_t n_tiles) {
+  // S holds ONE item array (the P2 output, or one pending batch of a single-level table: the host launches per batch)
   constexpr int NP = 9216 / BLOCK;                          // register-held items per lane and round (9216 per round)
   constexpr uint32_t kVec = 16 / sizeof(SLOT);              // slots per 16-byte vector
   constexpr uint32_t kBV = 4 / kVec;                        // vectors per bucket
   constexpr uint32_t kSlotBits = 8 * sizeof(SLOT);
   JF_DYN_LDS(s_raw);
   const TableGeom& g = T.g;
-  const uint32_t tsz = 1u << g.tile_bits, nslots = TPB * tsz, nbkt = nslots >> kBucketBits, tmask = tsz - 1;
+  // (the partitioned path only exists for full-size tiles: part_geom_init)
+  constexpr uint32_t tsz = 1u << kMaxTileBits, nslots = TPB * tsz, nbkt = nslots >> kBucketBits, tmask = tsz - 1;
+  constexpr uint32_t NBK = nbkt / BLOCK;                    // buckets per lane
   SLOT* const s_tile = reinterpret_cast<SLOT*>(s_raw);
   uint32_t* const s_cnt = reinterpret_cast<uint32_t*>(s_raw + (size_t)nslots * sizeof(SLOT));      // two 16-bit counters per word
-  uint32_t* const s_qn = s_cnt + (nbkt >> 1);                 // [0] queued items  [1] lanes holding items back  [2] deferred items exist
-  ITEM* const s_q = reinterpret_cast<ITEM*>(s_qn + 4);
-  constexpr uint32_t qcap = kTileQueueBytes / sizeof(ITEM);
+  uint32_t* const s_qn = s_cnt + (nbkt >> 1);                 // (16 bytes of padding)
+  // phase C's queue: one segment per wave (positions come from a ballot: no atomic, no count to read back)
+  constexpr uint32_t qcap = kTileQueueBytes / sizeof(ITEM) / (BLOCK / 64);
+  ITEM* const s_q = reinterpret_cast<ITEM*>(s_qn + 4) + (threadIdx.x >> 6) * qcap;
   SLOT* const gslots = reinterpret_cast<SLOT*>(T.slots);
   const SLOT lmask = (SLOT)g.low_mask, inc = (SLOT)g.inc, occ = (SLOT)g.occ_bit;
   const uint32_t cshift = g.tag_bits + 1, idshift = kSlotBits - cshift;
@@ -86,7 +89,6 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
   };
   auto zero_counters = [&]() {
     for(uint32_t i = threadIdx.x; i < (nbkt >> 1); i += BLOCK) s_cnt[i] = 0;
-    if(threadIdx.x < 3) s_qn[threadIdx.x] = 0;
   };
   auto zero_tile = [&]() {
     for(uint32_t i = threadIdx.x * kVec; i < nslots; i += BLOCK * kVec) *reinterpret_cast<uint4*>(s_tile + i) = make_uint4(0, 0, 0, 0);
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
   // counters start at the number of entries already there (front to back, so that is also the first free slot)
   auto load_tile = [&](const SLOT* gt, uint32_t d) {
     for(uint32_t b = threadIdx.x; b < nbkt; b += BLOCK) {
-      const bool ld = (d >> (8 * ((b << kBucketBits) >> g.tile_bits))) & 0xFFu;
+      const bool ld = (d >> (8 * ((b << kBucketBits) >> kMaxTileBits))) & 0xFFu;
       uint32_t c = 0;
 #pragma unroll
       for(uint32_t q = 0; q < kBV; ++q) {
@@ -121,53 +123,71 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
       else { w[2 * q] = (SLOT)(((uint64_t)v.y << 32) | v.x); w[2 * q + 1] = (SLOT)(((uint64_t)v.w << 32) | v.z); }
     }
   };
-  // do two of a bucket's entries carry the same tag?  identity = occupied bit + tag (count shifted out); empty slots get
-  // distinct small values
+  // do two of a bucket's entries carry the same tag?  identity = occupied bit + tag (count shifted out).  Six compares
+  // whose results meet in scalar registers; an empty slot equals nothing.
   auto has_dups = [&](const SLOT (&w)[4]) -> bool {
-    const SLOT s0 = w[0] << idshift, s1 = w[1] ? (SLOT)(w[1] << idshift) : (SLOT)1, s2 = w[2] ? (SLOT)(w[2] << idshift) : (SLOT)2,
-               s3 = w[3] ? (SLOT)(w[3] << idshift) : (SLOT)3;
-    const SLOT m01 = s0 ^ s1, m02 = s0 ^ s2, m03 = s0 ^ s3, m12 = s1 ^ s2, m13 = s1 ^ s3, m23 = s2 ^ s3;
-    SLOT mn = m01 < m02 ? m01 : m02; mn = mn < m03 ? mn : m03; mn = mn < m12 ? mn : m12; mn = mn < m13 ? mn : m13; mn = mn < m23 ? mn : m23;
-    return mn == 0 && w[0] != 0;
+    const SLOT s0 = w[0] << idshift, s1 = w[1] << idshift, s2 = w[2] << idshift, s3 = w[3] << idshift;
+    return ((s0 == s1) & (w[1] != 0)) | (((s0 == s2) | (s1 == s2)) & (w[2] != 0)) | (((s0 == s3) | (s1 == s3) | (s2 == s3)) & (w[3] != 0));
   };
-  // M: equal tags of one bucket into the first of them, compacted to the front (static indices only: registers)
+  // M: equal tags of one bucket into the first of them, compacted to the front.  Straight-line code (selects, no
+  // branches: a wave runs this whenever one of its 64 buckets needs it) on static indices (registers).
   auto merge_bucket = [&](SLOT (&w)[4], uint64_t bucket_slot0) {
-    uint32_t carry[4] = {0, 0, 0, 0};                       // count-field wrap-arounds, in units of 2^cnt_bits
+    const SLOT cmask = (SLOT)g.cnt_max;
+    SLOT carry[4] = {0, 0, 0, 0};                            // count-field wrap-arounds, in units of 2^cnt_bits
 #pragma unroll
     for(int j = 1; j < 4; ++j)
 #pragma unroll
-      for(int i = 0; i < j; ++i)
-        if(w[j] != 0 && w[i] != 0 && ((w[i] ^ w[j]) & lmask) == 0) {
-          const uint64_t sum = ((uint64_t)w[i] >> cshift) + ((uint64_t)w[j] >> cshift);
-          w[i] = (w[i] & lmask) | (SLOT)((sum & g.cnt_max) << cshift);
-          carry[i] += (uint32_t)(sum >> g.cnt_bits);
-          w[j] = 0;
-        }
-    SLOT o[4] = {0, 0, 0, 0}; uint32_t oc[4] = {0, 0, 0, 0}; uint32_t n = 0;
-#pragma unroll
-    for(int j = 0; j < 4; ++j) {
-#pragma unroll
-      for(int q = 0; q <= j; ++q) if(w[j] != 0 && n == (uint32_t)q) { o[q] = w[j]; oc[q] = carry[j]; }
-      n += w[j] != 0;
+      for(int i = 0; i < j; ++i) {
+        const bool same = (w[j] != 0) & (w[i] != 0) & (((w[i] ^ w[j]) & lmask) == 0);
+        const SLOT sum = (SLOT)(w[i] >> cshift) + (same ? (SLOT)(w[j] >> cshift) : (SLOT)0);      // (no carry out of the word: both counts < 2^cnt_bits <= 2^(bits - 2))
+        w[i] = (w[i] & lmask) | (SLOT)((sum & cmask) << cshift);
+        carry[i] += (SLOT)(sum >> g.cnt_bits);
+        w[j] = same ? (SLOT)0 : w[j];
+      }
+    // stable compaction: entry j moves to the number of non-empty entries before it
+    const uint32_t n0 = w[0] != 0, n1 = n0 + (w[1] != 0), n2 = n1 + (w[2] != 0);
+    SLOT o[4], oc[4];
+    o[0] = n0 ? w[0] : (n1 ? w[1] : (n2 ? w[2] : w[3]));                       oc[0] = n0 ? carry[0] : (n1 ? carry[1] : (n2 ? carry[2] : carry[3]));
+    {  // position 1: the second non-empty entry
+      const bool t1 = (w[1] != 0) & (n0 == 1), t2 = (w[2] != 0) & (n1 == 1), t3 = (w[3] != 0) & (n2 == 1);
+      o[1] = t1 ? w[1] : (t2 ? w[2] : (t3 ? w[3] : (SLOT)0));                  oc[1] = t1 ? carry[1] : (t2 ? carry[2] : (t3 ? carry[3] : (SLOT)0));
     }
+    {  // position 2: the third
+      const bool t2 = (w[2] != 0) & (n1 == 2), t3 = (w[3] != 0) & (n2 == 2);
+      o[2] = t2 ? w[2] : (t3 ? w[3] : (SLOT)0);                                oc[2] = t2 ? carry[2] : (t3 ? carry[3] : (SLOT)0);
+    }
+    { const bool t3 = (w[3] != 0) & (n2 == 3); o[3] = t3 ? w[3] : (SLOT)0;    oc[3] = t3 ? carry[3] : (SLOT)0; }
+    if(n2 + (w[3] != 0) == 0) { o[0] = 0; oc[0] = 0; }                         // (nothing at all: position 0 picked up w[3] = 0 anyway)
 #pragma unroll
-    for(int q = 0; q < 4; ++q) {
-      w[q] = o[q];
-      if(RETURNING && oc[q]) ovf_add_call(T.ovf_key, T.ovf_cnt, T.ovf_mask, T.counters, bucket_slot0 + q, oc[q]);
+    for(int q = 0; q < 4; ++q) w[q] = o[q];
+    if(RETURNING && (oc[0] | oc[1] | oc[2] | oc[3]) != 0) {                    // rare: some count left its field
+#pragma unroll
+      for(int q = 0; q < 4; ++q) if(oc[q]) ovf_add_call(T.ovf_key, T.ovf_cnt, T.ovf_mask, T.counters, bucket_slot0 + q, (uint64_t)oc[q]);
     }
   };
-  // LDS -> table, merging on the way (M); the counters are cleared for the next unit
+  // LDS -> table, merging on the way (M); tile and counters are cleared behind it for the next unit
   auto store_tile = [&](SLOT* gt, uint32_t t, uint64_t unit_slot0) {
-    for(uint32_t b = threadIdx.x; b < nbkt; b += BLOCK) {
-      SLOT w[4];
-      load_bucket(b << kBucketBits, w);
-      if(has_dups(w)) merge_bucket(w, unit_slot0 + ((uint64_t)b << kBucketBits));
+    SLOT wb[NBK][4];
+#pragma unroll
+    for(uint32_t k = 0; k < NBK; ++k) load_bucket((threadIdx.x + k * BLOCK) << kBucketBits, wb[k]);      // one LDS round trip for all of them
+#pragma unroll
+    for(uint32_t k = 0; k < NBK; ++k) {
+      const uint32_t b = threadIdx.x + k * BLOCK;
+      SLOT (&w)[4] = wb[k];
+      // (equal tags, or a hole phase C left when it folded a copy away: compact)
+#ifndef JFGPU_T_NOM
+      if(has_dups(w) || ((w[1] == 0) & ((w[2] | w[3]) != 0)) || ((w[2] == 0) & (w[3] != 0)))
+#else
+      if(false)
+#endif
+        merge_bucket(w, unit_slot0 + ((uint64_t)b << kBucketBits));
 #pragma unroll
       for(uint32_t q = 0; q < kBV; ++q) {
         uint4 v;
         if(sizeof(SLOT) == 4) v = make_uint4((uint32_t)w[0], (uint32_t)w[1], (uint32_t)w[2], (uint32_t)w[3]);
         else v = make_uint4((uint32_t)w[2 * q], (uint32_t)((uint64_t)w[2 * q] >> 32), (uint32_t)w[2 * q + 1], (uint32_t)((uint64_t)w[2 * q + 1] >> 32));
         *reinterpret_cast<uint4*>(gt + ((size_t)b << kBucketBits) + q * kVec) = v;
+        *reinterpret_cast<uint4*>(s_tile + ((size_t)b << kBucketBits) + q * kVec) = make_uint4(0, 0, 0, 0);      // the next unit starts from an empty tile
       }
     }
     zero_counters();
@@ -176,23 +196,12 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
       else T.dirty[tile0 + t] = 1;
     }
   };
-  // the rare path's merge: in LDS, so that the deferred items see every bucket as it will be
-  auto merge_in_lds = [&](uint64_t unit_slot0) {
-    for(uint32_t b = threadIdx.x; b < nbkt; b += BLOCK) {
-      SLOT w[4];
-      load_bucket(b << kBucketBits, w);
-      if(has_dups(w)) {
-        merge_bucket(w, unit_slot0 + ((uint64_t)b << kBucketBits));
-#pragma unroll
-        for(int q = 0; q < 4; ++q) s_tile[((size_t)b << kBucketBits) + q] = w[q];
-      }
-    }
-  };
-
   // C for one item: find the key or a free slot, bucket by bucket from its home bucket.  The bucket after the one being
-  // looked at is already on its way (an LDS round trip is long while the other workgroup of the CU is in phase A).
-  // merged == false: buckets may still hold equal tags; a full-looking one that does ends the walk -> false (deferred).
-  auto slow_insert = [&](ITEM x, uint64_t unit_slot0, bool merged) -> bool {
+  // looked at is already on its way.  Buckets may still hold equal tags (M comes last); one that looks full but does
+  // will have room once they are merged, and walking past it would strand the key behind a free slot: its later copies
+  // are folded into the first one right here.  That is safe beside the other lanes of this phase: an add always goes to
+  // the FIRST slot carrying the tag, so nobody touches a later copy except to take it out (a compare-and-swap on the exact word decides who).
+  auto slow_insert = [&](ITEM x, uint64_t unit_slot0) {
     const SLOT low = occ | (SLOT)((uint64_t)x & (g.occ_bit - 1)), neww = inc | low;
     const uint32_t h = home_of(x), hbase = h & ~tmask, hb = h & tmask & ~3u;
     SLOT w[4], wn[4];
@@ -208,23 +217,40 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
           const SLOT prev = atomicAdd(&s_tile[bs + hit], inc);
           if(((uint64_t)prev >> cshift) + 1 > g.cnt_max) ovf_add_call(T.ovf_key, T.ovf_cnt, T.ovf_mask, T.counters, unit_slot0 + bs + hit, 1);
         } else atomicAdd(&s_tile[bs + hit], inc);
-        return true;
+        return;
       }
       if(emp >= 0) {
-        if(atomicCAS(&s_tile[bs + emp], (SLOT)0, neww) == 0) return true;
+        if(atomicCAS(&s_tile[bs + emp], (SLOT)0, neww) == 0) return;
         load_bucket(bs, w);                                   // somebody else took it: look at this bucket again
         continue;
       }
-#ifndef JFGPU_T_NODEFER
-      if(!merged && has_dups(w)) return false;
-#endif
+      if(has_dups(w)) {                                       // full, but not for long: make the room now
+#pragma unroll
+        for(int j = 3; j >= 1; --j) {
+          int first = -1;
+#pragma unroll
+          for(int i = j - 1; i >= 0; --i) if(((w[i] ^ w[j]) & lmask) == 0) first = i;
+          if(first >= 0) {
+            // (w[] may be an old look: take the copy out only if it is still exactly what was seen -- a later copy
+            //  never changes, but it may be gone and its slot claimed by another key since)
+            const SLOT v = w[j];
+            if(atomicCAS(&s_tile[bs + j], v, (SLOT)0) == v) {
+              const SLOT add = (SLOT)(((uint64_t)v >> cshift) << cshift);
+              const SLOT prev = atomicAdd(&s_tile[bs + first], add);
+              if(RETURNING && ((uint64_t)prev >> cshift) + ((uint64_t)v >> cshift) > g.cnt_max)
+                ovf_add_call(T.ovf_key, T.ovf_cnt, T.ovf_mask, T.counters, unit_slot0 + bs + first, 1);
+            }
+          }
+        }
+        load_bucket(bs, w);
+        continue;
+      }
       ++step;
 #pragma unroll
       for(int i = 0; i < 4; ++i) w[i] = wn[i];
       load_bucket(hbase + ((hb + ((step + 1) << kBucketBits)) & tmask), wn);
     }
     atomicAdd((unsigned long long*)&T.counters[CTR_FULL], 1ull);
-    return true;
   };
 
   [[maybe_unused]] PhaseClk pc;
@@ -237,7 +263,7 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
   // A, second half, then C.  `again`: where the round's items came from (held-back items are read again from there:
   // indexing the register array would put it in scratch).  after_a(): it[] is dead from there on.
   auto place_round = [&](ITEM (&it)[NP], uint32_t vm, const uint32_t (&old)[NP], uint64_t unit_slot0, const ITEM* again, auto&& after_a) {
-    uint32_t over = 0, n_over = 0;                            // over: this lane's items that did not fit; n_over: the wave's count
+    uint32_t qn = 0, pend = 0;                                 // qn: items this wave queued (wave-uniform)
 #pragma unroll
     for(int r = 0; r < NP; ++r) JF_OPAQUE(it[r]);
 #pragma unroll
@@ -249,181 +275,105 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
         if(rank < 4) s_tile[(b << kBucketBits) + rank] = inc | occ | (SLOT)((uint64_t)it[r] & (g.occ_bit - 1));
         else ov = true;
       }
-      over |= (uint32_t)ov << r;
-      n_over += (uint32_t)__popcll(__ballot(ov));
-    }
-    uint32_t pend = 0;
-    if(n_over) {                                              // wave-uniform: one queue reservation per wave
-      uint32_t qb = 0;
-      if(lane == 0) qb = atomicAdd(&s_qn[0], n_over);
-      qb = __shfl(qb, 0, 64);
-#pragma unroll
-      for(int r = 0; r < NP; ++r) {
-        const bool ov = (over >> r) & 1;
-        const unsigned long long m = __ballot(ov);
-        if(ov) {
-          const uint32_t at = qb + (uint32_t)__popcll(m & below);
-          if(at < qcap) s_q[at] = it[r]; else pend |= 1u << r;
-        }
-        qb += (uint32_t)__popcll(m);
+      const unsigned long long m = __ballot(ov);
+      if(ov) {
+        const uint32_t at = qn + (uint32_t)__popcll(m & below);
+        if(at < qcap) s_q[at] = it[r]; else pend |= 1u << r;
       }
-      if(pend) atomicOr(&s_qn[1], 1u);
+      qn += (uint32_t)__popcll(m);
     }
     after_a();
     lds_barrier();
     JF_PHASE(pc, 2);
-    // ---- C: the queue, then what lanes held back
-    const uint32_t nq = s_qn[0] < qcap ? s_qn[0] : qcap;
-    const bool held = s_qn[1] != 0;
-    if(nq || held) {                                           // block-uniform
-      bool deferred = false;
-      uint32_t qleft = 0;                                     // which of this lane's queue entries were deferred
-      for(uint32_t i = threadIdx.x, k = 0; i < nq; i += BLOCK, ++k)
-        if(!slow_insert(s_q[i], unit_slot0, false)) { qleft |= 1u << k; deferred = true; }
-      if(held) {
-        uint32_t left = pend;
-        while(left) {
-          const uint32_t r = (uint32_t)__ffs((int)left) - 1u;
-          if(slow_insert(again[r * BLOCK + threadIdx.x], unit_slot0, false)) pend &= ~(1u << r); else deferred = true;
-          left &= left - 1;
-        }
-      }
-      if(deferred) atomicOr(&s_qn[2], 1u);
-      lds_barrier();
-      if(s_qn[2]) {                                            // rare (block-uniform): merge in LDS, then the deferred items
-        merge_in_lds(unit_slot0);
-        lds_barrier();
-        for(uint32_t i = threadIdx.x, k = 0; i < nq; i += BLOCK, ++k) if((qleft >> k) & 1) slow_insert(s_q[i], unit_slot0, true);
-        uint32_t left = pend;
-        while(left) {
-          const uint32_t r = (uint32_t)__ffs((int)left) - 1u;
-          slow_insert(again[r * BLOCK + threadIdx.x], unit_slot0, true);
-          left &= left - 1;
-        }
-        lds_barrier();
-      }
+    // ---- C: this wave's queue, then what its lanes held back (one copy of the insert for both)
+    const uint32_t nq = qn < qcap ? qn : qcap;                 // wave-uniform
+    for(uint32_t i = lane;; i += 64) {
+      ITEM x;
+      if(i < nq) x = s_q[i];
+      else if(pend) { const uint32_t r = (uint32_t)__ffs((int)pend) - 1u; x = again[r * BLOCK + threadIdx.x]; pend &= pend - 1; }
+      else break;
+#ifndef JFGPU_T_NOC
+      slow_insert(x, unit_slot0);
+#endif
     }
+    JF_PHASE(pc, 5);
+    lds_barrier();
     JF_PHASE(pc, 3);
   };
-  // a further round of the same unit (more than 9216 items, or several pending batches): the counters no longer know
-  // about merged and claimed slots, so they are recounted first
-  auto extra_round = [&](ITEM (&it)[NP], uint32_t vm, uint64_t unit_slot0, const ITEM* again) {
-    lds_barrier();
+  auto recount = [&]() {      // a further round of the same unit: the counters no longer know about merged and claimed slots
     for(uint32_t b = threadIdx.x; b < nbkt; b += BLOCK) {
       SLOT w[4];
       load_bucket(b << kBucketBits, w);
       reinterpret_cast<uint16_t*>(s_cnt)[b] = (uint16_t)((w[0] != 0) + (w[1] != 0) + (w[2] != 0) + (w[3] != 0));
     }
-    if(threadIdx.x < 3) s_qn[threadIdx.x] = 0;
     lds_barrier();
-    uint32_t old[NP];
-    rank_request(it, vm, old);
-    place_round(it, vm, old, unit_slot0, again, [] {});
   };
 
   zero_counters();
+  zero_tile();
   lds_barrier();
-  if(S.n == 1) {
-    // Fast path (one item array, e.g. the P2 output).  Software pipeline over this block's units: offsets are fetched
-    // two units ahead, and a unit's items are requested as soon as the previous unit's are placed (same registers):
-    // they travel during that unit's queue phase and store and this unit's fill.
-    const uint64_t* off = S.off[0];
-    const uint32_t sh = S.sh[0];                            // 0: packed offsets off[t], off[t + 1]; 1: pairs (begin, end), items may be holes
-    const bool holes = sh != 0;
-    const ITEM* src = reinterpret_cast<const ITEM*>(S.items[0]);
-    const uint32_t G = gridDim.x;
-    uint32_t t = blockIdx.x;
-    uint64_t a0 = 0, b0 = 0, a1 = 0, b1 = 0; uint32_t d0 = 0, d1 = 0;
-    ITEM cur[NP];
-    // a unit's items: src[a .. b), addressed as a block-uniform base plus a 32-bit index
-    auto fetch = [&](uint64_t a, uint64_t b) {
-      const ITEM* ub = src + a;
-      const uint32_t n = (uint32_t)((b - a) < (uint64_t)NP * BLOCK ? (b - a) : (uint64_t)NP * BLOCK);
-      if(n == 0) return;                                      // (block-uniform; the unit is skipped anyway)
-      uint32_t tid = threadIdx.x;
-      JF_OPAQUE(tid);                                         // (or the item indices are hoisted out of the unit loop and spilled)
+  // One loop over CHUNKS: a unit's items in rounds of 9216 (nearly always one).  Offsets are fetched two units ahead, and
+  // a chunk's items are requested as soon as the previous chunk's are placed (same registers): they travel during that
+  // chunk's queue phase and store.
+  const uint64_t* off = S.off[0];
+  const uint32_t sh = S.sh[0];                              // 0: packed offsets off[t], off[t + 1]; 1: pairs (begin, end), items may be holes
+  const bool holes = sh != 0;
+  const ITEM* src = reinterpret_cast<const ITEM*>(S.items[0]);
+  const uint32_t G = gridDim.x;
+  constexpr uint64_t kRound = (uint64_t)NP * BLOCK;
+  uint32_t t = blockIdx.x;
+  uint64_t a0 = 0, b0 = 0, a1 = 0, b1 = 0; uint32_t d0 = 0, d1 = 0;
+  ITEM cur[NP];
+  auto fetch = [&](uint64_t a, uint64_t b) {                // items src[a .. min(b, a + 9216)): block-uniform base + 32-bit index
+    const ITEM* ub = src + a;
+    const uint32_t n = (uint32_t)((b - a) < kRound ? (b - a) : kRound);
+    if(b <= a) return;                                      // (block-uniform; such a unit is skipped)
+    uint32_t tid = threadIdx.x;
+    JF_OPAQUE(tid);                                         // (or the item indices are hoisted out of the loop and spilled)
 #pragma unroll
-      for(int r = 0; r < NP; ++r) {                           // unconditional loads at clamped indices: no branch per item
-        const uint32_t i = (uint32_t)r * BLOCK + tid;
-        cur[r] = ub[i < n ? i : n - 1];
-      }
-    };
-    if(t < n_tiles) { a0 = off[(size_t)t << sh]; b0 = off[((size_t)t << sh) + 1]; d0 = unit_dirty(t); }
-    if(t + G < n_tiles) { a1 = off[(size_t)(t + G) << sh]; b1 = off[((size_t)(t + G) << sh) + 1]; d1 = unit_dirty(t + G); }
-    fetch(a0, b0);
-    for(; t < n_tiles; t += G) {
+    for(int r = 0; r < NP; ++r) {                           // unconditional loads at clamped indices: no branch per item
+      const uint32_t i = (uint32_t)r * BLOCK + tid;
+      cur[r] = ub[i < n ? i : n - 1];
+    }
+  };
+  if(t < n_tiles) { a0 = off[(size_t)t << sh]; b0 = off[((size_t)t << sh) + 1]; d0 = unit_dirty(t); }
+  if(t + G < n_tiles) { a1 = off[(size_t)(t + G) << sh]; b1 = off[((size_t)(t + G) << sh) + 1]; d1 = unit_dirty(t + G); }
+  fetch(a0, b0);
+  uint64_t c0 = a0;                                          // start of the current chunk inside [a0, b0)
+  while(t < n_tiles) {
+    if(b0 <= a0) {                                           // nothing for this unit (block-uniform): next one
       uint64_t a2 = 0, b2 = 0; uint32_t d2 = 0;
       if(t + 2 * G < n_tiles) { a2 = off[(size_t)(t + 2 * G) << sh]; b2 = off[((size_t)(t + 2 * G) << sh) + 1]; d2 = unit_dirty(t + 2 * G); }
-      auto fetch_next = [&] { fetch(a1, b1); };
-      if(b0 > a0) {                                          // block-uniform
-        const uint64_t unit_slot0 = (tile0 + (uint64_t)TPB * t) << g.tile_bits;
-        SLOT* gt = gslots + unit_slot0;
-        JF_PHASE(pc, 0);
-        const uint32_t n0 = (uint32_t)((b0 - a0) < (uint64_t)NP * BLOCK ? (b0 - a0) : (uint64_t)NP * BLOCK);
-        uint32_t vm = 0, tid = threadIdx.x;
-        JF_OPAQUE(tid);
-#pragma unroll
-        for(int r = 0; r < NP; ++r)
-          if((uint32_t)r * BLOCK + tid < n0 && !(holes && cur[r] == hole)) vm |= 1u << r;      // (what a clamped load fetched is not an item)
-        uint32_t old[NP];
-        if(d0) { load_tile(gt, d0); lds_barrier(); rank_request(cur, vm, old); }
-        else { rank_request(cur, vm, old); zero_tile(); lds_barrier(); }      // the adds' round trip hides behind the zeroing
-        JF_PHASE(pc, 1);
-        place_round(cur, vm, old, unit_slot0, src + a0, fetch_next);
-        for(uint64_t c0 = a0 + (uint64_t)NP * BLOCK; c0 < b0; c0 += (uint64_t)NP * BLOCK) {      // rare: an over-full unit
-          ITEM more[NP]; uint32_t mv = 0;
-#pragma unroll
-          for(int r = 0; r < NP; ++r) {
-            const uint64_t v = c0 + (uint64_t)r * BLOCK + threadIdx.x;
-            more[r] = v < b0 ? src[v] : hole;
-            if(v < b0 && !(holes && more[r] == hole)) mv |= 1u << r;
-          }
-          extra_round(more, mv, unit_slot0, src + c0);
-        }
-        lds_barrier();
-        store_tile(gt, t, unit_slot0);
-        lds_barrier();
-        JF_PHASE(pc, 4);
-      } else fetch_next();
-      a0 = a1; b0 = b1; d0 = d1; a1 = a2; b1 = b2; d1 = d2;
+      t += G; a0 = a1; b0 = b1; d0 = d1; a1 = a2; b1 = b2; d1 = d2; c0 = a0;
+      fetch(a0, b0);
+      continue;
     }
-    JF_PHASE_FLUSH(pc, 16);
-    return;
-  }
-  for(uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-    // general path (several pending batches, single-level tables): a round per batch and 9216 items
-    uint64_t n_items = 0;
-    for(uint32_t s = 0; s < S.n; ++s) n_items += seg_hi(S, s, t) - seg_lo(S, s, t);
-    if(n_items == 0) continue;                                   // block-uniform
-    const uint64_t unit_slot0 = (tile0 + (uint64_t)TPB * t) << g.tile_bits;
+    const bool first = c0 == a0, last = c0 + kRound >= b0;
+    const uint64_t unit_slot0 = (tile0 + (uint64_t)TPB * t) << kMaxTileBits;
     SLOT* gt = gslots + unit_slot0;
-    load_tile(gt, unit_dirty(t));
-    bool first = true;
-    for(uint32_t s = 0; s < S.n; ++s) {
-      const uint64_t a = seg_lo(S, s, t), b = seg_hi(S, s, t);
-      const ITEM* src = reinterpret_cast<const ITEM*>(S.items[s]);
-      const bool holes = S.sh[s] != 0;
-      for(uint64_t c0 = a; c0 < b; c0 += (uint64_t)NP * BLOCK) {
-        ITEM it[NP]; uint32_t vm = 0;
+    JF_PHASE(pc, 0);
+    const uint32_t n0 = (uint32_t)((b0 - c0) < kRound ? (b0 - c0) : kRound);
+    uint32_t vm = 0, tid = threadIdx.x;
+    JF_OPAQUE(tid);
 #pragma unroll
-        for(int r = 0; r < NP; ++r) {
-          const uint64_t v = c0 + (uint64_t)r * BLOCK + threadIdx.x;
-          it[r] = v < b ? src[v] : hole;
-          if(v < b && !(holes && it[r] == hole)) vm |= 1u << r;
-        }
-        if(first) {
-          lds_barrier();
-          uint32_t old[NP];
-          rank_request(it, vm, old);
-          place_round(it, vm, old, unit_slot0, src + c0, [] {});
-          first = false;
-        } else extra_round(it, vm, unit_slot0, src + c0);
-      }
-    }
-    lds_barrier();
-    store_tile(gt, t, unit_slot0);
-    lds_barrier();
+    for(int r = 0; r < NP; ++r)
+      if((uint32_t)r * BLOCK + tid < n0 && !(holes && cur[r] == hole)) vm |= 1u << r;      // (what a clamped load fetched is not an item)
+    if(!first) recount();
+    else if(d0) { load_tile(gt, d0); lds_barrier(); }       // (otherwise the previous store left tile and counters zeroed)
+    uint32_t old[NP];
+    rank_request(cur, vm, old);
+    JF_PHASE(pc, 1);
+    uint64_t a2 = 0, b2 = 0; uint32_t d2 = 0;
+    if(last && t + 2 * G < n_tiles) { a2 = off[(size_t)(t + 2 * G) << sh]; b2 = off[((size_t)(t + 2 * G) << sh) + 1]; d2 = unit_dirty(t + 2 * G); }
+    place_round(cur, vm, old, unit_slot0, src + c0, [&] { if(last) fetch(a1, b1); else fetch(c0 + kRound, b0); });
+    if(last) {
+      store_tile(gt, t, unit_slot0);                          // (every round ends on a barrier)
+      lds_barrier();
+      JF_PHASE(pc, 4);
+      t += G; a0 = a1; b0 = b1; d0 = d1; a1 = a2; b1 = b2; d1 = d2; c0 = a0;
+    } else c0 += kRound;
   }
+  JF_PHASE_FLUSH(pc, 16);
 }
 
 }  // namespace jfgpu
