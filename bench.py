@@ -17,15 +17,22 @@ The reads are generated on the device before the timed region: `value` is throug
            one step.  torch.distributed (gloo) only hands out the RCCL id and reduces the timings.  Weak scaling: every
            rank brings its own reads.
 
+  --gpus N > 1 without WORLD_SIZE in the environment: this script starts its own N rank processes (one per GPU, rendezvous on
+           127.0.0.1); under an external launcher (torch.distributed.run) it is one of the ranks.  Per GPU the work is 12.5 Gbp
+           (BASELINE configs[3]: 100 Gbp over 8 GPUs), the same at every N > 1: weak scaling.
+
 Prints ONE JSON line (rank 0).  `value` comes from the contract's timed region (K steps, once); `repeats` re-runs the
 same job a few more times (median/min/max), `flush_sweep` forces 1/2/4/8 flushes per job, `end_to_end` is the Counting
 phase of `jellyfish-amd count` from a FASTA file of the same reads (host read + H2D + device parse included), `roofline`
 and `cpu_baseline` are the contract's extra objects (algorithmic bytes per k-mer from SURVEY 8(d); the reference's own
-CPU path, oracle/_ref, timed on this box's host cores on a bounded sample).  The oracle is only baseline / checker here.
+CPU path, oracle/_ref, timed on this box's host cores on a bounded sample, its table's content digest compared with the
+engine's on the same sample), `secondary` carries BASELINE configs[2] and configs[4] (C3, C5: one job each, run after the
+metric's own work in child processes of this script).  The oracle is only baseline / checker here.
 """
 import argparse
 import json
 import os
+import socket
 import statistics
 import subprocess
 import sys
@@ -43,6 +50,10 @@ CONFIGS = {
     "C3": dict(k=31, lsize=33, slot=8, name="BASELINE configs[2]: k=31 -C, Bloom-counter pass (m = 14 x {gbp:.0f}e9 cells, 10 hashes) then count --bc, {gbp:.1f} Gbp of 150 bp reads, 2^{lsize}-slot table"),
     "C5": dict(k=63, lsize=33, slot=16, name="BASELINE configs[4]: k=63 -C (two-word keys), {gbp:.1f} Gbp of 150 bp reads, 2^{lsize}-slot 128-bit table in HBM"),
 }
+C4_NAME = ("BASELINE configs[3]: k=21 -C, {total:.1f} Gbp of 150 bp reads hash-prefix partitioned across {world} GPUs ({gbp:.1f} Gbp and a 2^{lsize}-slot "
+           "shard per GPU, {slot_bytes}-byte slots), routed k-mers exchanged by RCCL over xGMI")
+GBP_PER_GPU_SHARDED = 12.5                       # configs[3]: 100 Gbp over 8 GPUs; kept at every N > 1 (weak scaling)
+DESIGN_MIN_BYTES = {"C2": 150.0 / 130.0 + 4.0 + 4.0}   # input + the 4-byte item written once + the 4-byte slot written once (what this design cannot go below)
 
 
 def b_alg(cfg, k):
@@ -72,16 +83,23 @@ def _all_cpus():
         pass
 
 
-def ref_count(ref, fa_list, k, size, threads, tmpdir, extra=()):
+def ref_count(ref, fa_list, k, size, threads, tmpdir, extra=(), digest=None):
     out, timing = os.path.join(tmpdir, "ref.jf"), os.path.join(tmpdir, "timing")
-    subprocess.check_call([ref, "count", "-m", str(k), "-C", "-s", str(size), "-t", str(threads), "-o", out, "--timing", timing] + list(extra) + fa_list, preexec_fn=_all_cpus)
+    dg = ["--digest", digest, "--no-write"] if digest else []
+    subprocess.check_call([ref, "count", "-m", str(k), "-C", "-s", str(size), "-t", str(threads), "-o", out, "--timing", timing] + dg + list(extra) + fa_list, preexec_fn=_all_cpus)
     t = dict(l.split() for l in open(timing).read().splitlines())
     return float(t["Counting"]), int(t["Mers"]), out
 
 
+def read_digest(path):
+    """(records, sum of counts, sum of h, xor of h) as `ref_jf count --digest` / `jellyfish-amd count --digest` write it."""
+    return tuple(int(l.split()[1]) for l in open(path).read().splitlines())
+
+
 def cpu_baseline(cfg, sample, k, tmpdir):
     """Reference CPU path (oracle/_ref: the reference's own classes, SSE2 hash like its configure enables) on a bounded
-    sample of the same reads.  Returns (dict for the JSON line, reference `stats` text of the sample or None)."""
+    sample of the same reads.  Returns (dict for the JSON line, content digest of the reference's in-memory table after
+    counting the sample -- walked by its own iterators, `ref_jf count --digest` -- or None)."""
     import numpy as np
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_jf")
     n_reads = sample.shape[0]
@@ -108,17 +126,18 @@ def cpu_baseline(cfg, sample, k, tmpdir):
         t0 = time.time()
         subprocess.check_call([ref, "bc", "-m", str(k), "-C", "-s", str(n_reads * READ_LEN), "-t", str(best_t), "-o", bc, fa], preexec_fn=_all_cpus)
         t_bc = time.time() - t0
-        t_cnt, mers, out = ref_count(ref, [fa], k, size, best_t, tmpdir, ["--bc", bc])
+        dgp = os.path.join(tmpdir, "ref.digest")
+        t_cnt, mers, out = ref_count(ref, [fa], k, size, best_t, tmpdir, ["--bc", bc], digest=dgp)
         assert mers == kmers
-        stats = subprocess.check_output([ref, "stats", out]).decode()
+        stats = read_digest(dgp)
         res.update({"value": kmers / (t_bc + t_cnt), "cores": best_t, "bc_pass_kmers_per_s": kmers / t_bc, "count_bc_pass_kmers_per_s": kmers / t_cnt,
                     "sample": "first %d reads (%.0f Mbp) of the same input: jellyfish 2.3.1 classes (oracle/_ref, SSE2 hash), bc (whole command, "
                               "-s %d -f 0.001) then count --bc (Counting phase), -t %d" % (n_reads, n_reads * READ_LEN / 1e6, n_reads * READ_LEN, best_t)})
         return res, stats
-    t_best, mers, out = ref_count(ref, [fa], k, size, best_t, tmpdir)
+    dgp = os.path.join(tmpdir, "ref.digest")
+    t_best, mers, out = ref_count(ref, [fa], k, size, best_t, tmpdir, digest=dgp)
     assert mers == kmers
-    stats = subprocess.check_output([ref, "stats", out]).decode()
-    os.unlink(out)
+    stats = read_digest(dgp)
     res.update({"value": kmers / t_best, "cores": best_t,
                 "sample": "first %d reads (%.0f Mbp) of the same synthetic input, jellyfish 2.3.1 classes (oracle/_ref, -DHAVE_SSE -msse2), "
                           "-t %d, table presized 2^%d (load %.2f), Counting phase only" % (n_reads, n_reads * READ_LEN / 1e6, best_t, size.bit_length() - 1, kmers / size)})
@@ -128,26 +147,50 @@ def cpu_baseline(cfg, sample, k, tmpdir):
         n1 = max(1, n_reads // 10)
         fa1 = os.path.join(tmpdir, "s1.fa")
         write_fasta(sample[:n1], fa1)
-        t1, m1, o1 = ref_count(ref, [fa1], k, size // 8, 1, tmpdir)
+        t1, m1, o1 = ref_count(ref, [fa1], k, size // 8, 1, tmpdir, ["--no-write"])
         variants["t1"] = {"kmers_per_s": m1 / t1, "threads": 1, "sample_reads": n1}
-        os.unlink(o1)
         if ncpu > best_t:
-            ta, ma, oa = ref_count(ref, [fa], k, size, ncpu, tmpdir)
+            ta, ma, oa = ref_count(ref, [fa], k, size, ncpu, tmpdir, ["--no-write"])
             variants["t_nproc"] = {"kmers_per_s": ma / ta, "threads": ncpu}
-            os.unlink(oa)
         # -F 4: the single serial parser is the reference's bottleneck at high thread counts; four files, four parsers
         parts = []
         for i in range(4):
             p = os.path.join(tmpdir, "q%d.fa" % i)
             write_fasta(sample[n_reads * i // 4: n_reads * (i + 1) // 4], p)
             parts.append(p)
-        tf, mf, of = ref_count(ref, parts, k, size, best_t, tmpdir, ["-F", "4"])
+        tf, mf, of = ref_count(ref, parts, k, size, best_t, tmpdir, ["-F", "4", "--no-write"])
         variants["F4"] = {"kmers_per_s": mf / tf, "threads": best_t, "files": 4}
-        os.unlink(of)
         res["variants"] = variants
         res["value"] = max([res["value"]] + [v["kmers_per_s"] for v in variants.values()])     # the reference at its best on this box
         res["value_is"] = "best of: -t %d one file; %s" % (best_t, ", ".join(sorted(variants)))
     return res, stats
+
+
+def spawn_ranks(n):
+    """python bench.py --gpus N from a bare shell: N copies of this command, one rank per GPU, rendezvous on 127.0.0.1 (what
+    torch.distributed.run would set up).  Rank 0's stdout (the JSON line) is this process's; a failing rank ends the others."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable] + sys.argv, env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            c = procs[r].poll()
+            if c is None:
+                continue
+            live.discard(r)
+            if c != 0 and rc == 0:
+                rc = c
+                for q in live:
+                    procs[q].terminate()
+        time.sleep(0.2)
+    return rc
 
 
 def main():
@@ -156,29 +199,30 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="C2")
-    ap.add_argument("--gbp", type=float, default=10.0, help="giga-bases of reads per GPU")
+    ap.add_argument("--gbp", type=float, default=0.0, help="giga-bases of reads per GPU (default: 10 at N = 1, 12.5 at N > 1)")
     ap.add_argument("--lsize", type=int, default=0, help="log2 slots per GPU (default: the configuration's)")
     ap.add_argument("--cpu-sample-reads", type=int, default=1032000, help="reads of the CPU-baseline sample (155 Mbp: load 0.50 in its 2^28 table at k = 21)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--repeats", type=int, default=5, help="how many times the whole job is run in all (first = the contract's timed region)")
-    ap.add_argument("--no-extras", action="store_true", help="skip flush sweep and end-to-end (quick runs, profiling)")
+    ap.add_argument("--no-extras", action="store_true", help="skip flush sweep, end-to-end and the secondary configurations (quick runs, profiling)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the C5 / C3 jobs attached to the default C2 line")
+    ap.add_argument("--as-secondary", action="store_true", help=argparse.SUPPRESS)      # child of the default run: one job, compact line
     ap.add_argument("--dist", choices=["U", "G"], default="U",
                     help="U: iid uniform reads (the metric's configuration); G: BASELINE.md's secondary distribution, reads sampled from a "
                          "100 Mbp random genome with 1 %% substitutions (about 100x coverage at 10 Gbp: most k-mers repeat)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+    if args.as_secondary:
+        args.no_extras = True; args.no_cpu_baseline = True; args.repeats = 1
+    if not args.gbp:
+        args.gbp = GBP_PER_GPU_SHARDED if args.gpus > 1 else 10.0
 
     import numpy as np
     from jellyfish_amd import capi
-
-    # JFGPU_EMU_BENCH=1: dry run of this script against the host-emulated engine (tests/host/run_emu.sh, tiny --gbp/--lsize):
-    # a debugging aid for the script itself; its numbers mean nothing and it refuses the default sizes.
-    emu = os.environ.get("JFGPU_EMU_BENCH") == "1"
-    if emu:
-        assert args.gbp <= 0.01 and args.gpus == 1, "emulated dry run: tiny single-process runs only"
-        torch = None
-    else:
-        import torch
-        assert torch.cuda.is_available(), "bench.py needs a GPU: there is no CPU path to measure"
+    import torch
+    assert torch.cuda.is_available(), "bench.py needs a GPU: there is no CPU path to measure"
+    emu = False
 
     cfg = args.config
     K = CONFIGS[cfg]["k"]
@@ -187,13 +231,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if world > 1 and cfg != "C2":
         raise SystemExit("--config %s is a single-GPU configuration (BASELINE.json)" % cfg)
-    dev = None
-    if not emu:
-        torch.cuda.set_device(local_rank)
-        dev = torch.device("cuda", local_rank)
+    if os.environ.get("JFGPU_COMM_TRANSPORT") == "ipc":     # the inter-process test transport: all ranks on the devices there are
+        local_rank %= torch.cuda.device_count()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -202,8 +246,7 @@ def main():
     assert 1 << sb == world, "the number of GPUs must be a power of two (shards = top hash bits)"
 
     def device_sync():
-        if not emu:
-            torch.cuda.synchronize()
+        torch.cuda.synchronize()
 
     n_reads = int(round(args.gbp * 1e9 / READ_LEN))
     steps, warmup = args.steps, args.warmup
@@ -369,9 +412,10 @@ def main():
             "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64" if CONFIGS[cfg]["slot"] == 8 else "u128", "data": "synthetic",
-            "config": {"workload": CONFIGS[cfg]["name"].format(gbp=args.gbp, lsize=lsize, slot_bytes=slot_bytes) +
+            "config": {"workload": (CONFIGS[cfg]["name"].format(gbp=args.gbp, lsize=lsize, slot_bytes=slot_bytes) if world == 1 else
+                                    C4_NAME.format(total=args.gbp * world, world=world, gbp=args.gbp, lsize=lsize, slot_bytes=slot_bytes)) +
                                    ("" if args.dist == "U" else "; SECONDARY distribution G (reads from a 100 Mbp random genome, 1 % substitutions)"),
-                       "id": cfg, "k": K, "read_len": READ_LEN, "reads_per_gpu": n_reads, "table_slots_per_gpu": 1 << lsize, "slot_bytes": slot_bytes,
+                       "id": cfg if world == 1 else "C4", "k": K, "read_len": READ_LEN, "reads_per_gpu": n_reads, "table_slots_per_gpu": 1 << lsize, "slot_bytes": slot_bytes,
                        "load_factor": float(tot[1]) / float(world << lsize),
                        "distinct": int(tot[1]), "total_kmers": total_kmers,
                        "parallelism": ("single GPU" if not force_dist else "single GPU through the sharded code path") if world == 1 else "hash-prefix shard x%d + all-to-all" % world},
@@ -384,7 +428,11 @@ def main():
                          "whole_path_achieved": value * whole_bpk / 1e9, "whole_path_frac": value * whole_bpk / 1e9 / HBM_PEAK_GBS,
                          "note": "achieved/frac follow the contract: the named (largest-total-time) kernel's k-mers per launch x its algorithmic "
                                  "bytes per k-mer / its average launch time; that kernel is one stage of a multi-kernel path, so whole_path_* "
-                                 "(k-mers/s of the whole job x the path's algorithmic bytes) is the number to compare with the 8 TB/s peak",
+                                 "(k-mers/s of the whole job x the path's algorithmic bytes) is the number to compare with the 8 TB/s peak.  "
+                                 "bytes_per_kmer is SURVEY 8(d)'s contract figure (one read-modify-write of an 8-byte slot for one-word keys) "
+                                 "whatever the slot width in use (config.slot_bytes); design_min_bytes_per_kmer is what this three-stage design "
+                                 "cannot go below (input + item written once + slot written once)",
+                         "design_min_bytes_per_kmer": DESIGN_MIN_BYTES.get(cfg),
                          "gups_atomic_add": gups.get("atomic_add"), "gups_atomic_cas": gups.get("atomic_cas"),
                          "value_over_gups": value / world / gups["atomic_cas"] if gups.get("atomic_cas") else None},
         }
@@ -427,7 +475,7 @@ def main():
         out["flush_sweep"] = {"kmers_per_s_by_flushes_per_job": sweep,
                               "note": "a flush streams every dirty tile of the table once, so its cost is O(table), not O(batch)"}
         # ---- end to end: `jellyfish-amd count` from a FASTA file of the same reads (page cache warm, /dev/shm) ----
-        cli = (os.environ.get("JFGPU_CLI") if emu else None) or os.path.join(ROOT, "bin", "jellyfish-amd")
+        cli = os.path.join(ROOT, "bin", "jellyfish-amd")
         shm = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
         if os.access(cli, os.X_OK):
             reset()
@@ -463,7 +511,7 @@ def main():
         with tempfile.TemporaryDirectory() as td:
             base, ref_stats = cpu_baseline(cfg, sample, K, td)
         out["cpu_baseline"] = base
-        if ref_stats is not None:       # bit-exactness spot check on the very sample the CPU counted
+        if ref_stats is not None:       # bit-exactness on the very sample the CPU counted: per-k-mer content, not aggregates
             if t is not None:
                 t.close(); t = None
             b2 = None
@@ -475,13 +523,35 @@ def main():
                     t2.attach_bloom(b2)
                 t2.count_ascii_dev(buf, ns * stride)
                 t2.sync()
-                s2 = t2.stats()
+                mine = tuple(t2.digest())
                 t2.attach_bloom(None)
             if b2 is not None:
                 b2.close()
-            mine = "Unique:    %d\nDistinct:  %d\nTotal:     %d\nMax_count: %d\n" % (s2.unique, s2.distinct, s2.total, s2.max_count)
-            out["cpu_baseline"]["stats_equal_on_sample"] = (mine == ref_stats)
-            assert mine == ref_stats, "GPU and reference disagree on the sample:\n%s\n%s" % (mine, ref_stats)
+            out["cpu_baseline"]["digest_equal_on_sample"] = (mine == tuple(ref_stats))
+            out["cpu_baseline"]["sample_digest"] = {"records": mine[0], "total": mine[1], "sum_h": mine[2], "xor_h": mine[3],
+                                                    "what": "content digest of the whole table (records, sum of counts, sum and xor of a per-record hash of key words and "
+                                                            "count): jfgpu_digest on the device table vs `ref_jf count --digest` on the reference's in-memory table"}
+            assert mine == tuple(ref_stats), "GPU and reference disagree on the sample: %r vs %r" % (mine, ref_stats)
+    # ---- BASELINE configs[4] and configs[2]: one job each, in children of this script (they need the device memory) ----
+    if rank == 0 and world == 1 and cfg == "C2" and not args.no_extras and not args.no_secondary and not args.as_secondary and args.dist == "U":
+        if t is not None:
+            t.close(); t = None
+        sec = {}
+        for c in ("C5", "C3"):
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", c, "--as-secondary", "--steps", str(steps), "--warmup", str(warmup)],
+                                   capture_output=True, text=True, timeout=900, preexec_fn=_all_cpus)
+                line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                if r.returncode == 0 and line:
+                    d = json.loads(line[-1])
+                    sec[c] = {k: d[k] for k in ("value", "unit", "ms_per_step", "dtype", "config", "kernels", "roofline", "content_digest") if k in d}
+                    if "passes" in d:
+                        sec[c]["passes"] = d["passes"]
+                else:
+                    sec[c] = {"error": (r.stderr or r.stdout)[-400:]}
+            except Exception as e:       # the contract line must come out whatever the extras do
+                sec[c] = {"error": repr(e)}
+        out["secondary"] = sec
     if rank == 0:
         print(json.dumps(out), flush=True)
     if bloom is not None:

@@ -11,7 +11,10 @@
 // (the reference generates them with yaggo); names, defaults and output text follow the
 // reference so scripts keep working.  dump/histo/stats/query/info are plain sequential file
 // readers (I/O bound, host only); count drives the GPU through the hash_counter facade.
+#include <algorithm>
+#include <cerrno>
 #include <chrono>
+#include <csignal>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -263,13 +266,17 @@ struct rank_env { int rank = 0, world = 1, local_rank = 0; std::string rendezvou
 
 rank_env read_rank_env() {
   rank_env e;
-  const char* r = getenv("JFGPU_RANK"); if(!r) r = getenv("RANK");
-  const char* w = getenv("JFGPU_WORLD"); if(!w) w = getenv("WORLD_SIZE");
+  const char* rdv = getenv("JFGPU_RENDEZVOUS");
+  const char* r = getenv("JFGPU_RANK");
+  const char* w = getenv("JFGPU_WORLD");
+  // a launcher's generic RANK / WORLD_SIZE count only together with JFGPU_RENDEZVOUS: `count --gpus 2` typed inside some
+  // torchrun / SLURM shell must start its own ranks, not become one rank waiting for peers that never come
+  if(rdv && (!r || !w)) { r = getenv("RANK"); w = getenv("WORLD_SIZE"); }
   if(!r || !w) return e;
   e.is_rank = true; e.rank = atoi(r); e.world = atoi(w);
   const char* l = getenv("JFGPU_LOCAL_RANK"); if(!l) l = getenv("LOCAL_RANK");
   e.local_rank = l ? atoi(l) : e.rank;
-  if(const char* d = getenv("JFGPU_RENDEZVOUS")) e.rendezvous = d;
+  if(rdv) e.rendezvous = rdv;
   return e;
 }
 
@@ -296,12 +303,21 @@ int spawn_ranks(unsigned n, char* argv[]) {
     }
     pids.push_back(pid);
   }
+  // The ranks meet in collectives: when one of them dies ("Hash full", an unreadable file, no memory ...) the others would
+  // wait for it forever, so the first failure ends them all and is what this command returns.
   int worst = 0;
-  for(pid_t pid : pids) {
+  size_t left = pids.size();
+  while(left) {
     int st = 0;
-    if(waitpid(pid, &st, 0) < 0) { worst = std::max(worst, 1); continue; }
+    const pid_t pid = waitpid(-1, &st, 0);
+    if(pid < 0) { if(errno == EINTR) continue; worst = std::max(worst, 1); break; }
+    if(std::find(pids.begin(), pids.end(), pid) == pids.end()) continue;
+    --left;
     const int rc = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
-    worst = std::max(worst, rc);
+    if(rc != 0 && worst == 0) {
+      worst = rc;
+      for(pid_t q : pids) if(q != pid) kill(q, SIGTERM);
+    }
   }
   unlink((std::string(dir) + "/id").c_str());
   rmdir(dir);
@@ -313,6 +329,7 @@ void exchange_unique_id(const rank_env& e, uint8_t* id128) {
   const std::string path = e.rendezvous + "/id", tmp = path + ".tmp";
   if(e.rank == 0) {
     if(jfgpu_comm_unique_id(id128)) die(jfgpu_last_error());
+    unlink(path.c_str());                                  // (a file left by an earlier job in a launcher-provided directory)
     std::ofstream out(tmp, std::ios::binary | std::ios::trunc);
     out.write((const char*)id128, 128);
     out.close();
@@ -444,6 +461,8 @@ int count_main(int argc, char* argv[]) {
     if(renv.world != (int)gpus || renv.rank < 0 || renv.rank >= renv.world) die("--gpus does not match the ranks' environment (WORLD_SIZE / RANK)");
     if(renv.rendezvous.empty()) die("--gpus under an external launcher: set JFGPU_RENDEZVOUS to a directory all ranks see");
     if(device < 0) device = renv.local_rank;
+    { const char* tr = getenv("JFGPU_COMM_TRANSPORT");     // the test transport: every rank on the devices there are (one GPU: all on it)
+      if(tr && !strcmp(tr, "ipc")) { const int nd = jfgpu_device_count(); if(nd > 0) device %= nd; } }
     while((1u << shard_bits) < gpus) ++shard_bits;
   }
 
@@ -459,6 +478,7 @@ int count_main(int argc, char* argv[]) {
     exchange_unique_id(renv, id);
     if(jfgpu_comm_create(renv.world, renv.rank, id, device, &comm)) die(std::string("Failed to create the communicator: ") + jfgpu_last_error());
     ary->attach_comm(comm);
+    if(const char* fr = getenv("JFGPU_TEST_FAIL_RANK")) if(atoi(fr) == renv.rank) die("rank told to fail (JFGPU_TEST_FAIL_RANK)");      // (tests: the siblings must not hang)
   }
 
   // Bloom counter read from file to filter out low frequency k-mers, two pass algorithm

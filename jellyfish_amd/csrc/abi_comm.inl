@@ -10,9 +10,24 @@
 // A second transport, "local", keeps all ranks' shards in ONE process on one device and moves the messages with
 // device copies: same routing, bookkeeping, rounds and insert code, no RCCL.  It exists so that the sharded path is
 // testable on a single GPU (and under tests/host/hip_emu) at world sizes 2 and 4.
+//
+// A third transport, "ipc", has one process per rank like RCCL but moves the messages with copies between the processes'
+// device allocations (hipIpcGetMemHandle / hipIpcOpenMemHandle) and keeps the small host-level agreements (counts,
+// barriers, allreduce / allgather) in a POSIX shared-memory block.  Every step ends on a host barrier, so nothing
+// overlaps: it exists so that the multi-PROCESS code around the exchange -- `count --gpus N`: rank start-up, rendezvous,
+// file parts, the collectives, the sharded writer, a failing rank -- runs and is tested on a box with a single GPU
+// (all ranks on device 0).  Chosen with JFGPU_COMM_TRANSPORT=ipc when the id is made (jfgpu_comm_unique_id).
 #if !defined(JFGPU_EMU)
 #include <rccl/rccl.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+#include <atomic>
+#include <chrono>
+#include <thread>
 #endif
+
+namespace { struct IpcShared; }
 
 struct jfgpu_comm {
   int world = 1, rank = 0, device = 0;
@@ -45,6 +60,15 @@ struct jfgpu_comm {
     double ipb = 0;
     uint64_t strag_seen = 0;
   };
+#if !defined(JFGPU_EMU)
+  // "ipc" transport (see the head of this file)
+  IpcShared* shm = nullptr; std::string shm_name;
+  struct PeerMap { void* ptr = nullptr; uint64_t epoch = 0; };
+  std::vector<PeerMap> peer_send[2];             // peers' send buffers as mapped here, per turn
+  uint64_t send_epoch[2] = {0, 0}; void* send_exported[2] = {nullptr, nullptr};
+  uint32_t barrier_gen = 0;
+#endif
+  bool ipc = false;
   bool items_on = true; int items_mode = 1;      // JFGPU_COMM_ITEMS: 0 always send 8-byte keys, 1 items when the step is large enough, 2 items always
   uint32_t strag_cap = 1u << 16;                 // stragglers per rank and step (JFGPU_COMM_STRAG)
   std::vector<Rank> ranks;                       // RCCL transport: one; local transport: `world`
@@ -527,6 +551,157 @@ int comm_exchange_items_local(jfgpu_comm* c) {
   return JFGPU_OK;
 }
 
+
+#if !defined(JFGPU_EMU)
+// ---- the "ipc" transport -----------------------------------------------------------------------------------------
+constexpr int kIpcMaxWorld = 16;
+struct IpcShared {
+  std::atomic<uint32_t> arrived, generation, failed, attached;
+  uint64_t coll[kIpcMaxWorld][64];                          // a rank's contribution to the running collective
+  struct Pub {
+    hipIpcMemHandle_t send[2]; uint64_t send_epoch[2];      // send buffers of both turns (epoch changes when one is re-allocated)
+    uint64_t scount[kIpcMaxWorld], soff[kIpcMaxWorld + 1];  // key path: what this rank holds for every owner, and where
+  } pub[kIpcMaxWorld];
+};
+
+int ipc_fail(jfgpu_comm* c, const char* what) {
+  if(c->shm) c->shm->failed.store(1);
+  return fail(JFGPU_E_HIP, std::string("ipc transport: ") + what);
+}
+
+// Sense-reversing barrier over the shared block; gives up when a rank reported a failure or nobody moves for 10 minutes.
+int ipc_barrier(jfgpu_comm* c) {
+  IpcShared* S = c->shm;
+  const uint32_t gen = S->generation.load();
+  if(S->arrived.fetch_add(1) + 1 == (uint32_t)c->world) { S->arrived.store(0); S->generation.fetch_add(1); return JFGPU_OK; }
+  const auto t0 = std::chrono::steady_clock::now();
+  for(uint64_t spins = 0; S->generation.load() == gen; ++spins) {
+    if(S->failed.load()) return fail(JFGPU_E_HIP, "ipc transport: another rank failed");
+    if(spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50)); else std::this_thread::yield();
+    if((spins & 0xFFFF) == 0xFFFF && std::chrono::steady_clock::now() - t0 > std::chrono::minutes(10)) return ipc_fail(c, "barrier timed out");
+  }
+  return JFGPU_OK;
+}
+
+// (Re-)publish this rank's send buffer of turn `cur` if it was re-allocated since.
+int ipc_publish_send(jfgpu_comm* c, int cur) {
+  jfgpu_comm::Rank& R = c->ranks[0];
+  IpcShared::Pub& P = c->shm->pub[c->rank];
+  if(R.send[cur] && c->send_exported[cur] != (void*)R.send[cur]) {
+    if(hipIpcGetMemHandle(&P.send[cur], R.send[cur]) != hipSuccess) return ipc_fail(c, "hipIpcGetMemHandle");
+    c->send_exported[cur] = R.send[cur];
+    P.send_epoch[cur] = ++c->send_epoch[cur];
+  }
+  return JFGPU_OK;
+}
+
+// Peer p's send buffer of turn `cur`, mapped into this process.
+int ipc_peer_send(jfgpu_comm* c, int p, int cur, uint8_t** out) {
+  jfgpu_comm::PeerMap& M = c->peer_send[cur][p];
+  const IpcShared::Pub& P = c->shm->pub[p];
+  if(M.epoch != P.send_epoch[cur]) {
+    if(M.ptr) { hipIpcCloseMemHandle(M.ptr); M.ptr = nullptr; }
+    if(hipIpcOpenMemHandle(&M.ptr, P.send[cur], hipIpcMemLazyEnablePeerAccess) != hipSuccess) return ipc_fail(c, "hipIpcOpenMemHandle");
+    M.epoch = P.send_epoch[cur];
+  }
+  *out = reinterpret_cast<uint8_t*>(M.ptr);
+  return JFGPU_OK;
+}
+
+// Key path: every rank publishes its per-owner counts and offsets, then PULLS what is meant for it out of the peers'
+// send buffers into its own receive buffer.
+int comm_exchange_ipc(jfgpu_comm* c) {
+  jfgpu_comm::Rank& R = c->ranks[0];
+  const int cur = R.turn, W = c->world;
+  HIP_TRY(hipStreamSynchronize(R.t->stream));                // the routed keys are in send[cur]
+  int rc = ipc_publish_send(c, cur); if(rc) return rc;
+  IpcShared::Pub& mine = c->shm->pub[c->rank];
+  for(int p = 0; p < W; ++p) { mine.scount[p] = R.scount[cur][p]; mine.soff[p] = R.soff[cur][p]; }
+  rc = ipc_barrier(c); if(rc) return rc;
+  uint64_t total = 0;
+  for(int p = 0; p < W; ++p) { R.rcount[cur][p] = c->shm->pub[p].scount[c->rank]; R.roff[cur][p] = total; total += R.rcount[cur][p]; }
+  R.roff[cur][W] = total;
+  if(R.used[cur]) HIP_TRY(hipEventSynchronize(R.consumed[cur]));
+  rc = comm_reserve(R.recv[cur], R.recv_cap[cur], total, R.t->stream, c->xstream); if(rc) return rc;
+  for(int p = 0; p < W; ++p) {
+    if(!R.rcount[cur][p]) continue;
+    uint8_t* src = reinterpret_cast<uint8_t*>(R.send[cur]);
+    if(p != c->rank) { rc = ipc_peer_send(c, p, cur, &src); if(rc) return rc; }
+    HIP_TRY(hipMemcpyAsync(R.recv[cur] + R.roff[cur][p], src + c->shm->pub[p].soff[c->rank] * 8, R.rcount[cur][p] * 8, hipMemcpyDeviceToDevice, c->xstream));
+  }
+  HIP_TRY(hipEventRecord(R.exchanged[cur], c->xstream));
+  HIP_TRY(hipStreamSynchronize(c->xstream));
+  rc = ipc_barrier(c); if(rc) return rc;                     // everybody has pulled: the send buffers may be written again
+  R.used[cur] = true;
+  return JFGPU_OK;
+}
+
+// Item path: fixed layout, nothing to publish but the buffers.
+int comm_exchange_items_ipc(jfgpu_comm* c) {
+  jfgpu_comm::Rank& R = c->ranks[0];
+  const int cur = R.turn, W = c->world, me = c->rank;
+  const ItemLayout L = item_layout(c, R.t, R.icap[cur]);
+  HIP_TRY(hipStreamSynchronize(R.t->stream));
+  int rc = ipc_publish_send(c, cur); if(rc) return rc;
+  if(R.used[cur]) HIP_TRY(hipEventSynchronize(R.consumed[cur]));
+  rc = comm_reserve(R.recv[cur], R.recv_cap[cur], (L.recv_bytes + 7) / 8, R.t->stream, c->xstream); if(rc) return rc;
+  rc = ipc_barrier(c); if(rc) return rc;
+  uint8_t* rb = reinterpret_cast<uint8_t*>(R.recv[cur]);
+  const size_t blk = (size_t)L.nbc * L.cap;
+  for(int p = 0; p < W; ++p) {                               // sender p's share for me
+    uint8_t* sb = reinterpret_cast<uint8_t*>(R.send[cur]);
+    if(p != me) { rc = ipc_peer_send(c, p, cur, &sb); if(rc) return rc; }
+    HIP_TRY(hipMemcpyAsync(rb + (size_t)p * blk * 4, sb + (size_t)me * blk * 4, blk * 4, hipMemcpyDeviceToDevice, c->xstream));
+    HIP_TRY(hipMemcpyAsync(rb + L.r_offs_at + (size_t)p * 2 * L.nbc * 8, sb + L.offs_at + (size_t)me * 2 * L.nbc * 8, (size_t)2 * L.nbc * 8, hipMemcpyDeviceToDevice, c->xstream));
+    HIP_TRY(hipMemcpyAsync(rb + L.r_claims_at + (size_t)p * 8, sb + L.claims_at + (size_t)me * 8, 8, hipMemcpyDeviceToDevice, c->xstream));
+    HIP_TRY(hipMemcpyAsync(rb + L.r_strag_at + (size_t)p * (1 + L.S) * 8, sb + L.strag_at, (size_t)(1 + L.S) * 8, hipMemcpyDeviceToDevice, c->xstream));
+  }
+  HIP_TRY(hipEventRecord(R.exchanged[cur], c->xstream));
+  HIP_TRY(hipStreamSynchronize(c->xstream));
+  rc = ipc_barrier(c); if(rc) return rc;
+  R.used[cur] = true;
+  return JFGPU_OK;
+}
+
+int ipc_collective(jfgpu_comm* c, uint64_t* values, int n, int op /* 0 sum, 1 max, 2 gather of values[0] into values[0..world) */) {
+  IpcShared* S = c->shm;
+  for(int i = 0; i < (op == 2 ? 1 : n); ++i) S->coll[c->rank][i] = values[i];
+  int rc = ipc_barrier(c); if(rc) return rc;
+  if(op == 2) { for(int p = 0; p < c->world; ++p) values[p] = S->coll[p][0]; }
+  else for(int i = 0; i < n; ++i) {
+    uint64_t v = op == 0 ? 0 : S->coll[0][i];
+    for(int p = 0; p < c->world; ++p) v = op == 0 ? v + S->coll[p][i] : std::max(v, S->coll[p][i]);
+    values[i] = v;
+  }
+  return ipc_barrier(c);                                     // (the slots are free again)
+}
+
+int ipc_attach(jfgpu_comm* c, const uint8_t* id128) {
+  if(c->world > kIpcMaxWorld) return fail(JFGPU_E_INVALID, "ipc transport: at most 16 ranks");
+  c->shm_name.assign(reinterpret_cast<const char*>(id128) + 8);
+  const int fd = shm_open(c->shm_name.c_str(), O_CREAT | O_RDWR, 0600);       // created zero-filled by whoever comes first
+  if(fd < 0) return fail(JFGPU_E_HIP, "ipc transport: shm_open failed");
+  if(ftruncate(fd, sizeof(IpcShared)) != 0) { close(fd); return fail(JFGPU_E_HIP, "ipc transport: ftruncate failed"); }
+  void* m = mmap(nullptr, sizeof(IpcShared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if(m == MAP_FAILED) return fail(JFGPU_E_HIP, "ipc transport: mmap failed");
+  c->shm = reinterpret_cast<IpcShared*>(m);
+  c->ipc = true;
+  for(int i = 0; i < 2; ++i) c->peer_send[i].assign(c->world, jfgpu_comm::PeerMap());
+  c->shm->attached.fetch_add(1);
+  return ipc_barrier(c);                                     // everybody is here
+}
+
+void ipc_detach(jfgpu_comm* c) {
+  if(!c->shm) return;
+  for(int i = 0; i < 2; ++i) for(auto& M : c->peer_send[i]) if(M.ptr) hipIpcCloseMemHandle(M.ptr);
+  const bool last = c->shm->attached.fetch_sub(1) == 1;
+  munmap(c->shm, sizeof(IpcShared));
+  if(last) shm_unlink(c->shm_name.c_str());
+  c->shm = nullptr;
+}
+#endif
+
 void comm_free_rank(jfgpu_comm::Rank& R) {
   for(int i = 0; i < 2; ++i) {
     if(R.send[i]) hipFree(R.send[i]);
@@ -551,6 +726,14 @@ int jfgpu_comm_unique_id(uint8_t* id128) {
   memset(id128, 0, 128);
   return JFGPU_OK;
 #else
+  if(const char* tr = getenv("JFGPU_COMM_TRANSPORT")) if(!strcmp(tr, "ipc")) {
+    // "JFGPUIPC" + the name of the shared block the ranks meet in
+    memset(id128, 0, 128);
+    memcpy(id128, "JFGPUIPC", 8);
+    snprintf(reinterpret_cast<char*>(id128) + 8, 100, "/jfgpu_ipc_%ld_%llx", (long)getpid(),
+             (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count());
+    return JFGPU_OK;
+  }
   ncclUniqueId id;
   NCCL_TRY(ncclGetUniqueId(&id));
   static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
@@ -571,9 +754,12 @@ int jfgpu_comm_create(int world, int rank, const uint8_t* id128, int device, jfg
   HIP_TRY(hipSetDevice(device));
   std::unique_ptr<jfgpu_comm> c(new jfgpu_comm);
   c->world = world; c->rank = rank; c->device = device; c->local = false;
-  ncclUniqueId id;
-  memcpy(&id, id128, 128);
-  NCCL_TRY(ncclCommInitRank(&c->nccl, world, id, rank));
+  if(!memcmp(id128, "JFGPUIPC", 8)) { int rc = ipc_attach(c.get(), id128); if(rc) return rc; }
+  else {
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    NCCL_TRY(ncclCommInitRank(&c->nccl, world, id, rank));
+  }
   HIP_TRY(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
   c->ranks.resize(1);
   int rc = comm_init_rank(c.get(), c->ranks[0]); if(rc) return rc;
@@ -612,6 +798,7 @@ void jfgpu_comm_destroy(jfgpu_comm* c) {
   if(c->d_coll) hipFree(c->d_coll);
 #if !defined(JFGPU_EMU)
   if(c->nccl) ncclCommDestroy(c->nccl);
+  ipc_detach(c);
 #endif
   if(c->xstream) hipStreamDestroy(c->xstream);
   delete c;
@@ -637,10 +824,10 @@ int jfgpu_comm_count_ascii_dev(jfgpu_comm* c, jfgpu_table* t, const char* d_base
     if(o) cap = 0;                                           // somebody has more stragglers than the list holds: this step goes as keys
   }
   R.icap[R.turn] = cap;
-  if(cap) { R.sent += routed; rc = comm_exchange_items_rccl(c); if(rc) return rc; }
+  if(cap) { R.sent += routed; rc = c->ipc ? comm_exchange_items_ipc(c) : comm_exchange_items_rccl(c); if(rc) return rc; }
   else {
     rc = comm_route(c, R, d_bases, n); if(rc) return rc;
-    rc = comm_exchange_rccl(c); if(rc) return rc;
+    rc = c->ipc ? comm_exchange_ipc(c) : comm_exchange_rccl(c); if(rc) return rc;
   }
   rc = comm_insert_prev(c, R); if(rc) return rc;            // overlaps with the exchange just enqueued
   R.inflight = true; R.turn ^= 1;
@@ -698,6 +885,7 @@ int jfgpu_comm_allreduce_u64(jfgpu_comm* c, uint64_t* values, int n, int op) {
   return fail(JFGPU_E_UNSUPPORTED, "no RCCL in the emulated build");
 #else
   HIP_TRY(hipSetDevice(c->device));
+  if(c->ipc) return ipc_collective(c, values, n, op);
   if(c->world == 1 && !c->self_rccl) return JFGPU_OK;
   if(!c->d_coll) HIP_TRY(hipMalloc((void**)&c->d_coll, sizeof(uint64_t) * 512));
   HIP_TRY(hipMemcpyAsync(c->d_coll, values, sizeof(uint64_t) * n, hipMemcpyHostToDevice, c->xstream));
@@ -716,6 +904,7 @@ int jfgpu_comm_allgather_u64(jfgpu_comm* c, uint64_t mine, uint64_t* all) {
   return fail(JFGPU_E_UNSUPPORTED, "no RCCL in the emulated build");
 #else
   HIP_TRY(hipSetDevice(c->device));
+  if(c->ipc) { all[0] = mine; return ipc_collective(c, all, 1, 2); }
   if(c->world == 1 && !c->self_rccl) { all[0] = mine; return JFGPU_OK; }
   if(c->world > 256) return fail(JFGPU_E_INVALID, "allgather: world too large");
   if(!c->d_coll) HIP_TRY(hipMalloc((void**)&c->d_coll, sizeof(uint64_t) * 512));

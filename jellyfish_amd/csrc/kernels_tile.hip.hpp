@@ -300,10 +300,17 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
     lds_barrier();
     JF_PHASE(pc, 3);
   };
-  auto recount = [&]() {      // a further round of the same unit: the counters no longer know about merged and claimed slots
+  // a further round of the same unit: the counters no longer know about merged and claimed slots, and phase C may have
+  // left holes inside buckets (ranks need them filled front to back): merge, compact, count
+  auto recount = [&](uint64_t unit_slot0) {
     for(uint32_t b = threadIdx.x; b < nbkt; b += BLOCK) {
       SLOT w[4];
       load_bucket(b << kBucketBits, w);
+      if(has_dups(w) || ((w[1] == 0) & ((w[2] | w[3]) != 0)) || ((w[2] == 0) & (w[3] != 0))) {
+        merge_bucket(w, unit_slot0 + ((uint64_t)b << kBucketBits));
+#pragma unroll
+        for(int q = 0; q < 4; ++q) s_tile[((size_t)b << kBucketBits) + q] = w[q];
+      }
       reinterpret_cast<uint16_t*>(s_cnt)[b] = (uint16_t)((w[0] != 0) + (w[1] != 0) + (w[2] != 0) + (w[3] != 0));
     }
     lds_barrier();
@@ -358,7 +365,7 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
 #pragma unroll
     for(int r = 0; r < NP; ++r)
       if((uint32_t)r * BLOCK + tid < n0 && !(holes && cur[r] == hole)) vm |= 1u << r;      // (what a clamped load fetched is not an item)
-    if(!first) recount();
+    if(!first) recount(unit_slot0);
     else if(d0) { load_tile(gt, d0); lds_barrier(); }       // (otherwise the previous store left tile and counters zeroed)
     uint32_t old[NP];
     rank_request(cur, vm, old);

@@ -571,6 +571,39 @@ def test_count_gpus_1_goes_through_the_ranks_machinery(cli, tmp_path, self_rccl)
         assert r.returncode != 0 and b"--gpus" in r.stderr
 
 
+@pytest.mark.parametrize("world,items", [(2, "2"), (4, "2"), (2, "0")])
+def test_count_gpus_n_as_rank_processes_on_one_device(cli, tmp_path, world, items):
+    """`count --gpus 2 / 4` as REAL rank processes (the command forks them; rendezvous directory; every rank reads its part
+    of the file, routes by hash prefix, exchanges, writes its records at its offset of the common file) -- on this box's
+    single GPU through the inter-process transport (JFGPU_COMM_TRANSPORT=ipc: hipIpc* copies between the ranks' device
+    buffers, host-level collectives in shared memory).  Item path (JFGPU_COMM_ITEMS=2) and key path (=0).  File body,
+    digest and stats equal the single-process run's."""
+    import random
+    rng = random.Random(17 + world)
+    fa = tmp_path / "reads.fa"
+    with open(fa, "wb") as f:
+        for r in range(6000):
+            f.write((">r%d\n%s\n" % (r, "".join(rng.choice("ACGT") for _ in range(150)))).encode())
+    ref, out = str(tmp_path / "ref.jf"), str(tmp_path / "gN.jf")
+    dg0, dg1 = str(tmp_path / "d0.txt"), str(tmp_path / "d1.txt")
+    subprocess.check_call([cli, "count", "-m", "21", "-C", "-s", "64M", "-o", ref, "--digest", dg0, str(fa)])
+    env = dict(os.environ, JFGPU_COMM_TRANSPORT="ipc", JFGPU_COMM_ITEMS=items, JFGPU_PARSE_CHUNK="150000", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    subprocess.check_call([cli, "count", "-m", "21", "-C", "-s", "64M", "-o", out, "--digest", dg1, "--gpus", str(world), str(fa)], env=env, timeout=900)
+    assert open(dg0).read() == open(dg1).read()
+    assert _body(out) == _body(ref) and len(_body(ref)) > 0
+    assert subprocess.check_output([cli, "stats", out]) == subprocess.check_output([cli, "stats", ref])
+
+
+def test_a_failing_rank_ends_the_others(cli, tmp_path):
+    """One rank of `count --gpus 2` cannot read its input (the file disappears for rank 1 only: JFGPU_TEST_FAIL_RANK): the
+    command must come back with an error instead of leaving the other rank waiting in a collective."""
+    fa = tmp_path / "reads.fa"
+    fa.write_bytes(b">r\n" + b"ACGT" * 5000 + b"\n")
+    env = dict(os.environ, JFGPU_COMM_TRANSPORT="ipc", JFGPU_TEST_FAIL_RANK="1")
+    r = subprocess.run([cli, "count", "-m", "21", "-C", "-s", "64M", "-o", str(tmp_path / "x.jf"), "--gpus", "2", str(fa)], env=env, capture_output=True, timeout=300)
+    assert r.returncode != 0
+
+
 def test_pipes_are_read_in_pieces_of_whole_records(cli, tmp_path):
     """Input that cannot be mapped (a pipe: `zcat reads.fa.gz |`, generator commands) used to be read whole into memory
     before anything was parsed; it is now handed over in pieces that end where a record starts.  With pieces of 700 bytes

@@ -515,6 +515,8 @@ MODES = {"direct": 1, "partitioned": 2}
     (16, True, 250000, "AT", 1 << 20),         # duplicates: LDS aggregation + run-length bypass
     (21, False, 100000, "A", 1 << 16),         # one k-mer 99980 times: all through the run bypass
     (13, True, 400000, "ACGT", 1 << 26),       # 4^13 = 2^26: identity matrix, rem_bits = 0
+    (8, True, 1200000, "ACGT", 1 << 16),       # 8 tiles, 32896 k-mers ~36 times each: many rounds per tile, queue overflow, merges
+    (21, True, 600000, "AC", 1 << 25),         # two-level, repeats spread over many tiles
 ])
 def test_modes_match_oracle(gpu, mode, k, canonical, n, alphabet, size):
     rng = random.Random(k * 7 + n)
