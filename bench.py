@@ -218,6 +218,9 @@ def main():
     if not args.gbp:
         args.gbp = GBP_PER_GPU_SHARDED if args.gpus > 1 else 10.0
 
+    import faulthandler
+    import signal
+    faulthandler.register(signal.SIGUSR1, all_threads=True)     # kill -USR1 <pid>: where a stuck run is waiting
     import numpy as np
     from jellyfish_amd import capi
     import torch

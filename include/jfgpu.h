@@ -41,7 +41,7 @@ enum {
   JFGPU_E_ALLOC = 3,      /* large_hash::array::ErrorAllocation, large_hash_array.hpp:55,169-172 */
   JFGPU_E_FULL = 4,       /* std::runtime_error("Hash full"), hash_counter.hpp:194-195 */
   JFGPU_E_HIP = 5,        /* HIP runtime error */
-  JFGPU_E_UNSUPPORTED = 6,/* feature not built yet (e.g. k > 32) */
+  JFGPU_E_UNSUPPORTED = 6,/* combination not built (e.g. k > 128, a sharded table for k > 32) */
   JFGPU_E_FORMAT = 7      /* device parser: chunk is not in the strict layout it handles; give it to the host parser */
 };
 
@@ -51,7 +51,8 @@ typedef struct jfgpu_table jfgpu_table; /* opaque: one hash shard resident in on
  * (hash_counter.hpp:56-64, large_hash_array.hpp:992-1001) minus the CPU-only knobs
  * (nb_threads, reprobe schedule: the in-memory probing is never serialised). */
 typedef struct jfgpu_params {
-  uint32_t k;            /* mer length; key_len = 2k bits.  1..32 today */
+  uint32_t k;            /* mer length; key_len = 2k bits.  1..128 (one to four 64-bit key words; the reference's
+                            mer_dna takes any length, mer_dna.hpp:711-717 -- longer is JFGPU_E_UNSUPPORTED here) */
   uint32_t canonical;    /* count_main.cc -C: count min(mer, revcomp) */
   uint64_t size;         /* requested GLOBAL number of slots (hint: rounded up to a power of
                             two, capped at 4^k, raised to the engine minimum for large k) */
@@ -78,7 +79,7 @@ typedef struct jfgpu_info {
   uint64_t local_size;       /* slots held by this shard */
   uint32_t shard_bits, shard_id;
   uint32_t val_len;          /* bits of the in-slot count field -> header "val_len" */
-  uint32_t slot_bytes;       /* 8 */
+  uint32_t slot_bytes;       /* 4 or 8 (one-word keys), 16 (two words), 32 (three and four) */
   uint32_t tile_slots;       /* probe domain (slots) */
   uint32_t matrix_identity;  /* 1 when size == 4^k (large_hash_array.hpp:997-1000) */
   uint32_t out_counter_len;
@@ -246,7 +247,7 @@ int  jfgpu_attach_bloom(jfgpu_table* t, jfgpu_bloom* b);
  * creation is a hint, the table doubles itself (device-side rehash, one more matrix row) before it
  * could exceed 80 % load, as long as device memory allows; jfgpu_get_info / jfgpu_get_matrix report
  * the current geometry.  Off: a full table is the deferred error "Hash full".  Unsharded tables
- * only for now (one- and two-word keys). */
+ * only (a shard of a multi-GPU table reports "Hash full": give count --gpus a size that fits). */
 int  jfgpu_set_growth(jfgpu_table* t, int on);
 
 /* The matrix a table gets when jfgpu_params gives neither matrix_columns nor matrix_seed: the one the

@@ -5,8 +5,8 @@ Layout (only what the path needs):
   lib/       built libjfgpu.so (git-ignored; `make engine`)
   include/   C++ facade mirroring the reference API (mer_dna, hash_counter, file_header, dumpers)
   cli/       `jellyfish-amd count|dump|histo|stats|query|info` host program
-  capi.py    ctypes plumbing over the C ABI for tests/ and bench.py
-  dist.py    one-process-per-GPU hash-prefix sharding over torch.distributed (RCCL)
+  capi.py    ctypes plumbing over the C ABI for tests/ and bench.py (multi-GPU: jfgpu_comm_* under the same ABI)
+  compat/    namespace jellyfish headers the reference's client sources compile against
 """
 from . import capi  # noqa: F401
 

@@ -249,6 +249,7 @@ int comm_insert_prev_items(jfgpu_comm* c, jfgpu_comm::Rank& R, int rank) {
     S.off[p] = r_offs + (int64_t)p * 2 * L.nbc - 2 * first;
     S.sh[p] = 1;
   }
+  { int rc = refresh_d_dt(t); if(rc) return rc; }
   PartGeom pd = t->pg;                                     // direct inserts of (coarse bucket, item)
   pd.b1 = L.cbits; pd.b2 = t->g.lsize_l - t->g.tile_bits - L.cbits;
   const uint32_t split_at = t->g.key_bits - L.gbits - sb;  // where those bits sit in a routed item (its top bits)
@@ -260,8 +261,8 @@ int comm_insert_prev_items(jfgpu_comm* c, jfgpu_comm::Rank& R, int rank) {
     unsigned int* gc_v = gcur - dshift; unsigned int* gs_v = gcur + nb - dshift;
     uint32_t* out_v = reinterpret_cast<uint32_t*>(b.items) - dshift * (int64_t)cap2;
     unsigned long long* tot_v = b.tot - dshift;
-    if(t->returning) hipLaunchKernelGGL((p2_granule_kernel<uint32_t, TableDirect<true>, kP2PairPer, true>), grid, block, lds, t->stream, TableDirect<true>{t->dt, pd}, sb, split_at, S, cap2, gc_v, gs_v, out_v, (uint32_t)first, tot_v, L.nbc - 1);
-    else             hipLaunchKernelGGL((p2_granule_kernel<uint32_t, TableDirect<false>, kP2PairPer, true>), grid, block, lds, t->stream, TableDirect<false>{t->dt, pd}, sb, split_at, S, cap2, gc_v, gs_v, out_v, (uint32_t)first, tot_v, L.nbc - 1);
+    if(t->returning) hipLaunchKernelGGL((p2_granule_kernel<uint32_t, TableDirect<true>, kP2PairPer, true>), grid, block, lds, t->stream, TableDirect<true>{t->d_dt, pd, (unsigned long long*)&t->dt.counters[CTR_DIRECT]}, sb, split_at, S, cap2, gc_v, gs_v, out_v, (uint32_t)first, tot_v, L.nbc - 1);
+    else             hipLaunchKernelGGL((p2_granule_kernel<uint32_t, TableDirect<false>, kP2PairPer, true>), grid, block, lds, t->stream, TableDirect<false>{t->d_dt, pd, (unsigned long long*)&t->dt.counters[CTR_DIRECT]}, sb, split_at, S, cap2, gc_v, gs_v, out_v, (uint32_t)first, tot_v, L.nbc - 1);
     hipLaunchKernelGGL(granule_finish_kernel, dim3(4), dim3(256), 0, t->stream, gcur, cap2, nb, b.off);
     for(int p = 0; p < W; ++p) {
       const uint64_t* lst = r_strag + (size_t)p * (1 + L.S);
@@ -700,6 +701,9 @@ void ipc_detach(jfgpu_comm* c) {
   if(last) shm_unlink(c->shm_name.c_str());
   c->shm = nullptr;
 }
+#else
+int comm_exchange_ipc(jfgpu_comm*) { return fail(JFGPU_E_UNSUPPORTED, "no inter-process transport in the emulated build"); }
+int comm_exchange_items_ipc(jfgpu_comm*) { return fail(JFGPU_E_UNSUPPORTED, "no inter-process transport in the emulated build"); }
 #endif
 
 void comm_free_rank(jfgpu_comm::Rank& R) {

@@ -24,6 +24,15 @@ void part_geom_init(jfgpu_table* t) {
 
 size_t item_size(const jfgpu_table* t) { return t->item128 ? 16 : t->item32 ? 4 : 8; }
 
+// The table's descriptor in device memory, for kernels that leave their hot loop through a real call (item_direct_call):
+// refreshed in stream order before every launch that uses it.
+int refresh_d_dt(jfgpu_table* t) {
+  if(!t->d_dt) HIP_TRY(hipMalloc((void**)&t->d_dt, sizeof(DevTable)));
+  HIP_TRY(hipMemcpyAsync(t->d_dt, &t->dt, sizeof(DevTable), hipMemcpyHostToDevice, t->stream));
+  return JFGPU_OK;
+}
+
+
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -183,8 +192,10 @@ int part_ingest(jfgpu_table* t, const uint8_t* base, int64_t lo, int64_t hi, boo
       else if(t->g.nbytes == 8) PK(false, 8);
       else PK(false, 0);
     } else
-#define PG(RT, BL, N) hipLaunchKernelGGL((p1_scatter_granule_kernel<RT, BL, N>), dim3(t->g1), dim3(kPBlock), lds, t->stream, t->dt, t->pg, base, lo, hi, gcap, gcur, b.tot, (uint32_t*)b.items)
+#define PG(RT, BL, N) hipLaunchKernelGGL((p1_ring_kernel<RT, BL, N>), dim3(t->n_cu), dim3(kPBlock), (size_t)nb * kRingSlots * 4, t->stream, t->dt, t->d_dt, t->pg, base, lo, hi, gcap, gcur, b.tot, (uint32_t*)b.items)
     {
+      // the rare direct inserts read the table's descriptor from device memory (kernels_p1ring.hip.hpp)
+      { int rc = refresh_d_dt(t); if(rc) return rc; }
       if(bl) { if(t->returning) PG(true, true, 0); else PG(false, true, 0); }
       else if(t->returning) {       // narrow count fields (32-bit slots among them): same kernels, overflow-aware direct inserts
         if(t->g.nbytes == 6) PG(true, false, 6); else if(t->g.nbytes == 7) PG(true, false, 7); else if(t->g.nbytes == 8) PG(true, false, 8); else PG(true, false, 0);
@@ -269,6 +280,7 @@ int part_flush_t(jfgpu_table* t) {
     if(in_bytes >= (1u << 20)) t->items_per_byte = (double)in_items / (double)in_bytes;
   }
   const uint64_t n_tiles = n_tiles_of(t);
+  if constexpr(!(sizeof(ITEM) == 16)) { int rc = refresh_d_dt(t); if(rc) return rc; }
   SegList S1; memset(&S1, 0, sizeof S1);
   S1.n = (uint32_t)nbatch;
   for(size_t s = 0; s < nbatch; ++s) { S1.items[s] = t->pending[s].items; S1.off[s] = t->pending[s].off; S1.sh[s] = t->pending[s].gran_cap ? 1 : 0; }
@@ -443,8 +455,8 @@ int part_flush_t(jfgpu_table* t) {
           ITEM* out_v = out2 - (share_groups ? (int64_t)d0 * (int64_t)cap2 : 0);
           if constexpr(sizeof(ITEM) == 4) {
             const size_t lds = (size_t)kPBlock * kP2PairPer * sizeof(ITEM);
-            if(rt) hipLaunchKernelGGL((p2_granule_kernel<uint32_t, TableDirect<true>, kP2PairPer>), g1p, block, lds, t->stream, TableDirect<true>{t->dt, t->pg}, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest, (uint32_t*)out_v, b0);
-            else   hipLaunchKernelGGL((p2_granule_kernel<uint32_t, TableDirect<false>, kP2PairPer>), g1p, block, lds, t->stream, TableDirect<false>{t->dt, t->pg}, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest, (uint32_t*)out_v, b0);
+            if(rt) hipLaunchKernelGGL((p2_granule_kernel<uint32_t, TableDirect<true>, kP2PairPer>), g1p, block, lds, t->stream, TableDirect<true>{t->d_dt, t->pg, (unsigned long long*)&t->dt.counters[CTR_DIRECT]}, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest, (uint32_t*)out_v, b0);
+            else   hipLaunchKernelGGL((p2_granule_kernel<uint32_t, TableDirect<false>, kP2PairPer>), g1p, block, lds, t->stream, TableDirect<false>{t->d_dt, t->pg, (unsigned long long*)&t->dt.counters[CTR_DIRECT]}, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest, (uint32_t*)out_v, b0);
           } else {
             const size_t lds = (size_t)kPBlock * kP2WidePer * sizeof(ITEM);
             if(rt) hipLaunchKernelGGL((p2_granule_kernel<u128, WideDirect<true>, kP2WidePer>), g1p, block, lds, t->stream, WideDirect<true>{t->wt, t->pg}, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest, (u128*)out_v, b0);

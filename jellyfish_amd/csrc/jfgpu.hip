@@ -19,6 +19,7 @@
 #include "kernels.hip.hpp"
 #include "kernels_part.hip.hpp"
 #include "kernels_tile.hip.hpp"
+#include "kernels_p1ring.hip.hpp"
 #include "kernels_bloom.hip.hpp"
 #include "kernels_bloom_part.hip.hpp"
 #include "kernels_wide.hip.hpp"
@@ -71,6 +72,7 @@ struct jfgpu_table {
   int n_cu = 256;
   hipStream_t stream = nullptr;
   DevTable dt{};
+  DevTable* d_dt = nullptr;      // a copy of dt in device memory for kernels that call out of line with it (refreshed before every such launch)
   uint64_t* d_fwd = nullptr;
   uint64_t* d_inv = nullptr;
   uint64_t ovf_cap = 0;
@@ -622,7 +624,7 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_sorted_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
 #define PATTR(N) HIP_TRY(hipFuncSetAttribute((const void*)p1_keys_scatter_sorted_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6)); \
                  HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_sorted_kernel<false, false, N>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6)); \
-                 HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_granule_kernel<false, false, N>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6))
+                 HIP_TRY(hipFuncSetAttribute((const void*)p1_ring_kernel<false, false, N>, hipFuncAttributeMaxDynamicSharedMemorySize, kGranMaxB * kRingSlots * 4))
     PATTR(0); PATTR(6); PATTR(7); PATTR(8);
 #undef PATTR
     HIP_TRY(hipFuncSetAttribute((const void*)p1_keys_granule_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
@@ -630,12 +632,12 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     HIP_TRY(hipFuncSetAttribute((const void*)p1_keys_granule_kernel<false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_keys_granule_kernel<false, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_keys_granule_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
-    HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_granule_kernel<true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
-    HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_granule_kernel<true, false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
-    HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_granule_kernel<true, false, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
-    HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_granule_kernel<true, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
-    HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_granule_kernel<false, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
-    HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_granule_kernel<true, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_ring_kernel<true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kGranMaxB * kRingSlots * 4));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_ring_kernel<true, false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, kGranMaxB * kRingSlots * 4));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_ring_kernel<true, false, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kGranMaxB * kRingSlots * 4));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_ring_kernel<true, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kGranMaxB * kRingSlots * 4));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_ring_kernel<false, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kGranMaxB * kRingSlots * 4));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_ring_kernel<true, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kGranMaxB * kRingSlots * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint32_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * 16 * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_route_granule_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_route_granule_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
@@ -679,6 +681,7 @@ void jfgpu_destroy(jfgpu_table* t) {
   prof_collect(t);
   for(auto e : t->ev_pool) hipEventDestroy(e);
   hipFree(t->dt.slots); hipFree(t->d_fwd); hipFree(t->d_inv);
+  if(t->d_dt) hipFree(t->d_dt);
   hipFree(t->dt.ovf_key); hipFree(t->dt.ovf_cnt); hipFree(t->dt.counters); hipFree(t->dt.dirty);
   for(int i = 0; i < 2; ++i) { if(t->d_stage[i]) hipFree(t->d_stage[i]); if(t->stage_done[i]) hipEventDestroy(t->stage_done[i]); }
   if(t->d_dump) hipFree(t->d_dump);
@@ -734,8 +737,8 @@ int jfgpu_sync(jfgpu_table* t) {
 #ifdef JFGPU_PHASE_PROF
   { unsigned long long c[24], z[24] = {0};
     if(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_phase_prof), sizeof c) == hipSuccess) {
-      fprintf(stderr, "[phase prof] P1: stage %llu  encode+hash+hist %llu  scan %llu  place+lds-scatter %llu  (barrier) %llu  write-out %llu  finish %llu\n",
-              c[0], c[1], c[2], c[3], c[4], c[5], c[6]);
+      fprintf(stderr, "[phase prof] P1 (ring): stage %llu  encode+hash+append %llu  (barrier) %llu  units out %llu  finish %llu\n",
+              c[0], c[1], c[2], c[3], c[4]);
       fprintf(stderr, "[phase prof] P2: (barrier) %llu  load %llu  hist %llu  scan %llu  lds-scatter %llu  write-out %llu  finish %llu\n",
               c[8], c[9], c[10], c[11], c[12], c[13], c[14]);
       fprintf(stderr, "[phase prof] T: loop+offsets %llu  rank adds + fill %llu  place %llu  queue (wave 0's own) %llu  (its wait for the others) %llu  merge + store %llu\n",
@@ -759,14 +762,14 @@ int jfgpu_wait(jfgpu_table* t) {
 
 int jfgpu_count_ascii_dev(jfgpu_table* t, const char* d_bases, size_t n) {
   int rc = use(t); if(rc) return rc;
-  if(t->g.shard_bits) return fail(JFGPU_E_INVALID, "sharded table: route k-mers with jfgpu_partition_ascii_dev + jfgpu_add_keys_dev");
+  if(t->g.shard_bits) return fail(JFGPU_E_INVALID, "sharded table: count through its communicator (jfgpu_comm_count_ascii_dev)");
   if(!d_bases && n) return fail(JFGPU_E_INVALID, "null buffer");
   return launch_count(t, d_bases, n);
 }
 
 int jfgpu_count_ascii(jfgpu_table* t, const char* bases, size_t n) {
   int rc = use(t); if(rc) return rc;
-  if(t->g.shard_bits) return fail(JFGPU_E_INVALID, "sharded table: route k-mers with jfgpu_partition_ascii_dev + jfgpu_add_keys_dev");
+  if(t->g.shard_bits) return fail(JFGPU_E_INVALID, "sharded table: count through its communicator (jfgpu_comm_count_ascii_dev)");
   if(!bases && n) return fail(JFGPU_E_INVALID, "null buffer");
   if(n < t->g.k) return JFGPU_OK;
   rc = ensure_stage(t); if(rc) return rc;

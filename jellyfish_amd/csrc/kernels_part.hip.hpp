@@ -891,11 +891,42 @@ __global__ __launch_bounds__(kPBlock) void p1_keys_granule_kernel(DevTable T, Pa
 // grid = (G2, buckets): blockIdx.y is the P1 bucket, blockIdx.x a contiguous slice of its items.  gcur / gshort / out are
 // indexed by destination = bucket * 2^b2e + sub-bucket.
 // What to do with an item that cannot be stored in its region: one-word keys (32-bit items) -- the table's global claim.
+// The rare ways out of the partition (an item that would read as a hole, a ring or a region that is full, a run of
+// identical consecutive k-mers) as ONE real function: inlined at every site, item_direct_insert keeps a few dozen scalars
+// of the table alive through the whole hot loop (the kernel then spills scalar registers) and multiplies the code.
+// T: the table's descriptor in device memory (taking the address of a kernel's by-value copy would put it in scratch).
+__device__ __attribute__((noinline)) void item_direct_call(const DevTable* T, uint32_t b2, uint32_t b, uint64_t item, uint32_t cnt, int returning) {
+  const TableGeom& g = T->g;
+  const uint32_t tmask = (uint32_t)g.tile_mask;
+  const uint64_t it = item;
+  const uint64_t tag = it & (g.occ_bit - 1);
+  const uint64_t tile = ((uint64_t)b << b2) | ((it >> g.tag_bits) & ((1ull << b2) - 1));
+  const uint64_t tile_base = tile << g.tile_bits;
+  const uint32_t idx0 = (uint32_t)(tag >> g.rem_bits);
+  { uint8_t* d = &T->dirty[tile]; if(!*d) *d = 1; }
+  const uint64_t low = g.occ_bit | tag, add = (uint64_t)cnt << (g.tag_bits + 1), neww = add | low;
+  for(uint32_t p = 0; p <= T->max_probe; ++p) {
+    const uint64_t slot = tile_base + probe_lin(idx0, p, tmask);
+    const uint64_t old = slot_cas(*T, slot, 0, neww);
+    if(old == 0ull) return;
+    if((old & g.low_mask) == low) {
+      if(returning) {
+        const uint64_t prev = slot_add_rtn(*T, slot, add);
+        if((prev >> (g.tag_bits + 1)) + cnt > g.cnt_max) ovf_add(*T, slot, 1);
+      } else slot_add(*T, slot, add);
+      return;
+    }
+  }
+  atomicAdd((unsigned long long*)&T->counters[CTR_FULL], 1ull);
+}
+
+// What to do with an item that cannot be stored in its region: one-word keys -- the table's global claim, out of line,
+// reading the table's descriptor from device memory (Tm).
 template <bool RETURNING>
 struct TableDirect {
-  DevTable T; PartGeom P;
-  __device__ void operator()(uint32_t bucket, uint32_t item) const { item_direct_insert<RETURNING>(T, P, bucket, (uint64_t)item); }
-  __device__ unsigned long long* direct_counter() const { return (unsigned long long*)&T.counters[CTR_DIRECT]; }
+  const DevTable* Tm; PartGeom P; unsigned long long* ctr_direct;
+  __device__ void operator()(uint32_t bucket, uint64_t item) const { item_direct_call(Tm, P.b2, bucket, item, 1, RETURNING ? 1 : 0); }
+  __device__ unsigned long long* direct_counter() const { return ctr_direct; }
 };
 
 // ITEM: uint32_t or unsigned __int128; DIRECT: see TableDirect (kernels_wide_part.hip.hpp has the two-word one).

@@ -300,22 +300,6 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
     lds_barrier();
     JF_PHASE(pc, 3);
   };
-  // a further round of the same unit: the counters no longer know about merged and claimed slots, and phase C may have
-  // left holes inside buckets (ranks need them filled front to back): merge, compact, count
-  auto recount = [&](uint64_t unit_slot0) {
-    for(uint32_t b = threadIdx.x; b < nbkt; b += BLOCK) {
-      SLOT w[4];
-      load_bucket(b << kBucketBits, w);
-      if(has_dups(w) || ((w[1] == 0) & ((w[2] | w[3]) != 0)) || ((w[2] == 0) & (w[3] != 0))) {
-        merge_bucket(w, unit_slot0 + ((uint64_t)b << kBucketBits));
-#pragma unroll
-        for(int q = 0; q < 4; ++q) s_tile[((size_t)b << kBucketBits) + q] = w[q];
-      }
-      reinterpret_cast<uint16_t*>(s_cnt)[b] = (uint16_t)((w[0] != 0) + (w[1] != 0) + (w[2] != 0) + (w[3] != 0));
-    }
-    lds_barrier();
-  };
-
   zero_counters();
   zero_tile();
   lds_barrier();
@@ -365,20 +349,21 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
 #pragma unroll
     for(int r = 0; r < NP; ++r)
       if((uint32_t)r * BLOCK + tid < n0 && !(holes && cur[r] == hole)) vm |= 1u << r;      // (what a clamped load fetched is not an item)
-    if(!first) recount(unit_slot0);
-    else if(d0) { load_tile(gt, d0); lds_barrier(); }       // (otherwise the previous store left tile and counters zeroed)
+    // a further round of the same unit (more than 9216 items: skewed input) starts from the tile as the previous round
+    // stored it -- merged, compacted, counted again on the way in -- by the lanes that stored it
+    const uint32_t d_eff = first ? d0 : (TPB == 2 ? 0x0101u : 1u);
+    if(d_eff) { load_tile(gt, d_eff); lds_barrier(); }       // (otherwise the previous store left tile and counters zeroed)
     uint32_t old[NP];
     rank_request(cur, vm, old);
     JF_PHASE(pc, 1);
     uint64_t a2 = 0, b2 = 0; uint32_t d2 = 0;
     if(last && t + 2 * G < n_tiles) { a2 = off[(size_t)(t + 2 * G) << sh]; b2 = off[((size_t)(t + 2 * G) << sh) + 1]; d2 = unit_dirty(t + 2 * G); }
     place_round(cur, vm, old, unit_slot0, src + c0, [&] { if(last) fetch(a1, b1); else fetch(c0 + kRound, b0); });
-    if(last) {
-      store_tile(gt, t, unit_slot0);                          // (every round ends on a barrier)
-      lds_barrier();
-      JF_PHASE(pc, 4);
-      t += G; a0 = a1; b0 = b1; d0 = d1; a1 = a2; b1 = b2; d1 = d2; c0 = a0;
-    } else c0 += kRound;
+    store_tile(gt, t, unit_slot0);                            // (every round ends on a barrier)
+    lds_barrier();
+    JF_PHASE(pc, 4);
+    if(last) { t += G; a0 = a1; b0 = b1; d0 = d1; a1 = a2; b1 = b2; d1 = d2; c0 = a0; }
+    else c0 += kRound;
   }
   JF_PHASE_FLUSH(pc, 16);
 }
