@@ -400,16 +400,16 @@ def main():
         value = total_kmers / elapsed
         whole_bpk = sum(B.values())          # C3: both passes touch every k-mer
         # HBM bytes per launch of the named kernel: PMC counters cannot be read from inside this process, so the figure
-        # comes from the committed rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this same command (profiles/r02_traffic_<cfg>.json,
+        # comes from the committed rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this same command (profiles/r03_traffic_<cfg>.json,
         # made by tools/profile_bench.sh); quoted whenever workload and kernel match, whatever --steps is (traffic per
         # job does not depend on how the input is cut into batches -- it is scaled to this run's launch count)
         traffic, traffic_src = None, None
-        tj = os.path.join(ROOT, "profiles", "r02_traffic_%s.json" % cfg)
+        tj = os.path.join(ROOT, "profiles", "r03_traffic_%s.json" % cfg)
         if os.path.exists(tj) and world == 1 and not force_dist and args.dist == "U":
             rec = json.load(open(tj))
             if abs(rec.get("gbp", 0) - args.gbp) < 1e-9 and rec.get("lsize") == lsize and dom in rec.get("per_job_bytes", {}):
                 traffic = rec["per_job_bytes"][dom] / max(launches, 1)
-                traffic_src = "profiles/r02_traffic_%s.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, same command): bytes per job / %d launches" % (cfg, launches)
+                traffic_src = "profiles/r03_traffic_%s.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, same command): bytes per job / %d launches" % (cfg, launches)
         out = {
             "metric": "k-mers/sec at k=%d canonical, 150 bp synthetic reads, bit-exact counts" % K,
             "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": steps, "warmup": warmup,

@@ -815,8 +815,11 @@ int jfgpu_comm_count_ascii_dev(jfgpu_comm* c, jfgpu_table* t, const char* d_base
   if((int)t->g.shard_id != c->rank) return fail(JFGPU_E_INVALID, "table shard_id is not this communicator's rank");
   jfgpu_comm::Rank& R = c->ranks[0];
   R.t = t;
+  rc = ensure_ovf(t, (uint64_t)n * (uint64_t)c->world, 0); if(rc) return rc;      // (what may arrive for this shard: about a world's worth of one rank's input)
   // item path or keys?  every rank says what region capacity it wants (0: keys); one "keys" decides for all
-  uint64_t v[2] = {items_cap_wanted(c, R, n) == 0 ? 1ull : 0ull, items_cap_wanted(c, R, n)};
+  // (a rank that has run out of input has no preference: it must not push the others onto the key path)
+  const uint32_t want = items_cap_wanted(c, R, n);
+  uint64_t v[2] = {(!items_geometry_ok(c, t) || (want == 0 && n >= t->g.k)) ? 1ull : 0ull, want};
   rc = jfgpu_comm_allreduce_u64(c, v, 2, 1); if(rc) return rc;
   uint32_t cap = v[0] ? 0u : (uint32_t)v[1];
   uint64_t routed = 0;
@@ -847,11 +850,12 @@ int jfgpu_comm_local_step(jfgpu_comm* c, jfgpu_table** tables, const char* const
     int rc = use(tables[r]); if(rc) return rc;
     if((int)tables[r]->g.shard_id != r) return fail(JFGPU_E_INVALID, "tables must be given in shard order");
     c->ranks[r].t = tables[r];
+    { uint64_t all = 0; for(int q = 0; q < c->world; ++q) all += n[q]; rc = ensure_ovf(tables[r], all, 0); if(rc) return rc; }
     const uint32_t w = items_cap_wanted(c, c->ranks[r], n[r]);
-    if(!w) cap = 0;
+    if(!items_geometry_ok(c, tables[r]) || (!w && n[r] >= tables[r]->g.k)) cap = 0;      // (a rank without input has no preference)
     want_max = std::max(want_max, w);
   }
-  if(cap) cap = want_max;
+  if(cap) cap = want_max;                                  // (0 when nobody has input: the key path with nothing to send)
   if(cap) {
     bool any_overflow = false;
     std::vector<uint64_t> routed(c->world, 0);

@@ -83,7 +83,7 @@ void launch_p1(jfgpu_table* t, bool scatter, bool from_keys, const uint8_t* base
 
 int part_flush(jfgpu_table* t);
 
-// Single-pass P1 (p1_scatter_granule_kernel): items per bucket region, 0 when the batch takes the exact
+// Single-pass P1 (p1_ring_kernel, p1_granule64_kernel, p1_keys_granule_kernel, ...): items per bucket region, 0 when the batch takes the exact
 // two-pass scheme.  Every block may strand part of one reservation per bucket, so small batches would be
 // mostly holes: auto mode wants the mean bucket load to be at least 4x that.
 uint32_t granule_cap(const jfgpu_table* t, bool from_keys, uint64_t max_items) {
@@ -161,7 +161,7 @@ int part_ingest(jfgpu_table* t, const uint8_t* base, int64_t lo, int64_t hi, boo
   b.off = (uint64_t*)ws_alloc(t, (2 * nb + 1) * sizeof(uint64_t));
   if(!b.items || !b.off) return fail(JFGPU_E_ALLOC, "partition workspace exhausted");
   if(gcap) {
-    // one pass: reservations of kGran items inside fixed bucket regions (p1_scatter_granule_kernel)
+    // one pass: reservations of kGran items inside fixed bucket regions
     unsigned int* gcur = (unsigned int*)ws_alloc(t, nb * 16);           // gcur[2 nb] (u32) then tot[nb] (u64)
     if(!gcur) return fail(JFGPU_E_ALLOC, "partition workspace exhausted");
     b.gran_cap = gcap; b.tot = (unsigned long long*)(gcur + 2 * nb);
@@ -556,9 +556,10 @@ int part_flush_t(jfgpu_table* t) {
 int part_flush(jfgpu_table* t) {
   if(t->pending.empty()) return JFGPU_OK;
   const int rc = t->item128 ? part_flush_t<u128>(t) : t->item32 ? part_flush_t<uint32_t>(t) : part_flush_t<uint64_t>(t);
-  if(rc) {      // report the failure once: what was pending is lost with it, the handle stays usable (jfgpu_clear not needed)
-    if(t->stream) hipStreamSynchronize(t->stream);
+  if(rc) {      // what was pending is lost with the failed flush: the table no longer holds what it was fed, and says so until
+    if(t->stream) hipStreamSynchronize(t->stream);      // it is cleared (jfgpu_clear), instead of carrying on with k-mers missing
     t->pending.clear(); t->pending_bytes = 0; t->ws_used = 0;
+    t->failed = rc; t->failed_msg = jfgpu_last_error();
   }
   return rc;
 }

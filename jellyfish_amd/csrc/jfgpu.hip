@@ -75,7 +75,10 @@ struct jfgpu_table {
   DevTable* d_dt = nullptr;      // a copy of dt in device memory for kernels that call out of line with it (refreshed before every such launch)
   uint64_t* d_fwd = nullptr;
   uint64_t* d_inv = nullptr;
+  int failed = 0; std::string failed_msg;   // a flush failed: every call reports it until jfgpu_clear (host_partition.inl: part_flush)
   uint64_t ovf_cap = 0;
+  // what the side table may have to hold: an entry needs 2^cnt_bits occurrences of its key, or one add of a large value
+  uint64_t occ_bound = 0, bigval_bound = 0;      // upper bounds since the last clear (ensure_ovf)
   bool returning = false;
   uint32_t out_counter_len = 4;
   // size doubling (hash_counter::do_size_doubling): occupancy bookkeeping, see ensure_capacity()
@@ -148,6 +151,7 @@ namespace {
 int use(const jfgpu_table* t) {
   if(!t) return fail(JFGPU_E_INVALID, "null table");
   HIP_TRY(hipSetDevice(t->device));
+  if(t->failed) return fail(t->failed, t->failed_msg + " (earlier; the table must be cleared)");
   return JFGPU_OK;
 }
 
@@ -220,8 +224,60 @@ void align_buffer(const char* d, size_t n, const uint8_t*& base, int64_t& lo, in
   base = (const uint8_t*)a; lo = (int64_t)(p - a); hi = lo + (int64_t)n;
 }
 
+// ---- the overflow side table grows with what it may have to hold -------------------------------------------------
+// A count field of cnt_bits bits wraps into the side table (ovf_add: one entry per key, units of 2^cnt_bits).  An entry
+// costs its key 2^cnt_bits occurrences (or one add of a value that large), so (occurrences fed >> cnt_bits) + large adds
+// bounds the entries whatever the input; the table is kept at twice that, rebuilt larger before the work that could
+// fill it is enqueued (the 32-bit slots of round 2 brought count fields of 8-10 bits: a fixed-size side table then
+// fails on repeat-rich input, where the reference just keeps counting: large_hash_array.hpp:887-937).
+__global__ void ovf_rehash_kernel(const uint64_t* __restrict__ okey, const uint64_t* __restrict__ ocnt, uint64_t ocap,
+                                  uint64_t* __restrict__ nkey, uint64_t* __restrict__ ncnt, uint64_t nmask, unsigned long long* __restrict__ lost) {
+  for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ocap; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t want = okey[i];
+    if(!want) continue;
+    const uint64_t h = ((want - 1) * 0x9E3779B97F4A7C15ull) >> 20;
+    bool placed = false;
+    for(uint64_t p = 0; p <= nmask && !placed; ++p) {
+      const uint64_t s = (h + p) & nmask;
+      const unsigned long long old = atomicCAS((unsigned long long*)&nkey[s], 0ull, (unsigned long long)want);
+      if(old == 0ull || old == want) { atomicAdd((unsigned long long*)&ncnt[s], (unsigned long long)ocnt[i]); placed = true; }
+    }
+    if(!placed) atomicAdd(lost, 1ull);
+  }
+}
+
+void refresh_views(jfgpu_table* t);     // the two- and N-word views of the table share its side table and counters
+
+int ensure_ovf(jfgpu_table* t, uint64_t more_occurrences, uint64_t more_big_adds) {
+  t->occ_bound += more_occurrences; t->bigval_bound += more_big_adds;
+  if(!t->returning) return JFGPU_OK;                              // count fields of 40 bits and more
+  const uint64_t need = 2 * ((t->occ_bound >> t->g.cnt_bits) + t->bigval_bound) + 4096;
+  if(need <= t->ovf_cap) return JFGPU_OK;
+  uint64_t cap2 = t->ovf_cap;
+  while(cap2 < 2 * need) cap2 <<= 1;                              // (room for the next few batches too)
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  if(t->stream2) HIP_TRY(hipStreamSynchronize(t->stream2));
+  uint64_t *nk = nullptr, *nc = nullptr;
+  if(hipMalloc((void**)&nk, cap2 * 8) != hipSuccess || hipMalloc((void**)&nc, cap2 * 8) != hipSuccess) {
+    if(nk) hipFree(nk);
+    (void)hipGetLastError();
+    return JFGPU_OK;                                              // no memory: carry on, CTR_OVF_FULL reports it if it really overflows
+  }
+  HIP_TRY(hipMemsetAsync(nk, 0, cap2 * 8, t->stream));
+  HIP_TRY(hipMemsetAsync(nc, 0, cap2 * 8, t->stream));
+  hipLaunchKernelGGL(ovf_rehash_kernel, dim3(grid_for(t, t->ovf_cap / kBlock + 1)), dim3(kBlock), 0, t->stream, t->dt.ovf_key, t->dt.ovf_cnt, t->ovf_cap, nk, nc, cap2 - 1,
+                     (unsigned long long*)&t->dt.counters[CTR_OVF_FULL]);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  hipFree(t->dt.ovf_key); hipFree(t->dt.ovf_cnt);
+  t->dt.ovf_key = nk; t->dt.ovf_cnt = nc; t->dt.ovf_mask = cap2 - 1; t->ovf_cap = cap2;
+  refresh_views(t);
+  return JFGPU_OK;
+}
+
 int launch_count_chunk(jfgpu_table* t, const char* d_bases, size_t n) {
   if(n < t->g.k) return JFGPU_OK;
+  { int rc = ensure_ovf(t, n, 0); if(rc) return rc; }
   const uint8_t* base; int64_t lo, hi;
   align_buffer(d_bases, n, base, lo, hi);
   if(t->nword) {
@@ -402,6 +458,8 @@ int table_grow(jfgpu_table* t) {
   const uint64_t n2 = 1ull << g2.lsize_l;
   const size_t slot_bytes = g2.slot32 ? 4 : 8 * (size_t)t->slot_words;
   uint64_t cap2 = std::max<uint64_t>(kMinOvf, std::min<uint64_t>(n2 / 256, 1ull << 26));
+  if(g2.cnt_bits < 40) cap2 = std::max<uint64_t>(cap2, 2 * ((t->occ_bound >> g2.cnt_bits) + t->bigval_bound) + 4096);      // (ensure_ovf's rule)
+  cap2 = std::max<uint64_t>(cap2, t->ovf_cap);
   { uint64_t x = 1; while(x < cap2) x <<= 1; cap2 = x; }
   DevTable nd = t->dt;
   nd.g = g2; nd.slots = nullptr; nd.ovf_key = nd.ovf_cnt = nullptr; nd.dirty = nullptr;
@@ -468,6 +526,11 @@ int table_grow(jfgpu_table* t) {
   t->pristine = false;
   ++t->grow_seed;
   return check_deferred(t);
+}
+
+void refresh_views(jfgpu_table* t) {
+  if(t->nword) { t->nt.ovf_key = t->dt.ovf_key; t->nt.ovf_cnt = t->dt.ovf_cnt; t->nt.ovf_mask = t->dt.ovf_mask; }
+  if(t->wide) { t->wt.ovf_key = t->dt.ovf_key; t->wt.ovf_cnt = t->dt.ovf_cnt; t->wt.ovf_mask = t->dt.ovf_mask; }
 }
 
 bool use_partitioned(const jfgpu_table* t, size_t nbytes) {
@@ -718,6 +781,7 @@ int jfgpu_get_matrix(const jfgpu_table* t, uint64_t* columns) {
 }
 
 int jfgpu_clear(jfgpu_table* t) {
+  if(t) { t->failed = 0; t->failed_msg.clear(); }              // (what a failed flush left behind goes with everything else)
   int rc = use(t); if(rc) return rc;
   part_discard(t);
   HIP_TRY(hipMemsetAsync(t->dt.slots, 0, (1ull << t->g.lsize_l) * slot_bytes_of(t), t->stream));
@@ -726,7 +790,7 @@ int jfgpu_clear(jfgpu_table* t) {
   HIP_TRY(hipMemsetAsync(t->dt.counters, 0, CTR_COUNT * sizeof(uint64_t), t->stream));
   HIP_TRY(hipMemsetAsync(t->dt.dirty, 0, (size_t)1 << (t->g.lsize_l - t->g.tile_bits), t->stream));
   HIP_TRY(hipStreamSynchronize(t->stream));
-  t->pristine = true; t->occ_known = 0; t->fed_since = 0; t->direct_seen = 0;
+  t->pristine = true; t->occ_known = 0; t->fed_since = 0; t->direct_seen = 0; t->occ_bound = 0; t->bigval_bound = 0;
   return JFGPU_OK;
 }
 
@@ -792,6 +856,8 @@ int jfgpu_count_ascii(jfgpu_table* t, const char* bases, size_t n) {
 static int add_keys_piece(jfgpu_table* t, const uint64_t* d_keys, size_t n, uint64_t val, uint8_t* d_is_new) {
   int rc = JFGPU_OK;
   if(!n) return JFGPU_OK;
+  { const bool big = t->g.cnt_bits < 64 && (val >> t->g.cnt_bits) != 0;
+    rc = ensure_ovf(t, big ? 0 : (uint64_t)n * val, big ? n : 0); if(rc) return rc; }
   if(t->nword) {
     ProfScope ps(t, 1, n);
     t->pristine = false;

@@ -15,6 +15,14 @@
 
 namespace jfgpu {
 
+// admission mask of count --bc (bit j <-> position j) in the bit order of the validity masks (bit 15 - j <-> position j)
+__device__ __forceinline__ uint32_t adm_to_vmask(uint32_t adm) {
+  uint32_t r = 0;
+#pragma unroll
+  for(int j = 0; j < 16; ++j) r |= ((adm >> j) & 1u) << (15 - j);
+  return r;
+}
+
 constexpr uint32_t kRingSlots = 32, kRingUnit = 16;      // items per ring and per emitted unit
 constexpr uint32_t kRingDirect = 0xFFFFFFFFu;            // a unit with nowhere to go in its region: inserted directly
 
@@ -117,45 +125,43 @@ __global__ __launch_bounds__(kPBlock) void p1_ring_kernel(DevTable T, const DevT
     const uint32_t adm = BLOOM ? bloom_admit_mask(T.bloom, g, L) : 0xFFFFu;
     uint64_t fw = (((uint64_t)L.p2 << 32) | L.p1) & g.key_mask;
     uint64_t rc = revcomp64(fw, k);
-    uint64_t prev = 0; uint32_t run = 0;
+    // which of the lane's 16 positions end a window of k valid bases: the invalid-base bits smeared over the k - 1
+    // positions after them, once per tile (bit 15 - j <-> position j, like inv48)
+    uint64_t smear = L.inv48;
+    for(uint32_t s = 1; s < k; ) { const uint32_t step = s < k - s ? s : k - s; smear |= smear >> step; s += step; }
+    const uint32_t rawmask = ~(uint32_t)smear & 0xFFFFu;
+    const uint32_t vmask = BLOOM ? (rawmask & adm_to_vmask(adm)) : rawmask;
+    my_mers += (uint32_t)__popc(rawmask);
+    // a k-mer is emitted one position late, when it is known whether the next one repeats it (homopolymers, tandem
+    // repeats: one insert for the run): pk / pv / run describe the position before
+    uint64_t pk = 0; uint32_t pv = 0, run = 0;
 #pragma unroll 1
     for(int j0 = 0; j0 < kPerLane; j0 += kPerLane / 2) {            // two rounds of eight positions per lane
-      constexpr int NE = kPerLane / 2 + 1;                          // k-mers a lane can emit in a round (the +1: the run closed at the tile's end)
-      uint64_t ek[NE]; uint32_t ec[NE]; uint32_t em = 0;           // emitted k-mers, how often (a run of identical consecutive ones), which
+      constexpr int NE = kPerLane / 2 + 1;                          // (the +1: the tile's last k-mer, emitted after the loop)
+      uint32_t eb[NE], ei[NE], eo[NE]; uint32_t em = 0;
+      auto emit = [&](int e, uint64_t key, uint32_t cnt) {
+        const uint64_t pos = hash_tables_t<NB>(s_fwd, key, g.nbytes);
+        const uint64_t local = pos & g.local_mask;
+        eb[e] = (uint32_t)(local >> bshift);
+        ei[e] = make_item<uint32_t>(g, P, key, local);
+        if(ei[e] == hole || cnt > 1) direct(eb[e], ei[e], cnt);      // (it would read as a hole; a run goes in at once)
+        else { eo[e] = atomicAdd(&s_fill[eb[e]], 1u); em |= 1u << e; }
+      };
 #pragma unroll
       for(int e = 0; e < kPerLane / 2; ++e) {
         const int j = j0 + e;
         const uint64_t c = (L.cur >> (2 * (15 - j))) & 3u;
         fw = ((fw << 2) | c) & g.key_mask;
         rc = (rc >> 2) | ((3ull - c) << rc_shift);
-        ek[e] = prev; ec[e] = run;
-        if(((L.inv48 >> (15 - j)) & kwin) == 0) {
-          ++my_mers;
-          if(!BLOOM || ((adm >> j) & 1u)) {
-            const uint64_t key = (g.canonical && rc < fw) ? rc : fw;
-            // runs of identical consecutive k-mers (homopolymers, tandem repeats): one insert for the run
-            if(run && key == prev) { ++run; continue; }
-            if(run) em |= 1u << e;
-            prev = key; run = 1;
-          }
-        }
+        const uint32_t v = (vmask >> (15 - j)) & 1u;
+        const uint64_t key = (g.canonical && rc < fw) ? rc : fw;
+        const bool same = v && pv && key == pk;
+        if(pv && !same) emit(e, pk, run);
+        run = same ? run + 1 : 1;
+        pk = key; pv = v;
       }
-      ek[NE - 1] = prev; ec[NE - 1] = run;
-      if(j0) { if(run) em |= 1u << (NE - 1); run = 0; }
-      // the appends, in two sweeps so that the ring stores do not wait for the fill adds one by one
-      uint32_t eb[NE], ei[NE], eo[NE];
-#pragma unroll
-      for(int e = 0; e < NE; ++e) {
-        eb[e] = 0; ei[e] = 0; eo[e] = 0;
-        if((em >> e) & 1) {
-          const uint64_t pos = hash_tables_t<NB>(s_fwd, ek[e], g.nbytes);
-          const uint64_t local = pos & g.local_mask;
-          eb[e] = (uint32_t)(local >> bshift);
-          ei[e] = make_item<uint32_t>(g, P, ek[e], local);
-          if(ei[e] == hole || ec[e] > 1) { direct(eb[e], ei[e], ec[e]); em &= ~(1u << e); }      // (it would read as a hole; a run goes in at once)
-          else eo[e] = atomicAdd(&s_fill[eb[e]], 1u);
-        }
-      }
+      if(j0) { if(pv) emit(NE - 1, pk, run); pv = 0; }
+      // (second sweep: the ring stores, once the fill adds are back -- not one wait per item)
 #pragma unroll
       for(int e = 0; e < NE; ++e)
         if((em >> e) & 1) {

@@ -696,68 +696,7 @@ __device__ inline void granule_finish(GranuleLds& G, uint32_t nb, uint32_t cap, 
   }
 }
 
-template <bool RETURNING, bool BLOOM, int NB>
-__global__ __launch_bounds__(kPBlock) void p1_scatter_granule_kernel(DevTable T, PartGeom P, const uint8_t* __restrict__ base,
-                                                                     int64_t lo, int64_t hi, uint32_t cap,
-                                                                     unsigned int* __restrict__ gcur,
-                                                                     unsigned long long* __restrict__ tot,
-                                                                     uint32_t* __restrict__ out) {
-  JF_DYN_LDS(s_dyn);
-  uint32_t* s_item = reinterpret_cast<uint32_t*>(s_dyn);                          // [kPTilePos]
-  uint16_t* s_bkt = reinterpret_cast<uint16_t*>(s_dyn + (size_t)kPTilePos * 4);   // [kPTilePos]
-  __shared__ uint64_t s_fwd[8 * 256];
-  __shared__ uint32_t s_codes[kPBlock + 2];
-  __shared__ uint32_t s_inv[kPBlock + 2];
-  __shared__ GranuleLds G;
-  const uint32_t nb = 1u << P.b1;
-  load_tables_lds(s_fwd, T.fwd_tbl, T.g.nbytes);
-  granule_init(G, nb);
-  const uint32_t bshift = T.g.lsize_l - P.b1;
-  uint32_t my_direct = 0, my_mers = 0;
-  const int64_t n_tiles = (hi + kPTilePos - 1) / kPTilePos;
-  TileRaw R = tile_fetch(base, (int64_t)blockIdx.x * kPTilePos, lo, hi);
-  [[maybe_unused]] PhaseClk pc;
-  for(int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    lds_barrier();
-    for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) G.hist[j] = 0;
-    const LaneWords L = tile_stage(R, tile * kPTilePos, lo, hi, s_codes, s_inv);      // barrier inside
-    JF_PHASE(pc, 0);
-    R = tile_fetch(base, (tile + gridDim.x) * kPTilePos, lo, hi);                      // next tile's bytes travel while this one is worked on
-    uint32_t it[kPerLane + 1], dr[kPerLane + 1];
-#pragma unroll
-    for(int e = 0; e <= kPerLane; ++e) dr[e] = 0xFFFFFFFFu;
-    uint64_t prev = 0; uint32_t run = 0; bool long_runs = false;
-    auto flush_run = [&](int site) {
-      if(run == 1) {
-        const uint64_t pos = hash_tables_t<NB>(s_fwd, prev, T.g.nbytes);
-        const uint64_t local = pos & T.g.local_mask;
-        const uint32_t b = (uint32_t)(local >> bshift);
-        it[site] = make_item<uint32_t>(T.g, P, prev, local);
-        dr[site] = (b << 16) | atomicAdd(&G.hist[b], 1u);
-      } else if(run > 1) long_runs = true;
-    };
-    const uint32_t adm = BLOOM ? bloom_admit_mask(T.bloom, T.g, L) : 0xFFFFu;
-    for_each_kmer(T.g, L, [&](int j, uint64_t key) {
-      ++my_mers;
-      if(BLOOM && !((adm >> j) & 1u)) return;
-      if(run && key == prev) { ++run; return; }
-      flush_run(j);
-      prev = key; run = 1;
-    });
-    flush_run(kPerLane);
-    if(long_runs) my_direct += apply_runs<RETURNING, BLOOM>(T, s_fwd, L);
-    JF_PHASE(pc, 1);
-    my_direct += granule_emit(G, nb, cap, gcur, out, s_item, s_bkt, it, dr,
-                              [&](uint32_t b, uint32_t v) { item_direct_insert<RETURNING>(T, P, b, (uint64_t)v); }, &pc);
-  }
-  granule_finish(G, nb, cap, tot, out);
-  JF_PHASE(pc, 6);
-  JF_PHASE_FLUSH(pc, 0);
-  if(my_direct) atomicAdd((unsigned long long*)&T.counters[CTR_DIRECT], (unsigned long long)my_direct);
-  uint64_t w = my_mers;
-  for(int o = 32; o > 0; o >>= 1) w += __shfl_down(w, o, 64);
-  if((threadIdx.x & 63) == 0 && w) atomicAdd((unsigned long long*)&T.counters[CTR_MERS], (unsigned long long)w);
-}
+// (32-bit items from sequence: kernels_p1ring.hip.hpp -- per-bucket rings in LDS instead of a sort per chunk.)
 
 // Single-pass P1 with 64-bit items (one-word keys whose item does not fit 32 bits, e.g. k = 31 at 2^33 slots): the
 // block's 16384 positions go through the sort in two rounds of 8 positions per lane (8192 items of 8 bytes = 64 KiB of

@@ -73,6 +73,44 @@ def test_count_digest_equals_the_reference_tables_digest(cli, name, tmp_path):
         assert subprocess.check_output([O.REF_JF, "digest", out]).decode() == mine
 
 
+@pytest.fixture(scope="module")
+def half_gbp_reads(tmp_path_factory):
+    """0.5 Gbp of 150 bp reads from the REFERENCE's generator (generate_sequence -s 42 -r 150: one-line records of 150
+    bases) in /dev/shm: the input of the at-scale parity tests below."""
+    if not O.have_ref() or not os.access(O.REF_GEN, os.X_OK):
+        pytest.skip("oracle/_ref not built")
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    d = tmp_path_factory.mktemp("halfgbp") if base is None else __import__("tempfile").mkdtemp(prefix="jf_halfgbp_", dir=base)
+    subprocess.check_call([O.REF_GEN, "-s", "42", "-r", "150", "-o", "reads", "500000000"], cwd=str(d))
+    yield os.path.join(str(d), "reads.fa")
+    __import__("shutil").rmtree(str(d), ignore_errors=True)
+
+
+@pytest.mark.parametrize("cfg,k,size", [("C2", 21, "2G"), ("C5", 63, "512M"), ("C3", 31, "512M")])
+def test_half_gbp_reference_file_digest_equals_the_reference(cli, half_gbp_reads, tmp_path, cfg, k, size):
+    """Parity at a size where every stage of the partitioned path works at realistic fill (P1 buckets, P2 regions, LDS
+    tiles: 433 M k-mers at k = 21 into 2^31 slots; 16-byte items at k = 63; the Bloom pass + filtered count at k = 31) on
+    a file written by the reference's own generator: the content digest of the whole table from `jellyfish-amd count
+    --digest` must equal `ref_jf count --digest` (the reference's in-memory table walked by its own iterators), counted
+    here on the host cores.  For C3 both sides first write their Bloom counter (`bc`), which must be byte-identical."""
+    nproc = str(min(os.cpu_count() or 1, 64))
+    env = dict(os.environ, JFGPU_QUIET="1", JFGPU_MODE="partitioned")
+    mine, ref = str(tmp_path / "mine.digest"), str(tmp_path / "ref.digest")
+    extra_m, extra_r = [], []
+    if cfg == "C3":
+        bm, br = str(tmp_path / "mine.bc"), str(tmp_path / "ref.bc")
+        subprocess.check_call([cli, "bc", "-m", str(k), "-C", "-s", "500M", "-o", bm, half_gbp_reads], env=env)
+        subprocess.check_call([O.REF_JF, "bc", "-m", str(k), "-C", "-s", "500M", "-t", nproc, "-o", br, half_gbp_reads])
+        offs = [9 + int(open(f, "rb").read(9)) for f in (bm, br)]          # (the headers carry command lines and times: bodies only)
+        assert subprocess.call(["cmp", "-s", "-i", "%d:%d" % tuple(offs), bm, br]) == 0, "Bloom counter bodies differ"
+        assert os.path.getsize(bm) - offs[0] == os.path.getsize(br) - offs[1] > 1_000_000_000
+        extra_m, extra_r = ["--bc", bm], ["--bc", br]
+    subprocess.check_call([cli, "count", "-m", str(k), "-C", "-s", size, "--no-write", "--digest", mine] + extra_m + [half_gbp_reads], env=env)
+    subprocess.check_call([O.REF_JF, "count", "-m", str(k), "-C", "-s", size, "-t", nproc, "--no-write", "--digest", ref] + extra_r + [half_gbp_reads])
+    assert open(mine).read() == open(ref).read()
+    assert int(open(mine).read().split()[1]) > (1000 if cfg == "C3" else 100_000_000)
+
+
 def test_count_text_format_and_bounds(cli, tmp_path):
     case = next(c for c in MANIFEST["cases"] if c["name"] == "reads150_k5C")
     inp = os.path.join(GOLD, case["input"])

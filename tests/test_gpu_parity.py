@@ -167,6 +167,24 @@ def test_count_field_overflow(gpu):
         assert vals.tolist() == [70000]
 
 
+def test_overflow_side_table_grows(gpu):
+    """More keys whose count leaves the slot's count field than the side table holds at creation (65536 entries): 32-bit
+    slots with an 8-bit count field (k = 16 at 2^22 slots), 100 000 keys added with value 300, then once more.  The
+    reference keeps counting whatever the counts (large_hash_array.hpp:887-937); so must this."""
+    rng = np.random.default_rng(9)
+    keys = np.unique(rng.integers(0, 1 << 32, size=120000, dtype=np.uint64))[:100000]
+    with gpu.Table(16, 1 << 22, canonical=False) as t:
+        assert t.info.slot_bytes == 4 and t.info.val_len <= 10
+        t.add_keys(keys, 300)
+        t.add_keys(keys[:50000], 300)
+        t.sync()
+        vals, found = t.lookup(keys)
+        assert found.all()
+        assert (vals[:50000] == 600).all() and (vals[50000:] == 300).all()
+        st = t.stats()
+        assert (st.distinct, st.total, st.max_count) == (100000, 100000 * 300 + 50000 * 300, 600)
+
+
 def test_lower_upper_and_histo(gpu):
     rng = random.Random(13)
     k = 8

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """<tag>_{fetch,write}.csv (tools/rocpd_pmc.py output of the FETCH_SIZE / WRITE_SIZE passes of tools/profile_bench.sh)
--> profiles/r02_traffic_<cfg>.json: HBM bytes per job of every stage bench.py names, the figures its `roofline.traffic`
+-> profiles/r03_traffic_<cfg>.json: HBM bytes per job of every stage bench.py names, the figures its `roofline.traffic`
 quotes.  The profiled command runs exactly one job (--warmup 0 --repeats 1), so sums over the run are per-job sums.
 Corrections per MI355X_MICROARCH.md: counters are KB; FETCH_SIZE is doubled for wide coalesced reads; WRITE_SIZE as is.
 usage: make_traffic_json.py <tag path prefix> <C2|C3|C5> <gbp> <lsize> [out.json]"""
@@ -9,7 +9,7 @@ import json
 import sys
 
 tag, cfg, gbp, lsize = sys.argv[1], sys.argv[2], float(sys.argv[3]), int(sys.argv[4])
-out = sys.argv[5] if len(sys.argv) > 5 else "profiles/r02_traffic_%s.json" % cfg
+out = sys.argv[5] if len(sys.argv) > 5 else "profiles/r03_traffic_%s.json" % cfg
 
 
 def load(path, col):
@@ -24,7 +24,7 @@ def stage_of(kernel):
     if "p1_bloom" in k: return "bc_p1_route"
     if "bloom_segment" in k: return "bc_segments"
     if "bloom_insert" in k or "bloom_items" in k: return "bc_direct"
-    if "tile_insert" in k: return "tile_insert"
+    if "tile_insert" in k or "tile_rank_insert" in k: return "tile_insert"
     if "items_direct" in k: return "items_direct"
     if "jfgpu::p2_" in k or "scan_matrix" in k: return "bc_p2_partition" if cfg == "C3" else "p2_partition"
     if "jfgpu::p1_" in k or "granule_finish" in k: return "p1_partition"
