@@ -128,6 +128,7 @@ bool items_geometry_ok(const jfgpu_comm* c, const jfgpu_table* t) {
   uint32_t sb = 0; while((1 << sb) < c->world) ++sb;
   const uint32_t gbits = std::min<uint32_t>(10, sb + t->pg.b1);
   if(gbits < sb || t->g.key_bits < gbits || t->g.key_bits - gbits > 32) return false;   // the routed item is 2k - gbits bits
+  if(t->pg.b1 - (gbits - sb) > 4) return false;                                          // the receiver splits a coarse bucket at most 16 ways
   return t->g.lsize_g >= t->g.tile_bits + gbits;
 }
 
@@ -261,8 +262,13 @@ int comm_insert_prev_items(jfgpu_comm* c, jfgpu_comm::Rank& R, int rank) {
     unsigned int* gc_v = gcur - dshift; unsigned int* gs_v = gcur + nb - dshift;
     uint32_t* out_v = reinterpret_cast<uint32_t*>(b.items) - dshift * (int64_t)cap2;
     unsigned long long* tot_v = b.tot - dshift;
-    if(t->returning) hipLaunchKernelGGL((p2_granule_kernel<uint32_t, TableDirect<true>, kP2PairPer, true>), grid, block, lds, t->stream, TableDirect<true>{t->d_dt, pd, (unsigned long long*)&t->dt.counters[CTR_DIRECT]}, sb, split_at, S, cap2, gc_v, gs_v, out_v, (uint32_t)first, tot_v, L.nbc - 1);
-    else             hipLaunchKernelGGL((p2_granule_kernel<uint32_t, TableDirect<false>, kP2PairPer, true>), grid, block, lds, t->stream, TableDirect<false>{t->d_dt, pd, (unsigned long long*)&t->dt.counters[CTR_DIRECT]}, sb, split_at, S, cap2, gc_v, gs_v, out_v, (uint32_t)first, tot_v, L.nbc - 1);
+    // (fan-out 2^sb <= 16: the packed-counter ranking of p2_granule_kernel, with 1, 2 or 4 words of four destinations)
+#define SPLIT(RT, SW) hipLaunchKernelGGL((p2_granule_kernel<uint32_t, TableDirect<RT>, kP2PairPer, SW>), grid, block, lds, t->stream, \
+                        TableDirect<RT>{t->d_dt, pd, (unsigned long long*)&t->dt.counters[CTR_DIRECT]}, sb, split_at, S, cap2, gc_v, gs_v, out_v, (uint32_t)first, tot_v, L.nbc - 1)
+    if(sb > 4) return fail(JFGPU_E_UNSUPPORTED, "item exchange: more than 16 fine buckets per coarse bucket");
+    if(t->returning) { if(sb <= 2) SPLIT(true, 1); else if(sb == 3) SPLIT(true, 2); else SPLIT(true, 4); }
+    else             { if(sb <= 2) SPLIT(false, 1); else if(sb == 3) SPLIT(false, 2); else SPLIT(false, 4); }
+#undef SPLIT
     hipLaunchKernelGGL(granule_finish_kernel, dim3(4), dim3(256), 0, t->stream, gcur, cap2, nb, b.off);
     for(int p = 0; p < W; ++p) {
       const uint64_t* lst = r_strag + (size_t)p * (1 + L.S);

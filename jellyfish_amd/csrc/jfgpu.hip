@@ -706,8 +706,10 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     HIP_TRY(hipFuncSetAttribute((const void*)p1_route_granule_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_route_granule_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_route_granule_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
-    HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint32_t, TableDirect<true>, kP2PairPer, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
-    HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint32_t, TableDirect<false>, kP2PairPer, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
+#define SATTR(SW) HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint32_t, TableDirect<true>, kP2PairPer, SW>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4)); \
+                  HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint32_t, TableDirect<false>, kP2PairPer, SW>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4))
+    SATTR(1); SATTR(2); SATTR(4);
+#undef SATTR
     HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint32_t, TableDirect<true>, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint32_t, TableDirect<false>, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint32_t, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));

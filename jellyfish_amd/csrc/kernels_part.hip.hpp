@@ -869,7 +869,7 @@ struct TableDirect {
 };
 
 // ITEM: uint32_t or unsigned __int128; DIRECT: see TableDirect (kernels_wide_part.hip.hpp has the two-word one).
-template <typename ITEM, typename DIRECT, int PER_THREAD, bool SMALL = false>
+template <typename ITEM, typename DIRECT, int PER_THREAD, int SMALL = 0>
 __global__ __launch_bounds__(kPBlock) void p2_granule_kernel(DIRECT D, uint32_t b2e, uint32_t tag_bits, SegList S, uint32_t cap,
                                                              unsigned int* __restrict__ gcur, unsigned int* __restrict__ gshort,
                                                              ITEM* __restrict__ out, uint32_t bucket0,
@@ -920,25 +920,61 @@ __global__ __launch_bounds__(kPBlock) void p2_granule_kernel(DIRECT D, uint32_t 
     }
     lds_barrier();
     JF_PHASE(pc, 1);
-    if(SMALL) {
-      // (SMALL: nb <= 16) a fan-out of a few destinations (the receive side of the multi-GPU exchange): thousands of lanes on a handful of
-      // LDS counters would serialise, so a wave ranks its lanes per destination itself and adds once per destination
-      const uint32_t lane = threadIdx.x & 63;
-      const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    if constexpr(SMALL != 0) {
+      // (SMALL: nb <= 4 * SMALL <= 16) a fan-out of a few destinations (the receive side of the multi-GPU exchange).  Thousands
+      // of lanes on a handful of LDS counters would serialise, and ranking lanes per destination with ballots costs
+      // 10 instructions per item AND destination.  Instead every lane counts its own items per destination in packed
+      // 16-bit fields (four per 64-bit word), one block-wide prefix sum of the packed words gives each lane its first
+      // rank per destination, and a second sweep hands the ranks out: a dozen instructions per item, whatever nb.
+      constexpr int SW = SMALL;
+      __shared__ unsigned long long s_wtot[kPBlock / 64][4];
+      const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      unsigned long long cnt[SW];
+#pragma unroll
+      for(int w = 0; w < SW; ++w) cnt[w] = 0;
 #pragma unroll
       for(int r = 0; r < PER_THREAD; ++r) {
-        bool valid = (vm >> r) & 1;
-        if(valid && ((hm >> r) & 1) && it[r] == (ITEM)~(ITEM)0) { vm &= ~(1u << r); valid = false; }   // a hole
-        const uint32_t d = (uint32_t)(it[r] >> tag_bits) & (nb - 1);
+        if(((vm >> r) & 1) && ((hm >> r) & 1) && it[r] == (ITEM)~(ITEM)0) vm &= ~(1u << r);   // a hole
+        if((vm >> r) & 1) {
+          const uint32_t d = (uint32_t)(it[r] >> tag_bits) & (nb - 1);
+          const unsigned long long one = 1ull << ((d & 3) * 16);
+#pragma unroll
+          for(int w = 0; w < SW; ++w) cnt[w] += (SW == 1 || (int)(d >> 2) == w) ? one : 0ull;
+        }
+      }
+      unsigned long long inc[SW];
+#pragma unroll
+      for(int w = 0; w < SW; ++w) inc[w] = cnt[w];
+      for(int o = 1; o < 64; o <<= 1) {
+#pragma unroll
+        for(int w = 0; w < SW; ++w) { const unsigned long long up = __shfl_up(inc[w], o, 64); if((int)lane >= o) inc[w] += up; }
+      }
+      if(lane == 63) {
+#pragma unroll
+        for(int w = 0; w < SW; ++w) s_wtot[wave][w] = inc[w];
+      }
+      lds_barrier();
+      unsigned long long run[SW];
+#pragma unroll
+      for(int w = 0; w < SW; ++w) {
+        unsigned long long before = 0;
+        for(uint32_t v = 0; v < wave; ++v) before += s_wtot[v][w];
+        run[w] = before + inc[w] - cnt[w];                   // this lane's first rank per destination
+        if(threadIdx.x == kPBlock - 1) {                      // (the last lane's inclusive sums are the chunk's totals)
+          const unsigned long long tot_w = before + inc[w];
+#pragma unroll
+          for(int f = 0; f < 4; ++f) if((uint32_t)(4 * w + f) < nb) G.hist[4 * w + f] = (uint32_t)(tot_w >> (16 * f)) & 0xFFFFu;
+        }
+      }
+#pragma unroll
+      for(int r = 0; r < PER_THREAD; ++r) {
         uint32_t rank = 0;
-        for(uint32_t v = 0; v < nb; ++v) {                 // block-uniform trip count
-          const unsigned long long m = __ballot(valid && d == v);
-          if(!m) continue;                                 // wave-uniform
-          const int leader = __ffsll((long long)m) - 1;
-          uint32_t base = 0;
-          if((int)lane == leader) base = atomicAdd(&G.hist[v], (uint32_t)__popcll(m));
-          base = __shfl(base, leader, 64);
-          if(valid && d == v) rank = base + (uint32_t)__popcll(m & below);
+        if((vm >> r) & 1) {
+          const uint32_t d = (uint32_t)(it[r] >> tag_bits) & (nb - 1);
+          const uint32_t sh = (d & 3) * 16;
+#pragma unroll
+          for(int w = 0; w < SW; ++w)
+            if(SW == 1 || (int)(d >> 2) == w) { rank = (uint32_t)(run[w] >> sh) & 0xFFFFu; run[w] += 1ull << sh; }
         }
         if(r & 1) rk[r >> 1] |= rank << 16; else rk[r >> 1] = rank;
       }

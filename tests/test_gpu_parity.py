@@ -932,7 +932,7 @@ def test_p2_variants_of_32bit_slots_give_the_same_table(gpu, monkeypatch, varian
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,strag", [(2, None), (4, None), (1, None), (2, "3")])
+@pytest.mark.parametrize("world,strag", [(2, None), (4, None), (1, None), (2, "3"), (8, None), (16, None)])
 def test_comm_item_path_equals_single_table(gpu, monkeypatch, world, strag):
     """The exchange's item path (abi_comm.inl: the sender runs the single-pass P1 over the GLOBAL table, an owner's regions
     travel as 4-byte items, the receiver splits them into its own P1 buckets) on the in-process transport, forced on
@@ -943,7 +943,7 @@ def test_comm_item_path_equals_single_table(gpu, monkeypatch, world, strag):
     if strag:
         monkeypatch.setenv("JFGPU_COMM_STRAG", strag)
     rng = random.Random(7 + world)
-    k, lsize_g = 16, 26
+    k, lsize_g = 16, max(26, 25 + world.bit_length() - 1)        # (a shard needs two partition levels for the item path; world 8 / 16: the receiver splits 8- / 16-way)
     inputs = [[rnd_seq(rng, rng.choice([0, 40000, 90000]), "ACGT" * 12 + "N") for _ in range(world)] for _step in range(4)]
     inputs[2][0] = rnd_seq(rng, 30000, "ACGT") + b"A" * 60000 + b"N" + rnd_seq(rng, 20000, "ACGT")
     inputs[1][world - 1] = b""
