@@ -807,8 +807,8 @@ int jfgpu_sync(jfgpu_table* t) {
               c[0], c[1], c[2], c[3], c[4]);
       fprintf(stderr, "[phase prof] P2: (barrier) %llu  load %llu  hist %llu  scan %llu  lds-scatter %llu  write-out %llu  finish %llu\n",
               c[8], c[9], c[10], c[11], c[12], c[13], c[14]);
-      fprintf(stderr, "[phase prof] T: loop+offsets %llu  rank adds + fill %llu  place %llu  queue (wave 0's own) %llu  (its wait for the others) %llu  merge + store %llu\n",
-              c[16], c[17], c[18], c[21], c[19], c[20]);
+      fprintf(stderr, "[phase prof] T: loop+offsets %llu  rank adds + fill %llu  place %llu  merge %llu  queue (wave 0's own) %llu  (its wait for the others) %llu  store %llu\n",
+              c[16], c[17], c[18], c[22], c[21], c[19], c[20]);
       (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_prof), z, sizeof z);
     } }
 #endif

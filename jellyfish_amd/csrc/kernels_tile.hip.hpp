@@ -15,13 +15,15 @@
 //      word at bucket * 4 + rank; otherwise the item goes on a small LDS queue.  All of a lane's items are in flight
 //      together (no dependent chain, full waves); for a tile nothing was ever inserted into, the adds are issued before
 //      the tile is zeroed and their round trip is hidden behind that.
+//   M  one lane per bucket, all buckets at once: equal tags among the bucket's (at most four) entries are merged into the
+//      first of them and the bucket is compacted -- the k-mers that occur several times in this flush or were already in
+//      the table.  This comes BEFORE C: a bucket that looks full but holds equal tags has room, and an item walking
+//      past it would strand its key behind a free slot.  (Folding such buckets from inside C, next to lanes that add,
+//      cannot be made safe with plain adds: an add issued on an old look can land in a slot whose entry was folded
+//      away meanwhile.  With M first, nothing is ever taken out of a slot while C runs.)
 //   C  the queued items (a few per cent at load 0.5; most of the input on high-coverage data, where they find their tag
 //      in the home bucket and end as one add): vector look at a bucket, add on a match, compare-and-swap on the first
-//      empty slot, next bucket otherwise.
-//   M  on the way out (LDS -> table), one lane per bucket: equal tags among the bucket's (at most four) entries are
-//      merged into the first of them and the bucket is compacted -- the k-mers that occur several times in this flush or
-//      were already in the table.  (A bucket that looks full in phase C but holds equal tags will have a free slot after
-//      M; an item that would walk past it folds the copies itself first, see slow_insert.)
+//      empty slot, next bucket otherwise.  C creates no equal tags, so the tile then goes out as it is.
 //
 // Same table format and count semantics as the global-atomic path (kernels.hip.hpp::table_add): (tile, tag) identifies
 // the key wherever in the tile it lands; large_hash_array.hpp:509-597,741-752 (claim_key / add_val) restated.
@@ -165,27 +167,40 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
       for(int q = 0; q < 4; ++q) if(oc[q]) ovf_add_call(T.ovf_key, T.ovf_cnt, T.ovf_mask, T.counters, bucket_slot0 + q, (uint64_t)oc[q]);
     }
   };
-  // LDS -> table, merging on the way (M); tile and counters are cleared behind it for the next unit
-  auto store_tile = [&](SLOT* gt, uint32_t t, uint64_t unit_slot0) {
-    SLOT wb[NBK][4];
+  // M for the whole unit, one lane per bucket, between A and C: all of a lane's buckets are fetched in one LDS round
+  // trip; the ones holding equal tags are folded and written back.
+  auto merge_tile = [&](uint64_t unit_slot0) {
+    constexpr uint32_t MB = (sizeof(ITEM) + sizeof(SLOT) == 8 && NBK >= 4) ? 4 : (NBK >= 2 ? 2 : 1);      // buckets in flight per lane (registers: the next round's items are too)
 #pragma unroll
-    for(uint32_t k = 0; k < NBK; ++k) load_bucket((threadIdx.x + k * BLOCK) << kBucketBits, wb[k]);      // one LDS round trip for all of them
+    for(uint32_t k0 = 0; k0 < NBK; k0 += MB) {
+      SLOT wb[MB][4];
+#pragma unroll
+      for(uint32_t k = 0; k < MB; ++k) load_bucket((threadIdx.x + (k0 + k) * BLOCK) << kBucketBits, wb[k]);
+#pragma unroll
+      for(uint32_t k = 0; k < MB; ++k) {
+        const uint32_t b = threadIdx.x + (k0 + k) * BLOCK;
+        SLOT (&w)[4] = wb[k];
+        if(has_dups(w)) {
+          merge_bucket(w, unit_slot0 + ((uint64_t)b << kBucketBits));
+#pragma unroll
+          for(uint32_t q = 0; q < kBV; ++q) {
+            uint4 v;
+            if(sizeof(SLOT) == 4) v = make_uint4((uint32_t)w[0], (uint32_t)w[1], (uint32_t)w[2], (uint32_t)w[3]);
+            else v = make_uint4((uint32_t)w[2 * q], (uint32_t)((uint64_t)w[2 * q] >> 32), (uint32_t)w[2 * q + 1], (uint32_t)((uint64_t)w[2 * q + 1] >> 32));
+            *reinterpret_cast<uint4*>(s_tile + ((size_t)b << kBucketBits) + q * kVec) = v;
+          }
+        }
+      }
+    }
+  };
+  // LDS -> table; tile and counters are cleared behind it for the next unit
+  auto store_tile = [&](SLOT* gt, uint32_t t) {
 #pragma unroll
     for(uint32_t k = 0; k < NBK; ++k) {
       const uint32_t b = threadIdx.x + k * BLOCK;
-      SLOT (&w)[4] = wb[k];
-      // (equal tags, or a hole phase C left when it folded a copy away: compact)
-#ifndef JFGPU_T_NOM
-      if(has_dups(w) || ((w[1] == 0) & ((w[2] | w[3]) != 0)) || ((w[2] == 0) & (w[3] != 0)))
-#else
-      if(false)
-#endif
-        merge_bucket(w, unit_slot0 + ((uint64_t)b << kBucketBits));
 #pragma unroll
       for(uint32_t q = 0; q < kBV; ++q) {
-        uint4 v;
-        if(sizeof(SLOT) == 4) v = make_uint4((uint32_t)w[0], (uint32_t)w[1], (uint32_t)w[2], (uint32_t)w[3]);
-        else v = make_uint4((uint32_t)w[2 * q], (uint32_t)((uint64_t)w[2 * q] >> 32), (uint32_t)w[2 * q + 1], (uint32_t)((uint64_t)w[2 * q + 1] >> 32));
+        const uint4 v = *reinterpret_cast<const uint4*>(s_tile + ((size_t)b << kBucketBits) + q * kVec);
         *reinterpret_cast<uint4*>(gt + ((size_t)b << kBucketBits) + q * kVec) = v;
         *reinterpret_cast<uint4*>(s_tile + ((size_t)b << kBucketBits) + q * kVec) = make_uint4(0, 0, 0, 0);      // the next unit starts from an empty tile
       }
@@ -197,10 +212,10 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
     }
   };
   // C for one item: find the key or a free slot, bucket by bucket from its home bucket.  The bucket after the one being
-  // looked at is already on its way.  Buckets may still hold equal tags (M comes last); one that looks full but does
-  // will have room once they are merged, and walking past it would strand the key behind a free slot: its later copies
-  // are folded into the first one right here.  That is safe beside the other lanes of this phase: an add always goes to
-  // the FIRST slot carrying the tag, so nobody touches a later copy except to take it out (a compare-and-swap on the exact word decides who).
+  // looked at is already on its way.  M has run: no bucket holds a tag twice, and nothing here can change that -- slots
+  // only ever go from empty to one key (two lanes with the same new key go for the same first empty slot of the same
+  // bucket; the loser looks again and finds the winner's entry).  So a full bucket is full for good, an add lands on
+  // the key it was meant for, and a look that has gone stale can only lead to a compare-and-swap that fails.
   auto slow_insert = [&](ITEM x, uint64_t unit_slot0) {
     const SLOT low = occ | (SLOT)((uint64_t)x & (g.occ_bit - 1)), neww = inc | low;
     const uint32_t h = home_of(x), hbase = h & ~tmask, hb = h & tmask & ~3u;
@@ -222,27 +237,6 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
       if(emp >= 0) {
         if(atomicCAS(&s_tile[bs + emp], (SLOT)0, neww) == 0) return;
         load_bucket(bs, w);                                   // somebody else took it: look at this bucket again
-        continue;
-      }
-      if(has_dups(w)) {                                       // full, but not for long: make the room now
-#pragma unroll
-        for(int j = 3; j >= 1; --j) {
-          int first = -1;
-#pragma unroll
-          for(int i = j - 1; i >= 0; --i) if(((w[i] ^ w[j]) & lmask) == 0) first = i;
-          if(first >= 0) {
-            // (w[] may be an old look: take the copy out only if it is still exactly what was seen -- a later copy
-            //  never changes, but it may be gone and its slot claimed by another key since)
-            const SLOT v = w[j];
-            if(atomicCAS(&s_tile[bs + j], v, (SLOT)0) == v) {
-              const SLOT add = (SLOT)(((uint64_t)v >> cshift) << cshift);
-              const SLOT prev = atomicAdd(&s_tile[bs + first], add);
-              if(RETURNING && ((uint64_t)prev >> cshift) + ((uint64_t)v >> cshift) > g.cnt_max)
-                ovf_add_call(T.ovf_key, T.ovf_cnt, T.ovf_mask, T.counters, unit_slot0 + bs + first, 1);
-            }
-          }
-        }
-        load_bucket(bs, w);
         continue;
       }
       ++step;
@@ -285,6 +279,9 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
     after_a();
     lds_barrier();
     JF_PHASE(pc, 2);
+    merge_tile(unit_slot0);
+    lds_barrier();
+    JF_PHASE(pc, 6);
     // ---- C: this wave's queue, then what its lanes held back (one copy of the insert for both)
     const uint32_t nq = qn < qcap ? qn : qcap;                 // wave-uniform
     for(uint32_t i = lane;; i += 64) {
@@ -292,9 +289,7 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
       if(i < nq) x = s_q[i];
       else if(pend) { const uint32_t r = (uint32_t)__ffs((int)pend) - 1u; x = again[r * BLOCK + threadIdx.x]; pend &= pend - 1; }
       else break;
-#ifndef JFGPU_T_NOC
       slow_insert(x, unit_slot0);
-#endif
     }
     JF_PHASE(pc, 5);
     lds_barrier();
@@ -359,7 +354,7 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
     uint64_t a2 = 0, b2 = 0; uint32_t d2 = 0;
     if(last && t + 2 * G < n_tiles) { a2 = off[(size_t)(t + 2 * G) << sh]; b2 = off[((size_t)(t + 2 * G) << sh) + 1]; d2 = unit_dirty(t + 2 * G); }
     place_round(cur, vm, old, unit_slot0, src + c0, [&] { if(last) fetch(a1, b1); else fetch(c0 + kRound, b0); });
-    store_tile(gt, t, unit_slot0);                            // (every round ends on a barrier)
+    store_tile(gt, t);                            // (every round ends on a barrier)
     lds_barrier();
     JF_PHASE(pc, 4);
     if(last) { t += G; a0 = a1; b0 = b1; d0 = d1; a1 = a2; b1 = b2; d1 = d2; c0 = a0; }

@@ -619,6 +619,31 @@ def test_partitioned_large_run_invariants(gpu):
     assert dumps[0] == dumps[1]
 
 
+@pytest.mark.gpu
+def test_high_coverage_reads_partitioned_equals_direct_every_time(gpu):
+    """2 Gbp of reads at 20x coverage of a random genome, 1 % substitutions (the bench's distribution G), four flushes into a 2^32-slot
+    table: most k-mers of a flush are already in the table or occur several times in the flush, so the tile stage's merge
+    (M) and its queue (C) carry most of the work.  The partitioned path must give the direct path's table -- content
+    digest: records, total, xor and sum of record hashes -- on every one of several runs (a k-mer entered twice shows
+    up as one record too many with the total unchanged)."""
+    k, L, genome, n_reads = 21, 150, 100_000_000, 13_333_333
+    seen = []
+    for mode in (1, 2, 2, 2):
+        with gpu.Table(k, 1 << 32) as t:
+            t.set_mode(mode)
+            d = t.malloc(n_reads * (L + 1) + 16)
+            t.gen_genome_reads_dev(d, 0, n_reads, L, genome, 0.01, 42)
+            for i in range(4):
+                a, b = n_reads * i // 4, n_reads * (i + 1) // 4
+                t.count_ascii_dev(d + a * (L + 1), (b - a) * (L + 1))
+            t.sync()
+            st = t.stats()
+            assert st.total == n_reads * (L - k + 1)
+            seen.append(tuple(t.digest()))
+            t.free(d)
+    assert len(set(seen)) == 1, seen
+
+
 # ---- the size is a hint: cooperative doubling (hash_counter::double_size, hash_counter.hpp:200-238) ------
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("k,size,n", [(21, 1 << 13, 400000), (15, 16, 200000), (31, 1 << 10, 150000), (8, 64, 300000)])
