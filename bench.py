@@ -168,15 +168,37 @@ def cpu_baseline(cfg, sample, k, tmpdir):
 
 def spawn_ranks(n):
     """python bench.py --gpus N from a bare shell: N copies of this command, one rank per GPU, rendezvous on 127.0.0.1 (what
-    torch.distributed.run would set up).  Rank 0's stdout (the JSON line) is this process's; a failing rank ends the others."""
+    torch.distributed.run would set up).  Rank 0's stdout (the JSON line) is this process's; a failing rank ends the others,
+    and so does SIGTERM / SIGINT to this process.  A box with fewer than N GPUs gets the inter-process test transport (ranks
+    share devices, hipIpc* copies between them) at a size that fits: a functional run of the N-rank path, not a scaling
+    number -- the JSON line says so.  JFGPU_BENCH_RANK_TIMEOUT (seconds, default 1500): ranks still running then are asked
+    where they are (SIGUSR1 -> faulthandler) and killed."""
+    import signal
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
+    extra = {}
+    if os.environ.get("JFGPU_COMM_TRANSPORT") != "ipc":
+        try:
+            import torch
+            if torch.cuda.device_count() < n:
+                extra = {"JFGPU_COMM_TRANSPORT": "ipc", "JFGPU_BENCH_SHARED_DEVICES": "1"}
+        except Exception:
+            pass
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), **extra)
         procs.append(subprocess.Popen([sys.executable] + sys.argv, env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+
+    def stop_all(*_):
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+        sys.exit(143)
+    signal.signal(signal.SIGTERM, stop_all)
+    signal.signal(signal.SIGINT, stop_all)
+    deadline = time.time() + float(os.environ.get("JFGPU_BENCH_RANK_TIMEOUT", "1500"))
     rc = 0
     live = set(range(n))
     while live:
@@ -189,6 +211,14 @@ def spawn_ranks(n):
                 rc = c
                 for q in live:
                     procs[q].terminate()
+        if live and time.time() > deadline:
+            sys.stderr.write("bench.py: ranks %s still running at the time limit\n" % sorted(live))
+            for q in live:
+                procs[q].send_signal(signal.SIGUSR1)
+            time.sleep(3)
+            for q in live:
+                procs[q].kill()
+            return 124
         time.sleep(0.2)
     return rc
 
@@ -215,8 +245,16 @@ def main():
         sys.exit(spawn_ranks(args.gpus))
     if args.as_secondary:
         args.no_extras = True; args.no_cpu_baseline = True; args.repeats = 1
+    shared = 1                                       # ranks per device (> 1: fewer GPUs than ranks, see spawn_ranks)
+    if os.environ.get("JFGPU_BENCH_SHARED_DEVICES") == "1":
+        import torch
+        shared = -(-args.gpus // max(torch.cuda.device_count(), 1))
     if not args.gbp:
         args.gbp = GBP_PER_GPU_SHARDED if args.gpus > 1 else 10.0
+        if shared > 1:                               # what fits `shared` ranks' tables, inputs and workspaces in one HBM
+            args.gbp = 10.0 / shared
+            if not args.lsize:
+                args.lsize = CONFIGS[args.config]["lsize"] - (shared - 1).bit_length()
 
     import faulthandler
     import signal
@@ -421,7 +459,9 @@ def main():
                        "id": cfg if world == 1 else "C4", "k": K, "read_len": READ_LEN, "reads_per_gpu": n_reads, "table_slots_per_gpu": 1 << lsize, "slot_bytes": slot_bytes,
                        "load_factor": float(tot[1]) / float(world << lsize),
                        "distinct": int(tot[1]), "total_kmers": total_kmers,
-                       "parallelism": ("single GPU" if not force_dist else "single GPU through the sharded code path") if world == 1 else "hash-prefix shard x%d + all-to-all" % world},
+                       "parallelism": ("single GPU" if not force_dist else "single GPU through the sharded code path") if world == 1 else
+                                      "hash-prefix shard x%d + all-to-all" % world + ("" if shared == 1 else
+                                      "; %d RANKS PER DEVICE over the inter-process test transport (hipIpc* copies): a functional run of the N-rank path on a box with fewer GPUs, not a scaling number" % shared)},
             "kernels": kernels,
             "content_digest": digest,
             "roofline": {"bound": "hbm", "kernel": dom,

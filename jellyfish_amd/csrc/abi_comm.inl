@@ -76,6 +76,10 @@ struct jfgpu_comm {
 
 namespace {
 
+// JFGPU_COMM_TRACE=1: every rank says on stderr where it is in the exchange (a stuck run shows who waits for whom).
+bool ipc_trace_on() { static const bool on = getenv("JFGPU_COMM_TRACE") != nullptr; return on; }
+#define IPC_TRACE(c, ...) do { if(ipc_trace_on()) { fprintf(stderr, "[comm rank %d] ", (c)->rank); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while(0)
+
 int comm_reserve(uint64_t*& buf, size_t& cap, size_t need, hipStream_t s1, hipStream_t s2);
 
 int comm_init_rank(jfgpu_comm* c, jfgpu_comm::Rank& R) {
@@ -143,6 +147,12 @@ uint32_t items_cap_wanted(const jfgpu_comm* c, const jfgpu_comm::Rank& R, size_t
   if(mean < 4 * strand && c->items_mode < 2) return 0;                      // regions would be mostly holes (2: forced, for tests)
   const uint64_t cap = ((uint64_t)((double)mean * 1.10) + strand + kGran - 1) / kGran * kGran;
   if(cap > 0x7FFF0000ull) return 0;
+#if !defined(JFGPU_EMU)
+  // (inter-process test transport, observed and not understood: with item-path send buffers of 2.6 GB and more the first
+  //  hipIpcOpenMemHandle of a peer's buffer never returns -- 1.8 GB is fine, and so are 5 GB buffers of the key path and
+  //  any size in tools/probes/r03_ipc_size_probe.hip.  Steps that large go as keys there.)
+  if(c->ipc && (uint64_t)L.nbg * cap * 5 > ((uint64_t)1 << 31)) return 0;
+#endif
   return (uint32_t)cap;
 }
 
@@ -385,6 +395,7 @@ int comm_exchange_rccl(jfgpu_comm* c) {
   uint64_t total = 0, gmax = 0;
   for(int p = 0; p < W; ++p) { R.roff[cur][p] = total; total += R.rcount[cur][p]; gmax = std::max(gmax, std::max(R.rcount[cur][p], R.scount[cur][p])); }
   R.roff[cur][W] = total;
+  IPC_TRACE(c, "keys: %llu to pull; waiting for recv[%d] to be consumed", (unsigned long long)total, cur);
   if(R.used[cur]) HIP_TRY(hipEventSynchronize(R.consumed[cur]));          // recv[cur] was read by the insert of step - 2
   int rc = comm_reserve(R.recv[cur], R.recv_cap[cur], total, R.t->stream, c->xstream); if(rc) return rc;
   if(!R.used[cur ^ 1]) { rc = comm_reserve(R.recv[cur ^ 1], R.recv_cap[cur ^ 1], total, R.t->stream, c->xstream); if(rc) return rc; }
@@ -615,16 +626,34 @@ int ipc_peer_send(jfgpu_comm* c, int p, int cur, uint8_t** out) {
   return JFGPU_OK;
 }
 
+// Map every peer's send buffer of turn `cur` (only those re-allocated since they were last mapped), ONE RANK AT A TIME.
+// Two processes importing each other's allocations at the same moment stalled in hipIpcOpenMemHandle for good with
+// buffers of 2.6 GB and more (1.8 GB: fine; one process importing while the other idles: fine at any size,
+// tools/probes/r03_ipc_size_probe.hip) -- so the imports take turns, with nothing of this exchange in flight yet.
+int ipc_open_peers(jfgpu_comm* c, int cur) {
+  for(int turn = 0; turn < c->world; ++turn) {
+    int rc = JFGPU_OK;
+    if(turn == c->rank)
+      for(int p = 0; p < c->world && rc == JFGPU_OK; ++p) { uint8_t* unused; if(p != c->rank) rc = ipc_peer_send(c, p, cur, &unused); }
+    if(rc) return rc;
+    rc = ipc_barrier(c); if(rc) return rc;
+  }
+  return JFGPU_OK;
+}
+
 // Key path: every rank publishes its per-owner counts and offsets, then PULLS what is meant for it out of the peers'
 // send buffers into its own receive buffer.
 int comm_exchange_ipc(jfgpu_comm* c) {
   jfgpu_comm::Rank& R = c->ranks[0];
   const int cur = R.turn, W = c->world;
+  IPC_TRACE(c, "keys: waiting for the routing kernels (turn %d)", cur);
   HIP_TRY(hipStreamSynchronize(R.t->stream));                // the routed keys are in send[cur]
   int rc = ipc_publish_send(c, cur); if(rc) return rc;
+  IPC_TRACE(c, "keys: published, barrier 1");
   IpcShared::Pub& mine = c->shm->pub[c->rank];
   for(int p = 0; p < W; ++p) { mine.scount[p] = R.scount[cur][p]; mine.soff[p] = R.soff[cur][p]; }
   rc = ipc_barrier(c); if(rc) return rc;
+  rc = ipc_open_peers(c, cur); if(rc) return rc;
   uint64_t total = 0;
   for(int p = 0; p < W; ++p) { R.rcount[cur][p] = c->shm->pub[p].scount[c->rank]; R.roff[cur][p] = total; total += R.rcount[cur][p]; }
   R.roff[cur][W] = total;
@@ -637,8 +666,11 @@ int comm_exchange_ipc(jfgpu_comm* c) {
     HIP_TRY(hipMemcpyAsync(R.recv[cur] + R.roff[cur][p], src + c->shm->pub[p].soff[c->rank] * 8, R.rcount[cur][p] * 8, hipMemcpyDeviceToDevice, c->xstream));
   }
   HIP_TRY(hipEventRecord(R.exchanged[cur], c->xstream));
+  IPC_TRACE(c, "keys: copies enqueued, waiting for them");
   HIP_TRY(hipStreamSynchronize(c->xstream));
+  IPC_TRACE(c, "keys: pulled, barrier 2");
   rc = ipc_barrier(c); if(rc) return rc;                     // everybody has pulled: the send buffers may be written again
+  IPC_TRACE(c, "keys: step exchanged");
   R.used[cur] = true;
   return JFGPU_OK;
 }
@@ -648,24 +680,37 @@ int comm_exchange_items_ipc(jfgpu_comm* c) {
   jfgpu_comm::Rank& R = c->ranks[0];
   const int cur = R.turn, W = c->world, me = c->rank;
   const ItemLayout L = item_layout(c, R.t, R.icap[cur]);
+  IPC_TRACE(c, "items: waiting for the routing kernels (turn %d, cap %u)", cur, R.icap[cur]);
   HIP_TRY(hipStreamSynchronize(R.t->stream));
   int rc = ipc_publish_send(c, cur); if(rc) return rc;
+  IPC_TRACE(c, "items: published; waiting for recv[%d] to be consumed", cur);
   if(R.used[cur]) HIP_TRY(hipEventSynchronize(R.consumed[cur]));
   rc = comm_reserve(R.recv[cur], R.recv_cap[cur], (L.recv_bytes + 7) / 8, R.t->stream, c->xstream); if(rc) return rc;
+  IPC_TRACE(c, "items: recv buffer of %zu bytes ready, barrier 1", L.recv_bytes);
   rc = ipc_barrier(c); if(rc) return rc;
+  rc = ipc_open_peers(c, cur); if(rc) return rc;
+  IPC_TRACE(c, "items: peers' send buffers mapped");
   uint8_t* rb = reinterpret_cast<uint8_t*>(R.recv[cur]);
   const size_t blk = (size_t)L.nbc * L.cap;
   for(int p = 0; p < W; ++p) {                               // sender p's share for me
     uint8_t* sb = reinterpret_cast<uint8_t*>(R.send[cur]);
     if(p != me) { rc = ipc_peer_send(c, p, cur, &sb); if(rc) return rc; }
+    IPC_TRACE(c, "items: rank %d's send buffer is at %p here", p, (void*)sb);
     HIP_TRY(hipMemcpyAsync(rb + (size_t)p * blk * 4, sb + (size_t)me * blk * 4, blk * 4, hipMemcpyDeviceToDevice, c->xstream));
+    IPC_TRACE(c, "items: regions copy enqueued (%zu bytes)", blk * 4);
     HIP_TRY(hipMemcpyAsync(rb + L.r_offs_at + (size_t)p * 2 * L.nbc * 8, sb + L.offs_at + (size_t)me * 2 * L.nbc * 8, (size_t)2 * L.nbc * 8, hipMemcpyDeviceToDevice, c->xstream));
+    IPC_TRACE(c, "items: offsets copy enqueued");
     HIP_TRY(hipMemcpyAsync(rb + L.r_claims_at + (size_t)p * 8, sb + L.claims_at + (size_t)me * 8, 8, hipMemcpyDeviceToDevice, c->xstream));
+    IPC_TRACE(c, "items: claims copy enqueued");
     HIP_TRY(hipMemcpyAsync(rb + L.r_strag_at + (size_t)p * (1 + L.S) * 8, sb + L.strag_at, (size_t)(1 + L.S) * 8, hipMemcpyDeviceToDevice, c->xstream));
+    IPC_TRACE(c, "items: straggler list copy enqueued");
   }
   HIP_TRY(hipEventRecord(R.exchanged[cur], c->xstream));
+  IPC_TRACE(c, "items: copies enqueued, waiting for them");
   HIP_TRY(hipStreamSynchronize(c->xstream));
+  IPC_TRACE(c, "items: pulled, barrier 2");
   rc = ipc_barrier(c); if(rc) return rc;
+  IPC_TRACE(c, "items: step exchanged");
   R.used[cur] = true;
   return JFGPU_OK;
 }
@@ -826,12 +871,15 @@ int jfgpu_comm_count_ascii_dev(jfgpu_comm* c, jfgpu_table* t, const char* d_base
   // (a rank that has run out of input has no preference: it must not push the others onto the key path)
   const uint32_t want = items_cap_wanted(c, R, n);
   uint64_t v[2] = {(!items_geometry_ok(c, t) || (want == 0 && n >= t->g.k)) ? 1ull : 0ull, want};
+  IPC_TRACE(c, "step: %zu bytes, wants cap %u", n, want);
   rc = jfgpu_comm_allreduce_u64(c, v, 2, 1); if(rc) return rc;
   uint32_t cap = v[0] ? 0u : (uint32_t)v[1];
+  IPC_TRACE(c, "step: agreed cap %u (0: keys)", cap);
   uint64_t routed = 0;
   if(cap) {
     bool overflow = false;
     rc = comm_route_items(c, R, d_bases, n, cap, &overflow, &routed); if(rc) return rc;
+    IPC_TRACE(c, "step: routed %llu items%s", (unsigned long long)routed, overflow ? " (straggler list overflow)" : "");
     uint64_t o = overflow ? 1 : 0;
     rc = jfgpu_comm_allreduce_u64(c, &o, 1, 1); if(rc) return rc;
     if(o) cap = 0;                                           // somebody has more stragglers than the list holds: this step goes as keys
@@ -842,7 +890,9 @@ int jfgpu_comm_count_ascii_dev(jfgpu_comm* c, jfgpu_table* t, const char* d_base
     rc = comm_route(c, R, d_bases, n); if(rc) return rc;
     rc = c->ipc ? comm_exchange_ipc(c) : comm_exchange_rccl(c); if(rc) return rc;
   }
+  IPC_TRACE(c, "step: exchanged, inserting the previous step's");
   rc = comm_insert_prev(c, R); if(rc) return rc;            // overlaps with the exchange just enqueued
+  IPC_TRACE(c, "step: done");
   R.inflight = true; R.turn ^= 1;
   return JFGPU_OK;
 }
