@@ -22,7 +22,9 @@ bench)
   timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "default rc=$?"
   timeout 300 python bench.py --dist G --no-cpu-baseline --no-extras > $O/bench_distG.json 2> $O/bench_distG.err; echo "G rc=$?"
   JFGPU_BENCH_FORCE_DIST=1 timeout 300 python bench.py --no-cpu-baseline --no-extras > $O/bench_forced_dist.json 2> $O/bench_forced_dist.err; echo "forced-dist rc=$?"
-  for f in bench_default bench_distG bench_forced_dist; do tail -1 $O/$f.json | python -c "
+  timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extras --repeats 1 > $O/bench_steps20.json 2> $O/bench_steps20.err; echo "steps20 rc=$?"
+  JFGPU_BENCH_RANK_TIMEOUT=200 timeout 260 python bench.py --gpus 2 --no-extras > $O/bench_gpus2_shared.json 2> $O/bench_gpus2_shared.err; echo "gpus2 (one device) rc=$?"
+  for f in bench_default bench_distG bench_forced_dist bench_steps20 bench_gpus2_shared; do tail -1 $O/$f.json | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('$f', d['value'], {k:v['ms'] for k,v in d['kernels'].items()}, 'whole_path_frac', d['roofline']['whole_path_frac'])
 for c,v in d.get('secondary',{}).items(): print('  ', c, v.get('value'), v.get('error'))
