@@ -63,7 +63,10 @@ inline size_t tile_rank_lds(size_t slot_bytes, uint32_t tile_bits, int tpb) {
 template <typename ITEM, bool RETURNING, typename SLOT, int TPB, int BLOCK = kTileBlock>
 __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kernel(DevTable T, SegList S, uint64_t tile0, uint32_t n_tiles) {
   // S holds ONE item array (the P2 output, or one pending batch of a single-level table: the host launches per batch)
-  constexpr int NP = 9216 / BLOCK;                          // register-held items per lane and round (9216 per round)
+  // register-held items per lane and round: 9216 items per round; 4608 for 8-byte items (k = 31 into a single tile of
+  // 8-byte slots: as many items as such a tile takes in one flush at load 0.5, and half the registers -- with 18
+  // two-register items those instantiations spilled 100 registers and ran 4 x slower per item)
+  constexpr int NP = (sizeof(ITEM) == 8 ? 4608 : 9216) / BLOCK;
   constexpr uint32_t kVec = 16 / sizeof(SLOT);              // slots per 16-byte vector
   constexpr uint32_t kBV = 4 / kVec;                        // vectors per bucket
   constexpr uint32_t kSlotBits = 8 * sizeof(SLOT);
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
   zero_counters();
   zero_tile();
   lds_barrier();
-  // One loop over CHUNKS: a unit's items in rounds of 9216 (nearly always one).  Offsets are fetched two units ahead, and
+  // One loop over CHUNKS: a unit's items in rounds of NP x BLOCK (nearly always one).  Offsets are fetched two units ahead, and
   // a chunk's items are requested as soon as the previous chunk's are placed (same registers): they travel during that
   // chunk's queue phase and store.
   const uint64_t* off = S.off[0];
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
   uint32_t t = blockIdx.x;
   uint64_t a0 = 0, b0 = 0, a1 = 0, b1 = 0; uint32_t d0 = 0, d1 = 0;
   ITEM cur[NP];
-  auto fetch = [&](uint64_t a, uint64_t b) {                // items src[a .. min(b, a + 9216)): block-uniform base + 32-bit index
+  auto fetch = [&](uint64_t a, uint64_t b) {                // items src[a .. min(b, a + NP x BLOCK)): block-uniform base + 32-bit index
     const ITEM* ub = src + a;
     const uint32_t n = (uint32_t)((b - a) < kRound ? (b - a) : kRound);
     if(b <= a) return;                                      // (block-uniform; such a unit is skipped)
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
 #pragma unroll
     for(int r = 0; r < NP; ++r)
       if((uint32_t)r * BLOCK + tid < n0 && !(holes && cur[r] == hole)) vm |= 1u << r;      // (what a clamped load fetched is not an item)
-    // a further round of the same unit (more than 9216 items: skewed input) starts from the tile as the previous round
+    // a further round of the same unit (more items than one round holds: skewed input) starts from the tile as the previous round
     // stored it -- merged, compacted, counted again on the way in -- by the lanes that stored it
     const uint32_t d_eff = first ? d0 : (TPB == 2 ? 0x0101u : 1u);
     if(d_eff) { load_tile(gt, d_eff); lds_barrier(); }       // (otherwise the previous store left tile and counters zeroed)
