@@ -297,12 +297,34 @@ int part_flush_t(jfgpu_table* t) {
     } else {
       // one-word keys: placement by rank inside buckets of four (kernels_tile.hip.hpp); two workgroups per CU
       const dim3 grid((unsigned)std::min<uint64_t>(ntile, (uint64_t)t->n_cu * 16));
-#define TR(SLOT, TPB) do { const size_t lds = tile_rank_lds(sizeof(SLOT), t->g.tile_bits, TPB); \
-        if(rt) hipLaunchKernelGGL((tile_rank_insert_kernel<ITEM, true, SLOT, TPB>), grid, tblock, lds, ts, t->dt, S, tile0, ntile); \
-        else   hipLaunchKernelGGL((tile_rank_insert_kernel<ITEM, false, SLOT, TPB>), grid, tblock, lds, ts, t->dt, S, tile0, ntile); } while(0)
+      // Which instantiation (kernels_tile.hip.hpp: plain, or HEAVY for high-coverage input) is decided from the flush
+      // itself: the first 64th of a large launch's units goes through the plain kernel with its counters on, the
+      // host reads them (one wait inside the flush) and the rest follows in the instantiation they call for.
+      // JFGPU_TILE_ADAPT=0: always plain; 2: always HEAVY (tests).
+      static const int adapt = getenv("JFGPU_TILE_ADAPT") ? atoi(getenv("JFGPU_TILE_ADAPT")) : 1;
+#define TRV(SLOT, TPB, HV, SM, SV, T0, NT) do { const size_t lds = tile_rank_lds(sizeof(SLOT), t->g.tile_bits, TPB); \
+        const dim3 gr((unsigned)std::min<uint64_t>((NT), (uint64_t)t->n_cu * 16)); \
+        if(rt) hipLaunchKernelGGL((tile_rank_insert_kernel<ITEM, true, SLOT, TPB, kTileBlock, HV, SM>), gr, tblock, lds, ts, t->dt, (SV), (T0), (NT)); \
+        else   hipLaunchKernelGGL((tile_rank_insert_kernel<ITEM, false, SLOT, TPB, kTileBlock, HV, SM>), gr, tblock, lds, ts, t->dt, (SV), (T0), (NT)); } while(0)
+#define TR(SLOT, TPB) do { \
+        bool heavy = adapt == 2; uint32_t done = 0; \
+        if(adapt == 1 && ntile >= 8192 && S.n == 1) { \
+          const uint32_t ns = ntile / 64; \
+          (void)hipMemsetAsync(&t->dt.counters[CTR_T_ITEMS], 0, 2 * sizeof(uint64_t), ts); \
+          TRV(SLOT, TPB, false, true, S, tile0, ns); \
+          uint64_t smp[2] = {0, 0}; \
+          if(hipMemcpyAsync(smp, &t->dt.counters[CTR_T_ITEMS], sizeof smp, hipMemcpyDeviceToHost, ts) == hipSuccess && hipStreamSynchronize(ts) == hipSuccess) \
+            heavy = smp[1] * 4 > smp[0]; \
+          done = ns; \
+        } \
+        SegList Sr = S; Sr.off[0] = S.off[0] + ((size_t)done << S.sh[0]); \
+        if(heavy) TRV(SLOT, TPB, true, false, Sr, tile0 + (uint64_t)(TPB) * done, ntile - done); \
+        else      TRV(SLOT, TPB, false, false, Sr, tile0 + (uint64_t)(TPB) * done, ntile - done); } while(0)
+      (void)grid;
       if(t->g.slot32) { if(pair) TR(unsigned int, 2); else TR(unsigned int, 1); }
       else TR(unsigned long long, 1);
 #undef TR
+#undef TRV
     }
   };
   auto launch_tiles = [&](const SegList& S, uint64_t tile0, uint32_t ntile, uint64_t units) {

@@ -676,11 +676,13 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
   if(const char* m = getenv("JFGPU_P2_CAP")) t->p2_cap = (uint32_t)atoi(m) / kGran * kGran;
   if(const char* m = getenv("JFGPU_P2_SLACK")) t->p2_slack = atof(m);
   {
-#define TATTR(I, S, P) HIP_TRY(hipFuncSetAttribute((const void*)tile_rank_insert_kernel<I, true, S, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_rank_lds(sizeof(S), kMaxTileBits, P))); \
-                       HIP_TRY(hipFuncSetAttribute((const void*)tile_rank_insert_kernel<I, false, S, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_rank_lds(sizeof(S), kMaxTileBits, P)))
+#define TATTR1(I, R, S, P, H, M) HIP_TRY(hipFuncSetAttribute((const void*)tile_rank_insert_kernel<I, R, S, P, kTileBlock, H, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_rank_lds(sizeof(S), kMaxTileBits, P)))
+#define TATTR(I, S, P) TATTR1(I, true, S, P, false, false); TATTR1(I, false, S, P, false, false); TATTR1(I, true, S, P, true, false); TATTR1(I, false, S, P, true, false); \
+                       TATTR1(I, true, S, P, false, true); TATTR1(I, false, S, P, false, true)
     TATTR(uint32_t, unsigned int, 1); TATTR(uint32_t, unsigned int, 2); TATTR(uint32_t, unsigned long long, 1);
     TATTR(uint64_t, unsigned int, 1); TATTR(uint64_t, unsigned int, 2); TATTR(uint64_t, unsigned long long, 1);
 #undef TATTR
+#undef TATTR1
     HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_sorted_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_sorted_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_sorted_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));

@@ -34,6 +34,7 @@ constexpr int kPerThread = kPerLane;           // positions per lane per tile (1
 constexpr int kTilePos = kBlock * kPerThread;  // 4096 sequence positions per block iteration
 
 enum Counter : int { CTR_FULL = 0, CTR_MERS = 1, CTR_OVF_FULL = 2, CTR_OVF_USED = 3, CTR_MISROUTED = 4, CTR_DIRECT = 5,
+                     CTR_T_ITEMS = 6, CTR_T_QUEUED = 7 /* tile stage: items placed / items past rank 3 (the sampling launch of a flush) */,
                      CTR_PROF0 = 8 /* .. 11: phase clocks of a -DJFGPU_TILE_PROF build */, CTR_COUNT = 12 };
 
 // -DJFGPU_PHASE_PROF builds: shader clocks per phase of the partition kernels, as wave 0 of every block sees them,

@@ -60,7 +60,15 @@ inline size_t tile_rank_lds(size_t slot_bytes, uint32_t tile_bits, int tpb) {
   return nslots * slot_bytes + (nslots >> kBucketBits) * 2 + 16 + kTileQueueBytes;
 }
 
-template <typename ITEM, bool RETURNING, typename SLOT, int TPB, int BLOCK = kTileBlock>
+// HEAVY: the instantiation for high-coverage input, where most of a round's items find their bucket full of -- after M --
+// their own key.  One at a time through the queue that is a chain of dependent LDS round trips per item and lane
+// (bench.py --dist G: T 53 ms against 28 on uniform reads).  Here a round's items stay in their registers past M and are
+// resolved in bulk first (C0): home buckets of six items fetched together, tags compared, adds issued together; only
+// what found no match goes on to the queue, and the prefetch of the next round's items starts after C0 instead of before
+// M.  Which instantiation a flush runs is decided by the host from a sample of the flush itself (the first units go
+// through the plain kernel, which counts how many items went past rank 3: SAMPLE) -- both paths in one kernel cost the
+// common case 3 % (instruction cache).
+template <typename ITEM, bool RETURNING, typename SLOT, int TPB, int BLOCK = kTileBlock, bool HEAVY = false, bool SAMPLE = false>
 __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kernel(DevTable T, SegList S, uint64_t tile0, uint32_t n_tiles) {
   // S holds ONE item array (the P2 output, or one pending batch of a single-level table: the host launches per batch)
   // register-held items per lane and round: 9216 items per round; 4608 for 8-byte items (k = 31 into a single tile of
@@ -257,10 +265,12 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
     for(int r = 0; r < NP; ++r)
       if((vm >> r) & 1) { const uint32_t b = home_of(it[r]) >> kBucketBits; old[r] = atomicAdd(&s_cnt[b >> 1], 1u << ((b & 1) * 16)); }
   };
-  // A, second half, then C.  `again`: where the round's items came from (held-back items are read again from there:
+  // A, second half, then M and C.  `again`: where the round's items came from (held-back items are read again from there:
   // indexing the register array would put it in scratch).  after_a(): it[] is dead from there on.
+  [[maybe_unused]] uint32_t smp_items = 0, smp_queued = 0;   // SAMPLE: this lane's items / this wave's items past rank 3
   auto place_round = [&](ITEM (&it)[NP], uint32_t vm, const uint32_t (&old)[NP], uint64_t unit_slot0, const ITEM* again, auto&& after_a) {
-    uint32_t qn = 0, pend = 0;                                 // qn: items this wave queued (wave-uniform)
+    uint32_t qn = 0, pend = 0;                                 // qn: items of this wave past rank 3 (wave-uniform)
+    [[maybe_unused]] uint32_t ovm = 0;
 #pragma unroll
     for(int r = 0; r < NP; ++r) JF_OPAQUE(it[r]);
 #pragma unroll
@@ -272,21 +282,79 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
         if(rank < 4) s_tile[(b << kBucketBits) + rank] = inc | occ | (SLOT)((uint64_t)it[r] & (g.occ_bit - 1));
         else ov = true;
       }
-      const unsigned long long m = __ballot(ov);
-      if(ov) {
-        const uint32_t at = qn + (uint32_t)__popcll(m & below);
-        if(at < qcap) s_q[at] = it[r]; else pend |= 1u << r;
+      if constexpr(HEAVY) { if(ov) ovm |= 1u << r; }
+      else {
+        const unsigned long long m = __ballot(ov);
+        if(ov) {
+          const uint32_t at = qn + (uint32_t)__popcll(m & below);
+          if(at < qcap) s_q[at] = it[r]; else pend |= 1u << r;
+        }
+        qn += (uint32_t)__popcll(m);
       }
-      qn += (uint32_t)__popcll(m);
     }
-    after_a();
+    if constexpr(SAMPLE) { smp_items += (uint32_t)__popc(vm); smp_queued += qn; }
+    if constexpr(!HEAVY) after_a();
     lds_barrier();
     JF_PHASE(pc, 2);
     merge_tile(unit_slot0);
     lds_barrier();
     JF_PHASE(pc, 6);
+    uint32_t nq = qn < qcap ? qn : qcap;                       // wave-uniform
+    if constexpr(HEAVY) {
+      // ---- C0: the items past rank 3, in bulk (it[] is still this round's)
+      uint32_t q2 = 0, carry = 0;
+      constexpr int CB = 6;
+#pragma unroll
+      for(int r0 = 0; r0 < NP; r0 += CB) {
+        SLOT wb[CB][4];
+#pragma unroll
+        for(int k = 0; k < CB; ++k)
+          if(r0 + k < NP && ((ovm >> (r0 + k)) & 1)) load_bucket(home_of(it[r0 + k < NP ? r0 + k : 0]) & ~3u, wb[k]);
+#pragma unroll
+        for(int k = 0; k < CB; ++k) {
+          if(r0 + k >= NP) continue;
+          const int r = r0 + k;
+          bool miss = false;
+          if((ovm >> r) & 1) {
+            const ITEM x = it[r];
+            const SLOT low = occ | (SLOT)((uint64_t)x & (g.occ_bit - 1));
+            const uint32_t bs = home_of(x) & ~3u;
+            int hit = -1;
+#pragma unroll
+            for(int i = 3; i >= 0; --i) if((wb[k][i] & lmask) == low) hit = i;
+            if(hit >= 0) {
+              if(RETURNING) {
+                const SLOT prev = atomicAdd(&s_tile[bs + hit], inc);
+                if(((uint64_t)prev >> cshift) + 1 > g.cnt_max) carry |= 1u << r;
+              } else atomicAdd(&s_tile[bs + hit], inc);
+            } else miss = true;
+          }
+          const unsigned long long m2 = __ballot(miss);
+          if(miss) {
+            const uint32_t at = q2 + (uint32_t)__popcll(m2 & below);
+            if(at < qcap) s_q[at] = it[r]; else pend |= 1u << r;
+          }
+          q2 += (uint32_t)__popcll(m2);
+        }
+      }
+      (void)__ballot(true);                                    // (the wave's queue entries are all written before any lane reads them: lockstep on the device, a rendezvous in the host emulation)
+      after_a();
+      while(carry) {                                           // rare: an add above left its count field
+        const uint32_t r = (uint32_t)__ffs((int)carry) - 1u; carry &= carry - 1;
+        const ITEM x = again[r * BLOCK + threadIdx.x];
+        const SLOT low = occ | (SLOT)((uint64_t)x & (g.occ_bit - 1));
+        const uint32_t bs = home_of(x) & ~3u;
+        SLOT w[4];
+        load_bucket(bs, w);
+        uint32_t hit = 0;
+#pragma unroll
+        for(int i = 3; i >= 1; --i) if((w[i] & lmask) == low) hit = (uint32_t)i;      // (the entry is there and does not move)
+        if((w[0] & lmask) == low) hit = 0;
+        ovf_add_call(T.ovf_key, T.ovf_cnt, T.ovf_mask, T.counters, unit_slot0 + bs + hit, 1);
+      }
+      nq = q2 < qcap ? q2 : qcap;
+    }
     // ---- C: this wave's queue, then what its lanes held back (one copy of the insert for both)
-    const uint32_t nq = qn < qcap ? qn : qcap;                 // wave-uniform
     for(uint32_t i = lane;; i += 64) {
       ITEM x;
       if(i < nq) x = s_q[i];
@@ -364,6 +432,14 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
     else c0 += kRound;
   }
   JF_PHASE_FLUSH(pc, 16);
+  if constexpr(SAMPLE) {
+    uint32_t w = smp_items;
+    for(int o = 32; o > 0; o >>= 1) w += __shfl_down(w, o, 64);
+    if(lane == 0) {
+      atomicAdd((unsigned long long*)&T.counters[CTR_T_ITEMS], (unsigned long long)w);
+      atomicAdd((unsigned long long*)&T.counters[CTR_T_QUEUED], (unsigned long long)smp_queued);
+    }
+  }
 }
 
 }  // namespace jfgpu
