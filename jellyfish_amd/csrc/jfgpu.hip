@@ -122,7 +122,7 @@ struct jfgpu_table {
   int p2_single = 1;             // ... and in one pass, reservations inside fixed regions (JFGPU_P2_SINGLE: 0 exact count + scatter, 1 when the
                                  // regions would be mostly items, 2 always); p2_cap: test knob, items per region
   uint32_t p2_cap = 0;
-  double p2_slack = 0.08;        // head-room of those regions over the mean load of a pair (JFGPU_P2_SLACK)
+  double p2_slack = -1;          // head-room of those regions over the mean load of a destination (JFGPU_P2_SLACK); < 0: 30 % for 4-byte items, 8 % for 16-byte ones
   bool tile_pair = true;         // 32-bit slots: P2 routes to pairs of tiles (JFGPU_TILE_PAIR=0: single tiles, for A/B)
   int flush_groups = 1;          // P2 / tile-insert pipeline depth of a flush (JFGPU_FLUSH_GROUPS).  Measured: 8 groups on two
                                  // streams run P2 and T concurrently but no faster (both are LDS-bound), so one launch each is the default
