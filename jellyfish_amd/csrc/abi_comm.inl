@@ -57,6 +57,7 @@ struct jfgpu_comm {
     unsigned int* d_gcur = nullptr;              // gcur[2 * 1024] (u32) then tot[1024] (u64)
     std::vector<uint64_t> claims;
     unsigned long long* d_claimed = nullptr;     // k-mers the senders said they sent here (item path), summed on the device
+    unsigned long long* d_arrived = nullptr;     // [2]: k-mers the receive side actually found in what arrived (regions split + direct inserts + stragglers kept); scratch word
     double ipb = 0;
     uint64_t strag_seen = 0;
   };
@@ -94,6 +95,8 @@ int comm_init_rank(jfgpu_comm* c, jfgpu_comm::Rank& R) {
   HIP_TRY(hipMalloc((void**)&R.d_gcur, 1024 * 16));
   HIP_TRY(hipMalloc((void**)&R.d_claimed, 8));
   HIP_TRY(hipMemset(R.d_claimed, 0, 8));
+  HIP_TRY(hipMalloc((void**)&R.d_arrived, 16));
+  HIP_TRY(hipMemset(R.d_arrived, 0, 16));
   return JFGPU_OK;
 }
 
@@ -219,6 +222,20 @@ __global__ void comm_add_claims_kernel(const uint64_t* __restrict__ claims, int 
   if(blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long s = 0; for(int i = 0; i < n; ++i) s += claims[i]; *total += s; }
 }
 
+// The receiver's own count of what arrived (the claims above are the senders' word): before the split, remember the
+// table's direct-insert counter; after it, add what the split stored in its regions (tot[]) and what it inserted directly.
+__global__ void comm_mark_direct_kernel(const uint64_t* __restrict__ counters, unsigned long long* __restrict__ arrived) {
+  if(blockIdx.x == 0 && threadIdx.x == 0) arrived[1] = counters[CTR_DIRECT];
+}
+__global__ void comm_count_arrived_kernel(const unsigned long long* __restrict__ tot, uint32_t nb, const uint64_t* __restrict__ counters,
+                                          unsigned long long* __restrict__ arrived) {
+  unsigned long long s = 0;
+  for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) s += tot[j];
+  for(int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if((threadIdx.x & 63) == 0 && s) atomicAdd(&arrived[0], s);
+  if(threadIdx.x == 0) atomicAdd(&arrived[0], (unsigned long long)(counters[CTR_DIRECT] - arrived[1]));
+}
+
 // What arrived for the previous step (item path): one split of every coarse bucket into the shard's own P1 buckets, then
 // the stragglers; the result is a pending batch.
 int comm_insert_prev_items(jfgpu_comm* c, jfgpu_comm::Rank& R, int rank) {
@@ -250,6 +267,7 @@ int comm_insert_prev_items(jfgpu_comm* c, jfgpu_comm::Rank& R, int rank) {
   const uint64_t* r_offs = reinterpret_cast<const uint64_t*>(rb + L.r_offs_at);
   const uint64_t* r_strag = reinterpret_cast<const uint64_t*>(rb + L.r_strag_at);
   hipLaunchKernelGGL(comm_add_claims_kernel, dim3(1), dim3(64), 0, t->stream, reinterpret_cast<const uint64_t*>(rb + L.r_claims_at), W, R.d_claimed);
+  hipLaunchKernelGGL(comm_mark_direct_kernel, dim3(1), dim3(64), 0, t->stream, t->dt.counters, R.d_arrived);
   // sender p's regions of my coarse buckets sit at r_items + p * nbc * cap, its offsets speak of its own whole output
   // (bucket j of 1024 at j * cap): bases shifted so that "bucket = rank * nbc + coarse" finds both
   SegList S; memset(&S, 0, sizeof S);
@@ -280,10 +298,11 @@ int comm_insert_prev_items(jfgpu_comm* c, jfgpu_comm::Rank& R, int rank) {
     else             { if(sb <= 2) SPLIT(false, 1); else if(sb == 3) SPLIT(false, 2); else SPLIT(false, 4); }
 #undef SPLIT
     hipLaunchKernelGGL(granule_finish_kernel, dim3(4), dim3(256), 0, t->stream, gcur, cap2, nb, b.off);
+    hipLaunchKernelGGL(comm_count_arrived_kernel, dim3(1), dim3(256), 0, t->stream, b.tot, nb, t->dt.counters, R.d_arrived);
     for(int p = 0; p < W; ++p) {
       const uint64_t* lst = r_strag + (size_t)p * (1 + L.S);
-      if(t->returning) hipLaunchKernelGGL(straggler_insert_kernel<true>, dim3(64), dim3(kBlock), 0, t->stream, t->dt, pd, lst + 1, (const unsigned long long*)lst, L.S, (uint32_t)rank, L.cbits);
-      else             hipLaunchKernelGGL(straggler_insert_kernel<false>, dim3(64), dim3(kBlock), 0, t->stream, t->dt, pd, lst + 1, (const unsigned long long*)lst, L.S, (uint32_t)rank, L.cbits);
+      if(t->returning) hipLaunchKernelGGL(straggler_insert_kernel<true>, dim3(64), dim3(kBlock), 0, t->stream, t->dt, pd, lst + 1, (const unsigned long long*)lst, L.S, (uint32_t)rank, L.cbits, R.d_arrived);
+      else             hipLaunchKernelGGL(straggler_insert_kernel<false>, dim3(64), dim3(kBlock), 0, t->stream, t->dt, pd, lst + 1, (const unsigned long long*)lst, L.S, (uint32_t)rank, L.cbits, R.d_arrived);
     }
   }
   HIP_TRY(hipGetLastError());
@@ -769,6 +788,7 @@ void comm_free_rank(jfgpu_comm::Rank& R) {
   if(R.d_xc) hipFree(R.d_xc);
   if(R.d_gcur) hipFree(R.d_gcur);
   if(R.d_claimed) hipFree(R.d_claimed);
+  if(R.d_arrived) hipFree(R.d_arrived);
 }
 
 }  // namespace
@@ -988,16 +1008,22 @@ int jfgpu_comm_world(const jfgpu_comm* c, int* world, int* rank) {
 }
 
 // Complete the last step's exchange and insert (call before jfgpu_sync / reading the tables).  sent / received: this
-// rank's (local: all ranks') totals since creation, for the conservation check sum(sent) == sum(received).
+// rank's (local: all ranks') totals since creation, for the conservation check sum(sent) == sum(received).  Item-path
+// steps: `received` counts what the receive side found in the regions and straggler lists that arrived (not what the
+// senders announced; the two are compared here, and a difference is an error).
 int jfgpu_comm_finish(jfgpu_comm* c, uint64_t* sent, uint64_t* received) {
   if(!c) return fail(JFGPU_E_INVALID, "null communicator");
   HIP_TRY(hipSetDevice(c->device));
   uint64_t s = 0, r = 0;
   for(auto& R : c->ranks) {
     if(R.t) { int rc = comm_insert_prev(c, R); if(rc) return rc; HIP_TRY(hipStreamSynchronize(R.t->stream)); }
-    unsigned long long claimed = 0;                          // item-path steps: what the senders said they sent here
+    unsigned long long claimed = 0, arrived = 0;             // item-path steps: what the senders said they sent here / what this rank found
     HIP_TRY(hipMemcpy(&claimed, R.d_claimed, 8, hipMemcpyDeviceToHost));
-    s += R.sent; r += R.received + claimed;
+    HIP_TRY(hipMemcpy(&arrived, R.d_arrived, 8, hipMemcpyDeviceToHost));
+    if(arrived != claimed)
+      return fail(JFGPU_E_HIP, "exchange: the senders announced " + std::to_string(claimed) + " k-mers for rank " + std::to_string(R.t ? (int)R.t->g.shard_id : c->rank) +
+                               ", " + std::to_string(arrived) + " were found in what arrived");
+    s += R.sent; r += R.received + arrived;
   }
   HIP_TRY(hipStreamSynchronize(c->xstream));
   if(sent) *sent = s;

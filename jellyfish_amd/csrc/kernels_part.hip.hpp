@@ -1065,13 +1065,15 @@ __global__ __launch_bounds__(kPBlock) void p1_route_granule_kernel(DevTable T, P
 template <bool RETURNING>
 __global__ __launch_bounds__(kBlock) void straggler_insert_kernel(DevTable T, PartGeom P, const uint64_t* __restrict__ rec,
                                                                   const unsigned long long* __restrict__ n_ptr, uint32_t cap,
-                                                                  uint32_t owner, uint32_t cbits) {
+                                                                  uint32_t owner, uint32_t cbits, unsigned long long* __restrict__ kept = nullptr) {
   const unsigned long long n = *n_ptr < cap ? *n_ptr : cap;
+  uint32_t mine = 0;                                             // kept: how many of the list were this owner's (the receiver's count of what arrived)
   for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t r = rec[i];
     const uint32_t gb = (uint32_t)(r >> 32);
-    if((gb >> cbits) == owner) item_direct_insert<RETURNING>(T, P, gb & ((1u << cbits) - 1), r & 0xFFFFFFFFull);
+    if((gb >> cbits) == owner) { item_direct_insert<RETURNING>(T, P, gb & ((1u << cbits) - 1), r & 0xFFFFFFFFull); ++mine; }
   }
+  if(kept && mine) atomicAdd(kept, (unsigned long long)mine);
 }
 
 // After the granule pass: bucket bounds in the pair format of SegList (sh == 1).
