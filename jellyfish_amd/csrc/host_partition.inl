@@ -374,9 +374,9 @@ int part_flush_t(jfgpu_table* t) {
     // block may strand one reservation per destination.  When the regions of the whole table do not fit the arena beside
     // what is pending, the P1 buckets go through P2 and the tile insert in `single_groups` groups sharing one buffer.
     constexpr uint32_t kG2Single = 4;                       // blocks per P1 bucket
-    constexpr bool kSingleItems = sizeof(ITEM) == 4 || sizeof(ITEM) == 16;
+    constexpr bool kSingleItems = sizeof(ITEM) == 4 || sizeof(ITEM) == 8 || sizeof(ITEM) == 16;
     uint32_t cap2 = 0, single_groups = 1; unsigned int* d_gcur2 = nullptr; uint64_t* d_off2 = nullptr; ITEM* out2 = nullptr; bool own2 = false;
-    const bool single_ok = kSingleItems && t->p2_single && (sizeof(ITEM) == 16 || pair) && t->flush_groups <= 1;
+    const bool single_ok = kSingleItems && t->p2_single && (sizeof(ITEM) >= 8 || pair) && t->flush_groups <= 1;      // (4-byte items: pairs only; 8- and 16-byte items: single tiles)
     const uint64_t n_dest = pair ? n_tiles >> 1 : n_tiles;
     if(single_ok) {
       const uint64_t mean = total / n_dest, strand = (uint64_t)kG2Single * kGran;
@@ -384,7 +384,7 @@ int part_flush_t(jfgpu_table* t) {
         // head-room over the mean load: a pair of tiles takes ~8 K items a flush, 1 % standard deviation on uniform reads --
         // but on high-coverage input its ~100 hot k-mers come 80 times each (10 %), and what overflows a region is
         // inserted with global atomics: with 8 % head-room P2 took 38 ms on distribution G instead of 29
-        const double slack = t->p2_slack >= 0 ? t->p2_slack : (sizeof(ITEM) == 4 ? 0.30 : 0.08);
+        const double slack = t->p2_slack >= 0 ? t->p2_slack : (sizeof(ITEM) <= 8 ? 0.30 : 0.08);
         cap2 = (uint32_t)(((uint64_t)((double)mean * (1.0 + slack)) + strand + 2 * kGran - 1) / kGran * kGran);
         if(t->p2_cap) cap2 = t->p2_cap;
         const size_t mark = t->ws_used;
@@ -483,6 +483,10 @@ int part_flush_t(jfgpu_table* t) {
             const size_t lds = (size_t)kPBlock * kP2PairPer * sizeof(ITEM);
             if(rt) hipLaunchKernelGGL((p2_granule_kernel<uint32_t, TableDirect<true>, kP2PairPer>), g1p, block, lds, t->stream, TableDirect<true>{t->d_dt, t->pg, (unsigned long long*)&t->dt.counters[CTR_DIRECT]}, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest, (uint32_t*)out_v, b0);
             else   hipLaunchKernelGGL((p2_granule_kernel<uint32_t, TableDirect<false>, kP2PairPer>), g1p, block, lds, t->stream, TableDirect<false>{t->d_dt, t->pg, (unsigned long long*)&t->dt.counters[CTR_DIRECT]}, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest, (uint32_t*)out_v, b0);
+          } else if constexpr(sizeof(ITEM) == 8) {     // keys of 22 to 32 bases: 8-byte items into single tiles, chunks of 112 KiB
+            const size_t lds = (size_t)kPBlock * kP2MidPer * sizeof(ITEM);
+            if(rt) hipLaunchKernelGGL((p2_granule_kernel<uint64_t, TableDirect<true>, kP2MidPer>), g1p, block, lds, t->stream, TableDirect<true>{t->d_dt, t->pg, (unsigned long long*)&t->dt.counters[CTR_DIRECT]}, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest, (uint64_t*)out_v, b0);
+            else   hipLaunchKernelGGL((p2_granule_kernel<uint64_t, TableDirect<false>, kP2MidPer>), g1p, block, lds, t->stream, TableDirect<false>{t->d_dt, t->pg, (unsigned long long*)&t->dt.counters[CTR_DIRECT]}, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest, (uint64_t*)out_v, b0);
           } else {
             const size_t lds = (size_t)kPBlock * kP2WidePer * sizeof(ITEM);
             if(rt) hipLaunchKernelGGL((p2_granule_kernel<u128, WideDirect<true>, kP2WidePer>), g1p, block, lds, t->stream, WideDirect<true>{t->wt, t->pg}, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest, (u128*)out_v, b0);

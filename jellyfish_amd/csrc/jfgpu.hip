@@ -712,6 +712,8 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
                   HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint32_t, TableDirect<false>, kP2PairPer, SW>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4))
     SATTR(1); SATTR(2); SATTR(4);
 #undef SATTR
+    HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint64_t, TableDirect<true>, kP2MidPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2MidPer * 8));
+    HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint64_t, TableDirect<false>, kP2MidPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2MidPer * 8));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint32_t, TableDirect<true>, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint32_t, TableDirect<false>, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint32_t, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));

@@ -429,6 +429,7 @@ __global__ __launch_bounds__(kPBlock) void p1_keys_scatter_sorted_kernel(DevTabl
 // items by destination bucket in LDS and then writes whole runs (consecutive lanes ->
 // consecutive addresses).  Same block->slice assignment and per-(block, bucket) cursors as
 // p2_kernel<.., false> counted, so positions are exact and no global atomic is needed.
+constexpr int kP2MidPer = 14;       // ... of 8-byte items (single tiles): 14 Ki items = 112 KiB
 constexpr int kP2PairPer = 28;      // items per lane and chunk when P2 routes to pairs of tiles (28 Ki items = 112 KiB of LDS; 32 would spill registers)
 template <typename ITEM, int PER_THREAD>
 __global__ __launch_bounds__(kPBlock) void p2_scatter_sorted_kernel(PartGeom P, uint32_t tag_bits, SegList S,

@@ -923,6 +923,39 @@ def test_genome_read_generator(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["exact", "single_pass", "single_pass_overflow"])
+@pytest.mark.parametrize("k", [24, 31])
+def test_p2_variants_of_8_byte_items_give_the_same_table(gpu, monkeypatch, variant, k):
+    """Keys of 22 to 32 bases travel as 8-byte items into 8-byte slots, single tiles.  Their P2 is the exact count + scatter
+    or -- large flushes -- the single-pass kernel with fixed regions per tile (p2_granule_kernel<uint64_t>), here forced at a
+    size the oracle can follow, once with regions far too small (most items take the overflow path).  Two flushes, the
+    second into dirty tiles; low-complexity stretches; dump and digest must equal the oracle's."""
+    env = {"exact": {"JFGPU_P2_SINGLE": "0"}, "single_pass": {"JFGPU_P2_SINGLE": "2"},
+           "single_pass_overflow": {"JFGPU_P2_SINGLE": "2", "JFGPU_P2_CAP": "64"}}[variant]
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
+    rng = random.Random(k * 13)
+    seq = rnd_seq(rng, 500000, "ACGT") + b"N" + b"A" * 3000 + b"N" + rnd_seq(rng, 100000, "AC") + b"N" + rnd_seq(rng, 100000, "ACGTN")
+    exp = oracle_map(seq, k, True)
+    with gpu.Table(k, 1 << 26) as t:
+        assert t.info.slot_bytes == 8
+        t.set_mode(2)
+        t.reserve(len(seq))
+        d = t.malloc(len(seq) + 64)
+        t.h2d(d, np.frombuffer(seq, dtype=np.uint8))
+        half = len(seq) // 2
+        t.count_ascii_dev(d, half)
+        t.sync()
+        t.count_ascii_dev(d + half - (k - 1), len(seq) - half + (k - 1))
+        t.sync()
+        assert table_map(gpu, t) == exp
+        keys = np.array(list(exp.keys()), dtype=np.uint64)
+        cnts = np.array(list(exp.values()), dtype=np.uint64)
+        assert t.digest() == gpu.digest_of(keys, cnts)
+        t.free(d)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("variant", ["pair_exact", "single_pass", "single_pass_overflow", "tiles"])
 def test_p2_variants_of_32bit_slots_give_the_same_table(gpu, monkeypatch, variant):
     """32-bit items into 32-bit slots have three P2 forms: exact count + scatter to single tiles, the same to pairs of tiles
