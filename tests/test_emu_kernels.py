@@ -20,7 +20,8 @@ SELECTION = [
     "tests/test_gpu_parity.py::test_comm_local_transport_equals_single_table",
     "tests/test_gpu_parity.py::test_comm_item_path_equals_single_table[4-None]",
     "tests/test_gpu_parity.py::test_comm_item_path_equals_single_table[2-3]",
-    "tests/test_gpu_parity.py::test_p2_variants_of_32bit_slots_give_the_same_table",
+    "tests/test_gpu_parity.py::test_p2_variants_of_32bit_slots_give_the_same_table[single_pass]",
+    "tests/test_gpu_parity.py::test_p2_variants_of_32bit_slots_give_the_same_table[tiles]",
     "tests/test_cli_gpu.py::test_file_parts_cover_the_file_exactly_once",
     "tests/test_cli_gpu.py::test_pipes_are_read_in_pieces_of_whole_records",
     "tests/test_gpu_wide.py::test_dump_of_saturated_count_fields_over_all_ones_tags",
