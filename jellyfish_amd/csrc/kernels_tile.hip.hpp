@@ -178,20 +178,37 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
       for(int q = 0; q < 4; ++q) if(oc[q]) ovf_add_call(T.ovf_key, T.ovf_cnt, T.ovf_mask, T.counters, bucket_slot0 + q, (uint64_t)oc[q]);
     }
   };
-  // M for the whole unit, one lane per bucket, between A and C: all of a lane's buckets are fetched in one LDS round
-  // trip; the ones holding equal tags are folded and written back.
+  // M for the whole unit, between A and C.  Every lane looks at its NBK buckets (fetched MB at a time in one LDS round
+  // trip); the buckets that hold equal tags -- a few per wave on uniform reads, a hundred per unit on high-coverage
+  // input -- go on a per-wave list and are folded from there one per lane: a wave runs the (long, branch-free) merge once
+  // per 64 such buckets instead of once per bucket position in which any of its lanes has one.  The list lives in the
+  // bucket counters' LDS, which nothing reads between the ranks of A and the store that zeroes them.
   auto merge_tile = [&](uint64_t unit_slot0) {
-    constexpr uint32_t MB = (sizeof(ITEM) + sizeof(SLOT) == 8 && NBK >= 4) ? 4 : (NBK >= 2 ? 2 : 1);      // buckets in flight per lane (registers: the next round's items are too)
-#pragma unroll
+    constexpr uint32_t MB = (TPB == 2 && sizeof(ITEM) + sizeof(SLOT) == 8 && NBK >= 4) ? 4 : (NBK >= 2 ? 2 : 1);      // buckets in flight per lane (registers: the next round's items are too)
+    constexpr uint32_t R = MB >= 4 ? 512 : 256;              // ring of bucket numbers per wave: 63 waiting + MB x 64 new at most
+    static_assert((BLOCK / 64) * R * 2 <= nbkt * 2, "the merge list must fit the bucket counters");
+    uint16_t* const lst = reinterpret_cast<uint16_t*>(s_cnt) + (threadIdx.x >> 6) * R;
+    uint32_t head = 0, cnt = 0;                               // wave-uniform
+#pragma unroll 1
     for(uint32_t k0 = 0; k0 < NBK; k0 += MB) {
       SLOT wb[MB][4];
 #pragma unroll
       for(uint32_t k = 0; k < MB; ++k) load_bucket((threadIdx.x + (k0 + k) * BLOCK) << kBucketBits, wb[k]);
 #pragma unroll
       for(uint32_t k = 0; k < MB; ++k) {
-        const uint32_t b = threadIdx.x + (k0 + k) * BLOCK;
-        SLOT (&w)[4] = wb[k];
-        if(has_dups(w)) {
+        const bool dup = has_dups(wb[k]);
+        const unsigned long long m = __ballot(dup);
+        if(dup) lst[(head + cnt + (uint32_t)__popcll(m & below)) & (R - 1)] = (uint16_t)(threadIdx.x + (k0 + k) * BLOCK);
+        cnt += (uint32_t)__popcll(m);
+      }
+      const bool last = k0 + MB >= NBK;
+      while(cnt >= 64 || (last && cnt)) {                     // (wave-uniform)
+        const uint32_t n = cnt < 64 ? cnt : 64;
+        (void)__ballot(true);                                 // (the list entries are written before they are read: lockstep on the device, a rendezvous in the host emulation)
+        if(lane < n) {
+          const uint32_t b = lst[(head + lane) & (R - 1)];
+          SLOT w[4];
+          load_bucket(b << kBucketBits, w);
           merge_bucket(w, unit_slot0 + ((uint64_t)b << kBucketBits));
 #pragma unroll
           for(uint32_t q = 0; q < kBV; ++q) {
@@ -201,6 +218,7 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
             *reinterpret_cast<uint4*>(s_tile + ((size_t)b << kBucketBits) + q * kVec) = v;
           }
         }
+        head += n; cnt -= n;
       }
     }
   };
