@@ -53,7 +53,11 @@ CONFIGS = {
 C4_NAME = ("BASELINE configs[3]: k=21 -C, {total:.1f} Gbp of 150 bp reads hash-prefix partitioned across {world} GPUs ({gbp:.1f} Gbp and a 2^{lsize}-slot "
            "shard per GPU, {slot_bytes}-byte slots), routed k-mers exchanged by RCCL over xGMI")
 GBP_PER_GPU_SHARDED = 12.5                       # configs[3]: 100 Gbp over 8 GPUs; kept at every N > 1 (weak scaling)
-DESIGN_MIN_BYTES = {"C2": 150.0 / 130.0 + 4.0 + 4.0}   # input + the 4-byte item written once + the 4-byte slot written once (what this design cannot go below)
+# What the three-stage design (P1 -> P2 -> T) cannot go below, in HBM bytes per k-mer occurrence of C2: the input (1.15), the
+# 4-byte item written by P1, read and written by P2 and read by T (16), and the table written once -- 2^34 4-byte slots for
+# 8.67 G occurrences, i.e. 7.9 B per occurrence at load 0.5.  (Round 3 quoted 9.15: it left out P2's read + write, T's read
+# and the empty half of the table.)
+DESIGN_MIN_BYTES = {"C2": 150.0 / 130.0 + 4 * 4.0 + 4.0 * 2 ** 34 / (10e9 / 150 * 130)}
 
 
 def b_alg(cfg, k):
@@ -61,6 +65,18 @@ def b_alg(cfg, k):
     if cfg == "C3":      # Bloom pass: input + 10 cells x (1 B read + 1 B write); count pass: input + slot RMW
         return {"bc": seq + 20.0, "count": seq + 16.0}
     return {"count": seq + 2.0 * CONFIGS[cfg]["slot"]}
+
+
+def kernel_sources_sha():
+    """sha256 over the engine's device and host sources (jellyfish_amd/csrc): what a committed PMC traffic file must have
+    been taken on to be quoted (tools/make_traffic_json.py records the same figure)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "jellyfish_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp", ".inl")):
+            h.update(name.encode()); h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()
 
 
 def write_fasta(arr, path):
@@ -140,7 +156,9 @@ def cpu_baseline(cfg, sample, k, tmpdir):
     stats = read_digest(dgp)
     res.update({"value": kmers / t_best, "cores": best_t,
                 "sample": "first %d reads (%.0f Mbp) of the same synthetic input, jellyfish 2.3.1 classes (oracle/_ref, -DHAVE_SSE -msse2), "
-                          "-t %d, table presized 2^%d (load %.2f), Counting phase only" % (n_reads, n_reads * READ_LEN / 1e6, best_t, size.bit_length() - 1, kmers / size)})
+                          "-t %d, table presized 2^%d (load %.2f), Counting phase only.  The sample's table is %.1f GB as the reference packs it, against "
+                          "~50 GB at the full job's 2^34 slots: cache- and TLB-friendlier than C2 scale, so this flatters the CPU if anything"
+                          % (n_reads, n_reads * READ_LEN / 1e6, best_t, size.bit_length() - 1, kmers / size, size * 25.0 / 8 / 1e9)})
     if cfg == "C2":
         variants = {}
         # one thread, on a tenth of the sample (same table, so the load factor is lower: stated)
@@ -244,7 +262,9 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
     if args.as_secondary:
-        args.no_extras = True; args.no_cpu_baseline = True; args.repeats = 1
+        args.no_extras = True; args.no_cpu_baseline = True
+        if "--repeats" not in sys.argv:
+            args.repeats = 1
     shared = 1                                       # ranks per device (> 1: fewer GPUs than ranks, see spawn_ranks)
     if os.environ.get("JFGPU_BENCH_SHARED_DEVICES") == "1":
         import torch
@@ -412,6 +432,7 @@ def main():
     else:
         assert int(tot[0]) == total_kmers, "counted %d k-mers, expected %d" % (int(tot[0]), total_kmers)
     digest = t.digest() if world == 1 else None
+    ctrs = t.counters()
 
     out = None
     if rank == 0:
@@ -442,12 +463,16 @@ def main():
         # made by tools/profile_bench.sh); quoted whenever workload and kernel match, whatever --steps is (traffic per
         # job does not depend on how the input is cut into batches -- it is scaled to this run's launch count)
         traffic, traffic_src = None, None
-        tj = os.path.join(ROOT, "profiles", "r03_traffic_%s.json" % cfg)
-        if os.path.exists(tj) and world == 1 and not force_dist and args.dist == "U":
+        tj = os.path.join(ROOT, "profiles", "r04_traffic_%s%s.json" % (cfg, "" if args.dist == "U" else "_G"))
+        if os.path.exists(tj) and world == 1 and not force_dist:
             rec = json.load(open(tj))
-            if abs(rec.get("gbp", 0) - args.gbp) < 1e-9 and rec.get("lsize") == lsize and dom in rec.get("per_job_bytes", {}):
+            if rec.get("kernel_sources_sha256") != kernel_sources_sha():
+                # counters taken on other kernels say nothing about these: refuse them rather than quote a stale figure
+                traffic_src = "%s was taken on different kernel sources (sha %s..., now %s...): not quoted" % (
+                    os.path.relpath(tj, ROOT), str(rec.get("kernel_sources_sha256"))[:12], kernel_sources_sha()[:12])
+            elif abs(rec.get("gbp", 0) - args.gbp) < 1e-9 and rec.get("lsize") == lsize and dom in rec.get("per_job_bytes", {}):
                 traffic = rec["per_job_bytes"][dom] / max(launches, 1)
-                traffic_src = "profiles/r03_traffic_%s.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, same command): bytes per job / %d launches" % (cfg, launches)
+                traffic_src = "%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, same command, same kernel sources): bytes per job / %d launches" % (os.path.relpath(tj, ROOT), launches)
         out = {
             "metric": "k-mers/sec at k=%d canonical, 150 bp synthetic reads, bit-exact counts" % K,
             "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -464,6 +489,9 @@ def main():
                                       "; %d RANKS PER DEVICE over the inter-process test transport (hipIpc* copies): a functional run of the N-rank path on a box with fewer GPUs, not a scaling number" % shared)},
             "kernels": kernels,
             "content_digest": digest,
+            "tile_kernel": {"flushes_plain": ctrs["flushes_plain"], "flushes_heavy": ctrs["flushes_heavy"], "direct_inserts": ctrs["direct"],
+                            "what": "instantiation of the tile stage chosen per flush from its own sample (plain / HEAVY for high-coverage input), and items "
+                                    "the partition kernels inserted with global atomics (region or ring overflow, runs of one k-mer)"},
             "roofline": {"bound": "hbm", "kernel": dom,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "bytes_per_kmer": bpk, "kmers_per_launch": per_launch_kmers,
@@ -474,7 +502,7 @@ def main():
                                  "(k-mers/s of the whole job x the path's algorithmic bytes) is the number to compare with the 8 TB/s peak.  "
                                  "bytes_per_kmer is SURVEY 8(d)'s contract figure (one read-modify-write of an 8-byte slot for one-word keys) "
                                  "whatever the slot width in use (config.slot_bytes); design_min_bytes_per_kmer is what this three-stage design "
-                                 "cannot go below (input + item written once + slot written once)",
+                                 "cannot go below (input + the 4-byte item written by P1, read and written by P2, read by T + every slot of the table written once)",
                          "design_min_bytes_per_kmer": DESIGN_MIN_BYTES.get(cfg),
                          "gups_atomic_add": gups.get("atomic_add"), "gups_atomic_cas": gups.get("atomic_cas"),
                          "value_over_gups": value / world / gups["atomic_cas"] if gups.get("atomic_cas") else None},
@@ -580,20 +608,23 @@ def main():
         if t is not None:
             t.close(); t = None
         sec = {}
-        for c in ("C5", "C3"):
+        # C5, C3: BASELINE configs[4] and [2] on the metric's uniform reads; C2_G, C3_G: the same engine on BASELINE.md's secondary
+        # distribution (reads from a 100 Mbp genome, 1 % substitutions, ~100 x coverage), each job run twice with the table
+        # digest asserted equal (the check that found the tile stage's race in round 3)
+        for name, c, extra in (("C5", "C5", []), ("C3", "C3", []), ("C2_G", "C2", ["--dist", "G", "--repeats", "2"]), ("C3_G", "C3", ["--dist", "G", "--repeats", "2"])):
             try:
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", c, "--as-secondary", "--steps", str(steps), "--warmup", str(warmup)],
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", c, "--as-secondary", "--steps", str(steps), "--warmup", str(warmup)] + extra,
                                    capture_output=True, text=True, timeout=900, preexec_fn=_all_cpus)
                 line = [l for l in r.stdout.splitlines() if l.startswith("{")]
                 if r.returncode == 0 and line:
                     d = json.loads(line[-1])
-                    sec[c] = {k: d[k] for k in ("value", "unit", "ms_per_step", "dtype", "config", "kernels", "roofline", "content_digest") if k in d}
+                    sec[name] = {k: d[k] for k in ("value", "unit", "ms_per_step", "dtype", "config", "kernels", "roofline", "content_digest", "repeats", "tile_kernel") if k in d}
                     if "passes" in d:
-                        sec[c]["passes"] = d["passes"]
+                        sec[name]["passes"] = d["passes"]
                 else:
-                    sec[c] = {"error": (r.stderr or r.stdout)[-400:]}
+                    sec[name] = {"error": (r.stderr or r.stdout)[-400:]}
             except Exception as e:       # the contract line must come out whatever the extras do
-                sec[c] = {"error": repr(e)}
+                sec[name] = {"error": repr(e)}
         out["secondary"] = sec
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -346,6 +346,14 @@ int  jfgpu_parser_last_ms(jfgpu_parser* p, double* ms);
 int  jfgpu_profile_enable(jfgpu_table* t, int on);
 int  jfgpu_profile_get(jfgpu_table* t, int which, double* ms, uint64_t* launches, uint64_t* units);
 int  jfgpu_profile_reset(jfgpu_table* t);
+/* The engine's event counters since the last jfgpu_clear, after waiting for the table's stream (tests assert from them
+ * which code path a flush took; `jellyfish-amd count --timing` reports them).  out[0..n): 0 tile-full events ("Hash
+ * full" is raised from it), 1 k-mer occurrences fed, 2 overflow side table full, 3 side-table entries, 4 k-mers sent to
+ * a shard that does not own them, 5 items inserted with global atomics by the partition kernels (ring / region
+ * overflow, runs of one k-mer), 6 / 7 items placed / items past rank 3 in the sampling launch of the last flush that
+ * sampled (host_partition.inl), 8 flushes that ran the plain tile kernel, 9 flushes that ran the HEAVY one. */
+#define JFGPU_N_COUNTERS 10
+int  jfgpu_get_counters(jfgpu_table* t, uint64_t* out, uint32_t n);
 /* Synthetic reads: n_reads records of read_len uniform iid bases, each followed by
  * one 'N' separator (the contract buffer the parser would produce for a FASTA of
  * such reads); counter-based RNG so any slice is reproducible.  d_out needs

@@ -128,6 +128,7 @@ SIGNATURES = {
     "jfgpu_profile_enable": (C.c_int, [_P, C.c_int]),
     "jfgpu_profile_get": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "jfgpu_profile_reset": (C.c_int, [_P]),
+    "jfgpu_get_counters": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_uint32]),
     "jfgpu_gen_reads_dev": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64]),
     "jfgpu_gen_genome_reads_dev": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_double, C.c_uint64]),
     "jfgpu_gups": (C.c_int, [_P, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
@@ -349,6 +350,14 @@ class Table:
 
     def profile_reset(self):
         _check(self._lib.jfgpu_profile_reset(self._h))
+
+    COUNTER_NAMES = ("full", "mers", "ovf_full", "ovf_used", "misrouted", "direct", "t_items", "t_queued", "flushes_plain", "flushes_heavy")
+
+    def counters(self):
+        """jfgpu_get_counters: which paths the work since the last clear took."""
+        out = (C.c_uint64 * len(self.COUNTER_NAMES))()
+        _check(self._lib.jfgpu_get_counters(self._h, out, len(self.COUNTER_NAMES)))
+        return dict(zip(self.COUNTER_NAMES, (int(x) for x in out)))
 
     def gen_reads_dev(self, d_out, first_read, n_reads, read_len, seed):
         _check(self._lib.jfgpu_gen_reads_dev(self._h, _ptr(d_out), first_read, n_reads, read_len, seed))

@@ -609,6 +609,8 @@ int count_main(int argc, char* argv[]) {
     } catch(std::exception& e) { die(e.what()); }
   }
   const double write_s = seconds_since(write_start);
+  uint64_t ctrs[JFGPU_N_COUNTERS] = {0};
+  if(!timing.empty() && getenv("JFGPU_TIMING_DETAIL")) (void)jfgpu_get_counters(ary->handle(), ctrs, JFGPU_N_COUNTERS);
 
   if(bc) { jfgpu_attach_bloom(ary->handle(), nullptr); jfgpu_bc_destroy(bc); }
   if(comm) {
@@ -624,7 +626,8 @@ int count_main(int argc, char* argv[]) {
        << "Counting " << count_s << "\n"
        << "Writing  " << write_s << "\n";
     if(!host_parse && getenv("JFGPU_TIMING_DETAIL"))     // extra lines only on request: the file keeps the reference's three
-      tf << "DeviceParse " << parse_ms / 1e3 << "\n" << "HostParsedBytes " << fallback_bytes << "\n";
+      tf << "DeviceParse " << parse_ms / 1e3 << "\n" << "HostParsedBytes " << fallback_bytes << "\n"
+         << "DirectInserts " << ctrs[5] << "\n" << "FlushesPlain " << ctrs[8] << "\n" << "FlushesHeavy " << ctrs[9] << "\n";
   }
   return 0;
 }

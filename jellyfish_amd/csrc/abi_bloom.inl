@@ -2,6 +2,7 @@
 // ---- Bloom counter (jellyfish bc / count --bc, BASELINE config 3) ---------------------------------
 struct jfgpu_bloom {
   int device = 0, n_cu = 256;
+  Tuning tun;                    // the JFGPU_* switches as they were at creation (tuning.hpp)
   hipStream_t stream = nullptr;
   TableGeom g{};                 // only k / key_mask / canonical / nbytes are used (encode side)
   bool wide = false; WideGeom wg{};   // 33 <= k <= 64: two-word keys
@@ -105,10 +106,9 @@ static int bloom_create(const jfgpu_bloom_params* p, jfgpu_bloom** out, uint32_t
   b->alloc_bytes = (b->data_bytes + 3) / 4 * 4 + 4;
   if(kind == 0) bloom_part_init(b.get());
   if(b->part_ok) b->alloc_bytes = ((size_t)b->bp.n_seg << kBloomSegBits) + 4;      // whole segments are loaded and stored
-  if(const char* e = getenv("JFGPU_BLOOM_MODE")) {
-    if(!strcmp(e, "direct")) b->mode = 1;
-    else if(!strcmp(e, "partitioned") && b->part_ok) b->mode = 2;
-  }
+  b->tun = Tuning::from_env();
+  if(b->tun.bloom_mode == 1) b->mode = 1;
+  else if(b->tun.bloom_mode == 2 && b->part_ok) b->mode = 2;
   {
     const int pl = (int)((size_t)kBloomChunk * 6 + (size_t)2 * 8 * 2048);
     HIP_TRY(hipFuncSetAttribute((const void*)p1_bloom_granule_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, pl));

@@ -31,6 +31,7 @@ namespace { struct IpcShared; }
 
 struct jfgpu_comm {
   int world = 1, rank = 0, device = 0;
+  Tuning tun = Tuning::from_env();               // the JFGPU_* switches as they were at creation (tuning.hpp)
   bool local = false;
 #if !defined(JFGPU_EMU)
   ncclComm_t nccl = nullptr;
@@ -78,10 +79,16 @@ struct jfgpu_comm {
 namespace {
 
 // JFGPU_COMM_TRACE=1: every rank says on stderr where it is in the exchange (a stuck run shows who waits for whom).
-bool ipc_trace_on() { static const bool on = getenv("JFGPU_COMM_TRACE") != nullptr; return on; }
-#define IPC_TRACE(c, ...) do { if(ipc_trace_on()) { fprintf(stderr, "[comm rank %d] ", (c)->rank); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while(0)
+#define IPC_TRACE(c, ...) do { if((c)->tun.comm_trace) { fprintf(stderr, "[comm rank %d] ", (c)->rank); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while(0)
 
 int comm_reserve(uint64_t*& buf, size_t& cap, size_t need, hipStream_t s1, hipStream_t s2);
+
+// the communicator's share of the JFGPU_* switches (tuning.hpp), applied once at creation
+void comm_apply_tuning(jfgpu_comm* c) {
+  if(c->tun.comm_max_msg) c->max_msg_keys = c->tun.comm_max_msg;
+  if(c->tun.comm_items >= 0) { c->items_mode = c->tun.comm_items; c->items_on = c->items_mode != 0; }
+  if(c->tun.comm_strag > 0) c->strag_cap = (uint32_t)c->tun.comm_strag;
+}
 
 int comm_init_rank(jfgpu_comm* c, jfgpu_comm::Rank& R) {
   for(int i = 0; i < 2; ++i) {
@@ -213,7 +220,7 @@ int comm_route_items(jfgpu_comm* c, jfgpu_comm::Rank& R, const char* d_bases, si
   HIP_TRY(hipMemcpyAsync(sb + L.claims_at, R.claims.data(), (size_t)c->world * 8, hipMemcpyHostToDevice, t->stream));
   HIP_TRY(hipStreamSynchronize(t->stream));                 // (R.claims is reused by the next step)
   *routed = stored + h[1024];
-  if(getenv("JFGPU_FLUSH_TRACE"))
+  if(t->tun.flush_trace)
     fprintf(stderr, "[comm] item path: %zu bytes -> %llu items in %u regions of %u, %llu stragglers\n", n, (unsigned long long)stored, L.nbg, cap, (unsigned long long)h[1024]);
   return JFGPU_OK;
 }
@@ -801,7 +808,7 @@ int jfgpu_comm_unique_id(uint8_t* id128) {
   memset(id128, 0, 128);
   return JFGPU_OK;
 #else
-  if(const char* tr = getenv("JFGPU_COMM_TRANSPORT")) if(!strcmp(tr, "ipc")) {
+  if(Tuning::from_env().comm_ipc) {
     // "JFGPUIPC" + the name of the shared block the ranks meet in
     memset(id128, 0, 128);
     memcpy(id128, "JFGPUIPC", 8);
@@ -838,10 +845,8 @@ int jfgpu_comm_create(int world, int rank, const uint8_t* id128, int device, jfg
   HIP_TRY(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
   c->ranks.resize(1);
   int rc = comm_init_rank(c.get(), c->ranks[0]); if(rc) return rc;
-  if(const char* e = getenv("JFGPU_COMM_MAX_MSG")) c->max_msg_keys = std::max<uint64_t>(1, strtoull(e, 0, 10));
-  if(const char* e = getenv("JFGPU_COMM_SELF_RCCL")) c->self_rccl = atoi(e) != 0;
-  if(const char* e = getenv("JFGPU_COMM_ITEMS")) { c->items_mode = atoi(e); c->items_on = c->items_mode != 0; }
-  if(const char* e = getenv("JFGPU_COMM_STRAG")) c->strag_cap = (uint32_t)std::max(1, atoi(e));
+  comm_apply_tuning(c.get());
+  if(c->tun.comm_self_rccl >= 0) c->self_rccl = c->tun.comm_self_rccl != 0;
   *out = c.release();
   return JFGPU_OK;
 #endif
@@ -858,9 +863,7 @@ int jfgpu_comm_create_local(int world, int device, jfgpu_comm** out) {
   HIP_TRY(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
   c->ranks.resize(world);
   for(auto& R : c->ranks) { int rc = comm_init_rank(c.get(), R); if(rc) return rc; }
-  if(const char* e = getenv("JFGPU_COMM_MAX_MSG")) c->max_msg_keys = std::max<uint64_t>(1, strtoull(e, 0, 10));
-  if(const char* e = getenv("JFGPU_COMM_ITEMS")) { c->items_mode = atoi(e); c->items_on = c->items_mode != 0; }
-  if(const char* e = getenv("JFGPU_COMM_STRAG")) c->strag_cap = (uint32_t)std::max(1, atoi(e));
+  comm_apply_tuning(c.get());
   *out = c.release();
   return JFGPU_OK;
 }

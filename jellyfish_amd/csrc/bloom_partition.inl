@@ -198,7 +198,7 @@ int bloom_flush_inner(jfgpu_bloom* b) {
     const size_t free_b = b->ws_cap > align_up(b->ws_used, 256) + 4096 ? b->ws_cap - align_up(b->ws_used, 256) - 4096 : 0;
     uint32_t n_groups = 1;
     uint64_t tmp_items = std::max<uint64_t>(total, 1);
-    const uint32_t forced = getenv("JFGPU_FLUSH_SHARE") ? (uint32_t)atoi(getenv("JFGPU_FLUSH_SHARE")) : 0;      // (tests)
+    const uint32_t forced = b->tun.flush_share;      // (tests)
     if(total * sizeof(uint32_t) > free_b || forced)
       for(uint32_t G = 2; G <= nb1 / 4; G *= 2) {
         uint64_t mx = 0;
@@ -210,7 +210,7 @@ int bloom_flush_inner(jfgpu_bloom* b) {
     constexpr uint32_t kG2Single = 4;
     uint32_t cap2 = 0;
     unsigned int* d_gcur2 = nullptr; uint64_t* d_off2 = nullptr; uint32_t* out2 = nullptr;
-    const int p2_single = getenv("JFGPU_P2_SINGLE") ? atoi(getenv("JFGPU_P2_SINGLE")) : 1;
+    const int p2_single = b->tun.p2_single;
     if(p2_single) {
       const uint64_t mean = total / std::max<uint32_t>(1, b->bp.n_seg), strand = (uint64_t)kG2Single * kGran;   // (the array ends before the last bucket does)
       if(mean >= 8 * strand || p2_single > 1) {

@@ -88,7 +88,7 @@ int part_flush(jfgpu_table* t);
 // mostly holes: auto mode wants the mean bucket load to be at least 4x that.
 uint32_t granule_cap(const jfgpu_table* t, bool from_keys, uint64_t max_items) {
   if(t->item128) { if(t->pg.b1 > 10 || !t->g1) return 0; }              // the only P1 two-word keys have
-  else if(t->pg.b2 == 0 || t->pg.b1 > 10 || t->p1_single == 0 || !t->g1) return 0;
+  else if(t->pg.b2 == 0 || t->pg.b1 > 10 || t->tun.p1_single == 0 || !t->g1) return 0;
   else if(!t->item32 && from_keys) return 0;                             // 64-bit items: single-pass from sequence only
   const uint64_t nb = 1ull << t->pg.b1, strand = (uint64_t)t->g1 * kGran;
   // Sequence input: one item per byte is the upper bound, what earlier flushes saw per byte (+10 %) the estimate -- reads
@@ -99,8 +99,8 @@ uint32_t granule_cap(const jfgpu_table* t, bool from_keys, uint64_t max_items) {
   // a filtered pass (count --bc) stores few items, but the exact two-pass scheme would ask the filter twice per k-mer
   // (random reads: what the pass costs); stranded reservations are at most g1 * nb * kGran items per batch
   const bool filtered = !from_keys && (t->wide ? t->wt.bloom.data : t->dt.bloom.data) != nullptr;
-  if(t->p1_single < 0 && mean < 4 * strand && !filtered && !(t->item128 && t->mode == MODE_PARTITIONED)) return 0;
-  const double want = (double)mean * (1.0 + t->p1_slack) + (double)strand;
+  if(t->tun.p1_single < 0 && mean < 4 * strand && !filtered && !(t->item128 && t->mode == MODE_PARTITIONED)) return 0;
+  const double want = (double)mean * (1.0 + t->tun.p1_slack) + (double)strand;
   uint64_t cap = want < (double)kGran ? kGran : (uint64_t)want;
   cap = (cap + kGran - 1) / kGran * kGran;
   if(cap > 0xFFFF0000ull) return 0;
@@ -301,7 +301,7 @@ int part_flush_t(jfgpu_table* t) {
       // itself: the first 64th of a large launch's units goes through the plain kernel with its counters on, the
       // host reads them (one wait inside the flush) and the rest follows in the instantiation they call for.
       // JFGPU_TILE_ADAPT=0: always plain; 2: always HEAVY (tests).
-      static const int adapt = getenv("JFGPU_TILE_ADAPT") ? atoi(getenv("JFGPU_TILE_ADAPT")) : 1;
+      const int adapt = t->tun.tile_adapt;
 #define TRV(SLOT, TPB, HV, SM, SV, T0, NT) do { const size_t lds = tile_rank_lds(sizeof(SLOT), t->g.tile_bits, TPB); \
         const dim3 gr((unsigned)std::min<uint64_t>((NT), (uint64_t)t->n_cu * 16)); \
         if(rt) hipLaunchKernelGGL((tile_rank_insert_kernel<ITEM, true, SLOT, TPB, kTileBlock, HV, SM>), gr, tblock, lds, ts, t->dt, (SV), (T0), (NT)); \
@@ -318,6 +318,7 @@ int part_flush_t(jfgpu_table* t) {
           done = ns; \
         } \
         SegList Sr = S; Sr.off[0] = S.off[0] + ((size_t)done << S.sh[0]); \
+        if(heavy) ++t->flushes_heavy; else ++t->flushes_plain; \
         if(heavy) TRV(SLOT, TPB, true, false, Sr, tile0 + (uint64_t)(TPB) * done, ntile - done); \
         else      TRV(SLOT, TPB, false, false, Sr, tile0 + (uint64_t)(TPB) * done, ntile - done); } while(0)
       (void)grid;
@@ -368,7 +369,7 @@ int part_flush_t(jfgpu_table* t) {
     bool tmp_owned = false;
     // 32-bit items into 32-bit slots: P2 routes to pairs of adjacent tiles (half as many destinations, and chunks of 28 Ki
     // items), so the runs it writes are ~112 bytes on average instead of 32; the tile kernel owns a pair (64 KiB) in LDS
-    const bool pair = sizeof(ITEM) == 4 && t->g.slot32 && t->pg.b2 >= 1 && t->tile_pair;
+    const bool pair = sizeof(ITEM) == 4 && t->g.slot32 && t->pg.b2 >= 1 && t->tun.tile_pair;
     // Single-pass P2 (32-bit items into pairs of tiles; 16-byte items into tiles): fixed regions of cap2 items per
     // destination, reservations of kGran items (p2_granule_kernel).  Worth it when the regions are mostly items: every
     // block may strand one reservation per destination.  When the regions of the whole table do not fit the arena beside
@@ -376,23 +377,23 @@ int part_flush_t(jfgpu_table* t) {
     constexpr uint32_t kG2Single = 4;                       // blocks per P1 bucket
     constexpr bool kSingleItems = sizeof(ITEM) == 4 || sizeof(ITEM) == 8 || sizeof(ITEM) == 16;
     uint32_t cap2 = 0, single_groups = 1; unsigned int* d_gcur2 = nullptr; uint64_t* d_off2 = nullptr; ITEM* out2 = nullptr; bool own2 = false;
-    const bool single_ok = kSingleItems && t->p2_single && (sizeof(ITEM) >= 8 || pair) && t->flush_groups <= 1;      // (4-byte items: pairs only; 8- and 16-byte items: single tiles)
+    const bool single_ok = kSingleItems && t->tun.p2_single && (sizeof(ITEM) >= 8 || pair) && t->tun.flush_groups <= 1;      // (4-byte items: pairs only; 8- and 16-byte items: single tiles)
     const uint64_t n_dest = pair ? n_tiles >> 1 : n_tiles;
     if(single_ok) {
       const uint64_t mean = total / n_dest, strand = (uint64_t)kG2Single * kGran;
-      if(mean >= 8 * strand || t->p2_single > 1) {
+      if(mean >= 8 * strand || t->tun.p2_single > 1) {
         // head-room over the mean load: a pair of tiles takes ~8 K items a flush, 1 % standard deviation on uniform reads --
         // but on high-coverage input its ~100 hot k-mers come 80 times each (10 %), and what overflows a region is
         // inserted with global atomics: with 8 % head-room P2 took 38 ms on distribution G instead of 29
-        const double slack = t->p2_slack >= 0 ? t->p2_slack : (sizeof(ITEM) <= 8 ? 0.30 : 0.08);
+        const double slack = t->tun.p2_slack >= 0 ? t->tun.p2_slack : (sizeof(ITEM) <= 8 ? 0.30 : 0.08);
         cap2 = (uint32_t)(((uint64_t)((double)mean * (1.0 + slack)) + strand + 2 * kGran - 1) / kGran * kGran);
-        if(t->p2_cap) cap2 = t->p2_cap;
+        if(t->tun.p2_cap) cap2 = t->tun.p2_cap;
         const size_t mark = t->ws_used;
         d_gcur2 = (unsigned int*)ws_alloc(t, 2 * n_dest * sizeof(unsigned int));
         d_off2 = (uint64_t*)ws_alloc(t, 2 * n_dest * sizeof(uint64_t));
         const size_t used = align_up(t->ws_used, 256) + 4096;
         const size_t free_b = t->ws_cap > used ? t->ws_cap - used : 0;
-        const uint32_t forced = getenv("JFGPU_FLUSH_SHARE") ? (uint32_t)atoi(getenv("JFGPU_FLUSH_SHARE")) : 0;      // (tests)
+        const uint32_t forced = t->tun.flush_share;      // (tests)
         uint32_t G = forced && forced <= nb1 / 8 ? forced : 1;
         while(!forced && G <= nb1 / 8 && (n_dest / G) * cap2 * sizeof(ITEM) > free_b) G *= 2;
         if(d_gcur2 && d_off2 && G <= std::max<uint32_t>(1, nb1 / 8)) out2 = (ITEM*)ws_alloc(t, (n_dest / G) * cap2 * sizeof(ITEM));
@@ -401,7 +402,7 @@ int part_flush_t(jfgpu_table* t) {
           t->ws_used = mark;
           d_gcur2 = nullptr; d_off2 = nullptr; out2 = nullptr;
           single_groups = forced && forced <= nb1 / 8 ? forced : 1;
-          if(t->p2_single > 1 && hipMalloc((void**)&d_gcur2, 2 * n_dest * sizeof(unsigned int)) == hipSuccess &&
+          if(t->tun.p2_single > 1 && hipMalloc((void**)&d_gcur2, 2 * n_dest * sizeof(unsigned int)) == hipSuccess &&
              hipMalloc((void**)&d_off2, 2 * n_dest * sizeof(uint64_t)) == hipSuccess &&
              hipMalloc((void**)&out2, (n_dest / single_groups) * cap2 * sizeof(ITEM)) == hipSuccess) own2 = true;
           else { if(d_gcur2) hipFree(d_gcur2); if(d_off2) hipFree(d_off2); if(out2) hipFree(out2); cap2 = 0; single_groups = 1; }
@@ -409,7 +410,7 @@ int part_flush_t(jfgpu_table* t) {
         if(cap2) HIP_TRY(hipMemsetAsync(d_gcur2, 0, 2 * n_dest * sizeof(unsigned int), t->stream));
       }
     }
-    if(getenv("JFGPU_FLUSH_TRACE"))
+    if(t->tun.flush_trace)
       fprintf(stderr, "[flush] %llu items in %zu batches, %llu tiles, pairs %d, single-pass P2 regions of %u items (0: exact P2) in %u group(s)\n",
               (unsigned long long)total, nbatch, (unsigned long long)n_tiles, (int)pair, cap2, single_groups);
     // When the arena cannot hold a P2 output of the whole flush beside what is pending, the P1 buckets go through P2 and
@@ -422,8 +423,8 @@ int part_flush_t(jfgpu_table* t) {
       const size_t fixed = align_up((n_tiles + 1) * sizeof(uint64_t), 256) + align_up(nb1 * sizeof(uint64_t), 256) + 1024;
       const size_t used = align_up(t->ws_used, 256);
       const size_t free_b = t->ws_cap > used + fixed ? t->ws_cap - used - fixed : 0;
-      const uint32_t forced = getenv("JFGPU_FLUSH_SHARE") ? (uint32_t)atoi(getenv("JFGPU_FLUSH_SHARE")) : 0;      // (tests)
-      if((total * sizeof(ITEM) > free_b || forced) && t->flush_groups <= 1) {
+      const uint32_t forced = t->tun.flush_share;      // (tests)
+      if((total * sizeof(ITEM) > free_b || forced) && t->tun.flush_groups <= 1) {
         for(uint32_t G = 2; G <= nb1 / 8; G *= 2) {
           uint64_t mx = 0;
           for(uint32_t g = 0; g < G; ++g) { uint64_t sum = 0; for(uint32_t j = g * (nb1 / G); j < (g + 1) * (nb1 / G); ++j) sum += bucket_tot[j]; mx = std::max(mx, sum); }
@@ -448,12 +449,12 @@ int part_flush_t(jfgpu_table* t) {
       { uint64_t run = 0; for(uint32_t j = 0; j < nb1; ++j) { if(share_groups && j % (nb1 / share_groups) == 0) run = 0; base[j] = run; run += bucket_tot[j]; } }
       HIP_TRY(hipMemcpyAsync(d_base, base.data(), nb1 * sizeof(uint64_t), hipMemcpyHostToDevice, t->stream));
     }
-    if(getenv("JFGPU_FLUSH_TRACE") && share_groups) fprintf(stderr, "[flush] P2 + tile insert in %u groups sharing an output buffer of %llu items\n", share_groups, (unsigned long long)tmp_items);
+    if(t->tun.flush_trace && share_groups) fprintf(stderr, "[flush] P2 + tile insert in %u groups sharing an output buffer of %llu items\n", share_groups, (unsigned long long)tmp_items);
     // Optionally (JFGPU_FLUSH_GROUPS > 1) the P1 buckets go through P2 and the tile insert in groups, P2 on the
     // table's stream and the tile insert on a second one, so that group g's tiles are inserted while group g+1
     // is partitioned (one P2-scatter block, 88 KB LDS, and one tile block, 64 KB, fit a CU together).
     if(cap2 && single_groups > 1) share_groups = single_groups;      // same loop, same per-group timers; the shared buffer holds regions
-    const uint32_t n_groups = share_groups ? share_groups : t->flush_groups > 1 && nb1 >= (uint32_t)t->flush_groups * 8 ? (uint32_t)t->flush_groups : 1;
+    const uint32_t n_groups = share_groups ? share_groups : t->tun.flush_groups > 1 && nb1 >= (uint32_t)t->tun.flush_groups * 8 ? (uint32_t)t->tun.flush_groups : 1;
     const bool two_streams = n_groups > 1 && !share_groups;
     const uint32_t gsz = nb1 / n_groups;
     if(two_streams && !t->stream2) {

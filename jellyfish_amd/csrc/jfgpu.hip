@@ -16,6 +16,7 @@
 
 #include "../../include/jfgpu.h"
 #include "gf2_matrix.hpp"
+#include "tuning.hpp"
 #include "kernels.hip.hpp"
 #include "kernels_part.hip.hpp"
 #include "kernels_tile.hip.hpp"
@@ -79,6 +80,8 @@ struct jfgpu_table {
   uint64_t ovf_cap = 0;
   // what the side table may have to hold: an entry needs 2^cnt_bits occurrences of its key, or one add of a large value
   uint64_t occ_bound = 0, bigval_bound = 0;      // upper bounds since the last clear (ensure_ovf)
+  uint64_t flushes_plain = 0, flushes_heavy = 0; // tile-kernel instantiation chosen per flush launch (jfgpu_get_counters)
+  uint64_t ovf_failed_need = 0;                  // the side-table size whose allocation failed (not retried per batch)
   bool returning = false;
   uint32_t out_counter_len = 4;
   // size doubling (hash_counter::do_size_doubling): occupancy bookkeeping, see ensure_capacity()
@@ -119,18 +122,10 @@ struct jfgpu_table {
   GlibcRandom glibc;
   int (*spill_fn)(void*) = nullptr; void* spill_user = nullptr;     // jfgpu_set_spill
   int operation = 0;             // what count_ascii does with a k-mer: 0 add, 1 set (prime), 2 update_add (jfgpu_set_operation)
-  int p2_single = 1;             // ... and in one pass, reservations inside fixed regions (JFGPU_P2_SINGLE: 0 exact count + scatter, 1 when the
-                                 // regions would be mostly items, 2 always); p2_cap: test knob, items per region
-  uint32_t p2_cap = 0;
-  double p2_slack = -1;          // head-room of those regions over the mean load of a destination (JFGPU_P2_SLACK); < 0: 30 % for 4-byte items, 8 % for 16-byte ones
-  bool tile_pair = true;         // 32-bit slots: P2 routes to pairs of tiles (JFGPU_TILE_PAIR=0: single tiles, for A/B)
-  int flush_groups = 1;          // P2 / tile-insert pipeline depth of a flush (JFGPU_FLUSH_GROUPS).  Measured: 8 groups on two
-                                 // streams run P2 and T concurrently but no faster (both are LDS-bound), so one launch each is the default
+  Tuning tun;                    // the JFGPU_* switches as they were when the table was created (tuning.hpp)
   hipStream_t stream2 = nullptr; hipEvent_t flush_ev[2] = {nullptr, nullptr}; hipEvent_t flush_done = nullptr;
-  int p1_single = -1;            // single-pass P1: -1 auto (large batches), 0 never, 1 whenever the geometry allows (JFGPU_P1_SINGLE)
   double items_per_byte = 0;     // k-mers per sequence byte seen by the last flush (0: unknown yet)
   uint64_t reserved_input = 0;   // sequence bytes the caller announced (jfgpu_reserve): lets forced flushes be spaced evenly
-  double p1_slack = 0.03;        // head-room of a bucket region over the mean (JFGPU_P1_SLACK; negative forces the exhausted path)
   uint32_t* d_M1 = nullptr; int g1 = 0;
   uint32_t* d_M2 = nullptr; int g2 = 0;
   // workspace arena for pending batches and flush temporaries: bump-allocated, reset at flush,
@@ -155,7 +150,6 @@ int use(const jfgpu_table* t) {
   return JFGPU_OK;
 }
 
-bool allow_slot32() { const char* e = getenv("JFGPU_SLOT64"); return !(e && atoi(e)); }     // JFGPU_SLOT64=1: never use 32-bit slots (A/B)
 size_t slot_bytes_of(const jfgpu_table* t) { return t->g.slot32 ? 4 : 8 * (size_t)t->slot_words; }
 uint64_t n_tiles_of(const jfgpu_table* t) { return 1ull << (t->g.lsize_l - t->g.tile_bits); }
 
@@ -251,16 +245,21 @@ void refresh_views(jfgpu_table* t);     // the two- and N-word views of the tabl
 int ensure_ovf(jfgpu_table* t, uint64_t more_occurrences, uint64_t more_big_adds) {
   t->occ_bound += more_occurrences; t->bigval_bound += more_big_adds;
   if(!t->returning) return JFGPU_OK;                              // count fields of 40 bits and more
-  const uint64_t need = 2 * ((t->occ_bound >> t->g.cnt_bits) + t->bigval_bound) + 4096;
-  if(need <= t->ovf_cap) return JFGPU_OK;
+  // entries are keyed by slot: there are never more of them than slots, whatever was fed (round-3 advisor finding: the
+  // bound alone asked for 32 GB of side table at 100 Gbp into 10-bit count fields)
+  const uint64_t slots = 1ull << t->g.lsize_l;
+  const uint64_t need = std::min<uint64_t>(2 * ((t->occ_bound >> t->g.cnt_bits) + t->bigval_bound) + 4096, std::max<uint64_t>(2 * slots, 4096));
+  if(need <= t->ovf_cap || need <= t->ovf_failed_need) return JFGPU_OK;      // (a size that could not be had is not asked for again until the table is cleared or grows)
   uint64_t cap2 = t->ovf_cap;
-  while(cap2 < 2 * need) cap2 <<= 1;                              // (room for the next few batches too)
+  while(cap2 < 2 * need && cap2 < 4 * slots) cap2 <<= 1;          // (room for the next few batches too)
+  while(cap2 < need) cap2 <<= 1;
   HIP_TRY(hipStreamSynchronize(t->stream));
   if(t->stream2) HIP_TRY(hipStreamSynchronize(t->stream2));
   uint64_t *nk = nullptr, *nc = nullptr;
   if(hipMalloc((void**)&nk, cap2 * 8) != hipSuccess || hipMalloc((void**)&nc, cap2 * 8) != hipSuccess) {
     if(nk) hipFree(nk);
     (void)hipGetLastError();
+    t->ovf_failed_need = need;
     return JFGPU_OK;                                              // no memory: carry on, CTR_OVF_FULL reports it if it really overflows
   }
   HIP_TRY(hipMemsetAsync(nk, 0, cap2 * 8, t->stream));
@@ -454,11 +453,11 @@ int table_grow(jfgpu_table* t) {
   NGeom ng2;
   if(t->nword) { if(!nword_geom_init(ng2, t->g.k, r + 1, t->g.canonical)) return -1; g2 = ng2.g; }
   else if(t->wide) { if(!wide_geom_init(w2, t->g.k, r + 1, t->g.canonical)) return -1; g2 = w2.g; }
-  else if(!geom_init(g2, t->g.k, r + 1, 0, 0, t->g.canonical, allow_slot32())) return -1;
+  else if(!geom_init(g2, t->g.k, r + 1, 0, 0, t->g.canonical, !t->tun.slot64)) return -1;
   const uint64_t n2 = 1ull << g2.lsize_l;
   const size_t slot_bytes = g2.slot32 ? 4 : 8 * (size_t)t->slot_words;
   uint64_t cap2 = std::max<uint64_t>(kMinOvf, std::min<uint64_t>(n2 / 256, 1ull << 26));
-  if(g2.cnt_bits < 40) cap2 = std::max<uint64_t>(cap2, 2 * ((t->occ_bound >> g2.cnt_bits) + t->bigval_bound) + 4096);      // (ensure_ovf's rule)
+  if(g2.cnt_bits < 40) cap2 = std::max<uint64_t>(cap2, std::min<uint64_t>(2 * ((t->occ_bound >> g2.cnt_bits) + t->bigval_bound) + 4096, 2 * n2));      // (ensure_ovf's rule)
   cap2 = std::max<uint64_t>(cap2, t->ovf_cap);
   { uint64_t x = 1; while(x < cap2) x <<= 1; cap2 = x; }
   DevTable nd = t->dt;
@@ -503,7 +502,7 @@ int table_grow(jfgpu_table* t) {
   // swap in
   hipFree(t->dt.slots); hipFree(t->dt.ovf_key); hipFree(t->dt.ovf_cnt); hipFree(t->dt.dirty); hipFree(t->d_fwd); hipFree(t->d_inv);
   t->dt = nd; t->g = g2; t->matrix = m2; t->d_fwd = nf; t->d_inv = ni; t->ovf_cap = cap2;
-  t->returning = t->g.cnt_bits < 40;
+  t->returning = t->g.cnt_bits < 40; t->ovf_failed_need = 0;
   if(t->d_M2) { hipFree(t->d_M2); t->d_M2 = nullptr; }
   if(t->nword) {
     t->nt = nn;
@@ -587,6 +586,8 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
   }
 
   std::unique_ptr<jfgpu_table> t(new jfgpu_table);
+  t->tun = Tuning::from_env();
+  t->tun.p2_cap = t->tun.p2_cap / kGran * kGran;
   t->params = *p; t->params.matrix_columns = nullptr;
   t->device = dev;
   t->out_counter_len = p->out_counter_len ? p->out_counter_len : 4;
@@ -598,7 +599,7 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
   } else if(wide) {
     if(!wide_geom_init(t->wt.W, p->k, lsize, p->canonical ? 1 : 0)) return fail(JFGPU_E_INVALID, "table geometry does not fit a 128-bit slot");
     t->g = t->wt.W.g;
-  } else if(!geom_init(t->g, p->k, lsize, p->shard_bits, p->shard_id, p->canonical ? 1 : 0, allow_slot32()))
+  } else if(!geom_init(t->g, p->k, lsize, p->shard_bits, p->shard_id, p->canonical ? 1 : 0, !t->tun.slot64))
     return fail(JFGPU_E_INVALID, "table geometry does not fit a 64-bit slot");
 
   // hash matrix (large_hash_array.hpp:992-1001)
@@ -664,17 +665,10 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     const int wl = (int)(((size_t)16 << t->g.tile_bits) + ((size_t)2 << t->g.tile_bits));
     HIP_TRY(hipFuncSetAttribute((const void*)dump_tiles_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
   } else part_geom_init(t.get());
-  if(!nword) if(const char* m = getenv("JFGPU_MODE")) {
-    if(!strcmp(m, "direct")) t->mode = MODE_DIRECT;
-    else if(!strcmp(m, "partitioned") && t->part_ok) t->mode = MODE_PARTITIONED;
+  if(!nword) {
+    if(t->tun.mode == 1) t->mode = MODE_DIRECT;
+    else if(t->tun.mode == 2 && t->part_ok) t->mode = MODE_PARTITIONED;
   }
-  if(const char* m = getenv("JFGPU_P1_SINGLE")) t->p1_single = atoi(m) ? 1 : 0;     // tuning / test knobs of the single-pass P1
-  if(const char* m = getenv("JFGPU_P1_SLACK")) t->p1_slack = atof(m);
-  if(const char* m = getenv("JFGPU_FLUSH_GROUPS")) t->flush_groups = std::max(1, atoi(m));
-  if(const char* m = getenv("JFGPU_TILE_PAIR")) t->tile_pair = atoi(m) != 0;
-  if(const char* m = getenv("JFGPU_P2_SINGLE")) t->p2_single = atoi(m);
-  if(const char* m = getenv("JFGPU_P2_CAP")) t->p2_cap = (uint32_t)atoi(m) / kGran * kGran;
-  if(const char* m = getenv("JFGPU_P2_SLACK")) t->p2_slack = atof(m);
   {
 #define TATTR1(I, R, S, P, H, M) HIP_TRY(hipFuncSetAttribute((const void*)tile_rank_insert_kernel<I, R, S, P, kTileBlock, H, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_rank_lds(sizeof(S), kMaxTileBits, P)))
 #define TATTR(I, S, P) TATTR1(I, true, S, P, false, false); TATTR1(I, false, S, P, false, false); TATTR1(I, true, S, P, true, false); TATTR1(I, false, S, P, true, false); \
@@ -796,7 +790,8 @@ int jfgpu_clear(jfgpu_table* t) {
   HIP_TRY(hipMemsetAsync(t->dt.counters, 0, CTR_COUNT * sizeof(uint64_t), t->stream));
   HIP_TRY(hipMemsetAsync(t->dt.dirty, 0, (size_t)1 << (t->g.lsize_l - t->g.tile_bits), t->stream));
   HIP_TRY(hipStreamSynchronize(t->stream));
-  t->pristine = true; t->occ_known = 0; t->fed_since = 0; t->direct_seen = 0; t->occ_bound = 0; t->bigval_bound = 0;
+  t->pristine = true; t->occ_known = 0; t->fed_since = 0; t->direct_seen = 0; t->occ_bound = 0; t->bigval_bound = 0; t->ovf_failed_need = 0;
+  t->flushes_plain = 0; t->flushes_heavy = 0;
   return JFGPU_OK;
 }
 
@@ -1187,7 +1182,7 @@ int jfgpu_reserve(jfgpu_table* t, uint64_t input_bytes) {
   // (single-pass P1 batches are regions with head-room: slack + one stranded reservation per block and bucket)
   const size_t pend = align_up(input_bytes * item_size(t), 256);
   const size_t strand = (size_t)nb1 * (2 * (size_t)t->n_cu) * kGran * item_size(t);              // per batch
-  const size_t headroom = t->pg.b2 ? (size_t)(pend * ((t->p1_slack > 0 ? t->p1_slack : 0.0) + 0.05)) + 2 * strand : 0;
+  const size_t headroom = t->pg.b2 ? (size_t)(pend * ((t->tun.p1_slack > 0 ? t->tun.p1_slack : 0.0) + 0.05)) + 2 * strand : 0;
   const size_t need = 2 * pend + headroom + (n_tiles_of(t) + 1 + nb1) * sizeof(uint64_t) +
                       (size_t)kMaxSeg * (align_up((2 * nb1 + 1) * sizeof(uint64_t), 256) + align_up(nb1 * 16, 256) + 1280) + ((size_t)1 << 20);
   size_t want = need;
@@ -1220,7 +1215,7 @@ int jfgpu_table_bytes(uint32_t k, uint64_t size, uint64_t* slots, uint64_t* byte
   { uint64_t c = 1; while(c < ovf) c <<= 1; ovf = c; }
   if(slots) *slots = n;
   TableGeom gg;
-  const bool s32 = !nword && !wide && geom_init(gg, k, lsize, 0, 0, 1, allow_slot32()) && gg.slot32;
+  const bool s32 = !nword && !wide && geom_init(gg, k, lsize, 0, 0, 1, !Tuning::from_env().slot64) && gg.slot32;
   if(bytes) *bytes = n * (nword ? 32 : wide ? 16 : s32 ? 4 : 8) + ovf * 16 + (n >> std::min<uint32_t>(lsize, kMaxTileBits)) + (size_t)(2 * k + 7) / 8 * 256 * 8 * 2;
   return JFGPU_OK;
 }
@@ -1270,6 +1265,17 @@ int jfgpu_profile_get(jfgpu_table* t, int which, double* ms, uint64_t* launches,
   if(ms) *ms = t->prof_ms[which];
   if(launches) *launches = t->prof_launches[which];
   if(units) *units = t->prof_units[which];
+  return JFGPU_OK;
+}
+
+int jfgpu_get_counters(jfgpu_table* t, uint64_t* out, uint32_t n) {
+  int rc = use(t); if(rc) return rc;
+  if(!out) return fail(JFGPU_E_INVALID, "null argument");
+  uint64_t c[CTR_COUNT];
+  rc = read_counters(t, c); if(rc) return rc;
+  const uint64_t v[JFGPU_N_COUNTERS] = {c[CTR_FULL], c[CTR_MERS], c[CTR_OVF_FULL], c[CTR_OVF_USED], c[CTR_MISROUTED], c[CTR_DIRECT],
+                                        c[CTR_T_ITEMS], c[CTR_T_QUEUED], t->flushes_plain, t->flushes_heavy};
+  for(uint32_t i = 0; i < n; ++i) out[i] = i < JFGPU_N_COUNTERS ? v[i] : 0;
   return JFGPU_OK;
 }
 

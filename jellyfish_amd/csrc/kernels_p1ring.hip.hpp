@@ -48,7 +48,6 @@ __global__ __launch_bounds__(kPBlock) void p1_ring_kernel(DevTable T, const DevT
   for(uint32_t j = t; j < nb; j += blockDim.x) s_fill[j] = 0;
   unsigned int* const gshort = gcur + nb;
   const uint32_t k = g.k, bshift = g.lsize_l - P.b1;
-  const uint64_t kwin = k >= 64 ? ~0ull : ((1ull << k) - 1);
   const uint32_t rc_shift = 2 * (k - 1);
   const uint32_t hole = 0xFFFFFFFFu;
   // bucket t's place in its region: gpos .. gpos + room of the current reservation, `nxt` the reservation asked for in
@@ -78,6 +77,13 @@ __global__ __launch_bounds__(kPBlock) void p1_ring_kernel(DevTable T, const DevT
           if((uint64_t)nxt + kGran <= cap) { gpos = nxt; room = kGran; }
           else { exhausted = true; if(nxt < cap) atomicMax(&gshort[t], cap - nxt); }     // (everything below nxt was handed out)
           nxt_asked = false;
+        }
+        // no reservation in hand and none asked for (the one taken above was used up inside this flush): ask now and
+        // wait -- rare, and cheaper than sixteen global-atomic inserts for a region that still has room
+        if(room == 0 && !exhausted) {
+          const uint32_t r0 = atomicAdd(&gcur[t], kGran);
+          if((uint64_t)r0 + kGran <= cap) { gpos = r0; room = kGran; }
+          else { exhausted = true; if(r0 < cap) atomicMax(&gshort[t], cap - r0); }
         }
         has[s] = 1; roff[s] = (rb + s * kRingUnit) & (kRingSlots - 1);
         const uint32_t real = cnt - s * kRingUnit < kRingUnit ? cnt - s * kRingUnit : kRingUnit;

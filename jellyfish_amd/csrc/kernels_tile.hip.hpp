@@ -251,7 +251,10 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
     SLOT w[4], wn[4];
     load_bucket(hbase + hb, w);
     load_bucket(hbase + ((hb + 4) & tmask), wn);
-    for(uint32_t step = 0; step < (tsz >> kBucketBits); ) {
+    // the walk ends where every other path's does (T.max_probe: table_add, lookups, update_add, the direct inserts) -- a key
+    // placed further from home would be in the table and invisible to them (round-3 advisor finding)
+    const uint32_t max_steps = (T.max_probe >> kBucketBits) + 1;
+    for(uint32_t step = 0; step < max_steps; ) {
       const uint32_t bs = hbase + ((hb + (step << kBucketBits)) & tmask);
       int hit = -1, emp = -1;
 #pragma unroll

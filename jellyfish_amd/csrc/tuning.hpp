@@ -1,0 +1,68 @@
+// jellyfish_amd/csrc/tuning.hpp -- every JFGPU_* environment switch of the engine, read in ONE place.
+//
+// The switches are A/B and test knobs (nothing a user of the reference's CLI needs): which insert path, the head-room of
+// the partition regions, forcing rare code paths so that the parity tests reach them.  An object (table, Bloom counter,
+// communicator) takes a snapshot when it is created -- Tuning::from_env() -- and nothing reads the environment after
+// that, so two objects of one process can be created under different settings (tests) and a setting cannot change under
+// a running job.
+#pragma once
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+
+namespace jfgpu {
+
+struct Tuning {
+  // ---- tables (jfgpu_create)
+  int mode = 0;                  // JFGPU_MODE=direct|partitioned            0: not set, 1 direct, 2 partitioned
+  bool slot64 = false;           // JFGPU_SLOT64=1         never use 32-bit slots (A/B against the 4-byte layout)
+  int p1_single = -1;            // JFGPU_P1_SINGLE        single-pass P1: -1 auto, 0 never, 1 whenever the geometry allows
+  double p1_slack = 0.03;        // JFGPU_P1_SLACK         head-room of a P1 bucket region over the mean (negative: forces the exhausted path)
+  int flush_groups = 1;          // JFGPU_FLUSH_GROUPS     P2 / tile-insert pipeline depth of a flush
+  bool tile_pair = true;         // JFGPU_TILE_PAIR=0      32-bit slots: single tiles instead of pairs (A/B)
+  int p2_single = 1;             // JFGPU_P2_SINGLE        single-pass P2: 0 exact count + scatter, 1 when regions would be mostly items, 2 always
+  uint32_t p2_cap = 0;           // JFGPU_P2_CAP           items per P2 region (tests: forces region overflow)
+  double p2_slack = -1;          // JFGPU_P2_SLACK         head-room of a P2 region; < 0: 30 % (4- and 8-byte items), 8 % (16-byte)
+  int tile_adapt = 1;            // JFGPU_TILE_ADAPT       tile kernel instantiation: 1 sampled per flush, 0 always plain, 2 always HEAVY
+  uint32_t flush_share = 0;      // JFGPU_FLUSH_SHARE      force a flush into this many bucket groups sharing one P2 buffer (tests)
+  bool flush_trace = false;      // JFGPU_FLUSH_TRACE      one stderr line per flush
+  int p1_ring = -1;              // JFGPU_P1_RING          P1 kernel family for sequence input: -1 auto, 0 sort-based granule kernels only
+  // ---- Bloom counters (jfgpu_bloom_create)
+  int bloom_mode = 0;            // JFGPU_BLOOM_MODE=direct|partitioned      0: not set
+  // ---- communicators (jfgpu_comm_create*)
+  bool comm_trace = false;       // JFGPU_COMM_TRACE       every rank reports where it is in a step
+  bool comm_ipc = false;         // JFGPU_COMM_TRANSPORT=ipc   rank processes exchange through hipIpc* copies instead of RCCL
+  uint64_t comm_max_msg = 0;     // JFGPU_COMM_MAX_MSG     keys per message round (0: default)
+  int comm_self_rccl = -1;       // JFGPU_COMM_SELF_RCCL   world 1: send the rank's own share through RCCL too (-1: default)
+  int comm_items = -1;           // JFGPU_COMM_ITEMS       item path: -1 default, 0 off, 1 on, 2 forced
+  int comm_strag = -1;           // JFGPU_COMM_STRAG       straggler list capacity (tests; -1: default)
+
+  static Tuning from_env() {
+    Tuning u;
+    auto str = [](const char* name) -> const char* { const char* e = getenv(name); return e && *e ? e : nullptr; };
+    if(const char* e = str("JFGPU_MODE")) u.mode = !strcmp(e, "direct") ? 1 : !strcmp(e, "partitioned") ? 2 : 0;
+    if(const char* e = str("JFGPU_SLOT64")) u.slot64 = atoi(e) != 0;
+    if(const char* e = str("JFGPU_P1_SINGLE")) u.p1_single = atoi(e) ? 1 : 0;
+    if(const char* e = str("JFGPU_P1_SLACK")) u.p1_slack = atof(e);
+    if(const char* e = str("JFGPU_FLUSH_GROUPS")) u.flush_groups = std::max(1, atoi(e));
+    if(const char* e = str("JFGPU_TILE_PAIR")) u.tile_pair = atoi(e) != 0;
+    if(const char* e = str("JFGPU_P2_SINGLE")) u.p2_single = atoi(e);
+    if(const char* e = str("JFGPU_P2_CAP")) u.p2_cap = (uint32_t)atoi(e);
+    if(const char* e = str("JFGPU_P2_SLACK")) u.p2_slack = atof(e);
+    if(const char* e = str("JFGPU_TILE_ADAPT")) u.tile_adapt = atoi(e);
+    if(const char* e = str("JFGPU_FLUSH_SHARE")) u.flush_share = (uint32_t)atoi(e);
+    u.flush_trace = str("JFGPU_FLUSH_TRACE") != nullptr;
+    if(const char* e = str("JFGPU_P1_RING")) u.p1_ring = atoi(e);
+    if(const char* e = str("JFGPU_BLOOM_MODE")) u.bloom_mode = !strcmp(e, "direct") ? 1 : !strcmp(e, "partitioned") ? 2 : 0;
+    u.comm_trace = str("JFGPU_COMM_TRACE") != nullptr;
+    if(const char* e = str("JFGPU_COMM_TRANSPORT")) u.comm_ipc = !strcmp(e, "ipc");
+    if(const char* e = str("JFGPU_COMM_MAX_MSG")) u.comm_max_msg = std::max<uint64_t>(1, strtoull(e, 0, 10));
+    if(const char* e = str("JFGPU_COMM_SELF_RCCL")) u.comm_self_rccl = atoi(e) != 0;
+    if(const char* e = str("JFGPU_COMM_ITEMS")) u.comm_items = atoi(e);
+    if(const char* e = str("JFGPU_COMM_STRAG")) u.comm_strag = std::max(1, atoi(e));
+    return u;
+  }
+};
+
+}  // namespace jfgpu

@@ -73,6 +73,24 @@ def test_count_digest_equals_the_reference_tables_digest(cli, name, tmp_path):
         assert subprocess.check_output([O.REF_JF, "digest", out]).decode() == mine
 
 
+def test_config1_recorded_md5s_through_the_engine(cli, tmp_path):
+    """BASELINE configs[0] on the engine: the reference generator's 10 MB file (md5 recorded by the
+    survey) counted with `-m 21 -C -s 16M`, and `histo` of the result has the recorded md5 `08762de4...`; the file the
+    engine wrote is read by the reference's own `histo` with the same result."""
+    import hashlib
+    if not os.access(O.REF_GEN, os.X_OK):
+        pytest.skip("oracle/_ref not built")
+    d = str(tmp_path)
+    subprocess.check_call([O.REF_GEN, "-s", "42", "-r", "150", "-o", "reads150", "10000000"], cwd=d)
+    assert hashlib.md5(open(os.path.join(d, "reads150.fa"), "rb").read()).hexdigest() == "e539471302c480c328f8908dad38ff67"
+    for mode in ("direct", "partitioned"):
+        subprocess.check_call([cli, "count", "-m", "21", "-C", "-s", "16M", "-t", "1", "-o", "c1.jf", "reads150.fa"], cwd=d, env=dict(os.environ, JFGPU_MODE=mode))
+        histo = subprocess.check_output([cli, "histo", "c1.jf"], cwd=d)
+        assert histo == b"1 8666626\n2 17\n" and hashlib.md5(histo).hexdigest() == "08762de4d79a53b64b58517437425c3e", mode
+    if O.have_ref():
+        assert subprocess.check_output([O.REF_JF, "histo", "c1.jf"], cwd=d) == histo
+
+
 @pytest.fixture(scope="module")
 def half_gbp_reads(tmp_path_factory):
     """0.5 Gbp of 150 bp reads from the REFERENCE's generator (generate_sequence -s 42 -r 150: one-line records of 150
@@ -109,6 +127,62 @@ def test_half_gbp_reference_file_digest_equals_the_reference(cli, half_gbp_reads
     subprocess.check_call([O.REF_JF, "count", "-m", str(k), "-C", "-s", size, "-t", nproc, "--no-write", "--digest", ref] + extra_r + [half_gbp_reads])
     assert open(mine).read() == open(ref).read()
     assert int(open(mine).read().split()[1]) > (1000 if cfg == "C3" else 100_000_000)
+
+
+@pytest.fixture(scope="module")
+def half_gbp_genome_reads(tmp_path_factory):
+    """0.5 Gbp of 150 bp reads sampled from a 5 Mbp random genome with 1 % substitutions (~100 x coverage: BASELINE.md's
+    secondary distribution, what sequencing data looks like), written by the engine's device generator to a FASTA file in
+    /dev/shm the way bench.py writes its end-to-end input."""
+    if not O.have_ref():
+        pytest.skip("oracle/_ref not built")
+    import numpy as np
+    from jellyfish_amd import capi
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    d = str(tmp_path_factory.mktemp("halfgbpG")) if base is None else __import__("tempfile").mkdtemp(prefix="jf_halfgbpG_", dir=base)
+    L, n_reads, path = 150, 3_333_333, os.path.join(d, "readsG.fa")
+    with capi.Table(21, 1 << 20) as t, open(path, "wb") as f:
+        step = 1 << 20
+        dbuf = t.malloc(step * (L + 1) + 16)
+        hdr = np.frombuffer(b">r\n", dtype=np.uint8)
+        for r0 in range(0, n_reads, step):
+            n = min(step, n_reads - r0)
+            t.gen_genome_reads_dev(dbuf, r0, n, L, 5_000_000, 0.01, 4242)
+            t.wait()
+            body = t.d2h(dbuf, n * (L + 1)).reshape(n, L + 1)
+            body[:, L] = ord("\n")
+            np.concatenate([np.tile(hdr, (n, 1)), body], axis=1).tofile(f)
+        t.free(dbuf)
+    yield path
+    __import__("shutil").rmtree(d, ignore_errors=True)
+
+
+@pytest.mark.parametrize("cfg,k,size", [("C2", 21, "2G"), ("C3", 31, "512M")])
+def test_half_gbp_high_coverage_file_digest_equals_the_reference(cli, half_gbp_genome_reads, tmp_path, cfg, k, size):
+    """The same check on high-coverage input (round-3 review, item 1b): every true k-mer ~100 times, so the tile stage's
+    merge, its queue and -- chosen by the flush's own sample -- its HEAVY instantiation carry the work, and in C3 geometry
+    most k-mers pass the Bloom filter (ten cell reads each).  Content digest of the whole table against `ref_jf count
+    --digest`; the Bloom counter bodies byte-identical."""
+    nproc = str(min(os.cpu_count() or 1, 64))
+    env = dict(os.environ, JFGPU_QUIET="1", JFGPU_MODE="partitioned")
+    mine, ref = str(tmp_path / "mine.digest"), str(tmp_path / "ref.digest")
+    extra_m, extra_r = [], []
+    if cfg == "C3":
+        bm, br = str(tmp_path / "mine.bc"), str(tmp_path / "ref.bc")
+        subprocess.check_call([cli, "bc", "-m", str(k), "-C", "-s", "500M", "-o", bm, half_gbp_genome_reads], env=env)
+        subprocess.check_call([O.REF_JF, "bc", "-m", str(k), "-C", "-s", "500M", "-t", nproc, "-o", br, half_gbp_genome_reads])
+        offs = [9 + int(open(f, "rb").read(9)) for f in (bm, br)]
+        assert subprocess.call(["cmp", "-s", "-i", "%d:%d" % tuple(offs), bm, br]) == 0, "Bloom counter bodies differ"
+        extra_m, extra_r = ["--bc", bm], ["--bc", br]
+    subprocess.run([cli, "count", "-m", str(k), "-C", "-s", size, "--no-write", "--digest", mine, "--timing", str(tmp_path / "timing")] + extra_m + [half_gbp_genome_reads],
+                   env=dict(env, JFGPU_TIMING_DETAIL="1"), check=True)
+    subprocess.check_call([O.REF_JF, "count", "-m", str(k), "-C", "-s", size, "-t", nproc, "--no-write", "--digest", ref] + extra_r + [half_gbp_genome_reads])
+    assert open(mine).read() == open(ref).read()
+    records, total = (int(x.split()[1]) for x in open(mine).read().splitlines()[:2])
+    assert total > 3 * records > 3_000_000      # high coverage: the true k-mers ~100 times each beside the error k-mers (one third of the occurrences)
+    if cfg == "C2":      # the flush chose the HEAVY tile kernel from its own sample (count --timing reports the counters)
+        tm = dict(l.split()[:2] for l in open(tmp_path / "timing").read().splitlines() if len(l.split()) >= 2)
+        assert int(tm.get("FlushesHeavy", 0)) >= 1, tm
 
 
 def test_count_text_format_and_bounds(cli, tmp_path):

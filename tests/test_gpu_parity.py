@@ -1040,3 +1040,109 @@ def test_comm_item_path_equals_single_table(gpu, monkeypatch, world, strag):
         comm.close()
         for t in shards:
             t.close()
+
+
+# ---- round 4: the rank-placement tile kernel anchored to the oracle, every instantiation -----------------------------
+def sorted_map(keys, cnts):
+    o = np.argsort(keys, kind="stable")
+    return keys[o], cnts[o]
+
+
+def table_arrays(capi, t):
+    recs = t.dump_records(chunk_records=1 << 20)
+    keys, cnts = capi.decode_records(recs, t.k, t.info.out_counter_len)
+    assert len(np.unique(keys)) == len(keys), "duplicate key in dump"
+    return sorted_map(keys, cnts)
+
+
+def high_coverage_reads(rng, genome_len, n_reads, L, sub_rate, extra=b""):
+    """Reads from a small random genome with substitutions (hundreds of copies per true k-mer), as one contract buffer."""
+    g = rng.integers(0, 4, genome_len, dtype=np.uint8)
+    starts = rng.integers(0, genome_len - L, n_reads)
+    idx = starts[:, None] + np.arange(L)[None, :]
+    reads = g[idx]
+    flip = rng.random(reads.shape) < sub_rate
+    reads = np.where(flip, (reads + rng.integers(1, 4, reads.shape, dtype=np.uint8)) & 3, reads)
+    out = np.full((n_reads, L + 1), ord("N"), dtype=np.uint8)
+    out[:, :L] = np.frombuffer(b"ACGT", dtype=np.uint8)[reads]
+    return out.tobytes() + extra
+
+
+@pytest.mark.parametrize("adapt", ["0", "2", "1"])
+@pytest.mark.parametrize("k,lsize,slot64", [(17, 25, "0"), (17, 25, "1"), (18, 27, "0")])
+def test_tile_kernel_instantiations_equal_the_oracle_on_high_coverage_input(gpu, monkeypatch, adapt, k, lsize, slot64):
+    """The plain and the HEAVY instantiation of tile_rank_insert_kernel (JFGPU_TILE_ADAPT=0 / 2 force one; 1 lets the flush
+    sample itself), 4-byte slots in pairs of tiles and 8-byte slots in single tiles, against the C oracle -- not against
+    another HIP path: reads from a 20 kbp genome with 1 % substitutions (every true k-mer hundreds of times per flush, so
+    most items find their bucket full of their own key), a homopolymer run, a tandem repeat, a k-mer counted far past the
+    count field (the overflow side table), and TWO flushes, the second into tiles the first left dirty.
+    large_hash_array.hpp:509-597,741-752 is what both must equal."""
+    if adapt == "1" and lsize < 27:
+        pytest.skip("the sampled choice needs 8192 units per launch")
+    if lsize >= 27 and slot64 == "1":
+        pytest.skip("one geometry per instantiation is enough at this size")
+    monkeypatch.setenv("JFGPU_TILE_ADAPT", adapt)
+    monkeypatch.setenv("JFGPU_SLOT64", slot64)
+    monkeypatch.setenv("JFGPU_P2_SINGLE", "2")
+    rng = np.random.default_rng(k * 31 + lsize)
+    n_reads = 60000 if lsize < 27 else 400000
+    extra = b"N" + b"A" * 70000 + b"N" + b"AC" * 20000 + b"N"
+    seq = high_coverage_reads(rng, 20000, n_reads, 150, 0.01, extra)
+    half = (n_reads // 2) * 151
+    ekeys, ecnt = O.count(seq[:half], k, True)
+    ek2, ec2 = O.count(seq[half:], k, True)
+    allk = np.concatenate([ekeys[:, 0], ek2[:, 0]]); allc = np.concatenate([ecnt, ec2])
+    uk, inv = np.unique(allk, return_inverse=True)
+    uc = np.zeros(len(uk), dtype=np.uint64); np.add.at(uc, inv, allc.astype(np.uint64))
+    with gpu.Table(k, 1 << lsize) as t:
+        assert t.info.slot_bytes == (8 if slot64 == "1" else 4)
+        t.set_mode(2)
+        t.count_ascii(seq[:half])
+        t.sync()                                              # first flush: into clean tiles
+        t.count_ascii(seq[half:])
+        t.sync()                                              # second flush: every tile is dirty, most keys are there already
+        gk, gc = table_arrays(gpu, t)
+        assert len(gk) == len(uk) and (gk == uk).all() and (gc.astype(np.uint64) == np.minimum(uc, 2 ** 32 - 1)).all()
+        st = t.stats()
+        assert (st.distinct, st.total) == (len(uk), int(uc.sum()))
+        assert tuple(t.digest())[:2] == (len(uk), int(uc.sum()))
+        assert tuple(t.digest()) == gpu.digest_of(uk.reshape(-1, 1), uc)
+        ctr = t.counters()                                     # which instantiation really ran
+        if adapt == "0":
+            assert ctr["flushes_plain"] >= 2 and ctr["flushes_heavy"] == 0, ctr
+        elif adapt == "2":
+            assert ctr["flushes_heavy"] >= 2 and ctr["flushes_plain"] == 0, ctr
+        else:
+            assert ctr["t_items"] > 0, "the sampling launch did not run"
+            assert ctr["t_queued"] * 4 > ctr["t_items"] and ctr["flushes_heavy"] >= 1, ("this input must call for the HEAVY instantiation", ctr)
+
+
+@pytest.mark.parametrize("load", [0.90, 0.97])
+def test_partitioned_near_full_table_keeps_every_key_visible(gpu, load):
+    """Growth off, load 0.9 and 0.97, inserted through the LDS tile kernel: a key the tile kernel places must be one that
+    look-ups, update_add and later global-atomic adds find (they all stop at max_probe) -- or the flush says "Hash full"
+    like hash_counter::add does (hash_counter.hpp:194-195).  Round-3 advisor finding: the rank-placement kernel's queue
+    phase walked the whole tile and stranded keys beyond max_probe."""
+    k, size = 15, 1 << 16
+    rng = random.Random(int(load * 100))
+    keys = np.array(rng.sample(range(4 ** k), int(size * load)), dtype=np.uint64)
+    with gpu.Table(k, size, canonical=False) as t:
+        t.set_growth(False)
+        t.set_mode(2)
+        t.add_keys(keys)
+        try:
+            t.sync()
+        except gpu.JfgpuError as e:
+            assert e.code == gpu.E_FULL and "Hash full" in e.msg
+            return
+        assert t.refresh_info().max_reprobe == 1023
+        vals, found = t.lookup(keys)
+        assert found.all() and (vals == 1).all()
+        t.set_mode(1)                                         # global-atomic adds of keys that are there: never "Hash full"
+        t.add_keys(keys[::3])
+        t.sync()
+        vals, found = t.lookup(keys)
+        exp = np.ones(len(keys), dtype=np.uint64); exp[::3] = 2
+        assert found.all() and (vals == exp).all()
+        is_new = t.add_keys(keys[:500], val=3, want_new=True)     # hash_counter::add(key, val, &is_new)
+        assert not is_new.any()

@@ -241,3 +241,22 @@ def test_content_digest_three_ways(tmp_path, k, can):
     subprocess.check_call(args[:2] + ["-L", "2", "-U", "3"] + args[2:], cwd=d)
     sel = (cnt >= 2) & (cnt <= 3)
     assert _digest_lines(open(os.path.join(d, "lu.txt")).read()) == capi.digest_of(keys[sel], cnt[sel])
+
+
+@needs_ref
+def test_config1_recorded_md5s(tmp_path):
+    """BASELINE configs[0]: `generate_sequence -s 42 -r 150 -o reads150 10000000` is the 10 MB
+    FASTA whose md5 the survey recorded, and `jellyfish count -m 21 -C -s 16M -t 1` + `histo` on it gives the recorded
+    histogram md5 -- through the reference's classes (oracle/_ref) and, same lines, through the C restatement."""
+    d = str(tmp_path)
+    subprocess.check_call([O.REF_GEN, "-s", "42", "-r", "150", "-o", "reads150", "10000000"], cwd=d)
+    fa = os.path.join(d, "reads150.fa")
+    data = open(fa, "rb").read()
+    assert len(data) == 10922231 and hashlib.md5(data).hexdigest() == "e539471302c480c328f8908dad38ff67"
+    subprocess.check_call([O.REF_JF, "count", "-m", "21", "-C", "-s", "16M", "-t", "1", "-o", "c1.jf", "reads150.fa"], cwd=d)
+    histo = subprocess.check_output([O.REF_JF, "histo", "c1.jf"], cwd=d)
+    assert histo == b"1 8666626\n2 17\n" and hashlib.md5(histo).hexdigest() == "08762de4d79a53b64b58517437425c3e"
+    keys, cnt = O.count(O.parse_file(data), 21, True)
+    assert int(cnt.sum()) == 8666660 and len(keys) == 8666643
+    vals, n = np.unique(cnt, return_counts=True)
+    assert "".join("%d %d\n" % (v, c) for v, c in zip(vals.tolist(), n.tolist())).encode() == histo

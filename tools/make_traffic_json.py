@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """<tag>_{fetch,write}.csv (tools/rocpd_pmc.py output of the FETCH_SIZE / WRITE_SIZE passes of tools/profile_bench.sh)
--> profiles/r03_traffic_<cfg>.json: HBM bytes per job of every stage bench.py names, the figures its `roofline.traffic`
+-> profiles/r04_traffic_<cfg>.json: HBM bytes per job of every stage bench.py names, the figures its `roofline.traffic`
 quotes.  The profiled command runs exactly one job (--warmup 0 --repeats 1), so sums over the run are per-job sums.
 Corrections per MI355X_MICROARCH.md: counters are KB; FETCH_SIZE is doubled for wide coalesced reads; WRITE_SIZE as is.
 usage: make_traffic_json.py <tag path prefix> <C2|C3|C5> <gbp> <lsize> [out.json]"""
@@ -9,7 +9,7 @@ import json
 import sys
 
 tag, cfg, gbp, lsize = sys.argv[1], sys.argv[2], float(sys.argv[3]), int(sys.argv[4])
-out = sys.argv[5] if len(sys.argv) > 5 else "profiles/r03_traffic_%s.json" % cfg
+out = sys.argv[5] if len(sys.argv) > 5 else "profiles/r04_traffic_%s.json" % cfg
 
 
 def load(path, col):
@@ -41,8 +41,18 @@ for k in f:
     rec = {"stage": st, "dispatches": f[k][0], "fetch_bytes": 2.0 * f[k][1], "write_bytes": w.get(k, (0, 0.0))[1]}
     kernels[k] = rec
     stages[st] = stages.get(st, 0.0) + rec["fetch_bytes"] + rec["write_bytes"]
+import os
+import subprocess
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench
+try:
+    commit = subprocess.check_output(["git", "rev-parse", "HEAD"], cwd=bench.ROOT, text=True).strip()
+except Exception:
+    commit = None
 res = {
     "config": cfg, "gbp": gbp, "lsize": lsize,
+    # bench.py quotes these figures only while the engine's sources are the ones they were measured on
+    "kernel_sources_sha256": bench.kernel_sources_sha(), "commit_when_made": commit,
     "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `python bench.py --config %s --warmup 0 --repeats 1 "
               "--no-extras --no-cpu-baseline` (tools/profile_bench.sh): one job, sums over all its dispatches; KB -> bytes; FETCH_SIZE doubled as "
               "MI355X_MICROARCH.md prescribes for wide coalesced reads; WRITE_SIZE as reported" % cfg,
