@@ -192,18 +192,21 @@ int part_ingest(jfgpu_table* t, const uint8_t* base, int64_t lo, int64_t hi, boo
       else if(t->g.nbytes == 8) PK(false, 8);
       else PK(false, 0);
     } else
-#define PG(RT, BL, N) hipLaunchKernelGGL((p1_ring_kernel<RT, BL, N>), dim3(t->n_cu), dim3(kPBlock), (size_t)nb * kRingSlots * 4, t->stream, t->dt, t->d_dt, t->pg, base, lo, hi, gcap, gcur, b.tot, (uint32_t*)b.items)
+#define PG(BL, N, CN) hipLaunchKernelGGL((p1_ring_kernel<BL, N, CN>), dim3(t->n_cu), dim3(kPBlock), (size_t)nb * kRingSlots * 4 + 128, t->stream, t->dt, t->d_dt, (int)t->returning, t->pg, base, lo, hi, gcap, gcur, b.tot, (uint32_t*)b.items, t->d_strag, t->d_strag_n)
     {
-      // the rare direct inserts read the table's descriptor from device memory (kernels_p1ring.hip.hpp)
+      // what cannot be stored in a region (p1_stragglers_kernel) reads the table's descriptor from device memory
       { int rc = refresh_d_dt(t); if(rc) return rc; }
-      if(bl) { if(t->returning) PG(true, true, 0); else PG(false, true, 0); }
-      else if(t->returning) {       // narrow count fields (32-bit slots among them): same kernels, overflow-aware direct inserts
-        if(t->g.nbytes == 6) PG(true, false, 6); else if(t->g.nbytes == 7) PG(true, false, 7); else if(t->g.nbytes == 8) PG(true, false, 8); else PG(true, false, 0);
+      // per-workgroup straggler lists (what does not go through a ring), appended to the regions by a second small kernel
+      if(!t->d_strag) {
+        HIP_TRY(hipMalloc((void**)&t->d_strag, (size_t)t->n_cu * kStragPerBlock * sizeof(uint64_t)));
+        HIP_TRY(hipMalloc((void**)&t->d_strag_n, (size_t)t->n_cu * sizeof(uint32_t)));
       }
-      else if(t->g.nbytes == 6) PG(false, false, 6);
-      else if(t->g.nbytes == 7) PG(false, false, 7);
-      else if(t->g.nbytes == 8) PG(false, false, 8);
-      else PG(false, false, 0);
+      // (32-bit items exist for keys of at most 42 bits: six key bytes is the only width worth a compiled-in hash)
+      if(t->g.nbytes == 6 && !bl) { if(t->g.canonical) PG(false, 6, 1); else PG(false, 6, 0); }
+      else if(bl) PG(true, 0, 2);
+      else PG(false, 0, 2);
+      hipLaunchKernelGGL(p1_stragglers_kernel, dim3(t->n_cu), dim3(256), 0, t->stream, t->dt, t->d_dt, t->pg, (const uint64_t*)t->d_strag, (const uint32_t*)t->d_strag_n,
+                         (uint32_t)t->n_cu, gcap, gcur, b.tot, (uint32_t*)b.items, (int)t->returning);
     }
 #undef PG
 #undef PK
@@ -482,8 +485,10 @@ int part_flush_t(jfgpu_table* t) {
           ITEM* out_v = out2 - (share_groups ? (int64_t)d0 * (int64_t)cap2 : 0);
           if constexpr(sizeof(ITEM) == 4) {
             const size_t lds = (size_t)kPBlock * kP2PairPer * sizeof(ITEM);
-            if(rt) hipLaunchKernelGGL((p2_granule_kernel<uint32_t, TableDirect<true>, kP2PairPer>), g1p, block, lds, t->stream, TableDirect<true>{t->d_dt, t->pg, (unsigned long long*)&t->dt.counters[CTR_DIRECT]}, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest, (uint32_t*)out_v, b0);
-            else   hipLaunchKernelGGL((p2_granule_kernel<uint32_t, TableDirect<false>, kP2PairPer>), g1p, block, lds, t->stream, TableDirect<false>{t->d_dt, t->pg, (unsigned long long*)&t->dt.counters[CTR_DIRECT]}, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest, (uint32_t*)out_v, b0);
+#define P2G(RT, PF) hipLaunchKernelGGL((p2_granule_kernel<uint32_t, TableDirect<RT>, kP2PairPer, 0, PF>), g1p, block, lds, t->stream, TableDirect<RT>{t->d_dt, t->pg, (unsigned long long*)&t->dt.counters[CTR_DIRECT]}, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest, (uint32_t*)out_v, b0)
+            if(t->tun.p2_prefetch) { if(rt) P2G(true, true); else P2G(false, true); }
+            else { if(rt) P2G(true, false); else P2G(false, false); }
+#undef P2G
           } else if constexpr(sizeof(ITEM) == 8) {     // keys of 22 to 32 bases: 8-byte items into single tiles, chunks of 112 KiB
             const size_t lds = (size_t)kPBlock * kP2MidPer * sizeof(ITEM);
             if(rt) hipLaunchKernelGGL((p2_granule_kernel<uint64_t, TableDirect<true>, kP2MidPer>), g1p, block, lds, t->stream, TableDirect<true>{t->d_dt, t->pg, (unsigned long long*)&t->dt.counters[CTR_DIRECT]}, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest, (uint64_t*)out_v, b0);

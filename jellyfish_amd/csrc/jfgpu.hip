@@ -127,6 +127,7 @@ struct jfgpu_table {
   double items_per_byte = 0;     // k-mers per sequence byte seen by the last flush (0: unknown yet)
   uint64_t reserved_input = 0;   // sequence bytes the caller announced (jfgpu_reserve): lets forced flushes be spaced evenly
   uint32_t* d_M1 = nullptr; int g1 = 0;
+  uint64_t* d_strag = nullptr; uint32_t* d_strag_n = nullptr;      // straggler lists of the ring P1 (kernels_p1ring.hip.hpp), one per workgroup
   uint32_t* d_M2 = nullptr; int g2 = 0;
   // workspace arena for pending batches and flush temporaries: bump-allocated, reset at flush,
   // grown geometrically (allocation of tens of GB costs ~100 ms, so never inside the hot path twice)
@@ -682,8 +683,7 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_sorted_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_sorted_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
 #define PATTR(N) HIP_TRY(hipFuncSetAttribute((const void*)p1_keys_scatter_sorted_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6)); \
-                 HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_sorted_kernel<false, false, N>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6)); \
-                 HIP_TRY(hipFuncSetAttribute((const void*)p1_ring_kernel<false, false, N>, hipFuncAttributeMaxDynamicSharedMemorySize, kGranMaxB * kRingSlots * 4))
+                 HIP_TRY(hipFuncSetAttribute((const void*)p1_scatter_sorted_kernel<false, false, N>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6))
     PATTR(0); PATTR(6); PATTR(7); PATTR(8);
 #undef PATTR
     HIP_TRY(hipFuncSetAttribute((const void*)p1_keys_granule_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
@@ -691,12 +691,12 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     HIP_TRY(hipFuncSetAttribute((const void*)p1_keys_granule_kernel<false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_keys_granule_kernel<false, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_keys_granule_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
-    HIP_TRY(hipFuncSetAttribute((const void*)p1_ring_kernel<true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kGranMaxB * kRingSlots * 4));
-    HIP_TRY(hipFuncSetAttribute((const void*)p1_ring_kernel<true, false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, kGranMaxB * kRingSlots * 4));
-    HIP_TRY(hipFuncSetAttribute((const void*)p1_ring_kernel<true, false, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kGranMaxB * kRingSlots * 4));
-    HIP_TRY(hipFuncSetAttribute((const void*)p1_ring_kernel<true, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kGranMaxB * kRingSlots * 4));
-    HIP_TRY(hipFuncSetAttribute((const void*)p1_ring_kernel<false, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kGranMaxB * kRingSlots * 4));
-    HIP_TRY(hipFuncSetAttribute((const void*)p1_ring_kernel<true, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kGranMaxB * kRingSlots * 4));
+    {
+      const int rl = kGranMaxB * kRingSlots * 4 + 128;
+#define RATTR(BL, N, CN) HIP_TRY(hipFuncSetAttribute((const void*)p1_ring_kernel<BL, N, CN>, hipFuncAttributeMaxDynamicSharedMemorySize, rl))
+      RATTR(false, 6, 1); RATTR(false, 6, 0); RATTR(true, 0, 2); RATTR(false, 0, 2);
+#undef RATTR
+    }
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint32_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * 16 * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_route_granule_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_route_granule_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
@@ -708,6 +708,8 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
 #undef SATTR
     HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint64_t, TableDirect<true>, kP2MidPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2MidPer * 8));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint64_t, TableDirect<false>, kP2MidPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2MidPer * 8));
+    HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint32_t, TableDirect<true>, kP2PairPer, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
+    HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint32_t, TableDirect<false>, kP2PairPer, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint32_t, TableDirect<true>, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint32_t, TableDirect<false>, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint32_t, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
@@ -751,6 +753,8 @@ void jfgpu_destroy(jfgpu_table* t) {
   if(t->d_tile_off) hipFree(t->d_tile_off);
   part_discard(t);
   if(t->d_M1) hipFree(t->d_M1);
+  if(t->d_strag) hipFree(t->d_strag);
+  if(t->d_strag_n) hipFree(t->d_strag_n);
   if(t->d_M2) hipFree(t->d_M2);
   if(t->ws) hipFree(t->ws);
   if(t->stream2) hipStreamDestroy(t->stream2);

@@ -3,13 +3,12 @@
 // Round 2's single-pass P1 counting-sorted every chunk of 16 Ki positions by bucket in LDS (histogram, scan, ranked
 // scatter, read-back by bucket, placement table) and wrote runs of ~16 items wherever the chunk's run of a bucket
 // happened to start: seven barriers per chunk on one workgroup per CU, and 64-byte runs straddling 128-byte lines
-// (1.6 x write amplification, profiles/r02_traffic_C2.json).  Here the sort is gone: every bucket owns a RING of 32 items
-// in LDS (1024 x 128 B), a k-mer's item is appended with one returning ds_add on the bucket's fill word and one store,
-// and after a round of 8 Ki positions every bucket that has 16 items together emits them as one aligned 64-byte unit
-// (tools/probes/scatter_write_probe.hip: aligned 64-byte runs travel at twice the rate of straddling ones).  Lane t of the
-// workgroup keeps bucket t's bookkeeping (read cursor, place in the region, reservations) in registers; the copy LDS ->
-// region is done by four lanes per unit.  Region format, reservations of kGran items and holes are exactly the granule
-// kernels' (kernels_part.hip.hpp), so P2 and the tile kernel read the output as before.
+// (1.6 x write amplification, profiles/r02_traffic_C2.json).  Since round 3 the sort is gone: every bucket owns a RING of
+// 32 items in LDS (1024 x 128 B), a k-mer's item is appended with one returning ds_add on the bucket's fill word and one
+// store, and after a round of 8 Ki positions every bucket that has 16 items together emits them as one aligned 64-byte
+// unit (tools/probes/scatter_write_probe.hip: aligned 64-byte runs travel at twice the rate of straddling ones).  Region
+// format, reservations of kGran items and holes are exactly the granule kernels' (kernels_part.hip.hpp), so P2 and the
+// tile kernel read the output as before.  Round 4 rebuilt the kernel around what its counters said (see below).
 #pragma once
 #include "kernels_part.hip.hpp"
 
@@ -26,163 +25,233 @@ __device__ __forceinline__ uint32_t adm_to_vmask(uint32_t adm) {
 constexpr uint32_t kRingSlots = 32, kRingUnit = 16;      // items per ring and per emitted unit
 constexpr uint32_t kRingDirect = 0xFFFFFFFFu;            // a unit with nowhere to go in its region: inserted directly
 
-// fill word of a bucket: (ring position of its oldest item) << 16 | items in the ring.  The count may run past the ring's
-// size inside a round (what came too late was inserted directly by its own lane); it is cut back at the round's end.
-template <bool RETURNING, bool BLOOM, int NB>
-__global__ __launch_bounds__(kPBlock) void p1_ring_kernel(DevTable T, const DevTable* __restrict__ Tmem, PartGeom P, const uint8_t* __restrict__ base,
-                                                          int64_t lo, int64_t hi, uint32_t cap,
-                                                          unsigned int* __restrict__ gcur,
-                                                          unsigned long long* __restrict__ tot,
-                                                          uint32_t* __restrict__ out) {
+// ---- round 4: rings owned lane by lane, stragglers on a list ------------------------------------------------------------
+// SQ counters of the round-3 kernel (profiles/r04_sq_counters_p1.txt): 13.4 G vector instructions per 10 Gbp = 85 per
+// position and lane, the SIMDs issuing them 64 % of the time; 10 LDS instructions per position, the LDS array busy 41 % of
+// the CU cycles plus 22 % in bank conflicts.  Both units are two-thirds busy and a wave's instruction stream alternates
+// between them, so the kernel moves only when BOTH get less to do.  What was done, with the P1 time of the 10 Gbp job:
+//   39.1 ms  round 3
+//   35.8     pack16 four characters at a time (kmer_core.hpp: 16 -> 5 vector instructions per character)
+//   35.2     this kernel:
+//   * the flush is every owner lane's own business: lane t reads bucket t's units out of its ring (four 16-byte reads) and
+//     writes them to the region (four 16-byte stores) -- no ballots, no shuffles, no four-lane teams.  A ring starts life
+//     at position 4 t (mod 32), so the 64 owners of a wave read 64 different bank groups.
+//   * nothing is inserted from inside the loop: an item that finds its ring full, a run of identical k-mers, the item
+//     that looks like a hole go on the workgroup's STRAGGLER list (an LDS counter, a plain global store) and
+//     p1_stragglers_kernel appends them to their regions afterwards, before the regions' bounds are taken.  Round 3
+//     inserted them on the spot with global atomics: a few microseconds during which the wave, and at the next barrier
+//     the workgroup, stood still -- and 121 K tiles per job were dirtied before the tile stage ran, which then had to
+//     read them (T 28.0 -> 26.9 ms).
+//   * a flush needs no quiescence after it: a ring slot that holds no item holds the HOLE marker (an item never equals
+//     it), a unit is complete exactly when none of its 16 slots reads as a hole, complete units go out, their slots are
+//     reset to holes and only then released (compare-and-swap on the fill word: ring position advanced, count reduced),
+//     so the next round's appends of other waves may run beside it.  An append that finds its ring full (rank >= 32)
+//     stays counted in the fill word as a "ghost" until the owner's next release drops it (min(count, 32) is what the
+//     ring really holds).  ONE barrier per round is left, before the flush, so that everything due has landed.
+//   * fewer instructions per position: the second sweep stores without a branch per item (positions without an item
+//     store into 32 dump slots behind the rings), the rolling forward / reverse-complement words move by funnel shifts
+//     on their two dwords, the six table words meet in v_bitop3_b32.
+// Measured and dropped (profiles/r04_p1_experiments.log): no barrier at all (a unit whose newest item is still on its
+// way -- an append stores its item only after all of its round's returning adds are back -- is put off by a round, its
+// ring overflows: 9 % of the items became stragglers, 130 ms); halo lanes instead of staging the neighbours' bases
+// through LDS (lanes 0 and 1 of a wave load the 32 bases before it and produce nothing: no staging barriers, but 3 % more
+// work: 37.4 ms); a second barrier after the flush (36.2 with LDS staging); half the table look-ups, as a sensitivity
+// test with wrong results (-7 %: neither unit alone is the limit).
+constexpr uint32_t kStragPerBlock = 16384;                                     // entries of a workgroup's straggler list (8 bytes each)
+
+// entry of a straggler list: occurrences << 48 | bucket << 32 | item
+__device__ __forceinline__ uint64_t strag_entry(uint32_t b, uint32_t item, uint32_t cnt) { return ((uint64_t)cnt << 48) | ((uint64_t)b << 32) | item; }
+
+// Bucket b's ring starts life at ring position 4 b (mod 32): the owners of a wave then read 16-byte chunks of 64
+// different bank groups at every step, with no address arithmetic spent on it.
+
+// CANON: 0 forward k-mers, 1 canonical, 2 decided at run time (the table's flag)
+template <bool BLOOM, int NB, int CANON>
+__global__ __launch_bounds__(kPBlock) void p1_ring_kernel(DevTable T, const DevTable* __restrict__ Tmem, int returning, PartGeom P, const uint8_t* __restrict__ base,
+                                                           int64_t lo, int64_t hi, uint32_t cap,
+                                                           unsigned int* __restrict__ gcur,
+                                                           unsigned long long* __restrict__ tot,
+                                                           uint32_t* __restrict__ out,
+                                                           uint64_t* __restrict__ strag, uint32_t* __restrict__ strag_n) {
   JF_DYN_LDS(s_dyn);
   uint32_t* s_ring = reinterpret_cast<uint32_t*>(s_dyn);          // [nb][kRingSlots]
   __shared__ uint64_t s_fwd[8 * 256];
+  __shared__ uint32_t s_fill[kGranMaxB];
+  __shared__ uint32_t s_nstrag;
   __shared__ uint32_t s_codes[kPBlock + 2];
   __shared__ uint32_t s_inv[kPBlock + 2];
-  __shared__ uint32_t s_fill[kGranMaxB];
   const TableGeom& g = T.g;
   const uint32_t nb = 1u << P.b1;
   const uint32_t t = threadIdx.x, lane = t & 63;
   const bool owner = t < nb;                                       // this lane keeps bucket t's books
+  const uint32_t hole = 0xFFFFFFFFu;
   load_tables_lds(s_fwd, T.fwd_tbl, g.nbytes);
-  for(uint32_t j = t; j < nb; j += blockDim.x) s_fill[j] = 0;
+  for(uint32_t j = t; j < nb; j += blockDim.x) s_fill[j] = ((4u * j) & (kRingSlots - 1)) << 16;
+  for(uint32_t j = t * 4; j < nb * kRingSlots; j += blockDim.x * 4) *reinterpret_cast<uint4*>(s_ring + j) = make_uint4(hole, hole, hole, hole);
+  if(t == 0) s_nstrag = 0;
+  const uint32_t dump = nb * kRingSlots + (lane & 31u);            // 32 dwords behind the rings: where the stores of positions without an item go
   unsigned int* const gshort = gcur + nb;
+  uint64_t* const my_strag = strag + (size_t)blockIdx.x * kStragPerBlock;
   const uint32_t k = g.k, bshift = g.lsize_l - P.b1;
   const uint32_t rc_shift = 2 * (k - 1);
-  const uint32_t hole = 0xFFFFFFFFu;
-  // bucket t's place in its region: gpos .. gpos + room of the current reservation, `nxt` the reservation asked for in
-  // advance (its answer is first looked at a round later), kNoRoom when the region has none left
+  // item = (rest << rem_bits) | rem in 32-bit arithmetic (32-bit items: rest_shift + rem_bits <= 32)
+  const uint32_t rest_mask = P.rest_shift >= 32 ? 0xFFFFFFFFu : ((1u << P.rest_shift) - 1u);
   uint32_t gpos = 0, room = 0, nxt = 0, stored = 0;
   bool nxt_asked = false, exhausted = false;
   if(owner) { nxt = atomicAdd(&gcur[t], kGran); nxt_asked = true; }
-  uint32_t my_direct = 0, my_mers = 0;
+  uint32_t* const my_region = out + (uint64_t)t * cap;
+  uint32_t my_mers = 0, my_direct = 0;
 
-  auto direct = [&](uint32_t b, uint32_t item, uint32_t cnt = 1) { item_direct_call(Tmem, P.b2, b, item, cnt, RETURNING ? 1 : 0); ++my_direct; };
+  // not for the rings: on the workgroup's list (p1_stragglers_kernel takes it from there); a full list (an input that
+  // sends everything to a few buckets) falls back to the table's global claim on the spot -- slow, never wrong
+  auto straggler = [&](uint32_t b, uint32_t item, uint32_t cnt = 1) {
+    const uint32_t at = atomicAdd(&s_nstrag, 1u);
+    if(at < kStragPerBlock) my_strag[at] = strag_entry(b, item, cnt);
+    else { item_direct_call(Tmem, P.b2, b, item, cnt, returning); ++my_direct; }
+  };
 
-  // After a round: every bucket with 16 items or more emits whole units (at most two: the ring holds 32); `all`: the
-  // kernel's last call also emits what is left, padded with holes.
+  // What bucket t has complete goes out.  `all`: the kernel's last call, after a barrier -- every append has landed, and the
+  // partial last unit goes out too (the slots behind its items are holes already).
   auto flush = [&](bool all) {
-    uint32_t has[2] = {0, 0}, roff[2] = {0, 0}, dest[2] = {0, 0};
-    if(owner) {
-      const uint32_t w = s_fill[t];
-      uint32_t cnt = w & 0xFFFFu, rb = (w >> 16) & (kRingSlots - 1);
-      if(cnt > kRingSlots) cnt = kRingSlots;
-      uint32_t units = cnt / kRingUnit;
-      if(all && (cnt % kRingUnit)) {                               // the last, partial unit: holes behind its items
-        for(uint32_t i = cnt; i < (units + 1) * kRingUnit; ++i) s_ring[t * kRingSlots + ((rb + i) & (kRingSlots - 1))] = hole;
-        ++units;
-      }
-      for(uint32_t s = 0; s < units; ++s) {
-        if(room == 0 && nxt_asked) {                               // take the reservation asked for earlier
-          if((uint64_t)nxt + kGran <= cap) { gpos = nxt; room = kGran; }
-          else { exhausted = true; if(nxt < cap) atomicMax(&gshort[t], cap - nxt); }     // (everything below nxt was handed out)
-          nxt_asked = false;
-        }
-        // no reservation in hand and none asked for (the one taken above was used up inside this flush): ask now and
-        // wait -- rare, and cheaper than sixteen global-atomic inserts for a region that still has room
-        if(room == 0 && !exhausted) {
-          const uint32_t r0 = atomicAdd(&gcur[t], kGran);
-          if((uint64_t)r0 + kGran <= cap) { gpos = r0; room = kGran; }
-          else { exhausted = true; if(r0 < cap) atomicMax(&gshort[t], cap - r0); }
-        }
-        has[s] = 1; roff[s] = (rb + s * kRingUnit) & (kRingSlots - 1);
-        const uint32_t real = cnt - s * kRingUnit < kRingUnit ? cnt - s * kRingUnit : kRingUnit;
-        if(room) { dest[s] = gpos; gpos += kRingUnit; room -= kRingUnit; stored += real; }
-        else dest[s] = kRingDirect;
-      }
-      const uint32_t taken = units * kRingUnit < cnt ? units * kRingUnit : cnt;
-      s_fill[t] = (((rb + units * kRingUnit) & (kRingSlots - 1)) << 16) | (cnt - taken);
-      // keep one reservation in hand whenever the current one cannot take a ring's worth: its round trip to L2 hides
-      // behind the next round
-      if(!all && !nxt_asked && !exhausted && room < kRingSlots) { nxt = atomicAdd(&gcur[t], kGran); nxt_asked = true; }
-    }
-    // the copies: four lanes per unit (16 bytes each), sixteen owners per wave instruction
+    if(!owner) return;
+    uint32_t w = s_fill[t];
+    uint32_t cnt = w & 0xFFFFu; if(cnt > kRingSlots) cnt = kRingSlots;
+    const uint32_t rb = (w >> 16) & (kRingSlots - 1);
+    uint32_t units = cnt / kRingUnit; if(all && (cnt % kRingUnit)) ++units;
+    uint32_t nout = 0;
+    for(uint32_t s = 0; s < units; ++s) {
+      uint4 v[4];
+      const uint32_t s0 = (rb + s * kRingUnit) & (kRingSlots - 1);
 #pragma unroll
-    for(int s = 0; s < 2; ++s) {
-      const unsigned long long m = __ballot(has[s] != 0);
-      if(!m) continue;                                             // wave-uniform
-#pragma unroll 1
-      for(int j = 0; j < 4; ++j) {
-        if(!((m >> (16 * j)) & 0xFFFFull)) continue;               // wave-uniform
-        const int own = 16 * j + (int)(lane >> 2);
-        const uint32_t f = __shfl(has[s], own, 64), ro = __shfl(roff[s], own, 64), d = __shfl(dest[s], own, 64);
-        if(!f) continue;
-        const uint32_t b = (t & ~63u) + (uint32_t)own, part = lane & 3;
-        const uint4 v = *reinterpret_cast<const uint4*>(s_ring + b * kRingSlots + ro + 4 * part);
-        if(d != kRingDirect) *reinterpret_cast<uint4*>(out + (uint64_t)b * cap + d + 4 * part) = v;
-        else {
-          if(v.x != hole) direct(b, v.x);
-          if(v.y != hole) direct(b, v.y);
-          if(v.z != hole) direct(b, v.z);
-          if(v.w != hole) direct(b, v.w);
+      for(int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const uint4*>(s_ring + t * kRingSlots + ((s0 + 4 * q) & (kRingSlots - 1)));
+      if(!all) {
+        uint32_t mx = 0;
+#pragma unroll
+        for(int q = 0; q < 4; ++q) { const uint32_t a = v[q].x > v[q].y ? v[q].x : v[q].y, c = v[q].z > v[q].w ? v[q].z : v[q].w; mx = mx > a ? mx : a; mx = mx > c ? mx : c; }
+        if(mx == hole) break;                                      // an item of this unit is still on its way: next time
+      }
+      if(room == 0 && nxt_asked) {                                 // take the reservation asked for earlier
+        if((uint64_t)nxt + kGran <= cap) { gpos = nxt; room = kGran; }
+        else { exhausted = true; if(nxt < cap) atomicMax(&gshort[t], cap - nxt); }       // (everything below nxt was handed out)
+        nxt_asked = false;
+      }
+      if(room == 0 && !exhausted) {                                // none in hand, none asked for: ask now and wait (rare)
+        const uint32_t r0 = atomicAdd(&gcur[t], kGran);
+        if((uint64_t)r0 + kGran <= cap) { gpos = r0; room = kGran; }
+        else { exhausted = true; if(r0 < cap) atomicMax(&gshort[t], cap - r0); }
+      }
+      if(room) {
+        uint32_t* dst = my_region + gpos;
+#pragma unroll
+        for(int q = 0; q < 4; ++q) *reinterpret_cast<uint4*>(dst + 4 * q) = v[q];
+        const uint32_t real = cnt - s * kRingUnit < kRingUnit ? cnt - s * kRingUnit : kRingUnit;
+        gpos += kRingUnit; room -= kRingUnit; stored += real;
+      } else {                                                     // the region is exhausted (skewed input): the list
+#pragma unroll
+        for(int q = 0; q < 4; ++q) {
+          if(v[q].x != hole) straggler(t, v[q].x);
+          if(v[q].y != hole) straggler(t, v[q].y);
+          if(v[q].z != hole) straggler(t, v[q].z);
+          if(v[q].w != hole) straggler(t, v[q].w);
         }
       }
+#pragma unroll
+      for(int q = 0; q < 4; ++q) *reinterpret_cast<uint4*>(s_ring + t * kRingSlots + ((s0 + 4 * q) & (kRingSlots - 1))) = make_uint4(hole, hole, hole, hole);
+      ++nout;
+    }
+    // keep one reservation in hand whenever the current one cannot take a ring's worth: its round trip to L2 hides
+    // behind the next round
+    if(!all && !nxt_asked && !exhausted && room < kRingSlots) { nxt = atomicAdd(&gcur[t], kGran); nxt_asked = true; }
+    // the release: ring position past what went out, the count without it -- and without the ghosts
+    uint32_t expect = w;
+    while(nout || (expect & 0xFFFFu) > kRingSlots) {
+      uint32_t c = expect & 0xFFFFu; if(c > kRingSlots) c = kRingSlots;
+      const uint32_t taken = nout * kRingUnit < c ? nout * kRingUnit : c;                 // (`all`: the partial unit takes what is there)
+      const uint32_t neww = ((((expect >> 16) + nout * kRingUnit) & 0xFFFFu) << 16) | (c - taken);
+      const uint32_t old = atomicCAS(&s_fill[t], expect, neww);
+      if(old == expect) break;
+      expect = old;                                                 // somebody appended meanwhile: the same release on the newer word
     }
   };
 
   const int64_t n_tiles = (hi + kPTilePos - 1) / kPTilePos;
   TileRaw R = tile_fetch(base, (int64_t)blockIdx.x * kPTilePos, lo, hi);
+  lds_barrier();                                                   // tables, fill words and holes are in place
   [[maybe_unused]] PhaseClk pc;
   for(int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     lds_barrier();
     const LaneWords L = tile_stage(R, tile * kPTilePos, lo, hi, s_codes, s_inv);      // barrier inside
-    JF_PHASE(pc, 0);
     R = tile_fetch(base, (tile + gridDim.x) * kPTilePos, lo, hi);                      // next tile's bytes travel while this one is worked on
+    JF_PHASE(pc, 0);
     const uint32_t adm = BLOOM ? bloom_admit_mask(T.bloom, g, L) : 0xFFFFu;
     uint64_t fw = (((uint64_t)L.p2 << 32) | L.p1) & g.key_mask;
     uint64_t rc = revcomp64(fw, k);
     // which of the lane's 16 positions end a window of k valid bases: the invalid-base bits smeared over the k - 1
-    // positions after them, once per tile (bit 15 - j <-> position j, like inv48)
+    // positions after them, once per tile (bit 15 - j <-> position j, like inv48); the halo lanes produce nothing
     uint64_t smear = L.inv48;
     for(uint32_t s = 1; s < k; ) { const uint32_t step = s < k - s ? s : k - s; smear |= smear >> step; s += step; }
     const uint32_t rawmask = ~(uint32_t)smear & 0xFFFFu;
     const uint32_t vmask = BLOOM ? (rawmask & adm_to_vmask(adm)) : rawmask;
     my_mers += (uint32_t)__popc(rawmask);
-    // a k-mer is emitted one position late, when it is known whether the next one repeats it (homopolymers, tandem
-    // repeats: one insert for the run): pk / pv / run describe the position before
     uint64_t pk = 0; uint32_t pv = 0, run = 0;
 #pragma unroll 1
     for(int j0 = 0; j0 < kPerLane; j0 += kPerLane / 2) {            // two rounds of eight positions per lane
       constexpr int NE = kPerLane / 2 + 1;                          // (the +1: the tile's last k-mer, emitted after the loop)
-      uint32_t eb[NE], ei[NE], eo[NE]; uint32_t em = 0;
+      // ea: the ring's first dword (bucket * 32), ei: item, eo: fill word before the append.  A position without an item
+      // keeps (dump, 0): the second sweep stores unconditionally, those stores land in the dump slots
+      uint32_t ea[NE], ei[NE], eo[NE];
+#pragma unroll
+      for(int e = 0; e < NE; ++e) { ea[e] = dump; ei[e] = 0; eo[e] = 0; }
       auto emit = [&](int e, uint64_t key, uint32_t cnt) {
         const uint64_t pos = hash_tables_t<NB>(s_fwd, key, g.nbytes);
-        const uint64_t local = pos & g.local_mask;
-        eb[e] = (uint32_t)(local >> bshift);
-        ei[e] = make_item<uint32_t>(g, P, key, local);
-        if(ei[e] == hole || cnt > 1) direct(eb[e], ei[e], cnt);      // (it would read as a hole; a run goes in at once)
-        else { eo[e] = atomicAdd(&s_fill[eb[e]], 1u); em |= 1u << e; }
+        const uint32_t b = (uint32_t)(pos >> bshift) & (nb - 1);
+        const uint32_t item = (((uint32_t)pos & rest_mask) << g.rem_bits) | (uint32_t)(key >> g.lsize_g);      // (32-bit items: lsize_g <= 2k <= 42)
+        if(item == hole || cnt > 1) straggler(b, item, cnt);         // (it would read as a hole; a run goes in at once)
+        else { ea[e] = b * kRingSlots; ei[e] = item; eo[e] = atomicAdd(&s_fill[b], 1u); }
       };
 #pragma unroll
       for(int e = 0; e < kPerLane / 2; ++e) {
         const int j = j0 + e;
-        const uint64_t c = (L.cur >> (2 * (15 - j))) & 3u;
-        fw = ((fw << 2) | c) & g.key_mask;
-        rc = (rc >> 2) | ((3ull - c) << rc_shift);
-        const uint32_t v = (vmask >> (15 - j)) & 1u;
-        const uint64_t key = (g.canonical && rc < fw) ? rc : fw;
+        const uint32_t c = (L.cur >> (2 * (15 - j))) & 3u;
+        if constexpr(NB >= 5) {
+          // keys of more than 32 bits (k >= 17): the two dwords by hand -- funnel shifts instead of 64-bit shifts, and the
+          // new base of the reverse complement enters the high dword directly (rc_shift >= 32)
+          const uint32_t flo = (uint32_t)fw, fhi = (uint32_t)(fw >> 32), rlo = (uint32_t)rc, rhi = (uint32_t)(rc >> 32);
+          fw = ((uint64_t)(funnel_r(fhi, flo, 30) & (uint32_t)(g.key_mask >> 32)) << 32) | ((flo << 2) | c);
+          rc = ((uint64_t)((rhi >> 2) | ((3u - c) << (rc_shift - 32))) << 32) | funnel_r(rhi, rlo, 2);
+        } else {
+          fw = ((fw << 2) | c) & g.key_mask;
+          rc = (rc >> 2) | ((uint64_t)(3u - c) << rc_shift);
+        }
+        const uint32_t v = vmask & (1u << (15 - j));
+        const uint64_t key = ((CANON == 1 || (CANON == 2 && g.canonical)) && rc < fw) ? rc : fw;
         const bool same = v && pv && key == pk;
         if(pv && !same) emit(e, pk, run);
         run = same ? run + 1 : 1;
         pk = key; pv = v;
       }
       if(j0) { if(pv) emit(NE - 1, pk, run); pv = 0; }
-      // (second sweep: the ring stores, once the fill adds are back -- not one wait per item)
+      // second sweep: the ring stores, once the fill adds are back (not one wait per item), without a branch per item
+      uint32_t ghosts = 0;
 #pragma unroll
-      for(int e = 0; e < NE; ++e)
-        if((em >> e) & 1) {
-          const uint32_t r = eo[e] & 0xFFFFu;
-          if(r < kRingSlots) s_ring[eb[e] * kRingSlots + (((eo[e] >> 16) + r) & (kRingSlots - 1))] = ei[e];
-          else direct(eb[e], ei[e]);                                 // more than a ring's worth for one bucket in one round: skewed input
-        }
+      for(int e = 0; e < NE; ++e) {
+        const uint32_t full = eo[e] & 0xFFE0u;                       // rank >= 32: the ring is full
+        ghosts |= full;
+        const uint32_t at = ea[e] + ((eo[e] + (eo[e] >> 16)) & (kRingSlots - 1));
+        s_ring[full ? dump : at] = ei[e];
+      }
+      if(ghosts) {                                                  // rare: a ghost in its bucket's count until the owner's next release
+#pragma unroll 1
+        for(int e = 0; e < NE; ++e) if(eo[e] & 0xFFE0u) straggler(ea[e] / kRingSlots, ei[e]);
+      }
       JF_PHASE(pc, 1);
-      lds_barrier();
+      lds_barrier();                                               // the round's items have all landed: what is due goes out now
       JF_PHASE(pc, 2);
       flush(false);
       JF_PHASE(pc, 3);
-      lds_barrier();
     }
   }
+  lds_barrier();                                                   // every append of every wave has landed
   flush(true);
   if(owner) {
     // what is left of the reservations becomes holes; the exact count of the bucket goes to tot
@@ -193,12 +262,40 @@ __global__ __launch_bounds__(kPBlock) void p1_ring_kernel(DevTable T, const DevT
     }
     if(tot && stored) atomicAdd(&tot[t], (unsigned long long)stored);
   }
+  lds_barrier();                                                   // (the final flush may have put items on the list)
+  if(t == 0) strag_n[blockIdx.x] = s_nstrag < kStragPerBlock ? s_nstrag : kStragPerBlock;
   JF_PHASE(pc, 4);
   JF_PHASE_FLUSH(pc, 0);
   if(my_direct) atomicAdd((unsigned long long*)&T.counters[CTR_DIRECT], (unsigned long long)my_direct);
   uint64_t w = my_mers;
   for(int o = 32; o > 0; o >>= 1) w += __shfl_down(w, o, 64);
   if((threadIdx.x & 63) == 0 && w) atomicAdd((unsigned long long*)&T.counters[CTR_MERS], (unsigned long long)w);
+}
+
+// The straggler lists of a P1 launch, after it: an item takes the next free place of its bucket's region (nobody reserves
+// granules any more, so places are handed out one by one), counted in tot like the others; what cannot be stored in a
+// region -- the region is full, the item reads as a hole, a run of identical k-mers -- is inserted with global atomics
+// (item_direct_call).
+__global__ __launch_bounds__(256) void p1_stragglers_kernel(DevTable T, const DevTable* __restrict__ Tmem, PartGeom P, const uint64_t* __restrict__ strag,
+                                                            const uint32_t* __restrict__ strag_n, uint32_t n_lists, uint32_t cap,
+                                                            unsigned int* __restrict__ gcur, unsigned long long* __restrict__ tot,
+                                                            uint32_t* __restrict__ out, int returning) {
+  uint32_t my_direct = 0;
+  for(uint32_t l = blockIdx.x; l < n_lists; l += gridDim.x) {
+    const uint32_t n = strag_n[l];
+    const uint64_t* rec = strag + (size_t)l * kStragPerBlock;
+    for(uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+      const uint64_t r = rec[i];
+      const uint32_t item = (uint32_t)r, b = (uint32_t)(r >> 32) & 0xFFFFu, cnt = (uint32_t)(r >> 48);
+      if(cnt == 1 && item != 0xFFFFFFFFu) {
+        const uint32_t at = atomicAdd(&gcur[b], 1u);
+        if(at < cap) { out[(uint64_t)b * cap + at] = item; if(tot) atomicAdd(&tot[b], 1ull); continue; }
+      }
+      item_direct_call(Tmem, P.b2, b, item, cnt, returning);
+      ++my_direct;
+    }
+  }
+  if(my_direct) atomicAdd((unsigned long long*)&T.counters[CTR_DIRECT], (unsigned long long)my_direct);
 }
 
 }  // namespace jfgpu

@@ -29,6 +29,15 @@
 
 namespace jfgpu {
 
+// Hides a value from the optimiser (the value itself is unchanged): what was derived from it before this point is not
+// kept alive across it, it is derived again.  The unrolled per-item code otherwise carries bucket numbers, shift counts
+// and addresses of all of a lane's items from the rank requests to the placement, and spills.
+#if defined(JFGPU_EMU)
+#define JF_OPAQUE(x) do {} while(0)
+#else
+#define JF_OPAQUE(x) asm volatile("" : "+v"(x))
+#endif
+
 constexpr int kPBlock = 1024;                 // threads per block in the partition passes
 constexpr int kPTilePos = kPBlock * kPerLane; // 16384 sequence positions per block iteration
 constexpr int kMaxBuckets = 2048;             // per pass
@@ -870,7 +879,9 @@ struct TableDirect {
 };
 
 // ITEM: uint32_t or unsigned __int128; DIRECT: see TableDirect (kernels_wide_part.hip.hpp has the two-word one).
-template <typename ITEM, typename DIRECT, int PER_THREAD, int SMALL = 0>
+// PREFETCH: the next chunk's items are requested into a second set of registers before the current chunk is sorted, so
+// that their way from HBM hides behind the LDS work (one workgroup per CU: nothing else would issue loads meanwhile).
+template <typename ITEM, typename DIRECT, int PER_THREAD, int SMALL = 0, bool PREFETCH = false>
 __global__ __launch_bounds__(kPBlock) void p2_granule_kernel(DIRECT D, uint32_t b2e, uint32_t tag_bits, SegList S, uint32_t cap,
                                                              unsigned int* __restrict__ gcur, unsigned int* __restrict__ gshort,
                                                              ITEM* __restrict__ out, uint32_t bucket0,
@@ -893,15 +904,13 @@ __global__ __launch_bounds__(kPBlock) void p2_granule_kernel(DIRECT D, uint32_t 
   const uint64_t my_lo = (uint64_t)blockIdx.x * per, my_hi = my_lo + per < n ? my_lo + per : n;
   uint32_t my_direct = 0;
   [[maybe_unused]] PhaseClk pc;
-  for(uint64_t c0 = my_lo; c0 < my_hi; c0 += kChunk) {
-    lds_barrier();                                      // previous chunk's readers are done
-    JF_PHASE(pc, 0);
-    for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) G.hist[j] = 0;
-    ITEM it[PER_THREAD];
-    uint32_t rk[(PER_THREAD + 1) / 2];                  // rank inside the chunk's bucket, 16 bits each
-    uint32_t hm = 0, vm = 0;
+  // one chunk's items into registers (vm: which of the lane's PER_THREAD positions hold an item, hm: which of those came
+  // from a batch with holes); no use of the loaded values here, so all the loads of a chunk are in flight together
+  auto load_chunk = [&](uint64_t c0, ITEM (&it)[PER_THREAD], uint32_t& vm, uint32_t& hm) {
+    vm = 0; hm = 0;
 #pragma unroll
     for(int r = 0; r < PER_THREAD; ++r) it[r] = 0;
+    if(c0 >= my_hi) return;                             // block-uniform
     const uint32_t cn = my_hi - c0 < (uint64_t)kChunk ? (uint32_t)(my_hi - c0) : (uint32_t)kChunk;
     uint64_t slo = 0;
     for(uint32_t s = 0; s < S.n; ++s) {                 // uniform loop: usually one or two batches overlap a chunk
@@ -919,6 +928,22 @@ __global__ __launch_bounds__(kPBlock) void p2_granule_kernel(DIRECT D, uint32_t 
       }
       slo = shi;
     }
+  };
+  ITEM nxt[PREFETCH ? PER_THREAD : 1]; uint32_t nvm = 0, nhm = 0;
+  if constexpr(PREFETCH) load_chunk(my_lo, nxt, nvm, nhm);
+  for(uint64_t c0 = my_lo; c0 < my_hi; c0 += kChunk) {
+    lds_barrier();                                      // previous chunk's readers are done
+    JF_PHASE(pc, 0);
+    for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) G.hist[j] = 0;
+    ITEM it[PER_THREAD];
+    uint32_t rk[(PER_THREAD + 1) / 2];                  // rank inside the chunk's bucket, 16 bits each
+    uint32_t hm = 0, vm = 0;
+    if constexpr(PREFETCH) {
+      hm = nhm; vm = nvm;
+#pragma unroll
+      for(int r = 0; r < PER_THREAD; ++r) it[r] = nxt[r];
+      load_chunk(c0 + kChunk, nxt, nvm, nhm);
+    } else load_chunk(c0, it, vm, hm);
     lds_barrier();
     JF_PHASE(pc, 1);
     if constexpr(SMALL != 0) {

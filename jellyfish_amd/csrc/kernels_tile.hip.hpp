@@ -39,15 +39,6 @@ __device__ __attribute__((noinline)) void ovf_add_call(uint64_t* ovf_key, uint64
   ovf_add(V, slot, units);
 }
 
-// Hides a value from the optimiser (the value itself is unchanged): what was derived from it before this point is not
-// kept alive across it, it is derived again.  The unrolled per-item code otherwise carries bucket numbers, shift counts
-// and addresses of all of a lane's items from the rank requests to the placement, and spills.
-#if defined(JFGPU_EMU)
-#define JF_OPAQUE(x) do {} while(0)
-#else
-#define JF_OPAQUE(x) asm volatile("" : "+v"(x))
-#endif
-
 #ifndef JFGPU_T_BLOCK
 #define JFGPU_T_BLOCK 512
 #endif

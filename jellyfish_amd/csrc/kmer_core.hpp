@@ -41,7 +41,68 @@ JF_HD uint32_t base_code(uint32_t c) {
 // 16-bit invalid mask.  Base j (0 = first character) sits at bits [2(15-j)+1 : 2(15-j)]
 // of codes and bit (15-j) of inval, so that earlier bases are MORE significant
 // and consecutive words concatenate into one big-endian base stream.
+//
+// Four characters at a time inside one dword (round 4; the per-character version cost 16 vector instructions per
+// character -- a fifth of the partition kernels' issue slots -- this one about 5):
+//   u      = w & 0xDFDFDFDF                        ASCII case folded, all four bytes
+//   code   = ((u >> 1) ^ (u >> 2)) & 0x03030303    A 0, C 1, G 2, T 3 (bits 1..3 of the letter; stays inside its byte)
+//   letter = "ACGT"[code], byte-wise               one v_perm_b32: what u must be for the character to be a base
+//   bad    = (u ^ letter) != 0, byte-wise          exact zero-byte test, flag in bit 7 of the byte
+// and the 2-bit / 1-bit fields of a dword are gathered with two shift-or steps each (no cross-talk: see the field
+// positions in the comments below).
+JF_HD uint32_t letters_of_codes(uint32_t code) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_perm(0u, 0x54474341u, code);      // selector bytes 0..3 pick bytes of the second operand
+#else
+  uint32_t r = 0;
+  for(int b = 0; b < 4; ++b) r |= (uint32_t)"ACGT"[(code >> (8 * b)) & 3u] << (8 * b);
+  return r;
+#endif
+}
+JF_HD uint32_t bitrev32(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_bitreverse32(x);
+#else
+  x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+  x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+  x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+  x = ((x >> 8) & 0x00FF00FFu) | ((x & 0x00FF00FFu) << 8);
+  return (x >> 16) | (x << 16);
+#endif
+}
+// One dword = characters 0..3 (byte 0 first).  Returns its four codes as one byte in bits 24..31 (character 0 most
+// significant; lower bits are junk) and its four invalid flags in bits 21..24 (character 0 at bit 24; other bits junk).
+JF_HD void pack4(uint32_t w, uint32_t& codes_hi8, uint32_t& inv_21_24) {
+  const uint32_t u = w & 0xDFDFDFDFu;
+  const uint32_t code = ((u >> 1) ^ (u >> 2)) & 0x03030303u;
+  const uint32_t t = u ^ letters_of_codes(code);
+  const uint32_t bad = (((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t) & 0x80808080u;      // bit 7 of a byte: that byte of t is not zero
+  // codes: fields at bits 0, 8, 16, 24 -> 30, 28, 26, 24.  y adds copies shifted by 10, z copies shifted by 20: into bits
+  // 24..31 fall char 3 (24 + 0), char 2 (16 + 10), char 1 (8 + 20), char 0 (0 + 10 + 20) and nothing else
+  const uint32_t y = (code << 10) | code;
+  codes_hi8 = (y << 20) | y;
+  // flags: bit 7 of byte j -> reversed to bit 24 - 8j; copies shifted by 7 and 14: bits 21..24 get char 3 (0 + 21),
+  // char 2 (8 + 14), char 1 (16 + 7), char 0 (24 + 0) and nothing else
+  const uint32_t f = bitrev32(bad);
+  const uint32_t g = (f << 7) | f;
+  inv_21_24 = (g << 14) | g;
+}
 JF_HD void pack16(const uint32_t w[4], uint32_t& codes, uint32_t& inval) {
+  uint32_t c[4], v[4];
+#pragma unroll
+  for(int i = 0; i < 4; ++i) pack4(w[i], c[i], v[i]);
+#if defined(__HIP_DEVICE_COMPILE__)
+  // the top bytes of c[0..3], in that order, most significant first
+  const uint32_t hi = __builtin_amdgcn_perm(c[0], c[1], 0x07030000u), lo = __builtin_amdgcn_perm(c[2], c[3], 0x00000703u);
+  codes = __builtin_amdgcn_perm(hi, lo, 0x07060100u);
+#else
+  codes = (c[0] & 0xFF000000u) | ((c[1] >> 8) & 0x00FF0000u) | ((c[2] >> 16) & 0x0000FF00u) | (c[3] >> 24);
+#endif
+  inval = ((v[0] >> 9) & 0xF000u) | ((v[1] >> 13) & 0x0F00u) | ((v[2] >> 17) & 0x00F0u) | ((v[3] >> 21) & 0x000Fu);
+}
+
+// (the per-character statement of the same function: what the one above must equal for every input)
+JF_HD void pack16_ref(const uint32_t w[4], uint32_t& codes, uint32_t& inval) {
   uint32_t c = 0, v = 0;
 #pragma unroll
   for(int i = 0; i < 4; ++i) {
@@ -137,15 +198,27 @@ inline uint32_t geom_min_lsize(uint32_t k, uint32_t shard_bits) {
 // byte b of the key having value v.  (H is linear over GF(2).)
 template <int NB>
 JF_HD uint64_t hash_tables_n(const uint64_t* tbl, uint64_t key) {
-  // constant byte positions: the key bytes come out of the two dwords with v_bfe_u32, no 64-bit shifts
+  // constant byte positions: the key bytes come out of the two dwords with v_bfe_u32 / SDWA, no 64-bit shifts; the two
+  // halves of the position are folded separately so that three table words meet in one v_bitop3_b32 (a 64-bit xor is
+  // split into two plain v_xor_b32 after instruction selection and never becomes one)
   const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
-  uint64_t pos = 0;
+  uint32_t plo = 0, phi = 0;
 #pragma unroll
   for(int b = 0; b < NB; ++b) {
     const uint32_t w = b < 4 ? lo : hi;
-    pos ^= tbl[b * 256 + ((w >> (8 * (b & 3))) & 0xFFu)];
+    const uint64_t v = tbl[b * 256 + ((w >> (8 * (b & 3))) & 0xFFu)];
+    plo ^= (uint32_t)v; phi ^= (uint32_t)(v >> 32);
   }
-  return pos;
+  return ((uint64_t)phi << 32) | plo;
+}
+
+// (hi : lo) >> s, low dword, 0 <= s < 32 (v_alignbit_b32)
+JF_HD uint32_t funnel_r(uint32_t hi, uint32_t lo, uint32_t s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_alignbit(hi, lo, s);
+#else
+  return (uint32_t)((((uint64_t)hi << 32) | lo) >> (s & 31u));
+#endif
 }
 
 // NB > 0: the number of key bytes is a compile-time constant of the kernel (no per-k-mer switch);
