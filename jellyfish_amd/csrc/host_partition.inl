@@ -83,7 +83,16 @@ void launch_p1(jfgpu_table* t, bool scatter, bool from_keys, const uint8_t* base
 
 int part_flush(jfgpu_table* t);
 
-// Single-pass P1 (p1_ring_kernel, p1_granule64_kernel, p1_keys_granule_kernel, ...): items per bucket region, 0 when the batch takes the exact
+// per-workgroup straggler lists of the ring P1 kernels (kernels_p1ring.hip.hpp), allocated at first use
+int ensure_strag(jfgpu_table* t) {
+  if(t->d_strag) return JFGPU_OK;
+  const size_t words = Ring<uint32_t>::kWords;
+  HIP_TRY(hipMalloc((void**)&t->d_strag, (size_t)t->n_cu * kStragPerBlock * words * sizeof(uint64_t)));
+  HIP_TRY(hipMalloc((void**)&t->d_strag_n, (size_t)t->n_cu * sizeof(uint32_t)));
+  return JFGPU_OK;
+}
+
+// Single-pass P1 (p1_ring_kernel, p1_keys_granule_kernel, ...): items per bucket region, 0 when the batch takes the exact
 // two-pass scheme.  Every block may strand part of one reservation per bucket, so small batches would be
 // mostly holes: auto mode wants the mean bucket load to be at least 4x that.
 uint32_t granule_cap(const jfgpu_table* t, bool from_keys, uint64_t max_items) {
@@ -192,21 +201,19 @@ int part_ingest(jfgpu_table* t, const uint8_t* base, int64_t lo, int64_t hi, boo
       else if(t->g.nbytes == 8) PK(false, 8);
       else PK(false, 0);
     } else
-#define PG(BL, N, CN) hipLaunchKernelGGL((p1_ring_kernel<BL, N, CN>), dim3(t->n_cu), dim3(kPBlock), (size_t)nb * kRingSlots * 4 + 128, t->stream, t->dt, t->d_dt, (int)t->returning, t->pg, base, lo, hi, gcap, gcur, b.tot, (uint32_t*)b.items, t->d_strag, t->d_strag_n)
+#define PG(IT, BL, N, CN) hipLaunchKernelGGL((p1_ring_kernel<IT, BL, N, CN>), dim3(t->n_cu), dim3(kPBlock), (size_t)nb * 128 + 128, t->stream, t->dt, t->d_dt, (int)t->returning, t->pg, base, lo, hi, gcap, gcur, b.tot, (IT*)b.items, t->d_strag, t->d_strag_n)
     {
       // what cannot be stored in a region (p1_stragglers_kernel) reads the table's descriptor from device memory
       { int rc = refresh_d_dt(t); if(rc) return rc; }
-      // per-workgroup straggler lists (what does not go through a ring), appended to the regions by a second small kernel
-      if(!t->d_strag) {
-        HIP_TRY(hipMalloc((void**)&t->d_strag, (size_t)t->n_cu * kStragPerBlock * sizeof(uint64_t)));
-        HIP_TRY(hipMalloc((void**)&t->d_strag_n, (size_t)t->n_cu * sizeof(uint32_t)));
-      }
+      { int rc = ensure_strag(t); if(rc) return rc; }
+      const OneWordDirect od{t->d_dt, t->pg.b2, (int)t->returning};
+      unsigned long long* ctr = (unsigned long long*)&t->dt.counters[CTR_DIRECT];
       // (32-bit items exist for keys of at most 42 bits: six key bytes is the only width worth a compiled-in hash)
-      if(t->g.nbytes == 6 && !bl) { if(t->g.canonical) PG(false, 6, 1); else PG(false, 6, 0); }
-      else if(bl) PG(true, 0, 2);
-      else PG(false, 0, 2);
-      hipLaunchKernelGGL(p1_stragglers_kernel, dim3(t->n_cu), dim3(256), 0, t->stream, t->dt, t->d_dt, t->pg, (const uint64_t*)t->d_strag, (const uint32_t*)t->d_strag_n,
-                         (uint32_t)t->n_cu, gcap, gcur, b.tot, (uint32_t*)b.items, (int)t->returning);
+      if(t->g.nbytes == 6 && !bl) { if(t->g.canonical) PG(uint32_t, false, 6, 1); else PG(uint32_t, false, 6, 0); }
+      else if(bl) PG(uint32_t, true, 0, 2);
+      else PG(uint32_t, false, 0, 2);
+      hipLaunchKernelGGL((p1_stragglers_kernel<uint32_t, OneWordDirect>), dim3(t->n_cu), dim3(256), 0, t->stream, od, ctr, (const uint64_t*)t->d_strag, (const uint32_t*)t->d_strag_n,
+                         (uint32_t)t->n_cu, gcap, gcur, b.tot, (uint32_t*)b.items);
     }
 #undef PG
 #undef PK

@@ -505,6 +505,7 @@ int table_grow(jfgpu_table* t) {
   t->dt = nd; t->g = g2; t->matrix = m2; t->d_fwd = nf; t->d_inv = ni; t->ovf_cap = cap2;
   t->returning = t->g.cnt_bits < 40; t->ovf_failed_need = 0;
   if(t->d_M2) { hipFree(t->d_M2); t->d_M2 = nullptr; }
+  if(t->d_strag) { hipFree(t->d_strag); hipFree(t->d_strag_n); t->d_strag = nullptr; t->d_strag_n = nullptr; }     // (the item width may change with the geometry)
   if(t->nword) {
     t->nt = nn;
     t->pristine = false;
@@ -692,9 +693,9 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     HIP_TRY(hipFuncSetAttribute((const void*)p1_keys_granule_kernel<false, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_keys_granule_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kPTilePos * 6));
     {
-      const int rl = kGranMaxB * kRingSlots * 4 + 128;
-#define RATTR(BL, N, CN) HIP_TRY(hipFuncSetAttribute((const void*)p1_ring_kernel<BL, N, CN>, hipFuncAttributeMaxDynamicSharedMemorySize, rl))
-      RATTR(false, 6, 1); RATTR(false, 6, 0); RATTR(true, 0, 2); RATTR(false, 0, 2);
+      const int rl = kGranMaxB * 128 + 128;
+#define RATTR(IT, BL, N, CN) HIP_TRY(hipFuncSetAttribute((const void*)p1_ring_kernel<IT, BL, N, CN>, hipFuncAttributeMaxDynamicSharedMemorySize, rl))
+      RATTR(uint32_t, false, 6, 1); RATTR(uint32_t, false, 6, 0); RATTR(uint32_t, true, 0, 2); RATTR(uint32_t, false, 0, 2);
 #undef RATTR
     }
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint32_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * 16 * 4));

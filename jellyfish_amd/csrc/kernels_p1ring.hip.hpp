@@ -22,8 +22,6 @@ __device__ __forceinline__ uint32_t adm_to_vmask(uint32_t adm) {
   return r;
 }
 
-constexpr uint32_t kRingSlots = 32, kRingUnit = 16;      // items per ring and per emitted unit
-constexpr uint32_t kRingDirect = 0xFFFFFFFFu;            // a unit with nowhere to go in its region: inserted directly
 
 // ---- round 4: rings owned lane by lane, stragglers on a list ------------------------------------------------------------
 // SQ counters of the round-3 kernel (profiles/r04_sq_counters_p1.txt): 13.4 G vector instructions per 10 Gbp = 85 per
@@ -57,24 +55,156 @@ constexpr uint32_t kRingDirect = 0xFFFFFFFFu;            // a unit with nowhere 
 // through LDS (lanes 0 and 1 of a wave load the 32 bases before it and produce nothing: no staging barriers, but 3 % more
 // work: 37.4 ms); a second barrier after the flush (36.2 with LDS staging); half the table look-ups, as a sensitivity
 // test with wrong results (-7 %: neither unit alone is the limit).
-constexpr uint32_t kStragPerBlock = 16384;                                     // entries of a workgroup's straggler list (8 bytes each)
+constexpr uint32_t kStragPerBlock = 16384;                                     // entries of a workgroup's straggler list
 
-// entry of a straggler list: occurrences << 48 | bucket << 32 | item
-__device__ __forceinline__ uint64_t strag_entry(uint32_t b, uint32_t item, uint32_t cnt) { return ((uint64_t)cnt << 48) | ((uint64_t)b << 32) | item; }
+// ---- the ring machinery, shared by the P1 kernels of every item width ---------------------------------------------------
+// A ring is 128 bytes of LDS whatever the item (32 four-byte, 16 eight-byte or 8 sixteen-byte items), a unit half of it
+// (one aligned 64-byte run in the bucket's region), and it is read and reset in 16-byte chunks.
+template <typename ITEM> struct Ring {
+  static constexpr uint32_t kSlots = 128 / sizeof(ITEM);
+  static constexpr uint32_t kUnit = kSlots / 2;
+  static constexpr uint32_t kChunk = 16 / sizeof(ITEM);                        // items per 16-byte chunk
+  static constexpr uint32_t kFull = 0xFFFFu & ~(kSlots - 1);                   // bits of a rank that say "the ring is full"
+  static constexpr uint32_t kWords = sizeof(ITEM) <= 4 ? 1 : 1 + sizeof(ITEM) / 8;   // 64-bit words of a straggler entry
+  // Bucket b's ring starts life at ring position b chunks (mod the ring): the 64 owners of a wave then read 16-byte
+  // chunks of 64 different bank groups at every step, with no address arithmetic spent on it.
+  __device__ static uint32_t first_fill(uint32_t b) { return ((kChunk * b) & (kSlots - 1)) << 16; }
+};
 
-// Bucket b's ring starts life at ring position 4 b (mod 32): the owners of a wave then read 16-byte chunks of 64
-// different bank groups at every step, with no address arithmetic spent on it.
+// 0xFFFFFFFF exactly when the chunk holds a hole (the all-ones item)
+template <typename ITEM> __device__ __forceinline__ uint32_t chunk_hole_key(const uint4& v) {
+  if constexpr(sizeof(ITEM) == 4) { const uint32_t a = v.x > v.y ? v.x : v.y, c = v.z > v.w ? v.z : v.w; return a > c ? a : c; }
+  else if constexpr(sizeof(ITEM) == 8) { const uint32_t a = v.x & v.y, c = v.z & v.w; return a > c ? a : c; }
+  else return v.x & v.y & v.z & v.w;
+}
+template <typename ITEM, typename F> __device__ __forceinline__ void chunk_items(const uint4& v, F&& f) {
+  if constexpr(sizeof(ITEM) == 4) { f((ITEM)v.x); f((ITEM)v.y); f((ITEM)v.z); f((ITEM)v.w); }
+  else if constexpr(sizeof(ITEM) == 8) { f((ITEM)(((uint64_t)v.y << 32) | v.x)); f((ITEM)(((uint64_t)v.w << 32) | v.z)); }
+  else f((ITEM)(((unsigned __int128)(((uint64_t)v.w << 32) | v.z) << 64) | (((uint64_t)v.y << 32) | v.x)));
+}
 
-// CANON: 0 forward k-mers, 1 canonical, 2 decided at run time (the table's flag)
-template <bool BLOOM, int NB, int CANON>
+// entry of a straggler list: occurrences << 48 | bucket << 32 (| the item, when it has 32 bits), then the item's words
+template <typename ITEM> __device__ __forceinline__ void strag_store(uint64_t* rec, uint32_t b, ITEM item, uint32_t cnt) {
+  const uint64_t meta = ((uint64_t)cnt << 48) | ((uint64_t)b << 32);
+  if constexpr(sizeof(ITEM) == 4) rec[0] = meta | (uint32_t)item;
+  else if constexpr(sizeof(ITEM) == 8) { rec[0] = meta; rec[1] = (uint64_t)item; }
+  else { rec[0] = meta; rec[1] = (uint64_t)item; rec[2] = (uint64_t)(item >> 64); }
+}
+template <typename ITEM> __device__ __forceinline__ void strag_load(const uint64_t* rec, uint32_t& b, ITEM& item, uint32_t& cnt) {
+  const uint64_t meta = rec[0];
+  b = (uint32_t)(meta >> 32) & 0xFFFFu; cnt = (uint32_t)(meta >> 48);
+  if constexpr(sizeof(ITEM) == 4) item = (ITEM)(uint32_t)meta;
+  else if constexpr(sizeof(ITEM) == 8) item = (ITEM)rec[1];
+  else item = (ITEM)(((unsigned __int128)rec[2] << 64) | rec[1]);
+}
+
+// an owner lane's books: its place in the region (gpos .. gpos + room of the current reservation), `nxt` the reservation
+// asked for in advance (its answer is first looked at a round later), the items it stored
+struct RingBooks { uint32_t gpos = 0, room = 0, nxt = 0, stored = 0; bool nxt_asked = false, exhausted = false; };
+
+// What bucket t has complete goes out (owner lanes only).  `all`: the kernel's last call, after a barrier -- every append
+// has landed, and the partial last unit goes out too (the slots behind its items are holes already).
+template <typename ITEM, typename STRAG>
+__device__ __forceinline__ void ring_flush(ITEM* s_ring, uint32_t* s_fill, uint32_t t, bool all, RingBooks& B, ITEM* my_region, uint32_t cap,
+                                           unsigned int* gcur, unsigned int* gshort, STRAG&& straggler) {
+  using R = Ring<ITEM>;
+  const ITEM hole = (ITEM)~(ITEM)0;
+  const uint32_t w = s_fill[t];
+  uint32_t cnt = w & 0xFFFFu; if(cnt > R::kSlots) cnt = R::kSlots;
+  const uint32_t rb = (w >> 16) & (R::kSlots - 1);
+  uint32_t units = cnt / R::kUnit; if(all && (cnt % R::kUnit)) ++units;
+  uint32_t nout = 0;
+  for(uint32_t s = 0; s < units; ++s) {
+    uint4 v[4];
+    const uint32_t s0 = (rb + s * R::kUnit) & (R::kSlots - 1);
+#pragma unroll
+    for(int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const uint4*>(s_ring + t * R::kSlots + ((s0 + R::kChunk * q) & (R::kSlots - 1)));
+    if(!all) {
+      uint32_t mx = 0;
+#pragma unroll
+      for(int q = 0; q < 4; ++q) { const uint32_t a = chunk_hole_key<ITEM>(v[q]); mx = mx > a ? mx : a; }
+      if(mx == 0xFFFFFFFFu) break;                                 // an item of this unit is still on its way: next time
+    }
+    if(B.room == 0 && B.nxt_asked) {                               // take the reservation asked for earlier
+      if((uint64_t)B.nxt + kGran <= cap) { B.gpos = B.nxt; B.room = kGran; }
+      else { B.exhausted = true; if(B.nxt < cap) atomicMax(&gshort[t], cap - B.nxt); }     // (everything below nxt was handed out)
+      B.nxt_asked = false;
+    }
+    if(B.room == 0 && !B.exhausted) {                              // none in hand, none asked for: ask now and wait (rare)
+      const uint32_t r0 = atomicAdd(&gcur[t], kGran);
+      if((uint64_t)r0 + kGran <= cap) { B.gpos = r0; B.room = kGran; }
+      else { B.exhausted = true; if(r0 < cap) atomicMax(&gshort[t], cap - r0); }
+    }
+    if(B.room) {
+      uint4* dst = reinterpret_cast<uint4*>(my_region + B.gpos);
+#pragma unroll
+      for(int q = 0; q < 4; ++q) dst[q] = v[q];
+      const uint32_t real = cnt - s * R::kUnit < R::kUnit ? cnt - s * R::kUnit : R::kUnit;
+      B.gpos += R::kUnit; B.room -= R::kUnit; B.stored += real;
+    } else {                                                       // the region is exhausted (skewed input): the list
+#pragma unroll
+      for(int q = 0; q < 4; ++q) chunk_items<ITEM>(v[q], [&](ITEM x) { if(x != hole) straggler(t, x, 1u); });
+    }
+#pragma unroll
+    for(int q = 0; q < 4; ++q)
+      *reinterpret_cast<uint4*>(s_ring + t * R::kSlots + ((s0 + R::kChunk * q) & (R::kSlots - 1))) = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    ++nout;
+  }
+  // keep one reservation in hand whenever the current one cannot take a ring's worth: its round trip to L2 hides
+  // behind the next round
+  if(!all && !B.nxt_asked && !B.exhausted && B.room < R::kSlots) { B.nxt = atomicAdd(&gcur[t], kGran); B.nxt_asked = true; }
+  // the release: ring position past what went out, the count without it -- and without the ghosts
+  uint32_t expect = w;
+  while(nout || (expect & 0xFFFFu) > R::kSlots) {
+    uint32_t c = expect & 0xFFFFu; if(c > R::kSlots) c = R::kSlots;
+    const uint32_t taken = nout * R::kUnit < c ? nout * R::kUnit : c;                       // (`all`: the partial unit takes what is there)
+    const uint32_t neww = ((((expect >> 16) + nout * R::kUnit) & 0xFFFFu) << 16) | (c - taken);
+    const uint32_t old = atomicCAS(&s_fill[t], expect, neww);
+    if(old == expect) break;
+    expect = old;                                                   // somebody appended meanwhile: the same release on the newer word
+  }
+}
+
+// rings, fill words, the list's counter: before the first append (the caller's barrier follows)
+template <typename ITEM>
+__device__ __forceinline__ void ring_init(ITEM* s_ring, uint32_t* s_fill, uint32_t nb, uint32_t* s_nstrag) {
+  using R = Ring<ITEM>;
+  for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) s_fill[j] = R::first_fill(j);
+  uint4* r4 = reinterpret_cast<uint4*>(s_ring);
+  for(uint32_t j = threadIdx.x; j < nb * 8 + 8; j += blockDim.x) r4[j] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);      // (+ the dump slots)
+  if(threadIdx.x == 0) *s_nstrag = 0;
+}
+
+// kernel end (owner lanes): what is left of the reservations becomes holes; the exact count of the bucket goes to tot
+template <typename ITEM>
+__device__ __forceinline__ void ring_finish(const RingBooks& B, uint32_t t, ITEM* my_region, uint32_t cap, unsigned int* gshort, unsigned long long* tot) {
+  const ITEM hole = (ITEM)~(ITEM)0;
+  for(uint32_t r = 0; r < B.room; ++r) my_region[B.gpos + r] = hole;
+  if(B.nxt_asked) {
+    if((uint64_t)B.nxt + kGran <= cap) { for(uint32_t r = 0; r < kGran; ++r) my_region[B.nxt + r] = hole; }
+    else if(B.nxt < cap) atomicMax(&gshort[t], cap - B.nxt);
+  }
+  if(tot && B.stored) atomicAdd(&tot[t], (unsigned long long)B.stored);
+}
+
+// ---- one-word keys, 4-byte items (k <= 21 at the metric's geometry) -----------------------------------------------------
+// CANON: 0 forward k-mers, 1 canonical, 2 decided at run time (the table's flag).  A round is 8 positions per lane.
+// The kernel is written over the item type, and was measured with the wider ones (profiles/r04_c5_ring_experiment.log,
+// r04_k31_stage_times.txt): 8-byte items (k = 22 .. 32: rings of 16, rounds of 4 positions) 29.6 ms per 5 Gbp at k = 31
+// against 28.4 for the sort-based p1_granule64_kernel before this round's pack16; 16-byte items (k = 63: rings of 8,
+// units of 4) 130 - 152 ms against 106.  A ring of 128 bytes holds too few wide items: either the rounds get short (a
+// barrier and a flush every two or four positions) or 0.6 % of the items overflow.  Those widths keep the sort.
+template <typename ITEM, bool BLOOM, int NB, int CANON>
 __global__ __launch_bounds__(kPBlock) void p1_ring_kernel(DevTable T, const DevTable* __restrict__ Tmem, int returning, PartGeom P, const uint8_t* __restrict__ base,
-                                                           int64_t lo, int64_t hi, uint32_t cap,
-                                                           unsigned int* __restrict__ gcur,
-                                                           unsigned long long* __restrict__ tot,
-                                                           uint32_t* __restrict__ out,
-                                                           uint64_t* __restrict__ strag, uint32_t* __restrict__ strag_n) {
+                                                          int64_t lo, int64_t hi, uint32_t cap,
+                                                          unsigned int* __restrict__ gcur,
+                                                          unsigned long long* __restrict__ tot,
+                                                          ITEM* __restrict__ out,
+                                                          uint64_t* __restrict__ strag, uint32_t* __restrict__ strag_n) {
+  using R = Ring<ITEM>;
+  constexpr int RP = sizeof(ITEM) == 4 ? 8 : 4;                     // positions per lane and round
   JF_DYN_LDS(s_dyn);
-  uint32_t* s_ring = reinterpret_cast<uint32_t*>(s_dyn);          // [nb][kRingSlots]
+  ITEM* s_ring = reinterpret_cast<ITEM*>(s_dyn);                    // [nb][R::kSlots], then 128 bytes of dump slots
   __shared__ uint64_t s_fwd[8 * 256];
   __shared__ uint32_t s_fill[kGranMaxB];
   __shared__ uint32_t s_nstrag;
@@ -84,133 +214,70 @@ __global__ __launch_bounds__(kPBlock) void p1_ring_kernel(DevTable T, const DevT
   const uint32_t nb = 1u << P.b1;
   const uint32_t t = threadIdx.x, lane = t & 63;
   const bool owner = t < nb;                                       // this lane keeps bucket t's books
-  const uint32_t hole = 0xFFFFFFFFu;
+  const ITEM hole = (ITEM)~(ITEM)0;
   load_tables_lds(s_fwd, T.fwd_tbl, g.nbytes);
-  for(uint32_t j = t; j < nb; j += blockDim.x) s_fill[j] = ((4u * j) & (kRingSlots - 1)) << 16;
-  for(uint32_t j = t * 4; j < nb * kRingSlots; j += blockDim.x * 4) *reinterpret_cast<uint4*>(s_ring + j) = make_uint4(hole, hole, hole, hole);
-  if(t == 0) s_nstrag = 0;
-  const uint32_t dump = nb * kRingSlots + (lane & 31u);            // 32 dwords behind the rings: where the stores of positions without an item go
+  ring_init<ITEM>(s_ring, s_fill, nb, &s_nstrag);
+  const uint32_t dump = nb * R::kSlots + (lane & (R::kSlots - 1));  // behind the rings: where the stores of positions without an item go
   unsigned int* const gshort = gcur + nb;
-  uint64_t* const my_strag = strag + (size_t)blockIdx.x * kStragPerBlock;
+  uint64_t* const my_strag = strag + (size_t)blockIdx.x * kStragPerBlock * R::kWords;
   const uint32_t k = g.k, bshift = g.lsize_l - P.b1;
   const uint32_t rc_shift = 2 * (k - 1);
-  // item = (rest << rem_bits) | rem in 32-bit arithmetic (32-bit items: rest_shift + rem_bits <= 32)
+  // 32-bit items in 32-bit arithmetic: item = (rest << rem_bits) | rem, rest_shift + rem_bits <= 32
   const uint32_t rest_mask = P.rest_shift >= 32 ? 0xFFFFFFFFu : ((1u << P.rest_shift) - 1u);
-  uint32_t gpos = 0, room = 0, nxt = 0, stored = 0;
-  bool nxt_asked = false, exhausted = false;
-  if(owner) { nxt = atomicAdd(&gcur[t], kGran); nxt_asked = true; }
-  uint32_t* const my_region = out + (uint64_t)t * cap;
+  RingBooks B;
+  if(owner) { B.nxt = atomicAdd(&gcur[t], kGran); B.nxt_asked = true; }
+  ITEM* const my_region = out + (uint64_t)t * cap;
   uint32_t my_mers = 0, my_direct = 0;
 
   // not for the rings: on the workgroup's list (p1_stragglers_kernel takes it from there); a full list (an input that
   // sends everything to a few buckets) falls back to the table's global claim on the spot -- slow, never wrong
-  auto straggler = [&](uint32_t b, uint32_t item, uint32_t cnt = 1) {
+  auto straggler = [&](uint32_t b, ITEM item, uint32_t cnt) {
     const uint32_t at = atomicAdd(&s_nstrag, 1u);
-    if(at < kStragPerBlock) my_strag[at] = strag_entry(b, item, cnt);
-    else { item_direct_call(Tmem, P.b2, b, item, cnt, returning); ++my_direct; }
-  };
-
-  // What bucket t has complete goes out.  `all`: the kernel's last call, after a barrier -- every append has landed, and the
-  // partial last unit goes out too (the slots behind its items are holes already).
-  auto flush = [&](bool all) {
-    if(!owner) return;
-    uint32_t w = s_fill[t];
-    uint32_t cnt = w & 0xFFFFu; if(cnt > kRingSlots) cnt = kRingSlots;
-    const uint32_t rb = (w >> 16) & (kRingSlots - 1);
-    uint32_t units = cnt / kRingUnit; if(all && (cnt % kRingUnit)) ++units;
-    uint32_t nout = 0;
-    for(uint32_t s = 0; s < units; ++s) {
-      uint4 v[4];
-      const uint32_t s0 = (rb + s * kRingUnit) & (kRingSlots - 1);
-#pragma unroll
-      for(int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const uint4*>(s_ring + t * kRingSlots + ((s0 + 4 * q) & (kRingSlots - 1)));
-      if(!all) {
-        uint32_t mx = 0;
-#pragma unroll
-        for(int q = 0; q < 4; ++q) { const uint32_t a = v[q].x > v[q].y ? v[q].x : v[q].y, c = v[q].z > v[q].w ? v[q].z : v[q].w; mx = mx > a ? mx : a; mx = mx > c ? mx : c; }
-        if(mx == hole) break;                                      // an item of this unit is still on its way: next time
-      }
-      if(room == 0 && nxt_asked) {                                 // take the reservation asked for earlier
-        if((uint64_t)nxt + kGran <= cap) { gpos = nxt; room = kGran; }
-        else { exhausted = true; if(nxt < cap) atomicMax(&gshort[t], cap - nxt); }       // (everything below nxt was handed out)
-        nxt_asked = false;
-      }
-      if(room == 0 && !exhausted) {                                // none in hand, none asked for: ask now and wait (rare)
-        const uint32_t r0 = atomicAdd(&gcur[t], kGran);
-        if((uint64_t)r0 + kGran <= cap) { gpos = r0; room = kGran; }
-        else { exhausted = true; if(r0 < cap) atomicMax(&gshort[t], cap - r0); }
-      }
-      if(room) {
-        uint32_t* dst = my_region + gpos;
-#pragma unroll
-        for(int q = 0; q < 4; ++q) *reinterpret_cast<uint4*>(dst + 4 * q) = v[q];
-        const uint32_t real = cnt - s * kRingUnit < kRingUnit ? cnt - s * kRingUnit : kRingUnit;
-        gpos += kRingUnit; room -= kRingUnit; stored += real;
-      } else {                                                     // the region is exhausted (skewed input): the list
-#pragma unroll
-        for(int q = 0; q < 4; ++q) {
-          if(v[q].x != hole) straggler(t, v[q].x);
-          if(v[q].y != hole) straggler(t, v[q].y);
-          if(v[q].z != hole) straggler(t, v[q].z);
-          if(v[q].w != hole) straggler(t, v[q].w);
-        }
-      }
-#pragma unroll
-      for(int q = 0; q < 4; ++q) *reinterpret_cast<uint4*>(s_ring + t * kRingSlots + ((s0 + 4 * q) & (kRingSlots - 1))) = make_uint4(hole, hole, hole, hole);
-      ++nout;
-    }
-    // keep one reservation in hand whenever the current one cannot take a ring's worth: its round trip to L2 hides
-    // behind the next round
-    if(!all && !nxt_asked && !exhausted && room < kRingSlots) { nxt = atomicAdd(&gcur[t], kGran); nxt_asked = true; }
-    // the release: ring position past what went out, the count without it -- and without the ghosts
-    uint32_t expect = w;
-    while(nout || (expect & 0xFFFFu) > kRingSlots) {
-      uint32_t c = expect & 0xFFFFu; if(c > kRingSlots) c = kRingSlots;
-      const uint32_t taken = nout * kRingUnit < c ? nout * kRingUnit : c;                 // (`all`: the partial unit takes what is there)
-      const uint32_t neww = ((((expect >> 16) + nout * kRingUnit) & 0xFFFFu) << 16) | (c - taken);
-      const uint32_t old = atomicCAS(&s_fill[t], expect, neww);
-      if(old == expect) break;
-      expect = old;                                                 // somebody appended meanwhile: the same release on the newer word
-    }
+    if(at < kStragPerBlock) strag_store<ITEM>(my_strag + (size_t)at * R::kWords, b, item, cnt);
+    else { item_direct_call(Tmem, P.b2, b, (uint64_t)item, cnt, returning); ++my_direct; }
   };
 
   const int64_t n_tiles = (hi + kPTilePos - 1) / kPTilePos;
-  TileRaw R = tile_fetch(base, (int64_t)blockIdx.x * kPTilePos, lo, hi);
+  TileRaw Rw = tile_fetch(base, (int64_t)blockIdx.x * kPTilePos, lo, hi);
   lds_barrier();                                                   // tables, fill words and holes are in place
   [[maybe_unused]] PhaseClk pc;
   for(int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     lds_barrier();
-    const LaneWords L = tile_stage(R, tile * kPTilePos, lo, hi, s_codes, s_inv);      // barrier inside
-    R = tile_fetch(base, (tile + gridDim.x) * kPTilePos, lo, hi);                      // next tile's bytes travel while this one is worked on
+    const LaneWords L = tile_stage(Rw, tile * kPTilePos, lo, hi, s_codes, s_inv);     // barrier inside
+    Rw = tile_fetch(base, (tile + gridDim.x) * kPTilePos, lo, hi);                     // next tile's bytes travel while this one is worked on
     JF_PHASE(pc, 0);
     const uint32_t adm = BLOOM ? bloom_admit_mask(T.bloom, g, L) : 0xFFFFu;
     uint64_t fw = (((uint64_t)L.p2 << 32) | L.p1) & g.key_mask;
     uint64_t rc = revcomp64(fw, k);
     // which of the lane's 16 positions end a window of k valid bases: the invalid-base bits smeared over the k - 1
-    // positions after them, once per tile (bit 15 - j <-> position j, like inv48); the halo lanes produce nothing
+    // positions after them, once per tile (bit 15 - j <-> position j, like inv48)
     uint64_t smear = L.inv48;
     for(uint32_t s = 1; s < k; ) { const uint32_t step = s < k - s ? s : k - s; smear |= smear >> step; s += step; }
     const uint32_t rawmask = ~(uint32_t)smear & 0xFFFFu;
     const uint32_t vmask = BLOOM ? (rawmask & adm_to_vmask(adm)) : rawmask;
     my_mers += (uint32_t)__popc(rawmask);
+    // a k-mer is emitted one position late, when it is known whether the next one repeats it (homopolymers, tandem
+    // repeats: one entry for the run): pk / pv / run describe the position before
     uint64_t pk = 0; uint32_t pv = 0, run = 0;
 #pragma unroll 1
-    for(int j0 = 0; j0 < kPerLane; j0 += kPerLane / 2) {            // two rounds of eight positions per lane
-      constexpr int NE = kPerLane / 2 + 1;                          // (the +1: the tile's last k-mer, emitted after the loop)
-      // ea: the ring's first dword (bucket * 32), ei: item, eo: fill word before the append.  A position without an item
+    for(int j0 = 0; j0 < kPerLane; j0 += RP) {
+      constexpr int NE = RP + 1;                                    // (the +1: the tile's last k-mer, emitted after the loop)
+      // ea: the ring's first slot (bucket * slots), ei: item, eo: fill word before the append.  A position without an item
       // keeps (dump, 0): the second sweep stores unconditionally, those stores land in the dump slots
-      uint32_t ea[NE], ei[NE], eo[NE];
+      uint32_t ea[NE], eo[NE]; ITEM ei[NE];
 #pragma unroll
       for(int e = 0; e < NE; ++e) { ea[e] = dump; ei[e] = 0; eo[e] = 0; }
       auto emit = [&](int e, uint64_t key, uint32_t cnt) {
         const uint64_t pos = hash_tables_t<NB>(s_fwd, key, g.nbytes);
         const uint32_t b = (uint32_t)(pos >> bshift) & (nb - 1);
-        const uint32_t item = (((uint32_t)pos & rest_mask) << g.rem_bits) | (uint32_t)(key >> g.lsize_g);      // (32-bit items: lsize_g <= 2k <= 42)
+        ITEM item;
+        if constexpr(sizeof(ITEM) == 4) item = (((uint32_t)pos & rest_mask) << g.rem_bits) | (uint32_t)(key >> g.lsize_g);      // (lsize_g <= 2k <= 42)
+        else item = make_item<ITEM>(g, P, key, pos & g.local_mask);
         if(item == hole || cnt > 1) straggler(b, item, cnt);         // (it would read as a hole; a run goes in at once)
-        else { ea[e] = b * kRingSlots; ei[e] = item; eo[e] = atomicAdd(&s_fill[b], 1u); }
+        else { ea[e] = b * R::kSlots; ei[e] = item; eo[e] = atomicAdd(&s_fill[b], 1u); }
       };
 #pragma unroll
-      for(int e = 0; e < kPerLane / 2; ++e) {
+      for(int e = 0; e < RP; ++e) {
         const int j = j0 + e;
         const uint32_t c = (L.cur >> (2 * (15 - j))) & 3u;
         if constexpr(NB >= 5) {
@@ -230,38 +297,29 @@ __global__ __launch_bounds__(kPBlock) void p1_ring_kernel(DevTable T, const DevT
         run = same ? run + 1 : 1;
         pk = key; pv = v;
       }
-      if(j0) { if(pv) emit(NE - 1, pk, run); pv = 0; }
+      if(j0 + RP >= kPerLane) { if(pv) emit(NE - 1, pk, run); pv = 0; }
       // second sweep: the ring stores, once the fill adds are back (not one wait per item), without a branch per item
       uint32_t ghosts = 0;
 #pragma unroll
       for(int e = 0; e < NE; ++e) {
-        const uint32_t full = eo[e] & 0xFFE0u;                       // rank >= 32: the ring is full
+        const uint32_t full = eo[e] & R::kFull;                      // rank >= the ring's size: the ring is full
         ghosts |= full;
-        const uint32_t at = ea[e] + ((eo[e] + (eo[e] >> 16)) & (kRingSlots - 1));
+        const uint32_t at = ea[e] + ((eo[e] + (eo[e] >> 16)) & (R::kSlots - 1));
         s_ring[full ? dump : at] = ei[e];
       }
       if(ghosts) {                                                  // rare: a ghost in its bucket's count until the owner's next release
 #pragma unroll 1
-        for(int e = 0; e < NE; ++e) if(eo[e] & 0xFFE0u) straggler(ea[e] / kRingSlots, ei[e]);
+        for(int e = 0; e < NE; ++e) if(eo[e] & R::kFull) straggler(ea[e] / R::kSlots, ei[e], 1u);
       }
       JF_PHASE(pc, 1);
       lds_barrier();                                               // the round's items have all landed: what is due goes out now
       JF_PHASE(pc, 2);
-      flush(false);
+      if(owner) ring_flush<ITEM>(s_ring, s_fill, t, false, B, my_region, cap, gcur, gshort, straggler);
       JF_PHASE(pc, 3);
     }
   }
   lds_barrier();                                                   // every append of every wave has landed
-  flush(true);
-  if(owner) {
-    // what is left of the reservations becomes holes; the exact count of the bucket goes to tot
-    for(uint32_t r = 0; r < room; ++r) out[(uint64_t)t * cap + gpos + r] = hole;
-    if(nxt_asked) {
-      if((uint64_t)nxt + kGran <= cap) { for(uint32_t r = 0; r < kGran; ++r) out[(uint64_t)t * cap + nxt + r] = hole; }
-      else if(nxt < cap) atomicMax(&gshort[t], cap - nxt);
-    }
-    if(tot && stored) atomicAdd(&tot[t], (unsigned long long)stored);
-  }
+  if(owner) { ring_flush<ITEM>(s_ring, s_fill, t, true, B, my_region, cap, gcur, gshort, straggler); ring_finish<ITEM>(B, t, my_region, cap, gshort, tot); }
   lds_barrier();                                                   // (the final flush may have put items on the list)
   if(t == 0) strag_n[blockIdx.x] = s_nstrag < kStragPerBlock ? s_nstrag : kStragPerBlock;
   JF_PHASE(pc, 4);
@@ -275,27 +333,35 @@ __global__ __launch_bounds__(kPBlock) void p1_ring_kernel(DevTable T, const DevT
 // The straggler lists of a P1 launch, after it: an item takes the next free place of its bucket's region (nobody reserves
 // granules any more, so places are handed out one by one), counted in tot like the others; what cannot be stored in a
 // region -- the region is full, the item reads as a hole, a run of identical k-mers -- is inserted with global atomics
-// (item_direct_call).
-__global__ __launch_bounds__(256) void p1_stragglers_kernel(DevTable T, const DevTable* __restrict__ Tmem, PartGeom P, const uint64_t* __restrict__ strag,
+// (DIRECT: (bucket, item, occurrences), the table's global claim for this key width).
+template <typename ITEM, typename DIRECT>
+__global__ __launch_bounds__(256) void p1_stragglers_kernel(DIRECT D, unsigned long long* __restrict__ ctr_direct, const uint64_t* __restrict__ strag,
                                                             const uint32_t* __restrict__ strag_n, uint32_t n_lists, uint32_t cap,
                                                             unsigned int* __restrict__ gcur, unsigned long long* __restrict__ tot,
-                                                            uint32_t* __restrict__ out, int returning) {
+                                                            ITEM* __restrict__ out) {
+  using R = Ring<ITEM>;
   uint32_t my_direct = 0;
   for(uint32_t l = blockIdx.x; l < n_lists; l += gridDim.x) {
     const uint32_t n = strag_n[l];
-    const uint64_t* rec = strag + (size_t)l * kStragPerBlock;
+    const uint64_t* rec = strag + (size_t)l * kStragPerBlock * R::kWords;
     for(uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-      const uint64_t r = rec[i];
-      const uint32_t item = (uint32_t)r, b = (uint32_t)(r >> 32) & 0xFFFFu, cnt = (uint32_t)(r >> 48);
-      if(cnt == 1 && item != 0xFFFFFFFFu) {
+      uint32_t b, cnt; ITEM item;
+      strag_load<ITEM>(rec + (size_t)i * R::kWords, b, item, cnt);
+      if(cnt == 1 && item != (ITEM)~(ITEM)0) {
         const uint32_t at = atomicAdd(&gcur[b], 1u);
         if(at < cap) { out[(uint64_t)b * cap + at] = item; if(tot) atomicAdd(&tot[b], 1ull); continue; }
       }
-      item_direct_call(Tmem, P.b2, b, item, cnt, returning);
+      D(b, item, cnt);
       ++my_direct;
     }
   }
-  if(my_direct) atomicAdd((unsigned long long*)&T.counters[CTR_DIRECT], (unsigned long long)my_direct);
+  if(my_direct) atomicAdd(ctr_direct, (unsigned long long)my_direct);
 }
+
+// (bucket, item, occurrences) of a one-word key into the table with global atomics (item_direct_call)
+struct OneWordDirect {
+  const DevTable* Tm; uint32_t b2; int returning;
+  __device__ void operator()(uint32_t b, uint64_t item, uint32_t cnt) const { item_direct_call(Tm, b2, b, item, cnt, returning); }
+};
 
 }  // namespace jfgpu

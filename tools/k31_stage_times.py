@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Stage times of a plain k = 31 count (64-bit items, 8-byte slots: the other instantiation of the one-word kernels) at
-5 Gbp into 2^33 slots, next to k = 21 at the same size.  usage: python tools/r03_k31_stage_times.py"""
+5 Gbp into 2^33 slots, next to k = 21 at the same size.  usage: python tools/k31_stage_times.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from jellyfish_amd import capi
