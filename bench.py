@@ -79,6 +79,25 @@ def kernel_sources_sha():
     return h.hexdigest()
 
 
+def release_device(held_bytes=0):
+    """This process's HIP allocations really go back to the driver, and the call returns when the driver is done with them.
+    The amdgpu driver wipes VRAM when it is released, in the background, at about 25 GB/s; a process that allocates while
+    that is going on waits for it -- round 3's end-to-end line charged the CLI's Init 5.4 s for the 165 GB this script had
+    just freed (tools/init_after_parent.py: Init 6.6 s right after the parent's free, 0.2 s after a pause; from a fresh
+    shell 0.2 - 1.1 s, profiles/r04_cli_writing.log).  hipDeviceReset, then wait for the wipe: there is no call to ask
+    the driver, so the wait is the freed bytes at 20 GB/s."""
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipDeviceSynchronize()
+        hip.hipDeviceReset()
+    except OSError:
+        pass
+    wait = min(20.0, held_bytes / 20e9)
+    time.sleep(wait)
+    return {"waited_s": wait, "held_GB": held_bytes / 1e9}
+
+
 def write_fasta(arr, path):
     """(n_reads, READ_LEN + 1) uint8 device-layout reads (bases + one 'N') -> FASTA with one-line records."""
     import numpy as np
@@ -532,6 +551,24 @@ def main():
         out["repeats"] = {"n": len(vals), "kmers_per_s": vals, "median": statistics.median(vals), "min": min(vals), "max": max(vals),
                           "note": "first entry = the contract's timed region (value); the others re-run the identical job after a clear, table digest equal every time"}
 
+    # ---- the CPU-baseline sample counted on the GPU (its digest is compared with the reference's further down; taken here,
+    # while the reads are still in device memory) ----
+    sample_digest = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        b2 = None
+        with capi.Table(K, 1 << 28, canonical=True, device=local_rank) as t2:
+            if cfg == "C3":
+                b2 = capi.Bloom(K, capi.opt_m(0.001, ns * READ_LEN), capi.opt_k(0.001), canonical=True, device=local_rank)
+                b2.insert_ascii_dev(buf, ns * stride)
+                b2.sync()
+                t2.attach_bloom(b2)
+            t2.count_ascii_dev(buf, ns * stride)
+            t2.sync()
+            sample_digest = tuple(t2.digest())
+            t2.attach_bloom(None)
+        if b2 is not None:
+            b2.close()
+
     if rank == 0 and world == 1 and not force_dist and not args.no_extras and cfg == "C2":
         # ---- how much of the rate depends on flushing once: forced flushes inside the job ----
         sweep = {}
@@ -561,21 +598,33 @@ def main():
                         arr[:, READ_LEN] = ord("\n")
                         np.concatenate([hdr, arr], axis=1).tofile(fh)
                 fbytes = os.path.getsize(fa)
-                t.close()                                         # the CLI needs the device memory
-                tim, dg = os.path.join(td, "timing"), os.path.join(td, "digest")
+                t.close()                                         # the CLI needs the device memory ...
+                if bloom is not None:
+                    bloom.close(); bloom = None
+                released = release_device((1 << lsize) * slot_bytes + n_reads * stride * (1 + 2 * 4.3))      # table + reads + workspace
+                tim, dg, outp = os.path.join(td, "timing"), os.path.join(td, "digest"), os.path.join(td, "out.jf")
                 env = dict(os.environ, JFGPU_QUIET="1")
                 t1 = time.perf_counter()
-                subprocess.check_call([cli, "count", "-m", str(K), "-C", "-s", str(1 << lsize), "--no-write", "--timing", tim, "--digest", dg,
+                subprocess.check_call([cli, "count", "-m", str(K), "-C", "-s", str(1 << lsize), "-o", outp, "--timing", tim, "--digest", dg,
                                        "--device", str(local_rank), fa], env=env, preexec_fn=_all_cpus)
                 wall = time.perf_counter() - t1
                 tm = dict(l.split() for l in open(tim).read().splitlines())
                 dgl = tuple(int(l.split()[1]) for l in open(dg).read().splitlines())
                 assert dgl == digest, "CLI run and HBM-resident run disagree: %r vs %r" % (dgl, digest)
-                cs = float(tm["Counting"])
-                out["end_to_end"] = {"parent_affinity_cpus": len(os.sched_getaffinity(0)), "counting_s": cs, "init_s": float(tm["Init"]), "process_wall_s": wall, "file_bytes": fbytes,
-                                     "file_GB_per_s": fbytes / cs / 1e9, "kmers_per_s": total_kmers / cs, "digest_equal_to_resident_run": True,
-                                     "what": "Counting phase (count_main.cc:286->345 equivalent) of `jellyfish-amd count --no-write` on a %.1f GB FASTA file of "
-                                             "the same reads in /dev/shm: host read, host->device copy, device parse, count; PCIe-inclusive, never `value`" % (fbytes / 1e9)}
+                obytes = os.path.getsize(outp)
+                rec_bytes = (2 * K + 7) // 8 + 4
+                hdr_len = 9 + int(open(outp, "rb").read(9))
+                assert obytes == hdr_len + digest[0] * rec_bytes, "output file: %d bytes, expected header %d + %d records of %d bytes" % (obytes, hdr_len, digest[0], rec_bytes)
+                os.unlink(outp)
+                cs, ws = float(tm["Counting"]), float(tm["Writing"])
+                out["end_to_end"] = {"parent_affinity_cpus": len(os.sched_getaffinity(0)), "init_s": float(tm["Init"]), "counting_s": cs, "writing_s": ws, "process_wall_s": wall,
+                                     "file_bytes": fbytes, "file_GB_per_s": fbytes / cs / 1e9, "kmers_per_s": total_kmers / cs,
+                                     "output_bytes": obytes, "output_GB_per_s": obytes / ws / 1e9, "kmers_per_s_wall": total_kmers / wall,
+                                     "digest_equal_to_resident_run": True, "device_released_before": released,
+                                     "what": "`jellyfish-amd count -o <file>` (output ENABLED) from a fresh process on a %.1f GB FASTA file of the same reads in /dev/shm: "
+                                             "Init / Counting / Writing as count_main.cc:375-382 reports them; Counting = host read, host->device copy, device parse, count "
+                                             "(PCIe-inclusive, never `value`); Writing = device sort + copy + %.1f GB of records into one file on /dev/shm (the file system's "
+                                             "single-file write rate is the limit: profiles/r04_cli_writing.log)" % (fbytes / 1e9, obytes / 1e9)}
             t = None
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -583,21 +632,7 @@ def main():
             base, ref_stats = cpu_baseline(cfg, sample, K, td)
         out["cpu_baseline"] = base
         if ref_stats is not None:       # bit-exactness on the very sample the CPU counted: per-k-mer content, not aggregates
-            if t is not None:
-                t.close(); t = None
-            b2 = None
-            with capi.Table(K, 1 << 28, canonical=True, device=local_rank) as t2:
-                if cfg == "C3":
-                    b2 = capi.Bloom(K, capi.opt_m(0.001, ns * READ_LEN), capi.opt_k(0.001), canonical=True, device=local_rank)
-                    b2.insert_ascii_dev(buf, ns * stride)
-                    b2.sync()
-                    t2.attach_bloom(b2)
-                t2.count_ascii_dev(buf, ns * stride)
-                t2.sync()
-                mine = tuple(t2.digest())
-                t2.attach_bloom(None)
-            if b2 is not None:
-                b2.close()
+            mine = sample_digest
             out["cpu_baseline"]["digest_equal_on_sample"] = (mine == tuple(ref_stats))
             out["cpu_baseline"]["sample_digest"] = {"records": mine[0], "total": mine[1], "sum_h": mine[2], "xor_h": mine[3],
                                                     "what": "content digest of the whole table (records, sum of counts, sum and xor of a per-record hash of key words and "
@@ -607,6 +642,7 @@ def main():
     if rank == 0 and world == 1 and cfg == "C2" and not args.no_extras and not args.no_secondary and not args.as_secondary and args.dist == "U":
         if t is not None:
             t.close(); t = None
+        release_device()                                          # the children need the device memory (they are not timed on their Init)
         sec = {}
         # C5, C3: BASELINE configs[4] and [2] on the metric's uniform reads; C2_G, C3_G: the same engine on BASELINE.md's secondary
         # distribution (reads from a 100 Mbp genome, 1 % substitutions, ~100 x coverage), each job run twice with the table

@@ -468,10 +468,15 @@ int count_main(int argc, char* argv[]) {
 
   mer_dna::k(mer_len);
   header.canonical(canonical);
+  // JFGPU_INIT_TRACE=1: where the Init phase goes (stderr)
+  const bool init_trace = getenv("JFGPU_INIT_TRACE") != nullptr;
+  auto init_mark = [&](const char* what) { if(init_trace) std::cerr << "[init] " << seconds_since(start_time) << " s  " << what << "\n"; };
+  init_mark("options parsed");
   std::unique_ptr<mer_hash> ary;
   try {
     ary.reset(new mer_hash(size, mer_len * 2, counter_len, threads, reprobes, canonical, device, out_counter_len, 0, shard_bits, (uint32_t)renv.rank));
   } catch(std::exception& e) { die(std::string("Failed to allocate the hash: ") + e.what()); }
+  init_mark("table created (allocated and cleared)");
   if(disk) ary->do_size_doubling(false);
   if(gpus_given) {
     uint8_t id[128];
@@ -529,11 +534,13 @@ int count_main(int argc, char* argv[]) {
     for(const auto& f : files) { struct stat st; if(stat(f.c_str(), &st) == 0 && S_ISREG(st.st_mode)) { total += (uint64_t)st.st_size; largest = std::max<uint64_t>(largest, st.st_size); } }
     if(gpus_given) { total = total / gpus + ((uint64_t)1 << 20); largest = largest / gpus + ((uint64_t)1 << 20); }   // this rank's part
     if(!host_parse && total > ((uint64_t)64 << 20)) ary->expect_input(std::min<uint64_t>(total, (uint64_t)12 << 30));
+    init_mark("partition workspace reserved");
     if(!host_parse) {
       try { dev_parser.reset(new device_sequence_parser(mer_len, device)); dev_parser->min_quality(min_qual); dev_parser->prepare(largest); }
       catch(std::exception& e) { die(e.what()); }
     }
   }
+  init_mark("feed prepared (pinned buffers, device staging)");
   const double init_s = seconds_since(start_time);
 
   auto count_start = std::chrono::steady_clock::now();

@@ -12,6 +12,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <chrono>
 #include <cmath>
 #include <fstream>
 #include <future>
@@ -98,7 +99,9 @@ public:
       if(!out.good()) { jfgpu_dump_end(ary->handle()); throw ErrorWriting("Error while writing '" + path + "'"); }
       body = (off_t)out.tellp();
       out.close();
-      if(comm && ::truncate(path.c_str(), body + (off_t)(all_records * rec)) != 0) { jfgpu_dump_end(ary->handle()); throw ErrorWriting("Can't size '" + path + "'"); }
+      // the body's size is known (fixed-width records, counted by jfgpu_dump_begin): the file is sized now, every rank and every
+      // writer thread then fills its own part of it
+      if(::truncate(path.c_str(), body + (off_t)(all_records * rec)) != 0 && comm) { jfgpu_dump_end(ary->handle()); throw ErrorWriting("Can't size '" + path + "'"); }
     }
     if(comm) {                                                 // where the body starts; also: the file exists from here on
       std::vector<uint64_t> bodies(world);
@@ -117,16 +120,30 @@ public:
     } bufs[2] = {pinned(cap * rec), pinned(cap * rec)};
     const int fd = ::open(path.c_str(), O_WRONLY);
     if(fd < 0) { jfgpu_dump_end(ary->handle()); throw ErrorWriting("Can't reopen '" + path + "' for writing"); }
+    // Where the Writing phase goes (profiles/r04_cli_writing.log, JFGPU_DUMP_TRACE=1): the device delivers sorted records at
+    // 21 GB/s (sort + copy to pinned memory); ONE file on tmpfs takes 4.5 - 6.8 GB/s whatever is tried from user space --
+    // write() / pwrite() hold the file's inode lock for the whole call (one thread 6.8 GB/s, four or sixteen 4.0 - 4.4
+    // between them), stores into a shared mapping fault page by page under per-inode accounting (fresh pages 3.7 - 5.9,
+    // pages made by fallocate() ahead of the stores no better inside this process); tools/probes/tmpfs_write_probe.cc.
+    // So: two pwrite() streams (one would idle while its chunk is replaced), which is what the file system gives.
     std::vector<std::future<bool>> pending[2];
     auto drain = [&](int b) { bool ok = true; for(auto& f : pending[b]) ok = f.get() && ok; pending[b].clear(); return ok; };
-    const unsigned nw = std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2));
+    unsigned nw = 2;
+    if(const char* e = getenv("JFGPU_DUMP_WRITERS")) nw = (unsigned)std::max(1, atoi(e));
     uint64_t written = 0;
     bool ok = true;
+    // JFGPU_DUMP_TRACE=1: where the Writing phase goes (waiting for the file writers / for the device's next chunk)
+    const bool trace = getenv("JFGPU_DUMP_TRACE") != nullptr;
+    double t_drain = 0, t_next = 0;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     try {
       for(int b = 0;; b ^= 1) {
+        const double a0 = now();
         ok = drain(b) && ok;                                   // this buffer's previous slices are on their way to disk
+        const double a1 = now();
         uint64_t got = 0;
         jf_check(jfgpu_dump_next(ary->handle(), bufs[b].data(), cap, &got));
+        t_drain += a1 - a0; t_next += now() - a1;
         if(!got) break;
         const size_t bytes = got * rec, per = (bytes / nw + 4095) / 4096 * 4096 + 4096;
         for(size_t o = 0; o < bytes; o += per) {
@@ -145,7 +162,11 @@ public:
         }
         written += got;
       }
+      const double a0 = now();
       ok = drain(0) && ok; ok = drain(1) && ok;
+      t_drain += now() - a0;
+      if(trace) std::cerr << "[dump] " << written << " records of " << rec << " bytes: " << t_next << " s in jfgpu_dump_next (device sort + copy), " << t_drain
+                          << " s waiting for " << nw << " file writers\n";
     } catch(...) { drain(0); drain(1); ::close(fd); jfgpu_dump_end(ary->handle()); throw; }
     ::close(fd);
     jf_check(jfgpu_dump_end(ary->handle()));
