@@ -305,27 +305,59 @@ public:
     }
   }
 
+  // Where is `key` in the body?  Records ascend by (pos, key) and the positions of hashed keys are uniform, so the record
+  // number is guessed from the position (one interpolation over the whole file), the guess is widened by doubling steps
+  // until it brackets the key, and the bracket is bisected.  (Same file order as the reference's binary_query relies on,
+  // binary_dumper.hpp:147-189; its search re-interpolates inside a shrinking window and ends in a linear scan.)
   bool val_id(const mer_dna& key, uint64_t* res, uint64_t* id) const {
     if(last_id_ == 0) return false;
-    uint64_t first = 0, last = last_id_, first_pos = first_pos_, last_pos = last_pos_;
     const uint64_t pos = key_pos(key);
-    uint64_t cid = 0;
-    if(key == first_key_) { *res = val_at(0); *id = 0; return true; }
-    cid = last_id_ - 1;
-    if(key == last_key_) { *res = val_at(cid); *id = cid; return true; }
     if(pos < first_pos_ || pos > last_pos_) return false;
-    for(uint64_t diff = last - first; diff >= 8; diff = last - first) {
-      cid = first + (uint64_t)lrint(diff * ((double)(pos - first_pos) / (double)(last_pos - first_pos)));
-      cid = std::max(first + 1, cid);
-      cid = std::min(cid, last - 1);
-      const mer_dna mid = key_at(cid);
-      if(key == mid) { *res = val_at(cid); *id = cid; return true; }
-      const uint64_t mid_pos = key_pos(mid);
-      if(mid_pos > pos || (mid_pos == pos && mid > key)) { last = cid; last_pos = mid_pos; }
-      else { first = cid; first_pos = mid_pos; }
+    // -1 / 0 / +1: record i sorts before / is / sorts after the key
+    auto side = [&](uint64_t i) -> int {
+      const mer_dna m = key_at(i);
+      if(m == key) return 0;
+      const uint64_t p = key_pos(m);
+      return (p < pos || (p == pos && m < key)) ? -1 : 1;
+    };
+    auto found = [&](uint64_t i) { *res = val_at(i); *id = i; return true; };
+    const uint64_t n = last_id_;
+    uint64_t guess = last_pos_ > first_pos_ ? (uint64_t)((long double)(n - 1) * (long double)(pos - first_pos_) / (long double)(last_pos_ - first_pos_)) : 0;
+    if(guess >= n) guess = n - 1;
+    int s = side(guess);
+    if(s == 0) return found(guess);
+    uint64_t lo, hi;                                          // the key, if present, is a record of the open interval (lo, hi) -- lo may be "before 0", hi == n "after the last"
+    bool lo_open = false;
+    if(s < 0) {                                               // the guess is before the key: gallop upwards
+      lo = guess; hi = n;
+      for(uint64_t step = 1; lo + step < n; step <<= 1) {
+        const int t = side(lo + step);
+        if(t == 0) return found(lo + step);
+        if(t > 0) { hi = lo + step; break; }
+        lo += step;
+      }
+    } else {                                                  // after the key: gallop downwards
+      hi = guess; lo = 0; lo_open = true;
+      for(uint64_t step = 1; hi >= step; step <<= 1) {
+        const int t = side(hi - step);
+        if(t == 0) return found(hi - step);
+        if(t < 0) { lo = hi - step; lo_open = false; break; }
+        hi -= step;
+      }
+      if(lo_open) {                                           // ran off the front: record 0 is still unseen when hi > 0
+        if(hi == 0) return false;
+        const int t = side(0);
+        if(t == 0) return found(0);
+        if(t > 0) return false;
+        lo = 0;
+      }
     }
-    for(cid = first + 1; cid < last; ++cid)
-      if(key == key_at(cid)) { *res = val_at(cid); *id = cid; return true; }
+    while(hi - lo > 1) {
+      const uint64_t mid = lo + (hi - lo) / 2;
+      const int t = side(mid);
+      if(t == 0) return found(mid);
+      if(t < 0) lo = mid; else hi = mid;
+    }
     return false;
   }
   uint64_t operator[](const mer_dna& key) const { uint64_t r, id; return val_id(key, &r, &id) ? r : 0; }
