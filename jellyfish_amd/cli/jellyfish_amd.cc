@@ -453,7 +453,7 @@ int count_main(int argc, char* argv[]) {
   uint32_t shard_bits = 0;
   if(gpus_given) {
     if(gpus < 1 || (gpus & (gpus - 1)) || gpus > 256) die("--gpus must be a power of two");
-    if(mer_len > 32) die("--gpus: sharded tables for mer length > 32 are not built yet");
+    if(mer_len > 64) die("--gpus: sharded tables for mer length > 64 are not built yet");
     if(!if_files.empty() || !bc_path.empty() || bf_size_given || disk || text || host_parse || !generator.empty())
       die("--gpus cannot be combined with --if, --bc, --bf-size, --disk, --text, --host-parse or -g yet");
     renv = read_rank_env();

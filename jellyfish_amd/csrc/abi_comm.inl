@@ -56,11 +56,14 @@ struct jfgpu_comm {
     // k-mers per input byte seen so far (sizes the regions)
     uint32_t icap[2] = {0, 0};
     unsigned int* d_gcur = nullptr;              // gcur[2 * 1024] (u32) then tot[1024] (u64)
-    std::vector<uint64_t> claims;
     unsigned long long* d_claimed = nullptr;     // k-mers the senders said they sent here (item path), summed on the device
     unsigned long long* d_arrived = nullptr;     // [2]: k-mers the receive side actually found in what arrived (regions split + direct inserts + stragglers kept); scratch word
     double ipb = 0;
     uint64_t strag_seen = 0;
+    uint64_t* d_route = nullptr;                 // [2] items stored / stragglers of the routing pass in flight
+    uint64_t* h_route = nullptr;                 // ... pinned copy, read after route_done
+    hipEvent_t route_done = nullptr;
+    size_t route_n = 0;                          // its input bytes
   };
 #if !defined(JFGPU_EMU)
   // "ipc" transport (see the head of this file)
@@ -104,6 +107,9 @@ int comm_init_rank(jfgpu_comm* c, jfgpu_comm::Rank& R) {
   HIP_TRY(hipMemset(R.d_claimed, 0, 8));
   HIP_TRY(hipMalloc((void**)&R.d_arrived, 16));
   HIP_TRY(hipMemset(R.d_arrived, 0, 16));
+  HIP_TRY(hipMalloc((void**)&R.d_route, 2 * sizeof(uint64_t)));
+  HIP_TRY(hipHostMalloc((void**)&R.h_route, 2 * sizeof(uint64_t), hipHostMallocDefault));
+  HIP_TRY(hipEventCreateWithFlags(&R.route_done, hipEventDisableTiming));
   return JFGPU_OK;
 }
 
@@ -166,13 +172,32 @@ uint32_t items_cap_wanted(const jfgpu_comm* c, const jfgpu_comm::Rank& R, size_t
   return (uint32_t)cap;
 }
 
-// P1 over the global table into send[cur]; the host waits once (stragglers, exact item count).  *overflow: more
-// stragglers than the list holds -- the step has to be redone with keys.
-int comm_route_items(jfgpu_comm* c, jfgpu_comm::Rank& R, const char* d_bases, size_t n, uint32_t cap, bool* overflow, uint64_t* routed) {
+// What every owner is being sent by this rank (its regions' items + its stragglers), written where the exchange takes it
+// from (claims[W] of the send buffer), and the two numbers the host wants back (items stored, stragglers): on the device,
+// so that the host has nothing to compute between the routing kernel and the exchange.
+__global__ __launch_bounds__(1024) void comm_claims_kernel(const unsigned long long* __restrict__ tot, uint32_t nbg, uint32_t nbc, const uint64_t* __restrict__ strag,
+                                                            uint32_t S, uint32_t world, uint64_t* __restrict__ claims, uint64_t* __restrict__ summary) {
+  __shared__ unsigned long long s_claims[512];
+  __shared__ unsigned long long s_stored;
+  for(uint32_t p = threadIdx.x; p < world; p += blockDim.x) s_claims[p] = 0;
+  if(threadIdx.x == 0) s_stored = 0;
+  lds_barrier();
+  for(uint32_t j = threadIdx.x; j < nbg; j += blockDim.x) { const unsigned long long v = tot[j]; if(v) { atomicAdd(&s_claims[j / nbc], v); atomicAdd(&s_stored, v); } }
+  const uint64_t ns = strag[0];
+  const uint64_t nl = ns < S ? ns : S;
+  for(uint64_t i = threadIdx.x; i < nl; i += blockDim.x) atomicAdd(&s_claims[(uint32_t)(strag[1 + i] >> 32) / nbc], 1ull);
+  lds_barrier();
+  for(uint32_t p = threadIdx.x; p < world; p += blockDim.x) claims[p] = s_claims[p];
+  if(threadIdx.x == 0) { summary[0] = s_stored; summary[1] = ns; }
+}
+
+// P1 over the global table into send[cur]: enqueued here, looked at in comm_route_items_complete -- between the two the
+// caller enqueues the insert of what arrived for the previous step, so the device has work while the host waits for the
+// two numbers it needs (stragglers, exact item count).
+int comm_route_items_enqueue(jfgpu_comm* c, jfgpu_comm::Rank& R, const char* d_bases, size_t n, uint32_t cap) {
   jfgpu_table* t = R.t;
   const int cur = R.turn;
   const ItemLayout L = item_layout(c, t, cap);
-  *overflow = false; *routed = 0;
   if(R.used[cur]) HIP_TRY(hipEventSynchronize(R.exchanged[cur]));       // send[cur] has left (step - 2)
   int rc = comm_reserve(R.send[cur], R.send_cap[cur], (L.send_bytes + 7) / 8, t->stream, c->xstream); if(rc) return rc;
   if(!R.used[cur ^ 1]) { rc = comm_reserve(R.send[cur ^ 1], R.send_cap[cur ^ 1], (L.send_bytes + 7) / 8, t->stream, c->xstream); if(rc) return rc; }   // (both buffers of the pair at once)
@@ -200,28 +225,27 @@ int comm_route_items(jfgpu_comm* c, jfgpu_comm::Rank& R, const char* d_bases, si
 #undef PR
   }
   hipLaunchKernelGGL(granule_finish_kernel, dim3(4), dim3(256), 0, t->stream, R.d_gcur, cap, L.nbg, offs);
+  hipLaunchKernelGGL(comm_claims_kernel, dim3(1), dim3(1024), 0, t->stream, tot, L.nbg, L.nbc, (const uint64_t*)strag, L.S, (uint32_t)c->world,
+                     reinterpret_cast<uint64_t*>(sb + L.claims_at), R.d_route);
   HIP_TRY(hipGetLastError());
-  std::vector<uint64_t> h(1024 + 1, 0);
-  HIP_TRY(hipMemcpyAsync(h.data(), tot, (size_t)L.nbg * 8, hipMemcpyDeviceToHost, t->stream));
-  HIP_TRY(hipMemcpyAsync(h.data() + 1024, strag, 8, hipMemcpyDeviceToHost, t->stream));
-  HIP_TRY(hipStreamSynchronize(t->stream));
-  uint64_t stored = 0; for(int j = 0; j < 1024; ++j) stored += h[j];
-  if(h[1024] > L.S) { *overflow = true; return JFGPU_OK; }
-  if(n >= ((size_t)1 << 20)) R.ipb = (double)(stored + h[1024]) / (double)n;
-  // what every owner is being sent (regions + its stragglers): travels with the regions, summed up by the receivers
-  R.claims.assign(c->world, 0);
-  for(uint32_t j = 0; j < L.nbg; ++j) R.claims[j / L.nbc] += h[j];
-  if(h[1024]) {
-    std::vector<uint64_t> lst(h[1024]);
-    HIP_TRY(hipMemcpyAsync(lst.data(), strag + 1, h[1024] * 8, hipMemcpyDeviceToHost, t->stream));
-    HIP_TRY(hipStreamSynchronize(t->stream));
-    for(uint64_t r : lst) R.claims[(uint32_t)(r >> 32) / L.nbc] += 1;
-  }
-  HIP_TRY(hipMemcpyAsync(sb + L.claims_at, R.claims.data(), (size_t)c->world * 8, hipMemcpyHostToDevice, t->stream));
-  HIP_TRY(hipStreamSynchronize(t->stream));                 // (R.claims is reused by the next step)
-  *routed = stored + h[1024];
+  HIP_TRY(hipMemcpyAsync(R.h_route, R.d_route, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, t->stream));
+  HIP_TRY(hipEventRecord(R.route_done, t->stream));
+  R.route_n = n;
+  return JFGPU_OK;
+}
+
+// *overflow: more stragglers than the list holds -- the step has to be redone with keys.
+int comm_route_items_complete(jfgpu_comm* c, jfgpu_comm::Rank& R, uint32_t cap, bool* overflow, uint64_t* routed) {
+  jfgpu_table* t = R.t;
+  const ItemLayout L = item_layout(c, t, cap);
+  *overflow = false; *routed = 0;
+  HIP_TRY(hipEventSynchronize(R.route_done));
+  const uint64_t stored = R.h_route[0], ns = R.h_route[1];
+  if(ns > L.S) { *overflow = true; return JFGPU_OK; }
+  if(R.route_n >= ((size_t)1 << 20)) R.ipb = (double)(stored + ns) / (double)R.route_n;
+  *routed = stored + ns;
   if(t->tun.flush_trace)
-    fprintf(stderr, "[comm] item path: %zu bytes -> %llu items in %u regions of %u, %llu stragglers\n", n, (unsigned long long)stored, L.nbg, cap, (unsigned long long)h[1024]);
+    fprintf(stderr, "[comm] item path: %zu bytes -> %llu items in %u regions of %u, %llu stragglers\n", R.route_n, (unsigned long long)stored, L.nbg, cap, (unsigned long long)ns);
   return JFGPU_OK;
 }
 
@@ -338,13 +362,14 @@ int comm_route(jfgpu_comm* c, jfgpu_comm::Rank& R, const char* d_bases, size_t n
   jfgpu_table* t = R.t;
   const int cur = R.turn, W = c->world;
   if((int)(1u << t->g.shard_bits) != W) return fail(JFGPU_E_INVALID, "table shard_bits does not match the communicator's world size");
-  if(t->wide || t->nword) return fail(JFGPU_E_UNSUPPORTED, "sharded tables with mer length > 32 are not built yet");
+  if(t->nword) return fail(JFGPU_E_UNSUPPORTED, "sharded tables with mer length > 64 are not built yet");
+  const uint64_t kw = t->wide ? 2 : 1;                                   // 64-bit words per routed k-mer (counts and offsets below are in words)
   if(R.used[cur]) HIP_TRY(hipEventSynchronize(R.exchanged[cur]));       // send[cur] has left (step - 2)
   std::fill(R.scount[cur].begin(), R.scount[cur].end(), 0);
   std::fill(R.soff[cur].begin(), R.soff[cur].end(), 0);
   if(n < t->g.k) return JFGPU_OK;
-  int rc = comm_reserve(R.send[cur], R.send_cap[cur], n, t->stream, c->xstream); if(rc) return rc;
-  if(!R.used[cur ^ 1]) { rc = comm_reserve(R.send[cur ^ 1], R.send_cap[cur ^ 1], n, t->stream, c->xstream); if(rc) return rc; }   // (both buffers of the pair at once)
+  int rc = comm_reserve(R.send[cur], R.send_cap[cur], n * kw, t->stream, c->xstream); if(rc) return rc;
+  if(!R.used[cur ^ 1]) { rc = comm_reserve(R.send[cur ^ 1], R.send_cap[cur ^ 1], n * kw, t->stream, c->xstream); if(rc) return rc; }   // (both buffers of the pair at once)
   const uint8_t* base; int64_t lo, hi;
   align_buffer(d_bases, n, base, lo, hi);
   const int64_t n_tiles = (hi + kTilePos - 1) / kTilePos;
@@ -352,18 +377,20 @@ int comm_route(jfgpu_comm* c, jfgpu_comm::Rank& R, const char* d_bases, size_t n
   HIP_TRY(hipMemsetAsync(R.d_cnt, 0, sizeof(unsigned long long) * W, t->stream));
   {
     ProfScope ps(t, 2, n);
-    hipLaunchKernelGGL(partition_count_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, base, lo, hi, R.d_cnt);
+    if(t->wide) hipLaunchKernelGGL(partition_count_wide_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->wt, base, lo, hi, R.d_cnt);
+    else hipLaunchKernelGGL(partition_count_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, base, lo, hi, R.d_cnt);
   }
   std::vector<unsigned long long> h(W);
   HIP_TRY(hipMemcpyAsync(h.data(), R.d_cnt, sizeof(unsigned long long) * W, hipMemcpyDeviceToHost, t->stream));
   HIP_TRY(hipStreamSynchronize(t->stream));
   uint64_t total = 0;
-  for(int p = 0; p < W; ++p) { R.scount[cur][p] = h[p]; R.soff[cur][p] = total; total += h[p]; h[p] = R.soff[cur][p]; }
-  R.soff[cur][W] = total;
+  for(int p = 0; p < W; ++p) { R.scount[cur][p] = h[p] * kw; R.soff[cur][p] = total * kw; const uint64_t first = total; total += h[p]; h[p] = first; }      // (cursors in k-mers, messages in words)
+  R.soff[cur][W] = total * kw;
   HIP_TRY(hipMemcpyAsync(R.d_cnt, h.data(), sizeof(unsigned long long) * W, hipMemcpyHostToDevice, t->stream));   // cursors = offsets
   {
     ProfScope ps(t, 2, 0);
-    hipLaunchKernelGGL(partition_scatter_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, base, lo, hi, R.d_cnt, R.send[cur]);
+    if(t->wide) hipLaunchKernelGGL(partition_scatter_wide_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->wt, base, lo, hi, R.d_cnt, R.send[cur]);
+    else hipLaunchKernelGGL(partition_scatter_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, base, lo, hi, R.d_cnt, R.send[cur]);
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(t->stream));       // the host vector h is read by the copy above
@@ -379,7 +406,7 @@ int comm_insert_prev(jfgpu_comm* c, jfgpu_comm::Rank& R) {
   if(R.icap[prev]) return comm_insert_prev_items(c, R, c->local ? (int)(&R - c->ranks.data()) : c->rank);
   jfgpu_table* t = R.t;
   HIP_TRY(hipStreamWaitEvent(t->stream, R.exchanged[prev], 0));
-  const uint64_t n = R.roff[prev][c->world];
+  const uint64_t n = R.roff[prev][c->world] / (t->wide ? 2 : 1);          // k-mers that arrived (the offsets are in words)
   int rc = JFGPU_OK;
   if(n) rc = add_keys_piece(t, R.recv[prev], (size_t)n, 1, nullptr);
   HIP_TRY(hipEventRecord(R.consumed[prev], t->stream));
@@ -796,6 +823,9 @@ void comm_free_rank(jfgpu_comm::Rank& R) {
   if(R.d_gcur) hipFree(R.d_gcur);
   if(R.d_claimed) hipFree(R.d_claimed);
   if(R.d_arrived) hipFree(R.d_arrived);
+  if(R.d_route) hipFree(R.d_route);
+  if(R.h_route) hipHostFree(R.h_route);
+  if(R.route_done) hipEventDestroy(R.route_done);
 }
 
 }  // namespace
@@ -899,9 +929,13 @@ int jfgpu_comm_count_ascii_dev(jfgpu_comm* c, jfgpu_table* t, const char* d_base
   uint32_t cap = v[0] ? 0u : (uint32_t)v[1];
   IPC_TRACE(c, "step: agreed cap %u (0: keys)", cap);
   uint64_t routed = 0;
+  // the routing of this step is enqueued, then the insert of what arrived for the previous one (it only waits for that
+  // step's exchange, on the device): the host's look at the routing pass and the agreement below happen beside device work
+  if(cap) { rc = comm_route_items_enqueue(c, R, d_bases, n, cap); if(rc) return rc; }
+  rc = comm_insert_prev(c, R); if(rc) return rc;
   if(cap) {
     bool overflow = false;
-    rc = comm_route_items(c, R, d_bases, n, cap, &overflow, &routed); if(rc) return rc;
+    rc = comm_route_items_complete(c, R, cap, &overflow, &routed); if(rc) return rc;
     IPC_TRACE(c, "step: routed %llu items%s", (unsigned long long)routed, overflow ? " (straggler list overflow)" : "");
     uint64_t o = overflow ? 1 : 0;
     rc = jfgpu_comm_allreduce_u64(c, &o, 1, 1); if(rc) return rc;
@@ -913,8 +947,6 @@ int jfgpu_comm_count_ascii_dev(jfgpu_comm* c, jfgpu_table* t, const char* d_base
     rc = comm_route(c, R, d_bases, n); if(rc) return rc;
     rc = c->ipc ? comm_exchange_ipc(c) : comm_exchange_rccl(c); if(rc) return rc;
   }
-  IPC_TRACE(c, "step: exchanged, inserting the previous step's");
-  rc = comm_insert_prev(c, R); if(rc) return rc;            // overlaps with the exchange just enqueued
   IPC_TRACE(c, "step: done");
   R.inflight = true; R.turn ^= 1;
   return JFGPU_OK;
@@ -935,12 +967,15 @@ int jfgpu_comm_local_step(jfgpu_comm* c, jfgpu_table** tables, const char* const
     want_max = std::max(want_max, w);
   }
   if(cap) cap = want_max;                                  // (0 when nobody has input: the key path with nothing to send)
+  // (same order as the RCCL step: routing enqueued, the previous step's insert enqueued, then the host's look at the routing)
+  if(cap) for(int r = 0; r < c->world; ++r) { int rc = comm_route_items_enqueue(c, c->ranks[r], d_bases[r], n[r], cap); if(rc) return rc; }
+  for(int r = 0; r < c->world; ++r) { int rc = comm_insert_prev(c, c->ranks[r]); if(rc) return rc; }
   if(cap) {
     bool any_overflow = false;
     std::vector<uint64_t> routed(c->world, 0);
     for(int r = 0; r < c->world; ++r) {
       bool overflow = false;
-      int rc = comm_route_items(c, c->ranks[r], d_bases[r], n[r], cap, &overflow, &routed[r]); if(rc) return rc;
+      int rc = comm_route_items_complete(c, c->ranks[r], cap, &overflow, &routed[r]); if(rc) return rc;
       any_overflow = any_overflow || overflow;
     }
     if(any_overflow) cap = 0;
@@ -954,10 +989,7 @@ int jfgpu_comm_local_step(jfgpu_comm* c, jfgpu_table** tables, const char* const
     rc = comm_exchange_local(c);
   }
   if(rc) return rc;
-  for(int r = 0; r < c->world; ++r) {
-    rc = comm_insert_prev(c, c->ranks[r]); if(rc) return rc;
-    c->ranks[r].inflight = true; c->ranks[r].turn ^= 1;
-  }
+  for(int r = 0; r < c->world; ++r) { c->ranks[r].inflight = true; c->ranks[r].turn ^= 1; }
   return JFGPU_OK;
 }
 

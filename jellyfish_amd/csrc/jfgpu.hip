@@ -558,7 +558,7 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
   *out = nullptr;
   if(p->k < 1) return fail(JFGPU_E_INVALID, "mer length must be >= 1");
   if(p->k > 128) return fail(JFGPU_E_UNSUPPORTED, "mer length > 128 (more than four key words) is not built");
-  if(p->k > 32 && p->shard_bits) return fail(JFGPU_E_UNSUPPORTED, "sharded tables with mer length > 32 are not built yet");
+  if(p->k > 64 && p->shard_bits) return fail(JFGPU_E_UNSUPPORTED, "sharded tables with mer length > 64 are not built yet");
   if(p->shard_bits > 8) return fail(JFGPU_E_INVALID, "at most 256 shards");
   if(p->shard_id >= (1u << p->shard_bits)) return fail(JFGPU_E_INVALID, "shard_id out of range");
   int ndev = 0;
@@ -578,6 +578,7 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     lsize = std::min<uint32_t>(lsize, 48);
   } else if(wide) {
     lsize = std::max(lsize, wide_min_lsize(p->k));
+    lsize = std::max<uint32_t>(lsize, kMaxTileBits + p->shard_bits);       // a shard holds at least one tile
     lsize = std::min<uint32_t>(lsize, 48);
   } else {
     lsize = std::max(lsize, geom_min_lsize(p->k, p->shard_bits));
@@ -599,7 +600,7 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     if(!nword_geom_init(t->nt.N, p->k, lsize, p->canonical ? 1 : 0)) return fail(JFGPU_E_INVALID, "table geometry does not fit a 256-bit slot");
     t->g = t->nt.N.g;
   } else if(wide) {
-    if(!wide_geom_init(t->wt.W, p->k, lsize, p->canonical ? 1 : 0)) return fail(JFGPU_E_INVALID, "table geometry does not fit a 128-bit slot");
+    if(!wide_geom_init(t->wt.W, p->k, lsize, p->canonical ? 1 : 0, p->shard_bits, p->shard_id)) return fail(JFGPU_E_INVALID, "table geometry does not fit a 128-bit slot");
     t->g = t->wt.W.g;
   } else if(!geom_init(t->g, p->k, lsize, p->shard_bits, p->shard_id, p->canonical ? 1 : 0, !t->tun.slot64))
     return fail(JFGPU_E_INVALID, "table geometry does not fit a 64-bit slot");

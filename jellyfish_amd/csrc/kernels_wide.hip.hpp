@@ -27,10 +27,12 @@ struct WideGeom {
   u128 key_mask;
 };
 
-inline bool wide_geom_init(WideGeom& W, uint32_t k, uint32_t lsize_g, uint32_t canonical) {
+// shard_bits / shard_id: one shard of a table spread over GPUs (the shard owns the global positions whose top shard_bits
+// bits are shard_id, like the one-word geometry: kmer_core.hpp).
+inline bool wide_geom_init(WideGeom& W, uint32_t k, uint32_t lsize_g, uint32_t canonical, uint32_t shard_bits = 0, uint32_t shard_id = 0) {
   TableGeom& g = W.g;
-  if(k < 33 || k > 64 || lsize_g > 63 || lsize_g < kMaxTileBits) return false;
-  g.k = k; g.key_bits = 2 * k; g.lsize_g = g.lsize_l = lsize_g; g.shard_bits = 0; g.shard_id = 0;
+  if(k < 33 || k > 64 || lsize_g > 63 || shard_bits > lsize_g || lsize_g - shard_bits < kMaxTileBits) return false;
+  g.k = k; g.key_bits = 2 * k; g.lsize_g = lsize_g; g.lsize_l = lsize_g - shard_bits; g.shard_bits = shard_bits; g.shard_id = shard_id;
   g.tile_bits = kMaxTileBits; g.slot32 = 0; g.pad_ = 0;
   g.rem_bits = g.key_bits - lsize_g;
   W.tag_full = g.tile_bits + g.rem_bits;
@@ -107,7 +109,7 @@ __device__ inline u128 wide_slot_key(const WideTable& T, const uint64_t* inv_tbl
   const u128 tag = ((u128)(hi & (W.g.occ_bit - 1)) << 63) | (lo >> 1);
   const u128 rem = tag & ((((u128)1) << W.g.rem_bits) - 1);
   const uint64_t idx0 = (uint64_t)(tag >> W.g.rem_bits);
-  const uint64_t pos = tile_base | idx0;
+  const uint64_t pos = ((uint64_t)W.g.shard_id << W.g.lsize_l) | tile_base | idx0;
   const u128 v = (rem << W.g.lsize_g) | pos;
   const uint64_t low_bits = hash_tables_wide(inv_tbl, v, W.g.nbytes);
   return (rem << W.g.lsize_g) | low_bits;
@@ -119,6 +121,7 @@ __device__ inline bool wide_add(const WideTable& T, const uint64_t* fwd_lds, u12
   const TableGeom& g = T.W.g;
   const uint64_t pos = hash_tables_wide(fwd_lds, key, g.nbytes);
   const SlotAddr a = slot_addr(g, pos);
+  if(a.shard != g.shard_id) { atomicAdd((unsigned long long*)&T.counters[CTR_MISROUTED], 1ull); return false; }      // not ours: never silently inserted
   const WideSlot w = wide_words(T.W, key, a.idx0);
   const uint64_t add = cnt << (g.tag_bits + 1);
   const uint32_t tmask = (uint32_t)g.tile_mask;
@@ -486,6 +489,64 @@ __global__ __launch_bounds__(kBlock) void dump_tiles_wide_kernel(WideTable T, ui
       for(uint32_t b = 0; b < key_bytes; ++b) dd[b] = (uint8_t)(key >> (8 * b));
       for(uint32_t b = 0; b < val_bytes; ++b) dd[key_bytes + b] = (uint8_t)(cnt >> (8 * b));
     }
+  }
+}
+
+// ---- multi-GPU: a contract buffer's two-word k-mers grouped by owner (abi_comm.inl, key path) -------------------------
+// The two passes of kernels.hip.hpp's partition_count / partition_scatter kernels for 128-bit keys: out receives two
+// 64-bit words per k-mer (low word first: what add_keys takes), counts and cursors are in k-mers.
+__global__ __launch_bounds__(kBlock) void partition_count_wide_kernel(WideTable T, const uint8_t* __restrict__ base, int64_t lo, int64_t hi,
+                                                                      unsigned long long* __restrict__ shard_counts) {
+  __shared__ uint64_t s_fwd[16 * 256];
+  __shared__ uint32_t s_codes[kBlock + 4];
+  __shared__ uint32_t s_inv[kBlock + 4];
+  __shared__ uint32_t s_hist[256];
+  load_tables_lds(s_fwd, T.fwd_tbl, T.W.g.nbytes);
+  const uint32_t n_shards = 1u << T.W.g.shard_bits;
+  for(uint32_t i = threadIdx.x; i < n_shards; i += blockDim.x) s_hist[i] = 0;
+  const int64_t n_tiles = (hi + kTilePos - 1) / kTilePos;
+  for(int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    __syncthreads();
+    const LaneWordsW L = stage_tile_wide(base, tile * kTilePos, lo, hi, s_codes, s_inv);
+    for_each_kmer_wide(T.W, L, [&](int, u128 key) {
+      const uint64_t pos = hash_tables_wide(s_fwd, key, T.W.g.nbytes);
+      atomicAdd(&s_hist[(uint32_t)(pos >> T.W.g.lsize_l)], 1u);
+    });
+  }
+  __syncthreads();
+  for(uint32_t i = threadIdx.x; i < n_shards; i += blockDim.x)
+    if(s_hist[i]) atomicAdd(&shard_counts[i], (unsigned long long)s_hist[i]);
+}
+
+__global__ __launch_bounds__(kBlock) void partition_scatter_wide_kernel(WideTable T, const uint8_t* __restrict__ base, int64_t lo, int64_t hi,
+                                                                        unsigned long long* __restrict__ cursors, uint64_t* __restrict__ out) {
+  __shared__ uint64_t s_fwd[16 * 256];
+  __shared__ uint32_t s_codes[kBlock + 4];
+  __shared__ uint32_t s_inv[kBlock + 4];
+  __shared__ uint32_t s_hist[256];
+  __shared__ unsigned long long s_base[256];
+  load_tables_lds(s_fwd, T.fwd_tbl, T.W.g.nbytes);
+  const uint32_t n_shards = 1u << T.W.g.shard_bits;
+  const int64_t n_tiles = (hi + kTilePos - 1) / kTilePos;
+  for(int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    __syncthreads();
+    for(uint32_t i = threadIdx.x; i < n_shards; i += blockDim.x) s_hist[i] = 0;
+    const LaneWordsW L = stage_tile_wide(base, tile * kTilePos, lo, hi, s_codes, s_inv);     // contains a barrier
+    // two sweeps over the lane's windows (the keys are wide: they are not kept, they are rolled again): ranks, then stores
+    uint32_t rank[kPerLane]; uint32_t vmask = 0, sh[kPerLane];
+    for_each_kmer_wide(T.W, L, [&](int j, u128 key) {
+      const uint32_t s = (uint32_t)(hash_tables_wide(s_fwd, key, T.W.g.nbytes) >> T.W.g.lsize_l);
+      sh[j] = s; rank[j] = atomicAdd(&s_hist[s], 1u); vmask |= 1u << j;
+    });
+    __syncthreads();
+    for(uint32_t i = threadIdx.x; i < n_shards; i += blockDim.x)
+      s_base[i] = s_hist[i] ? atomicAdd(&cursors[i], (unsigned long long)s_hist[i]) : 0ull;
+    __syncthreads();
+    for_each_kmer_wide(T.W, L, [&](int j, u128 key) {
+      if(!((vmask >> j) & 1u)) return;
+      const unsigned long long at = s_base[sh[j]] + rank[j];
+      out[2 * at] = (uint64_t)key; out[2 * at + 1] = (uint64_t)(key >> 64);
+    });
   }
 }
 

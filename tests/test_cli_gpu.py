@@ -683,13 +683,14 @@ def test_count_gpus_1_goes_through_the_ranks_machinery(cli, tmp_path, self_rccl)
         assert r.returncode != 0 and b"--gpus" in r.stderr
 
 
-@pytest.mark.parametrize("world,items", [(2, "2"), (4, "2"), (2, "0")])
-def test_count_gpus_n_as_rank_processes_on_one_device(cli, tmp_path, world, items):
+@pytest.mark.parametrize("world,items,k", [(2, "2", 21), (4, "2", 21), (2, "0", 21), (2, "1", 63), (4, "1", 40)])
+def test_count_gpus_n_as_rank_processes_on_one_device(cli, tmp_path, world, items, k):
     """`count --gpus 2 / 4` as REAL rank processes (the command forks them; rendezvous directory; every rank reads its part
     of the file, routes by hash prefix, exchanges, writes its records at its offset of the common file) -- on this box's
     single GPU through the inter-process transport (JFGPU_COMM_TRANSPORT=ipc: hipIpc* copies between the ranks' device
-    buffers, host-level collectives in shared memory).  Item path (JFGPU_COMM_ITEMS=2) and key path (=0).  File body,
-    digest and stats equal the single-process run's."""
+    buffers, host-level collectives in shared memory).  Item path (JFGPU_COMM_ITEMS=2) and key path (=0); two-word keys
+    (k = 40, 63: shards of 128-bit slots, two words per routed k-mer -- round 4).  File body, digest and stats equal the
+    single-process run's."""
     import random
     rng = random.Random(17 + world)
     fa = tmp_path / "reads.fa"
@@ -698,9 +699,10 @@ def test_count_gpus_n_as_rank_processes_on_one_device(cli, tmp_path, world, item
             f.write((">r%d\n%s\n" % (r, "".join(rng.choice("ACGT") for _ in range(150)))).encode())
     ref, out = str(tmp_path / "ref.jf"), str(tmp_path / "gN.jf")
     dg0, dg1 = str(tmp_path / "d0.txt"), str(tmp_path / "d1.txt")
-    subprocess.check_call([cli, "count", "-m", "21", "-C", "-s", "64M", "-o", ref, "--digest", dg0, str(fa)])
+    size = "64M" if k <= 32 else "1G"                         # (k = 63 needs 2^29 slots; every rank's shard a share of them)
+    subprocess.check_call([cli, "count", "-m", str(k), "-C", "-s", size, "-o", ref, "--digest", dg0, str(fa)])
     env = dict(os.environ, JFGPU_COMM_TRANSPORT="ipc", JFGPU_COMM_ITEMS=items, JFGPU_PARSE_CHUNK="150000", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    subprocess.check_call([cli, "count", "-m", "21", "-C", "-s", "64M", "-o", out, "--digest", dg1, "--gpus", str(world), str(fa)], env=env, timeout=900)
+    subprocess.check_call([cli, "count", "-m", str(k), "-C", "-s", size, "-o", out, "--digest", dg1, "--gpus", str(world), str(fa)], env=env, timeout=900)
     assert open(dg0).read() == open(dg1).read()
     assert _body(out) == _body(ref) and len(_body(ref)) > 0
     assert subprocess.check_output([cli, "stats", out]) == subprocess.check_output([cli, "stats", ref])

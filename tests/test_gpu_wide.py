@@ -2,6 +2,7 @@
 64-bit atomics.  Bit-exact {k-mer -> count} against the multi-word oracle (the reference's
 ceil(k/32)-word mer_dna, mer_dna.hpp:143-170; tests/large_key.sh is the reference's own check of
 this path), dump in (pos, key) order, lookups, hash_counter::add, count-field overflow."""
+import os
 import random
 
 import numpy as np
@@ -307,3 +308,67 @@ def test_flush_in_groups_sharing_one_p2_buffer(gpu, monkeypatch):
                 st = t.stats()
                 digests[share] = (t.digest(), st.total, st.distinct)
         assert digests["4"] == digests["0"] == digests["4s"]
+
+
+@pytest.mark.parametrize("k,world,max_msg", [(40, 2, None), (48, 4, "997"), (33, 1, None), (63, 2, None)])
+def test_sharded_two_word_keys_equal_single_table(gpu, monkeypatch, k, world, max_msg):
+    """Hash-prefix shards of a table of two-word keys (round 4; round 3 refused k > 32 with shard_bits): every rank routes
+    the 128-bit k-mers of its input by owner (partition_count / scatter_wide_kernel), the messages carry two words per
+    k-mer, receivers insert with the two-word claim.  The shards' dumps concatenated in rank order are byte-identical to the
+    dump of one table of the global size under the same matrix, and nothing is lost or duplicated."""
+    if max_msg:
+        monkeypatch.setenv("JFGPU_COMM_MAX_MSG", max_msg)
+    if k == 63 and os.environ.get("JFGPU_LIB"):
+        pytest.skip("k = 63 needs 2^29 slots (8 GB): not under the host emulation")
+    rng = random.Random(k * 7 + world)
+    inputs = [[rnd_seq(rng, rng.choice([0, 70, 20000, 40000]), "ACGTN") for _ in range(world)] for _step in range(3)]
+    inputs[1][0] = b""
+    inputs[0][world - 1] = rnd_seq(rng, 30000, "ACGT")
+    whole_seq = b"N".join(b"N".join(step) for step in inputs)
+    keys, cnt = O.count(whole_seq, k, True)
+    assert len(keys) > 1000
+    with gpu.Table(k, 1 << 18) as single:
+        single.set_growth(False)
+        single.count_ascii(whole_seq); single.sync()
+        whole = single.dump_records()
+        cols = single.matrix()
+        lsize_g = single.info.lsize                           # (the engine raises the size to the slot format's minimum: 2^29 at k = 63)
+    sb = world.bit_length() - 1
+    shards = [gpu.Table(k, 1 << lsize_g, shard_bits=sb, shard_id=r, matrix_columns=cols) for r in range(world)]
+    comm = gpu.Comm(world, local=True)
+    try:
+        assert all(t.info.lsize == lsize_g for t in shards)
+        bufs = []
+        for step in inputs:
+            ptrs, ns = [], []
+            for r, seq in enumerate(step):
+                d = shards[r].malloc(len(seq) + 64)
+                if seq:
+                    shards[r].h2d(d, np.frombuffer(seq, dtype=np.uint8))
+                bufs.append((shards[r], d)); ptrs.append(d); ns.append(len(seq))
+            comm.local_step(shards, ptrs, ns)
+        sent, received = comm.finish()
+        assert sent == received == int(cnt.sum())
+        for t in shards:
+            t.sync()
+        parts = [t.dump_records() for t in shards]
+        assert (np.concatenate(parts) == whole).all()
+        assert sum(t.stats().total for t in shards) == int(cnt.sum())
+        assert sum(t.stats().distinct for t in shards) == len(keys)
+        # a k-mer sent to a shard that does not own it is refused, never silently counted
+        foreign = np.array([[int(keys[0][0]), int(keys[0][1])]], dtype=np.uint64)
+        refused = 0
+        for t in shards:
+            try:
+                t.add_keys(foreign)
+                t.sync()
+            except gpu.JfgpuError as e:
+                assert "does not own" in e.msg
+                refused += 1
+        assert refused == world - 1
+        for t, d in bufs:
+            t.free(d)
+    finally:
+        comm.close()
+        for t in shards:
+            t.close()
