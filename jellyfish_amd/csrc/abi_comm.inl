@@ -70,7 +70,7 @@ struct jfgpu_comm {
   IpcShared* shm = nullptr; std::string shm_name;
   struct PeerMap { void* ptr = nullptr; uint64_t epoch = 0; };
   std::vector<PeerMap> peer_send[2];             // peers' send buffers as mapped here, per turn
-  uint64_t send_epoch[2] = {0, 0}; void* send_exported[2] = {nullptr, nullptr};
+  uint64_t send_epoch[2] = {0, 0}; void* send_exported[2] = {nullptr, nullptr}; size_t send_exported_cap[2] = {0, 0};
   uint32_t barrier_gen = 0;
 #endif
   bool ipc = false;
@@ -658,9 +658,11 @@ int ipc_barrier(jfgpu_comm* c) {
 int ipc_publish_send(jfgpu_comm* c, int cur) {
   jfgpu_comm::Rank& R = c->ranks[0];
   IpcShared::Pub& P = c->shm->pub[c->rank];
-  if(R.send[cur] && c->send_exported[cur] != (void*)R.send[cur]) {
+  // (pointer AND capacity: comm_reserve frees and allocates, and the allocator likes to hand the same address back for the
+  //  larger buffer -- peers would go on copying through their mapping of the freed one.  Round-3 advisor finding.)
+  if(R.send[cur] && (c->send_exported[cur] != (void*)R.send[cur] || c->send_exported_cap[cur] != R.send_cap[cur])) {
     if(hipIpcGetMemHandle(&P.send[cur], R.send[cur]) != hipSuccess) return ipc_fail(c, "hipIpcGetMemHandle");
-    c->send_exported[cur] = R.send[cur];
+    c->send_exported[cur] = R.send[cur]; c->send_exported_cap[cur] = R.send_cap[cur];
     P.send_epoch[cur] = ++c->send_epoch[cur];
   }
   return JFGPU_OK;
@@ -810,6 +812,91 @@ int comm_exchange_ipc(jfgpu_comm*) { return fail(JFGPU_E_UNSUPPORTED, "no inter-
 int comm_exchange_items_ipc(jfgpu_comm*) { return fail(JFGPU_E_UNSUPPORTED, "no inter-process transport in the emulated build"); }
 #endif
 
+// ---- the shards of a table grow together -------------------------------------------------------------------------------
+// hash_counter::double_size (hash_counter.hpp:200-238) for a table spread over ranks.  The doubled table has a new matrix
+// (the next one of the reference's random() stream, the same on every rank), so an entry's owner changes: every rank
+// walks its old shard, puts what stays with it into its new shard and sends the rest -- (key, count) pairs, grouped by
+// new owner -- through the key path's exchange, twice (keys, then counts, same grouping).  One-word keys.
+//   pass 0: how many pairs for every owner;  pass 1: the pairs, at the cursors (= offsets), and the local inserts
+__global__ __launch_bounds__(kBlock) void reshard_kernel(DevTable old, DevTable neu, int have_ovf, int pass, unsigned long long* __restrict__ cursors,
+                                                         uint64_t* __restrict__ keys_out, uint64_t* __restrict__ cnts_out) {
+  const uint64_t n = 1ull << old.g.lsize_l;
+  for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t w = slot_ld(old, i);
+    if(!w) continue;
+    const uint64_t key = slot_key(old.g, old.inv_tbl, w, i & ~old.g.tile_mask);
+    const uint32_t owner = (uint32_t)(hash_tables(neu.fwd_tbl, key, neu.g.nbytes) >> neu.g.lsize_l);
+    if(owner == neu.g.shard_id) { if(pass) table_add_val(neu, neu.fwd_tbl, key, full_count(old, w, i, have_ovf)); }
+    else {
+      const unsigned long long at = atomicAdd(&cursors[owner], 1ull);
+      if(pass) { keys_out[at] = key; cnts_out[at] = full_count(old, w, i, have_ovf); }
+    }
+  }
+}
+__global__ __launch_bounds__(kBlock) void add_pairs_kernel(DevTable T, const uint64_t* __restrict__ keys, const uint64_t* __restrict__ cnts, uint64_t n) {
+  for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    table_add_val(T, T.fwd_tbl, keys[i], cnts[i]);
+}
+
+int comm_exchange_rccl(jfgpu_comm* c); int comm_exchange_local(jfgpu_comm* c); int comm_exchange_ipc(jfgpu_comm* c);
+
+// Collective (every rank of the communicator; the local transport: all its ranks here).
+int comm_grow(jfgpu_comm* c) {
+  const int W = c->world;
+  std::vector<GrowNew> N(c->ranks.size());
+  // every rank: nothing in flight, the new shard allocated, the pairs that leave grouped by their new owner in send[0] / send[1]
+  for(size_t q = 0; q < c->ranks.size(); ++q) {
+    jfgpu_comm::Rank& R = c->ranks[q];
+    jfgpu_table* t = R.t;
+    if(t->wide || t->nword) return fail(JFGPU_E_UNSUPPORTED, "sharded tables of two-word keys do not grow yet: give -s the size the input needs");
+    int rc = comm_insert_prev(c, R); if(rc) return rc;
+    rc = grow_prepare(t, N[q]);
+    if(rc < 0) return fail(JFGPU_E_FULL, "Hash full (no memory to double a shard)");
+    if(rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->xstream));
+    const int have_ovf = (int)(N[q].ctr[CTR_OVF_USED] != 0);
+    const dim3 grid(grid_for(t, (1ull << t->g.lsize_l) / kBlock + 1)), block(kBlock);
+    HIP_TRY(hipMemsetAsync(R.d_cnt, 0, sizeof(unsigned long long) * W, t->stream));
+    hipLaunchKernelGGL(reshard_kernel, grid, block, 0, t->stream, t->dt, N[q].nd, have_ovf, 0, R.d_cnt, (uint64_t*)nullptr, (uint64_t*)nullptr);
+    std::vector<unsigned long long> h(W);
+    HIP_TRY(hipMemcpyAsync(h.data(), R.d_cnt, sizeof(unsigned long long) * W, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    uint64_t total = 0;
+    for(int p = 0; p < W; ++p) { R.scount[0][p] = h[p]; R.soff[0][p] = total; total += h[p]; h[p] = R.soff[0][p]; }
+    R.soff[0][W] = total;
+    R.scount[1] = R.scount[0]; R.soff[1] = R.soff[0];
+    for(int b = 0; b < 2; ++b) { rc = comm_reserve(R.send[b], R.send_cap[b], std::max<uint64_t>(total, 1), t->stream, c->xstream); if(rc) return rc; }
+    HIP_TRY(hipMemcpyAsync(R.d_cnt, h.data(), sizeof(unsigned long long) * W, hipMemcpyHostToDevice, t->stream));   // cursors = offsets
+    hipLaunchKernelGGL(reshard_kernel, grid, block, 0, t->stream, t->dt, N[q].nd, have_ovf, 1, R.d_cnt, R.send[0], R.send[1]);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    R.used[0] = R.used[1] = false;                            // (everything before is complete: the exchanges below start from a clean slate)
+    R.icap[0] = R.icap[1] = 0;
+  }
+  // keys (turn 0), then counts (turn 1): the key path's exchange, as it is
+  for(int turn = 0; turn < 2; ++turn) {
+    for(auto& R : c->ranks) R.turn = turn;
+    int rc = c->local ? comm_exchange_local(c) : c->ipc ? comm_exchange_ipc(c) : comm_exchange_rccl(c);
+    if(rc) return rc;
+  }
+  for(size_t q = 0; q < c->ranks.size(); ++q) {
+    jfgpu_comm::Rank& R = c->ranks[q];
+    jfgpu_table* t = R.t;
+    HIP_TRY(hipStreamWaitEvent(t->stream, R.exchanged[0], 0));
+    HIP_TRY(hipStreamWaitEvent(t->stream, R.exchanged[1], 0));
+    const uint64_t n = R.roff[0][W];
+    if(n) hipLaunchKernelGGL(add_pairs_kernel, dim3(grid_for(t, n / kBlock + 1)), dim3(kBlock), 0, t->stream, N[q].nd, (const uint64_t*)R.recv[0], (const uint64_t*)R.recv[1], n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(R.consumed[0], t->stream));
+    HIP_TRY(hipEventRecord(R.consumed[1], t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    int rc = grow_swap(t, N[q]); if(rc) return rc;
+    R.turn = 0; R.inflight = false;
+    rc = measure_occupancy(t); if(rc) return rc;
+  }
+  return JFGPU_OK;
+}
+
 void comm_free_rank(jfgpu_comm::Rank& R) {
   for(int i = 0; i < 2; ++i) {
     if(R.send[i]) hipFree(R.send[i]);
@@ -826,6 +913,49 @@ void comm_free_rank(jfgpu_comm::Rank& R) {
   if(R.d_route) hipFree(R.d_route);
   if(R.h_route) hipHostFree(R.h_route);
   if(R.route_done) hipEventDestroy(R.route_done);
+}
+
+extern "C" int jfgpu_comm_allreduce_u64(jfgpu_comm* c, uint64_t* values, int n, int op);
+
+// The size question of a step.  The size given at creation is a hint (doc/Readme.md:67-72) for a sharded table too: a
+// shard keeps an upper bound of its occupancy (what it measured last + the largest piece any rank fed in every exchange
+// since: k-mers <= bytes, and a hash prefix gets its even share of them), input is fed in pieces that fit the head-room the
+// ranks have between them (the smallest), and when a rank's head-room runs out every rank measures its shard; if one is
+// more than half full, all of them double together (comm_grow).  Shards of two-word keys do not grow yet.
+bool comm_growing(const jfgpu_table* t) { return t->grow_on && !t->wide && !t->nword && t->g.lsize_g < t->g.key_bits; }
+uint64_t comm_headroom(const jfgpu_table* t) {
+  const uint64_t limit = capacity_limit(t), used = t->occ_known + t->fed_since;
+  return limit > used ? limit - used : 0;
+}
+// head-room too small for a useful piece of `left` bytes: time to measure
+bool comm_bound_out(const jfgpu_table* t, uint64_t left) { return comm_headroom(t) < std::min<uint64_t>(left, std::max<uint64_t>(capacity_limit(t) / 8, 1)); }
+
+// One piece of this rank's step through routing, exchange and the insert of the previous piece (cap: the agreed region
+// capacity of the item path, 0: keys).
+int comm_piece_rccl(jfgpu_comm* c, jfgpu_comm::Rank& R, const char* d_bases, size_t n, uint32_t cap) {
+  jfgpu_table* t = R.t;
+  int rc = ensure_ovf(t, (uint64_t)n * (uint64_t)c->world, 0); if(rc) return rc;      // (what may arrive for this shard: about a world's worth of one rank's input)
+  uint64_t routed = 0;
+  // the routing of this piece is enqueued, then the insert of what arrived for the previous one (it only waits for that
+  // piece's exchange, on the device): the host's look at the routing pass and the agreement below happen beside device work
+  if(cap) { rc = comm_route_items_enqueue(c, R, d_bases, n, cap); if(rc) return rc; }
+  rc = comm_insert_prev(c, R); if(rc) return rc;
+  if(cap) {
+    bool overflow = false;
+    rc = comm_route_items_complete(c, R, cap, &overflow, &routed); if(rc) return rc;
+    IPC_TRACE(c, "step: routed %llu items%s", (unsigned long long)routed, overflow ? " (straggler list overflow)" : "");
+    uint64_t o = overflow ? 1 : 0;
+    rc = jfgpu_comm_allreduce_u64(c, &o, 1, 1); if(rc) return rc;
+    if(o) cap = 0;                                           // somebody has more stragglers than the list holds: this piece goes as keys
+  }
+  R.icap[R.turn] = cap;
+  if(cap) { R.sent += routed; rc = c->ipc ? comm_exchange_items_ipc(c) : comm_exchange_items_rccl(c); if(rc) return rc; }
+  else {
+    rc = comm_route(c, R, d_bases, n); if(rc) return rc;
+    rc = c->ipc ? comm_exchange_ipc(c) : comm_exchange_rccl(c); if(rc) return rc;
+  }
+  R.inflight = true; R.turn ^= 1;
+  return JFGPU_OK;
 }
 
 }  // namespace
@@ -919,36 +1049,43 @@ int jfgpu_comm_count_ascii_dev(jfgpu_comm* c, jfgpu_table* t, const char* d_base
   if((int)t->g.shard_id != c->rank) return fail(JFGPU_E_INVALID, "table shard_id is not this communicator's rank");
   jfgpu_comm::Rank& R = c->ranks[0];
   R.t = t;
-  rc = ensure_ovf(t, (uint64_t)n * (uint64_t)c->world, 0); if(rc) return rc;      // (what may arrive for this shard: about a world's worth of one rank's input)
-  // item path or keys?  every rank says what region capacity it wants (0: keys); one "keys" decides for all
-  // (a rank that has run out of input has no preference: it must not push the others onto the key path)
-  const uint32_t want = items_cap_wanted(c, R, n);
-  uint64_t v[2] = {(!items_geometry_ok(c, t) || (want == 0 && n >= t->g.k)) ? 1ull : 0ull, want};
-  IPC_TRACE(c, "step: %zu bytes, wants cap %u", n, want);
-  rc = jfgpu_comm_allreduce_u64(c, v, 2, 1); if(rc) return rc;
-  uint32_t cap = v[0] ? 0u : (uint32_t)v[1];
-  IPC_TRACE(c, "step: agreed cap %u (0: keys)", cap);
-  uint64_t routed = 0;
-  // the routing of this step is enqueued, then the insert of what arrived for the previous one (it only waits for that
-  // step's exchange, on the device): the host's look at the routing pass and the agreement below happen beside device work
-  if(cap) { rc = comm_route_items_enqueue(c, R, d_bases, n, cap); if(rc) return rc; }
-  rc = comm_insert_prev(c, R); if(rc) return rc;
-  if(cap) {
-    bool overflow = false;
-    rc = comm_route_items_complete(c, R, cap, &overflow, &routed); if(rc) return rc;
-    IPC_TRACE(c, "step: routed %llu items%s", (unsigned long long)routed, overflow ? " (straggler list overflow)" : "");
-    uint64_t o = overflow ? 1 : 0;
-    rc = jfgpu_comm_allreduce_u64(c, &o, 1, 1); if(rc) return rc;
-    if(o) cap = 0;                                           // somebody has more stragglers than the list holds: this step goes as keys
-  }
-  R.icap[R.turn] = cap;
-  if(cap) { R.sent += routed; rc = c->ipc ? comm_exchange_items_ipc(c) : comm_exchange_items_rccl(c); if(rc) return rc; }
-  else {
-    rc = comm_route(c, R, d_bases, n); if(rc) return rc;
-    rc = c->ipc ? comm_exchange_ipc(c) : comm_exchange_rccl(c); if(rc) return rc;
+  const uint64_t k = t->g.k;
+  size_t off = 0;
+  for(bool first = true;; first = false) {
+    const size_t left = n - off;
+    const bool growing = comm_growing(t);
+    // item path or keys?  every rank says what region capacity it wants (0: keys); one "keys" decides for all (a rank that
+    // has run out of input has no preference: it must not push the others onto the key path).  The same agreement carries
+    // what is left anywhere, whether somebody's head-room has run out, and the smallest head-room.
+    const uint64_t head = growing ? comm_headroom(t) : ~0ull >> 1;
+    const size_t mine = (size_t)std::min<uint64_t>(left, head);
+    const uint32_t want = items_cap_wanted(c, R, mine);
+    uint64_t v[5] = {(!items_geometry_ok(c, t) || (want == 0 && mine >= k)) ? 1ull : 0ull, want, (uint64_t)left,
+                     growing && comm_bound_out(t, left) ? 1ull : 0ull, ~0ull - head};
+    IPC_TRACE(c, "step: %zu bytes left, head-room %llu, wants cap %u", left, (unsigned long long)head, want);
+    rc = jfgpu_comm_allreduce_u64(c, v, 5, 1); if(rc) return rc;
+    if(!first && v[2] == 0) break;                           // every rank has fed its whole buffer
+    if(growing && v[3]) {
+      rc = comm_insert_prev(c, R); if(rc) return rc;
+      rc = measure_occupancy(t); if(rc) return rc;
+      uint64_t full = t->occ_known > (1ull << t->g.lsize_l) / 2 ? 1 : 0;
+      rc = jfgpu_comm_allreduce_u64(c, &full, 1, 1); if(rc) return rc;
+      IPC_TRACE(c, "step: shard holds %llu of %llu slots%s", (unsigned long long)t->occ_known, (unsigned long long)(1ull << t->g.lsize_l), full ? ": the shards double" : "");
+      if(full) { rc = comm_grow(c); if(rc) return rc; }
+      first = true;                                          // (the agreement is taken again: new head-room, maybe a new geometry)
+      continue;
+    }
+    const uint64_t agreed = ~0ull - v[4];                    // the smallest head-room
+    size_t piece = (size_t)std::min<uint64_t>(left, agreed);
+    if(piece < left && piece < 2 * k) piece = (size_t)std::min<uint64_t>(left, 2 * k);      // (a piece holds a window and moves forward)
+    const uint32_t cap = v[0] ? 0u : (uint32_t)v[1];
+    IPC_TRACE(c, "step: piece of %zu bytes, agreed cap %u (0: keys)", piece, cap);
+    rc = comm_piece_rccl(c, R, d_bases + off, piece, cap); if(rc) return rc;
+    if(growing) t->fed_since += std::min<uint64_t>(v[2], std::max<uint64_t>(agreed, 2 * k));
+    if(off + piece >= n) off = n; else off += piece - (size_t)(k - 1);      // the next piece re-reads the last k-1 characters: every window exactly once
+    if(!growing) break;                                      // (no pieces without growth: the step is one exchange, as the caller counts them)
   }
   IPC_TRACE(c, "step: done");
-  R.inflight = true; R.turn ^= 1;
   return JFGPU_OK;
 }
 
@@ -956,40 +1093,80 @@ int jfgpu_comm_count_ascii_dev(jfgpu_comm* c, jfgpu_table* t, const char* d_base
 int jfgpu_comm_local_step(jfgpu_comm* c, jfgpu_table** tables, const char* const* d_bases, const size_t* n) {
   if(!c || !c->local) return fail(JFGPU_E_INVALID, "not a local communicator");
   if(!tables || !d_bases || !n) return fail(JFGPU_E_INVALID, "null argument");
-  uint32_t cap = 0xFFFFFFFFu, want_max = 0;
-  for(int r = 0; r < c->world; ++r) {
+  const int W = c->world;
+  bool growing = true;
+  for(int r = 0; r < W; ++r) {
     int rc = use(tables[r]); if(rc) return rc;
     if((int)tables[r]->g.shard_id != r) return fail(JFGPU_E_INVALID, "tables must be given in shard order");
     c->ranks[r].t = tables[r];
-    { uint64_t all = 0; for(int q = 0; q < c->world; ++q) all += n[q]; rc = ensure_ovf(tables[r], all, 0); if(rc) return rc; }
-    const uint32_t w = items_cap_wanted(c, c->ranks[r], n[r]);
-    if(!items_geometry_ok(c, tables[r]) || (!w && n[r] >= tables[r]->g.k)) cap = 0;      // (a rank without input has no preference)
-    want_max = std::max(want_max, w);
+    growing = growing && comm_growing(tables[r]);
   }
-  if(cap) cap = want_max;                                  // (0 when nobody has input: the key path with nothing to send)
-  // (same order as the RCCL step: routing enqueued, the previous step's insert enqueued, then the host's look at the routing)
-  if(cap) for(int r = 0; r < c->world; ++r) { int rc = comm_route_items_enqueue(c, c->ranks[r], d_bases[r], n[r], cap); if(rc) return rc; }
-  for(int r = 0; r < c->world; ++r) { int rc = comm_insert_prev(c, c->ranks[r]); if(rc) return rc; }
-  if(cap) {
-    bool any_overflow = false;
-    std::vector<uint64_t> routed(c->world, 0);
-    for(int r = 0; r < c->world; ++r) {
-      bool overflow = false;
-      int rc = comm_route_items_complete(c, c->ranks[r], cap, &overflow, &routed[r]); if(rc) return rc;
-      any_overflow = any_overflow || overflow;
+  const uint64_t k = tables[0]->g.k;
+  std::vector<size_t> off(W, 0), piece(W, 0);
+  std::vector<const char*> at(W);
+  for(bool first = true;; first = false) {
+    // the agreement of jfgpu_comm_count_ascii_dev, with every rank in this process
+    uint64_t max_left = 0, head = ~0ull >> 1; bool bound_out = false;
+    for(int r = 0; r < W; ++r) {
+      const uint64_t left = n[r] - off[r];
+      max_left = std::max(max_left, left);
+      if(growing) { head = std::min(head, comm_headroom(tables[r])); bound_out = bound_out || comm_bound_out(tables[r], left); }
     }
-    if(any_overflow) cap = 0;
-    else for(int r = 0; r < c->world; ++r) c->ranks[r].sent += routed[r];
+    if(!first && max_left == 0) break;
+    if(growing && bound_out) {
+      bool full = false;
+      for(int r = 0; r < W; ++r) {
+        int rc = comm_insert_prev(c, c->ranks[r]); if(rc) return rc;
+        rc = measure_occupancy(tables[r]); if(rc) return rc;
+        full = full || tables[r]->occ_known > (1ull << tables[r]->g.lsize_l) / 2;
+      }
+      if(full) { int rc = comm_grow(c); if(rc) return rc; }
+      first = true;
+      continue;
+    }
+    uint32_t cap = 0xFFFFFFFFu, want_max = 0;
+    for(int r = 0; r < W; ++r) {
+      const uint64_t left = n[r] - off[r];
+      piece[r] = (size_t)std::min<uint64_t>(left, head);
+      if(piece[r] < left && piece[r] < 2 * k) piece[r] = (size_t)std::min<uint64_t>(left, 2 * k);
+      at[r] = d_bases[r] + off[r];
+      const uint32_t w = items_cap_wanted(c, c->ranks[r], piece[r]);
+      if(!items_geometry_ok(c, tables[r]) || (!w && piece[r] >= k)) cap = 0;      // (a rank without input has no preference)
+      want_max = std::max(want_max, w);
+    }
+    if(cap) cap = want_max;                                // (0 when nobody has input: the key path with nothing to send)
+    for(int r = 0; r < W; ++r) { uint64_t all = 0; for(int q = 0; q < W; ++q) all += piece[q]; int rc = ensure_ovf(tables[r], all, 0); if(rc) return rc; }
+    // (same order as the RCCL piece: routing enqueued, the previous piece's insert enqueued, then the host's look at the routing)
+    if(cap) for(int r = 0; r < W; ++r) { int rc = comm_route_items_enqueue(c, c->ranks[r], at[r], piece[r], cap); if(rc) return rc; }
+    for(int r = 0; r < W; ++r) { int rc = comm_insert_prev(c, c->ranks[r]); if(rc) return rc; }
+    if(cap) {
+      bool any_overflow = false;
+      std::vector<uint64_t> routed(W, 0);
+      for(int r = 0; r < W; ++r) {
+        bool overflow = false;
+        int rc = comm_route_items_complete(c, c->ranks[r], cap, &overflow, &routed[r]); if(rc) return rc;
+        any_overflow = any_overflow || overflow;
+      }
+      if(any_overflow) cap = 0;
+      else for(int r = 0; r < W; ++r) c->ranks[r].sent += routed[r];
+    }
+    for(int r = 0; r < W; ++r) c->ranks[r].icap[c->ranks[r].turn] = cap;
+    int rc = JFGPU_OK;
+    if(cap) rc = comm_exchange_items_local(c);
+    else {
+      for(int r = 0; r < W; ++r) { rc = comm_route(c, c->ranks[r], at[r], piece[r]); if(rc) return rc; }
+      rc = comm_exchange_local(c);
+    }
+    if(rc) return rc;
+    uint64_t max_piece = 0;
+    for(int r = 0; r < W; ++r) {
+      c->ranks[r].inflight = true; c->ranks[r].turn ^= 1;
+      max_piece = std::max<uint64_t>(max_piece, piece[r]);
+      if(off[r] + piece[r] >= n[r]) off[r] = n[r]; else off[r] += piece[r] - (size_t)(k - 1);
+    }
+    if(growing) for(int r = 0; r < W; ++r) tables[r]->fed_since += max_piece;
+    if(!growing) break;
   }
-  for(int r = 0; r < c->world; ++r) c->ranks[r].icap[c->ranks[r].turn] = cap;
-  int rc = JFGPU_OK;
-  if(cap) rc = comm_exchange_items_local(c);
-  else {
-    for(int r = 0; r < c->world; ++r) { rc = comm_route(c, c->ranks[r], d_bases[r], n[r]); if(rc) return rc; }
-    rc = comm_exchange_local(c);
-  }
-  if(rc) return rc;
-  for(int r = 0; r < c->world; ++r) { c->ranks[r].inflight = true; c->ranks[r].turn ^= 1; }
   return JFGPU_OK;
 }
 

@@ -425,13 +425,25 @@ int measure_occupancy(jfgpu_table* t) {
 
 // Double the table: one more matrix row (so old positions are the low bits of new ones), new slots,
 // rehash on the device, swap.  < 0: not possible (memory) -- the caller carries on with the old table.
-int table_grow(jfgpu_table* t) {
-  int rc = part_flush(t); if(rc) return rc;
+// In three parts, because a SHARD grows together with the other shards of its table (abi_comm.inl: comm_grow): the new
+// geometry, matrix and allocations (grow_prepare), what moves the entries (the rehash kernels here; a redistribution
+// between the ranks there), and the exchange of old for new (grow_swap).
+struct GrowNew {
+  TableGeom g2; WideGeom w2; NGeom ng2;
+  Gf2Matrix m2;
+  DevTable nd; WideTable nw; NTable nn;
+  uint64_t *nf = nullptr, *ni = nullptr;
+  uint64_t cap2 = 0;
   uint64_t ctr[CTR_COUNT];
-  rc = check_deferred(t, ctr); if(rc) return rc;
+};
+
+int grow_prepare(jfgpu_table* t, GrowNew& N) {
+  int rc = part_flush(t); if(rc) return rc;
+  rc = check_deferred(t, N.ctr); if(rc) return rc;
   const uint32_t r = t->g.lsize_g, c = t->g.key_bits;
   if(r >= c) return -1;
-  Gf2Matrix m2 = t->matrix; m2.r = r + 1; m2.identity = false;
+  Gf2Matrix& m2 = N.m2;
+  m2 = t->matrix; m2.r = r + 1; m2.identity = false;
   std::vector<uint64_t> fwd, inv;
   if(t->ref_matrix) {
     // like the reference: a brand-new matrix for the doubled table, next in the same random() stream
@@ -449,84 +461,89 @@ int table_grow(jfgpu_table* t) {
       if(tries > 1000) return fail(JFGPU_E_INVALID, "could not extend the hash matrix");
     }
   }
-  TableGeom g2;
-  WideGeom w2;
-  NGeom ng2;
-  if(t->nword) { if(!nword_geom_init(ng2, t->g.k, r + 1, t->g.canonical)) return -1; g2 = ng2.g; }
-  else if(t->wide) { if(!wide_geom_init(w2, t->g.k, r + 1, t->g.canonical)) return -1; g2 = w2.g; }
-  else if(!geom_init(g2, t->g.k, r + 1, 0, 0, t->g.canonical, !t->tun.slot64)) return -1;
+  TableGeom& g2 = N.g2;
+  if(t->nword) { if(!nword_geom_init(N.ng2, t->g.k, r + 1, t->g.canonical)) return -1; g2 = N.ng2.g; }
+  else if(t->wide) { if(!wide_geom_init(N.w2, t->g.k, r + 1, t->g.canonical, t->g.shard_bits, t->g.shard_id)) return -1; g2 = N.w2.g; }
+  else if(!geom_init(g2, t->g.k, r + 1, t->g.shard_bits, t->g.shard_id, t->g.canonical, !t->tun.slot64)) return -1;
   const uint64_t n2 = 1ull << g2.lsize_l;
   const size_t slot_bytes = g2.slot32 ? 4 : 8 * (size_t)t->slot_words;
   uint64_t cap2 = std::max<uint64_t>(kMinOvf, std::min<uint64_t>(n2 / 256, 1ull << 26));
   if(g2.cnt_bits < 40) cap2 = std::max<uint64_t>(cap2, std::min<uint64_t>(2 * ((t->occ_bound >> g2.cnt_bits) + t->bigval_bound) + 4096, 2 * n2));      // (ensure_ovf's rule)
   cap2 = std::max<uint64_t>(cap2, t->ovf_cap);
   { uint64_t x = 1; while(x < cap2) x <<= 1; cap2 = x; }
-  DevTable nd = t->dt;
+  N.cap2 = cap2;
+  DevTable& nd = N.nd;
+  nd = t->dt;
   nd.g = g2; nd.slots = nullptr; nd.ovf_key = nd.ovf_cnt = nullptr; nd.dirty = nullptr;
-  uint64_t *nf = nullptr, *ni = nullptr;
   size_t free_b = 0, total_b = 0;
   HIP_TRY(hipMemGetInfo(&free_b, &total_b));
   if(n2 * slot_bytes + cap2 * 16 + ((size_t)1 << 30) > free_b) return -1;
   bool ok = hipMalloc((void**)&nd.slots, n2 * slot_bytes) == hipSuccess && hipMalloc((void**)&nd.ovf_key, cap2 * 8) == hipSuccess &&
             hipMalloc((void**)&nd.ovf_cnt, cap2 * 8) == hipSuccess && hipMalloc((void**)&nd.dirty, (size_t)1 << (g2.lsize_l - g2.tile_bits)) == hipSuccess &&
-            hipMalloc((void**)&nf, fwd.size() * 8) == hipSuccess && hipMalloc((void**)&ni, inv.size() * 8) == hipSuccess;
+            hipMalloc((void**)&N.nf, fwd.size() * 8) == hipSuccess && hipMalloc((void**)&N.ni, inv.size() * 8) == hipSuccess;
   if(!ok) {
-    hipFree(nd.slots); hipFree(nd.ovf_key); hipFree(nd.ovf_cnt); hipFree(nd.dirty); hipFree(nf); hipFree(ni);
+    hipFree(nd.slots); hipFree(nd.ovf_key); hipFree(nd.ovf_cnt); hipFree(nd.dirty); hipFree(N.nf); hipFree(N.ni);
     (void)hipGetLastError();
     return -1;
   }
-  nd.fwd_tbl = nf; nd.inv_tbl = ni; nd.ovf_mask = cap2 - 1;
+  nd.fwd_tbl = N.nf; nd.inv_tbl = N.ni; nd.ovf_mask = cap2 - 1;
   nd.max_probe = (uint32_t)std::min<uint64_t>(g2.tile_mask, 1023);
   HIP_TRY(hipMemsetAsync(nd.slots, 0, n2 * slot_bytes, t->stream));
   HIP_TRY(hipMemsetAsync(nd.ovf_key, 0, cap2 * 8, t->stream));
   HIP_TRY(hipMemsetAsync(nd.ovf_cnt, 0, cap2 * 8, t->stream));
   HIP_TRY(hipMemsetAsync(nd.dirty, 0, (size_t)1 << (g2.lsize_l - g2.tile_bits), t->stream));
-  HIP_TRY(hipMemcpyAsync(nf, fwd.data(), fwd.size() * 8, hipMemcpyHostToDevice, t->stream));
-  HIP_TRY(hipMemcpyAsync(ni, inv.data(), inv.size() * 8, hipMemcpyHostToDevice, t->stream));
-  WideTable nw = t->wt;
-  NTable nn = t->nt;
+  HIP_TRY(hipMemcpyAsync(N.nf, fwd.data(), fwd.size() * 8, hipMemcpyHostToDevice, t->stream));
+  HIP_TRY(hipMemcpyAsync(N.ni, inv.data(), inv.size() * 8, hipMemcpyHostToDevice, t->stream));
+  HIP_TRY(hipStreamSynchronize(t->stream));                  // (fwd / inv are this function's)
+  N.nw = t->wt; N.nn = t->nt;
   if(t->nword) {
-    nn.N = ng2; nn.slots = nd.slots; nn.fwd_tbl = nf; nn.inv_tbl = ni; nn.ovf_key = nd.ovf_key; nn.ovf_cnt = nd.ovf_cnt;
+    NTable& nn = N.nn;
+    nn.N = N.ng2; nn.slots = nd.slots; nn.fwd_tbl = N.nf; nn.inv_tbl = N.ni; nn.ovf_key = nd.ovf_key; nn.ovf_cnt = nd.ovf_cnt;
     nn.ovf_mask = nd.ovf_mask; nn.counters = nd.counters; nn.max_probe = nd.max_probe;
-    hipLaunchKernelGGL(rehash_nword_kernel, dim3(grid_for(t, (1ull << t->g.lsize_l) / kBlock + 1)), dim3(kBlock), 0, t->stream, t->nt, nn,
-                       (int)(ctr[CTR_OVF_USED] != 0));
   } else if(t->wide) {
-    nw.W = w2; nw.slots = nd.slots; nw.fwd_tbl = nf; nw.inv_tbl = ni; nw.ovf_key = nd.ovf_key; nw.ovf_cnt = nd.ovf_cnt;
+    WideTable& nw = N.nw;
+    nw.W = N.w2; nw.slots = nd.slots; nw.fwd_tbl = N.nf; nw.inv_tbl = N.ni; nw.ovf_key = nd.ovf_key; nw.ovf_cnt = nd.ovf_cnt;
     nw.ovf_mask = nd.ovf_mask; nw.counters = nd.counters; nw.max_probe = nd.max_probe; nw.dirty = nd.dirty;
-    hipLaunchKernelGGL(rehash_wide_kernel, dim3(grid_for(t, (1ull << t->g.lsize_l) / kBlock + 1)), dim3(kBlock), 0, t->stream, t->wt, nw,
-                       (int)(ctr[CTR_OVF_USED] != 0));
-  } else
-  hipLaunchKernelGGL(rehash_kernel, dim3(grid_for(t, (1ull << t->g.lsize_l) / kBlock + 1)), dim3(kBlock), 0, t->stream, t->dt, nd,
-                     (int)(ctr[CTR_OVF_USED] != 0));
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(t->stream));
-  // swap in
+  }
+  return JFGPU_OK;
+}
+
+// the new table takes the old one's place (the entries have been moved and the stream is idle)
+int grow_swap(jfgpu_table* t, GrowNew& N) {
   hipFree(t->dt.slots); hipFree(t->dt.ovf_key); hipFree(t->dt.ovf_cnt); hipFree(t->dt.dirty); hipFree(t->d_fwd); hipFree(t->d_inv);
-  t->dt = nd; t->g = g2; t->matrix = m2; t->d_fwd = nf; t->d_inv = ni; t->ovf_cap = cap2;
+  t->dt = N.nd; t->g = N.g2; t->matrix = N.m2; t->d_fwd = N.nf; t->d_inv = N.ni; t->ovf_cap = N.cap2;
   t->returning = t->g.cnt_bits < 40; t->ovf_failed_need = 0;
   if(t->d_M2) { hipFree(t->d_M2); t->d_M2 = nullptr; }
   if(t->d_strag) { hipFree(t->d_strag); hipFree(t->d_strag_n); t->d_strag = nullptr; t->d_strag_n = nullptr; }     // (the item width may change with the geometry)
   if(t->nword) {
-    t->nt = nn;
+    t->nt = N.nn;
     t->pristine = false;
     ++t->grow_seed;
     return check_deferred(t);
   }
   if(t->wide) {
-    t->wt = nw;
+    t->wt = N.nw;
     const int wl = (int)(((size_t)16 << t->g.tile_bits) + ((size_t)2 << t->g.tile_bits));
     HIP_TRY(hipFuncSetAttribute((const void*)dump_tiles_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
-    part_geom_init(t);
-    if(t->mode == MODE_PARTITIONED && !t->part_ok) t->mode = MODE_AUTO;
-    t->pristine = false;
-    ++t->grow_seed;
-    return check_deferred(t);
   }
   part_geom_init(t);
   if(t->mode == MODE_PARTITIONED && !t->part_ok) t->mode = MODE_AUTO;
   t->pristine = false;
   ++t->grow_seed;
   return check_deferred(t);
+}
+
+int table_grow(jfgpu_table* t) {
+  GrowNew N;
+  int rc = grow_prepare(t, N); if(rc) return rc;
+  const int have_ovf = (int)(N.ctr[CTR_OVF_USED] != 0);
+  const dim3 grid(grid_for(t, (1ull << t->g.lsize_l) / kBlock + 1)), block(kBlock);
+  if(t->nword) hipLaunchKernelGGL(rehash_nword_kernel, grid, block, 0, t->stream, t->nt, N.nn, have_ovf);
+  else if(t->wide) hipLaunchKernelGGL(rehash_wide_kernel, grid, block, 0, t->stream, t->wt, N.nw, have_ovf);
+  else hipLaunchKernelGGL(rehash_kernel, grid, block, 0, t->stream, t->dt, N.nd, have_ovf);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  return grow_swap(t, N);
 }
 
 void refresh_views(jfgpu_table* t) {
