@@ -260,6 +260,38 @@ def spawn_ranks(n):
     return rc
 
 
+def plan(args):
+    """The workload of `bench.py --gpus N --config C` without running it: which BASELINE configuration, how much sequence,
+    which table and which device memory per rank.  The arithmetic main() does on the GPU box, in one place that a CPU test
+    can call (tests/test_bench_launcher.py)."""
+    world = args.gpus
+    sb = (world - 1).bit_length()
+    if 1 << sb != world:
+        raise SystemExit("the number of GPUs must be a power of two (shards = top hash bits)")
+    cfg = args.config
+    if world > 1 and cfg != "C2":
+        raise SystemExit("--config %s is a single-GPU configuration (BASELINE.json)" % cfg)
+    gbp = args.gbp or (GBP_PER_GPU_SHARDED if world > 1 else 10.0)
+    K = CONFIGS[cfg]["k"]
+    lsize = args.lsize or CONFIGS[cfg]["lsize"]
+    n_reads = int(round(gbp * 1e9 / READ_LEN))
+    stride = READ_LEN + 1
+    slot_bytes = 4 if (cfg == "C2" and 2 * K - (lsize + sb) <= 10) else CONFIGS[cfg]["slot"]      # kmer_core.hpp: 32-bit slots when at most ten key bits are left to store
+    table = (1 << lsize) * slot_bytes
+    reads = n_reads * stride
+    kmers = n_reads * (READ_LEN - K + 1)
+    item = 4 if cfg == "C2" else (8 if cfg == "C3" else 16)
+    workspace = int(kmers * item * (2.3 if world == 1 else 3.4))       # P1 regions + P2 regions (+ routed regions and what arrived, sharded)
+    return {"id": cfg if world == 1 else "C4", "world": world, "shard_bits": sb, "k": K, "gbp_per_gpu": gbp, "total_gbp": gbp * world,
+            "reads_per_gpu": n_reads, "kmers_per_gpu": kmers, "table_slots_per_gpu": 1 << lsize, "global_table_slots": 1 << (lsize + sb), "slot_bytes": slot_bytes,
+            "scaling": "weak", "steps": args.steps, "warmup": args.warmup,
+            "launch": "one process per GPU (torch.distributed.run or bench.py's own launcher), RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 from the environment",
+            "exchange": None if world == 1 else "jfgpu_comm_count_ascii_dev per step: route by hash prefix, ncclSend / ncclRecv of 4-byte items grouped for the receiver, insert",
+            "hbm_bytes_per_gpu": {"table": table, "reads": reads, "workspace_estimate": workspace, "total_estimate": table + reads + workspace},
+            "workload": (CONFIGS[cfg]["name"].format(gbp=gbp, lsize=lsize, slot_bytes=slot_bytes) if world == 1 else
+                         C4_NAME.format(total=gbp * world, world=world, gbp=gbp, lsize=lsize, slot_bytes=slot_bytes))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -277,7 +309,11 @@ def main():
     ap.add_argument("--dist", choices=["U", "G"], default="U",
                     help="U: iid uniform reads (the metric's configuration); G: BASELINE.md's secondary distribution, reads sampled from a "
                          "100 Mbp random genome with 1 %% substitutions (about 100x coverage at 10 Gbp: most k-mers repeat)")
+    ap.add_argument("--plan", action="store_true", help="print the run's workload as JSON (what every rank would be given) and exit: no GPU needed")
     args = ap.parse_args()
+    if args.plan:
+        print(json.dumps(plan(args)))
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
     if args.as_secondary:
