@@ -390,7 +390,9 @@ int part_flush_t(jfgpu_table* t) {
     const bool single_ok = kSingleItems && t->tun.p2_single && (sizeof(ITEM) >= 8 || pair) && t->tun.flush_groups <= 1;      // (4-byte items: pairs only; 8- and 16-byte items: single tiles)
     const uint64_t n_dest = pair ? n_tiles >> 1 : n_tiles;
     if(single_ok) {
-      const uint64_t mean = total / n_dest, strand = (uint64_t)kG2Single * kGran;
+      // what a destination's region may lose to reservations nobody fills: one granule per block -- two with the ring kernel,
+      // whose owners ask for the next reservation a round ahead -- and the holes behind the blocks' last units
+      const uint64_t mean = total / n_dest, strand = (uint64_t)kG2Single * kGran * (sizeof(ITEM) == 4 && t->tun.p2_ring ? 2 : 1) + (sizeof(ITEM) == 4 && t->tun.p2_ring ? kGran : 0);
       if(mean >= 8 * strand || t->tun.p2_single > 1) {
         // head-room over the mean load: a pair of tiles takes ~8 K items a flush, 1 % standard deviation on uniform reads --
         // but on high-coverage input its ~100 hot k-mers come 80 times each (10 %), and what overflows a region is
@@ -492,10 +494,35 @@ int part_flush_t(jfgpu_table* t) {
           ITEM* out_v = out2 - (share_groups ? (int64_t)d0 * (int64_t)cap2 : 0);
           if constexpr(sizeof(ITEM) == 4) {
             const size_t lds = (size_t)kPBlock * kP2PairPer * sizeof(ITEM);
-#define P2G(RT, PF) hipLaunchKernelGGL((p2_granule_kernel<uint32_t, TableDirect<RT>, kP2PairPer, 0, PF>), g1p, block, lds, t->stream, TableDirect<RT>{t->d_dt, t->pg, (unsigned long long*)&t->dt.counters[CTR_DIRECT]}, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest, (uint32_t*)out_v, b0)
-            if(t->tun.p2_prefetch) { if(rt) P2G(true, true); else P2G(false, true); }
-            else { if(rt) P2G(true, false); else P2G(false, false); }
-#undef P2G
+            if(t->tun.p2_ring) {
+              // rings per destination, like P1 (kernels_p1ring.hip.hpp); what does not go through a ring is appended to its
+              // region by the straggler kernel before the regions' bounds are taken
+              const uint32_t n_lists = kG2Single * nbk;
+              if(!t->d_strag2 || t->strag2_lists < n_lists) {
+                if(t->d_strag2) { hipFree(t->d_strag2); hipFree(t->d_strag2_n); t->d_strag2 = nullptr; t->d_strag2_n = nullptr; }
+                HIP_TRY(hipMalloc((void**)&t->d_strag2, (size_t)n_lists * kP2StragPerBlock * sizeof(uint64_t)));
+                HIP_TRY(hipMalloc((void**)&t->d_strag2_n, (size_t)n_lists * sizeof(uint32_t)));
+                t->strag2_lists = n_lists;
+              }
+              const P2RingDirect pd{t->d_dt, t->pg.b2, pg2.b2, (int)rt};
+              unsigned long long* ctr = (unsigned long long*)&t->dt.counters[CTR_DIRECT];
+              hipLaunchKernelGGL((p2_ring_kernel<P2RingDirect>), g1p, block, ((size_t)1 << pg2.b2) * 128 + 128, t->stream, pd, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest,
+                                 (uint32_t*)out_v, b0, (unsigned long long*)nullptr, t->d_strag2, t->d_strag2_n, ctr);
+              hipLaunchKernelGGL((p1_stragglers_kernel<uint32_t, P2RingDirect>), dim3(t->n_cu), dim3(256), 0, t->stream, pd, ctr, (const uint64_t*)t->d_strag2, (const uint32_t*)t->d_strag2_n,
+                                 n_lists, cap2, d_gcur2, (unsigned long long*)nullptr, (uint32_t*)out_v, kP2StragPerBlock);
+              if(t->tun.flush_trace) {        // how full the blocks' straggler lists ran
+                std::vector<uint32_t> hn(n_lists);
+                HIP_TRY(hipStreamSynchronize(t->stream));
+                HIP_TRY(hipMemcpy(hn.data(), t->d_strag2_n, n_lists * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                uint64_t sum = 0; uint32_t mx = 0, at_cap = 0, over256 = 0;
+                for(uint32_t v : hn) { sum += v; mx = std::max(mx, v); at_cap += v >= kP2StragPerBlock; over256 += v > 256; }
+                fprintf(stderr, "[jfgpu flush] P2 ring stragglers: %llu in %u lists, max %u, %u lists > 256, %u lists full\n", (unsigned long long)sum, n_lists, mx, over256, at_cap);
+                for(uint32_t l = 0, shown = 0; l < n_lists && shown < 8; ++l) if(hn[l] >= kP2StragPerBlock) { fprintf(stderr, "[jfgpu flush]   full list %u (bucket %u, block %u)\n", l, b0 + l / kG2Single, l % kG2Single); ++shown; }
+              }
+            } else {
+              if(rt) hipLaunchKernelGGL((p2_granule_kernel<uint32_t, TableDirect<true>, kP2PairPer>), g1p, block, lds, t->stream, TableDirect<true>{t->d_dt, t->pg, (unsigned long long*)&t->dt.counters[CTR_DIRECT]}, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest, (uint32_t*)out_v, b0);
+              else   hipLaunchKernelGGL((p2_granule_kernel<uint32_t, TableDirect<false>, kP2PairPer>), g1p, block, lds, t->stream, TableDirect<false>{t->d_dt, t->pg, (unsigned long long*)&t->dt.counters[CTR_DIRECT]}, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest, (uint32_t*)out_v, b0);
+            }
           } else if constexpr(sizeof(ITEM) == 8) {     // keys of 22 to 32 bases: 8-byte items into single tiles, chunks of 112 KiB
             const size_t lds = (size_t)kPBlock * kP2MidPer * sizeof(ITEM);
             if(rt) hipLaunchKernelGGL((p2_granule_kernel<uint64_t, TableDirect<true>, kP2MidPer>), g1p, block, lds, t->stream, TableDirect<true>{t->d_dt, t->pg, (unsigned long long*)&t->dt.counters[CTR_DIRECT]}, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest, (uint64_t*)out_v, b0);

@@ -127,6 +127,7 @@ struct jfgpu_table {
   double items_per_byte = 0;     // k-mers per sequence byte seen by the last flush (0: unknown yet)
   uint64_t reserved_input = 0;   // sequence bytes the caller announced (jfgpu_reserve): lets forced flushes be spaced evenly
   uint32_t* d_M1 = nullptr; int g1 = 0;
+  uint64_t* d_strag2 = nullptr; uint32_t* d_strag2_n = nullptr; uint32_t strag2_lists = 0;      // ... and of the ring P2, one per workgroup
   uint64_t* d_strag = nullptr; uint32_t* d_strag_n = nullptr;      // straggler lists of the ring P1 (kernels_p1ring.hip.hpp), one per workgroup
   uint32_t* d_M2 = nullptr; int g2 = 0;
   // workspace arena for pending batches and flush temporaries: bump-allocated, reset at flush,
@@ -713,6 +714,7 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     {
       const int rl = kGranMaxB * 128 + 128;
 #define RATTR(IT, BL, N, CN) HIP_TRY(hipFuncSetAttribute((const void*)p1_ring_kernel<IT, BL, N, CN>, hipFuncAttributeMaxDynamicSharedMemorySize, rl))
+      HIP_TRY(hipFuncSetAttribute((const void*)p2_ring_kernel<P2RingDirect>, hipFuncAttributeMaxDynamicSharedMemorySize, rl));
       RATTR(uint32_t, false, 6, 1); RATTR(uint32_t, false, 6, 0); RATTR(uint32_t, true, 0, 2); RATTR(uint32_t, false, 0, 2);
 #undef RATTR
     }
@@ -727,8 +729,6 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
 #undef SATTR
     HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint64_t, TableDirect<true>, kP2MidPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2MidPer * 8));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint64_t, TableDirect<false>, kP2MidPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2MidPer * 8));
-    HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint32_t, TableDirect<true>, kP2PairPer, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
-    HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint32_t, TableDirect<false>, kP2PairPer, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint32_t, TableDirect<true>, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint32_t, TableDirect<false>, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint32_t, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
@@ -773,6 +773,8 @@ void jfgpu_destroy(jfgpu_table* t) {
   part_discard(t);
   if(t->d_M1) hipFree(t->d_M1);
   if(t->d_strag) hipFree(t->d_strag);
+  if(t->d_strag2) hipFree(t->d_strag2);
+  if(t->d_strag2_n) hipFree(t->d_strag2_n);
   if(t->d_strag_n) hipFree(t->d_strag_n);
   if(t->d_M2) hipFree(t->d_M2);
   if(t->ws) hipFree(t->ws);

@@ -83,16 +83,17 @@ template <typename ITEM, typename F> __device__ __forceinline__ void chunk_items
   else f((ITEM)(((unsigned __int128)(((uint64_t)v.w << 32) | v.z) << 64) | (((uint64_t)v.y << 32) | v.x)));
 }
 
-// entry of a straggler list: occurrences << 48 | bucket << 32 (| the item, when it has 32 bits), then the item's words
+// entry of a straggler list: occurrences (8 bits) << 56 | bucket (24 bits) << 32 (| the item, when it has 32 bits), then the
+// item's words
 template <typename ITEM> __device__ __forceinline__ void strag_store(uint64_t* rec, uint32_t b, ITEM item, uint32_t cnt) {
-  const uint64_t meta = ((uint64_t)cnt << 48) | ((uint64_t)b << 32);
+  const uint64_t meta = ((uint64_t)(cnt < 255u ? cnt : 255u) << 56) | ((uint64_t)(b & 0xFFFFFFu) << 32);
   if constexpr(sizeof(ITEM) == 4) rec[0] = meta | (uint32_t)item;
   else if constexpr(sizeof(ITEM) == 8) { rec[0] = meta; rec[1] = (uint64_t)item; }
   else { rec[0] = meta; rec[1] = (uint64_t)item; rec[2] = (uint64_t)(item >> 64); }
 }
 template <typename ITEM> __device__ __forceinline__ void strag_load(const uint64_t* rec, uint32_t& b, ITEM& item, uint32_t& cnt) {
   const uint64_t meta = rec[0];
-  b = (uint32_t)(meta >> 32) & 0xFFFFu; cnt = (uint32_t)(meta >> 48);
+  b = (uint32_t)(meta >> 32) & 0xFFFFFFu; cnt = (uint32_t)(meta >> 56);
   if constexpr(sizeof(ITEM) == 4) item = (ITEM)(uint32_t)meta;
   else if constexpr(sizeof(ITEM) == 8) item = (ITEM)rec[1];
   else item = (ITEM)(((unsigned __int128)rec[2] << 64) | rec[1]);
@@ -338,12 +339,12 @@ template <typename ITEM, typename DIRECT>
 __global__ __launch_bounds__(256) void p1_stragglers_kernel(DIRECT D, unsigned long long* __restrict__ ctr_direct, const uint64_t* __restrict__ strag,
                                                             const uint32_t* __restrict__ strag_n, uint32_t n_lists, uint32_t cap,
                                                             unsigned int* __restrict__ gcur, unsigned long long* __restrict__ tot,
-                                                            ITEM* __restrict__ out) {
+                                                            ITEM* __restrict__ out, uint32_t list_cap = kStragPerBlock) {
   using R = Ring<ITEM>;
   uint32_t my_direct = 0;
   for(uint32_t l = blockIdx.x; l < n_lists; l += gridDim.x) {
     const uint32_t n = strag_n[l];
-    const uint64_t* rec = strag + (size_t)l * kStragPerBlock * R::kWords;
+    const uint64_t* rec = strag + (size_t)l * list_cap * R::kWords;
     for(uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
       uint32_t b, cnt; ITEM item;
       strag_load<ITEM>(rec + (size_t)i * R::kWords, b, item, cnt);
@@ -363,5 +364,154 @@ struct OneWordDirect {
   const DevTable* Tm; uint32_t b2; int returning;
   __device__ void operator()(uint32_t b, uint64_t item, uint32_t cnt) const { item_direct_call(Tm, b2, b, item, cnt, returning); }
 };
+
+// ---- P2 with the same rings (round 4): every P1 bucket -> its pairs of tiles, 32-bit items -----------------------------
+// p2_granule_kernel counting-sorts chunks of 28 Ki items in LDS (histogram, scan, ranked scatter, read-back with a placement
+// look-up per item: five barriers a chunk) and writes runs of ~28 items wherever a destination's run of the chunk starts:
+// 29.5 ms for the 8.67 G items of the metric's job.  P2 has no hashing to do -- an item names its destination in a few of
+// its own bits -- so with P1's rings (kernels above) it is a stream: two 16-byte loads give a lane its eight items of a
+// round, each is appended to its destination's ring (one returning ds_add, one store), and after the round's barrier the
+// owner lanes write out the units that are complete (aligned 64-byte runs).  grid = (blocks per bucket, buckets); the
+// blocks of a bucket share its destinations' regions through the granule reservations, like P1's blocks.
+// DIRECT: (destination, item, occurrences) for what cannot be stored in a region; strag: one list of kP2StragPerBlock
+// entries per block.
+// Measured on the metric's job (profiles/r04_p2_ring.log): 27.8 ms with one barrier a round -- a wave that is through its
+// flush appended the next round into rings not yet released, 6.7 M stragglers a flush against the 0.3 M the rings' own
+// overflow gives, and on BASELINE.md's secondary distribution the lists ran full (350 K global-atomic inserts dirtying
+// tiles); 21.7 ms with a second barrier after the flush (0.4 M stragglers); 19.6 ms with the next round's loads issued
+// before the current round is appended, in straight-line code (with the loads under the tail's conditions the compiler
+// waited for them on the spot: s_waitcnt vmcnt(0) at the control-flow merge).
+constexpr uint32_t kP2StragPerBlock = 2048;                                    // entries of a block's straggler list (the iid model: ~70 a block)
+
+struct P2RingDirect {
+  const DevTable* Tm; uint32_t b2; uint32_t dest_shift; int returning;      // destination >> dest_shift = the P1 bucket
+  __device__ void operator()(uint32_t dest, uint64_t item, uint32_t cnt) const { item_direct_call(Tm, b2, dest >> dest_shift, item, cnt, returning); }
+};
+
+template <typename DIRECT>
+__global__ __launch_bounds__(kPBlock) void p2_ring_kernel(DIRECT D, uint32_t b2e, uint32_t tag_bits, SegList S, uint32_t cap,
+                                                          unsigned int* __restrict__ gcur, unsigned int* __restrict__ gshort,
+                                                          uint32_t* __restrict__ out, uint32_t bucket0, unsigned long long* __restrict__ tot,
+                                                          uint64_t* __restrict__ strag, uint32_t* __restrict__ strag_n, unsigned long long* __restrict__ ctr_direct) {
+  using R = Ring<uint32_t>;
+  constexpr int RP = 8;                                            // items per lane and round: two 16-byte loads
+  JF_DYN_LDS(s_dyn);
+  uint32_t* s_ring = reinterpret_cast<uint32_t*>(s_dyn);          // [nb][32], then 32 dump slots
+  __shared__ uint32_t s_fill[kGranMaxB];
+  __shared__ uint32_t s_nstrag;
+  const uint32_t nb = 1u << b2e;
+  const uint32_t bucket = bucket0 + blockIdx.y;
+  const uint32_t dest0 = bucket * nb;                              // this bucket's first destination
+  const uint32_t t = threadIdx.x, lane = t & 63;
+  const bool owner = t < nb;
+  const uint32_t hole = 0xFFFFFFFFu;
+  ring_init<uint32_t>(s_ring, s_fill, nb, &s_nstrag);
+  const uint32_t dump = nb * R::kSlots + (lane & (R::kSlots - 1));
+  unsigned int* const gc = gcur + dest0;
+  unsigned int* const gs = gshort + dest0;
+  const uint32_t list = blockIdx.y * gridDim.x + blockIdx.x;
+  uint64_t* const my_strag = strag + (size_t)list * kP2StragPerBlock;
+  RingBooks B;
+  if(owner) { B.nxt = atomicAdd(&gc[t], kGran); B.nxt_asked = true; }
+  uint32_t* const my_region = out + ((uint64_t)dest0 + t) * cap;
+  uint32_t my_direct = 0;
+  auto straggler = [&](uint32_t d, uint32_t item, uint32_t cnt) {   // d: destination inside this bucket
+    const uint32_t at = atomicAdd(&s_nstrag, 1u);
+    if(at < kP2StragPerBlock) strag_store<uint32_t>(my_strag + at, dest0 + d, item, cnt);
+    else { D(dest0 + d, (uint64_t)item, cnt); ++my_direct; }
+  };
+  // ring_flush speaks of "bucket t" with gcur / gshort indexed from the workgroup's first one: here, destinations
+  auto flush = [&](bool all) { if(owner) ring_flush<uint32_t>(s_ring, s_fill, t, all, B, my_region, cap, gc, gs, straggler); };
+  lds_barrier();
+  // The rounds of this block, over the batches' regions for the bucket: batch s's region is cut among the bucket's blocks
+  // at multiples of four items (16-byte loads; regions start at multiples of 64 items).  The items of round r + 1 are
+  // requested before round r is appended, so their way from HBM hides behind the appends, the barriers and the flush.
+  uint32_t seg = 0; uint64_t my_a = 0, my_b = 0;
+  const uint32_t* src = nullptr;
+  auto next_seg = [&]() -> bool {
+    for(; seg < S.n; ++seg) {
+      const uint64_t a0 = seg_lo(S, seg, bucket), b0 = seg_hi(S, seg, bucket);
+      const uint64_t len4 = (b0 - a0 + 3) / 4;
+      const uint64_t per4 = (len4 + gridDim.x - 1) / gridDim.x;
+      const uint64_t q0 = (uint64_t)blockIdx.x * per4, q1 = q0 + per4;
+      const uint64_t e1 = a0 + 4 * (q1 < len4 ? q1 : len4);
+      my_a = a0 + 4 * (q0 < len4 ? q0 : len4); my_b = e1 < b0 ? e1 : b0;
+      src = reinterpret_cast<const uint32_t*>(S.items[seg]);
+      if(my_a < my_b) return true;
+    }
+    return false;
+  };
+  constexpr uint64_t RS = (uint64_t)kPBlock * RP;                  // items of a round
+  // a whole round: two unconditional 16-byte loads (straight-line code, so that the wait for them can be counted and sits
+  // where the values are first used)
+  auto load_full = [&](uint64_t r0, uint32_t (&it)[RP]) {
+#pragma unroll
+    for(int h = 0; h < RP / 4; ++h) {
+      const uint4 v = *reinterpret_cast<const uint4*>(src + r0 + (uint64_t)h * kPBlock * 4 + 4 * (uint64_t)t);
+      it[4 * h] = v.x; it[4 * h + 1] = v.y; it[4 * h + 2] = v.z; it[4 * h + 3] = v.w;
+    }
+  };
+  // the last, partial round of a batch's region
+  auto load_partial = [&](uint64_t r0, uint32_t (&it)[RP]) {
+#pragma unroll
+    for(int h = 0; h < RP / 4; ++h) {
+      const uint64_t i = r0 + (uint64_t)h * kPBlock * 4 + 4 * (uint64_t)t;
+      uint4 v = make_uint4(hole, hole, hole, hole);
+      if(i + 4 <= my_b) v = *reinterpret_cast<const uint4*>(src + i);
+      else if(i < my_b) { v.x = src[i]; if(i + 1 < my_b) v.y = src[i + 1]; if(i + 2 < my_b) v.z = src[i + 2]; }
+      it[4 * h] = v.x; it[4 * h + 1] = v.y; it[4 * h + 2] = v.z; it[4 * h + 3] = v.w;
+    }
+  };
+  auto process = [&](const uint32_t (&it)[RP]) {
+    uint32_t ea[RP], eo[RP];
+#pragma unroll
+    for(int e = 0; e < RP; ++e) {
+      ea[e] = dump; eo[e] = 0;
+      if(it[e] != hole) { const uint32_t d = (it[e] >> tag_bits) & (nb - 1); ea[e] = d * R::kSlots; eo[e] = atomicAdd(&s_fill[d], 1u); }
+    }
+    uint32_t ghosts = 0;
+#pragma unroll
+    for(int e = 0; e < RP; ++e) {
+      const uint32_t full = eo[e] & R::kFull;
+      ghosts |= full;
+      const uint32_t at = ea[e] + ((eo[e] + (eo[e] >> 16)) & (R::kSlots - 1));
+      s_ring[full ? dump : at] = it[e];
+    }
+    if(ghosts) {
+#pragma unroll 1
+      for(int e = 0; e < RP; ++e) if(eo[e] & R::kFull) straggler(ea[e] / R::kSlots, it[e], 1u);
+    }
+    lds_barrier();                                                 // the round's items have all landed
+    flush(false);
+    // Without this barrier a wave that is through its flush appends the next round into rings whose owners have not
+    // released them yet: ~25 x the stragglers of the rings' own overflow (measured: 6.7 M a flush of 8.67 G items against
+    // the 0.3 M of the iid model; P2 27.4 ms instead of 21.7).
+    lds_barrier();
+  };
+  for(bool have = next_seg(); have; ++seg, have = next_seg()) {    // (have: the same for every lane of the block)
+    uint64_t r0 = my_a;
+    const uint64_t n_full = (my_b - my_a) / RS;
+    if(n_full) {
+      uint32_t nx[RP];
+      load_full(r0, nx);
+#pragma unroll 1
+      for(uint64_t k = 0; k < n_full; ++k) {
+        uint32_t it[RP];
+#pragma unroll
+        for(int e = 0; e < RP; ++e) it[e] = nx[e];
+        r0 += RS;
+        load_full(k + 1 < n_full ? r0 : my_a, nx);                 // (after the last round: a load nobody looks at)
+        process(it);
+      }
+    }
+    if(r0 < my_b) { uint32_t it[RP]; load_partial(r0, it); process(it); }
+  }
+  lds_barrier();
+  flush(true);
+  if(owner) ring_finish<uint32_t>(B, t, my_region, cap, gs, tot ? tot + dest0 : nullptr);
+  lds_barrier();
+  if(t == 0) strag_n[list] = s_nstrag < kP2StragPerBlock ? s_nstrag : kP2StragPerBlock;
+  if(my_direct) atomicAdd(ctr_direct, (unsigned long long)my_direct);
+}
 
 }  // namespace jfgpu

@@ -879,9 +879,9 @@ struct TableDirect {
 };
 
 // ITEM: uint32_t or unsigned __int128; DIRECT: see TableDirect (kernels_wide_part.hip.hpp has the two-word one).
-// PREFETCH: the next chunk's items are requested into a second set of registers before the current chunk is sorted, so
-// that their way from HBM hides behind the LDS work (one workgroup per CU: nothing else would issue loads meanwhile).
-template <typename ITEM, typename DIRECT, int PER_THREAD, int SMALL = 0, bool PREFETCH = false>
+// (Requesting the next chunk into a second set of registers before the current one is sorted was measured in round 4: no
+// gain, 29.5 ms either way on the metric's job -- the five barriers of a chunk are the cost, not the loads' latency.)
+template <typename ITEM, typename DIRECT, int PER_THREAD, int SMALL = 0>
 __global__ __launch_bounds__(kPBlock) void p2_granule_kernel(DIRECT D, uint32_t b2e, uint32_t tag_bits, SegList S, uint32_t cap,
                                                              unsigned int* __restrict__ gcur, unsigned int* __restrict__ gshort,
                                                              ITEM* __restrict__ out, uint32_t bucket0,
@@ -929,8 +929,6 @@ __global__ __launch_bounds__(kPBlock) void p2_granule_kernel(DIRECT D, uint32_t 
       slo = shi;
     }
   };
-  ITEM nxt[PREFETCH ? PER_THREAD : 1]; uint32_t nvm = 0, nhm = 0;
-  if constexpr(PREFETCH) load_chunk(my_lo, nxt, nvm, nhm);
   for(uint64_t c0 = my_lo; c0 < my_hi; c0 += kChunk) {
     lds_barrier();                                      // previous chunk's readers are done
     JF_PHASE(pc, 0);
@@ -938,12 +936,7 @@ __global__ __launch_bounds__(kPBlock) void p2_granule_kernel(DIRECT D, uint32_t 
     ITEM it[PER_THREAD];
     uint32_t rk[(PER_THREAD + 1) / 2];                  // rank inside the chunk's bucket, 16 bits each
     uint32_t hm = 0, vm = 0;
-    if constexpr(PREFETCH) {
-      hm = nhm; vm = nvm;
-#pragma unroll
-      for(int r = 0; r < PER_THREAD; ++r) it[r] = nxt[r];
-      load_chunk(c0 + kChunk, nxt, nvm, nhm);
-    } else load_chunk(c0, it, vm, hm);
+    load_chunk(c0, it, vm, hm);
     lds_barrier();
     JF_PHASE(pc, 1);
     if constexpr(SMALL != 0) {

@@ -27,7 +27,7 @@ struct Tuning {
   int tile_adapt = 1;            // JFGPU_TILE_ADAPT       tile kernel instantiation: 1 sampled per flush, 0 always plain, 2 always HEAVY
   uint32_t flush_share = 0;      // JFGPU_FLUSH_SHARE      force a flush into this many bucket groups sharing one P2 buffer (tests)
   bool flush_trace = false;      // JFGPU_FLUSH_TRACE      one stderr line per flush
-  int p2_prefetch = 1;           // JFGPU_P2_PREFETCH      single-pass P2 of 4-byte items: next chunk requested before the current one is sorted (0: A/B)
+  int p2_ring = 1;               // JFGPU_P2_RING          single-pass P2 of 4-byte items through per-destination rings (0: the sort-based kernel, A/B)
   // ---- Bloom counters (jfgpu_bloom_create)
   int bloom_mode = 0;            // JFGPU_BLOOM_MODE=direct|partitioned      0: not set
   // ---- communicators (jfgpu_comm_create*)
@@ -53,7 +53,7 @@ struct Tuning {
     if(const char* e = str("JFGPU_TILE_ADAPT")) u.tile_adapt = atoi(e);
     if(const char* e = str("JFGPU_FLUSH_SHARE")) u.flush_share = (uint32_t)atoi(e);
     u.flush_trace = str("JFGPU_FLUSH_TRACE") != nullptr;
-    if(const char* e = str("JFGPU_P2_PREFETCH")) u.p2_prefetch = atoi(e);
+    if(const char* e = str("JFGPU_P2_RING")) u.p2_ring = atoi(e);
     if(const char* e = str("JFGPU_BLOOM_MODE")) u.bloom_mode = !strcmp(e, "direct") ? 1 : !strcmp(e, "partitioned") ? 2 : 0;
     u.comm_trace = str("JFGPU_COMM_TRACE") != nullptr;
     if(const char* e = str("JFGPU_COMM_TRANSPORT")) u.comm_ipc = !strcmp(e, "ipc");
