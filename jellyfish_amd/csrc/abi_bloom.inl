@@ -22,6 +22,7 @@ struct jfgpu_bloom {
   struct Pending { uint32_t* items; uint64_t* off; unsigned long long* tot; uint32_t cap; };
   std::vector<Pending> pending;
   uint32_t* d_M2 = nullptr;
+  uint64_t* d_strag2 = nullptr; uint32_t* d_strag2_n = nullptr; uint32_t strag2_lists = 0;     // p2_ring_kernel's straggler lists
   bool prof_on = false;
   std::vector<ProfSpan> spans;
   double prof_ms[4] = {}; uint64_t prof_launches[4] = {}, prof_units[4] = {};
@@ -117,6 +118,7 @@ static int bloom_create(const jfgpu_bloom_params* p, jfgpu_bloom** out, uint32_t
     HIP_TRY(hipFuncSetAttribute((const void*)bloom_segment_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 1 << kBloomSegBits));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint32_t, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint32_t, BloomDirect, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
+    HIP_TRY(hipFuncSetAttribute((const void*)p2_ring_kernel<BloomRingDirect>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kGranMaxB * 128 + 128)));
   }
   HIP_TRY(hipMalloc((void**)&b->d_data, b->alloc_bytes));
   HIP_TRY(hipMemsetAsync(b->d_data, 0, b->alloc_bytes, b->stream));
@@ -139,6 +141,7 @@ void jfgpu_bc_destroy(jfgpu_bloom* b) {
   if(b->d_stage) hipFree(b->d_stage);
   if(b->ws) hipFree(b->ws);
   if(b->d_M2) hipFree(b->d_M2);
+  if(b->d_strag2) { hipFree(b->d_strag2); hipFree(b->d_strag2_n); }
   if(b->stream) hipStreamDestroy(b->stream);
   delete b;
 }

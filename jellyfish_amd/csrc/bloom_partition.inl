@@ -212,7 +212,8 @@ int bloom_flush_inner(jfgpu_bloom* b) {
     unsigned int* d_gcur2 = nullptr; uint64_t* d_off2 = nullptr; uint32_t* out2 = nullptr;
     const int p2_single = b->tun.p2_single;
     if(p2_single) {
-      const uint64_t mean = total / std::max<uint32_t>(1, b->bp.n_seg), strand = (uint64_t)kG2Single * kGran;   // (the array ends before the last bucket does)
+      const bool ring2 = b->tun.p2_ring && nb2 <= kGranMaxB;      // (its owners hold a second reservation: see part_flush_t)
+      const uint64_t mean = total / std::max<uint32_t>(1, b->bp.n_seg), strand = (uint64_t)kG2Single * kGran * (ring2 ? 2 : 1) + (ring2 ? kGran : 0);   // (the array ends before the last bucket does)
       if(mean >= 8 * strand || p2_single > 1) {
         cap2 = (uint32_t)(((uint64_t)((double)mean * 1.08) + strand + 2 * kGran - 1) / kGran * kGran);
         const size_t mark = b->ws_used;
@@ -230,6 +231,7 @@ int bloom_flush_inner(jfgpu_bloom* b) {
     uint32_t* tmp = cap2 ? out2 : (uint32_t*)bloom_ws_alloc(b, tmp_items * sizeof(uint32_t));
     if(!d_goff || !d_base || !tmp) return fail(JFGPU_E_ALLOC, "Bloom partition workspace too small for the flush");
     const uint32_t gsz = nb1 / n_groups;
+    if(b->tun.flush_trace) fprintf(stderr, "[jfgpu flush] Bloom: %zu batches, %llu cell updates, %u bucket groups of %u, regions of %u\n", nbatch, (unsigned long long)total, n_groups, gsz, cap2);
     std::vector<uint64_t> basev(nb1);
     { uint64_t run = 0; for(uint32_t j = 0; j < nb1; ++j) { if(j % gsz == 0) run = 0; basev[j] = run; run += bucket_tot[j]; } }
     HIP_TRY(hipMemcpyAsync(d_base, basev.data(), nb1 * sizeof(uint64_t), hipMemcpyHostToDevice, b->stream));
@@ -243,10 +245,33 @@ int bloom_flush_inner(jfgpu_bloom* b) {
         uint32_t* out_v = out2 - (n_groups > 1 ? (int64_t)seg0 * (int64_t)cap2 : 0);      // segment d of the whole array sits at d * cap2
         {
           BloomProf ps(b, BS_P2, gtot);
-          const dim3 g1p(kG2Single, gsz), block(kPBlock);
+          const dim3 block(kPBlock);
           const BloomDirect D{B, b->bp, reinterpret_cast<unsigned long long*>(d_gcur2 + 2 * n_tiles)};
-          hipLaunchKernelGGL((p2_granule_kernel<uint32_t, BloomDirect, kP2PairPer>), g1p, block, (size_t)kPBlock * kP2PairPer * sizeof(uint32_t), b->stream,
-                             D, b->bp.b2, kBloomItemLow, S1, cap2, d_gcur2, d_gcur2 + n_tiles, out_v, b0);
+          // The count path's ring kernel (kernels_p1ring.hip.hpp) -- a cell update names its segment in its own bits too --
+          // for the buckets whose segments all exist.  The array ends inside the last bucket: its rounds of 8 Ki updates
+          // fall on a fraction of the 1024 rings and overflow them (measured: that one bucket's four blocks, all through
+          // the lists and global atomics, doubled the stage's time), so it keeps the sort-based kernel, like every bucket
+          // when JFGPU_P2_RING=0.
+          const uint32_t whole = (uint32_t)std::min<uint64_t>(b->bp.n_seg >> b->bp.b2, (uint64_t)b0 + gsz);   // buckets below this one are whole
+          const uint32_t n_ring = b->tun.p2_ring && nb2 <= kGranMaxB && whole > b0 ? whole - b0 : 0;
+          if(n_ring) {
+            const uint32_t n_lists = kG2Single * n_ring;
+            if(!b->d_strag2 || b->strag2_lists < n_lists) {
+              if(b->d_strag2) { hipFree(b->d_strag2); hipFree(b->d_strag2_n); b->d_strag2 = nullptr; b->d_strag2_n = nullptr; }
+              HIP_TRY(hipMalloc((void**)&b->d_strag2, (size_t)n_lists * kP2StragPerBlock * sizeof(uint64_t)));
+              HIP_TRY(hipMalloc((void**)&b->d_strag2_n, (size_t)n_lists * sizeof(uint32_t)));
+              b->strag2_lists = n_lists;
+            }
+            const BloomRingDirect RD{B.data};
+            hipLaunchKernelGGL((p2_ring_kernel<BloomRingDirect>), dim3(kG2Single, n_ring), block, (size_t)nb2 * 128 + 128, b->stream, RD, b->bp.b2, kBloomItemLow, S1, cap2, d_gcur2, d_gcur2 + n_tiles,
+                               out_v, b0, (unsigned long long*)nullptr, b->d_strag2, b->d_strag2_n, D.counter);
+            hipLaunchKernelGGL((p1_stragglers_kernel<uint32_t, BloomRingDirect>), dim3(b->n_cu), dim3(256), 0, b->stream, RD, D.counter, (const uint64_t*)b->d_strag2, (const uint32_t*)b->d_strag2_n,
+                               n_lists, cap2, d_gcur2, (unsigned long long*)nullptr, out_v, kP2StragPerBlock);
+            if(b->tun.flush_trace) { const int rc_ = trace_strag_lists(b->stream, b->d_strag2_n, n_lists, kP2StragPerBlock, kG2Single, b0); if(rc_) return rc_; }
+          }
+          if(n_ring < gsz && (uint64_t)(b0 + n_ring) * nb2 < b->bp.n_seg)
+            hipLaunchKernelGGL((p2_granule_kernel<uint32_t, BloomDirect, kP2PairPer>), dim3(kG2Single, n_ring ? 1 : gsz), block, (size_t)kPBlock * kP2PairPer * sizeof(uint32_t), b->stream,
+                               D, b->bp.b2, kBloomItemLow, S1, cap2, d_gcur2, d_gcur2 + n_tiles, out_v, b0 + n_ring);
           hipLaunchKernelGGL(granule_finish_range_kernel, dim3(256), dim3(256), 0, b->stream, d_gcur2, cap2, (uint32_t)n_tiles, d_off2, (uint32_t)seg0, gsz * nb2);
         }
         if(seg0 >= b->bp.n_seg) break;

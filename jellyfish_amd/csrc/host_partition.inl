@@ -84,6 +84,19 @@ void launch_p1(jfgpu_table* t, bool scatter, bool from_keys, const uint8_t* base
 int part_flush(jfgpu_table* t);
 
 // per-workgroup straggler lists of the ring P1 kernels (kernels_p1ring.hip.hpp), allocated at first use
+// JFGPU_FLUSH_TRACE: how full the blocks' straggler lists of a p2_ring_kernel launch ran (waits for the stream)
+int trace_strag_lists(hipStream_t stream, const uint32_t* d_n, uint32_t n_lists, uint32_t list_cap, uint32_t per_bucket, uint32_t bucket0) {
+  std::vector<uint32_t> hn(n_lists);
+  HIP_TRY(hipStreamSynchronize(stream));
+  HIP_TRY(hipMemcpy(hn.data(), d_n, n_lists * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  uint64_t sum = 0; uint32_t mx = 0, at_cap = 0, over256 = 0;
+  for(uint32_t v : hn) { sum += v; mx = std::max(mx, v); at_cap += v >= list_cap; over256 += v > 256; }
+  fprintf(stderr, "[jfgpu flush] P2 ring stragglers: %llu in %u lists, max %u, %u lists > 256, %u lists full\n", (unsigned long long)sum, n_lists, mx, over256, at_cap);
+  for(uint32_t l = 0, shown = 0; l < n_lists && shown < 8; ++l)
+    if(hn[l] >= list_cap) { fprintf(stderr, "[jfgpu flush]   full list %u (bucket %u, block %u)\n", l, bucket0 + l / per_bucket, l % per_bucket); ++shown; }
+  return JFGPU_OK;
+}
+
 int ensure_strag(jfgpu_table* t) {
   if(t->d_strag) return JFGPU_OK;
   const size_t words = Ring<uint32_t>::kWords;
@@ -510,15 +523,7 @@ int part_flush_t(jfgpu_table* t) {
                                  (uint32_t*)out_v, b0, (unsigned long long*)nullptr, t->d_strag2, t->d_strag2_n, ctr);
               hipLaunchKernelGGL((p1_stragglers_kernel<uint32_t, P2RingDirect>), dim3(t->n_cu), dim3(256), 0, t->stream, pd, ctr, (const uint64_t*)t->d_strag2, (const uint32_t*)t->d_strag2_n,
                                  n_lists, cap2, d_gcur2, (unsigned long long*)nullptr, (uint32_t*)out_v, kP2StragPerBlock);
-              if(t->tun.flush_trace) {        // how full the blocks' straggler lists ran
-                std::vector<uint32_t> hn(n_lists);
-                HIP_TRY(hipStreamSynchronize(t->stream));
-                HIP_TRY(hipMemcpy(hn.data(), t->d_strag2_n, n_lists * sizeof(uint32_t), hipMemcpyDeviceToHost));
-                uint64_t sum = 0; uint32_t mx = 0, at_cap = 0, over256 = 0;
-                for(uint32_t v : hn) { sum += v; mx = std::max(mx, v); at_cap += v >= kP2StragPerBlock; over256 += v > 256; }
-                fprintf(stderr, "[jfgpu flush] P2 ring stragglers: %llu in %u lists, max %u, %u lists > 256, %u lists full\n", (unsigned long long)sum, n_lists, mx, over256, at_cap);
-                for(uint32_t l = 0, shown = 0; l < n_lists && shown < 8; ++l) if(hn[l] >= kP2StragPerBlock) { fprintf(stderr, "[jfgpu flush]   full list %u (bucket %u, block %u)\n", l, b0 + l / kG2Single, l % kG2Single); ++shown; }
-              }
+              if(t->tun.flush_trace) { const int rc_ = trace_strag_lists(t->stream, t->d_strag2_n, n_lists, kP2StragPerBlock, kG2Single, b0); if(rc_) return rc_; }
             } else {
               if(rt) hipLaunchKernelGGL((p2_granule_kernel<uint32_t, TableDirect<true>, kP2PairPer>), g1p, block, lds, t->stream, TableDirect<true>{t->d_dt, t->pg, (unsigned long long*)&t->dt.counters[CTR_DIRECT]}, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest, (uint32_t*)out_v, b0);
               else   hipLaunchKernelGGL((p2_granule_kernel<uint32_t, TableDirect<false>, kP2PairPer>), g1p, block, lds, t->stream, TableDirect<false>{t->d_dt, t->pg, (unsigned long long*)&t->dt.counters[CTR_DIRECT]}, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest, (uint32_t*)out_v, b0);

@@ -48,6 +48,18 @@ struct BloomDirect {
   __device__ unsigned long long* direct_counter() const { return counter; }
 };
 
+// The same for p2_ring_kernel (kernels_p1ring.hip.hpp), which speaks of destinations: destination = segment.  A real call
+// with three scalars-worth of arguments: inlined into the ring kernel with the whole DevBloom, the rare path put 304 bytes
+// of every lane in scratch and the stage ran at half its speed (535 ms against 246 for the sort-based kernel on config 3).
+__device__ __attribute__((noinline)) void bloom_segment_item_direct_call(uint32_t* data, uint32_t seg, uint32_t item) {
+  const uint64_t byte = ((uint64_t)seg << kBloomSegBits) | ((item >> 3) & 0xFFFFu);
+  bloom_bump(data, byte, item & 7u);
+}
+struct BloomRingDirect {
+  uint32_t* data;
+  __device__ void operator()(uint32_t dest, uint64_t item, uint32_t cnt) const { for(uint32_t i = 0; i < cnt; ++i) bloom_segment_item_direct_call(data, dest, (uint32_t)item); }
+};
+
 // ---- P1b ----------------------------------------------------------------------------------------------------
 // One block iteration = 16384 sequence positions.  The lanes roll their 16 windows together, one position per round:
 // a round gives every lane at most kBloomPer items (nh > kBloomPer takes more rounds), 10240 per block, sorted and
