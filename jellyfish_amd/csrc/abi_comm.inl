@@ -64,6 +64,7 @@ struct jfgpu_comm {
     uint64_t* h_route = nullptr;                 // ... pinned copy, read after route_done
     hipEvent_t route_done = nullptr;
     size_t route_n = 0;                          // its input bytes
+    const uint32_t* self_items[2] = {nullptr, nullptr};   // item path, RCCL transport: the rank's own share is read where the routing left it (send[turn]), not copied
   };
 #if !defined(JFGPU_EMU)
   // "ipc" transport (see the head of this file)
@@ -114,7 +115,7 @@ int comm_init_rank(jfgpu_comm* c, jfgpu_comm::Rank& R) {
 }
 
 // ---- the item path: 4 bytes per k-mer, already grouped for the receiver ------------------------------------------
-// Sender: p1_route_granule_kernel = the single-pass P1 over the global table (1024 buckets = owner x coarse bucket), so
+// Sender: p1_ring_kernel<.., RouteListDirect> = the single-pass P1 over the global table (1024 buckets = owner x coarse bucket), so
 // an owner's share is one contiguous run of regions -- equal-sized messages, no counts to exchange.  Receiver: the regions
 // of its coarse buckets from all W senders go through one more split (fan-out W, p2_granule_kernel) into the regions of
 // its own 1024 P1 buckets: a pending batch like any other, applied by the next flush.  Region capacity is agreed per
@@ -216,13 +217,17 @@ int comm_route_items_enqueue(jfgpu_comm* c, jfgpu_comm::Rank& R, const char* d_b
     pg.b1 = L.gbits; pg.b2 = gv.g.lsize_g - gv.g.tile_bits - L.gbits; pg.rest_shift = gv.g.lsize_g - L.gbits; pg.item_bits = pg.rest_shift + gv.g.rem_bits;
     const uint8_t* base; int64_t lo, hi;
     align_buffer(d_bases, n, base, lo, hi);
-    const StragList SL{reinterpret_cast<unsigned long long*>(strag), strag + 1, L.S, 0};
-    const size_t lds = (size_t)kPTilePos * 6;
-    const dim3 grid(2 * t->n_cu), block(kPBlock);
+    const RouteListDirect rd{StragList{reinterpret_cast<unsigned long long*>(strag), strag + 1, L.S, 0}};
+    { const int rc2 = ensure_strag(t); if(rc2) return rc2; }
+    const dim3 grid(t->n_cu), block(kPBlock);
+    const size_t lds = ((size_t)1 << pg.b1) * 128 + 128;
     ProfScope ps(t, 2, n);
-#define PR(N) hipLaunchKernelGGL(p1_route_granule_kernel<N>, grid, block, lds, t->stream, gv, pg, base, lo, hi, cap, R.d_gcur, tot, items, SL)
-    if(t->g.nbytes == 6) PR(6); else if(t->g.nbytes == 7) PR(7); else if(t->g.nbytes == 8) PR(8); else PR(0);
+    // the count path's ring P1 (kernels_p1ring.hip.hpp) over the global geometry; what it cannot store goes on the list
+#define PR(N, CN) hipLaunchKernelGGL((p1_ring_kernel<uint32_t, false, N, CN, RouteListDirect>), grid, block, lds, t->stream, gv, rd, pg, base, lo, hi, cap, R.d_gcur, tot, items, t->d_strag, t->d_strag_n)
+    if(t->g.nbytes == 6) { if(t->g.canonical) PR(6, 1); else PR(6, 0); } else PR(0, 2);
 #undef PR
+    hipLaunchKernelGGL((p1_stragglers_kernel<uint32_t, RouteListDirect>), dim3(t->n_cu), dim3(256), 0, t->stream, rd, (unsigned long long*)nullptr, (const uint64_t*)t->d_strag,
+                       (const uint32_t*)t->d_strag_n, (uint32_t)t->n_cu, cap, R.d_gcur, tot, items, kStragPerBlock);
   }
   hipLaunchKernelGGL(granule_finish_kernel, dim3(4), dim3(256), 0, t->stream, R.d_gcur, cap, L.nbg, offs);
   hipLaunchKernelGGL(comm_claims_kernel, dim3(1), dim3(1024), 0, t->stream, tot, L.nbg, L.nbc, (const uint64_t*)strag, L.S, (uint32_t)c->world,
@@ -306,6 +311,7 @@ int comm_insert_prev_items(jfgpu_comm* c, jfgpu_comm::Rank& R, int rank) {
   const int64_t first = (int64_t)rank * L.nbc;
   for(int p = 0; p < W; ++p) {
     S.items[p] = r_items + (int64_t)p * L.nbc * L.cap - first * (int64_t)L.cap;
+    if(p == rank && !c->local && R.self_items[prev]) S.items[p] = R.self_items[prev];      // (its offsets speak of the sender's whole output: no shift)
     S.off[p] = r_offs + (int64_t)p * 2 * L.nbc - 2 * first;
     S.sh[p] = 1;
   }
@@ -550,9 +556,13 @@ int comm_exchange_items_rccl(jfgpu_comm* c) {
   uint64_t* r_claims = reinterpret_cast<uint64_t*>(rb + L.r_claims_at);
   uint64_t* s_strag = reinterpret_cast<uint64_t*>(sb + L.strag_at);
   auto r_strag = [&](int p) { return reinterpret_cast<uint64_t*>(rb + L.r_strag_at) + (size_t)p * (1 + L.S); };
+  R.self_items[cur] = nullptr;
   if(skip >= 0) {
     const int p = c->rank;
-    HIP_TRY(hipMemcpyAsync(r_items(p), s_items(p), blk * 4, hipMemcpyDeviceToDevice, c->xstream));
+    // The rank's own share does not move: the split reads it from the send buffer (stream order keeps it there: the next
+    // routing into send[cur] is enqueued behind that split, on the table's stream).  At world 8 an eighth of the items, on
+    // one GPU all of them (a 3.5 GB copy per step that ran beside the next step's routing kernel and slowed it).
+    R.self_items[cur] = reinterpret_cast<const uint32_t*>(sb);
     HIP_TRY(hipMemcpyAsync(r_offs(p), s_offs(p), (size_t)2 * L.nbc * 8, hipMemcpyDeviceToDevice, c->xstream));
     HIP_TRY(hipMemcpyAsync(r_claims + p, s_claims + p, 8, hipMemcpyDeviceToDevice, c->xstream));
     HIP_TRY(hipMemcpyAsync(r_strag(p), s_strag, (size_t)(1 + L.S) * 8, hipMemcpyDeviceToDevice, c->xstream));

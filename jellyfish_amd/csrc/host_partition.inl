@@ -214,7 +214,7 @@ int part_ingest(jfgpu_table* t, const uint8_t* base, int64_t lo, int64_t hi, boo
       else if(t->g.nbytes == 8) PK(false, 8);
       else PK(false, 0);
     } else
-#define PG(IT, BL, N, CN) hipLaunchKernelGGL((p1_ring_kernel<IT, BL, N, CN>), dim3(t->n_cu), dim3(kPBlock), (size_t)nb * 128 + 128, t->stream, t->dt, t->d_dt, (int)t->returning, t->pg, base, lo, hi, gcap, gcur, b.tot, (IT*)b.items, t->d_strag, t->d_strag_n)
+#define PG(IT, BL, N, CN) hipLaunchKernelGGL((p1_ring_kernel<IT, BL, N, CN>), dim3(t->n_cu), dim3(kPBlock), (size_t)nb * 128 + 128, t->stream, t->dt, od, t->pg, base, lo, hi, gcap, gcur, b.tot, (IT*)b.items, t->d_strag, t->d_strag_n)
     {
       // what cannot be stored in a region (p1_stragglers_kernel) reads the table's descriptor from device memory
       { int rc = refresh_d_dt(t); if(rc) return rc; }

@@ -188,6 +188,24 @@ __device__ __forceinline__ void ring_finish(const RingBooks& B, uint32_t t, ITEM
   if(tot && B.stored) atomicAdd(&tot[t], (unsigned long long)B.stored);
 }
 
+// What p1_ring_kernel / p1_stragglers_kernel do with an entry that cannot be stored in a region: DIRECT(bucket, item,
+// occurrences).  kCountsDirect: the calls are counted in the table's CTR_DIRECT.
+// (bucket, item, occurrences) of a one-word key into the table with global atomics (item_direct_call)
+struct OneWordDirect {
+  static constexpr bool kCountsDirect = true;
+  const DevTable* Tm; uint32_t b2; int returning;
+  __device__ void operator()(uint32_t b, uint64_t item, uint32_t cnt) const { item_direct_call(Tm, b2, b, item, cnt, returning); }
+};
+// The sending side of the multi-GPU exchange (abi_comm.inl): nothing may be inserted here -- the k-mers belong to other
+// GPUs -- so such entries go on the list of stragglers every rank receives (bucket << 32 | item, once per occurrence).
+struct RouteListDirect {
+  static constexpr bool kCountsDirect = false;
+  StragList SL;
+  __device__ void operator()(uint32_t b, uint64_t item, uint32_t cnt) const {
+    for(uint32_t i = 0; i < cnt; ++i) { const unsigned long long at = atomicAdd(SL.n, 1ull); if(at < SL.cap) SL.rec[at] = ((uint64_t)b << 32) | (uint32_t)item; }
+  }
+};
+
 // ---- one-word keys, 4-byte items (k <= 21 at the metric's geometry) -----------------------------------------------------
 // CANON: 0 forward k-mers, 1 canonical, 2 decided at run time (the table's flag).  A round is 8 positions per lane.
 // The kernel is written over the item type, and was measured with the wider ones (profiles/r04_c5_ring_experiment.log,
@@ -195,8 +213,8 @@ __device__ __forceinline__ void ring_finish(const RingBooks& B, uint32_t t, ITEM
 // against 28.4 for the sort-based p1_granule64_kernel before this round's pack16; 16-byte items (k = 63: rings of 8,
 // units of 4) 130 - 152 ms against 106.  A ring of 128 bytes holds too few wide items: either the rounds get short (a
 // barrier and a flush every two or four positions) or 0.6 % of the items overflow.  Those widths keep the sort.
-template <typename ITEM, bool BLOOM, int NB, int CANON>
-__global__ __launch_bounds__(kPBlock) void p1_ring_kernel(DevTable T, const DevTable* __restrict__ Tmem, int returning, PartGeom P, const uint8_t* __restrict__ base,
+template <typename ITEM, bool BLOOM, int NB, int CANON, typename DIRECT = OneWordDirect>
+__global__ __launch_bounds__(kPBlock) void p1_ring_kernel(DevTable T, DIRECT D, PartGeom P, const uint8_t* __restrict__ base,
                                                           int64_t lo, int64_t hi, uint32_t cap,
                                                           unsigned int* __restrict__ gcur,
                                                           unsigned long long* __restrict__ tot,
@@ -231,11 +249,11 @@ __global__ __launch_bounds__(kPBlock) void p1_ring_kernel(DevTable T, const DevT
   uint32_t my_mers = 0, my_direct = 0;
 
   // not for the rings: on the workgroup's list (p1_stragglers_kernel takes it from there); a full list (an input that
-  // sends everything to a few buckets) falls back to the table's global claim on the spot -- slow, never wrong
+  // sends everything to a few buckets) falls back to DIRECT on the spot (the table's global claim: slow, never wrong)
   auto straggler = [&](uint32_t b, ITEM item, uint32_t cnt) {
     const uint32_t at = atomicAdd(&s_nstrag, 1u);
     if(at < kStragPerBlock) strag_store<ITEM>(my_strag + (size_t)at * R::kWords, b, item, cnt);
-    else { item_direct_call(Tmem, P.b2, b, (uint64_t)item, cnt, returning); ++my_direct; }
+    else { D(b, (uint64_t)item, cnt); ++my_direct; }
   };
 
   const int64_t n_tiles = (hi + kPTilePos - 1) / kPTilePos;
@@ -325,7 +343,7 @@ __global__ __launch_bounds__(kPBlock) void p1_ring_kernel(DevTable T, const DevT
   if(t == 0) strag_n[blockIdx.x] = s_nstrag < kStragPerBlock ? s_nstrag : kStragPerBlock;
   JF_PHASE(pc, 4);
   JF_PHASE_FLUSH(pc, 0);
-  if(my_direct) atomicAdd((unsigned long long*)&T.counters[CTR_DIRECT], (unsigned long long)my_direct);
+  if(DIRECT::kCountsDirect && my_direct) atomicAdd((unsigned long long*)&T.counters[CTR_DIRECT], (unsigned long long)my_direct);
   uint64_t w = my_mers;
   for(int o = 32; o > 0; o >>= 1) w += __shfl_down(w, o, 64);
   if((threadIdx.x & 63) == 0 && w) atomicAdd((unsigned long long*)&T.counters[CTR_MERS], (unsigned long long)w);
@@ -356,14 +374,8 @@ __global__ __launch_bounds__(256) void p1_stragglers_kernel(DIRECT D, unsigned l
       ++my_direct;
     }
   }
-  if(my_direct) atomicAdd(ctr_direct, (unsigned long long)my_direct);
+  if(ctr_direct && my_direct) atomicAdd(ctr_direct, (unsigned long long)my_direct);
 }
-
-// (bucket, item, occurrences) of a one-word key into the table with global atomics (item_direct_call)
-struct OneWordDirect {
-  const DevTable* Tm; uint32_t b2; int returning;
-  __device__ void operator()(uint32_t b, uint64_t item, uint32_t cnt) const { item_direct_call(Tm, b2, b, item, cnt, returning); }
-};
 
 // ---- P2 with the same rings (round 4): every P1 bucket -> its pairs of tiles, 32-bit items -----------------------------
 // p2_granule_kernel counting-sorts chunks of 28 Ki items in LDS (histogram, scan, ranked scatter, read-back with a placement

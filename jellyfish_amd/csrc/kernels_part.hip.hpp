@@ -1027,57 +1027,12 @@ __global__ __launch_bounds__(kPBlock) void p2_granule_kernel(DIRECT D, uint32_t 
 // The single-pass P1 over the GLOBAL table: T is a view of the shard's table whose geometry says "one table of 2^lsize_g
 // slots" (same matrix, same tags), so bucket = top 10 bits of the global position = (owner rank, the owner's coarse
 // bucket) and the regions of one owner are contiguous: they are what travels, 4 bytes per k-mer, already grouped for the
-// receiver.  Nothing may be inserted here (the k-mers belong to other GPUs): runs of identical k-mers are not merged,
-// and what the local P1 would insert directly -- items that do not fit their region, the item that looks like a hole --
-// is appended to a list of stragglers (bucket << 32 | item) every rank receives.
+// receiver.  It is the count path's p1_ring_kernel with RouteListDirect (kernels_p1ring.hip.hpp; round 3's sort-based
+// p1_route_granule_kernel: 48 ms per 10 Gbp where the ring kernel takes 35): nothing may be inserted here (the k-mers
+// belong to other GPUs), so what the local P1 would insert directly -- items that do not fit their region, the item that
+// looks like a hole, runs of identical k-mers -- is appended to a list of stragglers (bucket << 32 | item) every rank
+// receives.
 struct StragList { unsigned long long* n; uint64_t* rec; uint32_t cap; uint32_t pad_; };
-
-template <int NB>
-__global__ __launch_bounds__(kPBlock) void p1_route_granule_kernel(DevTable T, PartGeom P, const uint8_t* __restrict__ base,
-                                                                   int64_t lo, int64_t hi, uint32_t cap,
-                                                                   unsigned int* __restrict__ gcur, unsigned long long* __restrict__ tot,
-                                                                   uint32_t* __restrict__ out, StragList SL) {
-  JF_DYN_LDS(s_dyn);
-  uint32_t* s_item = reinterpret_cast<uint32_t*>(s_dyn);                          // [kPTilePos]
-  uint16_t* s_bkt = reinterpret_cast<uint16_t*>(s_dyn + (size_t)kPTilePos * 4);   // [kPTilePos]
-  __shared__ uint64_t s_fwd[8 * 256];
-  __shared__ uint32_t s_codes[kPBlock + 2];
-  __shared__ uint32_t s_inv[kPBlock + 2];
-  __shared__ GranuleLds G;
-  const uint32_t nb = 1u << P.b1;
-  load_tables_lds(s_fwd, T.fwd_tbl, T.g.nbytes);
-  granule_init(G, nb);
-  const uint32_t bshift = T.g.lsize_l - P.b1;
-  uint32_t my_mers = 0;
-  const int64_t n_tiles = (hi + kPTilePos - 1) / kPTilePos;
-  TileRaw R = tile_fetch(base, (int64_t)blockIdx.x * kPTilePos, lo, hi);
-  for(int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    lds_barrier();
-    for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) G.hist[j] = 0;
-    const LaneWords L = tile_stage(R, tile * kPTilePos, lo, hi, s_codes, s_inv);      // barrier inside
-    R = tile_fetch(base, (tile + gridDim.x) * kPTilePos, lo, hi);
-    uint32_t it[kPerLane], dr[kPerLane];
-#pragma unroll
-    for(int e = 0; e < kPerLane; ++e) dr[e] = 0xFFFFFFFFu;
-    for_each_kmer(T.g, L, [&](int j, uint64_t key) {
-      ++my_mers;
-      const uint64_t pos = hash_tables_t<NB>(s_fwd, key, T.g.nbytes);
-      const uint64_t local = pos & T.g.local_mask;
-      const uint32_t b = (uint32_t)(local >> bshift);
-      it[j] = make_item<uint32_t>(T.g, P, key, local);
-      dr[j] = (b << 16) | atomicAdd(&G.hist[b], 1u);
-    });
-    granule_emit(G, nb, cap, gcur, out, s_item, s_bkt, it, dr,
-                 [&](uint32_t b, uint32_t v) {
-                   const unsigned long long at = atomicAdd(SL.n, 1ull);
-                   if(at < SL.cap) SL.rec[at] = ((uint64_t)b << 32) | v;
-                 });
-  }
-  granule_finish(G, nb, cap, tot, out);
-  uint64_t w = my_mers;
-  for(int o = 32; o > 0; o >>= 1) w += __shfl_down(w, o, 64);
-  if((threadIdx.x & 63) == 0 && w) atomicAdd((unsigned long long*)&T.counters[CTR_MERS], (unsigned long long)w);
-}
 
 // The stragglers a rank received: those of its own buckets go straight to the table.  cbits: bits of the coarse bucket
 // index inside an owner; P: the geometry item_direct_insert needs for (coarse bucket, item).

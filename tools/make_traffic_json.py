@@ -26,6 +26,7 @@ def stage_of(kernel):
     if "bloom_insert" in k or "bloom_items" in k: return "bc_direct"
     if "tile_insert" in k or "tile_rank_insert" in k: return "tile_insert"
     if "items_direct" in k: return "items_direct"
+    if "p1_stragglers" in k and ("P2RingDirect" in k or "BloomRingDirect" in k): return "bc_p2_partition" if cfg == "C3" else "p2_partition"   # P2's lists
     if "jfgpu::p2_" in k or "scan_matrix" in k: return "bc_p2_partition" if cfg == "C3" else "p2_partition"
     if "jfgpu::p1_" in k or "granule_finish" in k: return "p1_partition"
     if "count_ascii" in k: return "count_direct"
