@@ -519,11 +519,17 @@ int part_flush_t(jfgpu_table* t) {
               }
               const P2RingDirect pd{t->d_dt, t->pg.b2, pg2.b2, (int)rt};
               unsigned long long* ctr = (unsigned long long*)&t->dt.counters[CTR_DIRECT];
+              // one workgroup per bucket with loader and storer waves when that fills the chip (p2_ring_roles_kernel), else
+              // several workgroups per bucket sharing the regions through reservations (p2_ring_kernel)
+              const bool roles = t->tun.p2_ring != 3 && nbk >= 2 * (uint32_t)t->n_cu;
+              if(roles) hipLaunchKernelGGL((p2_ring_roles_kernel<P2RingDirect>), dim3(nbk), block, ((size_t)1 << pg2.b2) * 128 + 128, t->stream, pd, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2,
+                                           (uint32_t*)out_v, b0, t->d_strag2, t->d_strag2_n, ctr);
+              else
               hipLaunchKernelGGL((p2_ring_kernel<P2RingDirect>), g1p, block, ((size_t)1 << pg2.b2) * 128 + 128, t->stream, pd, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest,
                                  (uint32_t*)out_v, b0, (unsigned long long*)nullptr, t->d_strag2, t->d_strag2_n, ctr);
               hipLaunchKernelGGL((p1_stragglers_kernel<uint32_t, P2RingDirect>), dim3(t->n_cu), dim3(256), 0, t->stream, pd, ctr, (const uint64_t*)t->d_strag2, (const uint32_t*)t->d_strag2_n,
-                                 n_lists, cap2, d_gcur2, (unsigned long long*)nullptr, (uint32_t*)out_v, kP2StragPerBlock);
-              if(t->tun.flush_trace) { const int rc_ = trace_strag_lists(t->stream, t->d_strag2_n, n_lists, kP2StragPerBlock, kG2Single, b0); if(rc_) return rc_; }
+                                 roles ? nbk : n_lists, cap2, d_gcur2, (unsigned long long*)nullptr, (uint32_t*)out_v, kP2StragPerBlock);
+              if(t->tun.flush_trace) { const int rc_ = trace_strag_lists(t->stream, t->d_strag2_n, roles ? nbk : n_lists, kP2StragPerBlock, roles ? 1 : kG2Single, b0); if(rc_) return rc_; }
             } else {
               if(rt) hipLaunchKernelGGL((p2_granule_kernel<uint32_t, TableDirect<true>, kP2PairPer>), g1p, block, lds, t->stream, TableDirect<true>{t->d_dt, t->pg, (unsigned long long*)&t->dt.counters[CTR_DIRECT]}, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest, (uint32_t*)out_v, b0);
               else   hipLaunchKernelGGL((p2_granule_kernel<uint32_t, TableDirect<false>, kP2PairPer>), g1p, block, lds, t->stream, TableDirect<false>{t->d_dt, t->pg, (unsigned long long*)&t->dt.counters[CTR_DIRECT]}, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest, (uint32_t*)out_v, b0);

@@ -105,7 +105,8 @@ struct RingBooks { uint32_t gpos = 0, room = 0, nxt = 0, stored = 0; bool nxt_as
 
 // What bucket t has complete goes out (owner lanes only).  `all`: the kernel's last call, after a barrier -- every append
 // has landed, and the partial last unit goes out too (the slots behind its items are holes already).
-template <typename ITEM, typename STRAG>
+// OWNED: the region has one writer (this lane) -- B.room is what is left of it, nothing is reserved.
+template <typename ITEM, bool OWNED = false, typename STRAG>
 __device__ __forceinline__ void ring_flush(ITEM* s_ring, uint32_t* s_fill, uint32_t t, bool all, RingBooks& B, ITEM* my_region, uint32_t cap,
                                            unsigned int* gcur, unsigned int* gshort, STRAG&& straggler) {
   using R = Ring<ITEM>;
@@ -126,6 +127,7 @@ __device__ __forceinline__ void ring_flush(ITEM* s_ring, uint32_t* s_fill, uint3
       for(int q = 0; q < 4; ++q) { const uint32_t a = chunk_hole_key<ITEM>(v[q]); mx = mx > a ? mx : a; }
       if(mx == 0xFFFFFFFFu) break;                                 // an item of this unit is still on its way: next time
     }
+    if constexpr(!OWNED) {
     if(B.room == 0 && B.nxt_asked) {                               // take the reservation asked for earlier
       if((uint64_t)B.nxt + kGran <= cap) { B.gpos = B.nxt; B.room = kGran; }
       else { B.exhausted = true; if(B.nxt < cap) atomicMax(&gshort[t], cap - B.nxt); }     // (everything below nxt was handed out)
@@ -135,6 +137,7 @@ __device__ __forceinline__ void ring_flush(ITEM* s_ring, uint32_t* s_fill, uint3
       const uint32_t r0 = atomicAdd(&gcur[t], kGran);
       if((uint64_t)r0 + kGran <= cap) { B.gpos = r0; B.room = kGran; }
       else { B.exhausted = true; if(r0 < cap) atomicMax(&gshort[t], cap - r0); }
+    }
     }
     if(B.room) {
       uint4* dst = reinterpret_cast<uint4*>(my_region + B.gpos);
@@ -153,7 +156,7 @@ __device__ __forceinline__ void ring_flush(ITEM* s_ring, uint32_t* s_fill, uint3
   }
   // keep one reservation in hand whenever the current one cannot take a ring's worth: its round trip to L2 hides
   // behind the next round
-  if(!all && !B.nxt_asked && !B.exhausted && B.room < R::kSlots) { B.nxt = atomicAdd(&gcur[t], kGran); B.nxt_asked = true; }
+  if constexpr(!OWNED) { if(!all && !B.nxt_asked && !B.exhausted && B.room < R::kSlots) { B.nxt = atomicAdd(&gcur[t], kGran); B.nxt_asked = true; } }
   // the release: ring position past what went out, the count without it -- and without the ghosts
   uint32_t expect = w;
   while(nout || (expect & 0xFFFFu) > R::kSlots) {
@@ -523,6 +526,138 @@ __global__ __launch_bounds__(kPBlock) void p2_ring_kernel(DIRECT D, uint32_t b2e
   if(owner) ring_finish<uint32_t>(B, t, my_region, cap, gs, tot ? tot + dest0 : nullptr);
   lds_barrier();
   if(t == 0) strag_n[list] = s_nstrag < kP2StragPerBlock ? s_nstrag : kP2StragPerBlock;
+  if(my_direct) atomicAdd(ctr_direct, (unsigned long long)my_direct);
+}
+
+// ---- P2 with loader waves and storer waves (round 4) ---------------------------------------------------------------------
+// What bounds p2_ring_kernel's round is not its work but a property of the vector-memory counter: on this chip loads and
+// stores of a wave are counted by ONE in-order counter (vmcnt), so a wave that waits for the items it requested a round
+// ago also waits for every store it issued in between -- the units of its last flush -- to be acknowledged by memory
+// (the compiler cannot count stores issued under divergent control flow and waits for all but the newest loads), and a
+// lane taking up a granule reservation (a returning atomic) waits the same way.  A round therefore cost ~4 us whatever it
+// held (measured with the Bloom P1b ring kernel, whose rounds of 2, 3 and 4 cells a lane took 4.4, 5.3 and 5.9 us).
+// Here no wave does both: waves 0-7 (storers) own the rings -- lane t those of destinations t and t + 512 -- and only
+// read LDS and store units; waves 8-15 (loaders) only load items and append them.  One workgroup per bucket, so a
+// destination's region has a single writer: no reservations, no atomics, a cursor in a register.  One barrier a round:
+// the storers write out round r while the loaders append round r + 1, which the rings can take because a round is 4 Ki
+// items (mean 4 a ring: 15 left over + 4 + 4 stays far below 32).  The hole markers tell a storer which units are complete.
+template <typename DIRECT>
+__global__ __launch_bounds__(kPBlock) void p2_ring_roles_kernel(DIRECT D, uint32_t b2e, uint32_t tag_bits, SegList S, uint32_t cap,
+                                                                unsigned int* __restrict__ gcur, uint32_t* __restrict__ out, uint32_t bucket0,
+                                                                uint64_t* __restrict__ strag, uint32_t* __restrict__ strag_n, unsigned long long* __restrict__ ctr_direct) {
+  using R = Ring<uint32_t>;
+  constexpr int RP = 8;                                            // items per loader lane and round: two 16-byte loads
+  constexpr uint32_t kHalf = kPBlock / 2;
+  constexpr uint64_t RS = (uint64_t)kHalf * RP;                    // items of a round
+  JF_DYN_LDS(s_dyn);
+  uint32_t* s_ring = reinterpret_cast<uint32_t*>(s_dyn);          // [nb][32], then 32 dump slots
+  __shared__ uint32_t s_fill[kGranMaxB];
+  __shared__ uint32_t s_nstrag;
+  const uint32_t nb = 1u << b2e;
+  const uint32_t bucket = bucket0 + blockIdx.x;
+  const uint32_t dest0 = bucket * nb;
+  const uint32_t t = threadIdx.x, lane = t & 63;
+  const bool storer = t < kHalf;                                   // (whole waves)
+  const uint32_t hole = 0xFFFFFFFFu;
+  ring_init<uint32_t>(s_ring, s_fill, nb, &s_nstrag);
+  const uint32_t dump = nb * R::kSlots + (lane & (R::kSlots - 1));
+  uint64_t* const my_strag = strag + (size_t)blockIdx.x * kP2StragPerBlock;
+  uint32_t my_direct = 0;
+  auto straggler = [&](uint32_t d, uint32_t item, uint32_t cnt) {   // d: destination inside this bucket
+    const uint32_t at = atomicAdd(&s_nstrag, 1u);
+    if(at < kP2StragPerBlock) strag_store<uint32_t>(my_strag + at, dest0 + d, item, cnt);
+    else { D(dest0 + d, (uint64_t)item, cnt); ++my_direct; }
+  };
+  lds_barrier();
+  // the rounds of the bucket, the same sequence for both roles: the batches' regions one after the other, whole rounds
+  // first, then a partial one
+  auto seg_bounds = [&](uint32_t seg, uint64_t& a, uint64_t& b) { a = seg_lo(S, seg, bucket); b = seg_hi(S, seg, bucket); };
+  if(storer) {
+    const uint32_t d0 = t, d1 = t + kHalf;
+    const bool has0 = d0 < nb, has1 = d1 < nb;
+    RingBooks B0, B1;
+    B0.room = B1.room = cap & ~(R::kUnit - 1);
+    uint32_t* const r0p = out + ((uint64_t)dest0 + d0) * cap;
+    uint32_t* const r1p = out + ((uint64_t)dest0 + d1) * cap;
+    auto flush = [&](bool all) {
+      if(has0) ring_flush<uint32_t, true>(s_ring, s_fill, d0, all, B0, r0p, cap, gcur, gcur, straggler);
+      if(has1) ring_flush<uint32_t, true>(s_ring, s_fill, d1, all, B1, r1p, cap, gcur, gcur, straggler);
+    };
+    for(uint32_t seg = 0; seg < S.n; ++seg) {
+      uint64_t a, b; seg_bounds(seg, a, b);
+      const uint64_t rounds = (b - a + RS - 1) / RS;
+#pragma unroll 1
+      for(uint64_t r = 0; r < rounds; ++r) { lds_barrier(); flush(false); }
+    }
+    lds_barrier();                                                 // the loaders are through: every append has landed
+    flush(true);
+    // the region's fill for what comes after (p1_stragglers_kernel appends one by one, granule_finish_kernel reads it)
+    if(has0) gcur[dest0 + d0] = B0.gpos;
+    if(has1) gcur[dest0 + d1] = B1.gpos;
+  } else {
+    const uint32_t l = t - kHalf;                                  // 0 .. 511
+    for(uint32_t seg = 0; seg < S.n; ++seg) {
+      uint64_t a, b; seg_bounds(seg, a, b);
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(S.items[seg]);
+      auto load_full = [&](uint64_t r0, uint32_t (&it)[RP]) {
+#pragma unroll
+        for(int h = 0; h < RP / 4; ++h) {
+          const uint4 v = *reinterpret_cast<const uint4*>(src + r0 + (uint64_t)h * kHalf * 4 + 4 * (uint64_t)l);
+          it[4 * h] = v.x; it[4 * h + 1] = v.y; it[4 * h + 2] = v.z; it[4 * h + 3] = v.w;
+        }
+      };
+      auto load_partial = [&](uint64_t r0, uint32_t (&it)[RP]) {
+#pragma unroll
+        for(int h = 0; h < RP / 4; ++h) {
+          const uint64_t i = r0 + (uint64_t)h * kHalf * 4 + 4 * (uint64_t)l;
+          uint4 v = make_uint4(hole, hole, hole, hole);
+          if(i + 4 <= b) v = *reinterpret_cast<const uint4*>(src + i);
+          else if(i < b) { v.x = src[i]; if(i + 1 < b) v.y = src[i + 1]; if(i + 2 < b) v.z = src[i + 2]; }
+          it[4 * h] = v.x; it[4 * h + 1] = v.y; it[4 * h + 2] = v.z; it[4 * h + 3] = v.w;
+        }
+      };
+      auto append = [&](const uint32_t (&it)[RP]) {
+        uint32_t ea[RP], eo[RP];
+#pragma unroll
+        for(int e = 0; e < RP; ++e) {
+          ea[e] = dump; eo[e] = 0;
+          if(it[e] != hole) { const uint32_t d = (it[e] >> tag_bits) & (nb - 1); ea[e] = d * R::kSlots; eo[e] = atomicAdd(&s_fill[d], 1u); }
+        }
+        uint32_t ghosts = 0;
+#pragma unroll
+        for(int e = 0; e < RP; ++e) {
+          const uint32_t full = eo[e] & R::kFull;
+          ghosts |= full;
+          const uint32_t at = ea[e] + ((eo[e] + (eo[e] >> 16)) & (R::kSlots - 1));
+          s_ring[full ? dump : at] = it[e];
+        }
+        if(ghosts) {
+#pragma unroll 1
+          for(int e = 0; e < RP; ++e) if(eo[e] & R::kFull) straggler(ea[e] / R::kSlots, it[e], 1u);
+        }
+        lds_barrier();                                             // the storers take this round from here
+      };
+      uint64_t r0 = a;
+      const uint64_t n_full = (b - a) / RS;
+      if(n_full) {
+        uint32_t nx[RP];
+        load_full(r0, nx);
+#pragma unroll 1
+        for(uint64_t k = 0; k < n_full; ++k) {
+          uint32_t it[RP];
+#pragma unroll
+          for(int e = 0; e < RP; ++e) it[e] = nx[e];
+          r0 += RS;
+          load_full(k + 1 < n_full ? r0 : a, nx);                  // (after the last round: a load nobody looks at)
+          append(it);
+        }
+      }
+      if(r0 < b) { uint32_t it[RP]; load_partial(r0, it); append(it); }
+    }
+    lds_barrier();
+  }
+  lds_barrier();                                                   // (the final flush may have put items on the list)
+  if(t == 0) strag_n[blockIdx.x] = s_nstrag < kP2StragPerBlock ? s_nstrag : kP2StragPerBlock;
   if(my_direct) atomicAdd(ctr_direct, (unsigned long long)my_direct);
 }
 

@@ -27,7 +27,7 @@ struct Tuning {
   int tile_adapt = 1;            // JFGPU_TILE_ADAPT       tile kernel instantiation: 1 sampled per flush, 0 always plain, 2 always HEAVY
   uint32_t flush_share = 0;      // JFGPU_FLUSH_SHARE      force a flush into this many bucket groups sharing one P2 buffer (tests)
   bool flush_trace = false;      // JFGPU_FLUSH_TRACE      one stderr line per flush
-  int p2_ring = 1;               // JFGPU_P2_RING          single-pass P2 of 4-byte items through per-destination rings (0: the sort-based kernel, A/B)
+  int p2_ring = 1;               // JFGPU_P2_RING          single-pass P2 of 4-byte items through per-destination rings (0: the sort-based kernel, 3: never the loader / storer kernel; A/B)
   // ---- Bloom counters (jfgpu_bloom_create)
   int bloom_mode = 0;            // JFGPU_BLOOM_MODE=direct|partitioned      0: not set
   int bloom_p1_ring = 1;         // JFGPU_BLOOM_P1_RING    P1b through rings (0: the sort-based kernel, A/B)
