@@ -227,7 +227,7 @@ int bloom_flush_inner(jfgpu_bloom* b) {
     unsigned int* d_gcur2 = nullptr; uint64_t* d_off2 = nullptr; uint32_t* out2 = nullptr;
     const int p2_single = b->tun.p2_single;
     if(p2_single) {
-      const bool ring2 = b->tun.p2_ring && nb2 <= kGranMaxB;      // (its owners hold a second reservation: see part_flush_t)
+      const bool ring2 = b->tun.p2_ring && nb2 == (uint32_t)kGranMaxB;      // (its owners hold a second reservation: see part_flush_t)
       const uint64_t mean = total / std::max<uint32_t>(1, b->bp.n_seg), strand = (uint64_t)kG2Single * kGran * (ring2 ? 2 : 1) + (ring2 ? kGran : 0);   // (the array ends before the last bucket does)
       if(mean >= 8 * strand || p2_single > 1) {
         cap2 = (uint32_t)(((uint64_t)((double)mean * 1.08) + strand + 2 * kGran - 1) / kGran * kGran);
@@ -268,7 +268,7 @@ int bloom_flush_inner(jfgpu_bloom* b) {
           // the lists and global atomics, doubled the stage's time), so it keeps the sort-based kernel, like every bucket
           // when JFGPU_P2_RING=0.
           const uint32_t whole = (uint32_t)std::min<uint64_t>(b->bp.n_seg >> b->bp.b2, (uint64_t)b0 + gsz);   // buckets below this one are whole
-          const uint32_t n_ring = b->tun.p2_ring && nb2 <= kGranMaxB && whole > b0 ? whole - b0 : 0;
+          const uint32_t n_ring = b->tun.p2_ring && nb2 == (uint32_t)kGranMaxB && whole > b0 ? whole - b0 : 0;
           if(n_ring) {
             const uint32_t n_lists = kG2Single * n_ring;
             if(!b->d_strag2 || b->strag2_lists < n_lists) {

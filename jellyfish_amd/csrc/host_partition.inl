@@ -97,6 +97,40 @@ int trace_strag_lists(hipStream_t stream, const uint32_t* d_n, uint32_t n_lists,
   return JFGPU_OK;
 }
 
+// Single-pass P2 of one bucket group of 4-byte items through per-destination rings (kernels_p1ring.hip.hpp): one workgroup
+// per bucket with loader and storer waves when that fills the chip (p2_ring_roles_kernel), else several workgroups per
+// bucket sharing the regions through reservations (p2_ring_kernel); then what did not go through a ring is appended to its
+// region by the straggler kernel, before the regions' bounds are taken.  Rings hold 32 items: the kernels are for buckets
+// of 1024 destinations (512 with the loader / storer kernel's short rounds) -- p2_rings_fit says so, else the sort.
+constexpr uint32_t kG2Blocks = 4;      // workgroups per bucket of the single-pass P2 kernels that share regions
+bool p2_rings_roles(const jfgpu_table* t, uint32_t b2e, uint32_t nbk) { return t->tun.p2_ring != 3 && nbk >= 2 * (uint32_t)t->n_cu && (b2e == 10 || b2e == 9); }
+bool p2_rings_fit(const jfgpu_table* t, uint32_t b2e, uint32_t nbk) { return t->tun.p2_ring && (b2e == 10 || p2_rings_roles(t, b2e, nbk)); }
+int launch_p2_rings(jfgpu_table* t, uint32_t b2e, uint32_t tag_bits, const SegList& S1, uint32_t cap2, unsigned int* d_gcur2, uint32_t n_dest, uint32_t* out_v,
+                    uint32_t b0, uint32_t nbk, bool rt) {
+  const bool roles = p2_rings_roles(t, b2e, nbk);
+  const uint32_t n_lists = roles ? nbk : kG2Blocks * nbk;
+  if(!t->d_strag2 || t->strag2_lists < n_lists) {
+    if(t->d_strag2) { hipFree(t->d_strag2); hipFree(t->d_strag2_n); t->d_strag2 = nullptr; t->d_strag2_n = nullptr; }
+    HIP_TRY(hipMalloc((void**)&t->d_strag2, (size_t)n_lists * kP2StragPerBlock * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc((void**)&t->d_strag2_n, (size_t)n_lists * sizeof(uint32_t)));
+    t->strag2_lists = n_lists;
+  }
+  const P2RingDirect pd{t->d_dt, t->pg.b2, b2e, (int)rt};
+  unsigned long long* ctr = (unsigned long long*)&t->dt.counters[CTR_DIRECT];
+  const size_t lds = ((size_t)1 << b2e) * 128 + 128;
+  if(roles && b2e == 10)
+    hipLaunchKernelGGL((p2_ring_roles_kernel<uint32_t, 2, P2RingDirect>), dim3(nbk), dim3(kPBlock), lds, t->stream, pd, b2e, tag_bits, S1, cap2, d_gcur2, out_v, b0, t->d_strag2, t->d_strag2_n, ctr);
+  else if(roles)
+    hipLaunchKernelGGL((p2_ring_roles_kernel<uint32_t, 1, P2RingDirect>), dim3(nbk), dim3(kPBlock), lds, t->stream, pd, b2e, tag_bits, S1, cap2, d_gcur2, out_v, b0, t->d_strag2, t->d_strag2_n, ctr);
+  else
+    hipLaunchKernelGGL((p2_ring_kernel<P2RingDirect>), dim3(kG2Blocks, nbk), dim3(kPBlock), lds, t->stream, pd, b2e, tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest,
+                       out_v, b0, (unsigned long long*)nullptr, t->d_strag2, t->d_strag2_n, ctr);
+  hipLaunchKernelGGL((p1_stragglers_kernel<uint32_t, P2RingDirect>), dim3(t->n_cu), dim3(256), 0, t->stream, pd, ctr, (const uint64_t*)t->d_strag2, (const uint32_t*)t->d_strag2_n,
+                     n_lists, cap2, d_gcur2, (unsigned long long*)nullptr, out_v, kP2StragPerBlock);
+  if(t->tun.flush_trace) return trace_strag_lists(t->stream, t->d_strag2_n, n_lists, kP2StragPerBlock, roles ? 1 : kG2Blocks, b0);
+  return JFGPU_OK;
+}
+
 int ensure_strag(jfgpu_table* t) {
   if(t->d_strag) return JFGPU_OK;
   const size_t words = Ring<uint32_t>::kWords;
@@ -507,35 +541,15 @@ int part_flush_t(jfgpu_table* t) {
           ITEM* out_v = out2 - (share_groups ? (int64_t)d0 * (int64_t)cap2 : 0);
           if constexpr(sizeof(ITEM) == 4) {
             const size_t lds = (size_t)kPBlock * kP2PairPer * sizeof(ITEM);
-            if(t->tun.p2_ring) {
-              // rings per destination, like P1 (kernels_p1ring.hip.hpp); what does not go through a ring is appended to its
-              // region by the straggler kernel before the regions' bounds are taken
-              const uint32_t n_lists = kG2Single * nbk;
-              if(!t->d_strag2 || t->strag2_lists < n_lists) {
-                if(t->d_strag2) { hipFree(t->d_strag2); hipFree(t->d_strag2_n); t->d_strag2 = nullptr; t->d_strag2_n = nullptr; }
-                HIP_TRY(hipMalloc((void**)&t->d_strag2, (size_t)n_lists * kP2StragPerBlock * sizeof(uint64_t)));
-                HIP_TRY(hipMalloc((void**)&t->d_strag2_n, (size_t)n_lists * sizeof(uint32_t)));
-                t->strag2_lists = n_lists;
-              }
-              const P2RingDirect pd{t->d_dt, t->pg.b2, pg2.b2, (int)rt};
-              unsigned long long* ctr = (unsigned long long*)&t->dt.counters[CTR_DIRECT];
-              // one workgroup per bucket with loader and storer waves when that fills the chip (p2_ring_roles_kernel), else
-              // several workgroups per bucket sharing the regions through reservations (p2_ring_kernel)
-              const bool roles = t->tun.p2_ring != 3 && nbk >= 2 * (uint32_t)t->n_cu;
-              if(roles) hipLaunchKernelGGL((p2_ring_roles_kernel<P2RingDirect>), dim3(nbk), block, ((size_t)1 << pg2.b2) * 128 + 128, t->stream, pd, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2,
-                                           (uint32_t*)out_v, b0, t->d_strag2, t->d_strag2_n, ctr);
-              else
-              hipLaunchKernelGGL((p2_ring_kernel<P2RingDirect>), g1p, block, ((size_t)1 << pg2.b2) * 128 + 128, t->stream, pd, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest,
-                                 (uint32_t*)out_v, b0, (unsigned long long*)nullptr, t->d_strag2, t->d_strag2_n, ctr);
-              hipLaunchKernelGGL((p1_stragglers_kernel<uint32_t, P2RingDirect>), dim3(t->n_cu), dim3(256), 0, t->stream, pd, ctr, (const uint64_t*)t->d_strag2, (const uint32_t*)t->d_strag2_n,
-                                 roles ? nbk : n_lists, cap2, d_gcur2, (unsigned long long*)nullptr, (uint32_t*)out_v, kP2StragPerBlock);
-              if(t->tun.flush_trace) { const int rc_ = trace_strag_lists(t->stream, t->d_strag2_n, roles ? nbk : n_lists, kP2StragPerBlock, roles ? 1 : kG2Single, b0); if(rc_) return rc_; }
+            if(p2_rings_fit(t, pg2.b2, nbk)) {
+              const int rc_ = launch_p2_rings(t, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, (uint32_t)n_dest, (uint32_t*)out_v, b0, nbk, rt);
+              if(rc_) return rc_;
             } else {
               if(rt) hipLaunchKernelGGL((p2_granule_kernel<uint32_t, TableDirect<true>, kP2PairPer>), g1p, block, lds, t->stream, TableDirect<true>{t->d_dt, t->pg, (unsigned long long*)&t->dt.counters[CTR_DIRECT]}, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest, (uint32_t*)out_v, b0);
               else   hipLaunchKernelGGL((p2_granule_kernel<uint32_t, TableDirect<false>, kP2PairPer>), g1p, block, lds, t->stream, TableDirect<false>{t->d_dt, t->pg, (unsigned long long*)&t->dt.counters[CTR_DIRECT]}, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest, (uint32_t*)out_v, b0);
             }
-          } else if constexpr(sizeof(ITEM) == 8) {     // keys of 22 to 32 bases: 8-byte items into single tiles, chunks of 112 KiB
-            const size_t lds = (size_t)kPBlock * kP2MidPer * sizeof(ITEM);
+          } else if constexpr(sizeof(ITEM) == 8) {     // keys of 22 to 32 bases: 8-byte items into single tiles
+            const size_t lds = (size_t)kPBlock * kP2MidPer * sizeof(ITEM);        // chunks of 112 KiB
             if(rt) hipLaunchKernelGGL((p2_granule_kernel<uint64_t, TableDirect<true>, kP2MidPer>), g1p, block, lds, t->stream, TableDirect<true>{t->d_dt, t->pg, (unsigned long long*)&t->dt.counters[CTR_DIRECT]}, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest, (uint64_t*)out_v, b0);
             else   hipLaunchKernelGGL((p2_granule_kernel<uint64_t, TableDirect<false>, kP2MidPer>), g1p, block, lds, t->stream, TableDirect<false>{t->d_dt, t->pg, (unsigned long long*)&t->dt.counters[CTR_DIRECT]}, pg2.b2, p2_tag_bits, S1, cap2, d_gcur2, d_gcur2 + n_dest, (uint64_t*)out_v, b0);
           } else {

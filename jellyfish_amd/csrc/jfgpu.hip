@@ -715,7 +715,8 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
       const int rl = kGranMaxB * 128 + 128;
 #define RATTR(IT, BL, N, CN) HIP_TRY(hipFuncSetAttribute((const void*)p1_ring_kernel<IT, BL, N, CN>, hipFuncAttributeMaxDynamicSharedMemorySize, rl))
       HIP_TRY(hipFuncSetAttribute((const void*)p2_ring_kernel<P2RingDirect>, hipFuncAttributeMaxDynamicSharedMemorySize, rl));
-      HIP_TRY(hipFuncSetAttribute((const void*)p2_ring_roles_kernel<P2RingDirect>, hipFuncAttributeMaxDynamicSharedMemorySize, rl));
+      HIP_TRY(hipFuncSetAttribute((const void*)p2_ring_roles_kernel<uint32_t, 2, P2RingDirect>, hipFuncAttributeMaxDynamicSharedMemorySize, rl));
+      HIP_TRY(hipFuncSetAttribute((const void*)p2_ring_roles_kernel<uint32_t, 1, P2RingDirect>, hipFuncAttributeMaxDynamicSharedMemorySize, rl));
       RATTR(uint32_t, false, 6, 1); RATTR(uint32_t, false, 6, 0); RATTR(uint32_t, true, 0, 2); RATTR(uint32_t, false, 0, 2);
 #undef RATTR
     }

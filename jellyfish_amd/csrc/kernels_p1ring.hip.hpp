@@ -541,16 +541,22 @@ __global__ __launch_bounds__(kPBlock) void p2_ring_kernel(DIRECT D, uint32_t b2e
 // destination's region has a single writer: no reservations, no atomics, a cursor in a register.  One barrier a round:
 // the storers write out round r while the loaders append round r + 1, which the rings can take because a round is 4 Ki
 // items (mean 4 a ring: 15 left over + 4 + 4 stays far below 32).  The hole markers tell a storer which units are complete.
-template <typename DIRECT>
+// NV: 16-byte loads per loader lane and round -- 2 for 1024 destinations, 1 for 512 (a ring must not see more than ~4
+// appends a round with the flush a round behind).  The kernel is written over the item type and was measured with 8-byte
+// items (k = 31: rings of 16, rounds of 1 Ki items): 28.5 ms per 5 Gbp against 23.4 for the sort-based kernel -- a round
+// costs ~1.9 us however little it holds, and a ring of 128 bytes takes too few wide items for long rounds.  Instantiated
+// for 4-byte items only.
+template <typename ITEM, int NV, typename DIRECT>
 __global__ __launch_bounds__(kPBlock) void p2_ring_roles_kernel(DIRECT D, uint32_t b2e, uint32_t tag_bits, SegList S, uint32_t cap,
-                                                                unsigned int* __restrict__ gcur, uint32_t* __restrict__ out, uint32_t bucket0,
+                                                                unsigned int* __restrict__ gcur, ITEM* __restrict__ out, uint32_t bucket0,
                                                                 uint64_t* __restrict__ strag, uint32_t* __restrict__ strag_n, unsigned long long* __restrict__ ctr_direct) {
-  using R = Ring<uint32_t>;
-  constexpr int RP = 8;                                            // items per loader lane and round: two 16-byte loads
+  using R = Ring<ITEM>;
+  constexpr int VPI = (int)R::kChunk;                              // items per load
+  constexpr int RP = NV * VPI;                                     // items per loader lane and round
   constexpr uint32_t kHalf = kPBlock / 2;
   constexpr uint64_t RS = (uint64_t)kHalf * RP;                    // items of a round
   JF_DYN_LDS(s_dyn);
-  uint32_t* s_ring = reinterpret_cast<uint32_t*>(s_dyn);          // [nb][32], then 32 dump slots
+  ITEM* s_ring = reinterpret_cast<ITEM*>(s_dyn);                  // [nb][R::kSlots], then 128 bytes of dump slots
   __shared__ uint32_t s_fill[kGranMaxB];
   __shared__ uint32_t s_nstrag;
   const uint32_t nb = 1u << b2e;
@@ -558,15 +564,15 @@ __global__ __launch_bounds__(kPBlock) void p2_ring_roles_kernel(DIRECT D, uint32
   const uint32_t dest0 = bucket * nb;
   const uint32_t t = threadIdx.x, lane = t & 63;
   const bool storer = t < kHalf;                                   // (whole waves)
-  const uint32_t hole = 0xFFFFFFFFu;
-  ring_init<uint32_t>(s_ring, s_fill, nb, &s_nstrag);
+  const ITEM hole = (ITEM)~(ITEM)0;
+  ring_init<ITEM>(s_ring, s_fill, nb, &s_nstrag);
   const uint32_t dump = nb * R::kSlots + (lane & (R::kSlots - 1));
-  uint64_t* const my_strag = strag + (size_t)blockIdx.x * kP2StragPerBlock;
+  uint64_t* const my_strag = strag + (size_t)blockIdx.x * kP2StragPerBlock * R::kWords;
   uint32_t my_direct = 0;
-  auto straggler = [&](uint32_t d, uint32_t item, uint32_t cnt) {   // d: destination inside this bucket
+  auto straggler = [&](uint32_t d, ITEM item, uint32_t cnt) {       // d: destination inside this bucket
     const uint32_t at = atomicAdd(&s_nstrag, 1u);
-    if(at < kP2StragPerBlock) strag_store<uint32_t>(my_strag + at, dest0 + d, item, cnt);
-    else { D(dest0 + d, (uint64_t)item, cnt); ++my_direct; }
+    if(at < kP2StragPerBlock) strag_store<ITEM>(my_strag + (size_t)at * R::kWords, dest0 + d, item, cnt);
+    else { D(dest0 + d, item, cnt); ++my_direct; }
   };
   lds_barrier();
   // the rounds of the bucket, the same sequence for both roles: the batches' regions one after the other, whole rounds
@@ -577,11 +583,11 @@ __global__ __launch_bounds__(kPBlock) void p2_ring_roles_kernel(DIRECT D, uint32
     const bool has0 = d0 < nb, has1 = d1 < nb;
     RingBooks B0, B1;
     B0.room = B1.room = cap & ~(R::kUnit - 1);
-    uint32_t* const r0p = out + ((uint64_t)dest0 + d0) * cap;
-    uint32_t* const r1p = out + ((uint64_t)dest0 + d1) * cap;
+    ITEM* const r0p = out + ((uint64_t)dest0 + d0) * cap;
+    ITEM* const r1p = out + ((uint64_t)dest0 + d1) * cap;
     auto flush = [&](bool all) {
-      if(has0) ring_flush<uint32_t, true>(s_ring, s_fill, d0, all, B0, r0p, cap, gcur, gcur, straggler);
-      if(has1) ring_flush<uint32_t, true>(s_ring, s_fill, d1, all, B1, r1p, cap, gcur, gcur, straggler);
+      if(has0) ring_flush<ITEM, true>(s_ring, s_fill, d0, all, B0, r0p, cap, gcur, gcur, straggler);
+      if(has1) ring_flush<ITEM, true>(s_ring, s_fill, d1, all, B1, r1p, cap, gcur, gcur, straggler);
     };
     for(uint32_t seg = 0; seg < S.n; ++seg) {
       uint64_t a, b; seg_bounds(seg, a, b);
@@ -598,30 +604,29 @@ __global__ __launch_bounds__(kPBlock) void p2_ring_roles_kernel(DIRECT D, uint32
     const uint32_t l = t - kHalf;                                  // 0 .. 511
     for(uint32_t seg = 0; seg < S.n; ++seg) {
       uint64_t a, b; seg_bounds(seg, a, b);
-      const uint32_t* src = reinterpret_cast<const uint32_t*>(S.items[seg]);
-      auto load_full = [&](uint64_t r0, uint32_t (&it)[RP]) {
+      const ITEM* src = reinterpret_cast<const ITEM*>(S.items[seg]);
+      auto load_full = [&](uint64_t r0, ITEM (&it)[RP]) {
 #pragma unroll
-        for(int h = 0; h < RP / 4; ++h) {
-          const uint4 v = *reinterpret_cast<const uint4*>(src + r0 + (uint64_t)h * kHalf * 4 + 4 * (uint64_t)l);
-          it[4 * h] = v.x; it[4 * h + 1] = v.y; it[4 * h + 2] = v.z; it[4 * h + 3] = v.w;
+        for(int h = 0; h < NV; ++h) {
+          const uint4 v = *reinterpret_cast<const uint4*>(src + r0 + (uint64_t)h * kHalf * VPI + (uint64_t)VPI * l);
+          int q = 0;
+          chunk_items<ITEM>(v, [&](ITEM x) { it[VPI * h + q] = x; ++q; });
         }
       };
-      auto load_partial = [&](uint64_t r0, uint32_t (&it)[RP]) {
+      auto load_partial = [&](uint64_t r0, ITEM (&it)[RP]) {
 #pragma unroll
-        for(int h = 0; h < RP / 4; ++h) {
-          const uint64_t i = r0 + (uint64_t)h * kHalf * 4 + 4 * (uint64_t)l;
-          uint4 v = make_uint4(hole, hole, hole, hole);
-          if(i + 4 <= b) v = *reinterpret_cast<const uint4*>(src + i);
-          else if(i < b) { v.x = src[i]; if(i + 1 < b) v.y = src[i + 1]; if(i + 2 < b) v.z = src[i + 2]; }
-          it[4 * h] = v.x; it[4 * h + 1] = v.y; it[4 * h + 2] = v.z; it[4 * h + 3] = v.w;
+        for(int h = 0; h < NV; ++h) {
+          const uint64_t i = r0 + (uint64_t)h * kHalf * VPI + (uint64_t)VPI * l;
+#pragma unroll
+          for(int q = 0; q < VPI; ++q) it[VPI * h + q] = i + q < b ? src[i + q] : hole;
         }
       };
-      auto append = [&](const uint32_t (&it)[RP]) {
+      auto append = [&](const ITEM (&it)[RP]) {
         uint32_t ea[RP], eo[RP];
 #pragma unroll
         for(int e = 0; e < RP; ++e) {
           ea[e] = dump; eo[e] = 0;
-          if(it[e] != hole) { const uint32_t d = (it[e] >> tag_bits) & (nb - 1); ea[e] = d * R::kSlots; eo[e] = atomicAdd(&s_fill[d], 1u); }
+          if(it[e] != hole) { const uint32_t d = (uint32_t)(it[e] >> tag_bits) & (nb - 1); ea[e] = d * R::kSlots; eo[e] = atomicAdd(&s_fill[d], 1u); }
         }
         uint32_t ghosts = 0;
 #pragma unroll
@@ -640,11 +645,11 @@ __global__ __launch_bounds__(kPBlock) void p2_ring_roles_kernel(DIRECT D, uint32
       uint64_t r0 = a;
       const uint64_t n_full = (b - a) / RS;
       if(n_full) {
-        uint32_t nx[RP];
+        ITEM nx[RP];
         load_full(r0, nx);
 #pragma unroll 1
         for(uint64_t k = 0; k < n_full; ++k) {
-          uint32_t it[RP];
+          ITEM it[RP];
 #pragma unroll
           for(int e = 0; e < RP; ++e) it[e] = nx[e];
           r0 += RS;
@@ -652,7 +657,7 @@ __global__ __launch_bounds__(kPBlock) void p2_ring_roles_kernel(DIRECT D, uint32
           append(it);
         }
       }
-      if(r0 < b) { uint32_t it[RP]; load_partial(r0, it); append(it); }
+      if(r0 < b) { ITEM it[RP]; load_partial(r0, it); append(it); }
     }
     lds_barrier();
   }
