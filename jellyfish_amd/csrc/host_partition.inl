@@ -295,13 +295,19 @@ int part_ingest(jfgpu_table* t, const uint8_t* base, int64_t lo, int64_t hi, boo
   return JFGPU_OK;
 }
 
-template <typename ITEM>
-int part_flush_t(jfgpu_table* t) {
-  const uint32_t nb1 = 1u << t->pg.b1, nb2 = 1u << t->pg.b2;
+// ---- a flush, first part: what is pending, bucket by bucket ------------------------------------------------------------
+// offs: for every pending batch the running sum of its nb1 bucket sizes (nb1 + 1 entries); bucket_tot: items per P1 bucket
+// over all batches.  One small copy per batch, which also drains the stream.  Side effects: the capacity accounting is
+// corrected from "one k-mer per input byte" to the exact counts, and items_per_byte (what sizes the next batches' regions)
+// is refreshed.
+struct FlushSizes { std::vector<uint64_t> offs, bucket_tot; uint64_t total = 0; };
+int flush_sizes(jfgpu_table* t, FlushSizes& fs) {
+  const uint32_t nb1 = 1u << t->pg.b1;
   const size_t nbatch = t->pending.size();
   // bucket sizes of every pending batch (one small D2H; also drains the stream)
   // (granule batches: the exact per-bucket counts, stored as a running sum so both kinds read alike)
-  std::vector<uint64_t> offs(nbatch * (nb1 + 1));
+  std::vector<uint64_t>& offs = fs.offs;
+  offs.assign(nbatch * (nb1 + 1), 0);
   for(size_t s = 0; s < nbatch; ++s) {
     const PendingBatch& pb = t->pending[s];
     if(pb.gran_cap) HIP_TRY(hipMemcpyAsync(&offs[s * (nb1 + 1) + 1], pb.tot, nb1 * sizeof(uint64_t), hipMemcpyDeviceToHost, t->stream));
@@ -316,7 +322,8 @@ int part_flush_t(jfgpu_table* t) {
       o[0] = 0;
       for(uint32_t j = 0; j < nb1; ++j) o[j + 1] += o[j];
     }
-  std::vector<uint64_t> bucket_tot(nb1, 0);
+  std::vector<uint64_t>& bucket_tot = fs.bucket_tot;
+  bucket_tot.assign(nb1, 0);
   uint64_t total = 0, max_bucket = 0;
   for(size_t s = 0; s < nbatch; ++s)
     for(uint32_t j = 0; j < nb1; ++j) bucket_tot[j] += offs[s * (nb1 + 1) + j + 1] - offs[s * (nb1 + 1) + j];
@@ -336,6 +343,52 @@ int part_flush_t(jfgpu_table* t) {
       if(t->pending[s].input_bytes) { in_bytes += t->pending[s].input_bytes; in_items += offs[s * (nb1 + 1) + nb1]; }
     if(in_bytes >= (1u << 20)) t->items_per_byte = (double)in_items / (double)in_bytes;
   }
+  fs.total = total;
+  return JFGPU_OK;
+}
+
+// ---- the tile insert of one-word keys (kernels_tile.hip.hpp) --------------------------------------------------------
+// One instantiation of tile_rank_insert_kernel over tiles [tile0, tile0 + TPB * ntile): HV the HEAVY variant, SM the plain
+// one with its two sample counters on.
+template <typename ITEM, typename SLOT, int TPB, bool HV, bool SM>
+void launch_tile_rank_variant(jfgpu_table* t, const SegList& S, uint64_t tile0, uint32_t ntile, hipStream_t ts) {
+  const size_t lds = tile_rank_lds(sizeof(SLOT), t->g.tile_bits, TPB);
+  const dim3 grid((unsigned)std::min<uint64_t>(ntile, (uint64_t)t->n_cu * 16)), block(kTileBlock);
+  if(t->returning) hipLaunchKernelGGL((tile_rank_insert_kernel<ITEM, true, SLOT, TPB, kTileBlock, HV, SM>), grid, block, lds, ts, t->dt, S, tile0, ntile);
+  else             hipLaunchKernelGGL((tile_rank_insert_kernel<ITEM, false, SLOT, TPB, kTileBlock, HV, SM>), grid, block, lds, ts, t->dt, S, tile0, ntile);
+}
+// Which instantiation (plain, or HEAVY for high-coverage input) is decided from the flush itself: the first 64th of a
+// large launch's units goes through the plain kernel with its counters on, the host reads them (one wait inside the
+// flush) and the rest follows in the instantiation they call for.  JFGPU_TILE_ADAPT=0: always plain; 2: always HEAVY (tests).
+template <typename ITEM, typename SLOT, int TPB>
+void launch_tile_rank(jfgpu_table* t, const SegList& S, uint64_t tile0, uint32_t ntile, hipStream_t ts) {
+  const int adapt = t->tun.tile_adapt;
+  bool heavy = adapt == 2;
+  uint32_t done = 0;
+  if(adapt == 1 && ntile >= 8192 && S.n == 1) {
+    const uint32_t ns = ntile / 64;
+    (void)hipMemsetAsync(&t->dt.counters[CTR_T_ITEMS], 0, 2 * sizeof(uint64_t), ts);
+    launch_tile_rank_variant<ITEM, SLOT, TPB, false, true>(t, S, tile0, ns, ts);
+    uint64_t smp[2] = {0, 0};                              // items placed, items past rank 3
+    if(hipMemcpyAsync(smp, &t->dt.counters[CTR_T_ITEMS], sizeof smp, hipMemcpyDeviceToHost, ts) == hipSuccess && hipStreamSynchronize(ts) == hipSuccess)
+      heavy = smp[1] * 4 > smp[0];
+    done = ns;
+  }
+  SegList Sr = S; Sr.off[0] = S.off[0] + ((size_t)done << S.sh[0]);
+  if(heavy) ++t->flushes_heavy; else ++t->flushes_plain;
+  if(heavy) launch_tile_rank_variant<ITEM, SLOT, TPB, true, false>(t, Sr, tile0 + (uint64_t)TPB * done, ntile - done, ts);
+  else      launch_tile_rank_variant<ITEM, SLOT, TPB, false, false>(t, Sr, tile0 + (uint64_t)TPB * done, ntile - done, ts);
+}
+
+template <typename ITEM>
+int part_flush_t(jfgpu_table* t) {
+  const uint32_t nb1 = 1u << t->pg.b1, nb2 = 1u << t->pg.b2;
+  const size_t nbatch = t->pending.size();
+  FlushSizes fs;
+  { const int rc = flush_sizes(t, fs); if(rc) return rc; }
+  const std::vector<uint64_t>& offs = fs.offs;
+  const std::vector<uint64_t>& bucket_tot = fs.bucket_tot;
+  const uint64_t total = fs.total;
   const uint64_t n_tiles = n_tiles_of(t);
   if constexpr(!(sizeof(ITEM) == 16)) { int rc = refresh_d_dt(t); if(rc) return rc; }
   SegList S1; memset(&S1, 0, sizeof S1);
@@ -346,43 +399,14 @@ int part_flush_t(jfgpu_table* t) {
   const bool rt = t->returning;      // a tile is read only if its dirty byte is set (clean after jfgpu_clear)
   // the tile insert of one item array (or of the pending batches themselves), on stream `ts`
   auto launch_tile_kernel = [&](const SegList& S, uint64_t tile0, uint32_t ntile, hipStream_t ts, bool pair = false) {
-    const dim3 block(kPBlock), tblock(kTileBlock);
     if constexpr(kWideItems) {
-      const dim3 grid((unsigned)std::min<uint64_t>(ntile, (uint64_t)t->n_cu * 4));     // 128 KiB of LDS: one block per CU
+      const dim3 block(kPBlock), grid((unsigned)std::min<uint64_t>(ntile, (uint64_t)t->n_cu * 4));     // 128 KiB of LDS: one block per CU
       if(rt) hipLaunchKernelGGL(tile_insert_wide_kernel<true>, grid, block, tile_lds, ts, t->wt, S, tile0, ntile);
       else   hipLaunchKernelGGL(tile_insert_wide_kernel<false>, grid, block, tile_lds, ts, t->wt, S, tile0, ntile);
     } else {
       // one-word keys: placement by rank inside buckets of four (kernels_tile.hip.hpp); two workgroups per CU
-      const dim3 grid((unsigned)std::min<uint64_t>(ntile, (uint64_t)t->n_cu * 16));
-      // Which instantiation (kernels_tile.hip.hpp: plain, or HEAVY for high-coverage input) is decided from the flush
-      // itself: the first 64th of a large launch's units goes through the plain kernel with its counters on, the
-      // host reads them (one wait inside the flush) and the rest follows in the instantiation they call for.
-      // JFGPU_TILE_ADAPT=0: always plain; 2: always HEAVY (tests).
-      const int adapt = t->tun.tile_adapt;
-#define TRV(SLOT, TPB, HV, SM, SV, T0, NT) do { const size_t lds = tile_rank_lds(sizeof(SLOT), t->g.tile_bits, TPB); \
-        const dim3 gr((unsigned)std::min<uint64_t>((NT), (uint64_t)t->n_cu * 16)); \
-        if(rt) hipLaunchKernelGGL((tile_rank_insert_kernel<ITEM, true, SLOT, TPB, kTileBlock, HV, SM>), gr, tblock, lds, ts, t->dt, (SV), (T0), (NT)); \
-        else   hipLaunchKernelGGL((tile_rank_insert_kernel<ITEM, false, SLOT, TPB, kTileBlock, HV, SM>), gr, tblock, lds, ts, t->dt, (SV), (T0), (NT)); } while(0)
-#define TR(SLOT, TPB) do { \
-        bool heavy = adapt == 2; uint32_t done = 0; \
-        if(adapt == 1 && ntile >= 8192 && S.n == 1) { \
-          const uint32_t ns = ntile / 64; \
-          (void)hipMemsetAsync(&t->dt.counters[CTR_T_ITEMS], 0, 2 * sizeof(uint64_t), ts); \
-          TRV(SLOT, TPB, false, true, S, tile0, ns); \
-          uint64_t smp[2] = {0, 0}; \
-          if(hipMemcpyAsync(smp, &t->dt.counters[CTR_T_ITEMS], sizeof smp, hipMemcpyDeviceToHost, ts) == hipSuccess && hipStreamSynchronize(ts) == hipSuccess) \
-            heavy = smp[1] * 4 > smp[0]; \
-          done = ns; \
-        } \
-        SegList Sr = S; Sr.off[0] = S.off[0] + ((size_t)done << S.sh[0]); \
-        if(heavy) ++t->flushes_heavy; else ++t->flushes_plain; \
-        if(heavy) TRV(SLOT, TPB, true, false, Sr, tile0 + (uint64_t)(TPB) * done, ntile - done); \
-        else      TRV(SLOT, TPB, false, false, Sr, tile0 + (uint64_t)(TPB) * done, ntile - done); } while(0)
-      (void)grid;
-      if(t->g.slot32) { if(pair) TR(unsigned int, 2); else TR(unsigned int, 1); }
-      else TR(unsigned long long, 1);
-#undef TR
-#undef TRV
+      if(t->g.slot32) { if(pair) launch_tile_rank<ITEM, unsigned int, 2>(t, S, tile0, ntile, ts); else launch_tile_rank<ITEM, unsigned int, 1>(t, S, tile0, ntile, ts); }
+      else launch_tile_rank<ITEM, unsigned long long, 1>(t, S, tile0, ntile, ts);
     }
   };
   auto launch_tiles = [&](const SegList& S, uint64_t tile0, uint32_t ntile, uint64_t units) {
