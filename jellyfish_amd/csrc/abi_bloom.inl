@@ -23,8 +23,6 @@ struct jfgpu_bloom {
   std::vector<Pending> pending;
   uint32_t* d_M2 = nullptr;
   uint64_t* d_strag2 = nullptr; uint32_t* d_strag2_n = nullptr; uint32_t strag2_lists = 0;     // p2_ring_kernel's straggler lists
-  uint64_t* d_strag1 = nullptr; uint32_t* d_strag1_n = nullptr;                                // p1_bloom_ring_kernel's (one per block, n_cu blocks)
-  size_t p1_ring_lds = 0; uint32_t p1_ring_cpr = 0;                                            // 0: P1b keeps the sort-based kernel
   bool prof_on = false;
   std::vector<ProfSpan> spans;
   double prof_ms[4] = {}; uint64_t prof_launches[4] = {}, prof_units[4] = {};
@@ -121,21 +119,6 @@ static int bloom_create(const jfgpu_bloom_params* p, jfgpu_bloom** out, uint32_t
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint32_t, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint32_t, BloomDirect, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_ring_kernel<BloomRingDirect>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kGranMaxB * 128 + 128)));
-    // P1b through rings: when the rings of the P1b buckets fit LDS beside the two hash tables, and a round of one cell a
-    // lane does not already overfill them (fewer than 128 buckets)
-    if(b->part_ok && b->tun.bloom_p1_ring && b->bp.b2 != 0) {
-      const uint32_t nb = 1u << b->bp.b1;
-      const size_t need = (size_t)nb * 128 + 128 + (size_t)2 * b->g.nbytes * 2048;
-      if(nb >= 128 && nb <= (uint32_t)kGranMaxB && need <= 150000) {
-        // buckets that really get updates: the array ends inside the last one
-        const uint32_t used = (uint32_t)(((uint64_t)b->bp.n_seg + (1u << b->bp.b2) - 1) >> b->bp.b2);
-        b->p1_ring_lds = need; b->p1_ring_cpr = std::min<uint32_t>(4, std::max<uint32_t>(1, 8 * used / kPBlock));
-        if(b->tun.bloom_p1_ring > 1) b->p1_ring_cpr = std::min<uint32_t>(4, (uint32_t)b->tun.bloom_p1_ring - 1);     // (A/B: 2..5 force 1..4 cells a round)
-        HIP_TRY(hipFuncSetAttribute((const void*)p1_bloom_ring_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
-        HIP_TRY(hipFuncSetAttribute((const void*)p1_bloom_ring_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
-        HIP_TRY(hipFuncSetAttribute((const void*)p1_bloom_ring_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
-      }
-    }
   }
   HIP_TRY(hipMalloc((void**)&b->d_data, b->alloc_bytes));
   HIP_TRY(hipMemsetAsync(b->d_data, 0, b->alloc_bytes, b->stream));
@@ -159,7 +142,6 @@ void jfgpu_bc_destroy(jfgpu_bloom* b) {
   if(b->ws) hipFree(b->ws);
   if(b->d_M2) hipFree(b->d_M2);
   if(b->d_strag2) { hipFree(b->d_strag2); hipFree(b->d_strag2_n); }
-  if(b->d_strag1) { hipFree(b->d_strag1); hipFree(b->d_strag1_n); }
   if(b->stream) hipStreamDestroy(b->stream);
   delete b;
 }

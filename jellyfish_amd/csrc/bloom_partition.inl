@@ -140,24 +140,9 @@ int bloom_ingest(jfgpu_bloom* b, const uint8_t* base, int64_t lo, int64_t hi) {
     const int64_t plo = at & 15, phi = plo + (int64_t)piece;
     {
       BloomProf ps(b, BS_P1, piece);
-      if(b->p1_ring_cpr) {
-        if(!b->d_strag1) {
-          HIP_TRY(hipMalloc((void**)&b->d_strag1, (size_t)b->n_cu * kStragPerBlock * sizeof(uint64_t)));
-          HIP_TRY(hipMalloc((void**)&b->d_strag1_n, (size_t)b->n_cu * sizeof(uint32_t)));
-        }
-#define PBR(N) hipLaunchKernelGGL(p1_bloom_ring_kernel<N>, dim3(b->n_cu), dim3(kPBlock), b->p1_ring_lds, b->stream, b->view(), b->bp, b->g, pbase, plo, phi, cap, gcur, p.tot, p.items, b->d_mers, \
-                                  b->d_strag1, b->d_strag1_n, b->p1_ring_cpr)
-        if(b->g.nbytes == 8) PBR(8); else if(b->g.nbytes == 6) PBR(6); else PBR(0);
-#undef PBR
-        const BloomP1Direct pd{b->d_data, b->bp.b2};
-        hipLaunchKernelGGL((p1_stragglers_kernel<uint32_t, BloomP1Direct>), dim3(b->n_cu), dim3(256), 0, b->stream, pd, (unsigned long long*)nullptr, (const uint64_t*)b->d_strag1,
-                           (const uint32_t*)b->d_strag1_n, (uint32_t)b->n_cu, cap, gcur, p.tot, p.items, kStragPerBlock);
-        if(b->tun.flush_trace) { const int rc_ = trace_strag_lists(b->stream, b->d_strag1_n, (uint32_t)b->n_cu, kStragPerBlock, 1, 0); if(rc_) return rc_; }
-      } else {
 #define PB(N) hipLaunchKernelGGL(p1_bloom_granule_kernel<N>, dim3(b->g1), dim3(kPBlock), lds, b->stream, b->view(), b->bp, b->g, pbase, plo, phi, cap, gcur, p.tot, p.items, b->d_mers)
       if(b->g.nbytes == 8) PB(8); else if(b->g.nbytes == 6) PB(6); else PB(0);
 #undef PB
-      }
       hipLaunchKernelGGL(granule_finish_kernel, dim3((nb + 255) / 256), dim3(256), 0, b->stream, gcur, cap, nb, p.off);
     }
     HIP_TRY(hipGetLastError());

@@ -136,136 +136,13 @@ __global__ __launch_bounds__(kPBlock) void p1_bloom_granule_kernel(DevBloom B, B
   (void)my_direct;
 }
 
-// ---- P1b through rings (round 4) ------------------------------------------------------------------------------------
-// The count path's ring machinery (kernels_p1ring.hip.hpp) for cell updates: every P1b bucket owns a ring of 32 updates
-// in LDS, a lane appends `cpr` of its current k-mer's cells per round (one returning ds_add, one store each; the next
-// k-mer of the lane is hashed when the cells of the current one run out, which happens in the same round for all lanes
-// whose windows are valid), and after the round's barrier the owner lanes write out complete units (aligned 64 bytes).
-// cpr is chosen by the host so that a ring sees at most 8 appends a round on average (1024 lanes x cpr / buckets): the
-// round-4 attempt with five cells a round on 512 rings (mean 10) and one barrier a round overflowed 1.4 % of its
-// appends and took 685 ms for config 3's pass against the sort-based kernel's 407 (profiles/r04_c3_ring_experiment.log).
-// Two barriers a round, like p2_ring_kernel: the rounds are short, and appends racing an owner's release are stragglers.
-struct BloomP1Direct {
-  uint32_t* data; uint32_t b2;
-  __device__ void operator()(uint32_t b, uint64_t item, uint32_t cnt) const {
-    for(uint32_t i = 0; i < cnt; ++i) bloom_segment_item_direct_call(data, (b << b2) | ((uint32_t)item >> kBloomItemLow), (uint32_t)item);
-  }
-};
-
-template <int NB>
-__global__ __launch_bounds__(kPBlock) void p1_bloom_ring_kernel(DevBloom B, BloomPart BP, TableGeom g, const uint8_t* __restrict__ base,
-                                                                int64_t lo, int64_t hi, uint32_t cap,
-                                                                unsigned int* __restrict__ gcur, unsigned long long* __restrict__ tot,
-                                                                uint32_t* __restrict__ out, unsigned long long* __restrict__ mers,
-                                                                uint64_t* __restrict__ strag, uint32_t* __restrict__ strag_n, uint32_t cpr) {
-  using R = Ring<uint32_t>;
-  constexpr int CPR = 4;                                           // cells per lane and round, at most
-  JF_DYN_LDS(s_dyn);
-  const uint32_t nb = 1u << BP.b1;
-  uint32_t* s_ring = reinterpret_cast<uint32_t*>(s_dyn);          // [nb][32], then 32 dump slots
-  uint64_t* s_t1 = reinterpret_cast<uint64_t*>(s_dyn + (size_t)nb * 128 + 128);          // [nbytes * 256]
-  uint64_t* s_t2 = s_t1 + (size_t)B.nbytes * 256;
-  __shared__ uint32_t s_fill[kGranMaxB];
-  __shared__ uint32_t s_nstrag;
-  __shared__ uint32_t s_codes[kPBlock + 2];
-  __shared__ uint32_t s_inv[kPBlock + 2];
-  const uint32_t t = threadIdx.x, lane = t & 63;
-  const bool owner = t < nb;
-  load_tables_lds(s_t1, B.tbl1, B.nbytes);
-  load_tables_lds(s_t2, B.tbl2, B.nbytes);
-  ring_init<uint32_t>(s_ring, s_fill, nb, &s_nstrag);
-  const uint32_t dump = nb * R::kSlots + (lane & (R::kSlots - 1));
-  unsigned int* const gshort = gcur + nb;
-  uint64_t* const my_strag = strag + (size_t)blockIdx.x * kStragPerBlock;
-  RingBooks Bk;
-  if(owner) { Bk.nxt = atomicAdd(&gcur[t], kGran); Bk.nxt_asked = true; }
-  uint32_t* const my_region = out + (uint64_t)t * cap;
-  const uint32_t k = g.k;
-  const uint64_t kwin = k >= 64 ? ~0ull : ((1ull << k) - 1);
-  const uint32_t rc_shift = 2 * (k - 1);
-  const uint32_t sub_mask = (1u << BP.b2) - 1;
-  uint32_t my_mers = 0;
-  auto straggler = [&](uint32_t b, uint32_t item, uint32_t cnt) {
-    const uint32_t at = atomicAdd(&s_nstrag, 1u);
-    if(at < kStragPerBlock) strag_store<uint32_t>(my_strag + at, b, item, cnt);
-    else bloom_segment_item_direct_call(B.data, (b << BP.b2) | (item >> kBloomItemLow), item);
-  };
-  const uint32_t rounds = (kPerLane * B.nh + cpr - 1) / cpr;      // per tile (the same for every lane)
-  const int64_t n_tiles = (hi + kPTilePos - 1) / kPTilePos;
-  TileRaw Rw = tile_fetch(base, (int64_t)blockIdx.x * kPTilePos, lo, hi);
-  lds_barrier();
-  for(int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    lds_barrier();
-    const LaneWords L = tile_stage(Rw, tile * kPTilePos, lo, hi, s_codes, s_inv);      // barrier inside
-    Rw = tile_fetch(base, (tile + gridDim.x) * kPTilePos, lo, hi);                      // next tile's bytes travel meanwhile
-    uint64_t fw = (((uint64_t)L.p2 << 32) | L.p1) & g.key_mask;
-    uint64_t rc = revcomp64(fw, k);
-    int j = 0;                                                     // next position of the lane's 16
-    uint32_t rem = 0;                                              // cells of the current k-mer still to emit
-    uint64_t cell = 0, inc = 0;
-#pragma unroll 1
-    for(uint32_t r = 0; r < rounds; ++r) {
-      uint32_t ea[CPR], eo[CPR], ei[CPR];
-#pragma unroll
-      for(int e = 0; e < CPR; ++e) { ea[e] = dump; eo[e] = 0; ei[e] = 0; }
-#pragma unroll
-      for(int e = 0; e < CPR; ++e) {
-        if((uint32_t)e < cpr) {                                    // (uniform)
-          if(rem == 0) {
-#pragma unroll 1
-            while(j < kPerLane) {                                  // the lane's next window of k valid bases
-              const uint64_t c = (L.cur >> (2 * (15 - j))) & 3u;
-              fw = ((fw << 2) | c) & g.key_mask;
-              rc = (rc >> 2) | ((3ull - c) << rc_shift);
-              const bool valid = ((L.inv48 >> (15 - j)) & kwin) == 0;
-              ++j;
-              if(valid) {
-                const uint64_t key = (g.canonical && rc < fw) ? rc : fw;
-                cell = bloom_mod(hash_tables_t<NB>(s_t1, key, B.nbytes), B.m, B.recip);
-                inc = bloom_mod(hash_tables_t<NB>(s_t2, key, B.nbytes), B.m, B.recip);
-                rem = B.nh; ++my_mers;
-                break;
-              }
-            }
-          }
-          if(rem) {
-            uint64_t byte; uint32_t dig;
-            divmod5(cell, byte, dig);
-            const uint32_t seg = (uint32_t)(byte >> kBloomSegBits);
-            const uint32_t b = seg >> BP.b2;
-            ei[e] = ((seg & sub_mask) << kBloomItemLow) | ((uint32_t)(byte & 0xFFFFu) << 3) | dig;    // (never all ones: its top bits are 0)
-            ea[e] = b * R::kSlots;
-            eo[e] = atomicAdd(&s_fill[b], 1u);
-            cell += inc; if(cell >= B.m) cell -= B.m;
-            --rem;
-          }
-        }
-      }
-      uint32_t ghosts = 0;
-#pragma unroll
-      for(int e = 0; e < CPR; ++e) {
-        const uint32_t full = eo[e] & R::kFull;
-        ghosts |= full;
-        const uint32_t at = ea[e] + ((eo[e] + (eo[e] >> 16)) & (R::kSlots - 1));
-        s_ring[full ? dump : at] = ei[e];
-      }
-      if(ghosts) {
-#pragma unroll 1
-        for(int e = 0; e < CPR; ++e) if(eo[e] & R::kFull) straggler(ea[e] / R::kSlots, ei[e], 1u);
-      }
-      lds_barrier();                                               // the round's updates have all landed
-      if(owner) ring_flush<uint32_t>(s_ring, s_fill, t, false, Bk, my_region, cap, gcur, gshort, straggler);
-      lds_barrier();                                               // ... and the rings are released before the next appends
-    }
-  }
-  lds_barrier();
-  if(owner) { ring_flush<uint32_t>(s_ring, s_fill, t, true, Bk, my_region, cap, gcur, gshort, straggler); ring_finish<uint32_t>(Bk, t, my_region, cap, gshort, tot); }
-  lds_barrier();
-  if(t == 0) strag_n[blockIdx.x] = s_nstrag < kStragPerBlock ? s_nstrag : kStragPerBlock;
-  uint64_t w = my_mers;
-  for(int o = 32; o > 0; o >>= 1) w += __shfl_down(w, o, 64);
-  if((threadIdx.x & 63) == 0 && w) atomicAdd(mers, (unsigned long long)w);
-}
+// (P1b through the count path's rings -- a ring of 32 cell updates per bucket, `cpr` cells of the current k-mer appended per
+// lane and round, two barriers a round -- was built and measured in round 4, profiles/r04_c3_p1b.log: 450 ms for config 3's
+// pass against 415 for the kernel above; a round cost 4.4 - 5.9 us whether it appended 2, 3 or 4 cells a lane.  Not the
+// reservations (static slices of the regions, nothing reserved: 597 ms), not the division by five per cell (cells walked
+// in (byte, digit) coordinates with additions only: 548 ms, and 431 in the kernel above).  SQ counters of the kernel
+// above: VALU busy 50 % of the CU's cycles, LDS 47 %, waves waiting 64 % of theirs at four waves per SIMD -- the pass is
+// bound by latency at this occupancy (93 KB of LDS per workgroup), which rings of 64 KB + 32 KB of tables do not change.)
 
 // ---- Tb: one workgroup owns one 64 KiB segment of the byte array in LDS ---------------------------------------
 __device__ inline void bloom_lds_bump(uint32_t* s_seg, uint32_t item) {

@@ -28,7 +28,7 @@ for n in (1, 2):
     except Exception as e:
         print("pass", n, "failed:", e); continue
     for r in rows:
-        if not any(s in r["Kernel"] for s in ("p1_", "p2_granule", "p2_ring", "tile_rank", "tile_insert", "bloom_seg")): continue
+        if not any(s in r["Kernel"] for s in ("p1_", "p2_granule", "p2_ring", "tile_rank", "tile_insert", "bloom_seg", "wide")): continue
         base = "SQ_WAVE_CYCLES" if n == 1 else "SQ_BUSY_CU_CYCLES"
         wc = float(r.get(base) or 0) or 1
         print("[sq%d] %s  dispatches %s  (%% of %s)" % (n, r["Kernel"][:70], r["Dispatches"], base))
