@@ -38,7 +38,7 @@ enum Counter : int { CTR_FULL = 0, CTR_MERS = 1, CTR_OVF_FULL = 2, CTR_OVF_USED 
                      CTR_PROF0 = 8 /* .. 11: phase clocks of a -DJFGPU_TILE_PROF build */, CTR_COUNT = 12 };
 
 // -DJFGPU_PHASE_PROF builds: shader clocks per phase of the partition kernels, as wave 0 of every block sees them,
-// summed over blocks into a device array the host prints at jfgpu_sync (tools/ablate.py).  Slots 0-7 P1, 8-15 P2, 16-23 T.
+// summed over blocks into a device array the host prints at jfgpu_sync (tools/build_libs.sh builds it, JFGPU_LIB selects it).  Slots 0-7 P1, 8-15 P2, 16-23 T.
 #ifdef JFGPU_PHASE_PROF
 __device__ unsigned long long g_phase_prof[24];
 struct PhaseClk {
