@@ -412,7 +412,9 @@ def main():
     bloom = None
     if cfg == "C3":
         bloom = capi.Bloom(K, capi.opt_m(0.001, int(args.gbp * 1e9)), capi.opt_k(0.001), canonical=True, device=local_rank)
-        bloom.reserve(int(os.environ.get("JFGPU_BENCH_BC_WS_GB", "150")) << 30)
+        # routing workspace of the Bloom pass: the more, the fewer flushes stream the 28 GB array (150 GB: three).  On
+        # distribution G the filtered count admits most k-mers and its own flush needs ~64 GB beside table, filter and reads
+        bloom.reserve(int(os.environ.get("JFGPU_BENCH_BC_WS_GB", "150" if args.dist == "U" else "100")) << 30)
     # Init phase: workspace for one sync-to-sync span (like -s presizes the table).  C3: the filtered pass admits next to
     # nothing of a uniform input, and the Bloom pass needs the memory: two batches' worth, flushed as it fills
     if cfg == "C3":
