@@ -848,6 +848,33 @@ __global__ __launch_bounds__(kBlock) void add_pairs_kernel(DevTable T, const uin
     table_add_val(T, T.fwd_tbl, keys[i], cnts[i]);
 }
 
+// The same for two-word keys: a pair is two key words (low, high) and a count.
+__global__ __launch_bounds__(kBlock) void reshard_wide_kernel(WideTable old, WideTable neu, int have_ovf, int pass, unsigned long long* __restrict__ cursors,
+                                                              uint64_t* __restrict__ keys_out, uint64_t* __restrict__ cnts_out) {
+  const TableGeom& g = old.W.g;
+  const DevTable od = ovf_view(old);
+  const uint64_t n = 1ull << g.lsize_l;
+  for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t hi = old.slots[2 * i + 1];
+    if(!hi) continue;
+    const uint64_t lo = old.slots[2 * i];
+    if(!lo) continue;                                    // hi claimed, never completed: holds no key
+    const u128 key = wide_slot_key(old, old.inv_tbl, lo, hi, i & ~g.tile_mask);
+    uint64_t cnt = slot_count(g, hi);
+    if(have_ovf) cnt += ovf_get(od, i) << g.cnt_bits;
+    const uint32_t owner = slot_addr(neu.W.g, hash_tables_wide(neu.fwd_tbl, key, neu.W.g.nbytes)).shard;
+    if(owner == neu.W.g.shard_id) { if(pass) wide_add_val(neu, neu.fwd_tbl, key, cnt); }
+    else {
+      const unsigned long long at = atomicAdd(&cursors[owner], 1ull);
+      if(pass) { keys_out[2 * at] = (uint64_t)key; keys_out[2 * at + 1] = (uint64_t)(key >> 64); cnts_out[at] = cnt; }
+    }
+  }
+}
+__global__ __launch_bounds__(kBlock) void add_pairs_wide_kernel(WideTable T, const uint64_t* __restrict__ keys, const uint64_t* __restrict__ cnts, uint64_t n) {
+  for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    wide_add_val(T, T.fwd_tbl, ((u128)keys[2 * i + 1] << 64) | keys[2 * i], cnts[i]);
+}
+
 int comm_exchange_rccl(jfgpu_comm* c); int comm_exchange_local(jfgpu_comm* c); int comm_exchange_ipc(jfgpu_comm* c);
 
 // Collective (every rank of the communicator; the local transport: all its ranks here).
@@ -858,7 +885,8 @@ int comm_grow(jfgpu_comm* c) {
   for(size_t q = 0; q < c->ranks.size(); ++q) {
     jfgpu_comm::Rank& R = c->ranks[q];
     jfgpu_table* t = R.t;
-    if(t->wide || t->nword) return fail(JFGPU_E_UNSUPPORTED, "sharded tables of two-word keys do not grow yet: give -s the size the input needs");
+    if(t->nword) return fail(JFGPU_E_UNSUPPORTED, "sharded tables of keys longer than two words are not built");
+    const uint64_t kw = t->wide ? 2 : 1;                   // 64-bit words per key
     int rc = comm_insert_prev(c, R); if(rc) return rc;
     rc = grow_prepare(t, N[q]);
     if(rc < 0) return fail(JFGPU_E_FULL, "Hash full (no memory to double a shard)");
@@ -867,17 +895,20 @@ int comm_grow(jfgpu_comm* c) {
     const int have_ovf = (int)(N[q].ctr[CTR_OVF_USED] != 0);
     const dim3 grid(grid_for(t, (1ull << t->g.lsize_l) / kBlock + 1)), block(kBlock);
     HIP_TRY(hipMemsetAsync(R.d_cnt, 0, sizeof(unsigned long long) * W, t->stream));
-    hipLaunchKernelGGL(reshard_kernel, grid, block, 0, t->stream, t->dt, N[q].nd, have_ovf, 0, R.d_cnt, (uint64_t*)nullptr, (uint64_t*)nullptr);
+    if(t->wide) hipLaunchKernelGGL(reshard_wide_kernel, grid, block, 0, t->stream, t->wt, N[q].nw, have_ovf, 0, R.d_cnt, (uint64_t*)nullptr, (uint64_t*)nullptr);
+    else hipLaunchKernelGGL(reshard_kernel, grid, block, 0, t->stream, t->dt, N[q].nd, have_ovf, 0, R.d_cnt, (uint64_t*)nullptr, (uint64_t*)nullptr);
     std::vector<unsigned long long> h(W);
     HIP_TRY(hipMemcpyAsync(h.data(), R.d_cnt, sizeof(unsigned long long) * W, hipMemcpyDeviceToHost, t->stream));
     HIP_TRY(hipStreamSynchronize(t->stream));
     uint64_t total = 0;
-    for(int p = 0; p < W; ++p) { R.scount[0][p] = h[p]; R.soff[0][p] = total; total += h[p]; h[p] = R.soff[0][p]; }
-    R.soff[0][W] = total;
-    R.scount[1] = R.scount[0]; R.soff[1] = R.soff[0];
-    for(int b = 0; b < 2; ++b) { rc = comm_reserve(R.send[b], R.send_cap[b], std::max<uint64_t>(total, 1), t->stream, c->xstream); if(rc) return rc; }
+    // turn 0 carries the keys (kw words each), turn 1 the counts: the same groups, in the same order
+    for(int p = 0; p < W; ++p) { R.scount[1][p] = h[p]; R.soff[1][p] = total; R.scount[0][p] = h[p] * kw; R.soff[0][p] = total * kw; total += h[p]; h[p] = R.soff[1][p]; }
+    R.soff[1][W] = total; R.soff[0][W] = total * kw;
+    rc = comm_reserve(R.send[0], R.send_cap[0], std::max<uint64_t>(total * kw, 1), t->stream, c->xstream); if(rc) return rc;
+    rc = comm_reserve(R.send[1], R.send_cap[1], std::max<uint64_t>(total, 1), t->stream, c->xstream); if(rc) return rc;
     HIP_TRY(hipMemcpyAsync(R.d_cnt, h.data(), sizeof(unsigned long long) * W, hipMemcpyHostToDevice, t->stream));   // cursors = offsets
-    hipLaunchKernelGGL(reshard_kernel, grid, block, 0, t->stream, t->dt, N[q].nd, have_ovf, 1, R.d_cnt, R.send[0], R.send[1]);
+    if(t->wide) hipLaunchKernelGGL(reshard_wide_kernel, grid, block, 0, t->stream, t->wt, N[q].nw, have_ovf, 1, R.d_cnt, R.send[0], R.send[1]);
+    else hipLaunchKernelGGL(reshard_kernel, grid, block, 0, t->stream, t->dt, N[q].nd, have_ovf, 1, R.d_cnt, R.send[0], R.send[1]);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(t->stream));
     R.used[0] = R.used[1] = false;                            // (everything before is complete: the exchanges below start from a clean slate)
@@ -894,8 +925,9 @@ int comm_grow(jfgpu_comm* c) {
     jfgpu_table* t = R.t;
     HIP_TRY(hipStreamWaitEvent(t->stream, R.exchanged[0], 0));
     HIP_TRY(hipStreamWaitEvent(t->stream, R.exchanged[1], 0));
-    const uint64_t n = R.roff[0][W];
-    if(n) hipLaunchKernelGGL(add_pairs_kernel, dim3(grid_for(t, n / kBlock + 1)), dim3(kBlock), 0, t->stream, N[q].nd, (const uint64_t*)R.recv[0], (const uint64_t*)R.recv[1], n);
+    const uint64_t n = R.roff[1][W];                        // pairs that arrived (turn 1's offsets count them; turn 0's count key words)
+    if(n && t->wide) hipLaunchKernelGGL(add_pairs_wide_kernel, dim3(grid_for(t, n / kBlock + 1)), dim3(kBlock), 0, t->stream, N[q].nw, (const uint64_t*)R.recv[0], (const uint64_t*)R.recv[1], n);
+    else if(n) hipLaunchKernelGGL(add_pairs_kernel, dim3(grid_for(t, n / kBlock + 1)), dim3(kBlock), 0, t->stream, N[q].nd, (const uint64_t*)R.recv[0], (const uint64_t*)R.recv[1], n);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(R.consumed[0], t->stream));
     HIP_TRY(hipEventRecord(R.consumed[1], t->stream));
@@ -931,8 +963,8 @@ extern "C" int jfgpu_comm_allreduce_u64(jfgpu_comm* c, uint64_t* values, int n, 
 // shard keeps an upper bound of its occupancy (what it measured last + the largest piece any rank fed in every exchange
 // since: k-mers <= bytes, and a hash prefix gets its even share of them), input is fed in pieces that fit the head-room the
 // ranks have between them (the smallest), and when a rank's head-room runs out every rank measures its shard; if one is
-// more than half full, all of them double together (comm_grow).  Shards of two-word keys do not grow yet.
-bool comm_growing(const jfgpu_table* t) { return t->grow_on && !t->wide && !t->nword && t->g.lsize_g < t->g.key_bits; }
+// more than half full, all of them double together (comm_grow).
+bool comm_growing(const jfgpu_table* t) { return t->grow_on && !t->nword && t->g.lsize_g < t->g.key_bits; }
 uint64_t comm_headroom(const jfgpu_table* t) {
   const uint64_t limit = capacity_limit(t), used = t->occ_known + t->fed_since;
   return limit > used ? limit - used : 0;

@@ -708,12 +708,12 @@ def test_count_gpus_n_as_rank_processes_on_one_device(cli, tmp_path, world, item
     assert subprocess.check_output([cli, "stats", out]) == subprocess.check_output([cli, "stats", ref])
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_count_gpus_n_with_a_size_hint_far_too_small(cli, tmp_path, world):
+@pytest.mark.parametrize("world,k", [(2, 21), (4, 21), (2, 40)])
+def test_count_gpus_n_with_a_size_hint_far_too_small(cli, tmp_path, world, k):
     """`-s` is a hint with --gpus too (doc/Readme.md:67-72; round-3 review, missing #1: `count --gpus 8 -s <too small>` was
     "Hash full"): rank processes whose shards start at 1 k slots double them together, as often as it takes, and the file
     they write holds the single-process run's counts, in (pos, key) order under the matrix its header names (the
-    reference's reader checks the order)."""
+    reference's reader checks the order).  k = 40: shards of two-word keys grow the same way (round 4)."""
     import random
     rng = random.Random(23 + world)
     fa = tmp_path / "reads.fa"
@@ -721,9 +721,9 @@ def test_count_gpus_n_with_a_size_hint_far_too_small(cli, tmp_path, world):
         for r in range(3000):
             f.write((">r%d\n%s\n" % (r, "".join(rng.choice("ACGT") for _ in range(150)))).encode())
     ref, out = str(tmp_path / "ref.jf"), str(tmp_path / "gN.jf")
-    subprocess.check_call([cli, "count", "-m", "21", "-C", "-s", "1k", "-o", ref, str(fa)])
+    subprocess.check_call([cli, "count", "-m", str(k), "-C", "-s", "1k", "-o", ref, str(fa)])
     env = dict(os.environ, JFGPU_COMM_TRANSPORT="ipc", JFGPU_PARSE_CHUNK="100000", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    subprocess.check_call([cli, "count", "-m", "21", "-C", "-s", "1k", "-o", out, "--gpus", str(world), str(fa)], env=env, timeout=900)
+    subprocess.check_call([cli, "count", "-m", str(k), "-C", "-s", "1k", "-o", out, "--gpus", str(world), str(fa)], env=env, timeout=900)
     want = sorted(subprocess.check_output([cli, "dump", "-c", ref]).decode().splitlines())
     got = subprocess.check_output([cli, "dump", "-c", out]).decode().splitlines()
     assert sorted(got) == want and len(want) > 300000

@@ -372,3 +372,51 @@ def test_sharded_two_word_keys_equal_single_table(gpu, monkeypatch, k, world, ma
         comm.close()
         for t in shards:
             t.close()
+
+
+@pytest.mark.parametrize("k,world", [(40, 2), (48, 4), (33, 1)])
+def test_two_word_shards_grow_together(gpu, k, world):
+    """hash_counter::double_size (hash_counter.hpp:200-238) for sharded tables of two-word keys: shards created far too
+    small double together (abi_comm.inl: comm_grow -- reshard_wide_kernel, pairs of (two key words, count) through the
+    key path's exchange, add_pairs_wide_kernel).  What the shards hold afterwards is what one table that grew on its own
+    holds: the same k-mers with the same counts, every k-mer on the shard its position names, nothing lost in transit."""
+    rng = random.Random(k * 11 + world)
+    steps = [[rnd_seq(rng, rng.choice([20000, 50000, 80000]), "ACGT") + b"N" + rnd_seq(rng, 300, "ACGTN") for _ in range(world)] for _step in range(4)]
+    whole_seq = b"N".join(b"N".join(step) for step in steps)
+    keys, cnt = O.count(whole_seq, k, True)
+    exp = oracle_map(whole_seq, k, True)
+    sb = world.bit_length() - 1
+    shards = [gpu.Table(k, 1 << 14, shard_bits=sb, shard_id=r) for r in range(world)]
+    comm = gpu.Comm(world, local=True)
+    try:
+        lsize0 = shards[0].info.lsize
+        bufs = []
+        for step in steps:
+            ptrs, ns = [], []
+            for r, seq in enumerate(step):
+                d = shards[r].malloc(len(seq) + 64)
+                shards[r].h2d(d, np.frombuffer(seq, dtype=np.uint8))
+                bufs.append((shards[r], d)); ptrs.append(d); ns.append(len(seq))
+            comm.local_step(shards, ptrs, ns)
+        sent, received = comm.finish()
+        assert sent == received == int(cnt.sum())
+        got = {}
+        for r, t in enumerate(shards):
+            t.sync()
+            assert t.info.lsize > lsize0 + 2 and t.info.lsize == shards[0].info.lsize, "the shards must have doubled, and together"
+            part = table_map(gpu, t)                          # (checks the (pos, key) order under the table's own matrix)
+            sub = np.array(list(part.keys())[:4000], dtype=np.uint64).reshape(-1, 2)
+            if sb and len(sub):
+                pos = O.matrix_times(t.matrix(), t.info.lsize, 2 * k, sub)
+                assert ((pos >> np.uint64(t.info.lsize - sb)) == r).all()
+            assert not (set(part) & set(got))
+            got.update(part)
+        assert got == exp
+        assert len({tuple(t.matrix().tolist()) for t in shards}) == 1
+        assert sum(t.stats().total for t in shards) == int(cnt.sum())
+        for t, d in bufs:
+            t.free(d)
+    finally:
+        comm.close()
+        for t in shards:
+            t.close()
