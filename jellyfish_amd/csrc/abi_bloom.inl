@@ -115,6 +115,12 @@ static int bloom_create(const jfgpu_bloom_params* p, jfgpu_bloom** out, uint32_t
     HIP_TRY(hipFuncSetAttribute((const void*)p1_bloom_granule_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, pl));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_bloom_granule_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, pl));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_bloom_granule_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, pl));
+    {
+      const int pl2 = (int)((size_t)kPBlock * 5 * 6 + (size_t)8 * 512);
+      HIP_TRY(hipFuncSetAttribute((const void*)p1_bloom_granule2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, pl2));
+      HIP_TRY(hipFuncSetAttribute((const void*)p1_bloom_granule2_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, pl2));
+      HIP_TRY(hipFuncSetAttribute((const void*)p1_bloom_granule2_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, pl2));
+    }
     HIP_TRY(hipFuncSetAttribute((const void*)bloom_segment_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 1 << kBloomSegBits));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint32_t, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint32_t, BloomDirect, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));

@@ -95,7 +95,7 @@ int bloom_launch_direct(jfgpu_bloom* b, const uint8_t* base, int64_t lo, int64_t
 
 // One contract buffer [lo, hi) through P1b, in pieces that fit half of the arena (the other half is the flush's).
 int bloom_ingest(jfgpu_bloom* b, const uint8_t* base, int64_t lo, int64_t hi) {
-  if(!b->g1) b->g1 = b->n_cu;                                  // ~130 KB of LDS per block: one block per CU
+  if(!b->g1) b->g1 = b->tun.bloom_p1_two ? 2 * b->n_cu : b->n_cu;      // workgroups of P1b: two per CU (78 KB of LDS each) or one (136 KB)
   int rc = bloom_ws_ensure(b, 0);
   if(rc < 0) return bloom_launch_direct(b, base, lo, hi);      // no memory for an arena
   if(rc) return rc;
@@ -141,7 +141,11 @@ int bloom_ingest(jfgpu_bloom* b, const uint8_t* base, int64_t lo, int64_t hi) {
     {
       BloomProf ps(b, BS_P1, piece);
 #define PB(N) hipLaunchKernelGGL(p1_bloom_granule_kernel<N>, dim3(b->g1), dim3(kPBlock), lds, b->stream, b->view(), b->bp, b->g, pbase, plo, phi, cap, gcur, p.tot, p.items, b->d_mers)
-      if(b->g.nbytes == 8) PB(8); else if(b->g.nbytes == 6) PB(6); else PB(0);
+#define PB2(N) hipLaunchKernelGGL(p1_bloom_granule2_kernel<N>, dim3(b->g1), dim3(kPBlock), (size_t)kPBlock * 5 * 6 + (size_t)b->g.nbytes * 512, b->stream, \
+                                  b->view(), b->bp, b->g, pbase, plo, phi, cap, gcur, p.tot, p.items, b->d_mers)
+      if(b->tun.bloom_p1_two) { if(b->g.nbytes == 8) PB2(8); else if(b->g.nbytes == 6) PB2(6); else PB2(0); }
+      else if(b->g.nbytes == 8) PB(8); else if(b->g.nbytes == 6) PB(6); else PB(0);
+#undef PB2
 #undef PB
       hipLaunchKernelGGL(granule_finish_kernel, dim3((nb + 255) / 256), dim3(256), 0, b->stream, gcur, cap, nb, p.off);
     }

@@ -64,22 +64,37 @@ struct BloomRingDirect {
 // One block iteration = 16384 sequence positions.  The lanes roll their 16 windows together, one position per round:
 // a round gives every lane at most kBloomPer items (nh > kBloomPer takes more rounds), 10240 per block, sorted and
 // placed by granule_emit.  NB: key bytes fed to the two hash tables (compile-time for the common widths).
-template <int NB>
-__global__ __launch_bounds__(kPBlock) void p1_bloom_granule_kernel(DevBloom B, BloomPart BP, TableGeom g, const uint8_t* __restrict__ base,
-                                                                   int64_t lo, int64_t hi, uint32_t cap,
-                                                                   unsigned int* __restrict__ gcur, unsigned long long* __restrict__ tot,
-                                                                   uint32_t* __restrict__ out, unsigned long long* __restrict__ mers) {
+// PER: cell updates per lane and round (nh > PER takes more rounds).  NIB: the two hashes come from nibble tables -- one
+// 16-byte entry (both hashes) per value of every 4 key bits, 512 bytes per key byte instead of 4 KiB, built here from
+// the byte tables: sixteen ds_read_b128 per k-mer instead of sixteen ds_read_b64.  <NB, 5, true> needs 35 KB of dynamic
+// LDS instead of 93: two workgroups per CU (the pass is latency-bound at 16 waves per CU, section 3.4 of DESIGN.md).
+template <int NB, int PER, bool NIB>
+__device__ __forceinline__ void p1_bloom_granule_body(const DevBloom& B, const BloomPart& BP, const TableGeom& g, const uint8_t* __restrict__ base,
+                                                      int64_t lo, int64_t hi, uint32_t cap,
+                                                      unsigned int* __restrict__ gcur, unsigned long long* __restrict__ tot,
+                                                      uint32_t* __restrict__ out, unsigned long long* __restrict__ mers) {
+  constexpr int kChunk = kPBlock * PER;
   JF_DYN_LDS(s_dyn);
-  uint32_t* s_item = reinterpret_cast<uint32_t*>(s_dyn);                               // [kBloomChunk]
-  uint16_t* s_bkt = reinterpret_cast<uint16_t*>(s_dyn + (size_t)kBloomChunk * 4);      // [kBloomChunk]
-  uint64_t* s_t1 = reinterpret_cast<uint64_t*>(s_dyn + (size_t)kBloomChunk * 6);       // [nbytes * 256]
+  uint32_t* s_item = reinterpret_cast<uint32_t*>(s_dyn);                               // [kChunk]
+  uint16_t* s_bkt = reinterpret_cast<uint16_t*>(s_dyn + (size_t)kChunk * 4);           // [kChunk]
+  uint64_t* s_t1 = reinterpret_cast<uint64_t*>(s_dyn + (size_t)kChunk * 6);            // [nbytes * 256]   (NIB: uint4 [nbytes * 32])
   uint64_t* s_t2 = s_t1 + (size_t)B.nbytes * 256;
+  uint4* s_tn = reinterpret_cast<uint4*>(s_dyn + (size_t)kChunk * 6);
   __shared__ uint32_t s_codes[kPBlock + 2];
   __shared__ uint32_t s_inv[kPBlock + 2];
   __shared__ GranuleLds G;
   const uint32_t nb = 1u << BP.b1;
-  load_tables_lds(s_t1, B.tbl1, B.nbytes);
-  load_tables_lds(s_t2, B.tbl2, B.nbytes);
+  if constexpr(NIB) {
+    for(uint32_t i = threadIdx.x; i < B.nbytes * 32; i += blockDim.x) {      // entry (nibble j, value v) = the byte tables' entry of that value in that nibble
+      const uint32_t j = i >> 4, v = i & 15u;
+      const uint32_t at = (j >> 1) * 256 + ((j & 1) ? (v << 4) : v);
+      const uint64_t a = B.tbl1[at], c = B.tbl2[at];
+      s_tn[i] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)c, (uint32_t)(c >> 32));
+    }
+  } else {
+    load_tables_lds(s_t1, B.tbl1, B.nbytes);
+    load_tables_lds(s_t2, B.tbl2, B.nbytes);
+  }
   granule_init(G, nb);
   const uint32_t k = g.k;
   const uint64_t kwin = k >= 64 ? ~0ull : ((1ull << k) - 1);
@@ -103,16 +118,26 @@ __global__ __launch_bounds__(kPBlock) void p1_bloom_granule_kernel(DevBloom B, B
       if(valid) {
         ++my_mers;
         const uint64_t key = (g.canonical && rc < fw) ? rc : fw;
-        cell = bloom_mod(hash_tables_t<NB>(s_t1, key, B.nbytes), B.m, B.recip);
-        inc = bloom_mod(hash_tables_t<NB>(s_t2, key, B.nbytes), B.m, B.recip);
+        if constexpr(NIB) {
+          constexpr int kNibs = NB ? 2 * NB : 16;
+          uint32_t a0 = 0, a1 = 0, c0 = 0, c1 = 0;
+#pragma unroll
+          for(int j = 0; j < kNibs; ++j)
+            if(NB || (uint32_t)j < 2 * B.nbytes) { const uint4 e = s_tn[j * 16 + ((uint32_t)(key >> (4 * j)) & 15u)]; a0 ^= e.x; a1 ^= e.y; c0 ^= e.z; c1 ^= e.w; }
+          cell = bloom_mod(((uint64_t)a1 << 32) | a0, B.m, B.recip);
+          inc = bloom_mod(((uint64_t)c1 << 32) | c0, B.m, B.recip);
+        } else {
+          cell = bloom_mod(hash_tables_t<NB>(s_t1, key, B.nbytes), B.m, B.recip);
+          inc = bloom_mod(hash_tables_t<NB>(s_t2, key, B.nbytes), B.m, B.recip);
+        }
       }
-      for(uint32_t h0 = 0; h0 < B.nh; h0 += kBloomPer) {                                // block-uniform trip count
+      for(uint32_t h0 = 0; h0 < B.nh; h0 += PER) {                                      // block-uniform trip count
         lds_barrier();
         for(uint32_t q = threadIdx.x; q < nb; q += blockDim.x) G.hist[q] = 0;
         lds_barrier();
-        uint32_t it[kBloomPer], dr[kBloomPer];
+        uint32_t it[PER], dr[PER];
 #pragma unroll
-        for(int e = 0; e < kBloomPer; ++e) {
+        for(int e = 0; e < PER; ++e) {
           dr[e] = 0xFFFFFFFFu; it[e] = 0;
           if(valid && h0 + e < B.nh) {
             uint64_t byte; uint32_t dig;
@@ -134,6 +159,23 @@ __global__ __launch_bounds__(kPBlock) void p1_bloom_granule_kernel(DevBloom B, B
   for(int o = 32; o > 0; o >>= 1) w += __shfl_down(w, o, 64);
   if((threadIdx.x & 63) == 0 && w) atomicAdd(mers, (unsigned long long)w);
   (void)my_direct;
+}
+
+template <int NB>
+__global__ __launch_bounds__(kPBlock) void p1_bloom_granule_kernel(DevBloom B, BloomPart BP, TableGeom g, const uint8_t* __restrict__ base,
+                                                                   int64_t lo, int64_t hi, uint32_t cap,
+                                                                   unsigned int* __restrict__ gcur, unsigned long long* __restrict__ tot,
+                                                                   uint32_t* __restrict__ out, unsigned long long* __restrict__ mers) {
+  p1_bloom_granule_body<NB, kBloomPer, false>(B, BP, g, base, lo, hi, cap, gcur, tot, out, mers);
+}
+// two workgroups per CU: eight waves per SIMD, so at most 64 vector registers
+template <int NB>
+__global__ __launch_bounds__(kPBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void p1_bloom_granule2_kernel(DevBloom B, BloomPart BP, TableGeom g, const uint8_t* __restrict__ base,
+                              int64_t lo, int64_t hi, uint32_t cap,
+                              unsigned int* __restrict__ gcur, unsigned long long* __restrict__ tot,
+                              uint32_t* __restrict__ out, unsigned long long* __restrict__ mers) {
+  p1_bloom_granule_body<NB, 5, true>(B, BP, g, base, lo, hi, cap, gcur, tot, out, mers);
 }
 
 // (P1b through the count path's rings -- a ring of 32 cell updates per bucket, `cpr` cells of the current k-mer appended per

@@ -30,6 +30,7 @@ struct Tuning {
   int p2_ring = 1;               // JFGPU_P2_RING          single-pass P2 of 4-byte items through per-destination rings (0: the sort-based kernel, 3: never the loader / storer kernel; A/B)
   // ---- Bloom counters (jfgpu_bloom_create)
   int bloom_mode = 0;            // JFGPU_BLOOM_MODE=direct|partitioned      0: not set
+  int bloom_p1_two = 1;          // JFGPU_BLOOM_P1_TWO     P1b as two workgroups per CU (rounds of 5 cells, nibble tables); 0: one, rounds of 10 (A/B)
   // ---- communicators (jfgpu_comm_create*)
   bool comm_trace = false;       // JFGPU_COMM_TRACE       every rank reports where it is in a step
   bool comm_ipc = false;         // JFGPU_COMM_TRANSPORT=ipc   rank processes exchange through hipIpc* copies instead of RCCL
@@ -54,6 +55,7 @@ struct Tuning {
     if(const char* e = str("JFGPU_FLUSH_SHARE")) u.flush_share = (uint32_t)atoi(e);
     u.flush_trace = str("JFGPU_FLUSH_TRACE") != nullptr;
     if(const char* e = str("JFGPU_P2_RING")) u.p2_ring = atoi(e);
+    if(const char* e = str("JFGPU_BLOOM_P1_TWO")) u.bloom_p1_two = atoi(e);
     if(const char* e = str("JFGPU_BLOOM_MODE")) u.bloom_mode = !strcmp(e, "direct") ? 1 : !strcmp(e, "partitioned") ? 2 : 0;
     u.comm_trace = str("JFGPU_COMM_TRACE") != nullptr;
     if(const char* e = str("JFGPU_COMM_TRANSPORT")) u.comm_ipc = !strcmp(e, "ipc");
