@@ -307,3 +307,19 @@ def test_host_sequence_parser_errors(parser_emu, tmp_path):
     empty = tmp_path / "empty.fa"
     empty.write_bytes(b"")
     assert subprocess.check_output([parser_emu, "21", "4096", str(empty)]) == b""
+
+
+def test_every_engine_switch_is_documented():
+    """The engine reads its JFGPU_* switches in one place (csrc/tuning.hpp, a snapshot per object; round-3 review item 7):
+    every name parsed there is listed in INTEGRATION.md's table, and nothing else under csrc/ calls getenv."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "jellyfish_amd", "csrc")
+    names = set(re.findall(r'str\("(JFGPU_[A-Z0-9_]+)"\)', open(os.path.join(csrc, "tuning.hpp")).read()))
+    assert len(names) >= 20
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    assert sorted(n for n in names if n not in doc) == []
+    for fn in sorted(os.listdir(csrc)):
+        if fn == "tuning.hpp" or not fn.endswith((".hip", ".hpp", ".inl")):
+            continue
+        assert "getenv(" not in open(os.path.join(csrc, fn)).read(), fn
