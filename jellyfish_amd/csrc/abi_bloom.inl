@@ -302,7 +302,8 @@ int jfgpu_attach_bloom(jfgpu_table* t, jfgpu_bloom* b) {   // count --bc (count_
   if(!b) { memset(&t->dt.bloom, 0, sizeof t->dt.bloom); memset(&t->wt.bloom, 0, sizeof t->wt.bloom); return JFGPU_OK; }
   if(b->device != t->device) return fail(JFGPU_E_INVALID, "Bloom counter lives on another device");
   if(b->g.k != t->g.k) return fail(JFGPU_E_INVALID, "Invalid mer length in bloom filter");
-  if(t->g.shard_bits) return fail(JFGPU_E_UNSUPPORTED, "count --bc on a sharded table is not built yet");
+  // a shard: the counter is asked on the sending side of the exchange (abi_comm.inl: comm_filter_ok), never on arrival
+  if(t->g.shard_bits && (t->wide || b->kind != 0)) return fail(JFGPU_E_UNSUPPORTED, "sharded tables take a Bloom counter (count --bc) with one-word keys only");
   if(t->nword) return fail(JFGPU_E_UNSUPPORTED, "Bloom filters for mer length > 64 are not built");
   rc = bloom_flush(b); if(rc) return rc;
   HIP_TRY(hipStreamSynchronize(b->stream));

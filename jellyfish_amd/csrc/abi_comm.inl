@@ -192,6 +192,14 @@ __global__ __launch_bounds__(1024) void comm_claims_kernel(const unsigned long l
   if(threadIdx.x == 0) { summary[0] = s_stored; summary[1] = ns; }
 }
 
+// A Bloom counter attached to a shard (count --bc) is asked on the SENDING side, every rank holding the whole read-only
+// counter.  A one-pass filter (--bf-size) changes as it is asked and would see only its rank's reads; two-word keys: not built.
+int comm_filter_ok(const jfgpu_table* t) {
+  if(t->wide && t->wt.bloom.data) return fail(JFGPU_E_UNSUPPORTED, "count --bc with --gpus: two-word keys are not built yet");
+  if(!t->wide && t->dt.bloom.data && t->dt.bloom.kind != 0) return fail(JFGPU_E_UNSUPPORTED, "--bf-size with --gpus: a one-pass filter cannot be sharded by input");
+  return JFGPU_OK;
+}
+
 // P1 over the global table into send[cur]: enqueued here, looked at in comm_route_items_complete -- between the two the
 // caller enqueues the insert of what arrived for the previous step, so the device has work while the host waits for the
 // two numbers it needs (stragglers, exact item count).
@@ -199,6 +207,7 @@ int comm_route_items_enqueue(jfgpu_comm* c, jfgpu_comm::Rank& R, const char* d_b
   jfgpu_table* t = R.t;
   const int cur = R.turn;
   const ItemLayout L = item_layout(c, t, cap);
+  { const int rc_ = comm_filter_ok(t); if(rc_) return rc_; }
   if(R.used[cur]) HIP_TRY(hipEventSynchronize(R.exchanged[cur]));       // send[cur] has left (step - 2)
   int rc = comm_reserve(R.send[cur], R.send_cap[cur], (L.send_bytes + 7) / 8, t->stream, c->xstream); if(rc) return rc;
   if(!R.used[cur ^ 1]) { rc = comm_reserve(R.send[cur ^ 1], R.send_cap[cur ^ 1], (L.send_bytes + 7) / 8, t->stream, c->xstream); if(rc) return rc; }   // (both buffers of the pair at once)
@@ -224,7 +233,9 @@ int comm_route_items_enqueue(jfgpu_comm* c, jfgpu_comm::Rank& R, const char* d_b
     ProfScope ps(t, 2, n);
     // the count path's ring P1 (kernels_p1ring.hip.hpp) over the global geometry; what it cannot store goes on the list
 #define PR(N, CN) hipLaunchKernelGGL((p1_ring_kernel<uint32_t, false, N, CN, RouteListDirect>), grid, block, lds, t->stream, gv, rd, pg, base, lo, hi, cap, R.d_gcur, tot, items, t->d_strag, t->d_strag_n)
-    if(t->g.nbytes == 6) { if(t->g.canonical) PR(6, 1); else PR(6, 0); } else PR(0, 2);
+    if(t->dt.bloom.data)      // count --bc: the sender asks its copy of the Bloom counter (read-only: the same answer on every rank)
+      hipLaunchKernelGGL((p1_ring_kernel<uint32_t, true, 0, 2, RouteListDirect>), grid, block, lds, t->stream, gv, rd, pg, base, lo, hi, cap, R.d_gcur, tot, items, t->d_strag, t->d_strag_n);
+    else if(t->g.nbytes == 6) { if(t->g.canonical) PR(6, 1); else PR(6, 0); } else PR(0, 2);
 #undef PR
     hipLaunchKernelGGL((p1_stragglers_kernel<uint32_t, RouteListDirect>), dim3(t->n_cu), dim3(256), 0, t->stream, rd, (unsigned long long*)nullptr, (const uint64_t*)t->d_strag,
                        (const uint32_t*)t->d_strag_n, (uint32_t)t->n_cu, cap, R.d_gcur, tot, items, kStragPerBlock);
@@ -369,6 +380,7 @@ int comm_route(jfgpu_comm* c, jfgpu_comm::Rank& R, const char* d_bases, size_t n
   const int cur = R.turn, W = c->world;
   if((int)(1u << t->g.shard_bits) != W) return fail(JFGPU_E_INVALID, "table shard_bits does not match the communicator's world size");
   if(t->nword) return fail(JFGPU_E_UNSUPPORTED, "sharded tables with mer length > 64 are not built yet");
+  { const int rc_ = comm_filter_ok(t); if(rc_) return rc_; }
   const uint64_t kw = t->wide ? 2 : 1;                                   // 64-bit words per routed k-mer (counts and offsets below are in words)
   if(R.used[cur]) HIP_TRY(hipEventSynchronize(R.exchanged[cur]));       // send[cur] has left (step - 2)
   std::fill(R.scount[cur].begin(), R.scount[cur].end(), 0);
@@ -384,7 +396,8 @@ int comm_route(jfgpu_comm* c, jfgpu_comm::Rank& R, const char* d_bases, size_t n
   {
     ProfScope ps(t, 2, n);
     if(t->wide) hipLaunchKernelGGL(partition_count_wide_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->wt, base, lo, hi, R.d_cnt);
-    else hipLaunchKernelGGL(partition_count_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, base, lo, hi, R.d_cnt);
+    else if(t->dt.bloom.data) hipLaunchKernelGGL(partition_count_kernel<true>, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, base, lo, hi, R.d_cnt);
+    else hipLaunchKernelGGL(partition_count_kernel<false>, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, base, lo, hi, R.d_cnt);
   }
   std::vector<unsigned long long> h(W);
   HIP_TRY(hipMemcpyAsync(h.data(), R.d_cnt, sizeof(unsigned long long) * W, hipMemcpyDeviceToHost, t->stream));
@@ -396,7 +409,8 @@ int comm_route(jfgpu_comm* c, jfgpu_comm::Rank& R, const char* d_bases, size_t n
   {
     ProfScope ps(t, 2, 0);
     if(t->wide) hipLaunchKernelGGL(partition_scatter_wide_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->wt, base, lo, hi, R.d_cnt, R.send[cur]);
-    else hipLaunchKernelGGL(partition_scatter_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, base, lo, hi, R.d_cnt, R.send[cur]);
+    else if(t->dt.bloom.data) hipLaunchKernelGGL(partition_scatter_kernel<true>, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, base, lo, hi, R.d_cnt, R.send[cur]);
+    else hipLaunchKernelGGL(partition_scatter_kernel<false>, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, base, lo, hi, R.d_cnt, R.send[cur]);
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(t->stream));       // the host vector h is read by the copy above

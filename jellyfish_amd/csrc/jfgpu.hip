@@ -724,6 +724,7 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     HIP_TRY(hipFuncSetAttribute((const void*)p1_ring_kernel<uint32_t, false, 6, 1, RouteListDirect>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kGranMaxB * 128 + 128)));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_ring_kernel<uint32_t, false, 6, 0, RouteListDirect>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kGranMaxB * 128 + 128)));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_ring_kernel<uint32_t, false, 0, 2, RouteListDirect>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kGranMaxB * 128 + 128)));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_ring_kernel<uint32_t, true, 0, 2, RouteListDirect>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kGranMaxB * 128 + 128)));
 #define SATTR(SW) HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint32_t, TableDirect<true>, kP2PairPer, SW>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4)); \
                   HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint32_t, TableDirect<false>, kP2PairPer, SW>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4))
     SATTR(1); SATTR(2); SATTR(4);
@@ -1011,7 +1012,7 @@ int jfgpu_partition_ascii_dev(jfgpu_table* t, const char* d_bases, size_t n, uin
   const int grid = grid_for(t, (uint64_t)n_tiles);
   {
     ProfScope ps(t, 2, n);
-    hipLaunchKernelGGL(partition_count_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, base, lo, hi, d_cnt);
+    hipLaunchKernelGGL(partition_count_kernel<false>, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, base, lo, hi, d_cnt);
   }
   std::vector<unsigned long long> h(n_shards);
   hipError_t e = hipMemcpyAsync(h.data(), d_cnt, sizeof(unsigned long long) * n_shards, hipMemcpyDeviceToHost, t->stream);
@@ -1024,7 +1025,7 @@ int jfgpu_partition_ascii_dev(jfgpu_table* t, const char* d_bases, size_t n, uin
   e = hipMemcpyAsync(d_cnt, offs.data(), sizeof(unsigned long long) * n_shards, hipMemcpyHostToDevice, t->stream);
   if(e == hipSuccess) {
     ProfScope ps(t, 2, 0);
-    hipLaunchKernelGGL(partition_scatter_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, base, lo, hi, d_cnt, d_keys_out);
+    hipLaunchKernelGGL(partition_scatter_kernel<false>, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, base, lo, hi, d_cnt, d_keys_out);
     e = hipGetLastError();
   }
   if(e == hipSuccess) e = hipStreamSynchronize(t->stream);

@@ -426,6 +426,8 @@ __global__ __launch_bounds__(kBlock) void lookup_kernel(DevTable T, const uint64
 
 // ---- multi-GPU routing: count per shard, then scatter ----------------------------
 // Pass A: how many k-mers of this buffer belong to each shard.
+// BLOOM: count --bc with --gpus -- the sender asks its copy of the Bloom counter, what it does not admit never travels.
+template <bool BLOOM = false>
 __global__ __launch_bounds__(kBlock) void partition_count_kernel(DevTable T, const uint8_t* __restrict__ base,
                                                                  int64_t lo, int64_t hi,
                                                                  unsigned long long* __restrict__ shard_counts) {
@@ -440,7 +442,9 @@ __global__ __launch_bounds__(kBlock) void partition_count_kernel(DevTable T, con
   for(int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     __syncthreads();
     const LaneWords L = stage_tile(base, tile * kTilePos, lo, hi, s_codes, s_inv);
-    for_each_kmer(T.g, L, [&](int, uint64_t key) {
+    const uint32_t adm = BLOOM ? bloom_admit_mask(T.bloom, T.g, L) : 0xFFFFu;
+    for_each_kmer(T.g, L, [&](int j, uint64_t key) {
+      if(BLOOM && !((adm >> j) & 1u)) return;
       const uint64_t pos = hash_tables(s_fwd, key, T.g.nbytes);
       atomicAdd(&s_hist[(uint32_t)(pos >> T.g.lsize_l)], 1u);
     });
@@ -452,6 +456,7 @@ __global__ __launch_bounds__(kBlock) void partition_count_kernel(DevTable T, con
 
 // Pass B: write each k-mer into its shard's region.  cursors[s] starts at the
 // region's offset; a block reserves its share with one atomic per (tile, shard).
+template <bool BLOOM = false>
 __global__ __launch_bounds__(kBlock) void partition_scatter_kernel(DevTable T, const uint8_t* __restrict__ base,
                                                                    int64_t lo, int64_t hi,
                                                                    unsigned long long* __restrict__ cursors,
@@ -470,7 +475,9 @@ __global__ __launch_bounds__(kBlock) void partition_scatter_kernel(DevTable T, c
     const LaneWords L = stage_tile(base, tile * kTilePos, lo, hi, s_codes, s_inv);  // contains a barrier
     // indexed by the unrolled position j (compile-time after unrolling) so these stay in VGPRs
     uint64_t keys[kPerThread]; uint32_t shard[kPerThread]; uint32_t rank[kPerThread]; uint32_t vmask = 0;
+    const uint32_t adm = BLOOM ? bloom_admit_mask(T.bloom, T.g, L) : 0xFFFFu;      // (the same answers as the count pass: the counter is read-only here)
     for_each_kmer(T.g, L, [&](int j, uint64_t key) {
+      if(BLOOM && !((adm >> j) & 1u)) return;
       const uint64_t pos = hash_tables(s_fwd, key, T.g.nbytes);
       const uint32_t s = (uint32_t)(pos >> T.g.lsize_l);
       keys[j] = key; shard[j] = s;

@@ -732,6 +732,30 @@ def test_count_gpus_n_with_a_size_hint_far_too_small(cli, tmp_path, world, k):
         assert subprocess.check_output([O.REF_JF, "dump", "--check-order", out]).decode().startswith("ORDER OK %d" % len(want))
 
 
+@pytest.mark.parametrize("k", [21, 31])
+def test_count_gpus_n_with_a_bloom_counter_file(cli, tmp_path, k):
+    """`count --bc file --gpus 2` (count_main.cc:109-119, 191-206 with hash-prefix shards; round-3 review, missing #1): every
+    rank process loads the counter file and asks it before routing; the file the ranks write equals the single-process
+    `count --bc` file.  k = 21 takes the item path, k = 31 the key path."""
+    import random
+    rng = random.Random(101 + k)
+    twice = ["".join(rng.choice("ACGT") for _ in range(150)) for _ in range(1500)]
+    fa = tmp_path / "reads.fa"
+    with open(fa, "wb") as f:
+        for r in range(4000):
+            seq = twice[r % 1500] if r < 3000 else "".join(rng.choice("ACGT") for _ in range(150))
+            f.write((">r%d\n%s\n" % (r, seq)).encode())
+    bc, ref, out = str(tmp_path / "reads.bc"), str(tmp_path / "ref.jf"), str(tmp_path / "g2.jf")
+    subprocess.check_call([cli, "bc", "-m", str(k), "-C", "-s", "1M", "-f", "0.01", "-o", bc, str(fa)])
+    subprocess.check_call([cli, "count", "-m", str(k), "-C", "-s", "4M", "--bc", bc, "-o", ref, str(fa)])
+    env = dict(os.environ, JFGPU_COMM_TRANSPORT="ipc", JFGPU_PARSE_CHUNK="100000", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    subprocess.check_call([cli, "count", "-m", str(k), "-C", "-s", "4M", "--bc", bc, "-o", out, "--gpus", "2", str(fa)], env=env, timeout=900)
+    want = subprocess.check_output([cli, "dump", "-c", ref]).decode().splitlines()
+    got = subprocess.check_output([cli, "dump", "-c", out]).decode().splitlines()
+    assert sorted(got) == sorted(want) and 100000 < len(want) < 400000      # (the once-seen reads' k-mers are not admitted)
+    assert subprocess.check_output([cli, "stats", out]) == subprocess.check_output([cli, "stats", ref])
+
+
 def test_a_failing_rank_ends_the_others(cli, tmp_path):
     """One rank of `count --gpus 2` cannot read its input (the file disappears for rank 1 only: JFGPU_TEST_FAIL_RANK): the
     command must come back with an error instead of leaving the other rank waiting in a collective."""

@@ -262,3 +262,62 @@ def test_one_pass_bloom_filter(gpu, monkeypatch, k, mode):
     fp_single = sum(1 for key in single if key in got)
     assert extra <= 0.03 * len(kt_all) and fp_single <= 0.03 * len(single)
     assert set(got) <= rep | single
+
+
+@pytest.mark.parametrize("k,world,items", [(21, 2, "2"), (21, 4, "0"), (31, 2, "0")])
+def test_sharded_count_with_a_bloom_counter_equals_the_single_table(gpu, monkeypatch, k, world, items):
+    """`count --bc` over hash-prefix shards (count_main.cc:109-119 with --gpus; round-3 review, missing #1): every rank
+    holds the whole read-only Bloom counter and asks it on the SENDING side -- in the routing kernels of the item path
+    (k = 21: p1_ring_kernel<.., BLOOM, RouteListDirect>) and of the key path (partition_count / scatter_kernel<BLOOM>) --
+    so what the filter does not admit never travels.  The shards together hold exactly what one table with the same
+    counter attached holds."""
+    monkeypatch.setenv("JFGPU_COMM_ITEMS", items)
+    rng = random.Random(k * 3 + world)
+    once = "".join(rng.choice("ACGT") for _ in range(120000))
+    twice = "".join(rng.choice("ACGT") for _ in range(60000))
+    steps = [[(twice[i * 15000:(i + 1) * 15000] + "N" + once[(4 * i + r) * 5000:(4 * i + r + 1) * 5000] + "N" + twice[i * 15000:(i + 1) * 15000]).encode()
+              for r in range(world)] for i in range(4)]
+    whole_seq = b"N".join(b"N".join(step) for step in steps)
+    n = 400000
+    with gpu.Bloom(k, gpu.opt_m(0.01, n), gpu.opt_k(0.01), canonical=True, seed=9) as b:
+        b.insert_ascii(whole_seq)
+        b.sync()
+        with gpu.Table(k, 1 << 22, canonical=True) as single:
+            single.attach_bloom(b)
+            single.count_ascii(whole_seq); single.sync()
+            kk, cc = gpu.decode_records(single.dump_records(), k, 4)
+            exp = dict(zip(kk.tolist(), cc.tolist()))
+            single.attach_bloom(None)
+        keys, cnt = O.count(whole_seq, k, True)
+        assert 1000 < len(exp) < len(keys), "the filter must admit some k-mers and refuse others"
+        sb = world.bit_length() - 1
+        shards = [gpu.Table(k, 1 << 22, canonical=True, shard_bits=sb, shard_id=r) for r in range(world)]
+        comm = gpu.Comm(world, local=True)
+        try:
+            for t in shards:
+                t.attach_bloom(b)
+            bufs = []
+            for step in steps:
+                ptrs, ns = [], []
+                for r, seq in enumerate(step):
+                    d = shards[r].malloc(len(seq) + 64)
+                    shards[r].h2d(d, np.frombuffer(seq, dtype=np.uint8))
+                    bufs.append((shards[r], d)); ptrs.append(d); ns.append(len(seq))
+                comm.local_step(shards, ptrs, ns)
+            sent, received = comm.finish()
+            assert sent == received == sum(exp.values())
+            got = {}
+            for t in shards:
+                t.sync()
+                kk, cc = gpu.decode_records(t.dump_records(), k, 4)
+                part = dict(zip(kk.tolist(), cc.tolist()))
+                assert not (set(part) & set(got))
+                got.update(part)
+            assert got == exp
+            for t, d in bufs:
+                t.free(d)
+        finally:
+            comm.close()
+            for t in shards:
+                t.attach_bloom(None)
+                t.close()
