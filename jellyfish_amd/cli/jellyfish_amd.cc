@@ -454,8 +454,9 @@ int count_main(int argc, char* argv[]) {
   if(gpus_given) {
     if(gpus < 1 || (gpus & (gpus - 1)) || gpus > 256) die("--gpus must be a power of two");
     if(mer_len > 64) die("--gpus: sharded tables for mer length > 64 are not built yet");
-    if(!if_files.empty() || bf_size_given || disk || text || host_parse || !generator.empty())
-      die("--gpus cannot be combined with --if, --bf-size, --disk, --text, --host-parse or -g yet");
+    if(bf_size_given || disk || text || host_parse || !generator.empty())
+      die("--gpus cannot be combined with --bf-size, --disk, --text, --host-parse or -g yet");
+    if(!if_files.empty() && mer_len > 32) die("--gpus with --if: mer length > 32 is not built yet");
     if(!bc_path.empty() && mer_len > 32) die("--gpus with --bc: mer length > 32 is not built yet");   // (every rank loads the whole counter and asks it before routing)
     renv = read_rank_env();
     if(!renv.is_rank) return spawn_ranks(gpus, argv);

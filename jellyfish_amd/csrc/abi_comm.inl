@@ -156,7 +156,7 @@ bool items_geometry_ok(const jfgpu_comm* c, const jfgpu_table* t) {
 // Region capacity this rank wants for a step of n bytes (0: it would rather send keys).
 uint32_t items_cap_wanted(const jfgpu_comm* c, const jfgpu_comm::Rank& R, size_t n) {
   const jfgpu_table* t = R.t;
-  if(!items_geometry_ok(c, t)) return 0;
+  if(!items_geometry_ok(c, t) || t->operation != 0) return 0;              // (the PRIME / UPDATE passes of count --if travel as keys)
   const ItemLayout L = item_layout(c, t, 64);
   const double ipb = R.ipb > 0 ? std::min(1.0, R.ipb * 1.10 + 0.005) : 1.0;
   const uint64_t items = (uint64_t)((double)n * ipb) + 4096;
@@ -195,6 +195,7 @@ __global__ __launch_bounds__(1024) void comm_claims_kernel(const unsigned long l
 // A Bloom counter attached to a shard (count --bc) is asked on the SENDING side, every rank holding the whole read-only
 // counter.  A one-pass filter (--bf-size) changes as it is asked and would see only its rank's reads; two-word keys: not built.
 int comm_filter_ok(const jfgpu_table* t) {
+  if(t->operation != 0 && (t->wide || t->nword)) return fail(JFGPU_E_UNSUPPORTED, "count --if with --gpus: two-word keys are not built yet");
   if(t->wide && t->wt.bloom.data) return fail(JFGPU_E_UNSUPPORTED, "count --bc with --gpus: two-word keys are not built yet");
   if(!t->wide && t->dt.bloom.data && t->dt.bloom.kind != 0) return fail(JFGPU_E_UNSUPPORTED, "--bf-size with --gpus: a one-pass filter cannot be sharded by input");
   return JFGPU_OK;
@@ -428,7 +429,15 @@ int comm_insert_prev(jfgpu_comm* c, jfgpu_comm::Rank& R) {
   HIP_TRY(hipStreamWaitEvent(t->stream, R.exchanged[prev], 0));
   const uint64_t n = R.roff[prev][c->world] / (t->wide ? 2 : 1);          // k-mers that arrived (the offsets are in words)
   int rc = JFGPU_OK;
-  if(n) rc = add_keys_piece(t, R.recv[prev], (size_t)n, 1, nullptr);
+  // what the table does with a k-mer (jfgpu_set_operation: the passes of count --if) holds for what arrives, too
+  if(n && t->operation == 2) {
+    rc = part_flush(t); if(rc) return rc;
+    ProfScope ps(t, 1, n);
+    const int grid = grid_for(t, (n + kBlock - 1) / kBlock);
+    if(t->returning) hipLaunchKernelGGL(update_keys_one_kernel<true>, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, (const uint64_t*)R.recv[prev], (uint64_t)n);
+    else             hipLaunchKernelGGL(update_keys_one_kernel<false>, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, (const uint64_t*)R.recv[prev], (uint64_t)n);
+    HIP_TRY(hipGetLastError());
+  } else if(n) rc = add_keys_piece(t, R.recv[prev], (size_t)n, t->operation == 1 ? 0 : 1, nullptr);
   HIP_TRY(hipEventRecord(R.consumed[prev], t->stream));
   R.received += n;
   R.inflight = false;

@@ -396,6 +396,17 @@ __global__ __launch_bounds__(kBlock) void add_keys_one_kernel(DevTable T, const 
     table_add<RETURNING>(T, s_fwd, keys[i] & T.g.key_mask, 1);
 }
 
+// hash_counter::update_add on encoded keys, val == 1: the receive side of the exchange in the UPDATE pass of count --if
+// (count_main.cc:152-184 with --gpus): only keys that are present are counted.
+template <bool RETURNING>
+__global__ __launch_bounds__(kBlock) void update_keys_one_kernel(DevTable T, const uint64_t* __restrict__ keys, uint64_t n) {
+  __shared__ uint64_t s_fwd[8 * 256];
+  load_tables_lds(s_fwd, T.fwd_tbl, T.g.nbytes);
+  __syncthreads();
+  for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    table_update_add<RETURNING>(T, s_fwd, keys[i] & T.g.key_mask, 1);
+}
+
 // ---- get_val_for_key -------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void lookup_kernel(DevTable T, const uint64_t* __restrict__ keys, uint64_t n,
                                                         uint64_t* __restrict__ vals, uint8_t* __restrict__ found,

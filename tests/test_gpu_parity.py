@@ -900,6 +900,56 @@ def test_prime_and_update_operations(gpu):
         assert got == exp
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_prime_and_update_over_shards(gpu, world):
+    """The two passes of `count --if` over hash-prefix shards (count_main.cc:152-184, 289-295 with --gpus): what a rank
+    receives is entered with count 0 in the PRIME pass and counted only if present in the UPDATE pass -- the table's
+    operation holds for arrivals too (abi_comm.inl: comm_insert_prev).  Both passes travel as keys."""
+    rng = random.Random(50 + world)
+    k = 21
+    wanted = [rnd_seq(rng, 6000) for _ in range(world)]
+    reads = [wanted[r][1000:4000] + b"N" + rnd_seq(rng, 5000) + b"N" + wanted[(r + 1) % world][500:2500] for r in range(world)]
+    exp_w = oracle_map(b"N".join(wanted), k, True)
+    exp_r = oracle_map(b"N".join(reads), k, True)
+    exp = {key: exp_r.get(key, 0) for key in exp_w}
+    sb = world.bit_length() - 1
+    shards = [gpu.Table(k, 1 << 18, shard_bits=sb, shard_id=r) for r in range(world)]
+    comm = gpu.Comm(world, local=True)
+    try:
+        bufs = []
+
+        def feed(seqs):
+            ptrs, ns = [], []
+            for r, seq in enumerate(seqs):
+                d = shards[r].malloc(len(seq) + 64)
+                shards[r].h2d(d, np.frombuffer(seq, dtype=np.uint8))
+                bufs.append((shards[r], d)); ptrs.append(d); ns.append(len(seq))
+            comm.local_step(shards, ptrs, ns)
+            comm.finish()
+        for t in shards:
+            t.set_operation(1)
+        feed(wanted)
+        for t in shards:
+            t.sync()
+        assert sum(t.stats().distinct for t in shards) == len(exp_w) and sum(t.stats().total for t in shards) == 0
+        for t in shards:
+            t.set_operation(2)
+        feed(reads)
+        got = {}
+        for t in shards:
+            t.sync()
+            part = table_map(gpu, t)
+            assert not (set(part) & set(got))
+            got.update(part)
+        assert got == exp and sum(exp.values()) > 1000
+        for t, d in bufs:
+            t.free(d)
+    finally:
+        comm.close()
+        for t in shards:
+            t.close()
+
+
 def test_genome_read_generator(gpu):
     """The secondary benchmark distribution: reads from a random genome with substitutions.  Reproducible, sliceable,
     only ACGT + one N per read, every window counted once, and coverage makes k-mers repeat."""
