@@ -33,6 +33,10 @@ SELECTION = [
     "tests/test_gpu_wide.py::test_keys_of_three_and_four_words",
     "tests/test_gpu_wide.py::test_wide_partitioned_path_equals_direct_and_oracle[33-65536]",
     "tests/test_gpu_wide.py::test_wide_partitioned_path_equals_direct_and_oracle[40-1048576]",
+    "tests/test_gpu_parity.py::test_shards_grow_together[2-0]",
+    "tests/test_gpu_wide.py::test_two_word_shards_grow_together[40-2]",
+    "tests/test_gpu_parity.py::test_prime_and_update_over_shards[2]",
+    "tests/test_gpu_bloom.py::test_sharded_count_with_a_bloom_counter_equals_the_single_table[21-2-2]",
 ]
 
 
