@@ -27,7 +27,7 @@ PY
 for rep in ${REPS:-1 2}; do
   T0=$(date +%s.%N)
   env JFGPU_QUIET=1 JFGPU_TIMING_DETAIL=1 $R/bin/jellyfish-amd count -m $K -C -s $SIZE -o $D/out.jf --timing $D/timing $D/reads.fa
-  T1=$(date +%s.%N); echo "wall $(echo "$T1 - $T0" | bc) s"
+  T1=$(date +%s.%N); echo "wall $(python3 -c "print(round($T1 - $T0, 3))") s"
   tr '\n' ' ' < $D/timing; echo; ls -l $D/out.jf | awk '{printf "output %.2f GB\n", $5/1e9}'
   rm -f $D/out.jf
 done
