@@ -294,7 +294,12 @@ int comm_insert_prev_items(jfgpu_comm* c, jfgpu_comm::Rank& R, int rank) {
   const uint32_t nb = 1u << t->pg.b1;
   // blocks per coarse bucket: about two workgroups per CU in all (world 8: 4 x 128 buckets; world 1: 1 x 1024)
   const uint32_t kBlocksPerBucket = std::max<uint32_t>(1, std::min<uint32_t>(4, (2u * (uint32_t)t->n_cu) / std::max<uint32_t>(1, L.nbc)));
-  const uint32_t cap2 = (uint32_t)(((uint64_t)L.cap + (uint64_t)kBlocksPerBucket * kGran + kGran - 1) / kGran * kGran);
+  // a fine bucket takes its share (1 / 2^sb) of a coarse bucket's W incoming regions.  (Round 4: this said L.cap, which is
+  // right only when the fan-out equals W -- a shard with 2^9 P1 buckets at world 4 splits two ways, its regions overflowed
+  // and a third of the items went in by global atomics: tools/local_world_stage_times.py.)
+  const uint64_t per_fine = ((uint64_t)W * L.cap + ((uint64_t)1 << sb) - 1) >> sb;
+  if(per_fine + (uint64_t)kBlocksPerBucket * kGran + kGran > 0xFFFF0000ull) return fail(JFGPU_E_UNSUPPORTED, "item exchange: a step too large for its regions");
+  const uint32_t cap2 = (uint32_t)((per_fine + (uint64_t)kBlocksPerBucket * kGran + kGran - 1) / kGran * kGran);
   const size_t bytes = (size_t)nb * cap2 * 4;
   const size_t need = align_up(bytes, 256) + align_up((2 * nb + 1) * sizeof(uint64_t), 256) + align_up(nb * 16, 256) + 1024;
   if(t->pending.size() >= kMaxSeg) { int rc = part_flush(t); if(rc) return rc; }
@@ -355,6 +360,17 @@ int comm_insert_prev_items(jfgpu_comm* c, jfgpu_comm::Rank& R, int rank) {
     }
   }
   HIP_TRY(hipGetLastError());
+  if(t->tun.flush_trace) {          // what the split stored per fine bucket
+    std::vector<unsigned long long> ht(nb);
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    HIP_TRY(hipMemcpy(ht.data(), b.tot, nb * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    unsigned long long sum = 0, mn = ~0ull, mx = 0;
+    for(unsigned long long v : ht) { sum += v; mn = std::min(mn, v); mx = std::max(mx, v); }
+    fprintf(stderr, "[comm] split of rank %d: %llu items into %u regions of %u (per region: min %llu, max %llu), fan-out %u, %u workgroups per coarse bucket; first regions:",
+            rank, sum, nb, cap2, mn, mx, 1u << sb, kBlocksPerBucket);
+    for(uint32_t j = 0; j < 8 && j < nb; ++j) fprintf(stderr, " %llu", ht[j]);
+    fprintf(stderr, "\n");
+  }
   t->pending.push_back(b);
   t->pending_bytes += bytes;
   t->pristine = false;
