@@ -4,6 +4,7 @@ Bar: bit-exact {k-mer -> count} (integer work), dump in the reference's (pos, ke
 order under the table's own matrix, same edge cases the reference tests cover
 (N / IUPAC / lower case resets, buffers shorter than k, empty input, count-field
 overflow = the reference's "large" entries, -L/-U filters)."""
+import os
 import random
 
 import numpy as np
@@ -943,6 +944,46 @@ def test_prime_and_update_over_shards(gpu, world):
             got.update(part)
         assert got == exp and sum(exp.values()) > 1000
         for t, d in bufs:
+            t.free(d)
+    finally:
+        comm.close()
+        for t in shards:
+            t.close()
+
+
+def test_receive_split_regions_fit_when_the_fan_out_is_below_the_world_size(gpu, monkeypatch):
+    """The receive side of the item exchange splits a coarse bucket into the shard's own P1 buckets; its fan-out is
+    2^(b1 - cbits), which equals the world size only when the shard has 2^10 P1 buckets.  Shards of 2^31 slots have 2^9:
+    at world 4 the split is two-way and every output region takes W / 2 senders' regions worth of items (round 4: the
+    regions were sized for one, a third of the items overflowed into global-atomic inserts -- correct, three times slower).
+    Asserted from the engine's counters: next to nothing goes in directly, nothing is lost."""
+    if os.environ.get("JFGPU_LIB"):
+        pytest.skip("four shards of 2^31 slots: not under the host emulation")
+    monkeypatch.setenv("JFGPU_COMM_ITEMS", "2")
+    world, k, L = 4, 21, 150
+    n_reads = 400_000                                         # per rank and step: 60 MB of reads
+    shards = [gpu.Table(k, 1 << 33, canonical=True, shard_bits=2, shard_id=r) for r in range(world)]
+    comm = gpu.Comm(world, local=True)
+    try:
+        bufs = []
+        for r, t in enumerate(shards):
+            assert t.info.slot_bytes == 4
+            d = t.malloc(2 * n_reads * (L + 1) + 16)
+            t.gen_reads_dev(d, r * 2 * n_reads, 2 * n_reads, L, 7)
+            t.sync()
+            bufs.append(d)
+        for step in range(2):
+            comm.local_step(shards, [bufs[r] + step * n_reads * (L + 1) for r in range(world)], [n_reads * (L + 1)] * world)
+        sent, received = comm.finish()
+        total = world * 2 * n_reads * (L - k + 1)
+        assert sent == received == total
+        direct = 0
+        for t in shards:
+            t.sync()
+            direct += t.counters()["direct"]
+        assert sum(t.stats().total for t in shards) == total
+        assert direct < total // 1000, "the split's regions overflowed: %d of %d items went in by global atomics" % (direct, total)
+        for t, d in zip(shards, bufs):
             t.free(d)
     finally:
         comm.close()
