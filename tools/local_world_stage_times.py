@@ -3,16 +3,17 @@
 instead of RCCL, the ranks' kernels run one after the other, so the per-stage device times are not inflated by processes
 time-slicing the GPU as in `bench.py --gpus N` on a one-GPU box).  What it shows: the cost of the receive side's W-way split
 (exchange_receive_split) and of the routing P1 at world W, per rank, for a total of `gbp` Gbp into a global table of 2^34 slots.
-usage: python tools/local_world_stage_times.py [world=4] [gbp=5]"""
+usage: python tools/local_world_stage_times.py [world=4] [gbp=5] [log2 of the global table size = 34]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from jellyfish_amd import capi
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 gbp = float(sys.argv[2]) if len(sys.argv) > 2 else 5.0
+lsize_g = int(sys.argv[3]) if len(sys.argv) > 3 else 34
 L, K, steps = 150, 21, 5
 n_reads = int(gbp * 1e9 / L) // world          # per rank
 sb = world.bit_length() - 1
-shards = [capi.Table(K, 1 << 34, canonical=True, shard_bits=sb, shard_id=r) for r in range(world)]
+shards = [capi.Table(K, 1 << lsize_g, canonical=True, shard_bits=sb, shard_id=r) for r in range(world)]
 comm = capi.Comm(world, local=True)
 bufs = []
 for r, t in enumerate(shards):
