@@ -951,6 +951,42 @@ def test_prime_and_update_over_shards(gpu, world):
             t.close()
 
 
+@pytest.mark.parametrize("lsize,p2_ring", [(33, "1"), (34, "1"), (34, "3")])
+def test_ring_p2_kernels_at_the_geometries_that_use_them(gpu, monkeypatch, lsize, p2_ring):
+    """The ring kernels of P2 (kernels_p1ring.hip.hpp) take buckets of 1024 destinations -- tables of 2^34 4-byte slots:
+    p2_ring_roles_kernel with rounds of 4 Ki items, or p2_ring_kernel with JFGPU_P2_RING=3 -- and, with short rounds, of
+    512 (2^33 slots); smaller tables, i.e. every other parity test, take the sort-based kernel.  Here 0.2 Gbp goes through
+    them and the table's content digest (keys and counts, whatever the matrix) must equal that of the global-atomic path
+    in a small table, which the oracle tests pin (large_hash_array.hpp:509-597, 741-752: every k-mer ends up counted once
+    per occurrence, wherever it sits)."""
+    if os.environ.get("JFGPU_LIB"):
+        pytest.skip("tables of 32 and 64 GB: not under the host emulation")
+    monkeypatch.setenv("JFGPU_P2_RING", p2_ring)
+    k, L, n_reads = 21, 150, 1_400_000
+    with gpu.Table(k, 1 << 29, canonical=True) as ref:
+        d = ref.malloc(n_reads * (L + 1) + 16)
+        ref.gen_reads_dev(d, 0, n_reads, L, 11)
+        ref.set_mode(1)
+        ref.count_ascii_dev(d, n_reads * (L + 1)); ref.sync()
+        want = ref.digest()
+        ref.free(d)
+    assert want[1] == n_reads * (L - k + 1)
+    with gpu.Table(k, 1 << lsize, canonical=True) as t:
+        assert t.info.slot_bytes == 4
+        d = t.malloc(n_reads * (L + 1) + 16)
+        t.gen_reads_dev(d, 0, n_reads, L, 11)
+        t.set_mode(2)
+        t.reserve(n_reads * (L + 1))
+        t.profile_enable(True); t.profile_reset()
+        half = (n_reads // 2) * (L + 1)
+        t.count_ascii_dev(d, half); t.sync()                       # two flushes: the second into dirty tiles
+        t.count_ascii_dev(d + half, n_reads * (L + 1) - half); t.sync()
+        assert t.profile_get(5)[1] >= 2 and t.profile_get(6)[1] >= 2, "P2 and the tile insert must have run"
+        assert t.digest() == want
+        assert t.counters()["direct"] < want[1] // 1000
+        t.free(d)
+
+
 def test_receive_split_regions_fit_when_the_fan_out_is_below_the_world_size(gpu, monkeypatch):
     """The receive side of the item exchange splits a coarse bucket into the shard's own P1 buckets; its fan-out is
     2^(b1 - cbits), which equals the world size only when the shard has 2^10 P1 buckets.  Shards of 2^31 slots have 2^9:
