@@ -321,3 +321,40 @@ def test_sharded_count_with_a_bloom_counter_equals_the_single_table(gpu, monkeyp
             for t in shards:
                 t.attach_bloom(None)
                 t.close()
+
+
+def test_partitioned_insert_at_config_3_geometry(gpu, monkeypatch):
+    """The Bloom pass at BASELINE configs[2]'s size (m = 14e10 cells = 28 GB: 2^9 P1b buckets of 2^10 segments): this is
+    where the cell updates' P2 goes through the ring kernel (p2_ring_kernel<BloomRingDirect>, the array's partial last
+    bucket through the sort) -- the filters of the other tests are too small for it.  Every k-mer of the input reads back
+    the same from the partitioned insert and from the global-CAS insert, and what was seen twice reads 2
+    (bloom_counter2.hpp:56-142)."""
+    if os.environ.get("JFGPU_LIB"):
+        pytest.skip("two filters of 28 GB: not under the host emulation")
+    monkeypatch.setenv("JFGPU_P2_SINGLE", "2")             # (the input is small: single-pass P2 even though its regions are mostly head-room)
+    rng = random.Random(77)
+    k = 31
+    once = "".join(rng.choice("ACGT") for _ in range(1_500_000))
+    twice = "".join(rng.choice("ACGT") for _ in range(500_000))
+    seq = (once + "N" + twice + "N" + twice).encode()
+    keys1, _ = O.count(seq[:400_000], k, True)                   # k-mers asked about: a sample of those inserted once ...
+    keys2, _ = O.count(twice[:200_000].encode(), k, True)         # ... and of those inserted twice
+    keys = np.concatenate([keys1, keys2]); n1 = len(keys1)
+    m, nh = 14 * 10_000_000_000, 10
+    got = []
+    for mode in (2, 1):
+        with gpu.Bloom(k, m, nh, canonical=True, seed=5) as b:
+            b.set_mode(mode)
+            if mode == 2:
+                b.reserve(8 << 30)
+                b.profile_enable(True); b.profile_reset()
+            for rep in range(3):                                  # several batches pending before the flush
+                b.insert_ascii(seq if rep == 0 else b"ACGTN" * 2000)
+            n = b.sync()
+            if mode == 2:
+                assert b.profile_get(2)[1] >= 1 and b.profile_get(3)[1] >= 1, "the partitioned stages (P2, segments) must have run"
+            got.append(b.keys(keys[:, 0]))
+    assert (got[0] == got[1]).all()
+    # a k-mer of `twice` was inserted at least twice: 2; the cells saturate at 2 (every k-mer asked about was inserted at least once)
+    assert (got[0] >= 1).all() and (got[0][n1:] == 2).all()
+    assert int((got[0][:n1] == 1).sum()) > 0.99 * n1           # (a once-seen k-mer reads 2 only if all its ten cells were bumped by others: never at this load)
