@@ -530,6 +530,11 @@ def main():
             elif abs(rec.get("gbp", 0) - args.gbp) < 1e-9 and rec.get("lsize") == lsize and dom in rec.get("per_job_bytes", {}):
                 traffic = rec["per_job_bytes"][dom] / max(launches, 1)
                 traffic_src = "%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, same command, same kernel sources): bytes per job / %d launches" % (os.path.relpath(tj, ROOT), launches)
+                # every stage's measured HBM traffic next to its live time: the rate each stage really runs at
+                for nm, kv in kernels.items():
+                    if nm in rec["per_job_bytes"] and kv.get("ms"):
+                        kv["hbm_traffic_bytes_per_job"] = rec["per_job_bytes"][nm]
+                        kv["hbm_GB_per_s"] = rec["per_job_bytes"][nm] / (kv["ms"] * 1e-3) / 1e9
         out = {
             "metric": "k-mers/sec at k=%d canonical, 150 bp synthetic reads, bit-exact counts" % K,
             "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": steps, "warmup": warmup,
