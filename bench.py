@@ -80,17 +80,16 @@ def kernel_sources_sha():
 
 
 def release_device(held_bytes=0):
-    """This process's HIP allocations really go back to the driver, and the call returns when the driver is done with them.
-    The amdgpu driver wipes VRAM when it is released, in the background, at about 25 GB/s; a process that allocates while
-    that is going on waits for it -- round 3's end-to-end line charged the CLI's Init 5.4 s for the 165 GB this script had
-    just freed (tools/init_after_parent.py: Init 6.6 s right after the parent's free, 0.2 s after a pause; from a fresh
-    shell 0.2 - 1.1 s, profiles/r04_cli_writing.log).  hipDeviceReset, then wait for the wipe: there is no call to ask
-    the driver, so the wait is the freed bytes at 20 GB/s."""
+    """Wait until the driver is done with what this process has just freed.  The amdgpu driver wipes VRAM when it is
+    released, in the background, at about 25 GB/s; a process that allocates while that is going on waits for it -- round
+    3's end-to-end line charged the CLI's Init 5.4 s for the 165 GB this script had just freed (tools/init_after_parent.py:
+    Init 6.6 s right after the parent's free, 0.2 s after a pause; from a fresh shell 0.2 - 1.1 s,
+    profiles/r04_cli_writing.log).  Everything this script holds on the device is plain hipMalloc memory behind the C ABI
+    (table, workspace, reads), freed explicitly by the caller before this is called: no hipDeviceReset under live
+    objects (round-4 advisor finding).  There is no call to ask the driver, so the wait is the freed bytes at 20 GB/s."""
     import ctypes
     try:
-        hip = ctypes.CDLL("libamdhip64.so")
-        hip.hipDeviceSynchronize()
-        hip.hipDeviceReset()
+        ctypes.CDLL("libamdhip64.so").hipDeviceSynchronize()
     except OSError:
         pass
     wait = min(20.0, held_bytes / 20e9)
@@ -300,7 +299,7 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="C2")
     ap.add_argument("--gbp", type=float, default=0.0, help="giga-bases of reads per GPU (default: 10 at N = 1, 12.5 at N > 1)")
     ap.add_argument("--lsize", type=int, default=0, help="log2 slots per GPU (default: the configuration's)")
-    ap.add_argument("--cpu-sample-reads", type=int, default=1032000, help="reads of the CPU-baseline sample (155 Mbp: load 0.50 in its 2^28 table at k = 21)")
+    ap.add_argument("--cpu-sample-reads", type=int, default=1100000, help="reads of the CPU-baseline sample (165 Mbp: load 0.53 in the reference's 2^28 table at k = 21; enough k-mers per P1 bucket for the engine's single-pass partition kernels, the timed job's, to take it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--repeats", type=int, default=5, help="how many times the whole job is run in all (first = the contract's timed region)")
     ap.add_argument("--no-extras", action="store_true", help="skip flush sweep, end-to-end and the secondary configurations (quick runs, profiling)")
@@ -594,21 +593,37 @@ def main():
         out["repeats"] = {"n": len(vals), "kmers_per_s": vals, "median": statistics.median(vals), "min": min(vals), "max": max(vals),
                           "note": "first entry = the contract's timed region (value); the others re-run the identical job after a clear, table digest equal every time"}
 
-    # ---- the CPU-baseline sample counted on the GPU (its digest is compared with the reference's further down; taken here,
-    # while the reads are still in device memory) ----
-    sample_digest = None
+    # ---- the CPU-baseline sample counted on the GPU, IN THE TIMED TABLE (after a clear): same geometry, same slot width, so
+    # the kernels that produced `value` -- ring P1, loader / storer P2, the 4-byte-slot tile kernel for C2 -- are the ones whose
+    # result is compared with the reference's digest further down (round-4 review: the sample used to go into a 2^28 side
+    # table with 8-byte slots).  Which kernels ran is read from the engine's counters and reported.  Taken here, while the
+    # reads are still in device memory.  (Through the sharded code path the sample goes into a side table as before.) ----
+    sample_digest, sample_kernels = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         b2 = None
-        with capi.Table(K, 1 << 28, canonical=True, device=local_rank) as t2:
-            if cfg == "C3":
-                b2 = capi.Bloom(K, capi.opt_m(0.001, ns * READ_LEN), capi.opt_k(0.001), canonical=True, device=local_rank)
-                b2.insert_ascii_dev(buf, ns * stride)
-                b2.sync()
-                t2.attach_bloom(b2)
-            t2.count_ascii_dev(buf, ns * stride)
-            t2.sync()
-            sample_digest = tuple(t2.digest())
-            t2.attach_bloom(None)
+        if cfg == "C3":      # the reference's `bc -s <sample bases>`: a filter of the sample's own size
+            b2 = capi.Bloom(K, capi.opt_m(0.001, ns * READ_LEN), capi.opt_k(0.001), canonical=True, device=local_rank)
+            b2.insert_ascii_dev(buf, ns * stride)
+            b2.sync()
+        if not force_dist:
+            reset()
+            if b2 is not None:
+                t.attach_bloom(b2)
+            t.count_ascii_dev(buf, ns * stride)
+            t.sync()
+            sample_digest = tuple(t.digest())
+            c2 = t.counters()
+            sample_kernels = {nm: c2[nm] for nm in ("p1_ring", "p1_other", "p2_roles", "p2_ring", "p2_sort", "p2_exact", "flushes_plain", "flushes_heavy", "direct")}
+            sample_kernels["table"] = "the timed table: 2^%d slots of %d bytes" % (lsize, slot_bytes)
+            t.attach_bloom(None)
+        else:
+            with capi.Table(K, 1 << 28, canonical=True, device=local_rank) as t2:
+                if b2 is not None:
+                    t2.attach_bloom(b2)
+                t2.count_ascii_dev(buf, ns * stride)
+                t2.sync()
+                sample_digest = tuple(t2.digest())
+                t2.attach_bloom(None)
         if b2 is not None:
             b2.close()
 
@@ -641,6 +656,7 @@ def main():
                         arr[:, READ_LEN] = ord("\n")
                         np.concatenate([hdr, arr], axis=1).tofile(fh)
                 fbytes = os.path.getsize(fa)
+                t.free(buf); buf = None
                 t.close()                                         # the CLI needs the device memory ...
                 if bloom is not None:
                     bloom.close(); bloom = None
@@ -677,6 +693,7 @@ def main():
         if ref_stats is not None:       # bit-exactness on the very sample the CPU counted: per-k-mer content, not aggregates
             mine = sample_digest
             out["cpu_baseline"]["digest_equal_on_sample"] = (mine == tuple(ref_stats))
+            out["cpu_baseline"]["sample_counted_by"] = sample_kernels      # launches per partition kernel: the timed job's own, in the timed table
             out["cpu_baseline"]["sample_digest"] = {"records": mine[0], "total": mine[1], "sum_h": mine[2], "xor_h": mine[3],
                                                     "what": "content digest of the whole table (records, sum of counts, sum and xor of a per-record hash of key words and "
                                                             "count): jfgpu_digest on the device table vs `ref_jf count --digest` on the reference's in-memory table"}
@@ -684,7 +701,11 @@ def main():
     # ---- BASELINE configs[4] and configs[2]: one job each, in children of this script (they need the device memory) ----
     if rank == 0 and world == 1 and cfg == "C2" and not args.no_extras and not args.no_secondary and not args.as_secondary and args.dist == "U":
         if t is not None:
+            if buf is not None:
+                t.free(buf); buf = None
             t.close(); t = None
+        if bloom is not None:
+            bloom.close(); bloom = None
         release_device()                                          # the children need the device memory (they are not timed on their Init)
         sec = {}
         # C5, C3: BASELINE configs[4] and [2] on the metric's uniform reads; C2_G, C3_G: the same engine on BASELINE.md's secondary
@@ -705,6 +726,12 @@ def main():
             except Exception as e:       # the contract line must come out whatever the extras do
                 sec[name] = {"error": repr(e)}
         out["secondary"] = sec
+        # the driver's record keeps the `roofline` dict whole but only the names of other top-level keys: the secondaries'
+        # numbers, compact, where they survive (round-4 review, item 9)
+        out["roofline"]["secondary_values"] = {
+            nm: ({"value": v["value"], "whole_path_frac": v.get("roofline", {}).get("whole_path_frac"),
+                  "kernel": v.get("roofline", {}).get("kernel"), "frac": v.get("roofline", {}).get("frac")} if "value" in v else {"error": v.get("error", "")[:120]})
+            for nm, v in sec.items()}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if bloom is not None:

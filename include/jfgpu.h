@@ -235,7 +235,8 @@ int  jfgpu_bf_create(const jfgpu_bloom_params* p, jfgpu_bloom** out);
  * jfgpu_bc_reserve sizes the routing workspace up front (default: taken from free memory at the first large batch). */
 int  jfgpu_bc_set_mode(jfgpu_bloom* b, int mode);
 int  jfgpu_bc_reserve(jfgpu_bloom* b, uint64_t workspace_bytes);
-/* per-stage device time on the counter's stream (bench.py): which = 0 direct, 1 route (P1), 2 partition (P2), 3 segments */
+/* per-stage device time on the counter's stream (bench.py): which = 0 direct, 1 route (P1), 2 partition (P2), 3 segments;
+ * 4: launches (no time) of the ring kernel inside stage 2, so that a test can tell which P2 kernel a flush took */
 int  jfgpu_bc_profile_enable(jfgpu_bloom* b, int on);
 int  jfgpu_bc_profile_get(jfgpu_bloom* b, int which, double* ms, uint64_t* launches, uint64_t* units);
 int  jfgpu_bc_profile_reset(jfgpu_bloom* b);
@@ -351,8 +352,10 @@ int  jfgpu_profile_reset(jfgpu_table* t);
  * full" is raised from it), 1 k-mer occurrences fed, 2 overflow side table full, 3 side-table entries, 4 k-mers sent to
  * a shard that does not own them, 5 items inserted with global atomics by the partition kernels (ring / region
  * overflow, runs of one k-mer), 6 / 7 items placed / items past rank 3 in the sampling launch of the last flush that
- * sampled (host_partition.inl), 8 flushes that ran the plain tile kernel, 9 flushes that ran the HEAVY one. */
-#define JFGPU_N_COUNTERS 10
+ * sampled (host_partition.inl), 8 flushes that ran the plain tile kernel, 9 flushes that ran the HEAVY one, 10-13 launches
+ * of the second partition level by kernel (loader / storer rings, shared rings, sort-based single pass, exact count +
+ * scatter), 14 / 15 launches of the first level (ring kernel / any other). */
+#define JFGPU_N_COUNTERS 16
 int  jfgpu_get_counters(jfgpu_table* t, uint64_t* out, uint32_t n);
 /* Synthetic reads: n_reads records of read_len uniform iid bases, each followed by
  * one 'N' separator (the contract buffer the parser would produce for a FASTA of

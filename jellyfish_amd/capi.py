@@ -351,7 +351,8 @@ class Table:
     def profile_reset(self):
         _check(self._lib.jfgpu_profile_reset(self._h))
 
-    COUNTER_NAMES = ("full", "mers", "ovf_full", "ovf_used", "misrouted", "direct", "t_items", "t_queued", "flushes_plain", "flushes_heavy")
+    COUNTER_NAMES = ("full", "mers", "ovf_full", "ovf_used", "misrouted", "direct", "t_items", "t_queued", "flushes_plain", "flushes_heavy",
+                     "p2_roles", "p2_ring", "p2_sort", "p2_exact", "p1_ring", "p1_other")
 
     def counters(self):
         """jfgpu_get_counters: which paths the work since the last clear took."""
@@ -523,6 +524,10 @@ class Bloom:
 
     def profile_reset(self):
         _check(self._lib.jfgpu_bc_profile_reset(self._h))
+
+    def ring_p2_launches(self):
+        """Launches of the ring P2 kernel (p2_ring_kernel<BloomRingDirect>) since the last profile_reset: profile slot 4."""
+        return self.profile_get(4)[1]
 
     def keys(self, keys, insert=False):
         keys = np.ascontiguousarray(keys, dtype=np.uint64)

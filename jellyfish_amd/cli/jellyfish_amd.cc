@@ -636,7 +636,9 @@ int count_main(int argc, char* argv[]) {
        << "Writing  " << write_s << "\n";
     if(!host_parse && getenv("JFGPU_TIMING_DETAIL"))     // extra lines only on request: the file keeps the reference's three
       tf << "DeviceParse " << parse_ms / 1e3 << "\n" << "HostParsedBytes " << fallback_bytes << "\n"
-         << "DirectInserts " << ctrs[5] << "\n" << "FlushesPlain " << ctrs[8] << "\n" << "FlushesHeavy " << ctrs[9] << "\n";
+         << "DirectInserts " << ctrs[5] << "\n" << "FlushesPlain " << ctrs[8] << "\n" << "FlushesHeavy " << ctrs[9] << "\n"
+         << "P2Roles " << ctrs[10] << "\n" << "P2Ring " << ctrs[11] << "\n" << "P2Sort " << ctrs[12] << "\n" << "P2Exact " << ctrs[13] << "\n"
+         << "P1Ring " << ctrs[14] << "\n" << "P1Other " << ctrs[15] << "\n";
   }
   return 0;
 }

@@ -25,8 +25,8 @@ struct jfgpu_bloom {
   uint64_t* d_strag2 = nullptr; uint32_t* d_strag2_n = nullptr; uint32_t strag2_lists = 0;     // p2_ring_kernel's straggler lists
   bool prof_on = false;
   std::vector<ProfSpan> spans;
-  double prof_ms[4] = {}; uint64_t prof_launches[4] = {}, prof_units[4] = {};
-  DevBloom view() const { DevBloom b; b.data = d_data; b.m = m; b.recip = bloom_recip(m); b.nh = nh; b.kind = kind; b.pad_ = 0; b.nbytes = g.nbytes; b.tbl1 = d_t1; b.tbl2 = d_t2; return b; }
+  double prof_ms[5] = {}; uint64_t prof_launches[5] = {}, prof_units[5] = {};      // [BS_COUNT] (bloom_partition.inl)
+  DevBloom view() const { DevBloom b; b.data = d_data; b.m = m; b.recip = bloom_recip(m); b.nh = nh; b.kind = kind; b.pad_ = 0; b.nbytes = g.nbytes; b.tbl1 = d_t1; b.tbl2 = d_t2; b.cache = nullptr; b.cache_mask = 0; return b; }
 };
 
 namespace {
@@ -299,6 +299,9 @@ int jfgpu_bc_profile_reset(jfgpu_bloom* b) {
 int jfgpu_attach_bloom(jfgpu_table* t, jfgpu_bloom* b) {   // count --bc (count_main.cc:191-206,313-316)
   int rc = use(t); if(rc) return rc;
   rc = part_flush(t); if(rc) return rc;
+  // the cache of admitted k-mers belongs to one attachment: its answers are this counter's
+  if(t->d_bcache) { HIP_TRY(hipStreamSynchronize(t->stream)); hipFree(t->d_bcache); t->d_bcache = nullptr; }
+  t->bcache_state = 0;
   if(!b) { memset(&t->dt.bloom, 0, sizeof t->dt.bloom); memset(&t->wt.bloom, 0, sizeof t->wt.bloom); return JFGPU_OK; }
   if(b->device != t->device) return fail(JFGPU_E_INVALID, "Bloom counter lives on another device");
   if(b->g.k != t->g.k) return fail(JFGPU_E_INVALID, "Invalid mer length in bloom filter");
@@ -308,6 +311,9 @@ int jfgpu_attach_bloom(jfgpu_table* t, jfgpu_bloom* b) {   // count --bc (count_
   rc = bloom_flush(b); if(rc) return rc;
   HIP_TRY(hipStreamSynchronize(b->stream));
   if(t->wide) t->wt.bloom = b->view(); else t->dt.bloom = b->view();
+  { uint64_t c[CTR_COUNT]; rc = read_counters(t, c); if(rc) return rc; t->mers_seen = c[CTR_MERS]; }
+  if(b->kind != 0 || t->wide || t->tun.bloom_cache == 0) t->bcache_state = -1;      // (a one-pass filter changes as it is asked: nothing to remember)
+  else if(t->tun.bloom_cache == 1) { rc = bloom_cache_enable(t); if(rc) return rc; }
   return JFGPU_OK;
 }
 

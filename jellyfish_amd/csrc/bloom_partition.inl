@@ -3,7 +3,7 @@
 // Included by abi_bloom.inl inside its anonymous namespace.
 
 constexpr size_t kBloomMinPiece = (size_t)1 << 20;        // bytes of sequence: smaller pieces take the direct kernel
-enum BloomSlot { BS_DIRECT = 0, BS_P1 = 1, BS_P2 = 2, BS_SEG = 3, BS_COUNT = 4 };
+enum BloomSlot { BS_DIRECT = 0, BS_P1 = 1, BS_P2 = 2, BS_SEG = 3, BS_P2RING = 4, BS_COUNT = 5 };      // (BS_P2RING: launches of the ring P2 only, inside BS_P2's time)
 
 struct BloomProf {      // HIP-event pair around a group of launches on the Bloom counter's stream
   jfgpu_bloom* b; int which; uint64_t units; hipEvent_t a = nullptr, e = nullptr;
@@ -267,6 +267,7 @@ int bloom_flush_inner(jfgpu_bloom* b) {
               b->strag2_lists = n_lists;
             }
             const BloomRingDirect RD{B.data};
+            ++b->prof_launches[BS_P2RING]; b->prof_units[BS_P2RING] += gtot;
             hipLaunchKernelGGL((p2_ring_kernel<BloomRingDirect>), dim3(kG2Single, n_ring), block, (size_t)nb2 * 128 + 128, b->stream, RD, b->bp.b2, kBloomItemLow, S1, cap2, d_gcur2, d_gcur2 + n_tiles,
                                out_v, b0, (unsigned long long*)nullptr, b->d_strag2, b->d_strag2_n, D.counter);
             hipLaunchKernelGGL((p1_stragglers_kernel<uint32_t, BloomRingDirect>), dim3(b->n_cu), dim3(256), 0, b->stream, RD, D.counter, (const uint64_t*)b->d_strag2, (const uint32_t*)b->d_strag2_n,

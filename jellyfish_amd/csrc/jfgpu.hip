@@ -81,6 +81,12 @@ struct jfgpu_table {
   // what the side table may have to hold: an entry needs 2^cnt_bits occurrences of its key, or one add of a large value
   uint64_t occ_bound = 0, bigval_bound = 0;      // upper bounds since the last clear (ensure_ovf)
   uint64_t flushes_plain = 0, flushes_heavy = 0; // tile-kernel instantiation chosen per flush launch (jfgpu_get_counters)
+  // which partition kernels ran since the last clear (jfgpu_get_counters 10..15): P2 launches by kind -- loader / storer
+  // rings, shared rings, the sort-based single pass, the exact count + scatter -- and P1 launches: ring kernel, any other
+  // count --bc: the cache of admitted k-mers (kernels_bloom.hip.hpp) -- 0 undecided, 1 on, -1 off; decided from the first
+  // filtered batches (host_partition.inl: bloom_cache_decide), dropped when the counter is detached
+  uint64_t* d_bcache = nullptr; int bcache_state = 0; uint64_t mers_seen = 0;
+  uint64_t n_p2_roles = 0, n_p2_ring = 0, n_p2_sort = 0, n_p2_exact = 0, n_p1_ring = 0, n_p1_other = 0;
   uint64_t ovf_failed_need = 0;                  // the side-table size whose allocation failed (not retried per batch)
   bool returning = false;
   uint32_t out_counter_len = 4;
@@ -715,8 +721,12 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
       const int rl = kGranMaxB * 128 + 128;
 #define RATTR(IT, BL, N, CN) HIP_TRY(hipFuncSetAttribute((const void*)p1_ring_kernel<IT, BL, N, CN>, hipFuncAttributeMaxDynamicSharedMemorySize, rl))
       HIP_TRY(hipFuncSetAttribute((const void*)p2_ring_kernel<P2RingDirect>, hipFuncAttributeMaxDynamicSharedMemorySize, rl));
-      HIP_TRY(hipFuncSetAttribute((const void*)p2_ring_roles_kernel<uint32_t, 2, P2RingDirect>, hipFuncAttributeMaxDynamicSharedMemorySize, rl));
-      HIP_TRY(hipFuncSetAttribute((const void*)p2_ring_roles_kernel<uint32_t, 1, P2RingDirect>, hipFuncAttributeMaxDynamicSharedMemorySize, rl));
+      HIP_TRY(hipFuncSetAttribute((const void*)p2_ring_roles_kernel<uint32_t, 2, P2RingDirect, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, rl));
+      HIP_TRY(hipFuncSetAttribute((const void*)p2_ring_roles_kernel<uint32_t, 1, P2RingDirect, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, rl));
+      HIP_TRY(hipFuncSetAttribute((const void*)p2_ring_roles_kernel<uint32_t, 2, P2RingDirect, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, rl));
+      HIP_TRY(hipFuncSetAttribute((const void*)p2_ring_roles_kernel<uint32_t, 1, P2RingDirect, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, rl));
+      HIP_TRY(hipFuncSetAttribute((const void*)p2_ring_roles_kernel<uint32_t, 2, P2RingDirect, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, rl));
+      HIP_TRY(hipFuncSetAttribute((const void*)p2_ring_roles_kernel<uint32_t, 1, P2RingDirect, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, rl));
       RATTR(uint32_t, false, 6, 1); RATTR(uint32_t, false, 6, 0); RATTR(uint32_t, true, 0, 2); RATTR(uint32_t, false, 0, 2);
 #undef RATTR
     }
@@ -771,6 +781,7 @@ void jfgpu_destroy(jfgpu_table* t) {
   hipFree(t->dt.ovf_key); hipFree(t->dt.ovf_cnt); hipFree(t->dt.counters); hipFree(t->dt.dirty);
   for(int i = 0; i < 2; ++i) { if(t->d_stage[i]) hipFree(t->d_stage[i]); if(t->stage_done[i]) hipEventDestroy(t->stage_done[i]); }
   if(t->d_dump) hipFree(t->d_dump);
+  if(t->d_bcache) hipFree(t->d_bcache);
   if(t->d_tile_off) hipFree(t->d_tile_off);
   part_discard(t);
   if(t->d_M1) hipFree(t->d_M1);
@@ -819,6 +830,7 @@ int jfgpu_clear(jfgpu_table* t) {
   HIP_TRY(hipStreamSynchronize(t->stream));
   t->pristine = true; t->occ_known = 0; t->fed_since = 0; t->direct_seen = 0; t->occ_bound = 0; t->bigval_bound = 0; t->ovf_failed_need = 0;
   t->flushes_plain = 0; t->flushes_heavy = 0;
+  t->n_p2_roles = t->n_p2_ring = t->n_p2_sort = t->n_p2_exact = t->n_p1_ring = t->n_p1_other = 0;
   return JFGPU_OK;
 }
 
@@ -1301,7 +1313,8 @@ int jfgpu_get_counters(jfgpu_table* t, uint64_t* out, uint32_t n) {
   uint64_t c[CTR_COUNT];
   rc = read_counters(t, c); if(rc) return rc;
   const uint64_t v[JFGPU_N_COUNTERS] = {c[CTR_FULL], c[CTR_MERS], c[CTR_OVF_FULL], c[CTR_OVF_USED], c[CTR_MISROUTED], c[CTR_DIRECT],
-                                        c[CTR_T_ITEMS], c[CTR_T_QUEUED], t->flushes_plain, t->flushes_heavy};
+                                        c[CTR_T_ITEMS], c[CTR_T_QUEUED], t->flushes_plain, t->flushes_heavy,
+                                        t->n_p2_roles, t->n_p2_ring, t->n_p2_sort, t->n_p2_exact, t->n_p1_ring, t->n_p1_other};
   for(uint32_t i = 0; i < n; ++i) out[i] = i < JFGPU_N_COUNTERS ? v[i] : 0;
   return JFGPU_OK;
 }

@@ -66,6 +66,11 @@ struct DevBloom {
   uint32_t pad_;              //    every bit was already set (count --bf-size, count_main.cc:121-131)
   const uint64_t* tbl1;       // byte tables of the two 64-row matrices
   const uint64_t* tbl2;
+  // count --bc on high-coverage input: k-mers the counter has ADMITTED before (bloom_admit_mask), two-way sets of
+  // key + 1 (0: empty); nullptr: off.  A hit answers for the ten cell reads; only admitted keys are ever stored, and an
+  // admitted key stays admitted (the cells saturate), so the answers are the counter's own (kernels_bloom.hip.hpp)
+  uint64_t* cache;
+  uint64_t cache_mask;        // sets - 1
 };
 
 struct DevTable {

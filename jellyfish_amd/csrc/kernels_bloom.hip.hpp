@@ -132,14 +132,38 @@ __device__ inline bool bloom_filter_insert(const DevBloom& B, uint64_t h0, uint6
 // loop per window a wave paid up to 16 x nh dependent memory round trips per tile; here it pays at most 2 x nh,
 // usually 6-10 (a window survives a round with probability ~0.16 on a filter at its design load, unless its k-mer
 // really was seen twice).  Eight windows at a time: sixteen would not fit the registers of a 1024-thread block.
+// The cache of admitted k-mers (DevBloom::cache).  On high-coverage input most windows hold a k-mer the counter has seen
+// twice: all nh cells read 2, ten random 128-byte line fetches per OCCURRENCE (config 3 on BASELINE.md's secondary
+// distribution: 80 G cell reads, 1.4 s).  The answer is a function of the key alone while the counter is read-only, so
+// it is asked once per distinct k-mer and remembered: a hit costs one 16-byte read of a 4 GB array and skips the two
+// hashes as well.  Exactness: an entry is written only after the counter itself admitted that very key (full key
+// compared, no fingerprints), entries are 8-byte words written whole (a torn pair of ways is two valid words), and a
+// miss falls through to the counter -- the mask is the counter's, always.  The host turns the cache on when the first
+// batches of a filtered pass admit a sizeable fraction of their windows (host_partition.inl: bloom_cache_decide).
+__device__ __forceinline__ uint64_t bloom_cache_set(const DevBloom& B, uint64_t key) { return ((key * 0x9E3779B97F4A7C15ull) >> 23) & B.cache_mask; }
+__device__ __forceinline__ bool bloom_cache_hit(const DevBloom& B, uint64_t key) {
+  const uint64_t* set = B.cache + 2 * bloom_cache_set(B, key);
+  const uint64_t a = set[0], b = set[1];
+  return a == key + 1 || b == key + 1;
+}
+__device__ inline void bloom_cache_insert(const DevBloom& B, uint64_t key) {
+  uint64_t* set = B.cache + 2 * bloom_cache_set(B, key);
+  const uint64_t a = set[0], b = set[1];
+  if(a == key + 1 || b == key + 1) return;
+  const uint32_t way = a == 0 ? 0u : b == 0 ? 1u : (uint32_t)(key >> 9) & 1u;       // both taken: the key picks its victim
+  set[way] = key + 1;
+}
+
 template <int J0>
 __device__ inline uint32_t bloom_admit_half(const DevBloom& B, const TableGeom& g, const LaneWords& L, uint64_t& fw, uint64_t& rc) {
   constexpr int H = kPerLane / 2;
   const uint32_t k = g.k;
   const uint64_t kwin = k >= 64 ? ~0ull : ((1ull << k) - 1);
   const uint32_t rc_shift = 2 * (k - 1);
+  const bool cached = B.cache != nullptr;                        // (uniform over the launch)
+  const uint64_t fw_in = fw, rc_in = rc;
   uint64_t p[H], inc[H];
-  uint32_t alive = 0;
+  uint32_t alive = 0, known = 0;
 #pragma unroll
   for(int e = 0; e < H; ++e) {
     const int j = J0 + e;
@@ -149,6 +173,7 @@ __device__ inline uint32_t bloom_admit_half(const DevBloom& B, const TableGeom& 
     p[e] = 0; inc[e] = 0;
     if(((L.inv48 >> (15 - j)) & kwin) == 0) {
       const uint64_t key = (g.canonical && rc < fw) ? rc : fw;
+      if(cached && bloom_cache_hit(B, key)) { known |= 1u << e; continue; }
       p[e] = bloom_mod(hash_tables(B.tbl1, key, B.nbytes), B.m, B.recip);
       inc[e] = bloom_mod(hash_tables(B.tbl2, key, B.nbytes), B.m, B.recip);
       alive |= 1u << e;
@@ -170,7 +195,17 @@ __device__ inline uint32_t bloom_admit_half(const DevBloom& B, const TableGeom& 
         else { p[e] += inc[e]; if(p[e] >= B.m) p[e] -= B.m; }
       }
   }
-  return alive << J0;
+  if(cached && alive) {                                          // what the counter has just admitted: remembered (keys rolled again)
+    uint64_t f2 = fw_in, r2 = rc_in;
+#pragma unroll 1
+    for(int e = 0; e < H; ++e) {
+      const uint64_t c = (L.cur >> (2 * (15 - (J0 + e)))) & 3u;
+      f2 = ((f2 << 2) | c) & g.key_mask;
+      r2 = (r2 >> 2) | ((3ull - c) << rc_shift);
+      if((alive >> e) & 1u) bloom_cache_insert(B, (g.canonical && r2 < f2) ? r2 : f2);
+    }
+  }
+  return (alive | known) << J0;
 }
 __device__ inline uint32_t bloom_admit_mask(const DevBloom& B, const TableGeom& g, const LaneWords& L) {
   uint64_t fw = (((uint64_t)L.p2 << 32) | L.p1) & g.key_mask;

@@ -546,7 +546,7 @@ __global__ __launch_bounds__(kPBlock) void p2_ring_kernel(DIRECT D, uint32_t b2e
 // items (k = 31: rings of 16, rounds of 1 Ki items): 28.5 ms per 5 Gbp against 23.4 for the sort-based kernel -- a round
 // costs ~1.9 us however little it holds, and a ring of 128 bytes takes too few wide items for long rounds.  Instantiated
 // for 4-byte items only.
-template <typename ITEM, int NV, typename DIRECT>
+template <typename ITEM, int NV, typename DIRECT, int PD = 1>
 __global__ __launch_bounds__(kPBlock) void p2_ring_roles_kernel(DIRECT D, uint32_t b2e, uint32_t tag_bits, SegList S, uint32_t cap,
                                                                 unsigned int* __restrict__ gcur, ITEM* __restrict__ out, uint32_t bucket0,
                                                                 uint64_t* __restrict__ strag, uint32_t* __restrict__ strag_n, unsigned long long* __restrict__ ctr_direct) {
@@ -621,6 +621,21 @@ __global__ __launch_bounds__(kPBlock) void p2_ring_roles_kernel(DIRECT D, uint32
           for(int q = 0; q < VPI; ++q) it[VPI * h + q] = i + q < b ? src[i + q] : hole;
         }
       };
+      // A batch of the exact two-pass P1 (a small batch: a file's tail chunk, add_keys) has no holes and starts anywhere:
+      // item by item, and an item that EQUALS the hole marker -- a real k-mer when items are 32 bits wide -- goes on the
+      // straggler list, from where it is inserted directly (round-4 advisor finding: it used to be dropped as a hole).
+      auto load_exact = [&](uint64_t r0, ITEM (&it)[RP]) {
+#pragma unroll 1
+        for(int h = 0; h < NV; ++h) {
+          const uint64_t i = r0 + (uint64_t)h * kHalf * VPI + (uint64_t)VPI * l;
+#pragma unroll
+          for(int q = 0; q < VPI; ++q) {
+            ITEM x = hole;
+            if(i + q < b) { x = src[i + q]; if(x == hole) straggler((uint32_t)(x >> tag_bits) & (nb - 1), x, 1u); }
+            it[VPI * h + q] = x;
+          }
+        }
+      };
       auto append = [&](const ITEM (&it)[RP]) {
         uint32_t ea[RP], eo[RP];
 #pragma unroll
@@ -643,19 +658,35 @@ __global__ __launch_bounds__(kPBlock) void p2_ring_roles_kernel(DIRECT D, uint32
         lds_barrier();                                             // the storers take this round from here
       };
       uint64_t r0 = a;
+      if(S.sh[seg] == 0) {                                         // (the same number of rounds as the storers count)
+#pragma unroll 1
+        for(; r0 < b; r0 += RS) { ITEM it[RP]; load_exact(r0, it); append(it); }
+        continue;
+      }
       const uint64_t n_full = (b - a) / RS;
       if(n_full) {
-        ITEM nx[RP];
-        load_full(r0, nx);
-#pragma unroll 1
-        for(uint64_t k = 0; k < n_full; ++k) {
-          ITEM it[RP];
+        // PD rounds of items are on their way while one is appended: a round lasts ~2 us, about what a load takes under
+        // load, so with one round ahead (round 4) the loaders met their own latency every round (round 5: JFGPU_P2_DEPTH)
+        ITEM nx[PD][RP];
 #pragma unroll
-          for(int e = 0; e < RP; ++e) it[e] = nx[e];
-          r0 += RS;
-          load_full(k + 1 < n_full ? r0 : a, nx);                  // (after the last round: a load nobody looks at)
-          append(it);
+        for(int d = 0; d < PD; ++d) load_full((uint64_t)d < n_full ? a + (uint64_t)d * RS : a, nx[d]);
+        uint64_t k = 0;
+#pragma unroll 1
+        for(; k + PD <= n_full; k += PD) {                          // straight-line body: the waits for nx[d] can be counted
+#pragma unroll
+          for(int d = 0; d < PD; ++d) {
+            ITEM it[RP];
+#pragma unroll
+            for(int e = 0; e < RP; ++e) it[e] = nx[d][e];
+            const uint64_t nxt = k + d + PD;
+            load_full(nxt < n_full ? a + nxt * RS : a, nx[d]);      // (past the last round: a load nobody looks at)
+            append(it);
+          }
         }
+#pragma unroll
+        for(int d = 0; d < PD - 1; ++d)                             // the last n_full % PD rounds are in nx already
+          if(k + d < n_full) append(nx[d]);
+        r0 = a + n_full * RS;
       }
       if(r0 < b) { ITEM it[RP]; load_partial(r0, it); append(it); }
     }

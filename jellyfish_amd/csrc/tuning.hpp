@@ -28,6 +28,9 @@ struct Tuning {
   uint32_t flush_share = 0;      // JFGPU_FLUSH_SHARE      force a flush into this many bucket groups sharing one P2 buffer (tests)
   bool flush_trace = false;      // JFGPU_FLUSH_TRACE      one stderr line per flush
   int p2_ring = 1;               // JFGPU_P2_RING          single-pass P2 of 4-byte items through per-destination rings (0: the sort-based kernel, 3: never the loader / storer kernel; A/B)
+  int p2_depth = 2;              // JFGPU_P2_DEPTH         rounds of items the loader waves of p2_ring_roles_kernel keep in flight (1, 2 or 3; A/B)
+  int bloom_cache = -1;          // JFGPU_BLOOM_CACHE      count --bc: remember admitted k-mers (-1: when the first batches admit > 15 % of their windows, 0 never, 1 always)
+  uint32_t bloom_cache_log2 = 28;// JFGPU_BLOOM_CACHE_LOG2 two-way sets of that cache (2^28 sets = 4 GB; tests: tiny caches evict all the time)
   // ---- Bloom counters (jfgpu_bloom_create)
   int bloom_mode = 0;            // JFGPU_BLOOM_MODE=direct|partitioned      0: not set
   int bloom_p1_two = 1;          // JFGPU_BLOOM_P1_TWO     P1b as two workgroups per CU (rounds of 5 cells, nibble tables); 0: one, rounds of 10 (A/B)
@@ -55,6 +58,9 @@ struct Tuning {
     if(const char* e = str("JFGPU_FLUSH_SHARE")) u.flush_share = (uint32_t)atoi(e);
     u.flush_trace = str("JFGPU_FLUSH_TRACE") != nullptr;
     if(const char* e = str("JFGPU_P2_RING")) u.p2_ring = atoi(e);
+    if(const char* e = str("JFGPU_P2_DEPTH")) u.p2_depth = std::min(3, std::max(1, atoi(e)));
+    if(const char* e = str("JFGPU_BLOOM_CACHE")) u.bloom_cache = atoi(e);
+    if(const char* e = str("JFGPU_BLOOM_CACHE_LOG2")) u.bloom_cache_log2 = (uint32_t)std::min(30, std::max(2, atoi(e)));
     if(const char* e = str("JFGPU_BLOOM_P1_TWO")) u.bloom_p1_two = atoi(e);
     if(const char* e = str("JFGPU_BLOOM_MODE")) u.bloom_mode = !strcmp(e, "direct") ? 1 : !strcmp(e, "partitioned") ? 2 : 0;
     u.comm_trace = str("JFGPU_COMM_TRACE") != nullptr;

@@ -49,6 +49,38 @@ def test_bloom_bytes_identical_to_reference(gpu, case):
                 t.attach_bloom(None)
 
 
+@pytest.mark.parametrize("log2_sets", ["2", "12"])
+@pytest.mark.parametrize("case", MANIFEST["bloom"], ids=lambda c: c["name"])
+def test_count_bc_with_the_cache_of_admitted_kmers(gpu, monkeypatch, case, log2_sets):
+    """count --bc with the cache of admitted k-mers forced on (JFGPU_BLOOM_CACHE=1; the engine turns it on by itself when a
+    pass admits most of its windows -- high-coverage input): a hit answers instead of the counter's ten cells, so the
+    filtered table must still be the reference's golden dump (count_main.cc:109-119, bloom_counter2.hpp:109-142), with a
+    cache of four sets (every insert evicts) and with one that holds everything, on both insert paths, the input fed
+    twice so that the second feed hits."""
+    monkeypatch.setenv("JFGPU_BLOOM_CACHE", "1")
+    monkeypatch.setenv("JFGPU_BLOOM_CACHE_LOG2", log2_sets)
+    header, body = read_bc(os.path.join(GOLD, case["ref_bc"]))
+    k, can = case["k"], case["canonical"]
+    m1 = np.array(header["matrix1"]["columns"], dtype=np.uint64)
+    m2 = np.array(header["matrix2"]["columns"], dtype=np.uint64)
+    seq = O.parse_file(open(os.path.join(GOLD, case["input"]), "rb").read())
+    golden = dict((l.split()[0], int(l.split()[1])) for l in open(os.path.join(GOLD, case["name"] + ".filtered.dump")).read().splitlines())
+    with gpu.Bloom(k, header["size"], header["nb_hashes"], canonical=can, matrix1=m1, matrix2=m2) as b:
+        b.load(body)
+        for mode in (1, 2):
+            with gpu.Table(k, 1 << 16, canonical=can) as t:
+                t.set_mode(mode)
+                t.attach_bloom(b)
+                t.count_ascii(seq)
+                t.count_ascii(seq)                                # the same windows again: admitted ones are in the cache now
+                t.sync()
+                kk, cc = gpu.decode_records(t.dump_records(), k, 4)
+                got = dict((O.to_str(np.array([a], dtype=np.uint64), k), c) for a, c in zip(kk.tolist(), cc.tolist()))
+                assert got == {key: 2 * c for key, c in golden.items()}, (mode, log2_sets)
+                assert t.stats().mers_fed == 2 * len(O.extract(seq, k, can))
+                t.attach_bloom(None)
+
+
 def test_bloom_against_oracle_on_random_input(gpu):
     """Own random matrices, larger input with lower-case / N resets, saturation at 2, load() round trip."""
     rng = random.Random(41)
@@ -323,38 +355,77 @@ def test_sharded_count_with_a_bloom_counter_equals_the_single_table(gpu, monkeyp
                 t.close()
 
 
+def np_matrix_times(cols, r, c, keys):
+    """pos = M * key over GF(2) for an array of one-word keys, vectorised: M's images of the key's bytes from the oracle's
+    matrix_times on the unit vectors (rectangular_binary_matrix.hpp:155-164 through oracle/jf_oracle.c), xor-combined."""
+    units = O.matrix_times(cols, r, c, np.array([1 << i for i in range(c)], dtype=np.uint64))
+    keys = np.asarray(keys, dtype=np.uint64)
+    out = np.zeros(len(keys), dtype=np.uint64)
+    for b in range((c + 7) // 8):
+        tbl = np.zeros(256, dtype=np.uint64)
+        for v in range(1, 256):
+            low = v & -v
+            bit = 8 * b + low.bit_length() - 1
+            tbl[v] = tbl[v ^ low] ^ (units[bit] if bit < c else np.uint64(0))
+        out ^= tbl[((keys >> np.uint64(8 * b)) & np.uint64(255)).astype(np.intp)]
+    return out
+
+
 def test_partitioned_insert_at_config_3_geometry(gpu, monkeypatch):
     """The Bloom pass at BASELINE configs[2]'s size (m = 14e10 cells = 28 GB: 2^9 P1b buckets of 2^10 segments): this is
     where the cell updates' P2 goes through the ring kernel (p2_ring_kernel<BloomRingDirect>, the array's partial last
-    bucket through the sort) -- the filters of the other tests are too small for it.  Every k-mer of the input reads back
-    the same from the partitioned insert and from the global-CAS insert, and what was seen twice reads 2
-    (bloom_counter2.hpp:56-142)."""
+    bucket through the sort) -- the filters of the other tests are too small for it.  Checked against the ORACLE's
+    restatement of bloom_counter2.hpp:56-107 (insert__: cell_i = (h0 % m + i (h1 % m)) % m, five base-3 cells a byte,
+    saturating at 2) evaluated sparsely -- the cells the input touches, by numpy from the oracle's own matrix products:
+    the whole 28 GB array read back must hold exactly those bytes with exactly those values and zero everywhere else,
+    and check__ (:109-142) of every k-mer asked about must be the minimum over its cells."""
     if os.environ.get("JFGPU_LIB"):
-        pytest.skip("two filters of 28 GB: not under the host emulation")
+        pytest.skip("a filter of 28 GB: not under the host emulation")
     monkeypatch.setenv("JFGPU_P2_SINGLE", "2")             # (the input is small: single-pass P2 even though its regions are mostly head-room)
     rng = random.Random(77)
     k = 31
     once = "".join(rng.choice("ACGT") for _ in range(1_500_000))
     twice = "".join(rng.choice("ACGT") for _ in range(500_000))
     seq = (once + "N" + twice + "N" + twice).encode()
-    keys1, _ = O.count(seq[:400_000], k, True)                   # k-mers asked about: a sample of those inserted once ...
-    keys2, _ = O.count(twice[:200_000].encode(), k, True)         # ... and of those inserted twice
-    keys = np.concatenate([keys1, keys2]); n1 = len(keys1)
+    tail = b"ACGTN" * 2000
     m, nh = 14 * 10_000_000_000, 10
-    got = []
-    for mode in (2, 1):
-        with gpu.Bloom(k, m, nh, canonical=True, seed=5) as b:
-            b.set_mode(mode)
-            if mode == 2:
-                b.reserve(8 << 30)
-                b.profile_enable(True); b.profile_reset()
-            for rep in range(3):                                  # several batches pending before the flush
-                b.insert_ascii(seq if rep == 0 else b"ACGTN" * 2000)
-            n = b.sync()
-            if mode == 2:
-                assert b.profile_get(2)[1] >= 1 and b.profile_get(3)[1] >= 1, "the partitioned stages (P2, segments) must have run"
-            got.append(b.keys(keys[:, 0]))
-    assert (got[0] == got[1]).all()
-    # a k-mer of `twice` was inserted at least twice: 2; the cells saturate at 2 (every k-mer asked about was inserted at least once)
-    assert (got[0] >= 1).all() and (got[0][n1:] == 2).all()
-    assert int((got[0][:n1] == 1).sum()) > 0.99 * n1           # (a once-seen k-mer reads 2 only if all its ten cells were bumped by others: never at this load)
+    with gpu.Bloom(k, m, nh, canonical=True, seed=5) as b:
+        b.set_mode(2)
+        b.reserve(8 << 30)
+        b.profile_enable(True); b.profile_reset()
+        for rep in range(3):                                  # several batches pending before the flush
+            b.insert_ascii(seq if rep == 0 else tail)
+        n = b.sync()
+        assert b.profile_get(2)[1] >= 1 and b.profile_get(3)[1] >= 1, "the partitioned stages (P2, segments) must have run"
+        assert b.ring_p2_launches() >= 1, "the cell updates' P2 must have gone through the ring kernel"
+        # the oracle, sparse: every occurrence of every k-mer bumps its nh cells
+        kmers = np.concatenate([O.extract(seq, k, True), O.extract(tail, k, True), O.extract(tail, k, True)])[:, 0]
+        assert n == len(kmers)
+        h0 = np_matrix_times(b.matrix1, 64, 2 * k, kmers) % np.uint64(m)
+        h1 = np_matrix_times(b.matrix2, 64, 2 * k, kmers) % np.uint64(m)
+        sub = slice(0, 2000)                                  # (the vectorised products against the oracle's own, on a sample)
+        assert (h0[sub] == O.matrix_times(b.matrix1, 64, 2 * k, kmers[sub]) % np.uint64(m)).all()
+        assert (h1[sub] == O.matrix_times(b.matrix2, 64, 2 * k, kmers[sub]) % np.uint64(m)).all()
+        cells = np.concatenate([(h0 + np.uint64(i) * h1) % np.uint64(m) for i in range(nh)])
+        ucell, hits = np.unique(cells, return_counts=True)
+        digit = np.minimum(hits, 2).astype(np.uint64)
+        byte_of, val = ucell // np.uint64(5), digit * (np.uint64(3) ** (ucell % np.uint64(5)))
+        ubyte, first = np.unique(byte_of, return_index=True)
+        expect = np.add.reduceat(val, first).astype(np.uint8)
+        got = b.read()
+        assert len(got) == (m + 4) // 5
+        assert (got[ubyte.astype(np.intp)] == expect).all(), "a touched byte of the array differs from bloom_counter2's"
+        assert int(np.count_nonzero(got)) == len(ubyte), "cells were bumped that no k-mer of the input owns"
+        # check__: the minimum over a k-mer's cells, for a sample of the k-mers inserted once and of those inserted twice
+        keys1, _ = O.count(seq[:400_000], k, True)
+        keys2, _ = O.count(twice[:200_000].encode(), k, True)
+        keys = np.concatenate([keys1, keys2])[:, 0]; n1 = len(keys1)
+        q0 = np_matrix_times(b.matrix1, 64, 2 * k, keys) % np.uint64(m)
+        q1 = np_matrix_times(b.matrix2, 64, 2 * k, keys) % np.uint64(m)
+        want = np.full(len(keys), 2, dtype=np.uint64)
+        for i in range(nh):
+            c = (q0 + np.uint64(i) * q1) % np.uint64(m)
+            want = np.minimum(want, digit[np.searchsorted(ucell, c)])
+        ans = b.keys(keys)
+        assert (ans == want).all()
+        assert (ans[n1:] == 2).all() and int((ans[:n1] == 1).sum()) > 0.99 * n1

@@ -956,12 +956,16 @@ def test_ring_p2_kernels_at_the_geometries_that_use_them(gpu, monkeypatch, lsize
     """The ring kernels of P2 (kernels_p1ring.hip.hpp) take buckets of 1024 destinations -- tables of 2^34 4-byte slots:
     p2_ring_roles_kernel with rounds of 4 Ki items, or p2_ring_kernel with JFGPU_P2_RING=3 -- and, with short rounds, of
     512 (2^33 slots); smaller tables, i.e. every other parity test, take the sort-based kernel.  Here 0.2 Gbp goes through
-    them and the table's content digest (keys and counts, whatever the matrix) must equal that of the global-atomic path
-    in a small table, which the oracle tests pin (large_hash_array.hpp:509-597, 741-752: every k-mer ends up counted once
-    per occurrence, wherever it sits)."""
+    them -- WHICH kernel ran is asserted from the engine's counters (round 4's version of this test never reached them:
+    its flushes were below the single-pass threshold and took the exact P2) -- and the table's content digest (keys and
+    counts, whatever the matrix) must equal that of the global-atomic path in a small table, which the oracle tests pin
+    (large_hash_array.hpp:509-597, 741-752: every k-mer ends up counted once per occurrence, wherever it sits).  The
+    reference-anchored check at these geometries is tests/test_cli_gpu.py's half-Gbp digest test with -s 16G / 8G."""
     if os.environ.get("JFGPU_LIB"):
         pytest.skip("tables of 32 and 64 GB: not under the host emulation")
     monkeypatch.setenv("JFGPU_P2_RING", p2_ring)
+    if p2_ring == "3":
+        monkeypatch.setenv("JFGPU_P2_SINGLE", "2")         # (the shared-ring kernel reserves granules: auto mode wants far larger flushes)
     k, L, n_reads = 21, 150, 1_400_000
     with gpu.Table(k, 1 << 29, canonical=True) as ref:
         d = ref.malloc(n_reads * (L + 1) + 16)
@@ -982,9 +986,103 @@ def test_ring_p2_kernels_at_the_geometries_that_use_them(gpu, monkeypatch, lsize
         t.count_ascii_dev(d, half); t.sync()                       # two flushes: the second into dirty tiles
         t.count_ascii_dev(d + half, n_reads * (L + 1) - half); t.sync()
         assert t.profile_get(5)[1] >= 2 and t.profile_get(6)[1] >= 2, "P2 and the tile insert must have run"
+        c = t.counters()
+        assert c["p1_ring"] >= 2 and c["p1_other"] == 0, c
+        assert c["p2_roles" if p2_ring == "1" else "p2_ring"] == 2 and c["p2_sort"] == 0 and c["p2_exact"] == 0, c
         assert t.digest() == want
-        assert t.counters()["direct"] < want[1] // 1000
+        assert c["direct"] < want[1] // 1000
         t.free(d)
+
+
+def gf2_solve(rows, rhs, n):
+    """x (an int of n bits) with parity(rows[i] & x) == rhs[i] for every i, or None: Gaussian elimination on Python ints."""
+    piv = {}
+    for r, b in zip(rows, rhs):
+        for col, (pr, pb) in piv.items():
+            if (r >> col) & 1:
+                r ^= pr; b ^= pb
+        if r == 0:
+            if b:
+                return None
+            continue
+        col = r.bit_length() - 1
+        for c2, (pr, pb) in list(piv.items()):
+            if (pr >> col) & 1:
+                piv[c2] = (pr ^ r, pb ^ b)
+        piv[col] = (r, b)
+    x = 0
+    for col, (pr, pb) in piv.items():
+        if pb:
+            x |= 1 << col
+    return x
+
+
+@pytest.mark.parametrize("p2_ring", ["1", "3"])
+def test_exact_batch_holding_the_all_ones_item_beside_granule_batches(gpu, monkeypatch, p2_ring):
+    """Round-4 advisor finding.  At the metric's geometry (k = 21, 2^34 slots) an item is 32 bits wide, so one k-mer's item
+    is 0xFFFFFFFF -- the marker the single-pass partition kernels use for a hole.  p1_ring_kernel diverts that k-mer to its
+    straggler list; an EXACT two-pass P1 batch (a small batch: a file's tail, add_keys) stores it like any other item, at
+    an arbitrary offset.  Round 4's ring kernels of P2 dropped it as a hole (and loaded 16 bytes at unaligned addresses).
+    Now the loader / storer kernel takes such a segment item by item and sends the all-ones item to its straggler list
+    (p2_ring = 1), and a flush that would take the shared-ring kernel (JFGPU_P2_RING=3) keeps the sort-based P2, which
+    knows which segments have holes.  The k-mer is found by solving M x = 1...1 for this table's matrix
+    (rectangular_binary_matrix.hpp:155-164 through the oracle's matrix_times); it must come out counted exactly, and the
+    counters say which P2 ran."""
+    if os.environ.get("JFGPU_LIB"):
+        pytest.skip("a table of 64 GB: not under the host emulation")
+    monkeypatch.setenv("JFGPU_P2_RING", p2_ring)
+    if p2_ring == "3":
+        monkeypatch.setenv("JFGPU_P2_SINGLE", "2")
+    k, L, n_reads, lsize = 21, 150, 1_000_000, 34
+    with gpu.Table(k, 1 << lsize, canonical=False) as t:
+        assert t.info.slot_bytes == 4 and t.info.lsize == lsize
+        cols = t.matrix()
+        units = O.matrix_times(cols, lsize, 2 * k, np.array([1 << i for i in range(2 * k)], dtype=np.uint64)).tolist()
+        low = (1 << 24) - 1                                        # the position bits an item carries: all but the 2^10 P1 buckets' top ten
+        fixed = 0
+        for i in range(lsize, 2 * k):                              # the eight key bits the position does not determine: all ones
+            fixed ^= units[i]
+        rows = [sum((((units[i] >> bit) & 1) << i) for i in range(lsize)) for bit in range(24)]
+        rhs = [((low ^ fixed) >> bit) & 1 for bit in range(24)]
+        x = gf2_solve(rows, rhs, lsize)
+        assert x is not None
+        key = x | (((1 << (2 * k - lsize)) - 1) << lsize)
+        pos = int(O.matrix_times(cols, lsize, 2 * k, np.array([key], dtype=np.uint64))[0])
+        assert ((pos & low) << 8 | key >> lsize) == 0xFFFFFFFF
+        special = O.to_str(np.array([key], dtype=np.uint64), k).encode() + b"N"
+        d = t.malloc(n_reads * (L + 1) + 64)
+        ds = t.malloc(64)
+        t.gen_reads_dev(d, 0, n_reads, L, 23)
+        t.h2d(ds, np.frombuffer(special, dtype=np.uint8))
+        t.set_mode(1)
+        t.count_ascii_dev(d, n_reads * (L + 1)); t.count_ascii_dev(ds, len(special)); t.sync()
+        want = t.digest()
+        assert want[1] == n_reads * (L - k + 1) + 1
+        base_count = int(t.lookup(np.array([key], dtype=np.uint64))[0][0])
+        assert base_count >= 1
+        t.clear()
+        t.set_mode(2)
+        t.reserve(n_reads * (L + 1))
+        half = (n_reads // 2) * (L + 1)
+        t.count_ascii_dev(d, half)                                 # a granule batch,
+        t.count_ascii_dev(ds, len(special))                        # an exact batch of one item: the all-ones one,
+        t.count_ascii_dev(d + half, n_reads * (L + 1) - half)      # another granule batch: one flush
+        t.sync()
+        c = t.counters()
+        assert c["p1_ring"] >= 2 and c["p1_other"] == 1, c
+        if p2_ring == "1":
+            assert c["p2_roles"] == 1 and c["p2_sort"] == 0 and c["p2_ring"] == 0 and c["p2_exact"] == 0, c
+        else:
+            assert c["p2_sort"] == 1 and c["p2_roles"] == 0 and c["p2_ring"] == 0 and c["p2_exact"] == 0, c
+        assert t.digest() == want
+        vals, found = t.lookup(np.array([key], dtype=np.uint64))
+        assert found[0] and int(vals[0]) == base_count
+        # the same flush without the exact batch takes a ring kernel either way
+        t.clear()
+        t.count_ascii_dev(d, half); t.count_ascii_dev(d + half, n_reads * (L + 1) - half); t.sync()
+        c = t.counters()
+        assert c["p2_roles" if p2_ring == "1" else "p2_ring"] == 1 and c["p2_sort"] == 0, c
+        t.free(d); t.free(ds)
 
 
 def test_receive_split_regions_fit_when_the_fan_out_is_below_the_world_size(gpu, monkeypatch):
