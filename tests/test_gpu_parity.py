@@ -966,7 +966,7 @@ def test_ring_p2_kernels_at_the_geometries_that_use_them(gpu, monkeypatch, lsize
     monkeypatch.setenv("JFGPU_P2_RING", p2_ring)
     if p2_ring == "3":
         monkeypatch.setenv("JFGPU_P2_SINGLE", "2")         # (the shared-ring kernel reserves granules: auto mode wants far larger flushes)
-    k, L, n_reads = 21, 150, 1_400_000
+    k, L, n_reads = 21, 150, 2_200_000                      # (two batches of 143 M k-mers: 2^17 and more per P1 bucket, what the single-pass P1 wants)
     with gpu.Table(k, 1 << 29, canonical=True) as ref:
         d = ref.malloc(n_reads * (L + 1) + 16)
         ref.gen_reads_dev(d, 0, n_reads, L, 11)
@@ -988,7 +988,7 @@ def test_ring_p2_kernels_at_the_geometries_that_use_them(gpu, monkeypatch, lsize
         assert t.profile_get(5)[1] >= 2 and t.profile_get(6)[1] >= 2, "P2 and the tile insert must have run"
         c = t.counters()
         assert c["p1_ring"] >= 2 and c["p1_other"] == 0, c
-        assert c["p2_roles" if p2_ring == "1" else "p2_ring"] == 2 and c["p2_sort"] == 0 and c["p2_exact"] == 0, c
+        assert c["p2_roles" if p2_ring == "1" else "p2_ring"] >= 2 and c["p2_sort"] == 0 and c["p2_exact"] == 0, c      # (a flush may go in bucket groups sharing one buffer: a launch per group)
         assert t.digest() == want
         assert c["direct"] < want[1] // 1000
         t.free(d)
@@ -1033,7 +1033,7 @@ def test_exact_batch_holding_the_all_ones_item_beside_granule_batches(gpu, monke
     monkeypatch.setenv("JFGPU_P2_RING", p2_ring)
     if p2_ring == "3":
         monkeypatch.setenv("JFGPU_P2_SINGLE", "2")
-    k, L, n_reads, lsize = 21, 150, 1_000_000, 34
+    k, L, n_reads, lsize = 21, 150, 2_200_000, 34            # (halves of 143 M k-mers: granule batches)
     with gpu.Table(k, 1 << lsize, canonical=False) as t:
         assert t.info.slot_bytes == 4 and t.info.lsize == lsize
         cols = t.matrix()
@@ -1062,7 +1062,7 @@ def test_exact_batch_holding_the_all_ones_item_beside_granule_batches(gpu, monke
         assert base_count >= 1
         t.clear()
         t.set_mode(2)
-        t.reserve(n_reads * (L + 1))
+        t.reserve(6 * n_reads * (L + 1))                           # (room for the whole flush's P2 regions at once: 2^20 of them, mostly head-room at this size)
         half = (n_reads // 2) * (L + 1)
         t.count_ascii_dev(d, half)                                 # a granule batch,
         t.count_ascii_dev(ds, len(special))                        # an exact batch of one item: the all-ones one,
@@ -1071,9 +1071,9 @@ def test_exact_batch_holding_the_all_ones_item_beside_granule_batches(gpu, monke
         c = t.counters()
         assert c["p1_ring"] >= 2 and c["p1_other"] == 1, c
         if p2_ring == "1":
-            assert c["p2_roles"] == 1 and c["p2_sort"] == 0 and c["p2_ring"] == 0 and c["p2_exact"] == 0, c
+            assert c["p2_roles"] >= 1 and c["p2_sort"] == 0 and c["p2_ring"] == 0 and c["p2_exact"] == 0, c
         else:
-            assert c["p2_sort"] == 1 and c["p2_roles"] == 0 and c["p2_ring"] == 0 and c["p2_exact"] == 0, c
+            assert c["p2_sort"] >= 1 and c["p2_roles"] == 0 and c["p2_ring"] == 0 and c["p2_exact"] == 0, c
         assert t.digest() == want
         vals, found = t.lookup(np.array([key], dtype=np.uint64))
         assert found[0] and int(vals[0]) == base_count
@@ -1081,7 +1081,7 @@ def test_exact_batch_holding_the_all_ones_item_beside_granule_batches(gpu, monke
         t.clear()
         t.count_ascii_dev(d, half); t.count_ascii_dev(d + half, n_reads * (L + 1) - half); t.sync()
         c = t.counters()
-        assert c["p2_roles" if p2_ring == "1" else "p2_ring"] == 1 and c["p2_sort"] == 0, c
+        assert c["p2_roles" if p2_ring == "1" else "p2_ring"] >= 1 and c["p2_sort"] == 0, c
         t.free(d); t.free(ds)
 
 
