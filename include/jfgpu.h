@@ -41,7 +41,7 @@ enum {
   JFGPU_E_ALLOC = 3,      /* large_hash::array::ErrorAllocation, large_hash_array.hpp:55,169-172 */
   JFGPU_E_FULL = 4,       /* std::runtime_error("Hash full"), hash_counter.hpp:194-195 */
   JFGPU_E_HIP = 5,        /* HIP runtime error */
-  JFGPU_E_UNSUPPORTED = 6,/* combination not built (e.g. k > 128, a sharded table for k > 32) */
+  JFGPU_E_UNSUPPORTED = 6,/* combination not built (e.g. k > 128, a sharded table for k > 64, --bc / --if over shards of two-word keys) */
   JFGPU_E_FORMAT = 7      /* device parser: chunk is not in the strict layout it handles; give it to the host parser */
 };
 
@@ -247,8 +247,10 @@ int  jfgpu_attach_bloom(jfgpu_table* t, jfgpu_bloom* b);
 /* hash_counter::do_size_doubling(bool) (hash_counter.hpp:78-79).  On (default): the size given at
  * creation is a hint, the table doubles itself (device-side rehash, one more matrix row) before it
  * could exceed 80 % load, as long as device memory allows; jfgpu_get_info / jfgpu_get_matrix report
- * the current geometry.  Off: a full table is the deferred error "Hash full".  Unsharded tables
- * only (a shard of a multi-GPU table reports "Hash full": give count --gpus a size that fits). */
+ * the current geometry.  Off: a full table is the deferred error "Hash full".  The shards of a multi-GPU
+ * table grow TOGETHER, inside jfgpu_comm_count_ascii_dev (abi_comm.inl: comm_grow -- every rank draws the next
+ * matrix of the same stream, re-shards its entries on the device and the (key, count) pairs travel to their new
+ * owners), for keys of one and two words; a shard fed outside a communicator reports "Hash full". */
 int  jfgpu_set_growth(jfgpu_table* t, int on);
 
 /* The matrix a table gets when jfgpu_params gives neither matrix_columns nor matrix_seed: the one the

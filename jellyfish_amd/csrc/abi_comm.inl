@@ -920,16 +920,36 @@ int comm_exchange_rccl(jfgpu_comm* c); int comm_exchange_local(jfgpu_comm* c); i
 int comm_grow(jfgpu_comm* c) {
   const int W = c->world;
   std::vector<GrowNew> N(c->ranks.size());
+  std::vector<char> prepared(c->ranks.size(), 0);
+  bool cannot = false;
   // every rank: nothing in flight, the new shard allocated, the pairs that leave grouped by their new owner in send[0] / send[1]
   for(size_t q = 0; q < c->ranks.size(); ++q) {
     jfgpu_comm::Rank& R = c->ranks[q];
     jfgpu_table* t = R.t;
     if(t->nword) return fail(JFGPU_E_UNSUPPORTED, "sharded tables of keys longer than two words are not built");
-    const uint64_t kw = t->wide ? 2 : 1;                   // 64-bit words per key
     int rc = comm_insert_prev(c, R); if(rc) return rc;
     rc = grow_prepare(t, N[q]);
-    if(rc < 0) return fail(JFGPU_E_FULL, "Hash full (no memory to double a shard)");
-    if(rc) return rc;
+    if(rc > 0) return rc;
+    prepared[q] = rc == 0;                                  // < 0: no memory for the doubled shard (nothing allocated)
+    cannot = cannot || rc < 0;
+  }
+  // Growing is collective: a rank that cannot allocate its doubled shard must not leave alone while the others go on into
+  // the exchange (round-4 advisor finding: they hung there).  One more agreement; if anybody cannot, nobody grows -- what
+  // was prepared is freed and the shards carry on as they are, growth off, like a single table short of memory
+  // (ensure_capacity): a shard that then really fills up reports "Hash full" through its tiles' probe bound.
+  if(!c->local) { uint64_t v = cannot ? 1 : 0; int rc = jfgpu_comm_allreduce_u64(c, &v, 1, 1); if(rc) return rc; cannot = v != 0; }
+  if(cannot) {
+    for(size_t q = 0; q < c->ranks.size(); ++q) {
+      if(prepared[q]) { DevTable& nd = N[q].nd; hipFree(nd.slots); hipFree(nd.ovf_key); hipFree(nd.ovf_cnt); hipFree(nd.dirty); hipFree(N[q].nf); hipFree(N[q].ni); }
+      c->ranks[q].t->grow_on = false;
+    }
+    return JFGPU_OK;
+  }
+  for(size_t q = 0; q < c->ranks.size(); ++q) {
+    jfgpu_comm::Rank& R = c->ranks[q];
+    jfgpu_table* t = R.t;
+    const uint64_t kw = t->wide ? 2 : 1;                   // 64-bit words per key
+    int rc = 0;
     HIP_TRY(hipStreamSynchronize(c->xstream));
     const int have_ovf = (int)(N[q].ctr[CTR_OVF_USED] != 0);
     const dim3 grid(grid_for(t, (1ull << t->g.lsize_l) / kBlock + 1)), block(kBlock);
@@ -1008,6 +1028,10 @@ uint64_t comm_headroom(const jfgpu_table* t) {
   const uint64_t limit = capacity_limit(t), used = t->occ_known + t->fed_since;
   return limit > used ? limit - used : 0;
 }
+// What a shard is charged for an exchange in which every rank fed at most `piece` bytes: a hash prefix gets its even share
+// of the W pieces only on average -- a sixteenth and four standard deviations on top, so that a shard that receives a
+// little more than its share cannot pass its load limit between two measurements (round-4 advisor finding).
+uint64_t comm_charge(uint64_t piece) { return piece + piece / 16 + 4 * (uint64_t)std::sqrt((double)piece); }
 // head-room too small for a useful piece of `left` bytes: time to measure
 bool comm_bound_out(const jfgpu_table* t, uint64_t left) { return comm_headroom(t) < std::min<uint64_t>(left, std::max<uint64_t>(capacity_limit(t) / 8, 1)); }
 
@@ -1162,7 +1186,7 @@ int jfgpu_comm_count_ascii_dev(jfgpu_comm* c, jfgpu_table* t, const char* d_base
     const uint32_t cap = v[0] ? 0u : (uint32_t)v[1];
     IPC_TRACE(c, "step: piece of %zu bytes, agreed cap %u (0: keys)", piece, cap);
     rc = comm_piece_rccl(c, R, d_bases + off, piece, cap); if(rc) return rc;
-    if(growing) t->fed_since += std::min<uint64_t>(v[2], std::max<uint64_t>(agreed, 2 * k));
+    if(growing) t->fed_since += comm_charge(std::min<uint64_t>(v[2], std::max<uint64_t>(agreed, 2 * k)));
     if(off + piece >= n) off = n; else off += piece - (size_t)(k - 1);      // the next piece re-reads the last k-1 characters: every window exactly once
     if(!growing) break;                                      // (no pieces without growth: the step is one exchange, as the caller counts them)
   }
@@ -1201,7 +1225,11 @@ int jfgpu_comm_local_step(jfgpu_comm* c, jfgpu_table** tables, const char* const
         rc = measure_occupancy(tables[r]); if(rc) return rc;
         full = full || tables[r]->occ_known > (1ull << tables[r]->g.lsize_l) / 2;
       }
-      if(full) { int rc = comm_grow(c); if(rc) return rc; }
+      if(full) {
+        int rc = comm_grow(c); if(rc) return rc;
+        growing = true;                                        // (a grow that had to be abandoned turns growth off on every shard)
+        for(int r = 0; r < W; ++r) growing = growing && comm_growing(tables[r]);
+      }
       first = true;
       continue;
     }
@@ -1245,7 +1273,7 @@ int jfgpu_comm_local_step(jfgpu_comm* c, jfgpu_table** tables, const char* const
       max_piece = std::max<uint64_t>(max_piece, piece[r]);
       if(off[r] + piece[r] >= n[r]) off[r] = n[r]; else off[r] += piece[r] - (size_t)(k - 1);
     }
-    if(growing) for(int r = 0; r < W; ++r) tables[r]->fed_since += max_piece;
+    if(growing) for(int r = 0; r < W; ++r) tables[r]->fed_since += comm_charge(max_piece);
     if(!growing) break;
   }
   return JFGPU_OK;

@@ -451,7 +451,12 @@ int part_flush_t(jfgpu_table* t) {
   auto launch_tile_kernel = [&](const SegList& S, uint64_t tile0, uint32_t ntile, hipStream_t ts, bool pair = false) {
     if constexpr(kWideItems) {
       const dim3 block(kPBlock), grid((unsigned)std::min<uint64_t>(ntile, (uint64_t)t->n_cu * 4));     // 128 KiB of LDS: one block per CU
-      if(rt) hipLaunchKernelGGL(tile_insert_wide_kernel<true>, grid, block, tile_lds, ts, t->wt, S, tile0, ntile);
+      if(S.n == 1 && t->tun.wide_pipe) {        // one item array (a flush's P2 output): the pipelined kernel
+        const dim3 gridp((unsigned)std::min<uint64_t>(ntile, (uint64_t)t->n_cu));
+        if(rt) hipLaunchKernelGGL(tile_insert_wide_pipe_kernel<true>, gridp, block, tile_lds, ts, t->wt, S, tile0, ntile);
+        else   hipLaunchKernelGGL(tile_insert_wide_pipe_kernel<false>, gridp, block, tile_lds, ts, t->wt, S, tile0, ntile);
+      }
+      else if(rt) hipLaunchKernelGGL(tile_insert_wide_kernel<true>, grid, block, tile_lds, ts, t->wt, S, tile0, ntile);
       else   hipLaunchKernelGGL(tile_insert_wide_kernel<false>, grid, block, tile_lds, ts, t->wt, S, tile0, ntile);
     } else {
       // one-word keys: placement by rank inside buckets of four (kernels_tile.hip.hpp); two workgroups per CU

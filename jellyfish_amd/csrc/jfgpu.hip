@@ -762,6 +762,8 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     HIP_TRY(hipFuncSetAttribute((const void*)p1_wide_granule_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
     HIP_TRY(hipFuncSetAttribute((const void*)tile_insert_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, wt));
     HIP_TRY(hipFuncSetAttribute((const void*)tile_insert_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, wt));
+    HIP_TRY(hipFuncSetAttribute((const void*)tile_insert_wide_pipe_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, wt));
+    HIP_TRY(hipFuncSetAttribute((const void*)tile_insert_wide_pipe_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, wt));
   }
   jfgpu_table* raw = t.release();
   int rc = jfgpu_clear(raw);

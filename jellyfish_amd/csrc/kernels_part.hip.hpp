@@ -929,6 +929,32 @@ __global__ __launch_bounds__(kPBlock) void p2_granule_kernel(DIRECT D, uint32_t 
       slo = shi;
     }
   };
+  // 16-byte items (two-word keys): the phase clocks of round 5 showed this kernel waiting for its chunk's loads 65 % of the
+  // time (seven 16-byte loads a lane, nothing else to do meanwhile).  The NEXT chunk is therefore requested into a second
+  // set of registers before the current one is ranked -- with unconditional loads when the chunk lies inside one batch's
+  // region (nearly always), so that the compiler can count them instead of waiting on the spot.  (For 4-byte items the
+  // same was measured in round 4 without gain: there the five barriers of a chunk are the cost.)
+  constexpr bool PF = sizeof(ITEM) == 16;
+  ITEM nx[PF ? PER_THREAD : 1];
+  [[maybe_unused]] uint32_t nvm = 0, nhm = 0;
+  auto load_chunk_pf = [&](uint64_t c0, ITEM (&x)[PER_THREAD], uint32_t& vm, uint32_t& hm) {
+    if(c0 < my_hi && my_hi - c0 >= (uint64_t)kChunk) {
+      uint64_t slo = 0;
+      for(uint32_t s = 0; s < S.n; ++s) {
+        const uint64_t o0 = seg_lo(S, s, bucket), shi = slo + (seg_hi(S, s, bucket) - o0);
+        if(c0 >= slo && c0 + kChunk <= shi) {                  // (block-uniform)
+          const ITEM* src = reinterpret_cast<const ITEM*>(S.items[s]) + (int64_t)o0 + ((int64_t)c0 - (int64_t)slo);
+#pragma unroll
+          for(int r = 0; r < PER_THREAD; ++r) x[r] = src[(uint32_t)r * kPBlock + threadIdx.x];
+          vm = (1u << PER_THREAD) - 1u; hm = S.sh[s] != 0 ? vm : 0u;
+          return;
+        }
+        slo = shi;
+      }
+    }
+    load_chunk(c0, x, vm, hm);
+  };
+  if constexpr(PF) load_chunk_pf(my_lo, nx, nvm, nhm);
   for(uint64_t c0 = my_lo; c0 < my_hi; c0 += kChunk) {
     lds_barrier();                                      // previous chunk's readers are done
     JF_PHASE(pc, 0);
@@ -936,7 +962,12 @@ __global__ __launch_bounds__(kPBlock) void p2_granule_kernel(DIRECT D, uint32_t 
     ITEM it[PER_THREAD];
     uint32_t rk[(PER_THREAD + 1) / 2];                  // rank inside the chunk's bucket, 16 bits each
     uint32_t hm = 0, vm = 0;
-    load_chunk(c0, it, vm, hm);
+    if constexpr(PF) {
+#pragma unroll
+      for(int r = 0; r < PER_THREAD; ++r) it[r] = nx[r];
+      vm = nvm; hm = nhm;
+      load_chunk_pf(c0 + kChunk, nx, nvm, nhm);
+    } else load_chunk(c0, it, vm, hm);
     lds_barrier();
     JF_PHASE(pc, 1);
     if constexpr(SMALL != 0) {

@@ -137,7 +137,7 @@ __device__ inline void tile_insert_wide_one(const WideTable& T, unsigned long lo
   const uint32_t tmask = (uint32_t)g.tile_mask;
   for(uint32_t p = 0; p <= T.max_probe; ++p) {
     const uint32_t slot = probe_slot(idx0, p, tmask);
-    const unsigned long long old = atomicCAS(&s_tile[2 * slot + 1], 0ull, whi);
+    const unsigned long long old = atomicCAS(&s_tile[2 * slot + 1], 0ull, whi);      // (a plain look first, to pass foreign tags without an atomic, was measured: slower, 63.6 -> 71.3 ms)
     if(old != 0ull && (old & g.low_mask) != whi) continue;
     const unsigned long long l = atomicCAS(&s_tile[2 * slot], 0ull, wlo);
     if(l != 0ull && l != wlo) continue;
@@ -192,6 +192,99 @@ __global__ __launch_bounds__(kPBlock) void tile_insert_wide_kernel(WideTable T, 
     if(threadIdx.x == 0) T.dirty[tile0 + t] = 1;
     lds_barrier();
   }
+}
+
+// ---- Tw, pipelined (round 5) ------------------------------------------------------------------------------------------------
+// tile_insert_wide_kernel runs its phases one after the other on the one workgroup a CU has room for (128 KiB of LDS):
+// zero the tile, fetch the items four at a time, claim them, store -- 18 us a tile at config 5's load (rocprofv3 r04: 75 ms
+// for 94 GB of items and 137 GB of table).  Same claims here, but nothing waits for HBM inside a tile: a chunk's items (8 per
+// lane) are requested as soon as the previous chunk's are claimed -- they travel during its store -- the offsets two units
+// ahead, and the store zeroes the LDS tile behind itself, so a tile nothing was ever inserted into costs no fill pass:
+// 75.6 -> 63.6 ms on config 5.  One item array (a flush's P2 output); flushes of single-level tables (several pending
+// batches per tile) keep the kernel above.
+template <bool RETURNING>
+__global__ __launch_bounds__(kPBlock) void tile_insert_wide_pipe_kernel(WideTable T, SegList S, uint64_t tile0, uint32_t n_tiles) {
+  constexpr int NPW = 8;                                                // items per lane and chunk
+  constexpr uint64_t kRound = (uint64_t)NPW * kPBlock;
+  JF_DYN_LDS(s_raw);
+  unsigned long long* s_tile = reinterpret_cast<unsigned long long*>(s_raw);
+  const TableGeom& g = T.W.g;
+  const uint32_t words = 2u << g.tile_bits;                            // 64-bit words of one tile
+  const uint64_t* off = S.off[0];
+  const uint32_t sh = S.sh[0];                                         // 1: (begin, end) pairs, items may be holes
+  const bool holes = sh != 0;
+  const u128* src = reinterpret_cast<const u128*>(S.items[0]);
+  const u128 hole = ~(u128)0;
+  const uint32_t G = gridDim.x;
+  struct Unit { uint64_t a, b; uint32_t d; };
+  auto unit_of = [&](uint32_t t) -> Unit {
+    Unit u{0, 0, 0};
+    if(t < n_tiles) { u.a = off[(size_t)t << sh]; u.b = off[((size_t)t << sh) + 1]; u.d = T.dirty[tile0 + t]; }
+    return u;
+  };
+  u128 cur[NPW];
+  auto fetch = [&](uint64_t c, uint64_t b) {                           // items src[c .. min(b, c + kRound)): clamped indices, no branch per item
+    if(b <= c) return;                                                 // (block-uniform)
+    const uint32_t n = (uint32_t)((b - c) < kRound ? (b - c) : kRound);
+    const u128* ub = src + c;
+    uint32_t tid = threadIdx.x;
+    JF_OPAQUE(tid);
+#pragma unroll
+    for(int r = 0; r < NPW; ++r) { const uint32_t i = (uint32_t)r * kPBlock + tid; cur[r] = ub[i < n ? i : n - 1]; }
+  };
+  for(uint32_t i = threadIdx.x * 2; i < words; i += blockDim.x * 2) *reinterpret_cast<ulonglong2*>(s_tile + i) = make_ulonglong2(0ull, 0ull);
+  uint32_t t = blockIdx.x;
+  Unit u0 = unit_of(t), u1 = unit_of(t + G);
+  while(t < n_tiles && u0.b <= u0.a) { t += G; u0 = u1; u1 = unit_of(t + G); }      // (block-uniform) units without items
+  uint64_t c0 = u0.a;
+#pragma unroll
+  for(int r = 0; r < NPW; ++r) cur[r] = hole;
+  if(t < n_tiles) fetch(c0, u0.b);
+  lds_barrier();
+  [[maybe_unused]] PhaseClk pc;
+  while(t < n_tiles) {
+    const bool first = c0 == u0.a, last = c0 + kRound >= u0.b;
+    // the chunk after this one: the unit's next round, or the first round of the next unit that has items
+    uint32_t tn = t; Unit un = u0, un1 = u1; uint64_t cn = c0 + kRound;
+    if(last) {
+      tn = t + G; un = u1; un1 = unit_of(tn + G);
+      while(tn < n_tiles && un.b <= un.a) { tn += G; un = un1; un1 = unit_of(tn + G); }
+      cn = un.a;
+    }
+    uint64_t* gt = T.slots + ((tile0 + t) << (g.tile_bits + 1));
+    // a further round of a unit starts from the tile as the previous round stored it
+    if(first ? u0.d != 0 : true) {
+      for(uint32_t i = threadIdx.x * 2; i < words; i += blockDim.x * 2)
+        *reinterpret_cast<ulonglong2*>(s_tile + i) = *reinterpret_cast<const ulonglong2*>(gt + i);
+      lds_barrier();
+    }
+    const uint32_t n0 = (uint32_t)((u0.b - c0) < kRound ? (u0.b - c0) : kRound);
+    JF_PHASE(pc, 1);
+    // The claims, one item after the other.  Measured and dropped in round 5 (profiles/r05_c5_tile_experiments.log): the first
+    // probe of all eight items together + a queue for the rest (91.6 ms: the queue's items are read again from memory), all
+    // probes of all items in lock step (154 ms: eight items x four predicated passes per step), a per-lane state machine
+    // issuing one atomic a step (128 ms: the 128-bit tag arithmetic of every step), a plain look before each compare-and-
+    // swap (71.3 ms).  The phase clocks say the claims are 48 % of this kernel and the waves' wait for each other at the
+    // barrier behind them 39 %; what removes them is placement by rank (kernels_tile.hip.hpp), which needs the bucketed
+    // probe sequence in every two-word kernel -- not built.
+#pragma unroll
+    for(int r = 0; r < NPW; ++r)
+      if((uint32_t)r * kPBlock + threadIdx.x < n0 && !(holes && cur[r] == hole)) tile_insert_wide_one<RETURNING>(T, s_tile, cur[r], tile0 + t);
+    JF_PHASE(pc, 2);
+    // cur[] is dead: the next chunk's items travel during the store
+    if(tn < n_tiles) fetch(cn, un.b);
+    lds_barrier();
+    JF_PHASE(pc, 3);
+    for(uint32_t i = threadIdx.x * 2; i < words; i += blockDim.x * 2) {
+      *reinterpret_cast<ulonglong2*>(gt + i) = *reinterpret_cast<const ulonglong2*>(s_tile + i);
+      *reinterpret_cast<ulonglong2*>(s_tile + i) = make_ulonglong2(0ull, 0ull);            // the next unit starts from an empty tile
+    }
+    if(threadIdx.x == 0) T.dirty[tile0 + t] = 1;
+    lds_barrier();
+    JF_PHASE(pc, 4);
+    t = tn; u0 = un; u1 = un1; c0 = cn;
+  }
+  JF_PHASE_FLUSH(pc, 16);
 }
 
 // Too few items to be worth streaming the tiles: pending granule batches inserted with global atomics.

@@ -1,4 +1,5 @@
-// jellyfish_amd/csrc/tuning.hpp -- every JFGPU_* environment switch of the engine, read in ONE place.
+// jellyfish_amd/csrc/tuning.hpp -- every JFGPU_* environment switch of the ENGINE LIBRARY (libjfgpu.so), read in ONE place
+// (the CLI and the facade headers above the C ABI read their own few where they use them: INTEGRATION.md lists both).
 //
 // The switches are A/B and test knobs (nothing a user of the reference's CLI needs): which insert path, the head-room of
 // the partition regions, forcing rare code paths so that the parity tests reach them.  An object (table, Bloom counter,
@@ -28,7 +29,8 @@ struct Tuning {
   uint32_t flush_share = 0;      // JFGPU_FLUSH_SHARE      force a flush into this many bucket groups sharing one P2 buffer (tests)
   bool flush_trace = false;      // JFGPU_FLUSH_TRACE      one stderr line per flush
   int p2_ring = 1;               // JFGPU_P2_RING          single-pass P2 of 4-byte items through per-destination rings (0: the sort-based kernel, 3: never the loader / storer kernel; A/B)
-  int p2_depth = 2;              // JFGPU_P2_DEPTH         rounds of items the loader waves of p2_ring_roles_kernel keep in flight (1, 2 or 3; A/B)
+  bool wide_pipe = true;        // JFGPU_WIDE_PIPE=0      two-word keys: the round-2 tile kernel instead of the pipelined one (A/B)
+  int p2_depth = 3;              // JFGPU_P2_DEPTH         rounds of items the loader waves of p2_ring_roles_kernel keep in flight (1, 2 or 3: 19.5 / 19.25 / 19.1 ms on the metric's job; A/B)
   int bloom_cache = -1;          // JFGPU_BLOOM_CACHE      count --bc: remember admitted k-mers (-1: when the first batches admit > 15 % of their windows, 0 never, 1 always)
   uint32_t bloom_cache_log2 = 28;// JFGPU_BLOOM_CACHE_LOG2 two-way sets of that cache (2^28 sets = 4 GB; tests: tiny caches evict all the time)
   // ---- Bloom counters (jfgpu_bloom_create)
@@ -58,6 +60,7 @@ struct Tuning {
     if(const char* e = str("JFGPU_FLUSH_SHARE")) u.flush_share = (uint32_t)atoi(e);
     u.flush_trace = str("JFGPU_FLUSH_TRACE") != nullptr;
     if(const char* e = str("JFGPU_P2_RING")) u.p2_ring = atoi(e);
+    if(const char* e = str("JFGPU_WIDE_PIPE")) u.wide_pipe = atoi(e) != 0;
     if(const char* e = str("JFGPU_P2_DEPTH")) u.p2_depth = std::min(3, std::max(1, atoi(e)));
     if(const char* e = str("JFGPU_BLOOM_CACHE")) u.bloom_cache = atoi(e);
     if(const char* e = str("JFGPU_BLOOM_CACHE_LOG2")) u.bloom_cache_log2 = (uint32_t)std::min(30, std::max(2, atoi(e)));

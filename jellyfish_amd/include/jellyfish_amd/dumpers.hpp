@@ -8,7 +8,10 @@
 // The (pos, key) sort the reference does with a per-thread min-heap happens on
 // the GPU, tile by tile (jfgpu_dump_next); the host only streams bytes to the file.
 #pragma once
+#include <errno.h>
 #include <fcntl.h>
+#include <stdio.h>
+#include <string.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -101,7 +104,12 @@ public:
       out.close();
       // the body's size is known (fixed-width records, counted by jfgpu_dump_begin): the file is sized now, every rank and every
       // writer thread then fills its own part of it
-      if(::truncate(path.c_str(), body + (off_t)(all_records * rec)) != 0 && comm) { jfgpu_dump_end(ary->handle()); throw ErrorWriting("Can't size '" + path + "'"); }
+      if(::truncate(path.c_str(), body + (off_t)(all_records * rec)) != 0) {
+        // ranks write at offsets of a file sized here: without it they cannot; a single writer only loses the pre-size
+        if(comm) { jfgpu_dump_end(ary->handle()); throw ErrorWriting("Can't size '" + path + "'"); }
+        static bool said = false;
+        if(!said) { said = true; fprintf(stderr, "jellyfish-amd: could not pre-size '%s' (%s): writing without\n", path.c_str(), strerror(errno)); }
+      }
     }
     if(comm) {                                                 // where the body starts; also: the file exists from here on
       std::vector<uint64_t> bodies(world);
