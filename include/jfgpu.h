@@ -243,6 +243,14 @@ int  jfgpu_bc_profile_reset(jfgpu_bloom* b);
 /* count --bc: from now on jfgpu_count_* admits a k-mer only if check(m) > 1 (count_main.cc:115-118).
  * b == NULL detaches.  The Bloom counter must outlive its use. */
 int  jfgpu_attach_bloom(jfgpu_table* t, jfgpu_bloom* b);
+/* `jellyfish bc` with the input split between the GPUs (sub_commands/bc_main.cc:84-161, mer_bloom_counter::start :67-71 per
+ * rank): every rank creates the same counter (jfgpu_bc_create with the same parameters: same size, same matrices), inserts
+ * ITS part of the input, and calls this -- collective.  On return every rank's counter is the counter of the whole input,
+ * byte for byte what one counter fed with everything holds (cells saturate at 2 and increments commute,
+ * bloom_counter2.hpp:56-107): rank 0 writes the file, `count --bc --gpus` asks it on every rank.  jfgpu_bc_sync then
+ * reports the k-mers of all ranks.  _local: the counters of all ranks of a local communicator, in rank order. */
+int  jfgpu_comm_bc_merge(jfgpu_comm* c, jfgpu_bloom* b);
+int  jfgpu_comm_bc_merge_local(jfgpu_comm* c, jfgpu_bloom** blooms);
 
 /* hash_counter::do_size_doubling(bool) (hash_counter.hpp:78-79).  On (default): the size given at
  * creation is a hint, the table doubles itself (device-side rehash, one more matrix row) before it

@@ -108,6 +108,8 @@ SIGNATURES = {
     "jfgpu_bc_profile_get": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "jfgpu_bc_profile_reset": (C.c_int, [_P]),
     "jfgpu_attach_bloom": (C.c_int, [_P, _P]),
+    "jfgpu_comm_bc_merge": (C.c_int, [_P, _P]),
+    "jfgpu_comm_bc_merge_local": (C.c_int, [_P, C.POINTER(_P)]),
     "jfgpu_parser_create": (C.c_int, [C.c_int, C.c_uint32, C.POINTER(_P)]),
     "jfgpu_parser_destroy": (None, [_P]),
     "jfgpu_parser_parse_dev": (C.c_int, [_P, _P, C.c_size_t, C.c_uint, C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
@@ -439,6 +441,15 @@ class Comm:
         a = np.array(values, dtype=np.uint64)
         _check(self._lib.jfgpu_comm_allreduce_u64(self._h, a.ctypes.data, len(a), {"sum": 0, "max": 1}[op]))
         return a.tolist()
+
+    def bc_merge(self, blooms):
+        """jfgpu_comm_bc_merge(_local): the ranks' Bloom counters (one here, or all W of a local communicator, in rank order)
+        become the counter of the whole input on every rank."""
+        if self.local:
+            arr = (_P * self.world)(*[b._h for b in blooms])
+            _check(self._lib.jfgpu_comm_bc_merge_local(self._h, arr))
+        else:
+            _check(self._lib.jfgpu_comm_bc_merge(self._h, blooms._h))
 
     def allgather(self, mine):
         a = np.zeros(self.world, dtype=np.uint64)

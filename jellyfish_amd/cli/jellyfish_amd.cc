@@ -652,6 +652,7 @@ int bc_main(int argc, char* argv[]) {
   header.set_cmdline(argc, argv);
   unsigned mer_len = 0; uint64_t size = 0; double fpr = 0.001; bool canonical = false, size_given = false, host_parse = false;
   int device = -1;
+  unsigned gpus = 1; bool gpus_given = false;
   std::string output = "mer_bloom_filter", timing, generator, shell;
   std::vector<std::string> files;
   ArgCursor a{argc, argv};
@@ -664,6 +665,7 @@ int bc_main(int argc, char* argv[]) {
     else if(a.is("-o", "--output")) output = a.value("-o", "--output");
     else if(a.is("", "--timing")) timing = a.value("", "--timing");
     else if(a.is("", "--device")) device = atoi(a.value("", "--device").c_str());
+    else if(a.is("", "--gpus")) { gpus = (unsigned)strtoul(a.value("", "--gpus").c_str(), 0, 10); gpus_given = true; }
     else if(a.cur() == "-C" || a.cur() == "--canonical") canonical = true;
     else if(a.cur() == "--host-parse") host_parse = true;
     else if(a.is("-g", "--generator")) generator = a.value("-g", "--generator");
@@ -676,10 +678,25 @@ int bc_main(int argc, char* argv[]) {
   if(!size_given) die("Error: mandatory switch missing: -s, --size");
   if(files.empty() && generator.empty()) die("Error: at least 1 file argument is required");
   if(mer_len > 64) die("jellyfish-amd: Bloom counters for mer length > 64 are not built");
+  // --gpus N (like count --gpus N: this process starts the ranks, or is one): every rank inserts its part of every file into
+  // its own counter, the counters are merged on the devices (jfgpu_comm_bc_merge) and rank 0 writes the file
+  rank_env renv;
+  if(gpus_given) {
+    if(gpus < 1 || (gpus & (gpus - 1)) || gpus > 256) die("--gpus must be a power of two");
+    if(host_parse || !generator.empty()) die("--gpus cannot be combined with --host-parse or -g yet");
+    renv = read_rank_env();
+    if(!renv.is_rank) return spawn_ranks(gpus, argv);
+    if(renv.world != (int)gpus || renv.rank < 0 || renv.rank >= renv.world) die("--gpus does not match the ranks' environment (WORLD_SIZE / RANK)");
+    if(renv.rendezvous.empty()) die("--gpus under an external launcher: set JFGPU_RENDEZVOUS to a directory all ranks see");
+    if(device < 0) device = renv.local_rank;
+    { const char* tr = getenv("JFGPU_COMM_TRANSPORT");
+      if(tr && !strcmp(tr, "ipc")) { const int nd = jfgpu_device_count(); if(nd > 0) device %= nd; } }
+  }
+  const bool writer = renv.rank == 0;
   mer_dna::k(mer_len);
   header.canonical(canonical);
-  std::ofstream out(output, std::ios::binary | std::ios::trunc);
-  if(!out.good()) die("Can't open output file '" + output + "'");
+  std::ofstream out;
+  if(writer) { out.open(output, std::ios::binary | std::ios::trunc); if(!out.good()) die("Can't open output file '" + output + "'"); }
   jfgpu_bloom_params bp;
   memset(&bp, 0, sizeof bp);
   bp.k = mer_len; bp.canonical = canonical; bp.device = device;
@@ -696,7 +713,14 @@ int bc_main(int argc, char* argv[]) {
   header.matrix(m2, 2);
   header.size(m);
   header.nb_hashes(nh);
-  header.write(out);
+  if(writer) header.write(out);
+  jfgpu_comm* comm = nullptr;
+  if(gpus_given) {
+    uint8_t id[128];
+    exchange_unique_id(renv, id);
+    if(jfgpu_comm_create(renv.world, renv.rank, id, device, &comm)) die(std::string("Failed to create the communicator: ") + jfgpu_last_error());
+    if(const char* fr = getenv("JFGPU_TEST_FAIL_RANK")) if(atoi(fr) == renv.rank) die("rank told to fail (JFGPU_TEST_FAIL_RANK)");
+  }
   const double init_s = seconds_since(start_time);
   auto count_start = std::chrono::steady_clock::now();
   try {
@@ -707,21 +731,30 @@ int bc_main(int argc, char* argv[]) {
     } else {
       device_sequence_parser parser(mer_len, device);
       for(const auto& f : files)
-        parser.parse_file(f.c_str(),
-                          [&](const char* d_buf, size_t n) { if(jfgpu_bc_insert_ascii_dev(bc, d_buf, n)) throw std::runtime_error(jfgpu_last_error()); },
-                          host_sink, [&]() { if(jfgpu_bc_sync(bc, nullptr)) throw std::runtime_error(jfgpu_last_error()); });
+        parser.parse_file_part(f.c_str(), gpus_given ? (unsigned)renv.rank : 0u, gpus_given ? gpus : 1u,
+                               [&](const char* d_buf, size_t n) { if(jfgpu_bc_insert_ascii_dev(bc, d_buf, n)) throw std::runtime_error(jfgpu_last_error()); },
+                               host_sink, [&]() { if(jfgpu_bc_sync(bc, nullptr)) throw std::runtime_error(jfgpu_last_error()); });
     }
     if(!generator.empty()) feed_generators(generator, shell, mer_len, host_sink);
     if(jfgpu_bc_sync(bc, nullptr)) throw std::runtime_error(jfgpu_last_error());
+    if(comm && jfgpu_comm_bc_merge(comm, bc)) throw std::runtime_error(jfgpu_last_error());      // every rank's counter: the whole input's
   } catch(std::exception& e) { die(e.what()); }
   const double count_s = seconds_since(count_start);
   auto write_start = std::chrono::steady_clock::now();
-  std::vector<uint8_t> body(nbytes);
-  if(jfgpu_bc_read(bc, body.data())) die(jfgpu_last_error());
-  out.write((const char*)body.data(), body.size());
-  out.close();
+  if(writer) {
+    std::vector<uint8_t> body(nbytes);
+    if(jfgpu_bc_read(bc, body.data())) die(jfgpu_last_error());
+    out.write((const char*)body.data(), body.size());
+    out.close();
+    if(!out.good()) die("Error writing '" + output + "'");
+  }
+  if(comm) {
+    uint64_t done = 1;                             // the file is written before anyone reports success
+    if(jfgpu_comm_allreduce_u64(comm, &done, 1, 0)) die(jfgpu_last_error());
+    jfgpu_comm_destroy(comm);
+  }
   jfgpu_bc_destroy(bc);
-  if(!timing.empty()) {
+  if(!timing.empty() && writer) {
     std::ofstream tf(timing);
     tf << "Init     " << init_s << "\n" << "Counting " << count_s << "\n" << "Writing  " << seconds_since(write_start) << "\n";
   }

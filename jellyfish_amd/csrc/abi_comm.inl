@@ -998,6 +998,112 @@ int comm_grow(jfgpu_comm* c) {
   return JFGPU_OK;
 }
 
+extern "C" int jfgpu_comm_allreduce_u64(jfgpu_comm* c, uint64_t* values, int n, int op);
+
+// ---- `jellyfish bc` over several GPUs: the ranks' counters merged ----------------------------------------------------------
+// Every rank inserts ITS part of the input into its own Bloom counter (same size, same matrices).  A cell of the counter
+// of the whole input is min(2, sum of the ranks' cells): the increments commute and saturate at 2 (bloom_counter2.hpp:56-107),
+// so the merged array is byte for byte the array one counter fed with everything holds -- what `bc` writes, what
+// `count --bc` asks.  The merge is two rounds of the key path's exchange (comm_exchange_*: an all-to-all of 64-bit words,
+// whatever the transport): the array is cut into W ranges of words; round one sends range p of every rank to rank p, which
+// adds them digit by digit (reduce-scatter); round two sends the merged range to everybody (all-gather).  Every rank ends
+// up with the whole merged counter -- the filtered count over shards wants exactly that (every rank asks before it routes).
+__device__ __forceinline__ uint32_t bloom_byte_add(uint32_t a, uint32_t b) {     // five base-3 digits a byte, digit-wise min(2, a + b)
+  uint32_t r = 0, w = 1;
+#pragma unroll
+  for(int d = 0; d < 5; ++d) { const uint32_t s = a % 3u + b % 3u; r += (s > 2u ? 2u : s) * w; w *= 3u; a /= 3u; b /= 3u; }
+  return r;
+}
+__global__ __launch_bounds__(kBlock) void bloom_merge_kernel(uint64_t* __restrict__ dst, const uint64_t* __restrict__ src, uint64_t n_words) {
+  for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t a = dst[i], b = src[i];
+    if(b == 0) continue;
+    uint64_t r = 0;
+#pragma unroll
+    for(int k = 0; k < 8; ++k) r |= (uint64_t)bloom_byte_add((uint32_t)(a >> (8 * k)) & 0xFFu, (uint32_t)(b >> (8 * k)) & 0xFFu) << (8 * k);
+    dst[i] = r;
+  }
+}
+
+int comm_exchange_rccl(jfgpu_comm* c); int comm_exchange_local(jfgpu_comm* c); int comm_exchange_ipc(jfgpu_comm* c);
+
+// blooms[q]: the counter of local rank q (RCCL / ipc transport: one; local transport: all W).  Collective.
+int comm_bc_merge(jfgpu_comm* c, jfgpu_bloom** blooms) {
+  const int W = c->world;
+  const size_t nr = c->ranks.size();
+  jfgpu_bloom* b0 = blooms[0];
+  const uint64_t words = (b0->data_bytes + 7) / 8;
+  const uint64_t per = (words + (uint64_t)W - 1) / (uint64_t)W;
+  auto r_lo = [&](int p) { return std::min<uint64_t>(words, (uint64_t)p * per); };
+  auto r_len = [&](int p) { return std::min<uint64_t>(words, (uint64_t)(p + 1) * per) - r_lo(p); };
+  // the exchange keeps its order on the rank's table stream: a stand-in that carries the counter's stream
+  std::vector<std::unique_ptr<jfgpu_table>> shim(nr);
+  std::vector<jfgpu_table*> saved(nr);
+  for(size_t q = 0; q < nr; ++q) {
+    jfgpu_bloom* b = blooms[q];
+    if(!b || b->kind != 0) return fail(JFGPU_E_INVALID, "bc merge: a Bloom counter per rank");
+    if(b->data_bytes != b0->data_bytes || b->nh != b0->nh || b->m != b0->m) return fail(JFGPU_E_INVALID, "bc merge: the ranks' counters differ in size");
+    if(b->alloc_bytes < words * 8) return fail(JFGPU_E_INVALID, "bc merge: counter allocation shorter than its last word");
+    int rc = bloom_flush(b); if(rc) return rc;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    shim[q].reset(new jfgpu_table); shim[q]->stream = b->stream; shim[q]->device = b->device;
+    saved[q] = c->ranks[q].t; c->ranks[q].t = shim[q].get();
+  }
+  auto restore = [&]() { for(size_t q = 0; q < nr; ++q) c->ranks[q].t = saved[q]; };
+  auto exchange = [&]() { return c->local ? comm_exchange_local(c) : c->ipc ? comm_exchange_ipc(c) : comm_exchange_rccl(c); };
+  auto rank_of = [&](size_t q) { return c->local ? (int)q : c->rank; };
+  int rc = JFGPU_OK;
+  // round one: range p of my array goes to rank p
+  for(size_t q = 0; q < nr && !rc; ++q) {
+    jfgpu_comm::Rank& R = c->ranks[q]; jfgpu_bloom* b = blooms[q];
+    if(R.inflight) { restore(); return fail(JFGPU_E_INVALID, "bc merge: a count step is still in flight on this communicator"); }
+    R.turn = 0;
+    rc = comm_reserve(R.send[0], R.send_cap[0], std::max<uint64_t>(words, 1), b->stream, c->xstream); if(rc) break;
+    if(hipMemcpyAsync(R.send[0], b->d_data, words * 8, hipMemcpyDeviceToDevice, b->stream) != hipSuccess) { rc = fail(JFGPU_E_HIP, "bc merge: copy"); break; }
+    for(int p = 0; p < W; ++p) { R.scount[0][p] = r_len(p); R.soff[0][p] = r_lo(p); }
+    R.soff[0][W] = words;
+  }
+  if(!rc) rc = exchange();
+  for(size_t q = 0; q < nr && !rc; ++q) {
+    jfgpu_comm::Rank& R = c->ranks[q]; jfgpu_bloom* b = blooms[q];
+    const int me = rank_of(q);
+    const uint64_t n = r_len(me);
+    uint64_t* mine = reinterpret_cast<uint64_t*>(b->d_data) + r_lo(me);
+    if(hipStreamWaitEvent(b->stream, R.exchanged[0], 0) != hipSuccess) { rc = fail(JFGPU_E_HIP, "bc merge: event"); break; }
+    if(n) {
+      (void)hipMemsetAsync(mine, 0, n * 8, b->stream);
+      const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((n + kBlock - 1) / kBlock, (uint64_t)b->n_cu * 8));
+      for(int p = 0; p < W; ++p) hipLaunchKernelGGL(bloom_merge_kernel, dim3(grid), dim3(kBlock), 0, b->stream, mine, (const uint64_t*)R.recv[0] + R.roff[0][p], n);
+    }
+    (void)hipEventRecord(R.consumed[0], b->stream);
+    // round two: my merged range to everybody
+    R.turn = 1;
+    rc = comm_reserve(R.send[1], R.send_cap[1], std::max<uint64_t>(n, 1), b->stream, c->xstream); if(rc) break;
+    if(n && hipMemcpyAsync(R.send[1], mine, n * 8, hipMemcpyDeviceToDevice, b->stream) != hipSuccess) { rc = fail(JFGPU_E_HIP, "bc merge: copy"); break; }
+    for(int p = 0; p < W; ++p) { R.scount[1][p] = n; R.soff[1][p] = 0; }
+    R.soff[1][W] = n;
+  }
+  if(!rc) rc = exchange();
+  unsigned long long mers_sum = 0;
+  for(size_t q = 0; q < nr && !rc; ++q) {
+    jfgpu_comm::Rank& R = c->ranks[q]; jfgpu_bloom* b = blooms[q];
+    if(hipStreamWaitEvent(b->stream, R.exchanged[1], 0) != hipSuccess) { rc = fail(JFGPU_E_HIP, "bc merge: event"); break; }
+    for(int p = 0; p < W; ++p)
+      if(R.rcount[1][p]) (void)hipMemcpyAsync(reinterpret_cast<uint64_t*>(b->d_data) + r_lo(p), R.recv[1] + R.roff[1][p], R.rcount[1][p] * 8, hipMemcpyDeviceToDevice, b->stream);
+    (void)hipEventRecord(R.consumed[1], b->stream);
+    unsigned long long m = 0;
+    if(hipMemcpyAsync(&m, b->d_mers, sizeof m, hipMemcpyDeviceToHost, b->stream) != hipSuccess || hipStreamSynchronize(b->stream) != hipSuccess) { rc = fail(JFGPU_E_HIP, "bc merge: sync"); break; }
+    mers_sum += m;
+    R.turn = 0;
+  }
+  restore();
+  if(rc) return rc;
+  // the k-mer tally of the whole input (jfgpu_bc_sync reports it)
+  if(!c->local) { uint64_t v = mers_sum; rc = jfgpu_comm_allreduce_u64(c, &v, 1, 0); if(rc) return rc; mers_sum = v; }
+  for(size_t q = 0; q < nr; ++q) HIP_TRY(hipMemcpy(blooms[q]->d_mers, &mers_sum, sizeof mers_sum, hipMemcpyHostToDevice));
+  return JFGPU_OK;
+}
+
 void comm_free_rank(jfgpu_comm::Rank& R) {
   for(int i = 0; i < 2; ++i) {
     if(R.send[i]) hipFree(R.send[i]);
@@ -1319,6 +1425,23 @@ int jfgpu_comm_allgather_u64(jfgpu_comm* c, uint64_t mine, uint64_t* all) {
   HIP_TRY(hipStreamSynchronize(c->xstream));
   return JFGPU_OK;
 #endif
+}
+
+// `jellyfish bc` over the ranks of a communicator (bc_main.cc:84-161 with the input split between the GPUs): collective,
+// after every rank has inserted its part; on return every rank's counter holds the counter of the whole input (comm_bc_merge).
+int jfgpu_comm_bc_merge(jfgpu_comm* c, jfgpu_bloom* b) {
+  if(!c || c->local) return fail(JFGPU_E_INVALID, "not an RCCL communicator");
+  if(!b) return fail(JFGPU_E_INVALID, "null bloom counter");
+  HIP_TRY(hipSetDevice(c->device));
+  if(b->device != c->device) return fail(JFGPU_E_INVALID, "Bloom counter lives on another device");
+  return comm_bc_merge(c, &b);
+}
+int jfgpu_comm_bc_merge_local(jfgpu_comm* c, jfgpu_bloom** blooms) {
+  if(!c || !c->local) return fail(JFGPU_E_INVALID, "not a local communicator");
+  if(!blooms) return fail(JFGPU_E_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(c->device));
+  for(int r = 0; r < c->world; ++r) if(!blooms[r]) return fail(JFGPU_E_INVALID, "null bloom counter");
+  return comm_bc_merge(c, blooms);
 }
 
 int jfgpu_comm_world(const jfgpu_comm* c, int* world, int* rank) {

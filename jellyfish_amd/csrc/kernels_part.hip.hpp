@@ -62,7 +62,10 @@ struct SegList {
 __device__ inline uint64_t seg_lo(const SegList& S, uint32_t s, uint32_t j) { return S.off[s][(size_t)j << S.sh[s]]; }
 __device__ inline uint64_t seg_hi(const SegList& S, uint32_t s, uint32_t j) { return S.off[s][((size_t)j << S.sh[s]) + 1]; }
 
-constexpr uint32_t kGran = 64;                // items per reservation of the single-pass P1
+#ifndef JFGPU_KGRAN
+#define JFGPU_KGRAN 64
+#endif
+constexpr uint32_t kGran = JFGPU_KGRAN;       // items per reservation of the single-pass P1
 
 template <typename ITEM>
 __device__ inline ITEM make_item(const TableGeom& g, const PartGeom& P, uint64_t key, uint64_t local) {
@@ -934,7 +937,10 @@ __global__ __launch_bounds__(kPBlock) void p2_granule_kernel(DIRECT D, uint32_t 
   // set of registers before the current one is ranked -- with unconditional loads when the chunk lies inside one batch's
   // region (nearly always), so that the compiler can count them instead of waiting on the spot.  (For 4-byte items the
   // same was measured in round 4 without gain: there the five barriers of a chunk are the cost.)
-  constexpr bool PF = sizeof(ITEM) == 16;
+#ifndef JFGPU_PF_MIN
+#define JFGPU_PF_MIN 16
+#endif
+  constexpr bool PF = sizeof(ITEM) >= JFGPU_PF_MIN;
   ITEM nx[PF ? PER_THREAD : 1];
   [[maybe_unused]] uint32_t nvm = 0, nhm = 0;
   auto load_chunk_pf = [&](uint64_t c0, ITEM (&x)[PER_THREAD], uint32_t& vm, uint32_t& hm) {

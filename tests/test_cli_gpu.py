@@ -397,6 +397,27 @@ def test_bc_file_is_byte_identical_to_the_reference(cli, tmp_path, case):
     assert _body(out) == _body(os.path.join(GOLD, case["ref_bc"]))
 
 
+@pytest.mark.parametrize("world", [1, 2, 4])
+@pytest.mark.parametrize("case", MANIFEST["bloom"], ids=lambda c: c["name"])
+def test_bc_gpus_n_file_is_byte_identical_to_the_reference(cli, tmp_path, case, world):
+    """`jellyfish-amd bc --gpus 2 / 4` (sub_commands/bc_main.cc:84-161 with the input split between the GPUs): rank
+    processes -- on this box's one GPU over the inter-process transport -- each insert their part of the file into their
+    own counter, the counters are merged on the device (jfgpu_comm_bc_merge: cells saturate at 2 and increments commute,
+    bloom_counter2.hpp:56-107) and rank 0 writes the file: its body must be the REFERENCE's golden file's, byte for byte,
+    and `count --bc` through it must give the golden filtered dump.  World 1: the RCCL transport itself, the rank's
+    own share sent through ncclSend / ncclRecv (JFGPU_COMM_SELF_RCCL=1) -- every RCCL call an N-rank merge makes."""
+    out = str(tmp_path / "out.bc")
+    env = dict(os.environ, JFGPU_PARSE_CHUNK="100000", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.update({"JFGPU_COMM_SELF_RCCL": "1"} if world == 1 else {"JFGPU_COMM_TRANSPORT": "ipc"})
+    cmd = [cli, "bc", "-m", str(case["k"]), "-s", str(case["n"]), "-f", str(case["fpr"]), "-o", out, "--gpus", str(world)] + (["-C"] if case["canonical"] else [])
+    subprocess.check_call(cmd + [os.path.join(GOLD, case["input"])], env=env, timeout=900)
+    assert _body(out) == _body(os.path.join(GOLD, case["ref_bc"]))
+    jf = str(tmp_path / "f.jf")
+    subprocess.check_call([cli, "count", "-m", str(case["k"]), "-s", "64k", "--bc", out, "-o", jf] + (["-C"] if case["canonical"] else []) + [os.path.join(GOLD, case["input"])])
+    got = sorted(subprocess.check_output([cli, "dump", "-c", jf]).decode().splitlines())
+    assert got == open(os.path.join(GOLD, case["name"] + ".filtered.dump")).read().splitlines()
+
+
 def test_cli_reproduces_the_reference_golden_md5s(cli, tmp_path):
     """The reference's own integration goldens (tests/parallel_hashing.sh:7-19) on its own seeded inputs
     (tests/generate_sequence.sh:6-7, generated here by the reference's generator built in oracle/_ref),

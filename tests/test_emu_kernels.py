@@ -38,6 +38,7 @@ SELECTION = [
     "tests/test_gpu_parity.py::test_prime_and_update_over_shards[2]",
     "tests/test_gpu_bloom.py::test_sharded_count_with_a_bloom_counter_equals_the_single_table[21-2-2]",
     "tests/test_gpu_bloom.py::test_count_bc_with_the_cache_of_admitted_kmers[bc_k21C-2]",
+    "tests/test_gpu_bloom.py::test_bloom_counters_of_the_ranks_merge_into_the_counter_of_the_whole_input[2]",
 ]
 
 

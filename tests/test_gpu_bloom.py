@@ -355,6 +355,47 @@ def test_sharded_count_with_a_bloom_counter_equals_the_single_table(gpu, monkeyp
                 t.close()
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_bloom_counters_of_the_ranks_merge_into_the_counter_of_the_whole_input(gpu, world):
+    """`bc` over several GPUs (jfgpu_comm_bc_merge_local: all ranks in this process, device copies as the transport; the
+    same code as the RCCL / ipc transports' jfgpu_comm_bc_merge): every rank inserts its part of the input into its own
+    counter, the merge makes every counter the counter of the WHOLE input -- checked against the oracle's insert__
+    (bloom_counter2.hpp:56-107) fed with everything in order: k-mers seen once on two ranks read 2, seen twice on one and
+    once on another still 2 (saturation), and the k-mer tally is the sum."""
+    rng = random.Random(91 + world)
+    k = 25
+    shared = "".join(rng.choice("ACGT") for _ in range(4000))            # on every rank: cells reach 2 by addition
+    parts = []
+    for r in range(world):
+        own = "".join(rng.choice("ACGTN") for _ in range(30000))
+        parts.append((own + "N" + shared + ("N" + shared if r == 1 else "")).encode())      # (rank 1 has it twice: 2 + 1 saturates)
+    whole = b"N".join(parts)
+    n = 60000
+    m, nh = gpu.opt_m(0.001, n), gpu.opt_k(0.001)
+    comm = gpu.Comm(world, local=True)
+    blooms = [gpu.Bloom(k, m, nh, canonical=True, seed=5) for _ in range(world)]
+    try:
+        for b, p in zip(blooms, parts):
+            b.insert_ascii(p)
+        comm.bc_merge(blooms)
+        kmers = O.extract(whole, k, True)
+        h0 = O.matrix_times(blooms[0].matrix1, 64, 2 * k, kmers)
+        h1 = O.matrix_times(blooms[0].matrix2, 64, 2 * k, kmers)
+        data = np.zeros(blooms[0].nb_bytes, dtype=np.uint8)
+        L = O.lib()
+        for x, y in zip(h0.tolist(), h1.tolist()):
+            L.jfo_bc_insert(data.ctypes.data, m, nh, x, y)
+        for b in blooms:
+            assert (b.read() == data).all()
+            assert b.sync() == len(kmers)
+        ks, _ = O.count(shared.encode(), k, True)
+        assert (blooms[world - 1].keys(ks[:, 0]) == 2).all()
+    finally:
+        comm.close()
+        for b in blooms:
+            b.close()
+
+
 def np_matrix_times(cols, r, c, keys):
     """pos = M * key over GF(2) for an array of one-word keys, vectorised: M's images of the key's bytes from the oracle's
     matrix_times on the unit vectors (rectangular_binary_matrix.hpp:155-164 through oracle/jf_oracle.c), xor-combined."""
