@@ -228,7 +228,7 @@ __global__ __launch_bounds__(kPBlock) void p1_ring_kernel(DevTable T, DIRECT D, 
   JF_DYN_LDS(s_dyn);
   ITEM* s_ring = reinterpret_cast<ITEM*>(s_dyn);                    // [nb][R::kSlots], then 128 bytes of dump slots
   __shared__ uint64_t s_fwd[8 * 256];
-  __shared__ uint32_t s_fill[kGranMaxB];
+  __shared__ uint32_t s_fill[kGranMaxB + 32];                      // (+ 32 spare words: where positions without a k-mer append)
   __shared__ uint32_t s_nstrag;
   __shared__ uint32_t s_codes[kPBlock + 2];
   __shared__ uint32_t s_inv[kPBlock + 2];
@@ -289,14 +289,21 @@ __global__ __launch_bounds__(kPBlock) void p1_ring_kernel(DevTable T, DIRECT D, 
       uint32_t ea[NE], eo[NE]; ITEM ei[NE];
 #pragma unroll
       for(int e = 0; e < NE; ++e) { ea[e] = dump; ei[e] = 0; eo[e] = 0; }
-      auto emit = [&](int e, uint64_t key, uint32_t cnt) {
+      // No branch around a position's hash and append (round 5: 35.4 -> 33.4 ms; with `if(k-mer to emit) { hash, append }` per
+      // position the compiler kept eight separate blocks, each waiting for its own table reads): a position without a k-mer
+      // to emit hashes whatever its registers hold and appends to one of 32 spare fill words behind the buckets'; its store
+      // goes to the dump slots.
+      auto emit = [&](int e, uint64_t key, uint32_t cnt, bool on) {
         const uint64_t pos = hash_tables_t<NB>(s_fwd, key, g.nbytes);
         const uint32_t b = (uint32_t)(pos >> bshift) & (nb - 1);
         ITEM item;
         if constexpr(sizeof(ITEM) == 4) item = (((uint32_t)pos & rest_mask) << g.rem_bits) | (uint32_t)(key >> g.lsize_g);      // (lsize_g <= 2k <= 42)
         else item = make_item<ITEM>(g, P, key, pos & g.local_mask);
-        if(item == hole || cnt > 1) straggler(b, item, cnt);         // (it would read as a hole; a run goes in at once)
-        else { ea[e] = b * R::kSlots; ei[e] = item; eo[e] = atomicAdd(&s_fill[b], 1u); }
+        const bool special = on && (item == hole || cnt > 1);        // (it would read as a hole; a run goes in at once)
+        const bool normal = on && !special;
+        if(special) straggler(b, item, cnt);                          // (rare; putting these off to one place after the round cost nine registers and 1.6 ms)
+        const uint32_t o = atomicAdd(&s_fill[normal ? b : nb + (lane & 31u)], 1u);
+        ea[e] = normal ? b * R::kSlots : dump; ei[e] = item; eo[e] = normal ? o : 0u;
       };
 #pragma unroll
       for(int e = 0; e < RP; ++e) {
@@ -315,11 +322,11 @@ __global__ __launch_bounds__(kPBlock) void p1_ring_kernel(DevTable T, DIRECT D, 
         const uint32_t v = vmask & (1u << (15 - j));
         const uint64_t key = ((CANON == 1 || (CANON == 2 && g.canonical)) && rc < fw) ? rc : fw;
         const bool same = v && pv && key == pk;
-        if(pv && !same) emit(e, pk, run);
+        emit(e, pk, run, pv && !same);
         run = same ? run + 1 : 1;
         pk = key; pv = v;
       }
-      if(j0 + RP >= kPerLane) { if(pv) emit(NE - 1, pk, run); pv = 0; }
+      if(j0 + RP >= kPerLane) { emit(NE - 1, pk, run, pv != 0); pv = 0; }
       // second sweep: the ring stores, once the fill adds are back (not one wait per item), without a branch per item
       uint32_t ghosts = 0;
 #pragma unroll
