@@ -50,7 +50,12 @@ if [ $PHASE = recheck ]; then
   t=$(date +%s%N); $CLI count -m 63 -C -s $SIZE63 --no-write --digest $OUT/gpu_c5.digest --timing $OUT/gpu_c5.timing reads.fa; echo "gpu_c5_wall_ms $(ms $t)" >> $OUT/timing.txt
   t=$(date +%s%N); $CLI bc -m 31 -C -s $BASES -o gpu.bc --timing $OUT/gpu_c3_bc.timing reads.fa; echo "gpu_c3_bc_wall_ms $(ms $t)" >> $OUT/timing.txt
   t=$(date +%s%N); $CLI count -m 31 -C -s $SIZE63 --bc gpu.bc --no-write --digest $OUT/gpu_c3.digest --timing $OUT/gpu_c3.timing reads.fa; echo "gpu_c3_count_wall_ms $(ms $t)" >> $OUT/timing.txt
+  # round 5: the same Bloom pass through `bc --gpus 1` with the rank's own share sent through RCCL (every ncclSend / ncclRecv an
+  # N-rank merge makes, 28 GB in rounds of 1 GiB): the file body must be the single-process one's
+  t=$(date +%s%N); JFGPU_COMM_SELF_RCCL=1 $CLI bc -m 31 -C -s $BASES -o gpu1.bc --gpus 1 reads.fa 2> $OUT/bc_gpus1.err; echo "gpu_c3_bc_gpus1_wall_ms $(ms $t)" >> $OUT/timing.txt
+  o0=$(( 9 + 10#$(head -c 9 gpu.bc) )); o1=$(( 9 + 10#$(head -c 9 gpu1.bc 2>/dev/null || echo 0) ))
   {
+    if [ -s gpu1.bc ] && cmp -s -i $o0:$o1 gpu.bc gpu1.bc; then echo "bc --gpus 1 (merge through RCCL): body byte-identical to the single-process file ($(( $(stat -c %s gpu.bc) - o0 )) bytes)"; else echo "bc --gpus 1: body DIFFERENT or missing"; grep -v "RCCL\|rccl" $OUT/bc_gpus1.err | tail -5; fi
     for c in c2 c5 c3; do
       if cmp -s $G/ref_$c.digest $OUT/gpu_$c.digest; then echo "$c digest EQUAL to the reference's (tests/golden/at_scale): $(tr '\n' ' ' < $OUT/gpu_$c.digest)"; else echo "$c digest DIFFERENT"; echo " ref: $(tr '\n' ' ' < $G/ref_$c.digest)"; echo " gpu: $(tr '\n' ' ' < $OUT/gpu_$c.digest)"; fi
     done

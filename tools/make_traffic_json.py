@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """<tag>_{fetch,write}.csv (tools/rocpd_pmc.py output of the FETCH_SIZE / WRITE_SIZE passes of tools/profile_bench.sh)
--> profiles/r04_traffic_<cfg>.json: HBM bytes per job of every stage bench.py names, the figures its `roofline.traffic`
+-> profiles/r05_traffic_<cfg>.json: HBM bytes per job of every stage bench.py names, the figures its `roofline.traffic`
 quotes.  The profiled command runs exactly one job (--warmup 0 --repeats 1), so sums over the run are per-job sums.
 Corrections per MI355X_MICROARCH.md: counters are KB; FETCH_SIZE is doubled for wide coalesced reads; WRITE_SIZE as is.
 usage: make_traffic_json.py <tag path prefix> <C2|C3|C5> <gbp> <lsize> [out.json]"""
@@ -9,7 +9,7 @@ import json
 import sys
 
 tag, cfg, gbp, lsize = sys.argv[1], sys.argv[2], float(sys.argv[3]), int(sys.argv[4])
-out = sys.argv[5] if len(sys.argv) > 5 else "profiles/r04_traffic_%s.json" % cfg
+out = sys.argv[5] if len(sys.argv) > 5 else "profiles/r05_traffic_%s.json" % cfg
 
 
 def load(path, col):
