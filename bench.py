@@ -281,11 +281,31 @@ def plan(args):
     kmers = n_reads * (READ_LEN - K + 1)
     item = 4 if cfg == "C2" else (8 if cfg == "C3" else 16)
     workspace = int(kmers * item * (2.3 if world == 1 else 3.4))       # P1 regions + P2 regions (+ routed regions and what arrived, sharded)
+    exchange = None
+    if world > 1:
+        # What a step puts on the wires (abi_comm.inl: item path).  A rank routes its step's k-mers into 1024 regions of `cap`
+        # 4-byte items -- (owner, the owner's coarse bucket) -- and sends every other owner its 1024 / W regions WHOLE (fixed
+        # capacity: mean x 1.10 for the per-byte estimate x 1.03 head-room + one stranded granule per workgroup and bucket),
+        # one message per peer and step over that peer's own xGMI link; its own share does not move.
+        items_step = kmers / args.steps
+        cap = int(items_step / 1024 * 1.10 * 1.03 + 2 * 256 * 64)
+        send = (world - 1) / world * 1024 * cap * 4
+        per_link = send / (world - 1)
+        link = 76.5e9        # one direction of one xGMI link: the guide's ~153 GB/s per link, halved (an assumption until a run measures it)
+        # one GPU's stage times per Gbp of input through the sharded code path (profiles/r05_final_bench_C2_sharded_path_one_gpu.json)
+        per_gbp_ms = {"route_p1": 3.32, "receive_split": 2.54, "p2_partition": 1.96, "tile_insert": 2.80}
+        exchange = {"items_per_step_per_rank": int(items_step), "region_capacity_items": cap, "item_bytes_per_step_per_rank": int(items_step * 4),
+                    "send_bytes_per_step_per_rank": int(send), "bytes_per_link_per_step": int(per_link), "link_GB_per_s_assumed": link / 1e9,
+                    "exchange_ms_per_step": per_link / link * 1e3,
+                    "compute_ms_per_step_measured_on_one_gpu": {k: v * gbp / args.steps for k, v in per_gbp_ms.items()},
+                    "note": "the exchange of step i runs beside the routing of step i + 1 and the split of step i - 1 (events, own stream): "
+                            "it is hidden while exchange_ms_per_step stays below route_p1 + receive_split of a step"}
     return {"id": cfg if world == 1 else "C4", "world": world, "shard_bits": sb, "k": K, "gbp_per_gpu": gbp, "total_gbp": gbp * world,
             "reads_per_gpu": n_reads, "kmers_per_gpu": kmers, "table_slots_per_gpu": 1 << lsize, "global_table_slots": 1 << (lsize + sb), "slot_bytes": slot_bytes,
             "scaling": "weak", "steps": args.steps, "warmup": args.warmup,
             "launch": "one process per GPU (torch.distributed.run or bench.py's own launcher), RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 from the environment",
             "exchange": None if world == 1 else "jfgpu_comm_count_ascii_dev per step: route by hash prefix, ncclSend / ncclRecv of 4-byte items grouped for the receiver, insert",
+            "exchange_estimate": exchange,
             "hbm_bytes_per_gpu": {"table": table, "reads": reads, "workspace_estimate": workspace, "total_estimate": table + reads + workspace},
             "workload": (CONFIGS[cfg]["name"].format(gbp=gbp, lsize=lsize, slot_bytes=slot_bytes) if world == 1 else
                          C4_NAME.format(total=gbp * world, world=world, gbp=gbp, lsize=lsize, slot_bytes=slot_bytes))}

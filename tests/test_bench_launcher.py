@@ -41,11 +41,17 @@ def test_gpus_8_plan_is_baseline_config_3():
     assert 0.5 < p8["kmers_per_gpu"] / p8["table_slots_per_gpu"] < 0.8          # load factor of a shard
     assert p8["hbm_bytes_per_gpu"]["total_estimate"] < 288e9
     assert "100.0 Gbp" in p8["workload"] and "8 GPUs" in p8["workload"]
+    # what a step puts on every link, and what that costs next to the step's own work (round-4 review, item 5)
+    x = p8["exchange_estimate"]
+    assert x["items_per_step_per_rank"] == p8["kmers_per_gpu"] // 20
+    assert x["send_bytes_per_step_per_rank"] == 7 * x["bytes_per_link_per_step"]
+    assert 1.0 < x["send_bytes_per_step_per_rank"] / (7 / 8 * x["item_bytes_per_step_per_rank"]) < 1.35       # whole regions travel: head-room on the wire
+    assert 0 < x["exchange_ms_per_step"] < sum(x["compute_ms_per_step_measured_on_one_gpu"].values())
     for n in (2, 4):
         pn = _plan("--gpus", str(n))
         assert pn["id"] == "C4" and pn["gbp_per_gpu"] == 12.5 and pn["table_slots_per_gpu"] == 1 << 34 and pn["global_table_slots"] == 1 << (34 + pn["shard_bits"])
     p1 = _plan()
-    assert p1["id"] == "C2" and p1["world"] == 1 and p1["gbp_per_gpu"] == 10.0 and p1["slot_bytes"] == 4 and p1["exchange"] is None
+    assert p1["id"] == "C2" and p1["world"] == 1 and p1["gbp_per_gpu"] == 10.0 and p1["slot_bytes"] == 4 and p1["exchange"] is None and p1["exchange_estimate"] is None
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--plan", "--gpus", "3"], cwd=ROOT, capture_output=True, text=True)
     assert r.returncode != 0 and "power of two" in r.stderr
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--plan", "--gpus", "2", "--config", "C5"], cwd=ROOT, capture_output=True, text=True)
