@@ -43,6 +43,7 @@ __device__ __attribute__((noinline)) void ovf_add_call(uint64_t* ovf_key, uint64
 #define JFGPU_T_BLOCK 512
 #endif
 constexpr int kTileBlock = JFGPU_T_BLOCK;               // threads per workgroup: two workgroups per CU (LDS), 128 registers per lane
+constexpr uint32_t kQueueLook = 2;             // buckets one look of phase C fetches (1: 24.9-25.1 ms, 2: 24.8, 4: 27.3 on the metric's job)
 constexpr uint32_t kTileQueueBytes = 6144;    // LDS queue of phase C (what does not fit stays with the lane)
 
 // dynamic LDS of one workgroup: slots | bucket counters (16 bit each) | queue header | queue
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
   uint32_t* const s_qn = s_cnt + (nbkt >> 1);                 // (16 bytes of padding)
   // phase C's queue: one segment per wave (positions come from a ballot: no atomic, no count to read back)
   constexpr uint32_t qcap = kTileQueueBytes / sizeof(ITEM) / (BLOCK / 64);
+  static_assert(qcap >= 64, "phase C stages one held-back item per lane through the queue");
   ITEM* const s_q = reinterpret_cast<ITEM*>(s_qn + 4) + (threadIdx.x >> 6) * qcap;
   SLOT* const gslots = reinterpret_cast<SLOT*>(T.slots);
   const SLOT lmask = (SLOT)g.low_mask, inc = (SLOT)g.inc, occ = (SLOT)g.occ_bit;
@@ -231,41 +233,59 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
       else T.dirty[tile0 + t] = 1;
     }
   };
-  // C for one item: find the key or a free slot, bucket by bucket from its home bucket.  The bucket after the one being
-  // looked at is already on its way.  M has run: no bucket holds a tag twice, and nothing here can change that -- slots
-  // only ever go from empty to one key (two lanes with the same new key go for the same first empty slot of the same
-  // bucket; the loser looks again and finds the winner's entry).  So a full bucket is full for good, an add lands on
-  // the key it was meant for, and a look that has gone stale can only lead to a compare-and-swap that fails.
+  // C for one item: find the key or a free slot, from its home bucket on, kQueueLook buckets per look (one LDS round trip).
+  // M has run: no bucket holds a tag twice, and nothing here can change that -- slots only ever go from empty to one key,
+  // and two lanes with the same new key go for the same first empty slot: the loser's compare-and-swap returns the
+  // winner's entry and it adds to that.  So a full bucket is full for good, an add lands on the key it was meant for, and
+  // a look that has gone stale can only lead to a compare-and-swap that fails.
+  // What this phase costs is its chain of dependent LDS round trips, not its instructions: 3.85 % of the metric's items come
+  // here, and compiling the insert out takes T from 27.0 to 18.9 ms.  Round 5 cut the chain -- the home bucket of a queued
+  // item is full of other keys nearly always, so one bucket per look meant two looks for every item; a lost slot meant
+  // a new look, now the next candidate of the same look -- 27.0 -> 24.8 ms.  Measured and not kept: four buckets per look
+  // (27.3: registers), the eight waves' queues dealt out as one list (25.1-25.4), s_setprio around the phase (25.6),
+  // waits between the rank adds of A to keep the LDS queue short (24.9).
   auto slow_insert = [&](ITEM x, uint64_t unit_slot0) {
+    constexpr uint32_t LK = kQueueLook;
     const SLOT low = occ | (SLOT)((uint64_t)x & (g.occ_bit - 1)), neww = inc | low;
     const uint32_t h = home_of(x), hbase = h & ~tmask, hb = h & tmask & ~3u;
-    SLOT w[4], wn[4];
-    load_bucket(hbase + hb, w);
-    load_bucket(hbase + ((hb + 4) & tmask), wn);
     // the walk ends where every other path's does (T.max_probe: table_add, lookups, update_add, the direct inserts) -- a key
     // placed further from home would be in the table and invisible to them (round-3 advisor finding)
     const uint32_t max_steps = (T.max_probe >> kBucketBits) + 1;
     for(uint32_t step = 0; step < max_steps; ) {
-      const uint32_t bs = hbase + ((hb + (step << kBucketBits)) & tmask);
-      int hit = -1, emp = -1;
+      SLOT w[LK][4];
 #pragma unroll
-      for(int i = 3; i >= 0; --i) { if((w[i] & lmask) == low) hit = i; if(w[i] == 0) emp = i; }
-      if(hit >= 0) {
-        if(RETURNING) {
-          const SLOT prev = atomicAdd(&s_tile[bs + hit], inc);
-          if(((uint64_t)prev >> cshift) + 1 > g.cnt_max) ovf_add_call(T.ovf_key, T.ovf_cnt, T.ovf_mask, T.counters, unit_slot0 + bs + hit, 1);
-        } else atomicAdd(&s_tile[bs + hit], inc);
-        return;
-      }
-      if(emp >= 0) {
-        if(atomicCAS(&s_tile[bs + emp], (SLOT)0, neww) == 0) return;
-        load_bucket(bs, w);                                   // somebody else took it: look at this bucket again
-        continue;
-      }
-      ++step;
+      for(uint32_t k = 0; k < LK; ++k) load_bucket(hbase + ((hb + ((step + k) << kBucketBits)) & tmask), w[k]);
+      uint32_t hitm = 0, empm = 0;
 #pragma unroll
-      for(int i = 0; i < 4; ++i) w[i] = wn[i];
-      load_bucket(hbase + ((hb + ((step + 1) << kBucketBits)) & tmask), wn);
+      for(uint32_t k = 0; k < LK; ++k)
+#pragma unroll
+        for(uint32_t i = 0; i < 4; ++i) {
+          hitm |= (uint32_t)((w[k][i] & lmask) == low) << (4 * k + i);
+          empm |= (uint32_t)(w[k][i] == 0) << (4 * k + i);
+        }
+      // candidates in probe order: the first slot that holds the key or nothing.  A compare-and-swap that fails says what
+      // the slot holds now -- the key (a lane with the same new key got there first: add to it), or another key: then the
+      // next candidate of the same look is still good (what was seen full stays full, and the key cannot have gone in
+      // behind a slot that was empty when it did), so losing a slot costs one more LDS trip and not a new look.
+      for(uint32_t cand = hitm | empm; cand; cand &= cand - 1) {
+        const uint32_t j = (uint32_t)__ffs((int)cand) - 1u;
+        if(step + (j >> kBucketBits) >= max_steps) { step = max_steps; break; }
+        const uint32_t at = hbase + ((hb + (step << kBucketBits) + j) & tmask);
+        bool add = (hitm >> j) & 1;
+        if(!add) {
+          const SLOT was = atomicCAS(&s_tile[at], (SLOT)0, neww);
+          if(was == 0) return;
+          add = (was & lmask) == low;
+        }
+        if(add) {
+          if(RETURNING) {
+            const SLOT prev = atomicAdd(&s_tile[at], inc);
+            if(((uint64_t)prev >> cshift) + 1 > g.cnt_max) ovf_add_call(T.ovf_key, T.ovf_cnt, T.ovf_mask, T.counters, unit_slot0 + at, 1);
+          } else atomicAdd(&s_tile[at], inc);
+          return;
+        }
+      }
+      step += LK;
     }
     atomicAdd((unsigned long long*)&T.counters[CTR_FULL], 1ull);
   };
@@ -366,13 +386,20 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
       }
       nq = q2 < qcap ? q2 : qcap;
     }
-    // ---- C: this wave's queue, then what its lanes held back (one copy of the insert for both)
-    for(uint32_t i = lane;; i += 64) {
-      ITEM x;
-      if(i < nq) x = s_q[i];
-      else if(pend) { const uint32_t r = (uint32_t)__ffs((int)pend) - 1u; x = again[r * BLOCK + threadIdx.x]; pend &= pend - 1; }
-      else break;
-      slow_insert(x, unit_slot0);
+    // ---- C: the queues, then what lanes held back -- staged through the queue too, so that the loop reads LDS and nothing
+    // else.  (A loop over "s_q[i] or again[...]" makes the item a FLAT load, and the wait behind a flat load is for every
+    // outstanding memory operation: the next unit's items, requested in after_a(), would be waited for right here.)
+    for(;;) {
+      for(uint32_t i = lane; i < nq; i += 64) slow_insert(s_q[i], unit_slot0);
+      const unsigned long long m = __ballot(pend != 0);      // (wave-uniform; nearly always 0)
+      if(!m) break;
+      if(pend) {
+        const uint32_t r = (uint32_t)__ffs((int)pend) - 1u;
+        pend &= pend - 1;
+        s_q[(uint32_t)__popcll(m & below)] = again[r * BLOCK + threadIdx.x];
+      }
+      nq = (uint32_t)__popcll(m);
+      (void)__ballot(true);                                  // (written before read: lockstep on the device, a rendezvous in the host emulation)
     }
     JF_PHASE(pc, 5);
     lds_barrier();
