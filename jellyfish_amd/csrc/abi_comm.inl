@@ -133,7 +133,7 @@ struct ItemLayout {
 ItemLayout item_layout(const jfgpu_comm* c, const jfgpu_table* t, uint32_t cap) {
   ItemLayout L;
   uint32_t sb = 0; while((1 << sb) < c->world) ++sb;
-  L.gbits = std::min<uint32_t>(10, sb + t->pg.b1); L.cbits = L.gbits - sb; L.split_bits = t->pg.b1 - L.cbits;
+  L.gbits = std::min<uint32_t>((uint32_t)c->tun.comm_gbits, sb + t->pg.b1); L.cbits = L.gbits - sb; L.split_bits = t->pg.b1 - L.cbits;
   L.cap = cap; L.nbg = 1u << L.gbits; L.nbc = 1u << L.cbits; L.S = c->strag_cap;
   L.items_bytes = align_up((size_t)L.nbg * cap * 4, 256);
   L.offs_at = L.items_bytes; L.claims_at = L.offs_at + (size_t)2 * L.nbg * 8; L.strag_at = L.claims_at + 1024 * 8;
@@ -147,7 +147,7 @@ bool items_geometry_ok(const jfgpu_comm* c, const jfgpu_table* t) {
   if(!c->items_on || t->wide || t->nword || c->world > 512) return false;
   if(!t->part_ok || !t->item32 || t->pg.b2 == 0) return false;              // the shard inserts through two partition levels, 32-bit items
   uint32_t sb = 0; while((1 << sb) < c->world) ++sb;
-  const uint32_t gbits = std::min<uint32_t>(10, sb + t->pg.b1);
+  const uint32_t gbits = std::min<uint32_t>((uint32_t)c->tun.comm_gbits, sb + t->pg.b1);
   if(gbits < sb || t->g.key_bits < gbits || t->g.key_bits - gbits > 32) return false;   // the routed item is 2k - gbits bits
   if(t->pg.b1 - (gbits - sb) > 4) return false;                                          // the receiver splits a coarse bucket at most 16 ways
   return t->g.lsize_g >= t->g.tile_bits + gbits;
@@ -298,8 +298,16 @@ int comm_insert_prev_items(jfgpu_comm* c, jfgpu_comm::Rank& R, int rank) {
   // right only when the fan-out equals W -- a shard with 2^9 P1 buckets at world 4 splits two ways, its regions overflowed
   // and a third of the items went in by global atomics: tools/local_world_stage_times.py.)
   const uint64_t per_fine = ((uint64_t)W * L.cap + ((uint64_t)1 << sb) - 1) >> sb;
-  if(per_fine + (uint64_t)kBlocksPerBucket * kGran + kGran > 0xFFFF0000ull) return fail(JFGPU_E_UNSUPPORTED, "item exchange: a step too large for its regions");
-  const uint32_t cap2 = (uint32_t)((per_fine + (uint64_t)kBlocksPerBucket * kGran + kGran - 1) / kGran * kGran);
+  // the wave-per-stream split (recv_split_kernel; JFGPU_COMM_SPLIT=0: round 4's sort-based kernel): about four workgroups
+  // per CU in all; a wave reserves `res` items at a time and may leave two reservations per destination partly unused
+  const bool wave_split = t->tun.comm_split != 0;
+  const uint32_t split_wgs = std::max<uint32_t>(1, std::min<uint32_t>(16, (4u * (uint32_t)t->n_cu) / std::max<uint32_t>(1, L.nbc)));
+  const uint32_t split_waves = split_wgs * (uint32_t)kSplitWaves;
+  const uint32_t row = split_row(sb);                      // items a wave writes at a time per destination
+  const uint32_t res = row * (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(1024 / row, per_fine / ((uint64_t)row * split_waves * 16)));
+  const uint64_t strand = wave_split ? 2ull * split_waves * res : (uint64_t)kBlocksPerBucket * kGran;
+  if(per_fine + strand + kGran > 0xFFFF0000ull) return fail(JFGPU_E_UNSUPPORTED, "item exchange: a step too large for its regions");
+  const uint32_t cap2 = (uint32_t)((per_fine + strand + kGran - 1) / kGran * kGran);
   const size_t bytes = (size_t)nb * cap2 * 4;
   const size_t need = align_up(bytes, 256) + align_up((2 * nb + 1) * sizeof(uint64_t), 256) + align_up(nb * 16, 256) + 1024;
   if(t->pending.size() >= kMaxSeg) { int rc = part_flush(t); if(rc) return rc; }
@@ -348,7 +356,16 @@ int comm_insert_prev_items(jfgpu_comm* c, jfgpu_comm::Rank& R, int rank) {
 #define SPLIT(RT, SW) hipLaunchKernelGGL((p2_granule_kernel<uint32_t, TableDirect<RT>, kP2PairPer, SW>), grid, block, lds, t->stream, \
                         TableDirect<RT>{t->d_dt, pd, (unsigned long long*)&t->dt.counters[CTR_DIRECT]}, sb, split_at, S, cap2, gc_v, gs_v, out_v, (uint32_t)first, tot_v, L.nbc - 1)
     if(sb > 4) return fail(JFGPU_E_UNSUPPORTED, "item exchange: more than 16 fine buckets per coarse bucket");
-    if(t->returning) { if(sb <= 2) SPLIT(true, 1); else if(sb == 3) SPLIT(true, 2); else SPLIT(true, 4); }
+    if(wave_split) {
+      const dim3 gridw(split_wgs, L.nbc), blockw(64 * kSplitWaves);
+#define WSPLIT(RT, LF) hipLaunchKernelGGL((recv_split_kernel<TableDirect<RT>, LF>), gridw, blockw, 0, t->stream, \
+                         TableDirect<RT>{t->d_dt, pd, (unsigned long long*)&t->dt.counters[CTR_DIRECT]}, split_at, S, cap2, res, gc_v, gs_v, out_v, (uint32_t)first, tot_v, L.nbc - 1)
+#define WSPLIT_LF(RT) do { switch(sb) { case 0: WSPLIT(RT, 0); break; case 1: WSPLIT(RT, 1); break; case 2: WSPLIT(RT, 2); break; case 3: WSPLIT(RT, 3); break; default: WSPLIT(RT, 4); } } while(0)
+      if(t->returning) WSPLIT_LF(true); else WSPLIT_LF(false);
+#undef WSPLIT_LF
+#undef WSPLIT
+    }
+    else if(t->returning) { if(sb <= 2) SPLIT(true, 1); else if(sb == 3) SPLIT(true, 2); else SPLIT(true, 4); }
     else             { if(sb <= 2) SPLIT(false, 1); else if(sb == 3) SPLIT(false, 2); else SPLIT(false, 4); }
 #undef SPLIT
     hipLaunchKernelGGL(granule_finish_kernel, dim3(4), dim3(256), 0, t->stream, gcur, cap2, nb, b.off);

@@ -1060,6 +1060,158 @@ __global__ __launch_bounds__(kPBlock) void p2_granule_kernel(DIRECT D, uint32_t 
   if(my_direct) atomicAdd(D.direct_counter(), (unsigned long long)my_direct);
 }
 
+// ---- multi-GPU: the receive split (abi_comm.inl: comm_insert_prev_items) ------------------------------------------------------
+// A coarse bucket of a shard arrives as W regions (one per sender) and is split into the shard's own P1 buckets: a
+// fan-out of F = 2^LF <= 16.  The sort-based p2_granule_kernel<.., SMALL> did that in round 4 at 25.5 ms per 10 Gbp (five
+// barriers a chunk, two workgroups a CU: 2.7 TB/s for a pass that only moves 35 GB in and 35 GB out).  Here every WAVE is
+// on its own -- no workgroup barrier anywhere: it streams its share of the regions 256 items at a time (16 bytes a lane,
+// three requests ahead), appends each item to its destination's ring in LDS (8 KB of rings per wave; the rank is a
+// ballot count for F <= 2, an LDS add for more) and, whenever a ring holds a row of kSplitRow(LF) items, writes the row
+// to the destination's region (up to 16 bytes a lane).  The kernel is bound by its instructions, not by HBM (a first
+// version with rows of 64 items for every F: 24.2 ms, with or without the requests ahead), hence the long rows.  Space in a
+// region is reserved `res` items at a time (one global add per reservation, by the lane that keeps the destination's
+// state, asked for when the previous reservation runs out and used a row or more later), so the output is what the
+// granule kernels' is: regions of cap items, gcur = what was handed out, gshort = the overflow note, holes behind what
+// was not filled, tot = items stored.  What does not fit its region goes to the table directly (D).
+constexpr int kSplitWaves = 4;                // waves per workgroup
+constexpr uint32_t split_row(uint32_t lf) { return (1024u >> lf) < 256u ? (1024u >> lf) : 256u; }      // items per row written: 256, 256, 256, 128, 64
+template <typename DIRECT, int LF>
+__global__ __launch_bounds__(64 * kSplitWaves) void recv_split_kernel(DIRECT D, uint32_t split_at, SegList S, uint32_t cap, uint32_t res,
+                                                                      unsigned int* __restrict__ gcur, unsigned int* __restrict__ gshort,
+                                                                      uint32_t* __restrict__ out, uint32_t bucket0,
+                                                                      unsigned long long* __restrict__ tot, uint32_t bucket_mask) {
+  constexpr uint32_t F = 1u << LF, RW = split_row(LF), RS = 2 * RW, V = RW / 64;      // ring of two rows per destination; V items a lane and row
+  constexpr int kCheck = (int)(RW / 64);                         // rounds of 64 items between two looks at the rings' fill: <= RW - 1 + RW items then
+  __shared__ __align__(16) uint32_t s_ring[kSplitWaves][F * RS];
+  __shared__ uint32_t s_cnt[kSplitWaves][16];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+  const uint32_t bucket = bucket0 + blockIdx.y;
+  uint32_t* const ring = s_ring[wave];
+  uint32_t* const cnt = s_cnt[wave];
+  unsigned int* const gc = gcur + (size_t)bucket * F;
+  unsigned int* const gs = gshort + (size_t)bucket * F;
+  uint32_t* const o = out + (size_t)bucket * F * cap;
+  const uint32_t hole = 0xFFFFFFFFu;
+  const uint32_t nw = gridDim.x * kSplitWaves, wid = blockIdx.x * kSplitWaves + wave;
+  // lane d < F keeps destination d: items flushed, the reservation in use [pos, pos + room), the one asked for ahead
+  uint32_t fl = 0, pos = 0, room = 0, nxt = 0, stored = 0, direct_n = 0;
+  bool has_nxt = false, dead = false;
+  uint32_t c0 = 0, c1 = 0;                                      // F <= 2: the rings' counts (wave-uniform)
+  if(lane < 16) cnt[lane] = 0;
+  (void)__ballot(true);
+  auto request = [&]() {                                         // (called by lane d alone)
+    if(!dead && !has_nxt) { nxt = atomicAdd(&gc[lane], res); has_nxt = true; }
+  };
+  // a row of destination d out of its ring (n < RW only at the end: the rest of the row becomes holes)
+  auto flush = [&](uint32_t d, uint32_t n) {
+    uint32_t fl_d = __shfl(fl, d, 64), room_d = __shfl(room, d, 64), pos_d = __shfl(pos, d, 64);
+    if(room_d == 0) {                                            // (wave-uniform) take the reservation asked for ahead
+      if(lane == d) {
+        request();
+        if(!dead) {
+          if((uint64_t)nxt + res <= cap) { pos = nxt; room = res; }
+          else { dead = true; if(nxt < cap) atomicMax(&gs[d], cap - nxt); }      // everything below nxt was handed out successfully
+          has_nxt = false;
+        }
+      }
+      room_d = __shfl(room, d, 64); pos_d = __shfl(pos, d, 64);
+    }
+    // (rows start at multiples of RW in a ring of 2 RW: contiguous, aligned)
+    uint32_t v[V];
+    const uint32_t* rp = ring + d * RS + (fl_d & (RS - 1)) + lane * V;
+    if constexpr(V == 4) { const uint4 x = *reinterpret_cast<const uint4*>(rp); v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; }
+    else if constexpr(V == 2) { const uint2 x = *reinterpret_cast<const uint2*>(rp); v[0] = x.x; v[1] = x.y; }
+    else v[0] = rp[0];
+#pragma unroll
+    for(uint32_t j = 0; j < V; ++j) if(lane * V + j >= n) v[j] = hole;
+    if(room_d) {
+      uint32_t* op = o + (size_t)d * cap + pos_d + lane * V;
+      if constexpr(V == 4) *reinterpret_cast<uint4*>(op) = make_uint4(v[0], v[1], v[2], v[3]);
+      else if constexpr(V == 2) *reinterpret_cast<uint2*>(op) = make_uint2(v[0], v[1]);
+      else op[0] = v[0];
+      if(lane == d) { pos += RW; room -= RW; stored += n; fl += n; if(room == 0) request(); }
+    } else {                                                     // region exhausted: straight to the table
+#pragma unroll
+      for(uint32_t j = 0; j < V; ++j) if(v[j] != hole) { D(bucket & bucket_mask, v[j]); ++direct_n; }
+      if(lane == d) fl += n;
+    }
+  };
+  for(uint32_t s = 0; s < S.n; ++s) {
+    const uint64_t o0 = seg_lo(S, s, bucket), len = seg_hi(S, s, bucket) - o0;
+    // this wave's part of the region: rows of 64 items dealt out evenly
+    const uint64_t rows = (len + 63) >> 6, r_lo = rows * wid / nw, r_hi = rows * (wid + 1) / nw;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(S.items[s]) + o0;
+    const uint64_t i_hi = r_hi << 6 < len ? r_hi << 6 : len;
+    // lane l's four items of a request are 4 l .. 4 l + 3 of its 256: the order of a region's items means nothing
+    constexpr int PD = 3;
+    auto ld = [&](uint64_t i0) -> uint4 {
+      const uint64_t i = i0 + 4 * lane;
+      if(i >= i_hi) return make_uint4(hole, hole, hole, hole);
+      uint4 x = *reinterpret_cast<const uint4*>(src + i);
+      if(i + 1 >= i_hi) x.y = hole;
+      if(i + 2 >= i_hi) x.z = hole;
+      if(i + 3 >= i_hi) x.w = hole;
+      return x;
+    };
+    uint4 q[PD];
+#pragma unroll
+    for(int k = 0; k < PD; ++k) q[k] = ld((r_lo << 6) + (uint64_t)k * 256);
+    for(uint64_t i0 = r_lo << 6; i0 < i_hi; i0 += 256) {
+      const uint4 cur = q[0];
+#pragma unroll
+      for(int k = 0; k + 1 < PD; ++k) q[k] = q[k + 1];
+      q[PD - 1] = ld(i0 + (uint64_t)PD * 256);
+      const uint32_t it[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+      for(int r = 0; r < 4; ++r) {
+        const bool valid = it[r] != hole;
+        const uint32_t d = (it[r] >> split_at) & (F - 1);
+        uint32_t p = 0;
+        if constexpr(F == 1) {
+          const unsigned long long m = __ballot(valid);
+          p = c0 + (uint32_t)__popcll(m & below); c0 += (uint32_t)__popcll(m);
+        } else if constexpr(F == 2) {
+          const unsigned long long m0 = __ballot(valid && d == 0), m1 = __ballot(valid && d == 1);
+          p = d ? c1 + (uint32_t)__popcll(m1 & below) : c0 + (uint32_t)__popcll(m0 & below);
+          c0 += (uint32_t)__popcll(m0); c1 += (uint32_t)__popcll(m1);
+        } else if(valid) p = atomicAdd(&cnt[d], 1u);
+        if(valid) ring[d * RS + (p & (RS - 1))] = it[r];
+        if((r + 1) % kCheck != 0) continue;
+        (void)__ballot(true);                                    // (written before read: lockstep on the device, a rendezvous in the host emulation)
+        const uint32_t c = F <= 2 ? (lane == 0 ? c0 : c1) : (lane < F ? cnt[lane] : 0u);
+        unsigned long long full = __ballot(lane < F && c - fl >= RW);
+        while(full) {                                            // (wave-uniform) one row per destination at most: RW items came in since the last look
+          const uint32_t d1 = (uint32_t)__ffsll((long long)full) - 1u;
+          full &= full - 1;
+          flush(d1, RW);
+        }
+        (void)__ballot(true);                                    // (read before the next round writes)
+      }
+    }
+  }
+  // what is left in the rings, then holes over what was reserved and not used
+  {
+    const uint32_t c = F <= 2 ? (lane == 0 ? c0 : c1) : (lane < F ? cnt[lane] : 0u);
+    for(uint32_t d = 0; d < F; ++d) {
+      const uint32_t left = __shfl(c, d, 64) - __shfl(fl, d, 64);
+      if(left) flush(d, left);
+      for(int pass = 0; pass < 2; ++pass) {                      // the reservation in use, then the one asked for and never used
+        if(pass == 1 && lane == d) {
+          pos = nxt; room = has_nxt && (uint64_t)nxt + res <= cap ? res : 0u;
+          if(has_nxt && (uint64_t)nxt + res > cap && nxt < cap) atomicMax(&gs[d], cap - nxt);
+        }
+        const uint32_t room_d = __shfl(room, d, 64), pos_d = __shfl(pos, d, 64);
+        for(uint32_t qq = lane; qq < room_d; qq += 64) o[(size_t)d * cap + pos_d + qq] = hole;
+      }
+    }
+    if(lane < F && stored && tot) atomicAdd(&tot[(size_t)bucket * F + lane], (unsigned long long)stored);
+    unsigned long long dn = direct_n;
+    for(int off = 32; off > 0; off >>= 1) dn += __shfl_down(dn, off, 64);
+    if(lane == 0 && dn) atomicAdd(D.direct_counter(), dn);
+  }
+}
+
 // ---- multi-GPU: P1 on the sending side (abi_comm.inl) ------------------------------------------------------------
 // The single-pass P1 over the GLOBAL table: T is a view of the shard's table whose geometry says "one table of 2^lsize_g
 // slots" (same matrix, same tags), so bucket = top 10 bits of the global position = (owner rank, the owner's coarse

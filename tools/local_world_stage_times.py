@@ -3,14 +3,15 @@
 instead of RCCL, the ranks' kernels run one after the other, so the per-stage device times are not inflated by processes
 time-slicing the GPU as in `bench.py --gpus N` on a one-GPU box).  What it shows: the cost of the receive side's W-way split
 (exchange_receive_split) and of the routing P1 at world W, per rank, for a total of `gbp` Gbp into a global table of 2^34 slots.
-usage: python tools/local_world_stage_times.py [world=4] [gbp=5] [log2 of the global table size = 34]"""
+usage: [JFGPU_COMM_GBITS=..] python tools/local_world_stage_times.py [world=4] [gbp=5] [log2 of the global table size = 34] [k=21]
+(JFGPU_COMM_GBITS=8 with k = 20 at world 4: the 8-way receive split of an 8-GPU run's full-size shards on 2^32-slot shards.)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from jellyfish_amd import capi
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 gbp = float(sys.argv[2]) if len(sys.argv) > 2 else 5.0
 lsize_g = int(sys.argv[3]) if len(sys.argv) > 3 else 34
-L, K, steps = 150, 21, 5
+L, K, steps = 150, (int(sys.argv[4]) if len(sys.argv) > 4 else 21), 5
 n_reads = int(gbp * 1e9 / L) // world          # per rank
 sb = world.bit_length() - 1
 shards = [capi.Table(K, 1 << lsize_g, canonical=True, shard_bits=sb, shard_id=r) for r in range(world)]
