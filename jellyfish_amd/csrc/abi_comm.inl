@@ -307,7 +307,8 @@ int comm_insert_prev_items(jfgpu_comm* c, jfgpu_comm::Rank& R, int rank) {
   const uint32_t res = row * (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(1024 / row, per_fine / ((uint64_t)row * split_waves * 16)));
   const uint64_t strand = wave_split ? 2ull * split_waves * res : (uint64_t)kBlocksPerBucket * kGran;
   if(per_fine + strand + kGran > 0xFFFF0000ull) return fail(JFGPU_E_UNSUPPORTED, "item exchange: a step too large for its regions");
-  const uint32_t cap2 = (uint32_t)((per_fine + strand + kGran - 1) / kGran * kGran);
+  uint32_t cap2 = (uint32_t)((per_fine + strand + kGran - 1) / kGran * kGran);
+  if(t->tun.comm_split_cap) cap2 = (t->tun.comm_split_cap + kGran - 1) / kGran * kGran;      // (tests: regions that overflow)
   const size_t bytes = (size_t)nb * cap2 * 4;
   const size_t need = align_up(bytes, 256) + align_up((2 * nb + 1) * sizeof(uint64_t), 256) + align_up(nb * 16, 256) + 1024;
   if(t->pending.size() >= kMaxSeg) { int rc = part_flush(t); if(rc) return rc; }

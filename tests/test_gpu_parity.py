@@ -1214,9 +1214,7 @@ def test_p2_variants_of_32bit_slots_give_the_same_table(gpu, monkeypatch, varian
         t.free(d)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("world,strag", [(2, None), (4, None), (1, None), (2, "3"), (8, None), (16, None)])
-def test_comm_item_path_equals_single_table(gpu, monkeypatch, world, strag):
+def comm_item_path_case(gpu, monkeypatch, world, strag):
     """The exchange's item path (abi_comm.inl: the sender runs the single-pass P1 over the GLOBAL table, an owner's regions
     travel as 4-byte items, the receiver splits them into its own P1 buckets) on the in-process transport, forced on
     (JFGPU_COMM_ITEMS=2) because test-sized steps would otherwise go as keys.  Inputs with a long homopolymer (one bucket
@@ -1259,12 +1257,41 @@ def test_comm_item_path_equals_single_table(gpu, monkeypatch, world, strag):
         assert sum(t.stats().total for t in shards) == sum(exp.values())
         parts = [t.dump_records() for t in shards]
         assert (np.concatenate(parts) == whole).all()
+        direct = sum(t.counters().get("direct", 0) for t in shards)
         for t, d in bufs:
             t.free(d)
+        return direct
     finally:
         comm.close()
         for t in shards:
             t.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,strag", [(2, None), (4, None), (1, None), (2, "3"), (8, None), (16, None)])
+def test_comm_item_path_equals_single_table(gpu, monkeypatch, world, strag):
+    comm_item_path_case(gpu, monkeypatch, world, strag)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [4, 8])
+def test_comm_item_path_with_the_sort_based_receive_split(gpu, monkeypatch, world):
+    """JFGPU_COMM_SPLIT=0: round 4's receive split (p2_granule_kernel<.., SMALL>) stays selectable for A/B runs against
+    recv_split_kernel, so it stays under the same parity test."""
+    monkeypatch.setenv("JFGPU_COMM_SPLIT", "0")
+    comm_item_path_case(gpu, monkeypatch, world, None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("split,world", [("1", 4), ("1", 8), ("1", 1), ("0", 4)])
+def test_receive_split_regions_that_overflow(gpu, monkeypatch, split, world):
+    """The receive split with regions far too small for what arrives (JFGPU_COMM_SPLIT_CAP): a destination's reservations
+    stop fitting, the overflow note is written, the rows that found no room are inserted directly -- and the shards still
+    equal the single table (recv_split_kernel's exhausted path at fan-outs 1, 2 and 8; round 4's kernel beside it)."""
+    monkeypatch.setenv("JFGPU_COMM_SPLIT", split)
+    roomy = comm_item_path_case(gpu, monkeypatch, world, None)
+    monkeypatch.setenv("JFGPU_COMM_SPLIT_CAP", "512")
+    assert comm_item_path_case(gpu, monkeypatch, world, None) > roomy      # (more items went to the table directly)
 
 
 # ---- round 4: the rank-placement tile kernel anchored to the oracle, every instantiation -----------------------------
