@@ -67,8 +67,20 @@ typedef struct jfgpu_params {
                             block must be invertible.  NULL = random from matrix_seed */
   uint32_t out_counter_len; /* bytes per count in dumps (binary_dumper ctor val_len,
                             count_main_cmdline.yaggo --out-counter-len); 0 = 4 */
-  uint32_t reserved;
+  uint32_t matrix_kind;  /* which family the matrix comes from when neither matrix_columns nor matrix_seed is given:
+                            JFGPU_MATRIX_DEFAULT (0, what the JFGPU_MATRIX environment switch says, else the reference's),
+                            JFGPU_MATRIX_XORSHIFT or JFGPU_MATRIX_REFERENCE.  (Was `reserved`, always 0.) */
 } jfgpu_params;
+
+/* Matrix families.  The file format admits any r x 2k matrix with an invertible low r x r block -- readers take the
+ * columns from the header (include/jellyfish/file_header.hpp:35-64) and multiply
+ * (rectangular_binary_matrix.hpp:155-164) -- so the choice changes where a k-mer lands, never what is counted.
+ *   REFERENCE: the matrix `jellyfish count` itself draws (lib/rectangular_binary_matrix.cc:160-247 on glibc's unseeded
+ *              random()): file bodies byte-identical to the reference's, files mergeable with the reference's.
+ *   XORSHIFT:  a fixed matrix per (size, k) made of xor-shift steps (jellyfish_amd/csrc/kmer_core.hpp: xs_hash), which
+ *              the partition kernel evaluates in registers instead of six LDS table reads per k-mer.  One-word keys
+ *              (k <= 32); longer keys get the reference family. */
+enum { JFGPU_MATRIX_DEFAULT = 0, JFGPU_MATRIX_XORSHIFT = 1, JFGPU_MATRIX_REFERENCE = 2 };
 
 /* Geometry + matrix actually used, for file_header::update_from_ary (file_header.hpp:25-33). */
 typedef struct jfgpu_info {

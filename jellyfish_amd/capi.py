@@ -28,7 +28,7 @@ class Params(C.Structure):
     _fields_ = [
         ("k", C.c_uint32), ("canonical", C.c_uint32), ("size", C.c_uint64), ("device", C.c_int32),
         ("shard_bits", C.c_uint32), ("shard_id", C.c_uint32), ("matrix_seed", C.c_uint64),
-        ("matrix_columns", C.POINTER(C.c_uint64)), ("out_counter_len", C.c_uint32), ("reserved", C.c_uint32),
+        ("matrix_columns", C.POINTER(C.c_uint64)), ("out_counter_len", C.c_uint32), ("matrix_kind", C.c_uint32),
     ]
 
 

@@ -236,6 +236,8 @@ int comm_route_items_enqueue(jfgpu_comm* c, jfgpu_comm::Rank& R, const char* d_b
 #define PR(N, CN) hipLaunchKernelGGL((p1_ring_kernel<uint32_t, false, N, CN, RouteListDirect>), grid, block, lds, t->stream, gv, rd, pg, base, lo, hi, cap, R.d_gcur, tot, items, t->d_strag, t->d_strag_n)
     if(t->dt.bloom.data)      // count --bc: the sender asks its copy of the Bloom counter (read-only: the same answer on every rank)
       hipLaunchKernelGGL((p1_ring_kernel<uint32_t, true, 0, 2, RouteListDirect>), grid, block, lds, t->stream, gv, rd, pg, base, lo, hi, cap, R.d_gcur, tot, items, t->d_strag, t->d_strag_n);
+    else if(t->g.hash_xs && gv.g.lsize_g > 32 && gv.g.lsize_g < 64 && gv.g.lsize_g - pg.b1 < 32) { if(t->g.canonical) PR(kHashXS, 1); else PR(kHashXS, 0); }
+    else if(t->g.hash_xs) PR(kHashXSLow, 2);
     else if(t->g.nbytes == 6) { if(t->g.canonical) PR(6, 1); else PR(6, 0); } else PR(0, 2);
 #undef PR
     hipLaunchKernelGGL((p1_stragglers_kernel<uint32_t, RouteListDirect>), dim3(t->n_cu), dim3(256), 0, t->stream, rd, (unsigned long long*)nullptr, (const uint64_t*)t->d_strag,

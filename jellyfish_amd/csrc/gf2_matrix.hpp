@@ -19,8 +19,10 @@
 // family of matrices.  Any matrix with an invertible low block is legal for the file format (readers
 // take it from the header, file_header.hpp:35-47).
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 #include <vector>
+#include "kmer_core.hpp"
 
 namespace jfgpu {
 
@@ -162,6 +164,22 @@ inline Gf2Matrix gf2_random(uint32_t r, uint32_t c, uint64_t seed) {
     for(uint32_t i = 0; i < c; ++i) m.columns[i] = splitmix64(s) & cmask;
     if(gf2_invert_low_block(m, binv)) return m;
   }
+}
+
+// The xor-shift family (kmer_core.hpp: xs_hash): the matrix of that linear map, column by column -- the image of key
+// bit j is xs_hash(1 << j).  One-word keys only (c <= 64); r >= c is the identity case like everywhere else.
+inline Gf2Matrix gf2_xorshift_matrix(uint32_t r, uint32_t c) {
+  if(r >= c) return gf2_identity(r, c);
+  Gf2Matrix m; m.r = r; m.c = c; m.columns.assign(c, 0);
+  for(uint32_t j = 0; j < c; ++j) m.columns[c - 1 - j] = xs_hash(1ull << j, r);
+  return m;
+}
+// is this matrix the family's member for its shape?  (a table created from explicit columns -- a file header's -- gets the
+// register hash too when it is)
+inline bool gf2_is_xorshift(const Gf2Matrix& m) {
+  if(m.c > 64 || m.r >= m.c || m.columns.size() != m.c) return false;
+  for(uint32_t j = 0; j < m.c; ++j) if(m.columns[m.c - 1 - j] != xs_hash(1ull << j, m.r)) return false;
+  return true;
 }
 
 inline bool gf2_is_low_identity(const Gf2Matrix& m) {  // rectangular_binary_matrix.cc:65-79

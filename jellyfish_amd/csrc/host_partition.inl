@@ -298,7 +298,12 @@ int part_ingest(jfgpu_table* t, const uint8_t* base, int64_t lo, int64_t hi, boo
       const OneWordDirect od{t->d_dt, t->pg.b2, (int)t->returning};
       unsigned long long* ctr = (unsigned long long*)&t->dt.counters[CTR_DIRECT];
       // (32-bit items exist for keys of at most 42 bits: six key bytes is the only width worth a compiled-in hash)
-      if(t->g.nbytes == 6 && !bl) { if(t->g.canonical) PG(uint32_t, false, 6, 1); else PG(uint32_t, false, 6, 0); }
+      // the xor-shift matrix is evaluated in registers (kmer_core.hpp: xs_hash); on the key's two dwords when the position has
+      // more than 32 bits, which is the metric's geometry
+      const bool xs = t->g.hash_xs && !bl, xs_hi = xs && t->g.lsize_g > 32 && t->g.lsize_g < 64 && t->g.lsize_l - t->pg.b1 < 32;
+      if(xs_hi) { if(t->g.canonical) PG(uint32_t, false, kHashXS, 1); else PG(uint32_t, false, kHashXS, 0); }
+      else if(xs) PG(uint32_t, false, kHashXSLow, 2);
+      else if(t->g.nbytes == 6 && !bl) { if(t->g.canonical) PG(uint32_t, false, 6, 1); else PG(uint32_t, false, 6, 0); }
       else if(bl) PG(uint32_t, true, 0, 2);
       else PG(uint32_t, false, 0, 2);
       hipLaunchKernelGGL((p1_stragglers_kernel<uint32_t, OneWordDirect>), dim3(t->n_cu), dim3(256), 0, t->stream, od, ctr, (const uint64_t*)t->d_strag, (const uint32_t*)t->d_strag_n,

@@ -125,6 +125,7 @@ struct jfgpu_table {
   std::vector<PendingBatch> pending;
   uint64_t pending_bytes = 0;
   bool ref_matrix = false;       // default matrix family: the reference's (glibc random() stream kept in `glibc`)
+  bool xs_matrix = false;        // the xor-shift family (gf2_xorshift_matrix): doublings stay in it
   GlibcRandom glibc;
   int (*spill_fn)(void*) = nullptr; void* spill_user = nullptr;     // jfgpu_set_spill
   int operation = 0;             // what count_ascii does with a k-mer: 0 add, 1 set (prime), 2 update_add (jfgpu_set_operation)
@@ -452,7 +453,10 @@ int grow_prepare(jfgpu_table* t, GrowNew& N) {
   Gf2Matrix& m2 = N.m2;
   m2 = t->matrix; m2.r = r + 1; m2.identity = false;
   std::vector<uint64_t> fwd, inv;
-  if(t->ref_matrix) {
+  if(t->xs_matrix) {
+    m2 = gf2_xorshift_matrix(r + 1, c);
+    if(!gf2_build_tables(m2, fwd, inv)) return fail(JFGPU_E_INVALID, "xor-shift matrix: singular low block");
+  } else if(t->ref_matrix) {
     // like the reference: a brand-new matrix for the doubled table, next in the same random() stream
     for(int tries = 0; ; ++tries) {
       m2 = r + 1 >= c ? gf2_identity(r + 1, c) : gf2_reference_matrix(r + 1, c, t->glibc);
@@ -472,6 +476,7 @@ int grow_prepare(jfgpu_table* t, GrowNew& N) {
   if(t->nword) { if(!nword_geom_init(N.ng2, t->g.k, r + 1, t->g.canonical)) return -1; g2 = N.ng2.g; }
   else if(t->wide) { if(!wide_geom_init(N.w2, t->g.k, r + 1, t->g.canonical, t->g.shard_bits, t->g.shard_id)) return -1; g2 = N.w2.g; }
   else if(!geom_init(g2, t->g.k, r + 1, t->g.shard_bits, t->g.shard_id, t->g.canonical, !t->tun.slot64)) return -1;
+  if(!t->wide && !t->nword) g2.hash_xs = gf2_is_xorshift(m2) ? 1 : 0;
   const uint64_t n2 = 1ull << g2.lsize_l;
   const size_t slot_bytes = g2.slot32 ? 4 : 8 * (size_t)t->slot_words;
   uint64_t cap2 = std::max<uint64_t>(kMinOvf, std::min<uint64_t>(n2 / 256, 1ull << 26));
@@ -636,12 +641,16 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     t->matrix.identity = gf2_is_low_identity(t->matrix);
   } else if(p->matrix_seed) {
     t->matrix = gf2_random(lsize, 2 * p->k, p->matrix_seed);
+  } else if(p->k <= 32 && lsize < 2 * p->k && (p->matrix_kind ? p->matrix_kind : (uint32_t)t->tun.matrix) == JFGPU_MATRIX_XORSHIFT) {
+    t->xs_matrix = true;
+    t->matrix = gf2_xorshift_matrix(lsize, 2 * p->k);
   } else {
     // the reference's default: first matrix of an unseeded glibc random() stream; the stream stays with the
     // table so that doublings draw their matrices like hash_counter::double_size does (hash_counter.hpp:210-214)
     t->ref_matrix = true;
     t->matrix = lsize >= 2 * p->k ? gf2_identity(lsize, 2 * p->k) : gf2_reference_matrix(lsize, 2 * p->k, t->glibc);
   }
+  if(!wide && !nword) t->g.hash_xs = gf2_is_xorshift(t->matrix) ? 1 : 0;       // (also a matrix given by its columns: a file header's)
   std::vector<uint64_t> fwd, inv;
   while(!gf2_build_tables(t->matrix, fwd, inv)) {
     if(!t->ref_matrix || t->matrix.identity) return fail(JFGPU_E_INVALID, "hash matrix: low r x r block is singular");
@@ -728,6 +737,7 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
       HIP_TRY(hipFuncSetAttribute((const void*)p2_ring_roles_kernel<uint32_t, 2, P2RingDirect, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, rl));
       HIP_TRY(hipFuncSetAttribute((const void*)p2_ring_roles_kernel<uint32_t, 1, P2RingDirect, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, rl));
       RATTR(uint32_t, false, 6, 1); RATTR(uint32_t, false, 6, 0); RATTR(uint32_t, true, 0, 2); RATTR(uint32_t, false, 0, 2);
+      RATTR(uint32_t, false, kHashXS, 1); RATTR(uint32_t, false, kHashXS, 0); RATTR(uint32_t, false, kHashXSLow, 2);
 #undef RATTR
     }
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint32_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * 16 * 4));
@@ -735,6 +745,9 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     HIP_TRY(hipFuncSetAttribute((const void*)p1_ring_kernel<uint32_t, false, 6, 0, RouteListDirect>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kGranMaxB * 128 + 128)));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_ring_kernel<uint32_t, false, 0, 2, RouteListDirect>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kGranMaxB * 128 + 128)));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_ring_kernel<uint32_t, true, 0, 2, RouteListDirect>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kGranMaxB * 128 + 128)));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_ring_kernel<uint32_t, false, kHashXS, 1, RouteListDirect>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kGranMaxB * 128 + 128)));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_ring_kernel<uint32_t, false, kHashXS, 0, RouteListDirect>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kGranMaxB * 128 + 128)));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_ring_kernel<uint32_t, false, kHashXSLow, 2, RouteListDirect>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kGranMaxB * 128 + 128)));
 #define SATTR(SW) HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint32_t, TableDirect<true>, kP2PairPer, SW>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4)); \
                   HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint32_t, TableDirect<false>, kP2PairPer, SW>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4))
     SATTR(1); SATTR(2); SATTR(4);

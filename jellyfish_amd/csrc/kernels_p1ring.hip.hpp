@@ -216,6 +216,8 @@ struct RouteListDirect {
 // against 28.4 for the sort-based p1_granule64_kernel before this round's pack16; 16-byte items (k = 63: rings of 8,
 // units of 4) 130 - 152 ms against 106.  A ring of 128 bytes holds too few wide items: either the rounds get short (a
 // barrier and a flush every two or four positions) or 0.6 % of the items overflow.  Those widths keep the sort.
+// NB: key bytes of the table hash compiled in (0: decided at run time); kHashXS / kHashXSLow: the table's matrix is the
+// xor-shift one and is evaluated in registers (on the key's two dwords for 32 < lsize_g, else in 64-bit arithmetic).
 template <typename ITEM, bool BLOOM, int NB, int CANON, typename DIRECT = OneWordDirect>
 __global__ __launch_bounds__(kPBlock) void p1_ring_kernel(DevTable T, DIRECT D, PartGeom P, const uint8_t* __restrict__ base,
                                                           int64_t lo, int64_t hi, uint32_t cap,
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(kPBlock) void p1_ring_kernel(DevTable T, DIRECT D, 
   constexpr int RP = sizeof(ITEM) == 4 ? 8 : 4;                     // positions per lane and round
   JF_DYN_LDS(s_dyn);
   ITEM* s_ring = reinterpret_cast<ITEM*>(s_dyn);                    // [nb][R::kSlots], then 128 bytes of dump slots
-  __shared__ uint64_t s_fwd[8 * 256];
+  __shared__ uint64_t s_fwd[NB < 0 ? 1 : 8 * 256];                 // (NB < 0: the xor-shift matrix, evaluated in registers -- no tables)
   __shared__ uint32_t s_fill[kGranMaxB + 32];                      // (+ 32 spare words: where positions without a k-mer append)
   __shared__ uint32_t s_nstrag;
   __shared__ uint32_t s_codes[kPBlock + 2];
@@ -237,9 +239,10 @@ __global__ __launch_bounds__(kPBlock) void p1_ring_kernel(DevTable T, DIRECT D, 
   const uint32_t t = threadIdx.x, lane = t & 63;
   const bool owner = t < nb;                                       // this lane keeps bucket t's books
   const ITEM hole = (ITEM)~(ITEM)0;
-  load_tables_lds(s_fwd, T.fwd_tbl, g.nbytes);
+  if constexpr(NB >= 0) load_tables_lds(s_fwd, T.fwd_tbl, g.nbytes);
   ring_init<ITEM>(s_ring, s_fill, nb, &s_nstrag);
   const uint32_t dump = nb * R::kSlots + (lane & (R::kSlots - 1));  // behind the rings: where the stores of positions without an item go
+  [[maybe_unused]] const uint32_t xs_hi_mask = g.lsize_g > 32 ? (g.lsize_g >= 64 ? 0xFFFFFFFFu : ((1u << (g.lsize_g - 32)) - 1u)) : 0u;
   unsigned int* const gshort = gcur + nb;
   uint64_t* const my_strag = strag + (size_t)blockIdx.x * kStragPerBlock * R::kWords;
   const uint32_t k = g.k, bshift = g.lsize_l - P.b1;
@@ -287,6 +290,7 @@ __global__ __launch_bounds__(kPBlock) void p1_ring_kernel(DevTable T, DIRECT D, 
       // ea: the ring's first slot (bucket * slots), ei: item, eo: fill word before the append.  A position without an item
       // keeps (dump, 0): the second sweep stores unconditionally, those stores land in the dump slots
       uint32_t ea[NE], eo[NE]; ITEM ei[NE];
+      [[maybe_unused]] uint32_t spm = 0;                            // bit e: entry e is a special one (JFGPU_P1_LATE_SPECIAL)
 #pragma unroll
       for(int e = 0; e < NE; ++e) { ea[e] = dump; ei[e] = 0; eo[e] = 0; }
       // No branch around a position's hash and append (round 5: 35.4 -> 33.4 ms; with `if(k-mer to emit) { hash, append }` per
@@ -294,22 +298,39 @@ __global__ __launch_bounds__(kPBlock) void p1_ring_kernel(DevTable T, DIRECT D, 
       // to emit hashes whatever its registers hold and appends to one of 32 spare fill words behind the buckets'; its store
       // goes to the dump slots.
       auto emit = [&](int e, uint64_t key, uint32_t cnt, bool on) {
-        const uint64_t pos = hash_tables_t<NB>(s_fwd, key, g.nbytes);
-        const uint32_t b = (uint32_t)(pos >> bshift) & (nb - 1);
-        ITEM item;
-        if constexpr(sizeof(ITEM) == 4) item = (((uint32_t)pos & rest_mask) << g.rem_bits) | (uint32_t)(key >> g.lsize_g);      // (lsize_g <= 2k <= 42)
-        else item = make_item<ITEM>(g, P, key, pos & g.local_mask);
+        uint32_t b; ITEM item;
+        if constexpr(NB == kHashXS && sizeof(ITEM) == 4) {
+          // the xor-shift matrix on the key's two dwords (the host takes this instantiation for 32 < lsize_g < 2k and
+          // bucket shifts below 32): position, bucket and item without a 64-bit shift and without a table
+          uint32_t ylo, yhi;
+          xs_hash_halves((uint32_t)key, (uint32_t)(key >> 32), xs_hi_mask, ylo, yhi);
+          b = funnel_r(yhi, ylo, bshift) & (nb - 1);
+          item = ((ylo & rest_mask) << g.rem_bits) | ((uint32_t)(key >> 32) >> (g.lsize_g - 32));
+        } else {
+          const uint64_t pos = NB < 0 ? xs_hash(key, g.lsize_g) : hash_tables_t<(NB < 0 ? 0 : NB)>(s_fwd, key, g.nbytes);
+          b = (uint32_t)(pos >> bshift) & (nb - 1);
+          if constexpr(sizeof(ITEM) == 4) item = (((uint32_t)pos & rest_mask) << g.rem_bits) | (uint32_t)(key >> g.lsize_g);      // (lsize_g <= 2k <= 42)
+          else item = make_item<ITEM>(g, P, key, pos & g.local_mask);
+        }
         const bool special = on && (item == hole || cnt > 1);        // (it would read as a hole; a run goes in at once)
         const bool normal = on && !special;
+#ifndef JFGPU_P1_LATE_SPECIAL
         if(special) straggler(b, item, cnt);                          // (rare; putting these off to one place after the round cost nine registers and 1.6 ms)
         const uint32_t o = atomicAdd(&s_fill[normal ? b : nb + (lane & 31u)], 1u);
         ea[e] = normal ? b * R::kSlots : dump; ei[e] = item; eo[e] = normal ? o : 0u;
+#else
+        // a special entry rides through the second sweep as a "ghost" of its own bucket: rank field full, its occurrences in
+        // the ring-position field; the sweep's rare branch puts it on the list
+        const uint32_t o = atomicAdd(&s_fill[normal ? b : nb + (lane & 31u)], 1u);
+        spm |= special ? 1u << e : 0u;
+        ea[e] = on ? b * R::kSlots : dump; ei[e] = item; eo[e] = normal ? o : special ? (R::kFull | ((cnt < 0xFFFFu ? cnt : 0xFFFFu) << 16)) : 0u;
+#endif
       };
 #pragma unroll
       for(int e = 0; e < RP; ++e) {
         const int j = j0 + e;
         const uint32_t c = (L.cur >> (2 * (15 - j))) & 3u;
-        if constexpr(NB >= 5) {
+        if constexpr(NB >= 5 || NB == kHashXS) {
           // keys of more than 32 bits (k >= 17): the two dwords by hand -- funnel shifts instead of 64-bit shifts, and the
           // new base of the reverse complement enters the high dword directly (rc_shift >= 32)
           const uint32_t flo = (uint32_t)fw, fhi = (uint32_t)(fw >> 32), rlo = (uint32_t)rc, rhi = (uint32_t)(rc >> 32);
@@ -338,7 +359,11 @@ __global__ __launch_bounds__(kPBlock) void p1_ring_kernel(DevTable T, DIRECT D, 
       }
       if(ghosts) {                                                  // rare: a ghost in its bucket's count until the owner's next release
 #pragma unroll 1
+#ifndef JFGPU_P1_LATE_SPECIAL
         for(int e = 0; e < NE; ++e) if(eo[e] & R::kFull) straggler(ea[e] / R::kSlots, ei[e], 1u);
+#else
+        for(int e = 0; e < NE; ++e) if(eo[e] & R::kFull) straggler(ea[e] / R::kSlots, ei[e], ((spm >> e) & 1u) ? eo[e] >> 16 : 1u);
+#endif
       }
       JF_PHASE(pc, 1);
       lds_barrier();                                               // the round's items have all landed: what is due goes out now

@@ -33,7 +33,7 @@ inline bool wide_geom_init(WideGeom& W, uint32_t k, uint32_t lsize_g, uint32_t c
   TableGeom& g = W.g;
   if(k < 33 || k > 64 || lsize_g > 63 || shard_bits > lsize_g || lsize_g - shard_bits < kMaxTileBits) return false;
   g.k = k; g.key_bits = 2 * k; g.lsize_g = lsize_g; g.lsize_l = lsize_g - shard_bits; g.shard_bits = shard_bits; g.shard_id = shard_id;
-  g.tile_bits = kMaxTileBits; g.slot32 = 0; g.pad_ = 0;
+  g.tile_bits = kMaxTileBits; g.slot32 = 0; g.hash_xs = 0;
   g.rem_bits = g.key_bits - lsize_g;
   W.tag_full = g.tile_bits + g.rem_bits;
   const uint32_t th = W.tag_full > 63 ? W.tag_full - 63 : 0;     // tag bits kept in the hi word

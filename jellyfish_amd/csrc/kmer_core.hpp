@@ -153,7 +153,7 @@ struct TableGeom {
   uint32_t nbytes;                // bytes of a key fed to the hash tables = ceil(2k/8)
   uint32_t canonical;
   uint32_t slot32;                // 1: slots are 32-bit words (same fields, cnt_bits = 31 - tag_bits)
-  uint32_t pad_;
+  uint32_t hash_xs;               // 1: the table's matrix is the xor-shift one (xs_hash below), so kernels may compute it in registers
   uint64_t key_mask, tile_mask, rem_mask, local_mask;
   uint64_t occ_bit, low_mask, inc, cnt_max;
 };
@@ -168,7 +168,7 @@ inline bool geom_init(TableGeom& g, uint32_t k, uint32_t lsize_g, uint32_t shard
   g.tile_bits = g.lsize_l < kMaxTileBits ? g.lsize_l : kMaxTileBits;
   g.rem_bits = g.key_bits - lsize_g;
   g.tag_bits = g.tile_bits + g.rem_bits;
-  g.slot32 = allow32 && g.tag_bits + 1 + kMinCountBits32 <= 32; g.pad_ = 0;
+  g.slot32 = allow32 && g.tag_bits + 1 + kMinCountBits32 <= 32; g.hash_xs = 0;
   if(!g.slot32 && g.tag_bits + 1 + kMinCountBits > 64) return false;
   g.cnt_bits = (g.slot32 ? 31 : 63) - g.tag_bits;
   g.nbytes = (g.key_bits + 7) / 8;
@@ -194,6 +194,15 @@ inline uint32_t geom_min_lsize(uint32_t k, uint32_t shard_bits) {
   return (uint32_t)need;
 }
 
+// (hi : lo) >> s, low dword, 0 <= s < 32 (v_alignbit_b32)
+JF_HD uint32_t funnel_r(uint32_t hi, uint32_t lo, uint32_t s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_alignbit(hi, lo, s);
+#else
+  return (uint32_t)((((uint64_t)hi << 32) | lo) >> (s & 31u));
+#endif
+}
+
 // pos = M * key via byte tables: tbl[b * 256 + v] = XOR of the columns selected by
 // byte b of the key having value v.  (H is linear over GF(2).)
 template <int NB>
@@ -212,14 +221,60 @@ JF_HD uint64_t hash_tables_n(const uint64_t* tbl, uint64_t key) {
   return ((uint64_t)phi << 32) | plo;
 }
 
-// (hi : lo) >> s, low dword, 0 <= s < 32 (v_alignbit_b32)
-JF_HD uint32_t funnel_r(uint32_t hi, uint32_t lo, uint32_t s) {
+// ---- the xor-shift matrix family (round 6) ----------------------------------------------------------------------
+// The file format takes ANY r x 2k matrix whose low r x r block is invertible (readers use the header's columns,
+// include/jellyfish/file_header.hpp:35-64; rectangular_binary_matrix.hpp:155-164 is a plain GF(2) product).  The
+// reference draws a random one, which a GPU can only apply through table look-ups: six random 8-byte LDS reads per k-mer
+// at k = 21, the bank conflicts and the waits behind them (profiles/r05_C2_sq_counters.txt).  This family is linear too --
+// every step below is an xor of shifted copies -- but is evaluated with eleven register instructions:
+//   r <= 32:  y = (key ^ key >> 9 ^ key >> 21) mod 2^r          the high key bits (those a slot stores) come down
+//             y ^= y << 13 ;  y ^= y << 7  (mod 2^r) ;  y ^= y >> 17
+//   r >  32:  lo = the same four steps mod 2^32                  (one dword of work)
+//             hi = (key >> 32 ^ lo >> 9) mod 2^(r - 32)           position = hi : lo
+// Restricted to the low r key bits, step one is unit upper triangular, the shift steps are invertible, and hi is the
+// key's own bits plus a function of lo: the low block is invertible by construction (and checked when a table is made).
+// The shifts were chosen on skewed, repeat-rich sequence (order-3 Markov chain + tandem repeats, 10 M distinct 21-mers):
+// P1 bucket and tile occupancies as even as under random matrices (structural excess <= 0.4 % at r = 26, 30, 34), where
+// the identity low block a CRC-like matrix has piles 36 x the mean into one tile.
+// gf2_matrix.hpp builds the matrix column by column from this very function, so tables, headers, look-ups and dumps
+// (which all go through the generic byte tables) agree with the kernels that evaluate it directly.
+constexpr uint32_t kXsR0a = 9, kXsR0b = 21, kXsL1 = 13, kXsL2 = 7, kXsR3 = 17, kXsFold = 9;
+JF_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return __builtin_amdgcn_alignbit(hi, lo, s);
+  return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
 #else
-  return (uint32_t)((((uint64_t)hi << 32) | lo) >> (s & 31u));
+  return a ^ b ^ c;
 #endif
 }
+JF_HD uint32_t xor_and(uint32_t a, uint32_t b, uint32_t mask) {        // (a ^ b) & mask
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_bitop3_b32(a, mask, b, 0x48);
+#else
+  return (a ^ b) & mask;
+#endif
+}
+// 32 < r < 64, on the two dwords of the key: hi_mask = 2^(r - 32) - 1
+JF_HD void xs_hash_halves(uint32_t klo, uint32_t khi, uint32_t hi_mask, uint32_t& ylo, uint32_t& yhi) {
+  uint32_t lo = xor3(klo, funnel_r(khi, klo, kXsR0a), funnel_r(khi, klo, kXsR0b));
+  lo ^= lo << kXsL1;
+  lo ^= lo << kXsL2;
+  lo ^= lo >> kXsR3;
+  ylo = lo; yhi = xor_and(khi, lo >> kXsFold, hi_mask);
+}
+JF_HD uint64_t xs_hash(uint64_t key, uint32_t r) {
+  if(r > 32) {
+    uint32_t lo, hi;
+    xs_hash_halves((uint32_t)key, (uint32_t)(key >> 32), r >= 64 ? 0xFFFFFFFFu : ((1u << (r - 32)) - 1u), lo, hi);
+    return ((uint64_t)hi << 32) | lo;
+  }
+  const uint32_t m = r >= 32 ? 0xFFFFFFFFu : ((1u << r) - 1u);
+  uint32_t y = (uint32_t)(key ^ (key >> kXsR0a) ^ (key >> kXsR0b)) & m;
+  y ^= (y << kXsL1) & m;
+  y ^= (y << kXsL2) & m;
+  y ^= y >> kXsR3;
+  return y;
+}
+constexpr int kHashXS = -1, kHashXSLow = -2;      // NB of the kernels' hash template: the position comes from xs_hash, no tables
 
 // NB > 0: the number of key bytes is a compile-time constant of the kernel (no per-k-mer switch);
 // NB == 0: decided at run time.

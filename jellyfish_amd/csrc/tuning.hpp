@@ -32,6 +32,7 @@ struct Tuning {
   bool wide_pipe = true;        // JFGPU_WIDE_PIPE=0      two-word keys: the round-2 tile kernel instead of the pipelined one (A/B)
   int p2_depth = 3;              // JFGPU_P2_DEPTH         rounds of items the loader waves of p2_ring_roles_kernel keep in flight (1, 2 or 3: 19.5 / 19.25 / 19.1 ms on the metric's job; A/B)
   int bloom_cache = -1;          // JFGPU_BLOOM_CACHE      count --bc: remember admitted k-mers (-1: when the first batches admit > 15 % of their windows, 0 never, 1 always)
+  int matrix = 0;                // JFGPU_MATRIX=xs|reference   the matrix family of tables created with matrix_kind 0 (0: not set -> the reference's)
   uint32_t bloom_cache_log2 = 28;// JFGPU_BLOOM_CACHE_LOG2 two-way sets of that cache (2^28 sets = 4 GB; tests: tiny caches evict all the time)
   // ---- Bloom counters (jfgpu_bloom_create)
   int bloom_mode = 0;            // JFGPU_BLOOM_MODE=direct|partitioned      0: not set
@@ -52,6 +53,7 @@ struct Tuning {
     auto str = [](const char* name) -> const char* { const char* e = getenv(name); return e && *e ? e : nullptr; };
     if(const char* e = str("JFGPU_MODE")) u.mode = !strcmp(e, "direct") ? 1 : !strcmp(e, "partitioned") ? 2 : 0;
     if(const char* e = str("JFGPU_SLOT64")) u.slot64 = atoi(e) != 0;
+    if(const char* e = str("JFGPU_MATRIX")) u.matrix = (!strcmp(e, "xs") || !strcmp(e, "xorshift")) ? 1 : (!strcmp(e, "reference") || !strcmp(e, "ref")) ? 2 : 0;
     if(const char* e = str("JFGPU_P1_SINGLE")) u.p1_single = atoi(e) ? 1 : 0;
     if(const char* e = str("JFGPU_P1_SLACK")) u.p1_slack = atof(e);
     if(const char* e = str("JFGPU_FLUSH_GROUPS")) u.flush_groups = std::max(1, atoi(e));
