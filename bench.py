@@ -49,6 +49,8 @@ CONFIGS = {
     "C2": dict(k=21, lsize=34, slot=8, name="BASELINE configs[1]: k=21 -C, {gbp:.1f} Gbp of 150 bp reads per GPU, 2^{lsize}-slot table per GPU in HBM ({slot_bytes}-byte slots)"),
     "C3": dict(k=31, lsize=33, slot=8, name="BASELINE configs[2]: k=31 -C, Bloom-counter pass (m = 14 x {gbp:.0f}e9 cells, 10 hashes) then count --bc, {gbp:.1f} Gbp of 150 bp reads, 2^{lsize}-slot table"),
     "C5": dict(k=63, lsize=33, slot=16, name="BASELINE configs[4]: k=63 -C (two-word keys), {gbp:.1f} Gbp of 150 bp reads, 2^{lsize}-slot 128-bit table in HBM"),
+    # not a BASELINE configuration: the plain count at the k most people use (8-byte items and slots), as a secondary of the default line
+    "K31": dict(k=31, lsize=33, slot=8, gbp=5.0, name="k=31 -C plain count (no filter), {gbp:.1f} Gbp of 150 bp reads, 2^{lsize}-slot table ({slot_bytes}-byte slots)"),
 }
 C4_NAME = ("BASELINE configs[3]: k=21 -C, {total:.1f} Gbp of 150 bp reads hash-prefix partitioned across {world} GPUs ({gbp:.1f} Gbp and a 2^{lsize}-slot "
            "shard per GPU, {slot_bytes}-byte slots), routed k-mers exchanged by RCCL over xGMI")
@@ -130,10 +132,11 @@ def read_digest(path):
     return tuple(int(l.split()[1]) for l in open(path).read().splitlines())
 
 
-def cpu_baseline(cfg, sample, k, tmpdir):
+def cpu_baseline(cfg, sample, k, tmpdir, job_load=0.5):
     """Reference CPU path (oracle/_ref: the reference's own classes, SSE2 hash like its configure enables) on a bounded
-    sample of the same reads.  Returns (dict for the JSON line, content digest of the reference's in-memory table after
-    counting the sample -- walked by its own iterators, `ref_jf count --digest` -- or None)."""
+    sample of the same reads, its table presized to the timed job's load factor (SURVEY 8(d) / BASELINE.md 3.2).  Returns
+    (dict for the JSON line, content digest of the reference's in-memory table after counting the sample -- walked by its
+    own iterators, `ref_jf count --digest` -- or None)."""
     import numpy as np
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_jf")
     n_reads = sample.shape[0]
@@ -151,9 +154,13 @@ def cpu_baseline(cfg, sample, k, tmpdir):
     write_fasta(sample, fa)
     ncpu = os.cpu_count() or 1
     best_t = min(ncpu, 64)                       # measured on 2 x EPYC 9575F: -t 64 beats -t 256 (profiles/r02_call2_*.log)
-    size = 1
-    while size < 2 * kmers:                      # presized, load ~0.5 like the full job's table
-        size <<= 1
+
+    def presize(n_kmers):                        # smallest power of two that keeps the load at or below the job's (1 % tolerance)
+        size = 1
+        while n_kmers > size * job_load * 1.01:
+            size <<= 1
+        return size
+    size = presize(kmers)
     res = {"unit": "k-mers/s", "kind": "reference"}
     if cfg == "C3":
         bc = os.path.join(tmpdir, "ref.bc")
@@ -172,33 +179,37 @@ def cpu_baseline(cfg, sample, k, tmpdir):
     t_best, mers, out = ref_count(ref, [fa], k, size, best_t, tmpdir, digest=dgp)
     assert mers == kmers
     stats = read_digest(dgp)
-    res.update({"value": kmers / t_best, "cores": best_t,
-                "sample": "first %d reads (%.0f Mbp) of the same synthetic input, jellyfish 2.3.1 classes (oracle/_ref, -DHAVE_SSE -msse2), "
-                          "-t %d, table presized 2^%d (load %.2f), Counting phase only.  The sample's table is %.1f GB as the reference packs it, against "
-                          "~50 GB at the full job's 2^34 slots: cache- and TLB-friendlier than C2 scale, so this flatters the CPU if anything"
-                          % (n_reads, n_reads * READ_LEN / 1e6, best_t, size.bit_length() - 1, kmers / size, size * 25.0 / 8 / 1e9)})
+    res.update({"value": kmers / t_best, "cores": best_t, "sample_gbp": n_reads * READ_LEN / 1e9, "table_log2": size.bit_length() - 1, "load": kmers / size, "job_load": job_load,
+                "sample": "first %d reads (%.2f Gbp) of the same synthetic input, jellyfish 2.3.1 classes (oracle/_ref, -DHAVE_SSE -msse2), -t %d, table presized "
+                          "2^%d = load %.2f (the timed job's: %.2f), Counting phase only (SURVEY 8(d): >= 1 Gbp at the job's load factor; the reference's table "
+                          "for it is %.1f GB as it packs entries)" % (n_reads, n_reads * READ_LEN / 1e9, best_t, size.bit_length() - 1, kmers / size, job_load, size * 25.0 / 8 / 1e9)})
     if cfg == "C2":
-        variants = {}
-        # one thread, on a tenth of the sample (same table, so the load factor is lower: stated)
-        n1 = max(1, n_reads // 10)
-        fa1 = os.path.join(tmpdir, "s1.fa")
-        write_fasta(sample[:n1], fa1)
-        t1, m1, o1 = ref_count(ref, [fa1], k, size // 8, 1, tmpdir, ["--no-write"])
-        variants["t1"] = {"kmers_per_s": m1 / t1, "threads": 1, "sample_reads": n1}
-        if ncpu > best_t:
-            ta, ma, oa = ref_count(ref, [fa], k, size, ncpu, tmpdir, ["--no-write"])
-            variants["t_nproc"] = {"kmers_per_s": ma / ta, "threads": ncpu}
-        # -F 4: the single serial parser is the reference's bottleneck at high thread counts; four files, four parsers
+        variants = {"one_file": {"kmers_per_s": kmers / t_best, "threads": best_t, "sample_reads": n_reads, "load": kmers / size}}
+        # -F 4 on the same sample, same table: the single serial parser is the reference's bottleneck at high thread counts
         parts = []
         for i in range(4):
             p = os.path.join(tmpdir, "q%d.fa" % i)
             write_fasta(sample[n_reads * i // 4: n_reads * (i + 1) // 4], p)
             parts.append(p)
         tf, mf, of = ref_count(ref, parts, k, size, best_t, tmpdir, ["-F", "4", "--no-write"])
-        variants["F4"] = {"kmers_per_s": mf / tf, "threads": best_t, "files": 4}
+        variants["F4"] = {"kmers_per_s": mf / tf, "threads": best_t, "files": 4, "sample_reads": n_reads, "load": mf / size}
+        # one thread and every hardware thread: on a 165 Mbp cut of the sample (a table of its own at the same load) -- minutes otherwise
+        n_small = min(n_reads, 1100000)
+        fas = os.path.join(tmpdir, "small.fa")
+        write_fasta(sample[:n_small], fas)
+        ks = n_small * (READ_LEN - k + 1)
+        n1 = max(1, n_small // 10)
+        fa1 = os.path.join(tmpdir, "s1.fa")
+        write_fasta(sample[:n1], fa1)
+        t1, m1, o1 = ref_count(ref, [fa1], k, presize(n1 * (READ_LEN - k + 1)), 1, tmpdir, ["--no-write"])
+        variants["t1"] = {"kmers_per_s": m1 / t1, "threads": 1, "sample_reads": n1, "load": m1 / presize(m1)}
+        if ncpu > best_t:
+            ta, ma, oa = ref_count(ref, [fas], k, presize(ks), ncpu, tmpdir, ["--no-write"])
+            variants["t_nproc"] = {"kmers_per_s": ma / ta, "threads": ncpu, "sample_reads": n_small, "load": ma / presize(ks)}
         res["variants"] = variants
-        res["value"] = max([res["value"]] + [v["kmers_per_s"] for v in variants.values()])     # the reference at its best on this box
-        res["value_is"] = "best of: -t %d one file; %s" % (best_t, ", ".join(sorted(variants)))
+        full = {nm: v for nm, v in variants.items() if v["sample_reads"] == n_reads}
+        res["value"] = max(v["kmers_per_s"] for v in full.values())     # the reference at its best on the 8(d) sample
+        res["value_is"] = "best of the runs on the whole sample: %s (t1 / t_nproc, on smaller cuts, are in `variants` only)" % ", ".join(sorted(full))
     return res, stats
 
 
@@ -270,7 +281,7 @@ def plan(args):
     cfg = args.config
     if world > 1 and cfg != "C2":
         raise SystemExit("--config %s is a single-GPU configuration (BASELINE.json)" % cfg)
-    gbp = args.gbp or (GBP_PER_GPU_SHARDED if world > 1 else 10.0)
+    gbp = args.gbp or (GBP_PER_GPU_SHARDED if world > 1 else CONFIGS[cfg].get("gbp", 10.0))
     K = CONFIGS[cfg]["k"]
     lsize = args.lsize or CONFIGS[cfg]["lsize"]
     n_reads = int(round(gbp * 1e9 / READ_LEN))
@@ -279,7 +290,7 @@ def plan(args):
     table = (1 << lsize) * slot_bytes
     reads = n_reads * stride
     kmers = n_reads * (READ_LEN - K + 1)
-    item = 4 if cfg == "C2" else (8 if cfg == "C3" else 16)
+    item = 4 if cfg == "C2" else (8 if cfg in ("C3", "K31") else 16)
     workspace = int(kmers * item * (2.3 if world == 1 else 3.4))       # P1 regions + P2 regions (+ routed regions and what arrived, sharded)
     exchange = None
     if world > 1:
@@ -319,7 +330,12 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="C2")
     ap.add_argument("--gbp", type=float, default=0.0, help="giga-bases of reads per GPU (default: 10 at N = 1, 12.5 at N > 1)")
     ap.add_argument("--lsize", type=int, default=0, help="log2 slots per GPU (default: the configuration's)")
-    ap.add_argument("--cpu-sample-reads", type=int, default=1100000, help="reads of the CPU-baseline sample (165 Mbp: load 0.53 in the reference's 2^28 table at k = 21; enough k-mers per P1 bucket for the engine's single-pass partition kernels, the timed job's, to take it)")
+    ap.add_argument("--cpu-sample-reads", type=int, default=0,
+                    help="reads of the CPU-baseline sample; 0 = SURVEY 8(d)'s protocol: at least 1 Gbp of the same reads, as many as put the reference's "
+                         "power-of-two table at the timed job's own load factor (C2: 8.26 M reads = 1.24 Gbp into 2^31 slots, load 0.50)")
+    ap.add_argument("--matrix", choices=["xs", "reference"], default="xs",
+                    help="hash matrix family of the table (include/jfgpu.h: JFGPU_MATRIX_*): xs = the xor-shift matrix the partition kernel evaluates in "
+                         "registers; reference = the matrix `jellyfish count` itself draws (file bodies byte-identical to the reference's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--repeats", type=int, default=5, help="how many times the whole job is run in all (first = the contract's timed region)")
     ap.add_argument("--no-extras", action="store_true", help="skip flush sweep, end-to-end and the secondary configurations (quick runs, profiling)")
@@ -344,7 +360,7 @@ def main():
         import torch
         shared = -(-args.gpus // max(torch.cuda.device_count(), 1))
     if not args.gbp:
-        args.gbp = GBP_PER_GPU_SHARDED if args.gpus > 1 else 10.0
+        args.gbp = GBP_PER_GPU_SHARDED if args.gpus > 1 else CONFIGS[args.config].get("gbp", 10.0)
         if shared > 1:                               # what fits `shared` ranks' tables, inputs and workspaces in one HBM
             args.gbp = 10.0 / shared
             if not args.lsize:
@@ -387,8 +403,9 @@ def main():
     steps, warmup = args.steps, args.warmup
     stride = READ_LEN + 1
     kmers_per_read = READ_LEN - K + 1
-    t = capi.Table(K, 1 << (lsize + sb), canonical=True, device=local_rank, shard_bits=sb, shard_id=rank)
+    t = capi.Table(K, 1 << (lsize + sb), canonical=True, device=local_rank, shard_bits=sb, shard_id=rank, matrix_kind=args.matrix)
     lsize = t.info.lsize - sb                        # the engine may raise a size below the slot format's minimum
+    t_info_xs = bool(t.matrix_is_xorshift())
     slot_bytes = t.info.slot_bytes
     buf = t.malloc(n_reads * stride + 16)            # plain device memory through the C ABI
     device_sync()
@@ -400,7 +417,16 @@ def main():
 
     def reads_to_host(a, b):                         # reads [a, b) as a (b - a, stride) uint8 array
         return t.d2h(buf + a * stride, (b - a) * stride).reshape(b - a, stride)
-    ns = min(args.cpu_sample_reads, n_reads)
+    ns = args.cpu_sample_reads
+    if not ns and cfg != "C2":
+        ns = 1100000                                 # (C3 / C5 run as secondaries without a CPU leg; asked for directly: 165 Mbp)
+    if not ns:      # "the first 1 Gbp at identical table load factor" -- the smallest power-of-two table that holds >= 1 Gbp at the job's load
+        job_load = n_reads * kmers_per_read / float(1 << lsize)
+        sz = 1
+        while sz * job_load < 1e9 / READ_LEN * kmers_per_read:
+            sz <<= 1
+        ns = int(sz * job_load / kmers_per_read)
+    ns = min(ns, n_reads)
     sample = reads_to_host(0, ns) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
 
     bounds = [n_reads * i // steps for i in range(steps + 1)]
@@ -451,7 +477,7 @@ def main():
         if world > 1:
             dist.barrier()
 
-    def job(n_steps, flushes=1):
+    def job(n_steps, flushes=1, wall=None):
         """n_steps batches through the whole path of this configuration (both passes for C3), applied and synchronised."""
         if cfg == "C3":
             t.attach_bloom(None)
@@ -464,6 +490,8 @@ def main():
             if sharded:
                 p, n = batch(i)
                 comm.step(t, p, n)
+                if wall is not None:
+                    wall.append(time.perf_counter())
             else:
                 p, n = batch(i)
                 t.count_ascii_dev(p, n)
@@ -483,9 +511,13 @@ def main():
     if bloom is not None:
         bloom.profile_enable(True); bloom.profile_reset()
     fence()
+    if comm is not None:
+        comm.exchange_times()                        # (drops what the warm-up logged)
+    step_wall = []                                   # host time at which every step's call returned (the calls only enqueue: a step that blocks shows here)
     t0 = time.perf_counter()
-    job(steps)
+    job(steps, wall=step_wall)
     elapsed = time.perf_counter() - t0
+    my_elapsed = elapsed
     t.profile_enable(False)
     if bloom is not None:
         bloom.profile_enable(False)
@@ -493,6 +525,32 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+
+    # ---- N-rank runs: what every rank did in every step, so that one record says where a slow run loses its time ----
+    per_rank = None
+    if sharded:
+        spans = t.profile_spans()
+        xt = comm.exchange_times()
+        names = {1: "split", 2: "route", 4: "p1", 5: "p2", 6: "tile", 7: "direct"}
+        sums = {}
+        for w_, ms_ in spans:
+            nm = names.get(w_, "slot%d" % w_)
+            sums[nm] = sums.get(nm, 0.0) + ms_
+        cw, cr = comm.world_rank()
+        mine = {"rank": rank, "comm_world": cw, "comm_rank": cr, "device": local_rank, "elapsed_s": round(my_elapsed, 4),
+                "device_ms": {k_: round(v_, 2) for k_, v_ in sorted(sums.items())},
+                "route_ms_per_launch": [round(ms_, 2) for w_, ms_ in spans if w_ == 2],
+                "split_ms_per_launch": [round(ms_, 2) for w_, ms_ in spans if w_ == 1],
+                "exchange_ms_per_step": [round(a, 2) for a, b_ in xt], "exchange_wire_MB_per_step": [round(b_ / 1e6, 1) for a, b_ in xt],
+                "exchange_GB_per_s": [round(b_ / 1e9 / (a * 1e-3), 1) if a > 0 else None for a, b_ in xt],
+                "step_call_returned_at_ms": [round((w_ - t0) * 1e3, 1) for w_ in step_wall],
+                "transport": os.environ.get("JFGPU_COMM_TRANSPORT", "rccl")}
+        if world > 1:
+            gathered = [None] * world if rank == 0 else None
+            dist.gather_object(mine, gathered, dst=0)
+            per_rank = gathered
+        else:
+            per_rank = [mine]
 
     # size-independent invariants of the timed job: every window was seen exactly once; unfiltered runs counted them all
     st = t.stats()
@@ -562,6 +620,9 @@ def main():
             "config": {"workload": (CONFIGS[cfg]["name"].format(gbp=args.gbp, lsize=lsize, slot_bytes=slot_bytes) if world == 1 else
                                     C4_NAME.format(total=args.gbp * world, world=world, gbp=args.gbp, lsize=lsize, slot_bytes=slot_bytes)) +
                                    ("" if args.dist == "U" else "; SECONDARY distribution G (reads from a 100 Mbp random genome, 1 % substitutions)"),
+                       "matrix": {"xs": "xor-shift family (jfgpu.h JFGPU_MATRIX_XORSHIFT): evaluated in registers by the partition kernel; any matrix with an invertible low block is "
+                                        "legal for the file format, readers take it from the header", "reference": "the reference's own draw (JFGPU_MATRIX_REFERENCE): byte-identical file bodies"}[args.matrix]
+                                  if t_info_xs == (args.matrix == "xs") else "reference family (the xor-shift one is defined for one-word keys)",
                        "id": cfg if world == 1 else "C4", "k": K, "read_len": READ_LEN, "reads_per_gpu": n_reads, "table_slots_per_gpu": 1 << lsize, "slot_bytes": slot_bytes,
                        "load_factor": float(tot[1]) / float(world << lsize),
                        "distinct": int(tot[1]), "total_kmers": total_kmers,
@@ -585,6 +646,7 @@ def main():
                                  "whatever the slot width in use (config.slot_bytes); design_min_bytes_per_kmer is what this three-stage design "
                                  "cannot go below (input + the 4-byte item written by P1, read and written by P2, read by T + every slot of the table written once)",
                          "design_min_bytes_per_kmer": DESIGN_MIN_BYTES.get(cfg),
+                         "per_rank": per_rank,
                          "gups_atomic_add": gups.get("atomic_add"), "gups_atomic_cas": gups.get("atomic_cas"),
                          "value_over_gups": value / world / gups["atomic_cas"] if gups.get("atomic_cas") else None},
         }
@@ -709,11 +771,14 @@ def main():
                                              "Init / Counting / Writing as count_main.cc:375-382 reports them; Counting = host read, host->device copy, device parse, count "
                                              "(PCIe-inclusive, never `value`); Writing = device sort + copy + %.1f GB of records into one file on /dev/shm (the file system's "
                                              "single-file write rate is the limit: profiles/r04_cli_writing.log)" % (fbytes / 1e9, obytes / 1e9)}
+                out["roofline"]["end_to_end"] = {"counting_s": cs, "kmers_per_s": total_kmers / cs, "writing_s": ws, "init_s": float(tm["Init"]),
+                                                 "file_GB_per_s": fbytes / cs / 1e9, "output_GB_per_s": obytes / ws / 1e9,
+                                                 "what": "`jellyfish-amd count` from a FASTA file in /dev/shm, Counting phase PCIe- and parse-inclusive (SURVEY 8(d)'s first number; never `value`)"}
             t = None
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         with tempfile.TemporaryDirectory() as td:
-            base, ref_stats = cpu_baseline(cfg, sample, K, td)
+            base, ref_stats = cpu_baseline(cfg, sample, K, td, job_load=n_reads * kmers_per_read / float(1 << lsize))
         out["cpu_baseline"] = base
         if ref_stats is not None:       # bit-exactness on the very sample the CPU counted: per-k-mer content, not aggregates
             mine = sample_digest
@@ -736,8 +801,11 @@ def main():
         # C5, C3: BASELINE configs[4] and [2] on the metric's uniform reads; C2_G, C3_G: the same engine on BASELINE.md's secondary
         # distribution (reads from a 100 Mbp genome, 1 % substitutions, ~100 x coverage), each job run twice with the table
         # digest asserted equal (the check that found the tile stage's race in round 3)
-        for name, c, extra in (("C5", "C5", []), ("C3", "C3", []), ("C2_G", "C2", ["--dist", "G", "--repeats", "2"]), ("C3_G", "C3", ["--dist", "G", "--repeats", "2"])):
+        for name, c, extra in (("C5", "C5", []), ("C3", "C3", []), ("C2_G", "C2", ["--dist", "G", "--repeats", "2"]), ("C3_G", "C3", ["--dist", "G", "--repeats", "2"]),
+                               ("K31", "K31", []), ("C2_reference_matrix", "C2", ["--matrix", "reference"])):
             try:
+                if "--matrix" not in extra:
+                    extra = extra + ["--matrix", args.matrix]
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", c, "--as-secondary", "--steps", str(steps), "--warmup", str(warmup)] + extra,
                                    capture_output=True, text=True, timeout=900, preexec_fn=_all_cpus)
                 line = [l for l in r.stdout.splitlines() if l.startswith("{")]

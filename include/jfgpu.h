@@ -184,6 +184,11 @@ int  jfgpu_comm_finish(jfgpu_comm* c, uint64_t* sent, uint64_t* received);
 int  jfgpu_comm_allreduce_u64(jfgpu_comm* c, uint64_t* values, int n, int op);
 int  jfgpu_comm_allgather_u64(jfgpu_comm* c, uint64_t mine, uint64_t* all);
 int  jfgpu_comm_world(const jfgpu_comm* c, int* world, int* rank);
+/* Exchange timing (measurement helper): device time of every exchange since the communicator was created or this was last
+ * called -- from the moment the routed data of a step was ready on the exchange stream to the moment everything of that
+ * step had been sent and received -- and the bytes this rank put on the wires for it (its own share does not travel).
+ * Waits for the exchange stream.  *n = exchanges recorded; at most cap entries are written; the log is cleared. */
+int  jfgpu_comm_exchange_times(jfgpu_comm* c, double* ms, uint64_t* wire_bytes, size_t cap, size_t* n);
 
 /* ---- results path ------------------------------------------------------ */
 int  jfgpu_stats_compute(jfgpu_table* t, uint64_t lower, uint64_t upper, jfgpu_stats* out);
@@ -369,6 +374,10 @@ int  jfgpu_parser_last_ms(jfgpu_parser* p, double* ms);
 int  jfgpu_profile_enable(jfgpu_table* t, int on);
 int  jfgpu_profile_get(jfgpu_table* t, int which, double* ms, uint64_t* launches, uint64_t* units);
 int  jfgpu_profile_reset(jfgpu_table* t);
+/* The same spans one by one, in launch order, since the last reset (at most 65536 are kept): which[i] is the slot above,
+ * ms[i] the span's device time.  *n = spans recorded (may exceed cap: only cap are written).  bench.py --gpus N rebuilds
+ * every step's route / split / partition / insert times from it, per rank. */
+int  jfgpu_profile_spans(jfgpu_table* t, int* which, double* ms, size_t cap, size_t* n);
 /* The engine's event counters since the last jfgpu_clear, after waiting for the table's stream (tests assert from them
  * which code path a flush took; `jellyfish-amd count --timing` reports them).  out[0..n): 0 tile-full events ("Hash
  * full" is raised from it), 1 k-mer occurrences fed, 2 overflow side table full, 3 side-table entries, 4 k-mers sent to

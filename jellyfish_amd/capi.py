@@ -83,6 +83,8 @@ SIGNATURES = {
     "jfgpu_comm_allreduce_u64": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "jfgpu_comm_allgather_u64": (C.c_int, [_P, C.c_uint64, _P]),
     "jfgpu_comm_world": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "jfgpu_comm_exchange_times": (C.c_int, [_P, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "jfgpu_profile_spans": (C.c_int, [_P, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "jfgpu_stats_compute": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.POINTER(Stats)]),
     "jfgpu_digest": (C.c_int, [_P, C.c_uint64, C.c_uint64, _P]),
     "jfgpu_histo": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64, _P, C.c_uint64]),
@@ -190,11 +192,39 @@ def _ptr(x):
     raise TypeError(type(x))
 
 
+def xs_hash(key, r, key_bits=42):
+    """kmer_core.hpp: xs_hash -- the xor-shift matrix family as a function (python ints, one-word keys)."""
+    m32 = 0xFFFFFFFF
+    y0 = key ^ (key >> 9) ^ (key >> 21) ^ ((key >> 32) if key_bits > 53 else 0)
+    if r > 32:
+        lo = y0 & m32
+        lo ^= (lo << 13) & m32
+        lo ^= (lo << 7) & m32
+        lo ^= lo >> 17
+        hi = ((key >> 32) ^ (lo >> 9)) & ((1 << (r - 32)) - 1)
+        return (hi << 32) | lo
+    m = (1 << r) - 1
+    y = y0 & m
+    y ^= (y << 13) & m
+    y ^= (y << 7) & m
+    y ^= y >> 17
+    return y
+
+
+def xs_hash_wide(lo, hi, r):
+    """kmer_core.hpp: xs_hash_wide -- two-word keys folded to one word, then xs_hash."""
+    m64 = (1 << 64) - 1
+    return xs_hash(lo ^ hi ^ (((hi << 25) | (hi >> 39)) & m64), r, 64)
+
+
+MATRIX_KINDS = {"default": 0, "xs": 1, "xorshift": 1, "reference": 2}      # include/jfgpu.h: JFGPU_MATRIX_*
+
+
 class Table:
     """One hash shard in one GPU's HBM (jfgpu_table*)."""
 
     def __init__(self, k, size, canonical=True, device=-1, shard_bits=0, shard_id=0, matrix_seed=0,
-                 matrix_columns=None, out_counter_len=4):
+                 matrix_columns=None, out_counter_len=4, matrix_kind=0):
         self._lib = load()
         p = Params()
         p.k, p.canonical, p.size, p.device = k, int(bool(canonical)), int(size), device
@@ -204,6 +234,7 @@ class Table:
             self._cols = np.ascontiguousarray(matrix_columns, dtype=np.uint64)
             p.matrix_columns = self._cols.ctypes.data_as(C.POINTER(C.c_uint64))
         p.out_counter_len = out_counter_len
+        p.matrix_kind = MATRIX_KINDS[matrix_kind] if isinstance(matrix_kind, str) else int(matrix_kind)
         h = _P()
         _check(self._lib.jfgpu_create(C.byref(p), C.byref(h)))
         self._h = h
@@ -211,6 +242,16 @@ class Table:
         _check(self._lib.jfgpu_get_info(self._h, C.byref(self.info)))
         self.k = k
         self.key_words = (2 * k + 63) // 64
+
+    def matrix_is_xorshift(self):
+        """Is the table's matrix the xor-shift family's member for its shape?  (restated here from jellyfish_amd/csrc/kmer_core.hpp:
+        xs_hash, for reporting; the engine decides for itself)"""
+        cols = self.matrix()
+        r, c = int(self.info.lsize), int(self.info.key_len)
+        if c > 128 or r >= c or r >= 64:
+            return False
+        img = lambda j: xs_hash(1 << j, r, c) if c <= 64 else (xs_hash_wide(1 << j, 0, r) if j < 64 else xs_hash_wide(0, 1 << (j - 64), r))
+        return all(int(cols[c - 1 - j]) == img(j) for j in range(c))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -353,6 +394,15 @@ class Table:
     def profile_reset(self):
         _check(self._lib.jfgpu_profile_reset(self._h))
 
+    def profile_spans(self, cap=65536):
+        """[(slot, device ms), ...] of every profiled launch since the last reset, in launch order (jfgpu_profile_spans)."""
+        which = np.zeros(cap, dtype=np.int32)
+        ms = np.zeros(cap, dtype=np.float64)
+        n = C.c_size_t()
+        _check(self._lib.jfgpu_profile_spans(self._h, which.ctypes.data, ms.ctypes.data, cap, C.byref(n)))
+        k = min(n.value, cap)
+        return list(zip(which[:k].tolist(), ms[:k].tolist()))
+
     COUNTER_NAMES = ("full", "mers", "ovf_full", "ovf_used", "misrouted", "direct", "t_items", "t_queued", "flushes_plain", "flushes_heavy",
                      "p2_roles", "p2_ring", "p2_sort", "p2_exact", "p1_ring", "p1_other")
 
@@ -450,6 +500,21 @@ class Comm:
             _check(self._lib.jfgpu_comm_bc_merge_local(self._h, arr))
         else:
             _check(self._lib.jfgpu_comm_bc_merge(self._h, blooms._h))
+
+    def world_rank(self):
+        """(world, rank) as the communicator itself knows them (jfgpu_comm_world)."""
+        w, r = C.c_int(), C.c_int()
+        _check(self._lib.jfgpu_comm_world(self._h, C.byref(w), C.byref(r)))
+        return w.value, r.value
+
+    def exchange_times(self, cap=65536):
+        """[(device ms, bytes this rank sent over the wires), ...] of every exchange since the last call (jfgpu_comm_exchange_times)."""
+        ms = np.zeros(cap, dtype=np.float64)
+        by = np.zeros(cap, dtype=np.uint64)
+        n = C.c_size_t()
+        _check(self._lib.jfgpu_comm_exchange_times(self._h, ms.ctypes.data, by.ctypes.data, cap, C.byref(n)))
+        k = min(n.value, cap)
+        return list(zip(ms[:k].tolist(), by[:k].tolist()))
 
     def allgather(self, mine):
         a = np.zeros(self.world, dtype=np.uint64)

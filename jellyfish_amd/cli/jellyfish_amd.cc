@@ -358,6 +358,7 @@ int count_main(int argc, char* argv[]) {
   int device = -1, min_qual = 0, quality_start = 64, min_quality = 0;
   unsigned gpus = 1; bool gpus_given = false;
   bool min_qual_char_given = false, min_quality_given = false;
+  uint32_t matrix_kind = JFGPU_MATRIX_DEFAULT;
   std::string output = "mer_counts.jf", timing, bc_path, generator, shell, digest_path;
   std::vector<std::string> files, if_files;
   ArgCursor a{argc, argv};
@@ -380,6 +381,12 @@ int count_main(int argc, char* argv[]) {
     else if(a.is("", "--device")) device = atoi(a.value("", "--device").c_str());
     else if(a.is("", "--gpus")) { gpus = (unsigned)strtoul(a.value("", "--gpus").c_str(), 0, 10); gpus_given = true; }
     else if(a.is("", "--bc")) bc_path = a.value("", "--bc");
+    else if(a.is("", "--matrix")) {                          // hash matrix family (jfgpu.h: JFGPU_MATRIX_*); the file header carries the matrix either way
+      const std::string v = a.value("", "--matrix");
+      if(v == "xs" || v == "xorshift") matrix_kind = JFGPU_MATRIX_XORSHIFT;
+      else if(v == "reference") matrix_kind = JFGPU_MATRIX_REFERENCE;
+      else die("--matrix must be xs or reference");
+    }
     else if(a.is("", "--digest")) digest_path = a.value("", "--digest");   // content checksum of the table (jfgpu_digest), for at-scale parity checks
     else if(a.cur() == "-C" || a.cur() == "--canonical") canonical = true;
     else if(a.cur() == "--text") text = true;
@@ -420,7 +427,9 @@ int count_main(int argc, char* argv[]) {
                    "     --timing=Timing file    Print timing information\n"
                    "     --device=int            HIP device ordinal (current)\n"
                    "     --gpus=N                Spread the table over N GPUs (a power of two), one process each\n"
-                   "     --host-parse            Parse the sequence files on the host (default: on the device)\n";
+                   "     --host-parse            Parse the sequence files on the host (default: on the device)\n"
+                   "     --matrix=xs|reference   Hash matrix family: xs = evaluated in registers by the GPU kernels (fastest);\n"
+                   "                             reference = the matrix jellyfish itself draws (byte-identical files; default)\n";
       return 0;
     } else if(a.cur().size() > 1 && a.cur()[0] == '-' && a.cur() != "-") die("Unknown option '" + a.cur() + "'");
     else files.push_back(a.cur());
@@ -476,7 +485,7 @@ int count_main(int argc, char* argv[]) {
   init_mark("options parsed");
   std::unique_ptr<mer_hash> ary;
   try {
-    ary.reset(new mer_hash(size, mer_len * 2, counter_len, threads, reprobes, canonical, device, out_counter_len, 0, shard_bits, (uint32_t)renv.rank));
+    ary.reset(new mer_hash(size, mer_len * 2, counter_len, threads, reprobes, canonical, device, out_counter_len, 0, shard_bits, (uint32_t)renv.rank, matrix_kind));
   } catch(std::exception& e) { die(std::string("Failed to allocate the hash: ") + e.what()); }
   init_mark("table created (allocated and cleared)");
   if(disk) ary->do_size_doubling(false);

@@ -300,15 +300,23 @@ int jfgpu_bc_profile_reset(jfgpu_bloom* b) {
 int jfgpu_attach_bloom(jfgpu_table* t, jfgpu_bloom* b) {   // count --bc (count_main.cc:191-206,313-316)
   int rc = use(t); if(rc) return rc;
   rc = part_flush(t); if(rc) return rc;
+  // (the new counter is looked at BEFORE anything of the old attachment is given up: a refused counter leaves the table as
+  // it was -- round-5 advisor finding: the cache used to be freed first, and a refusal left the old view pointing at it)
+  if(b) {
+    if(b->device != t->device) return fail(JFGPU_E_INVALID, "Bloom counter lives on another device");
+    if(b->g.k != t->g.k) return fail(JFGPU_E_INVALID, "Invalid mer length in bloom filter");
+    // a shard: the counter is asked on the sending side of the exchange (abi_comm.inl: comm_filter_ok), never on arrival
+    if(t->g.shard_bits && (t->wide || b->kind != 0)) return fail(JFGPU_E_UNSUPPORTED, "sharded tables take a Bloom counter (count --bc) with one-word keys only");
+    if(t->nword) return fail(JFGPU_E_UNSUPPORTED, "Bloom filters for mer length > 64 are not built");
+  }
   // the cache of admitted k-mers belongs to one attachment: its answers are this counter's
-  if(t->d_bcache) { HIP_TRY(hipStreamSynchronize(t->stream)); hipFree(t->d_bcache); t->d_bcache = nullptr; }
+  if(t->d_bcache) {
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    t->dt.bloom.cache = nullptr; t->dt.bloom.cache_mask = 0;
+    hipFree(t->d_bcache); t->d_bcache = nullptr;
+  }
   t->bcache_state = 0;
   if(!b) { memset(&t->dt.bloom, 0, sizeof t->dt.bloom); memset(&t->wt.bloom, 0, sizeof t->wt.bloom); return JFGPU_OK; }
-  if(b->device != t->device) return fail(JFGPU_E_INVALID, "Bloom counter lives on another device");
-  if(b->g.k != t->g.k) return fail(JFGPU_E_INVALID, "Invalid mer length in bloom filter");
-  // a shard: the counter is asked on the sending side of the exchange (abi_comm.inl: comm_filter_ok), never on arrival
-  if(t->g.shard_bits && (t->wide || b->kind != 0)) return fail(JFGPU_E_UNSUPPORTED, "sharded tables take a Bloom counter (count --bc) with one-word keys only");
-  if(t->nword) return fail(JFGPU_E_UNSUPPORTED, "Bloom filters for mer length > 64 are not built");
   rc = bloom_flush(b); if(rc) return rc;
   HIP_TRY(hipStreamSynchronize(b->stream));
   if(t->wide) t->wt.bloom = b->view(); else t->dt.bloom = b->view();

@@ -65,7 +65,12 @@ struct jfgpu_comm {
     hipEvent_t route_done = nullptr;
     size_t route_n = 0;                          // its input bytes
     const uint32_t* self_items[2] = {nullptr, nullptr};   // item path, RCCL transport: the rank's own share is read where the routing left it (send[turn]), not copied
+    // exchange timing (jfgpu_comm_exchange_times): a pair of timing events per turn, open while its exchange may be running
+    hipEvent_t x_begin[2] = {nullptr, nullptr}, x_end[2] = {nullptr, nullptr};
+    bool x_open[2] = {false, false}; uint64_t x_seq[2] = {0, 0}, x_bytes[2] = {0, 0};
   };
+  uint64_t x_next = 0;                           // exchanges started so far
+  std::vector<std::pair<double, uint64_t>> x_log;   // (device ms, bytes this rank sent over the wires) per exchange, in order
 #if !defined(JFGPU_EMU)
   // "ipc" transport (see the head of this file)
   IpcShared* shm = nullptr; std::string shm_name;
@@ -100,6 +105,8 @@ int comm_init_rank(jfgpu_comm* c, jfgpu_comm::Rank& R) {
     HIP_TRY(hipEventCreateWithFlags(&R.exchanged[i], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&R.consumed[i], hipEventDisableTiming));
     R.scount[i].assign(c->world, 0); R.soff[i].assign(c->world + 1, 0); R.rcount[i].assign(c->world, 0); R.roff[i].assign(c->world + 1, 0);
+    HIP_TRY(hipEventCreate(&R.x_begin[i]));
+    HIP_TRY(hipEventCreate(&R.x_end[i]));
   }
   HIP_TRY(hipMalloc((void**)&R.d_cnt, sizeof(unsigned long long) * c->world));
   HIP_TRY(hipMalloc((void**)&R.d_xc, sizeof(uint64_t) * 2 * c->world));
@@ -485,6 +492,26 @@ int comm_insert_prev(jfgpu_comm* c, jfgpu_comm::Rank& R) {
 #endif
 
 // The exchange of the current step for the RCCL transport: counts (host-visible), then the keys in rounds.
+// exchange timing: harvest a turn's finished pair (the caller knows its exchange is over), open it for the next one
+void comm_x_harvest(jfgpu_comm* c, jfgpu_comm::Rank& R, int turn) {
+  if(!R.x_open[turn]) return;
+  float ms = 0;
+  if(hipEventSynchronize(R.x_end[turn]) == hipSuccess && hipEventElapsedTime(&ms, R.x_begin[turn], R.x_end[turn]) == hipSuccess && c->x_log.size() < ((size_t)1 << 16)) {
+    if(c->x_log.size() <= R.x_seq[turn]) c->x_log.resize(R.x_seq[turn] + 1, std::make_pair(-1.0, (uint64_t)0));
+    c->x_log[R.x_seq[turn]] = std::make_pair((double)ms, R.x_bytes[turn]);
+  }
+  R.x_open[turn] = false;
+}
+void comm_x_begin(jfgpu_comm* c, jfgpu_comm::Rank& R, int turn) {
+  comm_x_harvest(c, R, turn);
+  (void)hipEventRecord(R.x_begin[turn], c->xstream);
+  R.x_seq[turn] = c->x_next++; R.x_bytes[turn] = 0; R.x_open[turn] = true;
+}
+void comm_x_end(jfgpu_comm* c, jfgpu_comm::Rank& R, int turn, uint64_t wire_bytes) {
+  (void)hipEventRecord(R.x_end[turn], c->xstream);
+  R.x_bytes[turn] = wire_bytes;
+}
+
 int comm_exchange_rccl(jfgpu_comm* c) {
 #if defined(JFGPU_EMU)
   (void)c;
@@ -519,6 +546,7 @@ int comm_exchange_rccl(jfgpu_comm* c) {
   if(!R.used[cur ^ 1]) { rc = comm_reserve(R.recv[cur ^ 1], R.recv_cap[cur ^ 1], total, R.t->stream, c->xstream); if(rc) return rc; }
   HIP_TRY(hipEventRecord(R.routed[cur], R.t->stream));
   HIP_TRY(hipStreamWaitEvent(c->xstream, R.routed[cur], 0));
+  comm_x_begin(c, R, cur);
   // this rank's own share: a device copy (1/W of the keys; everything, for a world of one)
   if(skip >= 0 && R.scount[cur][c->rank])
     HIP_TRY(hipMemcpyAsync(R.recv[cur] + R.roff[cur][c->rank], R.send[cur] + R.soff[cur][c->rank], R.scount[cur][c->rank] * sizeof(uint64_t),
@@ -545,6 +573,7 @@ int comm_exchange_rccl(jfgpu_comm* c) {
       NCCL_TRY(ncclGroupEnd());
     }
   }
+  { uint64_t wire = 0; for(int p = 0; p < W; ++p) if(p != skip && via_rccl) wire += R.scount[cur][p] * 8; comm_x_end(c, R, cur, wire); }
   HIP_TRY(hipEventRecord(R.exchanged[cur], c->xstream));
   R.used[cur] = true;
   return JFGPU_OK;
@@ -603,6 +632,7 @@ int comm_exchange_items_rccl(jfgpu_comm* c) {
   if(!R.used[cur ^ 1]) { rc = comm_reserve(R.recv[cur ^ 1], R.recv_cap[cur ^ 1], (L.recv_bytes + 7) / 8, R.t->stream, c->xstream); if(rc) return rc; }
   HIP_TRY(hipEventRecord(R.routed[cur], R.t->stream));
   HIP_TRY(hipStreamWaitEvent(c->xstream, R.routed[cur], 0));
+  comm_x_begin(c, R, cur);
   uint8_t* sb = reinterpret_cast<uint8_t*>(R.send[cur]);
   uint8_t* rb = reinterpret_cast<uint8_t*>(R.recv[cur]);
   const size_t blk = (size_t)L.nbc * L.cap;                               // items per (sender, receiver) message
@@ -653,6 +683,8 @@ int comm_exchange_items_rccl(jfgpu_comm* c) {
     }
     NCCL_TRY(ncclGroupEnd());
   }
+  { const int peers = (W > 1 || c->self_rccl) ? W - (skip >= 0 ? 1 : 0) : 0;
+    comm_x_end(c, R, cur, (uint64_t)peers * (blk * 4 + (uint64_t)2 * L.nbc * 8 + 8 + (uint64_t)(1 + L.S) * 8)); }
   HIP_TRY(hipEventRecord(R.exchanged[cur], c->xstream));
   R.used[cur] = true;
   return JFGPU_OK;
@@ -942,25 +974,38 @@ int comm_grow(jfgpu_comm* c) {
   std::vector<GrowNew> N(c->ranks.size());
   std::vector<char> prepared(c->ranks.size(), 0);
   bool cannot = false;
+  int hard = 0; std::string hard_msg;                       // a rank's own failure (rc > 0): agreed on like "cannot", then returned by everybody
   // every rank: nothing in flight, the new shard allocated, the pairs that leave grouped by their new owner in send[0] / send[1]
-  for(size_t q = 0; q < c->ranks.size(); ++q) {
+  for(size_t q = 0; q < c->ranks.size() && !hard; ++q) {
     jfgpu_comm::Rank& R = c->ranks[q];
     jfgpu_table* t = R.t;
-    if(t->nword) return fail(JFGPU_E_UNSUPPORTED, "sharded tables of keys longer than two words are not built");
-    int rc = comm_insert_prev(c, R); if(rc) return rc;
-    rc = grow_prepare(t, N[q]);
-    if(rc > 0) return rc;
+    if(t->nword) return fail(JFGPU_E_UNSUPPORTED, "sharded tables of keys longer than two words are not built");      // (the same on every rank)
+    int rc = comm_insert_prev(c, R);
+    if(rc == 0) rc = grow_prepare(t, N[q]);
+    if(rc > 0) { hard = rc; hard_msg = g_err; break; }
     prepared[q] = rc == 0;                                  // < 0: no memory for the doubled shard (nothing allocated)
     cannot = cannot || rc < 0;
   }
   // Growing is collective: a rank that cannot allocate its doubled shard must not leave alone while the others go on into
   // the exchange (round-4 advisor finding: they hung there).  One more agreement; if anybody cannot, nobody grows -- what
   // was prepared is freed and the shards carry on as they are, growth off, like a single table short of memory
-  // (ensure_capacity): a shard that then really fills up reports "Hash full" through its tiles' probe bound.
-  if(!c->local) { uint64_t v = cannot ? 1 : 0; int rc = jfgpu_comm_allreduce_u64(c, &v, 1, 1); if(rc) return rc; cannot = v != 0; }
+  // (ensure_capacity): a shard that then really fills up reports "Hash full" through its tiles' probe bound.  A rank whose
+  // preparation FAILED (a HIP error, a deferred "Hash full") takes part in the agreement too and everybody returns an error
+  // (round-5 advisor finding: it used to return before the all-reduce, the peers blocked in it).
+  auto free_prepared = [&]() {
+    for(size_t q = 0; q < c->ranks.size(); ++q)
+      if(prepared[q]) { DevTable& nd = N[q].nd; hipFree(nd.slots); hipFree(nd.ovf_key); hipFree(nd.ovf_cnt); hipFree(nd.dirty); hipFree(N[q].nf); hipFree(N[q].ni); prepared[q] = 0; }
+  };
+  uint64_t agreed = hard ? 2 : cannot ? 1 : 0;
+  if(!c->local) { int rc = jfgpu_comm_allreduce_u64(c, &agreed, 1, 1); if(rc) { free_prepared(); return rc; } }
+  if(agreed >= 2) {
+    free_prepared();
+    return hard ? fail(hard, hard_msg) : fail(JFGPU_E_HIP, "another rank failed while the shards were growing");
+  }
+  cannot = agreed != 0;
   if(cannot) {
+    free_prepared();
     for(size_t q = 0; q < c->ranks.size(); ++q) {
-      if(prepared[q]) { DevTable& nd = N[q].nd; hipFree(nd.slots); hipFree(nd.ovf_key); hipFree(nd.ovf_cnt); hipFree(nd.dirty); hipFree(N[q].nf); hipFree(N[q].ni); }
       c->ranks[q].t->grow_on = false;
     }
     return JFGPU_OK;
@@ -1059,31 +1104,42 @@ int comm_bc_merge(jfgpu_comm* c, jfgpu_bloom** blooms) {
   // the exchange keeps its order on the rank's table stream: a stand-in that carries the counter's stream
   std::vector<std::unique_ptr<jfgpu_table>> shim(nr);
   std::vector<jfgpu_table*> saved(nr);
-  for(size_t q = 0; q < nr; ++q) {
+  int rc = JFGPU_OK;
+  for(size_t q = 0; q < nr; ++q) { saved[q] = c->ranks[q].t; }
+  for(size_t q = 0; q < nr && !rc; ++q) {
     jfgpu_bloom* b = blooms[q];
-    if(!b || b->kind != 0) return fail(JFGPU_E_INVALID, "bc merge: a Bloom counter per rank");
-    if(b->data_bytes != b0->data_bytes || b->nh != b0->nh || b->m != b0->m) return fail(JFGPU_E_INVALID, "bc merge: the ranks' counters differ in size");
-    if(b->alloc_bytes < words * 8) return fail(JFGPU_E_INVALID, "bc merge: counter allocation shorter than its last word");
-    int rc = bloom_flush(b); if(rc) return rc;
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    if(!b || b->kind != 0) { rc = fail(JFGPU_E_INVALID, "bc merge: a Bloom counter per rank"); break; }
+    if(b->data_bytes != b0->data_bytes || b->nh != b0->nh || b->m != b0->m) { rc = fail(JFGPU_E_INVALID, "bc merge: the ranks' counters differ in size"); break; }
+    if(b->alloc_bytes < words * 8) { rc = fail(JFGPU_E_INVALID, "bc merge: counter allocation shorter than its last word"); break; }
+    if(c->ranks[q].inflight) { rc = fail(JFGPU_E_INVALID, "bc merge: a count step is still in flight on this communicator"); break; }
+    rc = bloom_flush(b); if(rc) break;
+    if(hipStreamSynchronize(b->stream) != hipSuccess) { rc = fail(JFGPU_E_HIP, "bc merge: sync"); break; }
     shim[q].reset(new jfgpu_table); shim[q]->stream = b->stream; shim[q]->device = b->device;
-    saved[q] = c->ranks[q].t; c->ranks[q].t = shim[q].get();
+    c->ranks[q].t = shim[q].get();
   }
   auto restore = [&]() { for(size_t q = 0; q < nr; ++q) c->ranks[q].t = saved[q]; };
   auto exchange = [&]() { return c->local ? comm_exchange_local(c) : c->ipc ? comm_exchange_ipc(c) : comm_exchange_rccl(c); };
   auto rank_of = [&](size_t q) { return c->local ? (int)q : c->rank; };
-  int rc = JFGPU_OK;
+  // Before every exchange the ranks agree that all of them got this far (round-5 advisor finding: a rank with a local error
+  // skipped the exchange and left the others waiting in it): a failure anywhere ends the merge on every rank.
+  auto all_fine = [&]() -> int {
+    std::string msg = g_err;
+    uint64_t bad = rc ? 1 : 0;
+    if(!c->local) { const int rc2 = jfgpu_comm_allreduce_u64(c, &bad, 1, 1); if(rc2) return rc2; }
+    if(!bad) return JFGPU_OK;
+    return rc ? fail(rc, msg) : fail(JFGPU_E_HIP, "bc merge: another rank failed");
+  };
   // round one: range p of my array goes to rank p
   for(size_t q = 0; q < nr && !rc; ++q) {
     jfgpu_comm::Rank& R = c->ranks[q]; jfgpu_bloom* b = blooms[q];
-    if(R.inflight) { restore(); return fail(JFGPU_E_INVALID, "bc merge: a count step is still in flight on this communicator"); }
     R.turn = 0;
     rc = comm_reserve(R.send[0], R.send_cap[0], std::max<uint64_t>(words, 1), b->stream, c->xstream); if(rc) break;
     if(hipMemcpyAsync(R.send[0], b->d_data, words * 8, hipMemcpyDeviceToDevice, b->stream) != hipSuccess) { rc = fail(JFGPU_E_HIP, "bc merge: copy"); break; }
     for(int p = 0; p < W; ++p) { R.scount[0][p] = r_len(p); R.soff[0][p] = r_lo(p); }
     R.soff[0][W] = words;
   }
-  if(!rc) rc = exchange();
+  rc = all_fine(); if(rc) { restore(); return rc; }
+  rc = exchange();
   for(size_t q = 0; q < nr && !rc; ++q) {
     jfgpu_comm::Rank& R = c->ranks[q]; jfgpu_bloom* b = blooms[q];
     const int me = rank_of(q);
@@ -1103,7 +1159,8 @@ int comm_bc_merge(jfgpu_comm* c, jfgpu_bloom** blooms) {
     for(int p = 0; p < W; ++p) { R.scount[1][p] = n; R.soff[1][p] = 0; }
     R.soff[1][W] = n;
   }
-  if(!rc) rc = exchange();
+  rc = all_fine(); if(rc) { restore(); return rc; }
+  rc = exchange();
   unsigned long long mers_sum = 0;
   for(size_t q = 0; q < nr && !rc; ++q) {
     jfgpu_comm::Rank& R = c->ranks[q]; jfgpu_bloom* b = blooms[q];
@@ -1131,6 +1188,8 @@ void comm_free_rank(jfgpu_comm::Rank& R) {
     if(R.routed[i]) hipEventDestroy(R.routed[i]);
     if(R.exchanged[i]) hipEventDestroy(R.exchanged[i]);
     if(R.consumed[i]) hipEventDestroy(R.consumed[i]);
+    if(R.x_begin[i]) hipEventDestroy(R.x_begin[i]);
+    if(R.x_end[i]) hipEventDestroy(R.x_end[i]);
   }
   if(R.d_cnt) hipFree(R.d_cnt);
   if(R.d_xc) hipFree(R.d_xc);
@@ -1492,6 +1551,17 @@ int jfgpu_comm_finish(jfgpu_comm* c, uint64_t* sent, uint64_t* received) {
   HIP_TRY(hipStreamSynchronize(c->xstream));
   if(sent) *sent = s;
   if(received) *received = r;
+  return JFGPU_OK;
+}
+
+int jfgpu_comm_exchange_times(jfgpu_comm* c, double* ms, uint64_t* wire_bytes, size_t cap, size_t* n) {
+  if(!c || !n) return fail(JFGPU_E_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->xstream));
+  for(auto& R : c->ranks) { comm_x_harvest(c, R, 0); comm_x_harvest(c, R, 1); }
+  *n = c->x_log.size();
+  for(size_t i = 0; i < c->x_log.size() && i < cap; ++i) { if(ms) ms[i] = c->x_log[i].first; if(wire_bytes) wire_bytes[i] = c->x_log[i].second; }
+  c->x_log.clear(); c->x_next = 0;
   return JFGPU_OK;
 }
 

@@ -166,19 +166,24 @@ inline Gf2Matrix gf2_random(uint32_t r, uint32_t c, uint64_t seed) {
   }
 }
 
-// The xor-shift family (kmer_core.hpp: xs_hash): the matrix of that linear map, column by column -- the image of key
-// bit j is xs_hash(1 << j).  One-word keys only (c <= 64); r >= c is the identity case like everywhere else.
+// The xor-shift family (kmer_core.hpp: xs_hash, xs_hash_wide): the matrix of that linear map, column by column -- the image
+// of key bit j is the function applied to the key with only that bit set.  Keys of one and two words (c <= 128); r >= c is
+// the identity case like everywhere else.
+inline uint64_t gf2_xorshift_image(uint32_t j, uint32_t r, uint32_t c) {
+  if(c <= 64) return xs_hash(1ull << j, r, c);
+  return j < 64 ? xs_hash_wide(1ull << j, 0, r) : xs_hash_wide(0, 1ull << (j - 64), r);
+}
 inline Gf2Matrix gf2_xorshift_matrix(uint32_t r, uint32_t c) {
   if(r >= c) return gf2_identity(r, c);
   Gf2Matrix m; m.r = r; m.c = c; m.columns.assign(c, 0);
-  for(uint32_t j = 0; j < c; ++j) m.columns[c - 1 - j] = xs_hash(1ull << j, r);
+  for(uint32_t j = 0; j < c; ++j) m.columns[c - 1 - j] = gf2_xorshift_image(j, r, c);
   return m;
 }
 // is this matrix the family's member for its shape?  (a table created from explicit columns -- a file header's -- gets the
 // register hash too when it is)
 inline bool gf2_is_xorshift(const Gf2Matrix& m) {
-  if(m.c > 64 || m.r >= m.c || m.columns.size() != m.c) return false;
-  for(uint32_t j = 0; j < m.c; ++j) if(m.columns[m.c - 1 - j] != xs_hash(1ull << j, m.r)) return false;
+  if(m.c > 128 || m.r >= m.c || m.r >= 64 || m.columns.size() != m.c) return false;
+  for(uint32_t j = 0; j < m.c; ++j) if(m.columns[m.c - 1 - j] != gf2_xorshift_image(j, m.r, m.c)) return false;
   return true;
 }
 

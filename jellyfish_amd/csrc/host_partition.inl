@@ -269,12 +269,16 @@ int part_ingest(jfgpu_table* t, const uint8_t* base, int64_t lo, int64_t hi, boo
     if(t->item128) {
       const size_t wlds = (size_t)kWideChunk * 18 + (size_t)t->g.nbytes * 2048;
 #define PW(RT, BL) hipLaunchKernelGGL((p1_wide_granule_kernel<RT, BL>), dim3(t->g1), dim3(kPBlock), wlds, t->stream, t->wt, t->pg, base, lo, hi, gcap, gcur, b.tot, (u128*)b.items)
-      if(t->returning) { if(bl) PW(true, true); else PW(true, false); } else { if(bl) PW(false, true); else PW(false, false); }
+#define PWX(RT) hipLaunchKernelGGL((p1_wide_granule_kernel<RT, false, true>), dim3(t->g1), dim3(kPBlock), wlds, t->stream, t->wt, t->pg, base, lo, hi, gcap, gcur, b.tot, (u128*)b.items)
+      if(t->g.hash_xs && !bl) { if(t->returning) PWX(true); else PWX(false); }
+      else if(t->returning) { if(bl) PW(true, true); else PW(true, false); } else { if(bl) PW(false, true); else PW(false, false); }
+#undef PWX
 #undef PW
     } else if(!t->item32) {
       const size_t glds = (size_t)kG64Chunk * 10;
 #define P64(RT, BL, N) hipLaunchKernelGGL((p1_granule64_kernel<RT, BL, N>), dim3(t->g1), dim3(kPBlock), glds, t->stream, t->dt, t->pg, base, lo, hi, gcap, gcur, b.tot, (uint64_t*)b.items)
       if(bl) { if(t->returning) P64(true, true, 0); else P64(false, true, 0); }
+      else if(t->g.hash_xs) { if(t->returning) P64(true, false, kHashXS); else P64(false, false, kHashXS); }
       else if(t->returning) P64(true, false, 0);
       else if(t->g.nbytes == 8) P64(false, false, 8);
       else if(t->g.nbytes == 7) P64(false, false, 7);

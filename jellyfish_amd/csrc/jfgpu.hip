@@ -112,6 +112,7 @@ struct jfgpu_table {
   bool prof_on = false;
   std::vector<ProfSpan> prof_pending;
   std::vector<hipEvent_t> ev_pool;
+  std::vector<std::pair<int, float>> prof_log;   // every span since the last reset, in launch order (jfgpu_profile_spans)
   double prof_ms[kNumProf] = {};
   uint64_t prof_launches[kNumProf] = {};
   uint64_t prof_units[kNumProf] = {};
@@ -190,6 +191,7 @@ void prof_collect(jfgpu_table* t) {
     hipEventSynchronize(s.b);
     if(hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
       t->prof_ms[s.which] += ms; t->prof_launches[s.which] += 1; t->prof_units[s.which] += s.units;
+      if(t->prof_log.size() < (size_t)1 << 16) t->prof_log.emplace_back(s.which, ms);
     }
     t->ev_pool.push_back(s.a); t->ev_pool.push_back(s.b);
   }
@@ -476,7 +478,7 @@ int grow_prepare(jfgpu_table* t, GrowNew& N) {
   if(t->nword) { if(!nword_geom_init(N.ng2, t->g.k, r + 1, t->g.canonical)) return -1; g2 = N.ng2.g; }
   else if(t->wide) { if(!wide_geom_init(N.w2, t->g.k, r + 1, t->g.canonical, t->g.shard_bits, t->g.shard_id)) return -1; g2 = N.w2.g; }
   else if(!geom_init(g2, t->g.k, r + 1, t->g.shard_bits, t->g.shard_id, t->g.canonical, !t->tun.slot64)) return -1;
-  if(!t->wide && !t->nword) g2.hash_xs = gf2_is_xorshift(m2) ? 1 : 0;
+  if(!t->nword) { g2.hash_xs = gf2_is_xorshift(m2) ? 1 : 0; if(t->wide) N.w2.g.hash_xs = g2.hash_xs; }
   const uint64_t n2 = 1ull << g2.lsize_l;
   const size_t slot_bytes = g2.slot32 ? 4 : 8 * (size_t)t->slot_words;
   uint64_t cap2 = std::max<uint64_t>(kMinOvf, std::min<uint64_t>(n2 / 256, 1ull << 26));
@@ -641,7 +643,7 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     t->matrix.identity = gf2_is_low_identity(t->matrix);
   } else if(p->matrix_seed) {
     t->matrix = gf2_random(lsize, 2 * p->k, p->matrix_seed);
-  } else if(p->k <= 32 && lsize < 2 * p->k && (p->matrix_kind ? p->matrix_kind : (uint32_t)t->tun.matrix) == JFGPU_MATRIX_XORSHIFT) {
+  } else if(p->k <= 64 && lsize < 2 * p->k && (p->matrix_kind ? p->matrix_kind : (uint32_t)t->tun.matrix) == JFGPU_MATRIX_XORSHIFT) {
     t->xs_matrix = true;
     t->matrix = gf2_xorshift_matrix(lsize, 2 * p->k);
   } else {
@@ -650,7 +652,10 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     t->ref_matrix = true;
     t->matrix = lsize >= 2 * p->k ? gf2_identity(lsize, 2 * p->k) : gf2_reference_matrix(lsize, 2 * p->k, t->glibc);
   }
-  if(!wide && !nword) t->g.hash_xs = gf2_is_xorshift(t->matrix) ? 1 : 0;       // (also a matrix given by its columns: a file header's)
+  if(!nword) {                                                                 // (also a matrix given by its columns: a file header's)
+    t->g.hash_xs = gf2_is_xorshift(t->matrix) ? 1 : 0;
+    if(wide) t->wt.W.g.hash_xs = t->g.hash_xs;
+  }
   std::vector<uint64_t> fwd, inv;
   while(!gf2_build_tables(t->matrix, fwd, inv)) {
     if(!t->ref_matrix || t->matrix.identity) return fail(JFGPU_E_INVALID, "hash matrix: low r x r block is singular");
@@ -765,6 +770,8 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     HIP_TRY(hipFuncSetAttribute((const void*)p1_granule64_kernel<false, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, gl));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_granule64_kernel<false, false, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, gl));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_granule64_kernel<false, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, gl));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_granule64_kernel<false, false, kHashXS>, hipFuncAttributeMaxDynamicSharedMemorySize, gl));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_granule64_kernel<true, false, kHashXS>, hipFuncAttributeMaxDynamicSharedMemorySize, gl));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<u128, WideDirect<true>, kP2WidePer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2WidePer * 16));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<u128, WideDirect<false>, kP2WidePer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2WidePer * 16));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<u128, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * 7 * 16));
@@ -773,6 +780,8 @@ int jfgpu_create(const jfgpu_params* p, jfgpu_table** out) {
     HIP_TRY(hipFuncSetAttribute((const void*)p1_wide_granule_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_wide_granule_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
     HIP_TRY(hipFuncSetAttribute((const void*)p1_wide_granule_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_wide_granule_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
+    HIP_TRY(hipFuncSetAttribute((const void*)p1_wide_granule_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
     HIP_TRY(hipFuncSetAttribute((const void*)tile_insert_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, wt));
     HIP_TRY(hipFuncSetAttribute((const void*)tile_insert_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, wt));
     HIP_TRY(hipFuncSetAttribute((const void*)tile_insert_wide_pipe_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, wt));
@@ -1339,6 +1348,17 @@ int jfgpu_profile_reset(jfgpu_table* t) {
   HIP_TRY(hipStreamSynchronize(t->stream));
   prof_collect(t);
   for(int i = 0; i < kNumProf; ++i) { t->prof_ms[i] = 0; t->prof_launches[i] = 0; t->prof_units[i] = 0; }
+  t->prof_log.clear();
+  return JFGPU_OK;
+}
+
+int jfgpu_profile_spans(jfgpu_table* t, int* which, double* ms, size_t cap, size_t* n) {
+  int rc = use(t); if(rc) return rc;
+  if(!n) return fail(JFGPU_E_INVALID, "null argument");
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  prof_collect(t);
+  *n = t->prof_log.size();
+  for(size_t i = 0; i < t->prof_log.size() && i < cap; ++i) { if(which) which[i] = t->prof_log[i].first; if(ms) ms[i] = t->prof_log[i].second; }
   return JFGPU_OK;
 }
 

@@ -143,15 +143,17 @@ __device__ inline bool bloom_filter_insert(const DevBloom& B, uint64_t h0, uint6
 __device__ __forceinline__ uint64_t bloom_cache_set(const DevBloom& B, uint64_t key) { return ((key * 0x9E3779B97F4A7C15ull) >> 23) & B.cache_mask; }
 __device__ __forceinline__ bool bloom_cache_hit(const DevBloom& B, uint64_t key) {
   const uint64_t* set = B.cache + 2 * bloom_cache_set(B, key);
-  const uint64_t a = set[0], b = set[1];
-  return a == key + 1 || b == key + 1;
+  const uint64_t a = set[0], b = set[1], tag = key + 1;
+  // (tag 0 = the all-T 32-mer without -C: it would read as "an empty way" -- that k-mer is never cached and always asks
+  // the counter; round-5 advisor finding)
+  return tag != 0 && (a == tag || b == tag);
 }
 __device__ inline void bloom_cache_insert(const DevBloom& B, uint64_t key) {
   uint64_t* set = B.cache + 2 * bloom_cache_set(B, key);
-  const uint64_t a = set[0], b = set[1];
-  if(a == key + 1 || b == key + 1) return;
+  const uint64_t a = set[0], b = set[1], tag = key + 1;
+  if(tag == 0 || a == tag || b == tag) return;
   const uint32_t way = a == 0 ? 0u : b == 0 ? 1u : (uint32_t)(key >> 9) & 1u;       // both taken: the key picks its victim
-  set[way] = key + 1;
+  set[way] = tag;
 }
 
 template <int J0>

@@ -14,6 +14,13 @@
 
 namespace jfgpu {
 
+// s_setprio: the issue priority of this wave among the waves of its SIMD (0 .. 3)
+template <int P> __device__ __forceinline__ void wave_prio() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_s_setprio(P);
+#endif
+}
+
 // admission mask of count --bc (bit j <-> position j) in the bit order of the validity masks (bit 15 - j <-> position j)
 __device__ __forceinline__ uint32_t adm_to_vmask(uint32_t adm) {
   uint32_t r = 0;
@@ -267,7 +274,11 @@ __global__ __launch_bounds__(kPBlock) void p1_ring_kernel(DevTable T, DIRECT D, 
   lds_barrier();                                                   // tables, fill words and holes are in place
   [[maybe_unused]] PhaseClk pc;
   for(int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    lds_barrier();
+    // (No barrier before the staging: the readers of the previous tile's words read them a round barrier ago.  Round 6 also
+    // tried staging without any barrier of its own -- the next tile's words published before the barrier that ends this
+    // tile's last round, two barriers a tile instead of three: 30.7 -> 34.2 ms.  A sweep that starts right behind a flush,
+    // without the staging barrier in between, lets the fast waves append into rings their owners have not released yet:
+    // ghosts, stragglers (p1_stragglers_kernel shows up in the trace).  profiles/r06_p1_experiments.log)
     const LaneWords L = tile_stage(Rw, tile * kPTilePos, lo, hi, s_codes, s_inv);     // barrier inside
     Rw = tile_fetch(base, (tile + gridDim.x) * kPTilePos, lo, hi);                     // next tile's bytes travel while this one is worked on
     JF_PHASE(pc, 0);
@@ -303,11 +314,11 @@ __global__ __launch_bounds__(kPBlock) void p1_ring_kernel(DevTable T, DIRECT D, 
           // the xor-shift matrix on the key's two dwords (the host takes this instantiation for 32 < lsize_g < 2k and
           // bucket shifts below 32): position, bucket and item without a 64-bit shift and without a table
           uint32_t ylo, yhi;
-          xs_hash_halves((uint32_t)key, (uint32_t)(key >> 32), xs_hi_mask, ylo, yhi);
+          xs_hash_halves<false>((uint32_t)key, (uint32_t)(key >> 32), xs_hi_mask, ylo, yhi);     // (32-bit items: keys of at most 42 bits, no fold)
           b = funnel_r(yhi, ylo, bshift) & (nb - 1);
           item = ((ylo & rest_mask) << g.rem_bits) | ((uint32_t)(key >> 32) >> (g.lsize_g - 32));
         } else {
-          const uint64_t pos = NB < 0 ? xs_hash(key, g.lsize_g) : hash_tables_t<(NB < 0 ? 0 : NB)>(s_fwd, key, g.nbytes);
+          const uint64_t pos = NB < 0 ? xs_hash(key, g.lsize_g, g.key_bits) : hash_tables_t<(NB < 0 ? 0 : NB)>(s_fwd, key, g.nbytes);
           b = (uint32_t)(pos >> bshift) & (nb - 1);
           if constexpr(sizeof(ITEM) == 4) item = (((uint32_t)pos & rest_mask) << g.rem_bits) | (uint32_t)(key >> g.lsize_g);      // (lsize_g <= 2k <= 42)
           else item = make_item<ITEM>(g, P, key, pos & g.local_mask);
@@ -368,7 +379,15 @@ __global__ __launch_bounds__(kPBlock) void p1_ring_kernel(DevTable T, DIRECT D, 
       JF_PHASE(pc, 1);
       lds_barrier();                                               // the round's items have all landed: what is due goes out now
       JF_PHASE(pc, 2);
+      // the flush at raised priority (round 6: 30.7 -> 29.8 ms): its few instructions are issued ahead of the sweeps of the
+      // waves already in the next round, so a ring is released before much is appended to it again
+#ifndef JFGPU_P1_NO_FLUSH_PRIO
+      wave_prio<3>();
+#endif
       if(owner) ring_flush<ITEM>(s_ring, s_fill, t, false, B, my_region, cap, gcur, gshort, straggler);
+#ifndef JFGPU_P1_NO_FLUSH_PRIO
+      wave_prio<0>();
+#endif
       JF_PHASE(pc, 3);
     }
   }

@@ -724,13 +724,13 @@ __global__ __launch_bounds__(kPBlock) void p1_granule64_kernel(DevTable T, PartG
   JF_DYN_LDS(s_dyn);
   uint64_t* s_item = reinterpret_cast<uint64_t*>(s_dyn);                               // [kG64Chunk]
   uint16_t* s_bkt = reinterpret_cast<uint16_t*>(s_dyn + (size_t)kG64Chunk * 8);        // [kG64Chunk]
-  __shared__ uint64_t s_fwd[8 * 256];
+  __shared__ uint64_t s_fwd[NB < 0 ? 1 : 8 * 256];                                      // (NB < 0: the xor-shift matrix, evaluated in registers)
   __shared__ uint32_t s_codes[kPBlock + 2];
   __shared__ uint32_t s_inv[kPBlock + 2];
   __shared__ GranuleLds G;
   const TableGeom& g = T.g;
   const uint32_t nb = 1u << P.b1;
-  load_tables_lds(s_fwd, T.fwd_tbl, g.nbytes);
+  if constexpr(NB >= 0) load_tables_lds(s_fwd, T.fwd_tbl, g.nbytes);
   granule_init(G, nb);
   const uint32_t k = g.k, bshift = g.lsize_l - P.b1;
   const uint64_t kwin = k >= 64 ? ~0ull : ((1ull << k) - 1);
@@ -762,7 +762,7 @@ __global__ __launch_bounds__(kPBlock) void p1_granule64_kernel(DevTable T, PartG
           ++my_mers;
           if(!BLOOM || ((adm >> j) & 1u)) {
             const uint64_t key = (g.canonical && rc < fw) ? rc : fw;
-            const uint64_t pos = hash_tables_t<NB>(s_fwd, key, g.nbytes);
+            const uint64_t pos = NB < 0 ? xs_hash(key, g.lsize_g, g.key_bits) : hash_tables_t<(NB < 0 ? 0 : NB)>(s_fwd, key, g.nbytes);
             const uint64_t local = pos & g.local_mask;
             it[e] = make_item<uint64_t>(g, P, key, local);
             const uint32_t b = (uint32_t)(local >> bshift);

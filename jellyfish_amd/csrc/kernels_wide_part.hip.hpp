@@ -65,7 +65,9 @@ constexpr int kP2WidePer = 7;
 
 // ---- P1w --------------------------------------------------------------------------------------------------
 // One block iteration = 16384 sequence positions, in rounds of kWidePer positions per lane (4096 items per round).
-template <bool RETURNING, bool BLOOM>
+// XS: the table's matrix is the xor-shift one (kmer_core.hpp: xs_hash_wide): a dozen register instructions instead of
+// sixteen 8-byte table reads per k-mer.
+template <bool RETURNING, bool BLOOM, bool XS = false>
 __global__ __launch_bounds__(kPBlock) void p1_wide_granule_kernel(WideTable T, PartGeom P, const uint8_t* __restrict__ base, int64_t lo, int64_t hi,
                                                                   uint32_t cap, unsigned int* __restrict__ gcur,
                                                                   unsigned long long* __restrict__ tot, u128* __restrict__ out) {
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(kPBlock) void p1_wide_granule_kernel(WideTable T, P
   const WideGeom& W = T.W;
   const TableGeom& g = W.g;
   const uint32_t nb = 1u << P.b1;
-  load_tables_lds(s_fwd, T.fwd_tbl, g.nbytes);
+  if constexpr(!XS) load_tables_lds(s_fwd, T.fwd_tbl, g.nbytes);
   granule_init(G, nb);
   const uint32_t k = g.k, bshift = g.lsize_l - P.b1;
   const u128 kwin = (((u128)1) << k) - 1;
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(kPBlock) void p1_wide_granule_kernel(WideTable T, P
           ++my_mers;
           const u128 key = (g.canonical && rc < fw) ? rc : fw;
           if(!BLOOM || bloom_admits_wide(T.bloom, key)) {
-            const uint64_t pos = hash_tables_wide(s_fwd, key, g.nbytes);
+            const uint64_t pos = XS ? xs_hash_wide((uint64_t)key, (uint64_t)(key >> 64), g.lsize_g) : hash_tables_wide(s_fwd, key, g.nbytes);
             const uint64_t local = pos & g.local_mask;
             const uint32_t b = P.b1 ? (uint32_t)(local >> bshift) : 0u;
             it[e] = make_item_wide(W, P, key, local);

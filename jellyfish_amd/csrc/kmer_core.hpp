@@ -227,7 +227,7 @@ JF_HD uint64_t hash_tables_n(const uint64_t* tbl, uint64_t key) {
 // reference draws a random one, which a GPU can only apply through table look-ups: six random 8-byte LDS reads per k-mer
 // at k = 21, the bank conflicts and the waits behind them (profiles/r05_C2_sq_counters.txt).  This family is linear too --
 // every step below is an xor of shifted copies -- but is evaluated with eleven register instructions:
-//   r <= 32:  y = (key ^ key >> 9 ^ key >> 21) mod 2^r          the high key bits (those a slot stores) come down
+//   r <= 32:  y = (key ^ key >> 9 ^ key >> 21 [^ key >> 32]) mod 2^r   the high key bits (those a slot stores) come down
 //             y ^= y << 13 ;  y ^= y << 7  (mod 2^r) ;  y ^= y >> 17
 //   r >  32:  lo = the same four steps mod 2^32                  (one dword of work)
 //             hi = (key >> 32 ^ lo >> 9) mod 2^(r - 32)           position = hi : lo
@@ -253,26 +253,43 @@ JF_HD uint32_t xor_and(uint32_t a, uint32_t b, uint32_t mask) {        // (a ^ b
   return (a ^ b) & mask;
 #endif
 }
+// Keys of more than 53 bits (k >= 27) get one more term in the first step, key >> 32: without it the key bits above
+// 32 + 21 never reach the low dword, and k = 31 piles 25 x the mean into one tile on the same test sequence (with it: as
+// even as a random matrix).  Two-word keys (33 <= k <= 64) are folded to one word first, x = lo ^ hi ^ rotl(hi, 25), and go
+// on as a 64-bit key: the low block is the one-word family's.
+JF_HD bool xs_folds(uint32_t key_bits) { return key_bits > 53; }
 // 32 < r < 64, on the two dwords of the key: hi_mask = 2^(r - 32) - 1
+template <bool FOLD>
 JF_HD void xs_hash_halves(uint32_t klo, uint32_t khi, uint32_t hi_mask, uint32_t& ylo, uint32_t& yhi) {
   uint32_t lo = xor3(klo, funnel_r(khi, klo, kXsR0a), funnel_r(khi, klo, kXsR0b));
+  if(FOLD) lo ^= khi;
   lo ^= lo << kXsL1;
   lo ^= lo << kXsL2;
   lo ^= lo >> kXsR3;
   ylo = lo; yhi = xor_and(khi, lo >> kXsFold, hi_mask);
 }
-JF_HD uint64_t xs_hash(uint64_t key, uint32_t r) {
+// key_bits = 2k of a one-word key (it only decides the fold)
+JF_HD uint64_t xs_hash(uint64_t key, uint32_t r, uint32_t key_bits) {
+  const bool fold = xs_folds(key_bits);
   if(r > 32) {
     uint32_t lo, hi;
-    xs_hash_halves((uint32_t)key, (uint32_t)(key >> 32), r >= 64 ? 0xFFFFFFFFu : ((1u << (r - 32)) - 1u), lo, hi);
+    const uint32_t hm = r >= 64 ? 0xFFFFFFFFu : ((1u << (r - 32)) - 1u);
+    if(fold) xs_hash_halves<true>((uint32_t)key, (uint32_t)(key >> 32), hm, lo, hi);
+    else xs_hash_halves<false>((uint32_t)key, (uint32_t)(key >> 32), hm, lo, hi);
     return ((uint64_t)hi << 32) | lo;
   }
   const uint32_t m = r >= 32 ? 0xFFFFFFFFu : ((1u << r) - 1u);
-  uint32_t y = (uint32_t)(key ^ (key >> kXsR0a) ^ (key >> kXsR0b)) & m;
+  uint32_t y = (uint32_t)(key ^ (key >> kXsR0a) ^ (key >> kXsR0b) ^ (fold ? key >> 32 : 0)) & m;
   y ^= (y << kXsL1) & m;
   y ^= (y << kXsL2) & m;
   y ^= y >> kXsR3;
   return y;
+}
+// two-word keys (lo = bits 0..63 of the key, hi = the bits above)
+JF_HD uint64_t xs_hash_wide(uint64_t lo, uint64_t hi, uint32_t r) {
+  const uint32_t h0 = (uint32_t)hi, h1 = (uint32_t)(hi >> 32);
+  const uint32_t xlo = xor3((uint32_t)lo, h0, funnel_r(h0, h1, 7)), xhi = xor3((uint32_t)(lo >> 32), h1, funnel_r(h1, h0, 7));      // lo ^ hi ^ rotl64(hi, 25)
+  return xs_hash(((uint64_t)xhi << 32) | xlo, r, 64);
 }
 constexpr int kHashXS = -1, kHashXSLow = -2;      // NB of the kernels' hash template: the position comes from xs_hash, no tables
 

@@ -44,7 +44,7 @@ public:
   // see attach_comm.
   hash_counter(size_t size, uint16_t key_len, uint16_t val_len, uint16_t nb_threads, uint16_t reprobe_limit = 126,
                bool canonical = false, int device = -1, uint32_t out_counter_len = 4, uint64_t matrix_seed = 0,
-               uint32_t shard_bits = 0, uint32_t shard_id = 0)
+               uint32_t shard_bits = 0, uint32_t shard_id = 0, uint32_t matrix_kind = 0 /* jfgpu.h: JFGPU_MATRIX_* */)
       : nb_threads_(nb_threads) {
     (void)val_len; (void)reprobe_limit;
     if(key_len == 0 || key_len % 2) throw std::length_error("key_len must be an even number of bits");
@@ -52,7 +52,7 @@ public:
     memset(&p, 0, sizeof p);
     p.k = key_len / 2; p.canonical = canonical; p.size = size; p.device = device;
     p.matrix_seed = matrix_seed; p.out_counter_len = out_counter_len;
-    p.shard_bits = shard_bits; p.shard_id = shard_id;
+    p.shard_bits = shard_bits; p.shard_id = shard_id; p.matrix_kind = matrix_kind;
     jf_check(jfgpu_create(&p, &t_));
     jf_check(jfgpu_get_info(t_, &info_));
     kw_ = (key_len + 63) / 64;

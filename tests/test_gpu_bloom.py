@@ -81,6 +81,51 @@ def test_count_bc_with_the_cache_of_admitted_kmers(gpu, monkeypatch, case, log2_
                 t.attach_bloom(None)
 
 
+def test_cache_of_admitted_kmers_and_the_all_ones_key(gpu, monkeypatch):
+    """k = 32 without -C: the all-T 32-mer is the key 2^64 - 1, whose cache tag (key + 1) is the empty way's 0 (round-5 advisor
+    finding: it was admitted on an empty way without the counter being asked, and counted although seen once).  A counter fed
+    everything once plus one half twice; exactly one all-T 32-mer in the once-only half: the filtered table must hold exactly the k-mers
+    the oracle's check() > 1 admits (bloom_counter2.hpp:109-142, count_main.cc:109-119), poly-T not among them -- and
+    with poly-T fed twice to the counter, among them."""
+    monkeypatch.setenv("JFGPU_BLOOM_CACHE", "1")
+    monkeypatch.setenv("JFGPU_BLOOM_CACHE_LOG2", "6")
+    rng = random.Random(3)
+    k = 32
+    twice = "".join(rng.choice("ACGT") for _ in range(6000))
+    once = "".join(rng.choice("ACGT") for _ in range(3000)) + "N" + "T" * 32 + "N" + "".join(rng.choice("ACGT") for _ in range(3000))
+    for polyt_twice in (False, True):
+        fed = (twice + "N" + twice + "N" + once + ("N" + "T" * 32 if polyt_twice else "")).encode()
+        n = 20000
+        with gpu.Bloom(k, gpu.opt_m(0.001, n), gpu.opt_k(0.001), canonical=False, seed=11) as b:
+            b.insert_ascii(fed)
+            b.sync()
+            seq = (twice + "N" + once).encode()
+            kmers = O.extract(seq, k, False)[:, 0]
+            # what the ORACLE's check() says of the counter's bytes, key by key (oracle/jf_oracle.c: jfo_bc_check)
+            uniq = np.unique(kmers)
+            data = b.read()
+            h0 = O.matrix_times(b.matrix1, 64, 2 * k, uniq.reshape(-1, 1))
+            h1 = O.matrix_times(b.matrix2, 64, 2 * k, uniq.reshape(-1, 1))
+            L = O.lib()
+            adm = np.array([L.jfo_bc_check(data.ctypes.data, b.m, b.nb_hashes, x, y) > 1 for x, y in zip(h0.tolist(), h1.tolist())])
+            exp_keys = set(uniq[adm].tolist())
+            assert len(exp_keys) >= 5000
+            for mode in (1, 2):
+                with gpu.Table(k, 1 << 16, canonical=False) as t:
+                    t.set_mode(mode)
+                    t.attach_bloom(b)
+                    t.count_ascii(seq)
+                    t.count_ascii(seq)
+                    t.sync()
+                    kk, cc = gpu.decode_records(t.dump_records(), k, 4)
+                    got = dict(zip(kk.tolist(), cc.tolist()))
+                    t.attach_bloom(None)
+                assert set(got) == exp_keys, (polyt_twice, mode)
+                assert ((1 << 64) - 1 in got) == polyt_twice, (polyt_twice, mode)      # poly-T: only when the counter saw it twice
+                occ = dict(zip(*[a.tolist() for a in np.unique(kmers, return_counts=True)]))
+                assert got == {key: 2 * occ[key] for key in exp_keys}
+
+
 def test_bloom_against_oracle_on_random_input(gpu):
     """Own random matrices, larger input with lower-case / N resets, saturation at 2, load() round trip."""
     rng = random.Random(41)

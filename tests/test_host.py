@@ -39,7 +39,7 @@ def test_device_arithmetic_on_host_matches_oracle(core_emu):
         lsize = max(min(2 * k, rng.choice([4, 10, 13, 14, 20, 26])), max(0, 2 * k - 34), 1)
         sb = min(rng.choice([0, 0, 1, 3]), lsize)
         lead = rng.randrange(16)
-        out = subprocess.run([core_emu, str(k), str(can), str(lsize), str(sb), str(lead)], input=seq.encode(),
+        out = subprocess.run([core_emu, str(k), str(can), str(lsize), str(sb), str(lead)] + (["xs"] if trial % 2 else []), input=seq.encode(),
                              capture_output=True, check=True)
         lines = out.stdout.decode().splitlines()
         cols = np.array([int(x) for x in lines[0].split()[1:]], dtype=np.uint64)
@@ -50,6 +50,20 @@ def test_device_arithmetic_on_host_matches_oracle(core_emu):
             pos = O.matrix_times(cols, lsize, 2 * k, exp[:1500])
             assert (pos == got[:1500, 1]).all()                 # byte-table hash == matrix product
             assert (got[:, 2] == got[:, 0]).all()               # slot word -> key round trip (inverse tables)
+
+
+def test_xorshift_matrix_family(core_emu):
+    """The matrix family the partition kernel evaluates in registers (kmer_core.hpp: xs_hash; jfgpu.h: JFGPU_MATRIX_XORSHIFT): for
+    every k <= 32 and every table size below 4^k its low block is invertible -- the property the file format asks of a matrix
+    (rectangular_binary_matrix.cc:160-210 constructs the reference's that way) --, the matrix product of the columns the
+    header would carry equals the register evaluation and its two-dword form, and the python restatement agrees."""
+    from jellyfish_amd import capi
+    out = subprocess.run([core_emu, "xs-family"], capture_output=True, check=True).stdout.decode().splitlines()
+    assert out[-1] == "ok", out[-3:]
+    vals = [l.split() for l in out if l.startswith("v ")]
+    assert len(vals) == 56
+    for _, r, c, key, pos in vals:
+        assert capi.xs_hash(int(key), int(r), int(c)) == int(pos)
 
 
 def declared_functions():

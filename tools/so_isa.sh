@@ -15,12 +15,11 @@ for line in sys.stdin:
     if not m: continue
     if m.group(2) in ("name", "vgpr_count", "agpr_count", "sgpr_count", "private_segment_fixed_size", "group_segment_fixed_size") :
         cur[m.group(2)] = m.group(3).strip()
-    if m.group(2) == "wavefront_size" or m.group(2) == "uses_dynamic_stack":
-        pass
     if m.group(2) == "vgpr_spill_count":
         cur["spill"] = m.group(3).strip()
-    if m.group(2) == "symbol":
-        print("%s vgpr %s agpr %s sgpr %s scratch %s lds %s spill %s" % (m.group(3).strip(), cur.get("vgpr_count"), cur.get("agpr_count"), cur.get("sgpr_count"), cur.get("private_segment_fixed_size"), cur.get("group_segment_fixed_size"), cur.get("spill")))
+    if m.group(2) == "symbol": cur["symbol"] = m.group(3).strip()
+    if m.group(2) == "wavefront_size":          # (the keys of a kernel come in alphabetical order: this is the last one)
+        print("%s vgpr %s agpr %s sgpr %s scratch %s lds %s spill %s" % (cur.get("symbol"), cur.get("vgpr_count"), cur.get("agpr_count"), cur.get("sgpr_count"), cur.get("private_segment_fixed_size"), cur.get("group_segment_fixed_size"), cur.get("spill")))
         cur = {}
 ' > $out/meta.txt
 wc -l $out/meta.txt
