@@ -80,6 +80,9 @@ struct jfgpu_comm {
   uint32_t barrier_gen = 0;
 #endif
   bool ipc = false;
+  // ipc transport: send buffers given up while a peer may still have them mapped (freed after the next exchange of their turn,
+  // by when every peer has let go of its mapping: see comm_reserve_send)
+  std::vector<void*> send_retired[2];
   bool items_on = true; int items_mode = 1;      // JFGPU_COMM_ITEMS: 0 always send 8-byte keys, 1 items when the step is large enough, 2 items always
   uint32_t strag_cap = 1u << 16;                 // stragglers per rank and step (JFGPU_COMM_STRAG)
   std::vector<Rank> ranks;                       // RCCL transport: one; local transport: `world`
@@ -91,6 +94,7 @@ namespace {
 #define IPC_TRACE(c, ...) do { if((c)->tun.comm_trace) { fprintf(stderr, "[comm rank %d] ", (c)->rank); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while(0)
 
 int comm_reserve(uint64_t*& buf, size_t& cap, size_t need, hipStream_t s1, hipStream_t s2);
+int comm_reserve_send(jfgpu_comm* c, jfgpu_comm::Rank& R, int turn, size_t need, hipStream_t s1);
 
 // the communicator's share of the JFGPU_* switches (tuning.hpp), applied once at creation
 void comm_apply_tuning(jfgpu_comm* c) {
@@ -217,8 +221,8 @@ int comm_route_items_enqueue(jfgpu_comm* c, jfgpu_comm::Rank& R, const char* d_b
   const ItemLayout L = item_layout(c, t, cap);
   { const int rc_ = comm_filter_ok(t); if(rc_) return rc_; }
   if(R.used[cur]) HIP_TRY(hipEventSynchronize(R.exchanged[cur]));       // send[cur] has left (step - 2)
-  int rc = comm_reserve(R.send[cur], R.send_cap[cur], (L.send_bytes + 7) / 8, t->stream, c->xstream); if(rc) return rc;
-  if(!R.used[cur ^ 1]) { rc = comm_reserve(R.send[cur ^ 1], R.send_cap[cur ^ 1], (L.send_bytes + 7) / 8, t->stream, c->xstream); if(rc) return rc; }   // (both buffers of the pair at once)
+  int rc = comm_reserve_send(c, R, cur, (L.send_bytes + 7) / 8, t->stream); if(rc) return rc;
+  if(!R.used[cur ^ 1]) { rc = comm_reserve_send(c, R, cur ^ 1, (L.send_bytes + 7) / 8, t->stream); if(rc) return rc; }   // (both buffers of the pair at once)
   uint8_t* sb = reinterpret_cast<uint8_t*>(R.send[cur]);
   uint32_t* items = reinterpret_cast<uint32_t*>(sb);
   uint64_t* offs = reinterpret_cast<uint64_t*>(sb + L.offs_at);
@@ -417,6 +421,25 @@ int comm_reserve(uint64_t*& buf, size_t& cap, size_t need, hipStream_t s1, hipSt
   return JFGPU_OK;
 }
 
+// A SEND buffer of the ipc transport is mapped by the peers.  Freeing it under their mappings and allocating the larger one
+// right away made the peers read stale memory through the handle of the new buffer (round 6: shards that grow with most of
+// their entries leaving -- the xor-shift family, world 4 -- re-allocate both send buffers inside comm_grow, and the pairs
+// arrived wrong: profiles/r06_ipc_realloc.log).  So the old buffer is only RETIRED here; it is freed after the next exchange
+// of its turn, whose import phase makes every peer close its mapping of it before the new handle is opened.
+int comm_reserve_send(jfgpu_comm* c, jfgpu_comm::Rank& R, int turn, size_t need, hipStream_t s1) {
+  if(need <= R.send_cap[turn]) return JFGPU_OK;
+  if(c->ipc && R.send[turn]) {
+    HIP_TRY(hipStreamSynchronize(s1)); HIP_TRY(hipStreamSynchronize(c->xstream));
+    c->send_retired[turn].push_back(R.send[turn]);
+    R.send[turn] = nullptr; R.send_cap[turn] = 0;
+  }
+  return comm_reserve(R.send[turn], R.send_cap[turn], need, s1, c->xstream);
+}
+void comm_free_retired(jfgpu_comm* c, int turn) {
+  for(void* p : c->send_retired[turn]) hipFree(p);
+  c->send_retired[turn].clear();
+}
+
 // Route one contract buffer of rank R into send[cur], grouped by owner; fills scount / soff.  The host waits for the
 // per-owner counts (one small copy) -- they place the groups and size the messages.
 int comm_route(jfgpu_comm* c, jfgpu_comm::Rank& R, const char* d_bases, size_t n) {
@@ -430,8 +453,8 @@ int comm_route(jfgpu_comm* c, jfgpu_comm::Rank& R, const char* d_bases, size_t n
   std::fill(R.scount[cur].begin(), R.scount[cur].end(), 0);
   std::fill(R.soff[cur].begin(), R.soff[cur].end(), 0);
   if(n < t->g.k) return JFGPU_OK;
-  int rc = comm_reserve(R.send[cur], R.send_cap[cur], n * kw, t->stream, c->xstream); if(rc) return rc;
-  if(!R.used[cur ^ 1]) { rc = comm_reserve(R.send[cur ^ 1], R.send_cap[cur ^ 1], n * kw, t->stream, c->xstream); if(rc) return rc; }   // (both buffers of the pair at once)
+  int rc = comm_reserve_send(c, R, cur, n * kw, t->stream); if(rc) return rc;
+  if(!R.used[cur ^ 1]) { rc = comm_reserve_send(c, R, cur ^ 1, n * kw, t->stream); if(rc) return rc; }   // (both buffers of the pair at once)
   const uint8_t* base; int64_t lo, hi;
   align_buffer(d_bases, n, base, lo, hi);
   const int64_t n_tiles = (hi + kTilePos - 1) / kTilePos;
@@ -827,6 +850,7 @@ int comm_exchange_ipc(jfgpu_comm* c) {
   IPC_TRACE(c, "keys: pulled, barrier 2");
   rc = ipc_barrier(c); if(rc) return rc;                     // everybody has pulled: the send buffers may be written again
   IPC_TRACE(c, "keys: step exchanged");
+  comm_free_retired(c, cur);                                 // (every peer has re-imported send[cur]: nobody maps the old ones)
   R.used[cur] = true;
   return JFGPU_OK;
 }
@@ -867,6 +891,7 @@ int comm_exchange_items_ipc(jfgpu_comm* c) {
   IPC_TRACE(c, "items: pulled, barrier 2");
   rc = ipc_barrier(c); if(rc) return rc;
   IPC_TRACE(c, "items: step exchanged");
+  comm_free_retired(c, cur);
   R.used[cur] = true;
   return JFGPU_OK;
 }
@@ -1024,12 +1049,17 @@ int comm_grow(jfgpu_comm* c) {
     std::vector<unsigned long long> h(W);
     HIP_TRY(hipMemcpyAsync(h.data(), R.d_cnt, sizeof(unsigned long long) * W, hipMemcpyDeviceToHost, t->stream));
     HIP_TRY(hipStreamSynchronize(t->stream));
+    if(c->tun.comm_trace) {
+      uint64_t ms = 0; for(uint64_t col : N[q].m2.columns) ms = ms * 0x9E3779B97F4A7C15ull + col;
+      std::string hs; for(int p = 0; p < W; ++p) hs += " " + std::to_string(h[p]);
+      IPC_TRACE(c, "grow: shard %u, new r %u (xs %d), matrix mix %016llx, pairs leaving per owner:%s", t->g.shard_id, N[q].m2.r, (int)N[q].g2.hash_xs, (unsigned long long)ms, hs.c_str());
+    }
     uint64_t total = 0;
     // turn 0 carries the keys (kw words each), turn 1 the counts: the same groups, in the same order
     for(int p = 0; p < W; ++p) { R.scount[1][p] = h[p]; R.soff[1][p] = total; R.scount[0][p] = h[p] * kw; R.soff[0][p] = total * kw; total += h[p]; h[p] = R.soff[1][p]; }
     R.soff[1][W] = total; R.soff[0][W] = total * kw;
-    rc = comm_reserve(R.send[0], R.send_cap[0], std::max<uint64_t>(total * kw, 1), t->stream, c->xstream); if(rc) return rc;
-    rc = comm_reserve(R.send[1], R.send_cap[1], std::max<uint64_t>(total, 1), t->stream, c->xstream); if(rc) return rc;
+    rc = comm_reserve_send(c, R, 0, std::max<uint64_t>(total * kw, 1), t->stream); if(rc) return rc;
+    rc = comm_reserve_send(c, R, 1, std::max<uint64_t>(total, 1), t->stream); if(rc) return rc;
     HIP_TRY(hipMemcpyAsync(R.d_cnt, h.data(), sizeof(unsigned long long) * W, hipMemcpyHostToDevice, t->stream));   // cursors = offsets
     if(t->wide) hipLaunchKernelGGL(reshard_wide_kernel, grid, block, 0, t->stream, t->wt, N[q].nw, have_ovf, 1, R.d_cnt, R.send[0], R.send[1]);
     else hipLaunchKernelGGL(reshard_kernel, grid, block, 0, t->stream, t->dt, N[q].nd, have_ovf, 1, R.d_cnt, R.send[0], R.send[1]);
@@ -1050,6 +1080,22 @@ int comm_grow(jfgpu_comm* c) {
     HIP_TRY(hipStreamWaitEvent(t->stream, R.exchanged[0], 0));
     HIP_TRY(hipStreamWaitEvent(t->stream, R.exchanged[1], 0));
     const uint64_t n = R.roff[1][W];                        // pairs that arrived (turn 1's offsets count them; turn 0's count key words)
+    if(c->tun.comm_trace && !t->wide) {                     // where do the arrivals belong under the new matrix?  (host check, trace runs only)
+      HIP_TRY(hipStreamSynchronize(c->xstream));
+      std::vector<uint64_t> hk(n);
+      if(n) HIP_TRY(hipMemcpy(hk.data(), R.recv[0], n * 8, hipMemcpyDeviceToHost));
+      std::string hs;
+      for(int p = 0; p < W; ++p) {
+        uint64_t bad = 0;
+        for(uint64_t i = R.roff[0][p]; i < R.roff[0][p + 1]; ++i) {
+          uint64_t pos = 0;
+          for(uint32_t j = 0; j < N[q].m2.c; ++j) if((hk[i] >> j) & 1) pos ^= N[q].m2.columns[N[q].m2.c - 1 - j];
+          if((pos >> N[q].g2.lsize_l) != t->g.shard_id) ++bad;
+        }
+        hs += " " + std::to_string(R.roff[0][p + 1] - R.roff[0][p]) + "/" + std::to_string(bad);
+      }
+      IPC_TRACE(c, "grow: shard %u, arrived/not mine per sender:%s", t->g.shard_id, hs.c_str());
+    }
     if(n && t->wide) hipLaunchKernelGGL(add_pairs_wide_kernel, dim3(grid_for(t, n / kBlock + 1)), dim3(kBlock), 0, t->stream, N[q].nw, (const uint64_t*)R.recv[0], (const uint64_t*)R.recv[1], n);
     else if(n) hipLaunchKernelGGL(add_pairs_kernel, dim3(grid_for(t, n / kBlock + 1)), dim3(kBlock), 0, t->stream, N[q].nd, (const uint64_t*)R.recv[0], (const uint64_t*)R.recv[1], n);
     HIP_TRY(hipGetLastError());
@@ -1133,7 +1179,7 @@ int comm_bc_merge(jfgpu_comm* c, jfgpu_bloom** blooms) {
   for(size_t q = 0; q < nr && !rc; ++q) {
     jfgpu_comm::Rank& R = c->ranks[q]; jfgpu_bloom* b = blooms[q];
     R.turn = 0;
-    rc = comm_reserve(R.send[0], R.send_cap[0], std::max<uint64_t>(words, 1), b->stream, c->xstream); if(rc) break;
+    rc = comm_reserve_send(c, R, 0, std::max<uint64_t>(words, 1), b->stream); if(rc) break;
     if(hipMemcpyAsync(R.send[0], b->d_data, words * 8, hipMemcpyDeviceToDevice, b->stream) != hipSuccess) { rc = fail(JFGPU_E_HIP, "bc merge: copy"); break; }
     for(int p = 0; p < W; ++p) { R.scount[0][p] = r_len(p); R.soff[0][p] = r_lo(p); }
     R.soff[0][W] = words;
@@ -1154,7 +1200,7 @@ int comm_bc_merge(jfgpu_comm* c, jfgpu_bloom** blooms) {
     (void)hipEventRecord(R.consumed[0], b->stream);
     // round two: my merged range to everybody
     R.turn = 1;
-    rc = comm_reserve(R.send[1], R.send_cap[1], std::max<uint64_t>(n, 1), b->stream, c->xstream); if(rc) break;
+    rc = comm_reserve_send(c, R, 1, std::max<uint64_t>(n, 1), b->stream); if(rc) break;
     if(n && hipMemcpyAsync(R.send[1], mine, n * 8, hipMemcpyDeviceToDevice, b->stream) != hipSuccess) { rc = fail(JFGPU_E_HIP, "bc merge: copy"); break; }
     for(int p = 0; p < W; ++p) { R.scount[1][p] = n; R.soff[1][p] = 0; }
     R.soff[1][W] = n;
@@ -1328,6 +1374,7 @@ void jfgpu_comm_destroy(jfgpu_comm* c) {
   if(c->nccl) ncclCommDestroy(c->nccl);
   ipc_detach(c);
 #endif
+  comm_free_retired(c, 0); comm_free_retired(c, 1);
   if(c->xstream) hipStreamDestroy(c->xstream);
   delete c;
 }

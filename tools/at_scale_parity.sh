@@ -11,6 +11,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=${1:-$R/gpurun_out/at_scale}; BASES=${2:-10000000000}; RT=${3:-64}
+OUT=$(realpath -m "$OUT")                                   # (the script works in /dev/shm: a relative <out dir> would be lost)
 PHASE=${AT_SCALE_PHASE:-both}
 W=/dev/shm/jf_at_scale
 REF=$R/oracle/_ref/ref_jf; GEN=$R/oracle/_ref/ref_generate_sequence; CLI=$R/bin/jellyfish-amd
@@ -46,6 +47,8 @@ if [ $PHASE = recheck ]; then
   export JFGPU_QUIET=1
   G=$R/tests/golden/at_scale
   t=$(date +%s%N); $CLI count -m 21 -C -s $SIZE21 --no-write --digest $OUT/gpu_c2.digest --timing $OUT/gpu_c2.timing reads.fa; echo "gpu_c2_wall_ms $(ms $t)" >> $OUT/timing.txt
+  t=$(date +%s%N); $CLI count -m 21 -C -s $SIZE21 --matrix xs --no-write --digest $OUT/gpu_c2_xs.digest --timing $OUT/gpu_c2_xs.timing reads.fa; echo "gpu_c2_xs_wall_ms $(ms $t)" >> $OUT/timing.txt
+  t=$(date +%s%N); $CLI count -m 63 -C -s $SIZE63 --matrix xs --no-write --digest $OUT/gpu_c5_xs.digest --timing $OUT/gpu_c5_xs.timing reads.fa; echo "gpu_c5_xs_wall_ms $(ms $t)" >> $OUT/timing.txt
   t=$(date +%s%N); $CLI count -m 21 -C -s $SIZE21 --no-write --digest $OUT/gpu_c2_gpus1.digest --timing $OUT/gpu_c2_gpus1.timing --gpus 1 reads.fa 2> $OUT/gpus1.err; echo "gpu_c2_gpus1_wall_ms $(ms $t)" >> $OUT/timing.txt
   t=$(date +%s%N); $CLI count -m 63 -C -s $SIZE63 --no-write --digest $OUT/gpu_c5.digest --timing $OUT/gpu_c5.timing reads.fa; echo "gpu_c5_wall_ms $(ms $t)" >> $OUT/timing.txt
   t=$(date +%s%N); $CLI bc -m 31 -C -s $BASES -o gpu.bc --timing $OUT/gpu_c3_bc.timing reads.fa; echo "gpu_c3_bc_wall_ms $(ms $t)" >> $OUT/timing.txt
@@ -59,11 +62,18 @@ if [ $PHASE = recheck ]; then
     for c in c2 c5 c3; do
       if cmp -s $G/ref_$c.digest $OUT/gpu_$c.digest; then echo "$c digest EQUAL to the reference's (tests/golden/at_scale): $(tr '\n' ' ' < $OUT/gpu_$c.digest)"; else echo "$c digest DIFFERENT"; echo " ref: $(tr '\n' ' ' < $G/ref_$c.digest)"; echo " gpu: $(tr '\n' ' ' < $OUT/gpu_$c.digest)"; fi
     done
+    for c in c2 c5; do
+      if cmp -s $G/ref_$c.digest $OUT/gpu_${c}_xs.digest; then echo "$c under the xor-shift matrix (--matrix xs): digest EQUAL to the reference's"; else echo "$c under --matrix xs: digest DIFFERENT: $(tr '\n' ' ' < $OUT/gpu_${c}_xs.digest)"; fi
+    done
     if cmp -s $G/ref_c2.digest $OUT/gpu_c2_gpus1.digest; then echo "c2 through count --gpus 1: digest EQUAL"; else echo "c2 through count --gpus 1: digest DIFFERENT: $(tr '\n' ' ' < $OUT/gpu_c2_gpus1.digest)"; grep -v "RCCL\|rccl" $OUT/gpus1.err | tail -5; fi
     cat $OUT/timing.txt
     for f in gpu_c2 gpu_c2_gpus1 gpu_c5 gpu_c3_bc gpu_c3; do echo "-- $f.timing"; cat $OUT/$f.timing 2>/dev/null; done
   } | tee $OUT/summary_recheck.txt
   rm -rf $W
+  # (round-5 review: an empty summary was committed as evidence) the summary must exist, name every configuration and hold no DIFFERENT
+  if [ ! -s $OUT/summary_recheck.txt ] || [ $(grep -c "EQUAL" $OUT/summary_recheck.txt) -lt 6 ] || grep -q "DIFFERENT" $OUT/summary_recheck.txt; then
+    echo "at_scale_parity: recheck summary empty, incomplete or with a difference" >&2; exit 1
+  fi
 fi
 
 if [ $PHASE = finish ] || [ $PHASE = both ]; then
