@@ -145,6 +145,11 @@ int  jfgpu_count_ascii(jfgpu_table* t, const char* bases, size_t n);      /* hos
 int  jfgpu_add_keys_dev(jfgpu_table* t, const uint64_t* d_keys, size_t n, uint64_t val, uint8_t* d_is_new);
 int  jfgpu_add_keys(jfgpu_table* t, const uint64_t* keys, size_t n, uint64_t val, uint8_t* is_new);
 
+/* The same with a value per key: hash_counter::add(const mer_dna&, uint64_t val) over a batch (hash_counter.hpp:122-126 ->
+ * large_hash_array.hpp:741-752 add_val) -- what loads the records of a binary/sorted file back into a table, so that
+ * `query -s` (sub_commands/query_main.cc:44-51) answers from the device.  Host arrays; keys of one or two words. */
+int  jfgpu_add_key_vals(jfgpu_table* t, const uint64_t* keys, const uint64_t* vals, size_t n);
+
 /* array::get_val_for_key (large_hash_array.hpp:354-372) for a batch.  vals[i] = 0 and
  * found[i] = 0 when absent.  Keys must already be canonical if the table is. */
 int  jfgpu_lookup_dev(jfgpu_table* t, const uint64_t* d_keys, size_t n, uint64_t* d_vals, uint8_t* d_found);

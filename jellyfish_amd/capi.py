@@ -70,6 +70,7 @@ SIGNATURES = {
     "jfgpu_count_ascii": (C.c_int, [_P, _P, C.c_size_t]),
     "jfgpu_add_keys_dev": (C.c_int, [_P, _P, C.c_size_t, C.c_uint64, _P]),
     "jfgpu_add_keys": (C.c_int, [_P, _P, C.c_size_t, C.c_uint64, _P]),
+    "jfgpu_add_key_vals": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "jfgpu_lookup_dev": (C.c_int, [_P, _P, C.c_size_t, _P, _P]),
     "jfgpu_lookup": (C.c_int, [_P, _P, C.c_size_t, _P, _P]),
     "jfgpu_partition_ascii_dev": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, _P]),
@@ -295,6 +296,12 @@ class Table:
         is_new = np.zeros(len(keys), dtype=np.uint8) if want_new else None
         _check(self._lib.jfgpu_add_keys(self._h, keys.ctypes.data, len(keys), val, _ptr(is_new)))
         return is_new
+
+    def add_key_vals(self, keys, vals):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64).reshape(-1, self.key_words)
+        vals = np.ascontiguousarray(vals, dtype=np.uint64)
+        assert len(keys) == len(vals)
+        _check(self._lib.jfgpu_add_key_vals(self._h, keys.ctypes.data, vals.ctypes.data, len(keys)))
 
     def add_keys_dev(self, d_keys, n, val=1, d_is_new=None):
         _check(self._lib.jfgpu_add_keys_dev(self._h, _ptr(d_keys), n, val, _ptr(d_is_new)))

@@ -957,7 +957,65 @@ int query_main(int argc, char* argv[]) {
   struct { binary_query* b; bloom_query* f; uint64_t check(const mer_dna& m) const { return b ? b->check(m) : f->check(m); } } bq{bin.get(), bloom.get()};
   const bool canonical = header.canonical();
   const unsigned k = mer_dna::k();
-  // query_from_sequence (query_main.cc:44-51): every (canonical) k-mer of the files, in order
+  // query_from_sequence (query_main.cc:44-51) answered by the device (batched GPU lookups): the file's records
+  // go back into a table under the header's own matrix (jfgpu_add_key_vals), the k-mers of the -s files are looked up in
+  // batches of a million (jfgpu_lookup: array::get_val_for_key over a batch).  Keys of one and two words, binary/sorted
+  // databases; anything else -- or JFGPU_QUERY_HOST=1, or no device -- takes the host's binary search below.
+  if(!sequences.empty() && bin && k <= 64 && !getenv("JFGPU_QUERY_HOST") && jfgpu_device_count() > 0) {
+    jfgpu_params p; memset(&p, 0, sizeof p);
+    p.k = k; p.canonical = canonical; p.size = header.size(); p.device = -1; p.out_counter_len = 8;
+    const header_matrix hm = header.matrix();
+    if(!hm.identity) p.matrix_columns = hm.columns.data();
+    jfgpu_table* t = nullptr;
+    if(jfgpu_create(&p, &t) != JFGPU_OK) die(std::string("query: ") + jfgpu_last_error());
+    const unsigned kw = (2 * k + 63) / 64, kb = (2 * k + 7) / 8, vb = header.counter_len();
+    const size_t rec = kb + vb, n_rec = (map.length() - header.offset()) / rec;
+    const unsigned char* body = reinterpret_cast<const unsigned char*>(map.base() + header.offset());
+    const size_t kBatch = (size_t)1 << 20;
+    std::vector<uint64_t> keys(kBatch * kw), vals(kBatch);
+    for(size_t r0 = 0; r0 < n_rec; r0 += kBatch) {
+      const size_t n = std::min(kBatch, n_rec - r0);
+      std::fill(keys.begin(), keys.begin() + n * kw, 0); std::fill(vals.begin(), vals.begin() + n, 0);
+      for(size_t i = 0; i < n; ++i) { memcpy(&keys[i * kw], body + (r0 + i) * rec, kb); memcpy(&vals[i], body + (r0 + i) * rec + kb, vb); }
+      if(jfgpu_add_key_vals(t, keys.data(), vals.data(), n) != JFGPU_OK) { const std::string e = jfgpu_last_error(); jfgpu_destroy(t); die("query: " + e); }
+    }
+    std::vector<uint8_t> found(kBatch);
+    size_t fill = 0;
+    std::string text;
+    auto answer = [&]() {
+      if(!fill) return;
+      if(jfgpu_lookup(t, keys.data(), fill, vals.data(), found.data()) != JFGPU_OK) { const std::string e = jfgpu_last_error(); jfgpu_destroy(t); die("query: " + e); }
+      mer_dna m(k);
+      text.clear();
+      for(size_t i = 0; i < fill; ++i) {
+        memcpy(m.data__(), &keys[i * kw], kw * sizeof(uint64_t));
+        text += m.to_str(); text += ' '; text += std::to_string(vals[i]); text += '\n';
+      }
+      out.write(text.data(), text.size());
+      fill = 0;
+    };
+    for(const auto& path : sequences) {
+      sequence_parser parser(k);
+      parser.parse_file(path.c_str(), [&](const char* buf, size_t n) {
+        mer_dna m(k), rc(k);
+        unsigned filled = 0;
+        for(size_t i = 0; i < n; ++i) {
+          const int code = mer_dna::code(buf[i]);
+          if(code < 0) { filled = 0; continue; }
+          m.shift_left(code); rc.shift_right(3 - code);
+          if(++filled >= k) {
+            filled = k;
+            const mer_dna& q = (!canonical || m < rc) ? m : rc;
+            for(unsigned w = 0; w < kw; ++w) keys[fill * kw + w] = q.word(w);
+            if(++fill == kBatch) answer();
+          }
+        }
+      });
+    }
+    answer();
+    jfgpu_destroy(t);
+    sequences.clear();
+  }
   for(const auto& path : sequences) {
     sequence_parser parser(k);
     parser.parse_file(path.c_str(), [&](const char* buf, size_t n) {

@@ -23,6 +23,8 @@ struct jfgpu_bloom {
   std::vector<Pending> pending;
   uint32_t* d_M2 = nullptr;
   uint64_t* d_strag2 = nullptr; uint32_t* d_strag2_n = nullptr; uint32_t strag2_lists = 0;     // p2_ring_kernel's straggler lists
+  uint64_t* d_strag1 = nullptr; uint32_t* d_strag1_n = nullptr;                                // p1_bloom_ring_kernel's (one list per workgroup)
+  int p1_ring_per = 0;                                                                         // cells per lane and round of the ring P1b (0: the sort-based kernels)
   bool prof_on = false;
   std::vector<ProfSpan> spans;
   double prof_ms[5] = {}; uint64_t prof_launches[5] = {}, prof_units[5] = {};      // [BS_COUNT] (bloom_partition.inl)
@@ -121,6 +123,14 @@ static int bloom_create(const jfgpu_bloom_params* p, jfgpu_bloom** out, uint32_t
       HIP_TRY(hipFuncSetAttribute((const void*)p1_bloom_granule2_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, pl2));
       HIP_TRY(hipFuncSetAttribute((const void*)p1_bloom_granule2_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, pl2));
     }
+    {
+      const int plr = (int)((size_t)512 * kBloomRingBytes + kBloomRingBytes + (size_t)8 * 512);
+      HIP_TRY(hipFuncSetAttribute((const void*)p1_bloom_ring_kernel<0, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, plr));
+      HIP_TRY(hipFuncSetAttribute((const void*)p1_bloom_ring_kernel<6, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, plr));
+      HIP_TRY(hipFuncSetAttribute((const void*)p1_bloom_ring_kernel<8, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, plr));
+      HIP_TRY(hipFuncSetAttribute((const void*)p1_bloom_ring_kernel<0, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, plr));
+      HIP_TRY(hipFuncSetAttribute((const void*)p1_bloom_ring_kernel<8, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, plr));
+    }
     HIP_TRY(hipFuncSetAttribute((const void*)bloom_segment_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 1 << kBloomSegBits));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_scatter_sorted_kernel<uint32_t, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)p2_granule_kernel<uint32_t, BloomDirect, kP2PairPer>, hipFuncAttributeMaxDynamicSharedMemorySize, kPBlock * kP2PairPer * 4));
@@ -149,6 +159,7 @@ void jfgpu_bc_destroy(jfgpu_bloom* b) {
   if(b->ws) hipFree(b->ws);
   if(b->d_M2) hipFree(b->d_M2);
   if(b->d_strag2) { hipFree(b->d_strag2); hipFree(b->d_strag2_n); }
+  if(b->d_strag1) { hipFree(b->d_strag1); hipFree(b->d_strag1_n); }
   if(b->stream) hipStreamDestroy(b->stream);
   delete b;
 }

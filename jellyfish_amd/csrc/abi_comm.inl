@@ -76,6 +76,7 @@ struct jfgpu_comm {
   IpcShared* shm = nullptr; std::string shm_name;
   struct PeerMap { void* ptr = nullptr; uint64_t epoch = 0; };
   std::vector<PeerMap> peer_send[2];             // peers' send buffers as mapped here, per turn
+  std::vector<void*> stale_maps;                 // mappings of send buffers the peers have replaced since (closed with the communicator)
   uint64_t send_epoch[2] = {0, 0}; void* send_exported[2] = {nullptr, nullptr}; size_t send_exported_cap[2] = {0, 0};
   uint32_t barrier_gen = 0;
 #endif
@@ -435,7 +436,8 @@ int comm_reserve_send(jfgpu_comm* c, jfgpu_comm::Rank& R, int turn, size_t need,
   }
   return comm_reserve(R.send[turn], R.send_cap[turn], need, s1, c->xstream);
 }
-void comm_free_retired(jfgpu_comm* c, int turn) {
+void comm_free_retired(jfgpu_comm* c, int turn, bool closing = false) {
+  if(c->tun.comm_ipc_keep && !closing) return;                 // (kept until the communicator goes: see tuning.hpp, JFGPU_IPC_KEEP)
   for(void* p : c->send_retired[turn]) hipFree(p);
   c->send_retired[turn].clear();
 }
@@ -797,7 +799,7 @@ int ipc_peer_send(jfgpu_comm* c, int p, int cur, uint8_t** out) {
   jfgpu_comm::PeerMap& M = c->peer_send[cur][p];
   const IpcShared::Pub& P = c->shm->pub[p];
   if(M.epoch != P.send_epoch[cur]) {
-    if(M.ptr) { hipIpcCloseMemHandle(M.ptr); M.ptr = nullptr; }
+    if(M.ptr) { if(c->tun.comm_ipc_keep) c->stale_maps.push_back(M.ptr); else hipIpcCloseMemHandle(M.ptr); M.ptr = nullptr; }
     if(hipIpcOpenMemHandle(&M.ptr, P.send[cur], hipIpcMemLazyEnablePeerAccess) != hipSuccess) return ipc_fail(c, "hipIpcOpenMemHandle");
     M.epoch = P.send_epoch[cur];
   }
@@ -928,6 +930,8 @@ int ipc_attach(jfgpu_comm* c, const uint8_t* id128) {
 void ipc_detach(jfgpu_comm* c) {
   if(!c->shm) return;
   for(int i = 0; i < 2; ++i) for(auto& M : c->peer_send[i]) if(M.ptr) hipIpcCloseMemHandle(M.ptr);
+  for(void* p : c->stale_maps) hipIpcCloseMemHandle(p);
+  c->stale_maps.clear();
   const bool last = c->shm->attached.fetch_sub(1) == 1;
   munmap(c->shm, sizeof(IpcShared));
   if(last) shm_unlink(c->shm_name.c_str());
@@ -1374,7 +1378,7 @@ void jfgpu_comm_destroy(jfgpu_comm* c) {
   if(c->nccl) ncclCommDestroy(c->nccl);
   ipc_detach(c);
 #endif
-  comm_free_retired(c, 0); comm_free_retired(c, 1);
+  comm_free_retired(c, 0, true); comm_free_retired(c, 1, true);
   if(c->xstream) hipStreamDestroy(c->xstream);
   delete c;
 }
@@ -1599,6 +1603,41 @@ int jfgpu_comm_finish(jfgpu_comm* c, uint64_t* sent, uint64_t* received) {
   if(sent) *sent = s;
   if(received) *received = r;
   return JFGPU_OK;
+}
+
+// hash_counter::add(key, val) for a batch with one value per key (large_hash_array.hpp:741-752 add_val with an arbitrary
+// increment): what loads a binary/sorted file back into a table -- `query -s` answers from the device that way
+// (sub_commands/query_main.cc:44-51).  Host arrays, staged; the growth / spill rules of jfgpu_add_keys.
+int jfgpu_add_key_vals(jfgpu_table* t, const uint64_t* keys, const uint64_t* vals, size_t n) {
+  int rc = use(t); if(rc) return rc;
+  if(!n) return JFGPU_OK;
+  if(!keys || !vals) return fail(JFGPU_E_INVALID, "null argument");
+  if(t->nword) return fail(JFGPU_E_UNSUPPORTED, "add_key_vals: keys longer than two words are not built");
+  if(t->g.shard_bits) return fail(JFGPU_E_UNSUPPORTED, "add_key_vals: not for a shard (route the keys first)");
+  const size_t kw = t->key_words;
+  uint64_t *d_k = nullptr, *d_v = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_k, n * kw * sizeof(uint64_t)));
+  if(hipMalloc((void**)&d_v, n * sizeof(uint64_t)) != hipSuccess) { hipFree(d_k); return fail(JFGPU_E_ALLOC, "hipMalloc values"); }
+  auto done = [&](int r) { hipStreamSynchronize(t->stream); hipFree(d_k); hipFree(d_v); return r; };
+  if(hipMemcpyAsync(d_k, keys, n * kw * sizeof(uint64_t), hipMemcpyHostToDevice, t->stream) != hipSuccess ||
+     hipMemcpyAsync(d_v, vals, n * sizeof(uint64_t), hipMemcpyHostToDevice, t->stream) != hipSuccess) return done(fail(JFGPU_E_HIP, "add_key_vals: copy"));
+  size_t off = 0;
+  while(off < n) {
+    uint64_t take = n - off;
+    if(capacity_managed(t)) { rc = ensure_capacity(t, n - off, &take); if(rc) return done(rc); }
+    uint64_t small = 0, big = 0;                              // what the overflow side table has to be ready for (ensure_ovf's two bounds)
+    for(size_t i = off; i < off + take; ++i) { if(t->g.cnt_bits < 64 && (vals[i] >> t->g.cnt_bits)) ++big; else small += vals[i]; }
+    rc = ensure_ovf(t, small, big); if(rc) return done(rc);
+    rc = part_flush(t); if(rc) return done(rc);
+    t->pristine = false;
+    const dim3 grid(grid_for(t, take / kBlock + 1)), block(kBlock);
+    if(t->wide) hipLaunchKernelGGL(add_pairs_wide_kernel, grid, block, 0, t->stream, t->wt, (const uint64_t*)(d_k + off * kw), (const uint64_t*)(d_v + off), (uint64_t)take);
+    else hipLaunchKernelGGL(add_pairs_kernel, grid, block, 0, t->stream, t->dt, (const uint64_t*)(d_k + off), (const uint64_t*)(d_v + off), (uint64_t)take);
+    if(hipGetLastError() != hipSuccess) return done(fail(JFGPU_E_HIP, "add_key_vals: launch"));
+    off += (size_t)take;
+  }
+  rc = done(JFGPU_OK);
+  return rc ? rc : check_deferred(t);
 }
 
 int jfgpu_comm_exchange_times(jfgpu_comm* c, double* ms, uint64_t* wire_bytes, size_t cap, size_t* n) {

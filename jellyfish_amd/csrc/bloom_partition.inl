@@ -95,7 +95,24 @@ int bloom_launch_direct(jfgpu_bloom* b, const uint8_t* base, int64_t lo, int64_t
 
 // One contract buffer [lo, hi) through P1b, in pieces that fit half of the arena (the other half is the flush's).
 int bloom_ingest(jfgpu_bloom* b, const uint8_t* base, int64_t lo, int64_t hi) {
-  if(!b->g1) b->g1 = b->tun.bloom_p1_two ? 2 * b->n_cu : b->n_cu;      // workgroups of P1b: two per CU (78 KB of LDS each) or one (136 KB)
+  if(!b->g1) {
+    b->g1 = b->tun.bloom_p1_two ? 2 * b->n_cu : b->n_cu;      // workgroups of P1b: two per CU (78 KB of LDS each) or one (136 KB)
+    // The ring P1b (p1_bloom_ring_kernel): one workgroup per CU, every owner lane may strand two reservations per bucket
+    // (g1 stays the regions' head-room unit: 2 x n_cu).  It wants its rounds to put ~25 cell updates on a ring of 64:
+    // ten cells a lane and round with >= 400 buckets in use, five with >= 200; smaller filters keep the sort-based kernels.
+    const uint32_t used = (uint32_t)(((uint64_t)b->bp.n_seg + ((1u << b->bp.b2) - 1)) >> b->bp.b2);
+    // (JFGPU_BLOOM_P1_RING=2 / 3: rounds of ten / five whatever the filter -- tests: on a small filter the rings overflow all
+    //  the time, so the lists, their overflow into global compare-and-swaps and exhausted regions are all on the path)
+    const int ring = b->tun.bloom_p1_ring;
+    if(ring && b->bp.b1 <= 9 && b->bp.b2 > 0 && (used >= 200 || ring >= 2) && b->g.nbytes <= 8) {
+      b->p1_ring_per = ring == 2 ? 10 : ring == 3 ? 5 : used >= 400 ? 10 : 5;
+      b->g1 = 2 * b->n_cu;
+      if(!b->d_strag1) {
+        HIP_TRY(hipMalloc((void**)&b->d_strag1, (size_t)b->n_cu * kStragPerBlock * sizeof(uint64_t)));
+        HIP_TRY(hipMalloc((void**)&b->d_strag1_n, (size_t)b->n_cu * sizeof(uint32_t)));
+      }
+    }
+  }
   int rc = bloom_ws_ensure(b, 0);
   if(rc < 0) return bloom_launch_direct(b, base, lo, hi);      // no memory for an arena
   if(rc) return rc;
@@ -143,8 +160,18 @@ int bloom_ingest(jfgpu_bloom* b, const uint8_t* base, int64_t lo, int64_t hi) {
 #define PB(N) hipLaunchKernelGGL(p1_bloom_granule_kernel<N>, dim3(b->g1), dim3(kPBlock), lds, b->stream, b->view(), b->bp, b->g, pbase, plo, phi, cap, gcur, p.tot, p.items, b->d_mers)
 #define PB2(N) hipLaunchKernelGGL(p1_bloom_granule2_kernel<N>, dim3(b->g1), dim3(kPBlock), (size_t)kPBlock * 5 * 6 + (size_t)b->g.nbytes * 512, b->stream, \
                                   b->view(), b->bp, b->g, pbase, plo, phi, cap, gcur, p.tot, p.items, b->d_mers)
-      if(b->tun.bloom_p1_two) { if(b->g.nbytes == 8) PB2(8); else if(b->g.nbytes == 6) PB2(6); else PB2(0); }
+#define PBR(N, PER) hipLaunchKernelGGL((p1_bloom_ring_kernel<N, PER>), dim3(b->n_cu), dim3(kPBlock), (size_t)nb * kBloomRingBytes + kBloomRingBytes + (size_t)b->g.nbytes * 512, b->stream, \
+                                       b->view(), b->bp, b->g, rd, pbase, plo, phi, cap, gcur, p.tot, p.items, b->d_mers, b->d_strag1, b->d_strag1_n)
+      if(b->p1_ring_per) {
+        const BloomP1RingDirect rd{b->view().data, b->bp.b2};
+        if(b->p1_ring_per == 10) { if(b->g.nbytes == 8) PBR(8, 10); else if(b->g.nbytes == 6) PBR(6, 10); else PBR(0, 10); }
+        else { if(b->g.nbytes == 8) PBR(8, 5); else PBR(0, 5); }
+        hipLaunchKernelGGL((p1_stragglers_kernel<uint32_t, BloomP1RingDirect>), dim3(b->n_cu), dim3(256), 0, b->stream, rd, (unsigned long long*)nullptr, (const uint64_t*)b->d_strag1,
+                           (const uint32_t*)b->d_strag1_n, (uint32_t)b->n_cu, cap, gcur, p.tot, p.items);
+      }
+      else if(b->tun.bloom_p1_two) { if(b->g.nbytes == 8) PB2(8); else if(b->g.nbytes == 6) PB2(6); else PB2(0); }
       else if(b->g.nbytes == 8) PB(8); else if(b->g.nbytes == 6) PB(6); else PB(0);
+#undef PBR
 #undef PB2
 #undef PB
       hipLaunchKernelGGL(granule_finish_kernel, dim3((nb + 255) / 256), dim3(256), 0, b->stream, gcur, cap, nb, p.off);

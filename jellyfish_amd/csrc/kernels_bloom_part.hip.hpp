@@ -18,6 +18,7 @@
 // item = (segment & (2^b2 - 1)) << 19 | byte offset in the segment (16 bits) << 3 | digit (p % 5)
 #pragma once
 #include "kernels_part.hip.hpp"
+#include "kernels_p1ring.hip.hpp"
 #include "kernels_bloom.hip.hpp"
 
 namespace jfgpu {
@@ -185,6 +186,143 @@ void p1_bloom_granule2_kernel(DevBloom B, BloomPart BP, TableGeom g, const uint8
 // in (byte, digit) coordinates with additions only: 548 ms, and 431 in the kernel above).  SQ counters of the kernel
 // above: VALU busy 50 % of the CU's cycles, LDS 47 %, waves waiting 64 % of theirs at four waves per SIMD -- the pass is
 // bound by latency at this occupancy (93 KB of LDS per workgroup), which rings of 64 KB + 32 KB of tables do not change.)
+
+// ---- P1b through rings of 256 bytes (round 6) ---------------------------------------------------------------------------
+// The sort-based kernel above writes a chunk's run of a bucket wherever the region's cursor stands: 735 GB of HBM writes for
+// 320 GB of cell updates on config 3 (profiles/r05_traffic_C3.json: 2.3 x), five to seven barriers per 5 Ki updates, 406 ms.
+// Round 4's ring version (rings of 32 updates, two barriers a round, at most four cells a lane and round because a ring of 32
+// takes no more) paid 4.4 - 5.9 us a round whatever it held.  Here: config 3's P1b has 512 buckets (417 in use: the array
+// ends inside the last one), so a ring may have 256 bytes -- 64 updates, four 64-byte units -- and ONE round takes all ten
+// cells of a k-mer: 10 Ki updates a round, 24.5 a ring in use (15 left over + 24.5 + 3 sigma = 55 < 64).  The rest is the
+// count path's ring kernel (kernels_p1ring.hip.hpp): appends by one returning ds_add and one store per update in two
+// sweeps, one barrier a round, owner lanes write the complete units out as aligned 64-byte runs (reservations asked a
+// round ahead), what finds its ring full goes on the workgroup's list (p1_stragglers_kernel).  A cell update never equals
+// the hole marker (its digit field is at most 4).  The two hashes come from nibble tables (4 KB for k = 31) like the
+// two-workgroup kernel's.  PER: cells per lane and round (10: >= 400 buckets in use, 5: >= 200).
+constexpr uint32_t kBloomRingBytes = 256;
+__device__ __attribute__((noinline)) void bloom_p1_item_direct_call(uint32_t* data, uint32_t b2, uint32_t bucket, uint32_t item) {
+  const uint64_t seg = ((uint64_t)bucket << b2) | (item >> kBloomItemLow);
+  const uint64_t byte = (seg << kBloomSegBits) | ((item >> 3) & 0xFFFFu);
+  bloom_bump(data, byte, item & 7u);
+}
+struct BloomP1RingDirect {
+  static constexpr bool kCountsDirect = false;
+  uint32_t* data; uint32_t b2;
+  __device__ void operator()(uint32_t bucket, uint64_t item, uint32_t cnt) const { for(uint32_t i = 0; i < cnt; ++i) bloom_p1_item_direct_call(data, b2, bucket, (uint32_t)item); }
+};
+
+template <int NB, int PER>
+__global__ __launch_bounds__(kPBlock) void p1_bloom_ring_kernel(DevBloom B, BloomPart BP, TableGeom g, BloomP1RingDirect D, const uint8_t* __restrict__ base,
+                                                                int64_t lo, int64_t hi, uint32_t cap,
+                                                                unsigned int* __restrict__ gcur, unsigned long long* __restrict__ tot,
+                                                                uint32_t* __restrict__ out, unsigned long long* __restrict__ mers,
+                                                                uint64_t* __restrict__ strag, uint32_t* __restrict__ strag_n) {
+  using R = Ring<uint32_t, kBloomRingBytes>;
+  JF_DYN_LDS(s_dyn);
+  const uint32_t nb = 1u << BP.b1;
+  uint32_t* s_ring = reinterpret_cast<uint32_t*>(s_dyn);                                // [nb][64], then 64 dump slots
+  uint4* s_tn = reinterpret_cast<uint4*>(s_dyn + (size_t)nb * kBloomRingBytes + kBloomRingBytes);      // [nbytes * 32] nibble tables
+  __shared__ uint32_t s_fill[kGranMaxB + 32];
+  __shared__ uint32_t s_nstrag;
+  __shared__ uint32_t s_codes[kPBlock + 2];
+  __shared__ uint32_t s_inv[kPBlock + 2];
+  const uint32_t t = threadIdx.x, lane = t & 63;
+  const bool owner = t < nb;
+  for(uint32_t i = t; i < B.nbytes * 32; i += blockDim.x) {        // entry (nibble j, value v) = the byte tables' entry of that value in that nibble
+    const uint32_t j = i >> 4, v = i & 15u;
+    const uint32_t at = (j >> 1) * 256 + ((j & 1) ? (v << 4) : v);
+    const uint64_t a = B.tbl1[at], c = B.tbl2[at];
+    s_tn[i] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)c, (uint32_t)(c >> 32));
+  }
+  ring_init<uint32_t, kBloomRingBytes>(s_ring, s_fill, nb, &s_nstrag);
+  const uint32_t dump = nb * R::kSlots + (lane & (R::kSlots - 1));
+  unsigned int* const gshort = gcur + nb;
+  uint64_t* const my_strag = strag + (size_t)blockIdx.x * kStragPerBlock;
+  const uint32_t k = g.k, rc_shift = 2 * (k - 1);
+  const uint32_t sub_mask = (1u << BP.b2) - 1u;
+  RingBooks Bk;
+  if(owner) { Bk.nxt = atomicAdd(&gcur[t], kGran); Bk.nxt_asked = true; }
+  uint32_t* const my_region = out + (uint64_t)t * cap;
+  uint32_t my_mers = 0;
+  auto straggler = [&](uint32_t b, uint32_t item, uint32_t cnt) {
+    const uint32_t at = atomicAdd(&s_nstrag, 1u);
+    if(at < kStragPerBlock) strag_store<uint32_t>(my_strag + at, b, item, cnt);
+    else D(b, (uint64_t)item, cnt);
+  };
+  const int64_t n_tiles = (hi + kPTilePos - 1) / kPTilePos;
+  TileRaw Rw = tile_fetch(base, (int64_t)blockIdx.x * kPTilePos, lo, hi);
+  lds_barrier();
+  for(int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const LaneWords L = tile_stage(Rw, tile * kPTilePos, lo, hi, s_codes, s_inv);      // barrier inside
+    Rw = tile_fetch(base, (tile + gridDim.x) * kPTilePos, lo, hi);
+    uint64_t fw = (((uint64_t)L.p2 << 32) | L.p1) & g.key_mask;
+    uint64_t rc = revcomp64(fw, k);
+    uint64_t smear = L.inv48;                                        // (kernels_p1ring.hip.hpp: which positions end a window of k valid bases)
+    for(uint32_t s = 1; s < k; ) { const uint32_t step = s < k - s ? s : k - s; smear |= smear >> step; s += step; }
+    const uint32_t vmask = ~(uint32_t)smear & 0xFFFFu;
+    my_mers += (uint32_t)__popc(vmask);
+#pragma unroll 1
+    for(int j = 0; j < kPerLane; ++j) {
+      const uint64_t c = (L.cur >> (2 * (15 - j))) & 3u;
+      fw = ((fw << 2) | c) & g.key_mask;
+      rc = (rc >> 2) | ((3ull - c) << rc_shift);
+      const bool valid = (vmask >> (15 - j)) & 1u;
+      const uint64_t key = (g.canonical && rc < fw) ? rc : fw;
+      // (a position without a k-mer hashes whatever its registers hold and appends to the spare fill words: no branch)
+      uint32_t a0 = 0, a1 = 0, c0 = 0, c1 = 0;
+      constexpr int kNibs = NB ? 2 * NB : 16;
+#pragma unroll
+      for(int q = 0; q < kNibs; ++q)
+        if(NB || (uint32_t)q < 2 * B.nbytes) { const uint4 e = s_tn[q * 16 + ((uint32_t)(key >> (4 * q)) & 15u)]; a0 ^= e.x; a1 ^= e.y; c0 ^= e.z; c1 ^= e.w; }
+      uint64_t cell = bloom_mod(((uint64_t)a1 << 32) | a0, B.m, B.recip);
+      const uint64_t inc = bloom_mod(((uint64_t)c1 << 32) | c0, B.m, B.recip);
+      // (Round 6 also walked the cells in (byte, digit) coordinates -- one division by five per k-mer and step instead of one
+      // per cell: the carry and wrap tests came out as branches, 655 vector instructions a round instead of 526.  The round
+      // is not bound by them anyway: 526 x 16 waves = 3.5 us of issue against the 9.1 us a round takes.)
+      for(uint32_t h0 = 0; h0 < B.nh; h0 += PER) {                    // block-uniform trip count (one round for nh = PER)
+        uint32_t ea[PER], eo[PER], ei[PER];
+#pragma unroll
+        for(int e = 0; e < PER; ++e) {
+          const bool on = valid && h0 + e < B.nh;
+          uint64_t byte; uint32_t dig;
+          divmod5(cell, byte, dig);
+          const uint32_t seg = (uint32_t)(byte >> kBloomSegBits);
+          const uint32_t b = seg >> BP.b2;
+          ei[e] = ((seg & sub_mask) << kBloomItemLow) | ((uint32_t)(byte & 0xFFFFu) << 3) | dig;
+          const uint32_t o = atomicAdd(&s_fill[on ? b : nb + (lane & 31u)], 1u);
+          ea[e] = on ? b * R::kSlots : dump; eo[e] = on ? o : 0u;
+          cell += inc; if(cell >= B.m) cell -= B.m;
+        }
+        uint32_t ghosts = 0;
+#pragma unroll
+        for(int e = 0; e < PER; ++e) {
+          const uint32_t full = eo[e] & R::kFull;
+          ghosts |= full;
+          const uint32_t at = ea[e] + ((eo[e] + (eo[e] >> 16)) & (R::kSlots - 1));
+          s_ring[full ? dump : at] = ei[e];
+        }
+        if(ghosts) {
+#pragma unroll 1
+          for(int e = 0; e < PER; ++e) if(eo[e] & R::kFull) straggler(ea[e] / R::kSlots, ei[e], 1u);
+        }
+        lds_barrier();                                                // the round's updates have all landed
+        wave_prio<3>();
+        if(owner) ring_flush<uint32_t, false, kBloomRingBytes>(s_ring, s_fill, t, false, Bk, my_region, cap, gcur, gshort, straggler);
+        wave_prio<0>();
+#ifdef JFGPU_BLOOM_P1_BAR2
+        lds_barrier();
+#endif
+      }
+    }
+  }
+  lds_barrier();
+  if(owner) { ring_flush<uint32_t, false, kBloomRingBytes>(s_ring, s_fill, t, true, Bk, my_region, cap, gcur, gshort, straggler); ring_finish<uint32_t>(Bk, t, my_region, cap, gshort, tot); }
+  lds_barrier();
+  if(t == 0) strag_n[blockIdx.x] = s_nstrag < kStragPerBlock ? s_nstrag : kStragPerBlock;
+  uint64_t w = my_mers;
+  for(int o = 32; o > 0; o >>= 1) w += __shfl_down(w, o, 64);
+  if((threadIdx.x & 63) == 0 && w) atomicAdd(mers, (unsigned long long)w);
+}
 
 // ---- Tb: one workgroup owns one 64 KiB segment of the byte array in LDS ---------------------------------------
 __device__ inline void bloom_lds_bump(uint32_t* s_seg, uint32_t item) {

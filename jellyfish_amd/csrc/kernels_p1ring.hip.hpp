@@ -66,10 +66,11 @@ constexpr uint32_t kStragPerBlock = 16384;                                     /
 
 // ---- the ring machinery, shared by the P1 kernels of every item width ---------------------------------------------------
 // A ring is 128 bytes of LDS whatever the item (32 four-byte, 16 eight-byte or 8 sixteen-byte items), a unit half of it
-// (one aligned 64-byte run in the bucket's region), and it is read and reset in 16-byte chunks.
-template <typename ITEM> struct Ring {
-  static constexpr uint32_t kSlots = 128 / sizeof(ITEM);
-  static constexpr uint32_t kUnit = kSlots / 2;
+// (one aligned 64-byte run in the bucket's region), and it is read and reset in 16-byte chunks.  RB: the ring's bytes
+// (round 6: the Bloom counter's P1b takes rings of 256 bytes -- 64 cell updates, four units -- for its 512 buckets).
+template <typename ITEM, uint32_t RB = 128> struct Ring {
+  static constexpr uint32_t kSlots = RB / sizeof(ITEM);
+  static constexpr uint32_t kUnit = 64 / sizeof(ITEM);
   static constexpr uint32_t kChunk = 16 / sizeof(ITEM);                        // items per 16-byte chunk
   static constexpr uint32_t kFull = 0xFFFFu & ~(kSlots - 1);                   // bits of a rank that say "the ring is full"
   static constexpr uint32_t kWords = sizeof(ITEM) <= 4 ? 1 : 1 + sizeof(ITEM) / 8;   // 64-bit words of a straggler entry
@@ -113,10 +114,10 @@ struct RingBooks { uint32_t gpos = 0, room = 0, nxt = 0, stored = 0; bool nxt_as
 // What bucket t has complete goes out (owner lanes only).  `all`: the kernel's last call, after a barrier -- every append
 // has landed, and the partial last unit goes out too (the slots behind its items are holes already).
 // OWNED: the region has one writer (this lane) -- B.room is what is left of it, nothing is reserved.
-template <typename ITEM, bool OWNED = false, typename STRAG>
+template <typename ITEM, bool OWNED = false, uint32_t RB = 128, typename STRAG>
 __device__ __forceinline__ void ring_flush(ITEM* s_ring, uint32_t* s_fill, uint32_t t, bool all, RingBooks& B, ITEM* my_region, uint32_t cap,
                                            unsigned int* gcur, unsigned int* gshort, STRAG&& straggler) {
-  using R = Ring<ITEM>;
+  using R = Ring<ITEM, RB>;
   const ITEM hole = (ITEM)~(ITEM)0;
   const uint32_t w = s_fill[t];
   uint32_t cnt = w & 0xFFFFu; if(cnt > R::kSlots) cnt = R::kSlots;
@@ -177,12 +178,12 @@ __device__ __forceinline__ void ring_flush(ITEM* s_ring, uint32_t* s_fill, uint3
 }
 
 // rings, fill words, the list's counter: before the first append (the caller's barrier follows)
-template <typename ITEM>
+template <typename ITEM, uint32_t RB = 128>
 __device__ __forceinline__ void ring_init(ITEM* s_ring, uint32_t* s_fill, uint32_t nb, uint32_t* s_nstrag) {
-  using R = Ring<ITEM>;
+  using R = Ring<ITEM, RB>;
   for(uint32_t j = threadIdx.x; j < nb; j += blockDim.x) s_fill[j] = R::first_fill(j);
   uint4* r4 = reinterpret_cast<uint4*>(s_ring);
-  for(uint32_t j = threadIdx.x; j < nb * 8 + 8; j += blockDim.x) r4[j] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);      // (+ the dump slots)
+  for(uint32_t j = threadIdx.x; j < nb * (RB / 16) + RB / 16; j += blockDim.x) r4[j] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);      // (+ the dump slots)
   if(threadIdx.x == 0) *s_nstrag = 0;
 }
 
@@ -353,7 +354,11 @@ __global__ __launch_bounds__(kPBlock) void p1_ring_kernel(DevTable T, DIRECT D, 
         }
         const uint32_t v = vmask & (1u << (15 - j));
         const uint64_t key = ((CANON == 1 || (CANON == 2 && g.canonical)) && rc < fw) ? rc : fw;
+#ifdef JFGPU_P1_NO_RUNS                                            /* ablation (round 6): every occurrence its own item */
+        const bool same = false;
+#else
         const bool same = v && pv && key == pk;
+#endif
         emit(e, pk, run, pv && !same);
         run = same ? run + 1 : 1;
         pk = key; pv = v;

@@ -264,7 +264,9 @@ JF_HD void xs_hash_halves(uint32_t klo, uint32_t khi, uint32_t hi_mask, uint32_t
   uint32_t lo = xor3(klo, funnel_r(khi, klo, kXsR0a), funnel_r(khi, klo, kXsR0b));
   if(FOLD) lo ^= khi;
   lo ^= lo << kXsL1;
+#ifndef JFGPU_XS_TWO_STEPS                                           /* ablation (round 6): what a shorter mix would buy */
   lo ^= lo << kXsL2;
+#endif
   lo ^= lo >> kXsR3;
   ylo = lo; yhi = xor_and(khi, lo >> kXsFold, hi_mask);
 }

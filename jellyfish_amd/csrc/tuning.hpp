@@ -37,9 +37,11 @@ struct Tuning {
   // ---- Bloom counters (jfgpu_bloom_create)
   int bloom_mode = 0;            // JFGPU_BLOOM_MODE=direct|partitioned      0: not set
   int bloom_p1_two = 1;          // JFGPU_BLOOM_P1_TWO     P1b as two workgroups per CU (rounds of 5 cells, nibble tables); 0: one, rounds of 10 (A/B)
+  int bloom_p1_ring = 1;         // JFGPU_BLOOM_P1_RING    P1b through rings of 256 bytes where the filter gives it >= 200 buckets of at most 512 (0: the sort-based kernels; A/B)
   // ---- communicators (jfgpu_comm_create*)
   bool comm_trace = false;       // JFGPU_COMM_TRACE       every rank reports where it is in a step
   bool comm_ipc = false;         // JFGPU_COMM_TRANSPORT=ipc   rank processes exchange through hipIpc* copies instead of RCCL
+  int comm_ipc_keep = 1;         // JFGPU_IPC_KEEP         ipc transport: 1 = re-allocated send buffers and the peers' mappings of them live until the communicator goes (0: closed / freed as soon as replaced; A/B)
   uint64_t comm_max_msg = 0;     // JFGPU_COMM_MAX_MSG     keys per message round (0: default)
   int comm_self_rccl = -1;       // JFGPU_COMM_SELF_RCCL   world 1: send the rank's own share through RCCL too (-1: default)
   int comm_items = -1;           // JFGPU_COMM_ITEMS       item path: -1 default, 0 off, 1 on, 2 forced
@@ -70,9 +72,11 @@ struct Tuning {
     if(const char* e = str("JFGPU_BLOOM_CACHE")) u.bloom_cache = atoi(e);
     if(const char* e = str("JFGPU_BLOOM_CACHE_LOG2")) u.bloom_cache_log2 = (uint32_t)std::min(30, std::max(2, atoi(e)));
     if(const char* e = str("JFGPU_BLOOM_P1_TWO")) u.bloom_p1_two = atoi(e);
+    if(const char* e = str("JFGPU_BLOOM_P1_RING")) u.bloom_p1_ring = atoi(e);
     if(const char* e = str("JFGPU_BLOOM_MODE")) u.bloom_mode = !strcmp(e, "direct") ? 1 : !strcmp(e, "partitioned") ? 2 : 0;
     u.comm_trace = str("JFGPU_COMM_TRACE") != nullptr;
     if(const char* e = str("JFGPU_COMM_TRANSPORT")) u.comm_ipc = !strcmp(e, "ipc");
+    if(const char* e = str("JFGPU_IPC_KEEP")) u.comm_ipc_keep = atoi(e);
     if(const char* e = str("JFGPU_COMM_MAX_MSG")) u.comm_max_msg = std::max<uint64_t>(1, strtoull(e, 0, 10));
     if(const char* e = str("JFGPU_COMM_SELF_RCCL")) u.comm_self_rccl = atoi(e) != 0;
     if(const char* e = str("JFGPU_COMM_ITEMS")) u.comm_items = atoi(e);

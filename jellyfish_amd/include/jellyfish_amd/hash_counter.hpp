@@ -155,6 +155,11 @@ public:
     for(unsigned i = 0; i < kw_; ++i) pending_.push_back(k.word(i));
     if(pending_.size() >= kBatch * kw_) flush_locked();
   }
+  // a batch of (key, value) pairs at once (keys: key_words() words each, little-endian): loading a sorted file
+  void add_batch(const uint64_t* keys, const uint64_t* vals, size_t n) {
+    flush();
+    jf_check(jfgpu_add_key_vals(t_, keys, vals, n));
+  }
   // add(k, v, &is_new, &id) (hash_counter.hpp:91-115): synchronous (SWIG HashCounter.add).
   void add(const mer_dna& k, uint64_t v, bool* is_new, size_t* id = nullptr) {
     flush();

@@ -376,8 +376,8 @@ def test_file_body_is_byte_identical_to_the_reference(cli, tmp_path, name):
     command line (tests/golden/*.ref.jf, produced by oracle/_ref)."""
     case = next(c for c in MANIFEST["cases"] if c["name"] == name)
     out = str(tmp_path / "out.jf")
-    cmd = [cli, "count", "-m", str(case["k"]), "-s", case["size"], "-o", out] + (["-C"] if case["canonical"] else [])
-    subprocess.check_call(cmd + [os.path.join(GOLD, case["input"])])
+    cmd = [cli, "count", "-m", str(case["k"]), "-s", case["size"], "-o", out, "--matrix", "reference"] + (["-C"] if case["canonical"] else [])
+    subprocess.check_call(cmd + [os.path.join(GOLD, case["input"])])       # (the family is named: a suite run under JFGPU_MATRIX=xs keeps this test meaningful)
     ref = os.path.join(GOLD, name + ".ref.jf")
     assert _body(out) == _body(ref)
     import json as _json
@@ -385,6 +385,79 @@ def test_file_body_is_byte_identical_to_the_reference(cli, tmp_path, name):
     h_ref = _json.loads(open(ref, "rb").read()[9:9 + int(open(ref, "rb").read()[:9])].decode().rstrip("\0 \n"))
     for key in ("matrix1", "size", "key_len", "counter_len", "format", "canonical"):
         assert h_mine[key] == h_ref[key], key
+
+
+@pytest.mark.parametrize("k,flags,size", [(21, ["-C"], "4M"), (21, [], "4M"), (21, ["-C"], "2k"), (31, ["-C"], "4M"), (32, [], "1M"),
+                                          (40, ["-C"], "4M"), (63, ["-C"], "2k"), (10, ["-C"], "4M"), (17, ["-C"], "16M")])
+def test_xorshift_matrix_files_are_read_by_the_reference(cli, tmp_path, k, flags, size):
+    """`count --matrix xs` (include/jfgpu.h: JFGPU_MATRIX_XORSHIFT; kmer_core.hpp: xs_hash): the hash matrix is any matrix with
+    an invertible low block as far as the file format goes -- readers take it from the header (include/jellyfish/file_header.hpp:35-64,
+    rectangular_binary_matrix.hpp:155-164).  The file written under the xor-shift family holds the counts of the file written
+    under the reference's own matrix; the reference's reader accepts its record order (--check-order walks the (pos, key)
+    order under the header's matrix), dumps the same records, answers queries from it (binary search by position) and
+    draws the same histogram.  -s 2k: the table doubles many times, every doubling under the next member of the family;
+    k = 10 and k = 17 -s 16M: the identity cases (table bits >= key bits) and the 32-bit-position members."""
+    import random
+    rng = random.Random(1000 + k)
+    fa = tmp_path / "reads.fa"
+    genome = "".join(rng.choice("ACGT") for _ in range(30000))
+    with open(fa, "w") as f:
+        for r in range(2500):
+            a = rng.randrange(len(genome) - 150)
+            read = list(genome[a:a + 150])
+            if r % 97 == 0:
+                read[rng.randrange(150)] = "N"
+            if r % 211 == 0:
+                read[40:110] = "A" * 70                                        # a homopolymer run: one k-mer many times in a row
+            f.write(">r%d\n%s\n" % (r, "".join(read)))
+    xs, rf = str(tmp_path / "xs.jf"), str(tmp_path / "ref.jf")
+    subprocess.check_call([cli, "count", "-m", str(k), "-s", size, "-o", xs, "--matrix", "xs"] + flags + [str(fa)])
+    subprocess.check_call([cli, "count", "-m", str(k), "-s", size, "-o", rf, "--matrix", "reference"] + flags + [str(fa)])
+    mine_xs = subprocess.check_output([cli, "dump", "-c", xs]).splitlines()
+    mine_rf = subprocess.check_output([cli, "dump", "-c", rf]).splitlines()
+    assert sorted(mine_xs) == sorted(mine_rf) and len(mine_xs) > 1000
+    info = subprocess.check_output([cli, "info", xs]).decode()
+    if 2 * k > {"4M": 22, "2k": 11, "1M": 20, "16M": 24}[size] and k > 10:
+        assert mine_xs != mine_rf                                              # (another matrix, another order)
+    if not O.have_ref():
+        pytest.skip("oracle/_ref not built")
+    assert subprocess.check_output([O.REF_JF, "dump", "--check-order", xs]).decode().startswith("ORDER OK"), info
+    assert subprocess.check_output([O.REF_JF, "dump", "-c", xs]).splitlines() == mine_xs
+    assert subprocess.check_output([O.REF_JF, "histo", xs]) == subprocess.check_output([O.REF_JF, "histo", rf])
+    picks = [l.split()[0].decode() for l in mine_xs[:: max(1, len(mine_xs) // 7)]][:7] + ["A" * k]
+    ans = subprocess.check_output([O.REF_JF, "query", xs] + picks).decode().split()
+    want = dict(l.decode().split() for l in mine_xs)
+    assert [ans[2 * i + 1] for i in range(len(picks))] == [want.get(q, "0") for q in picks]
+
+
+@pytest.mark.parametrize("k,flags,matrix", [(21, ["-C"], "reference"), (21, ["-C"], "xs"), (40, ["-C"], "xs"), (12, [], "reference")])
+def test_query_sequence_is_answered_from_the_device(cli, tmp_path, k, flags, matrix):
+    """`query -s file` (sub_commands/query_main.cc:44-51: every k-mer of the sequence files, in order, with its count): the
+    records of the database go back into a device table under the header's matrix (jfgpu_add_key_vals) and the k-mers are
+    looked up in batches (jfgpu_lookup) -- the output is, byte for byte, the host path's (binary search in the mapped
+    file, JFGPU_QUERY_HOST=1), and its counts are the dump's."""
+    import random
+    rng = random.Random(7 * k)
+    genome = "".join(rng.choice("ACGT") for _ in range(20000))
+    fa = tmp_path / "reads.fa"
+    with open(fa, "w") as f:
+        for r in range(1500):
+            a = rng.randrange(len(genome) - 120)
+            f.write(">r%d\n%s\n" % (r, genome[a:a + 120]))
+    db = str(tmp_path / "db.jf")
+    subprocess.check_call([cli, "count", "-m", str(k), "-s", "1M", "-o", db, "--matrix", matrix] + flags + [str(fa)])
+    q = tmp_path / "q.fa"
+    with open(q, "w") as f:
+        f.write(">known\n%s\n>with_N\n%sN%s\n>novel\n%s\n" % (genome[100:700], genome[3000:3100], genome[3100:3200],
+                                                              "".join(rng.choice("ACGT") for _ in range(300))))
+    dev = subprocess.check_output([cli, "query", db, "-s", str(q)])
+    host = subprocess.check_output([cli, "query", db, "-s", str(q)], env=dict(os.environ, JFGPU_QUERY_HOST="1"))
+    assert dev == host
+    lines = dev.decode().splitlines()
+    assert len(lines) == (600 - k + 1) + 2 * (100 - k + 1) + (300 - k + 1)
+    want = dict(l.split() for l in subprocess.check_output([cli, "dump", "-c", db]).decode().splitlines())
+    assert all(want.get(l.split()[0], "0") == l.split()[1] for l in lines)
+    assert sum(1 for l in lines if l.split()[1] != "0") >= (600 - k + 1)
 
 
 @pytest.mark.parametrize("case", MANIFEST["bloom"], ids=lambda c: c["name"])

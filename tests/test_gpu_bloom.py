@@ -225,7 +225,8 @@ def test_count_bc_single_pass_partition_equals_direct(gpu, monkeypatch):
 
 
 @pytest.mark.parametrize("n_cells,two_level,share", [(14 * 150000, False, None), (14 * 30_000_000, True, None), (14 * 30_000_000, True, "4"),
-                                                     (14 * 30_000_000, True, "single"), (14 * 30_000_000, True, "single4")])
+                                                     (14 * 30_000_000, True, "single"), (14 * 30_000_000, True, "single4"),
+                                                     (14 * 30_000_000, True, "ring10"), (14 * 30_000_000 + 3, True, "ring10"), (14 * 30_000_000 + 1, True, "ring5"), (5 * 3_400_000_000, True, "single")])
 def test_partitioned_insert_equals_direct_and_oracle(gpu, monkeypatch, n_cells, two_level, share):
     """The partitioned insert (cell updates routed to 64 KiB segments, applied in LDS: kernels_bloom_part.hip.hpp) leaves
     the same bytes as one global compare-and-swap per cell and as the oracle's bloom_counter2 restatement; with more
@@ -233,7 +234,12 @@ def test_partitioned_insert_equals_direct_and_oracle(gpu, monkeypatch, n_cells, 
     a flush in the middle (check on encoded keys), inserts after it."""
     # share: P2 and the segment kernel go through the P1b buckets in groups that share one output buffer; single: the
     # single-pass P2 (fixed regions per segment, forced on: test-sized flushes would take the exact one)
+    # ring10 / ring5 (round 6): P1b through rings of 256 bytes (p1_bloom_ring_kernel) forced onto a filter of 32 buckets -- every
+    # round overflows its rings, so the straggler lists, their overflow into global compare-and-swaps and the final partial
+    # units carry most of the updates; the 3.4 GB filter (206 of 256 buckets in use) takes the ring kernel by itself
     monkeypatch.setenv("JFGPU_P2_SINGLE", "2" if share and share.startswith("single") else "0")
+    if share and share.startswith("ring"):
+        monkeypatch.setenv("JFGPU_BLOOM_P1_RING", "2" if share == "ring10" else "3")
     if share and share[-1] == "4":
         monkeypatch.setenv("JFGPU_FLUSH_SHARE", "4")
     rng = random.Random(17)
