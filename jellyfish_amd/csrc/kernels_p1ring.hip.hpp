@@ -10,6 +10,7 @@
 // format, reservations of kGran items and holes are exactly the granule kernels' (kernels_part.hip.hpp), so P2 and the
 // tile kernel read the output as before.  Round 4 rebuilt the kernel around what its counters said (see below).
 #pragma once
+#include <type_traits>
 #include "kernels_part.hip.hpp"
 
 namespace jfgpu {
@@ -293,12 +294,19 @@ __global__ __launch_bounds__(kPBlock) void p1_ring_kernel(DevTable T, DIRECT D, 
     const uint32_t rawmask = ~(uint32_t)smear & 0xFFFFu;
     const uint32_t vmask = BLOOM ? (rawmask & adm_to_vmask(adm)) : rawmask;
     my_mers += (uint32_t)__popc(rawmask);
-    // a k-mer is emitted one position late, when it is known whether the next one repeats it (homopolymers, tandem
-    // repeats: one entry for the run): pk / pv / run describe the position before
+    // RUNS: a k-mer is emitted one position late, when it is known whether the next one repeats it (homopolymers: one entry
+    // for the run, with its length): pk / pv / run describe the position before.  Round 6: that logic -- the compare with the
+    // k-mer before, the run counter, a ninth entry per round for the tile's last k-mer -- is worth 1.2 ms of the metric's job
+    // (profiles/r06_p1_experiments.log: -DJFGPU_P1_NO_RUNS), and a run of k + 1 equal bases (k >= 14) always covers one
+    // aligned chunk of eight bases of the lane's own word or of the word before it.  So a wave whose lanes see no such chunk
+    // takes the rounds WITHOUT the run logic (every position emits its own k-mer at once, eight entries a round); a wave that
+    // sees one (2 % of the waves on random sequence: a chunk of eight equal bases by chance) takes the rounds above as they were.
+    auto rounds = [&](auto runs_tag) {
+    constexpr bool RUNS = decltype(runs_tag)::value;
     uint64_t pk = 0; uint32_t pv = 0, run = 0;
 #pragma unroll 1
     for(int j0 = 0; j0 < kPerLane; j0 += RP) {
-      constexpr int NE = RP + 1;                                    // (the +1: the tile's last k-mer, emitted after the loop)
+      constexpr int NE = RUNS ? RP + 1 : RP;                        // (the +1: the tile's last k-mer, emitted after the loop)
       // ea: the ring's first slot (bucket * slots), ei: item, eo: fill word before the append.  A position without an item
       // keeps (dump, 0): the second sweep stores unconditionally, those stores land in the dump slots
       uint32_t ea[NE], eo[NE]; ITEM ei[NE];
@@ -354,16 +362,18 @@ __global__ __launch_bounds__(kPBlock) void p1_ring_kernel(DevTable T, DIRECT D, 
         }
         const uint32_t v = vmask & (1u << (15 - j));
         const uint64_t key = ((CANON == 1 || (CANON == 2 && g.canonical)) && rc < fw) ? rc : fw;
+        if constexpr(RUNS) {
 #ifdef JFGPU_P1_NO_RUNS                                            /* ablation (round 6): every occurrence its own item */
-        const bool same = false;
+          const bool same = false;
 #else
-        const bool same = v && pv && key == pk;
+          const bool same = v && pv && key == pk;
 #endif
-        emit(e, pk, run, pv && !same);
-        run = same ? run + 1 : 1;
-        pk = key; pv = v;
+          emit(e, pk, run, pv && !same);
+          run = same ? run + 1 : 1;
+          pk = key; pv = v;
+        } else emit(e, key, 1u, v != 0);
       }
-      if(j0 + RP >= kPerLane) { emit(NE - 1, pk, run, pv != 0); pv = 0; }
+      if constexpr(RUNS) { if(j0 + RP >= kPerLane) { emit(NE - 1, pk, run, pv != 0); pv = 0; } }
       // second sweep: the ring stores, once the fill adds are back (not one wait per item), without a branch per item
       uint32_t ghosts = 0;
 #pragma unroll
@@ -376,7 +386,12 @@ __global__ __launch_bounds__(kPBlock) void p1_ring_kernel(DevTable T, DIRECT D, 
       if(ghosts) {                                                  // rare: a ghost in its bucket's count until the owner's next release
 #pragma unroll 1
 #ifndef JFGPU_P1_LATE_SPECIAL
-        for(int e = 0; e < NE; ++e) if(eo[e] & R::kFull) straggler(ea[e] / R::kSlots, ei[e], 1u);
+        for(int e = 0; e < NE; ++e) {                               // (entry e by selects on static indices: a dynamic index would put the three arrays in scratch)
+          uint32_t a = 0, o = 0; ITEM it = 0;
+#pragma unroll
+          for(int q = 0; q < NE; ++q) if(q == e) { a = ea[q]; o = eo[q]; it = ei[q]; }
+          if(o & R::kFull) straggler(a / R::kSlots, it, 1u);
+        }
 #else
         for(int e = 0; e < NE; ++e) if(eo[e] & R::kFull) straggler(ea[e] / R::kSlots, ei[e], ((spm >> e) & 1u) ? eo[e] >> 16 : 1u);
 #endif
@@ -395,6 +410,18 @@ __global__ __launch_bounds__(kPBlock) void p1_ring_kernel(DevTable T, DIRECT D, 
 #endif
       JF_PHASE(pc, 3);
     }
+    };
+    bool may_run = k < 14;
+    {
+      const uint32_t hc = L.cur ^ (L.cur >> 2), hp = L.p1 ^ (L.p1 >> 2);      // zero fields: a base equal to the one before it
+      // (a run that ends at the lane's position j covers bases j - k .. j, so its last aligned chunk starts at -8, 0 or 8:
+      //  the low half of the word before, either half of the lane's own)
+      may_run = may_run || (hc & 0x3FFFu) == 0 || ((hc >> 16) & 0x3FFFu) == 0 || (hp & 0x3FFFu) == 0;
+    }
+#ifdef JFGPU_P1_ALWAYS_RUNS
+    may_run = true;
+#endif
+    if(__ballot(may_run) != 0ull) rounds(std::true_type{}); else rounds(std::false_type{});      // (wave-uniform: both sides meet the same barriers)
   }
   lds_barrier();                                                   // every append of every wave has landed
   if(owner) { ring_flush<ITEM>(s_ring, s_fill, t, true, B, my_region, cap, gcur, gshort, straggler); ring_finish<ITEM>(B, t, my_region, cap, gshort, tot); }
