@@ -597,7 +597,7 @@ def main():
         # made by tools/profile_bench.sh); quoted whenever workload and kernel match, whatever --steps is (traffic per
         # job does not depend on how the input is cut into batches -- it is scaled to this run's launch count)
         traffic, traffic_src = None, None
-        tj = os.path.join(ROOT, "profiles", "r05_traffic_%s%s.json" % (cfg, "" if args.dist == "U" else "_G"))
+        tj = os.path.join(ROOT, "profiles", "r06_traffic_%s%s.json" % (cfg, "" if args.dist == "U" else "_G"))
         if os.path.exists(tj) and world == 1 and not force_dist:
             rec = json.load(open(tj))
             if rec.get("kernel_sources_sha256") != kernel_sources_sha():

@@ -9,7 +9,7 @@ import json
 import sys
 
 tag, cfg, gbp, lsize = sys.argv[1], sys.argv[2], float(sys.argv[3]), int(sys.argv[4])
-out = sys.argv[5] if len(sys.argv) > 5 else "profiles/r05_traffic_%s.json" % cfg
+out = sys.argv[5] if len(sys.argv) > 5 else "profiles/r06_traffic_%s.json" % cfg
 
 
 def load(path, col):
