@@ -465,8 +465,8 @@ int count_main(int argc, char* argv[]) {
     if(mer_len > 64) die("--gpus: sharded tables for mer length > 64 are not built yet");
     if(bf_size_given || disk || text || host_parse || !generator.empty())
       die("--gpus cannot be combined with --bf-size, --disk, --text, --host-parse or -g yet");
-    if(!if_files.empty() && mer_len > 32) die("--gpus with --if: mer length > 32 is not built yet");
-    if(!bc_path.empty() && mer_len > 32) die("--gpus with --bc: mer length > 32 is not built yet");   // (every rank loads the whole counter and asks it before routing)
+    // (--if and --bc over shards: keys of one and two words -- every rank loads the whole counter and asks it before routing;
+    //  mer length > 64 has no shards at all: refused above)
     renv = read_rank_env();
     if(!renv.is_rank) return spawn_ranks(gpus, argv);
     if(renv.world != (int)gpus || renv.rank < 0 || renv.rank >= renv.world) die("--gpus does not match the ranks' environment (WORLD_SIZE / RANK)");

@@ -317,7 +317,7 @@ int jfgpu_attach_bloom(jfgpu_table* t, jfgpu_bloom* b) {   // count --bc (count_
     if(b->device != t->device) return fail(JFGPU_E_INVALID, "Bloom counter lives on another device");
     if(b->g.k != t->g.k) return fail(JFGPU_E_INVALID, "Invalid mer length in bloom filter");
     // a shard: the counter is asked on the sending side of the exchange (abi_comm.inl: comm_filter_ok), never on arrival
-    if(t->g.shard_bits && (t->wide || b->kind != 0)) return fail(JFGPU_E_UNSUPPORTED, "sharded tables take a Bloom counter (count --bc) with one-word keys only");
+    if(t->g.shard_bits && b->kind != 0) return fail(JFGPU_E_UNSUPPORTED, "sharded tables take a Bloom counter (count --bc), not a one-pass filter (--bf-size)");
     if(t->nword) return fail(JFGPU_E_UNSUPPORTED, "Bloom filters for mer length > 64 are not built");
   }
   // the cache of admitted k-mers belongs to one attachment: its answers are this counter's

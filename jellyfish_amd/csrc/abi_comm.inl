@@ -207,8 +207,8 @@ __global__ __launch_bounds__(1024) void comm_claims_kernel(const unsigned long l
 // A Bloom counter attached to a shard (count --bc) is asked on the SENDING side, every rank holding the whole read-only
 // counter.  A one-pass filter (--bf-size) changes as it is asked and would see only its rank's reads; two-word keys: not built.
 int comm_filter_ok(const jfgpu_table* t) {
-  if(t->operation != 0 && (t->wide || t->nword)) return fail(JFGPU_E_UNSUPPORTED, "count --if with --gpus: two-word keys are not built yet");
-  if(t->wide && t->wt.bloom.data) return fail(JFGPU_E_UNSUPPORTED, "count --bc with --gpus: two-word keys are not built yet");
+  if(t->operation != 0 && t->nword) return fail(JFGPU_E_UNSUPPORTED, "count --if with --gpus: keys longer than two words are not built yet");
+  if(t->wide && t->wt.bloom.data && t->wt.bloom.kind != 0) return fail(JFGPU_E_UNSUPPORTED, "--bf-size with --gpus: a one-pass filter cannot be sharded by input");
   if(!t->wide && t->dt.bloom.data && t->dt.bloom.kind != 0) return fail(JFGPU_E_UNSUPPORTED, "--bf-size with --gpus: a one-pass filter cannot be sharded by input");
   return JFGPU_OK;
 }
@@ -464,7 +464,8 @@ int comm_route(jfgpu_comm* c, jfgpu_comm::Rank& R, const char* d_bases, size_t n
   HIP_TRY(hipMemsetAsync(R.d_cnt, 0, sizeof(unsigned long long) * W, t->stream));
   {
     ProfScope ps(t, 2, n);
-    if(t->wide) hipLaunchKernelGGL(partition_count_wide_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->wt, base, lo, hi, R.d_cnt);
+    if(t->wide && t->wt.bloom.data) hipLaunchKernelGGL(partition_count_wide_kernel<true>, dim3(grid), dim3(kBlock), 0, t->stream, t->wt, base, lo, hi, R.d_cnt);
+    else if(t->wide) hipLaunchKernelGGL(partition_count_wide_kernel<false>, dim3(grid), dim3(kBlock), 0, t->stream, t->wt, base, lo, hi, R.d_cnt);
     else if(t->dt.bloom.data) hipLaunchKernelGGL(partition_count_kernel<true>, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, base, lo, hi, R.d_cnt);
     else hipLaunchKernelGGL(partition_count_kernel<false>, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, base, lo, hi, R.d_cnt);
   }
@@ -477,7 +478,8 @@ int comm_route(jfgpu_comm* c, jfgpu_comm::Rank& R, const char* d_bases, size_t n
   HIP_TRY(hipMemcpyAsync(R.d_cnt, h.data(), sizeof(unsigned long long) * W, hipMemcpyHostToDevice, t->stream));   // cursors = offsets
   {
     ProfScope ps(t, 2, 0);
-    if(t->wide) hipLaunchKernelGGL(partition_scatter_wide_kernel, dim3(grid), dim3(kBlock), 0, t->stream, t->wt, base, lo, hi, R.d_cnt, R.send[cur]);
+    if(t->wide && t->wt.bloom.data) hipLaunchKernelGGL(partition_scatter_wide_kernel<true>, dim3(grid), dim3(kBlock), 0, t->stream, t->wt, base, lo, hi, R.d_cnt, R.send[cur]);
+    else if(t->wide) hipLaunchKernelGGL(partition_scatter_wide_kernel<false>, dim3(grid), dim3(kBlock), 0, t->stream, t->wt, base, lo, hi, R.d_cnt, R.send[cur]);
     else if(t->dt.bloom.data) hipLaunchKernelGGL(partition_scatter_kernel<true>, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, base, lo, hi, R.d_cnt, R.send[cur]);
     else hipLaunchKernelGGL(partition_scatter_kernel<false>, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, base, lo, hi, R.d_cnt, R.send[cur]);
   }
@@ -502,7 +504,11 @@ int comm_insert_prev(jfgpu_comm* c, jfgpu_comm::Rank& R) {
     rc = part_flush(t); if(rc) return rc;
     ProfScope ps(t, 1, n);
     const int grid = grid_for(t, (n + kBlock - 1) / kBlock);
-    if(t->returning) hipLaunchKernelGGL(update_keys_one_kernel<true>, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, (const uint64_t*)R.recv[prev], (uint64_t)n);
+    if(t->wide) {
+      if(t->returning) hipLaunchKernelGGL(update_keys_wide_kernel<true>, dim3(grid), dim3(kBlock), 0, t->stream, t->wt, (const uint64_t*)R.recv[prev], (uint64_t)n);
+      else             hipLaunchKernelGGL(update_keys_wide_kernel<false>, dim3(grid), dim3(kBlock), 0, t->stream, t->wt, (const uint64_t*)R.recv[prev], (uint64_t)n);
+    }
+    else if(t->returning) hipLaunchKernelGGL(update_keys_one_kernel<true>, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, (const uint64_t*)R.recv[prev], (uint64_t)n);
     else             hipLaunchKernelGGL(update_keys_one_kernel<false>, dim3(grid), dim3(kBlock), 0, t->stream, t->dt, (const uint64_t*)R.recv[prev], (uint64_t)n);
     HIP_TRY(hipGetLastError());
   } else if(n) rc = add_keys_piece(t, R.recv[prev], (size_t)n, t->operation == 1 ? 0 : 1, nullptr);

@@ -325,6 +325,17 @@ __global__ __launch_bounds__(kBlock) void add_keys_wide_kernel(WideTable T, cons
   }
 }
 
+// hash_counter::update_add on encoded two-word keys, val == 1: the receive side of the exchange in the UPDATE pass of
+// count --if over shards (count_main.cc:152-184 with --gpus; the one-word twin is update_keys_one_kernel)
+template <bool RETURNING>
+__global__ __launch_bounds__(kBlock) void update_keys_wide_kernel(WideTable T, const uint64_t* __restrict__ keys, uint64_t n) {
+  __shared__ uint64_t s_fwd[16 * 256];
+  load_tables_lds(s_fwd, T.fwd_tbl, T.W.g.nbytes);
+  __syncthreads();
+  for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    wide_update_add<RETURNING>(T, s_fwd, load_key2(keys, i, T.W.key_mask), 1);
+}
+
 __global__ __launch_bounds__(kBlock) void lookup_wide_kernel(WideTable T, const uint64_t* __restrict__ keys, uint64_t n,
                                                              uint64_t* __restrict__ vals, uint8_t* __restrict__ found, int have_ovf) {
   __shared__ uint64_t s_fwd[16 * 256];
@@ -495,6 +506,8 @@ __global__ __launch_bounds__(kBlock) void dump_tiles_wide_kernel(WideTable T, ui
 // ---- multi-GPU: a contract buffer's two-word k-mers grouped by owner (abi_comm.inl, key path) -------------------------
 // The two passes of kernels.hip.hpp's partition_count / partition_scatter kernels for 128-bit keys: out receives two
 // 64-bit words per k-mer (low word first: what add_keys takes), counts and cursors are in k-mers.
+// BLOOM: count --bc with --gpus -- the sender asks its copy of the (read-only) Bloom counter, what it does not admit never travels
+template <bool BLOOM = false>
 __global__ __launch_bounds__(kBlock) void partition_count_wide_kernel(WideTable T, const uint8_t* __restrict__ base, int64_t lo, int64_t hi,
                                                                       unsigned long long* __restrict__ shard_counts) {
   __shared__ uint64_t s_fwd[16 * 256];
@@ -509,6 +522,7 @@ __global__ __launch_bounds__(kBlock) void partition_count_wide_kernel(WideTable 
     __syncthreads();
     const LaneWordsW L = stage_tile_wide(base, tile * kTilePos, lo, hi, s_codes, s_inv);
     for_each_kmer_wide(T.W, L, [&](int, u128 key) {
+      if(BLOOM && !bloom_admits_wide(T.bloom, key)) return;
       const uint64_t pos = hash_tables_wide(s_fwd, key, T.W.g.nbytes);
       atomicAdd(&s_hist[(uint32_t)(pos >> T.W.g.lsize_l)], 1u);
     });
@@ -518,6 +532,7 @@ __global__ __launch_bounds__(kBlock) void partition_count_wide_kernel(WideTable 
     if(s_hist[i]) atomicAdd(&shard_counts[i], (unsigned long long)s_hist[i]);
 }
 
+template <bool BLOOM = false>
 __global__ __launch_bounds__(kBlock) void partition_scatter_wide_kernel(WideTable T, const uint8_t* __restrict__ base, int64_t lo, int64_t hi,
                                                                         unsigned long long* __restrict__ cursors, uint64_t* __restrict__ out) {
   __shared__ uint64_t s_fwd[16 * 256];
@@ -535,6 +550,7 @@ __global__ __launch_bounds__(kBlock) void partition_scatter_wide_kernel(WideTabl
     // two sweeps over the lane's windows (the keys are wide: they are not kept, they are rolled again): ranks, then stores
     uint32_t rank[kPerLane]; uint32_t vmask = 0, sh[kPerLane];
     for_each_kmer_wide(T.W, L, [&](int j, u128 key) {
+      if(BLOOM && !bloom_admits_wide(T.bloom, key)) return;      // (the same answers as the count pass: the counter is read-only here)
       const uint32_t s = (uint32_t)(hash_tables_wide(s_fwd, key, T.W.g.nbytes) >> T.W.g.lsize_l);
       sh[j] = s; rank[j] = atomicAdd(&s_hist[s], 1u); vmask |= 1u << j;
     });

@@ -844,11 +844,12 @@ def test_count_gpus_n_with_a_size_hint_far_too_small(cli, tmp_path, world, k):
         assert subprocess.check_output([O.REF_JF, "dump", "--check-order", out]).decode().startswith("ORDER OK %d" % len(want))
 
 
-@pytest.mark.parametrize("k", [21, 31])
+@pytest.mark.parametrize("k", [21, 31, 40])
 def test_count_gpus_n_with_a_bloom_counter_file(cli, tmp_path, k):
     """`count --bc file --gpus 2` (count_main.cc:109-119, 191-206 with hash-prefix shards; round-3 review, missing #1): every
     rank process loads the counter file and asks it before routing; the file the ranks write equals the single-process
-    `count --bc` file.  k = 21 takes the item path, k = 31 the key path."""
+    `count --bc` file.  k = 21 takes the item path, k = 31 the key path, k = 40 (round 6) the key path of two-word keys:
+    partition_count / scatter_wide_kernel<BLOOM> ask the counter on the sending side."""
     import random
     rng = random.Random(101 + k)
     twice = ["".join(rng.choice("ACGT") for _ in range(150)) for _ in range(1500)]
@@ -868,10 +869,12 @@ def test_count_gpus_n_with_a_bloom_counter_file(cli, tmp_path, k):
     assert subprocess.check_output([cli, "stats", out]) == subprocess.check_output([cli, "stats", ref])
 
 
-def test_count_gpus_n_with_if_files(cli, tmp_path):
+@pytest.mark.parametrize("k", [21, 40])
+def test_count_gpus_n_with_if_files(cli, tmp_path, k):
     """`count --if wanted.fa --gpus 2` (count_main.cc:289-295 with hash-prefix shards; round-3 review, missing #1): the rank
     processes prime their shards with the --if k-mers (each reads its part of the file, every k-mer travels to its owner),
-    then count only those; the file equals the single-process one."""
+    then count only those; the file equals the single-process one.  k = 40 (round 6): shards of two-word keys -- the PRIME
+    pass adds with value 0, the UPDATE pass goes through update_keys_wide_kernel on arrival."""
     import random
     rng = random.Random(77)
     wanted = ["".join(rng.choice("ACGT") for _ in range(200)) for _ in range(600)]
@@ -884,12 +887,12 @@ def test_count_gpus_n_with_if_files(cli, tmp_path):
             seq = wanted[r % 600][20:170] if r % 3 else "".join(rng.choice("ACGT") for _ in range(150))
             f.write((">r%d\n%s\n" % (r, seq)).encode())
     ref, out = str(tmp_path / "ref.jf"), str(tmp_path / "g2.jf")
-    subprocess.check_call([cli, "count", "-m", "21", "-C", "-s", "1M", "--if", str(iff), "-o", ref, str(fa)])
+    subprocess.check_call([cli, "count", "-m", str(k), "-C", "-s", "1M", "--if", str(iff), "-o", ref, str(fa)])
     env = dict(os.environ, JFGPU_COMM_TRANSPORT="ipc", JFGPU_PARSE_CHUNK="100000", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    subprocess.check_call([cli, "count", "-m", "21", "-C", "-s", "1M", "--if", str(iff), "-o", out, "--gpus", "2", str(fa)], env=env, timeout=900)
+    subprocess.check_call([cli, "count", "-m", str(k), "-C", "-s", "1M", "--if", str(iff), "-o", out, "--gpus", "2", str(fa)], env=env, timeout=900)
     want = subprocess.check_output([cli, "dump", "-c", ref]).decode().splitlines()
     got = subprocess.check_output([cli, "dump", "-c", out]).decode().splitlines()
-    assert sorted(got) == sorted(want) and len(want) > 100000
+    assert sorted(got) == sorted(want) and len(want) > 90000
     assert any(l.endswith(" 0") for l in want) and any(not l.endswith(" 0") for l in want)     # primed and never seen / counted
     assert subprocess.check_output([cli, "stats", out]) == subprocess.check_output([cli, "stats", ref])
 
