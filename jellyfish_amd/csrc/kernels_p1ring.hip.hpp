@@ -346,21 +346,31 @@ __global__ __launch_bounds__(kPBlock) void p1_ring_kernel(DevTable T, DIRECT D, 
         ea[e] = on ? b * R::kSlots : dump; ei[e] = item; eo[e] = normal ? o : special ? (R::kFull | ((cnt < 0xFFFFu ? cnt : 0xFFFFu) << 16)) : 0u;
 #endif
       };
+      // the round's codes, their complements and its validity bits moved up once (j0 is a run-time 0 or RP), so that every
+      // position's field sits at a compile-time offset: one bit-field extract each instead of shift + and by a scalar amount
+#ifndef JFGPU_P1_OLD_EXTRACT
+      const uint32_t cur_r = L.cur << (2 * j0), ncur_r = ~cur_r, vm_r = vmask << j0;
+#endif
 #pragma unroll
       for(int e = 0; e < RP; ++e) {
+#ifndef JFGPU_P1_OLD_EXTRACT
+        const uint32_t c = (cur_r >> (2 * (15 - e))) & 3u, nc = (ncur_r >> (2 * (15 - e))) & 3u;
+        const uint32_t v = vm_r & (1u << (15 - e));
+#else
         const int j = j0 + e;
-        const uint32_t c = (L.cur >> (2 * (15 - j))) & 3u;
+        const uint32_t c = (L.cur >> (2 * (15 - j))) & 3u, nc = 3u - c;
+        const uint32_t v = vmask & (1u << (15 - j));
+#endif
         if constexpr(NB >= 5 || NB == kHashXS) {
           // keys of more than 32 bits (k >= 17): the two dwords by hand -- funnel shifts instead of 64-bit shifts, and the
           // new base of the reverse complement enters the high dword directly (rc_shift >= 32)
           const uint32_t flo = (uint32_t)fw, fhi = (uint32_t)(fw >> 32), rlo = (uint32_t)rc, rhi = (uint32_t)(rc >> 32);
           fw = ((uint64_t)(funnel_r(fhi, flo, 30) & (uint32_t)(g.key_mask >> 32)) << 32) | ((flo << 2) | c);
-          rc = ((uint64_t)((rhi >> 2) | ((3u - c) << (rc_shift - 32))) << 32) | funnel_r(rhi, rlo, 2);
+          rc = ((uint64_t)((rhi >> 2) | (nc << (rc_shift - 32))) << 32) | funnel_r(rhi, rlo, 2);
         } else {
           fw = ((fw << 2) | c) & g.key_mask;
-          rc = (rc >> 2) | ((uint64_t)(3u - c) << rc_shift);
+          rc = (rc >> 2) | ((uint64_t)nc << rc_shift);
         }
-        const uint32_t v = vmask & (1u << (15 - j));
         const uint64_t key = ((CANON == 1 || (CANON == 2 && g.canonical)) && rc < fw) ? rc : fw;
         if constexpr(RUNS) {
 #ifdef JFGPU_P1_NO_RUNS                                            /* ablation (round 6): every occurrence its own item */
