@@ -68,7 +68,8 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
   // two-register items those instantiations spilled 100 registers and ran 4 x slower per item)
   constexpr int NP = (sizeof(ITEM) == 8 ? 4608 : 9216) / BLOCK;
   constexpr uint32_t kVec = 16 / sizeof(SLOT);              // slots per 16-byte vector
-  constexpr uint32_t kBV = 4 / kVec;                        // vectors per bucket
+  constexpr uint32_t kB = 1u << kBucketBits;                // slots per bucket (kmer_core.hpp: the probe rule every path follows)
+  constexpr uint32_t kBV = kB / kVec;                       // vectors per bucket
   constexpr uint32_t kSlotBits = 8 * sizeof(SLOT);
   JF_DYN_LDS(s_raw);
   const TableGeom& g = T.g;
@@ -121,54 +122,74 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
     if constexpr(sizeof(ITEM) == 4) return ((uint32_t)x >> g.rem_bits) & (nslots - 1);
     else return (uint32_t)((uint64_t)x >> g.rem_bits) & (nslots - 1);
   };
-  auto load_bucket = [&](uint32_t bs, SLOT (&w)[4]) {
+  auto load_bucket = [&](uint32_t bs, SLOT (&w)[kB]) {
 #pragma unroll
     for(uint32_t q = 0; q < kBV; ++q) {
       const uint4 v = *reinterpret_cast<const uint4*>(s_tile + bs + q * kVec);
-      if(sizeof(SLOT) == 4) { w[0] = (SLOT)v.x; w[1] = (SLOT)v.y; w[2] = (SLOT)v.z; w[3] = (SLOT)v.w; }
+      if constexpr(sizeof(SLOT) == 4) { w[4 * q] = (SLOT)v.x; w[4 * q + 1] = (SLOT)v.y; w[4 * q + 2] = (SLOT)v.z; w[4 * q + 3] = (SLOT)v.w; }
       else { w[2 * q] = (SLOT)(((uint64_t)v.y << 32) | v.x); w[2 * q + 1] = (SLOT)(((uint64_t)v.w << 32) | v.z); }
+    }
+  };
+  auto store_bucket = [&](uint32_t bs, const SLOT (&w)[kB]) {
+#pragma unroll
+    for(uint32_t q = 0; q < kBV; ++q) {
+      uint4 v;
+      if constexpr(sizeof(SLOT) == 4) v = make_uint4((uint32_t)w[4 * q], (uint32_t)w[4 * q + 1], (uint32_t)w[4 * q + 2], (uint32_t)w[4 * q + 3]);
+      else v = make_uint4((uint32_t)w[2 * q], (uint32_t)((uint64_t)w[2 * q] >> 32), (uint32_t)w[2 * q + 1], (uint32_t)((uint64_t)w[2 * q + 1] >> 32));
+      *reinterpret_cast<uint4*>(s_tile + bs + q * kVec) = v;
     }
   };
   // do two of a bucket's entries carry the same tag?  identity = occupied bit + tag (count shifted out).  Six compares
   // whose results meet in scalar registers; an empty slot equals nothing.
-  auto has_dups = [&](const SLOT (&w)[4]) -> bool {
-    const SLOT s0 = w[0] << idshift, s1 = w[1] << idshift, s2 = w[2] << idshift, s3 = w[3] << idshift;
-    return ((s0 == s1) & (w[1] != 0)) | (((s0 == s2) | (s1 == s2)) & (w[2] != 0)) | (((s0 == s3) | (s1 == s3) | (s2 == s3)) & (w[3] != 0));
+  auto has_dups = [&](const SLOT (&w)[kB]) -> bool {
+    SLOT sh[kB];
+#pragma unroll
+    for(uint32_t i = 0; i < kB; ++i) sh[i] = w[i] << idshift;
+    bool d = false;
+#pragma unroll
+    for(uint32_t j = 1; j < kB; ++j) {
+      bool e = false;
+#pragma unroll
+      for(uint32_t i = 0; i < j; ++i) e = e | (sh[i] == sh[j]);
+      d = d | (e & (w[j] != 0));
+    }
+    return d;
   };
   // M: equal tags of one bucket into the first of them, compacted to the front.  Straight-line code (selects, no
   // branches: a wave runs this whenever one of its 64 buckets needs it) on static indices (registers).
-  auto merge_bucket = [&](SLOT (&w)[4], uint64_t bucket_slot0) {
+  auto merge_bucket = [&](SLOT (&w)[kB], uint64_t bucket_slot0) {
     const SLOT cmask = (SLOT)g.cnt_max;
-    SLOT carry[4] = {0, 0, 0, 0};                            // count-field wrap-arounds, in units of 2^cnt_bits
+    SLOT carry[kB];                                          // count-field wrap-arounds, in units of 2^cnt_bits
 #pragma unroll
-    for(int j = 1; j < 4; ++j)
+    for(uint32_t i = 0; i < kB; ++i) carry[i] = 0;
 #pragma unroll
-      for(int i = 0; i < j; ++i) {
+    for(uint32_t j = 1; j < kB; ++j)
+#pragma unroll
+      for(uint32_t i = 0; i < j; ++i) {
         const bool same = (w[j] != 0) & (w[i] != 0) & (((w[i] ^ w[j]) & lmask) == 0);
         const SLOT sum = (SLOT)(w[i] >> cshift) + (same ? (SLOT)(w[j] >> cshift) : (SLOT)0);      // (no carry out of the word: both counts < 2^cnt_bits <= 2^(bits - 2))
         w[i] = (w[i] & lmask) | (SLOT)((sum & cmask) << cshift);
         carry[i] += (SLOT)(sum >> g.cnt_bits);
         w[j] = same ? (SLOT)0 : w[j];
       }
-    // stable compaction: entry j moves to the number of non-empty entries before it
-    const uint32_t n0 = w[0] != 0, n1 = n0 + (w[1] != 0), n2 = n1 + (w[2] != 0);
-    SLOT o[4], oc[4];
-    o[0] = n0 ? w[0] : (n1 ? w[1] : (n2 ? w[2] : w[3]));                       oc[0] = n0 ? carry[0] : (n1 ? carry[1] : (n2 ? carry[2] : carry[3]));
-    {  // position 1: the second non-empty entry
-      const bool t1 = (w[1] != 0) & (n0 == 1), t2 = (w[2] != 0) & (n1 == 1), t3 = (w[3] != 0) & (n2 == 1);
-      o[1] = t1 ? w[1] : (t2 ? w[2] : (t3 ? w[3] : (SLOT)0));                  oc[1] = t1 ? carry[1] : (t2 ? carry[2] : (t3 ? carry[3] : (SLOT)0));
-    }
-    {  // position 2: the third
-      const bool t2 = (w[2] != 0) & (n1 == 2), t3 = (w[3] != 0) & (n2 == 2);
-      o[2] = t2 ? w[2] : (t3 ? w[3] : (SLOT)0);                                oc[2] = t2 ? carry[2] : (t3 ? carry[3] : (SLOT)0);
-    }
-    { const bool t3 = (w[3] != 0) & (n2 == 3); o[3] = t3 ? w[3] : (SLOT)0;    oc[3] = t3 ? carry[3] : (SLOT)0; }
-    if(n2 + (w[3] != 0) == 0) { o[0] = 0; oc[0] = 0; }                         // (nothing at all: position 0 picked up w[3] = 0 anyway)
+    // stable compaction: entry j moves to the number of non-empty entries before it (selects on static indices)
+    SLOT o[kB], oc[kB];
 #pragma unroll
-    for(int q = 0; q < 4; ++q) w[q] = o[q];
-    if(RETURNING && (oc[0] | oc[1] | oc[2] | oc[3]) != 0) {                    // rare: some count left its field
+    for(uint32_t i = 0; i < kB; ++i) { o[i] = 0; oc[i] = 0; }
+    uint32_t n = 0;
 #pragma unroll
-      for(int q = 0; q < 4; ++q) if(oc[q]) ovf_add_call(T.ovf_key, T.ovf_cnt, T.ovf_mask, T.counters, bucket_slot0 + q, (uint64_t)oc[q]);
+    for(uint32_t j = 0; j < kB; ++j) {
+      const bool ne = w[j] != 0;
+#pragma unroll
+      for(uint32_t d = 0; d <= j; ++d) { const bool here = ne & (n == d); o[d] = here ? w[j] : o[d]; oc[d] = here ? carry[j] : oc[d]; }
+      n += ne ? 1u : 0u;
+    }
+    SLOT any = 0;
+#pragma unroll
+    for(uint32_t q = 0; q < kB; ++q) { w[q] = o[q]; any |= oc[q]; }
+    if(RETURNING && any != 0) {                                                // rare: some count left its field
+#pragma unroll
+      for(uint32_t q = 0; q < kB; ++q) if(oc[q]) ovf_add_call(T.ovf_key, T.ovf_cnt, T.ovf_mask, T.counters, bucket_slot0 + q, (uint64_t)oc[q]);
     }
   };
   // M for the whole unit, between A and C.  Every lane looks at its NBK buckets (fetched MB at a time in one LDS round
@@ -177,14 +198,20 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
   // per 64 such buckets instead of once per bucket position in which any of its lanes has one.  The list lives in the
   // bucket counters' LDS, which nothing reads between the ranks of A and the store that zeroes them.
   auto merge_tile = [&](uint64_t unit_slot0) {
-    constexpr uint32_t MB = (TPB == 2 && sizeof(ITEM) + sizeof(SLOT) == 8 && NBK >= 4) ? 4 : (NBK >= 2 ? 2 : 1);      // buckets in flight per lane (registers: the next round's items are too)
-    constexpr uint32_t R = MB >= 4 ? 512 : 256;              // ring of bucket numbers per wave: 63 waiting + MB x 64 new at most
+    constexpr uint32_t MB0 = (TPB == 2 && sizeof(ITEM) + sizeof(SLOT) == 8 && NBK >= 4) ? 4 : (NBK >= 2 ? 2 : 1);      // buckets in flight per lane (registers: the next round's items are too)
+    // ring of bucket numbers per wave, in the bucket counters' LDS (2 bytes a bucket): 63 waiting + MB x 64 new at most
+    constexpr uint32_t Rmax = nbkt / (BLOCK / 64);
+    static_assert(Rmax >= 128, "the merge list must fit the bucket counters");
+    constexpr uint32_t R = Rmax >= 512 ? 512 : Rmax >= 256 ? 256 : 128;
+    constexpr uint32_t MBr = R >= 512 ? 4 : R >= 256 ? 2 : 1;                                    // what the list takes
+    constexpr uint32_t MBw = 16 / kB >= 1 ? 16 / kB : 1;                                         // at most sixteen slot words in flight
+    constexpr uint32_t MB = MB0 < MBr ? (MB0 < MBw ? MB0 : MBw) : (MBr < MBw ? MBr : MBw);
     static_assert((BLOCK / 64) * R * 2 <= nbkt * 2, "the merge list must fit the bucket counters");
     uint16_t* const lst = reinterpret_cast<uint16_t*>(s_cnt) + (threadIdx.x >> 6) * R;
     uint32_t head = 0, cnt = 0;                               // wave-uniform
 #pragma unroll 1
     for(uint32_t k0 = 0; k0 < NBK; k0 += MB) {
-      SLOT wb[MB][4];
+      SLOT wb[MB][kB];
 #pragma unroll
       for(uint32_t k = 0; k < MB; ++k) load_bucket((threadIdx.x + (k0 + k) * BLOCK) << kBucketBits, wb[k]);
 #pragma unroll
@@ -200,16 +227,10 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
         (void)__ballot(true);                                 // (the list entries are written before they are read: lockstep on the device, a rendezvous in the host emulation)
         if(lane < n) {
           const uint32_t b = lst[(head + lane) & (R - 1)];
-          SLOT w[4];
+          SLOT w[kB];
           load_bucket(b << kBucketBits, w);
           merge_bucket(w, unit_slot0 + ((uint64_t)b << kBucketBits));
-#pragma unroll
-          for(uint32_t q = 0; q < kBV; ++q) {
-            uint4 v;
-            if(sizeof(SLOT) == 4) v = make_uint4((uint32_t)w[0], (uint32_t)w[1], (uint32_t)w[2], (uint32_t)w[3]);
-            else v = make_uint4((uint32_t)w[2 * q], (uint32_t)((uint64_t)w[2 * q] >> 32), (uint32_t)w[2 * q + 1], (uint32_t)((uint64_t)w[2 * q + 1] >> 32));
-            *reinterpret_cast<uint4*>(s_tile + ((size_t)b << kBucketBits) + q * kVec) = v;
-          }
+          store_bucket(b << kBucketBits, w);
         }
         head += n; cnt -= n;
       }
@@ -247,21 +268,21 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
   auto slow_insert = [&](ITEM x, uint64_t unit_slot0) {
     constexpr uint32_t LK = kQueueLook;
     const SLOT low = occ | (SLOT)((uint64_t)x & (g.occ_bit - 1)), neww = inc | low;
-    const uint32_t h = home_of(x), hbase = h & ~tmask, hb = h & tmask & ~3u;
+    const uint32_t h = home_of(x), hbase = h & ~tmask, hb = h & tmask & ~(kB - 1u);
     // the walk ends where every other path's does (T.max_probe: table_add, lookups, update_add, the direct inserts) -- a key
     // placed further from home would be in the table and invisible to them (round-3 advisor finding)
     const uint32_t max_steps = (T.max_probe >> kBucketBits) + 1;
     for(uint32_t step = 0; step < max_steps; ) {
-      SLOT w[LK][4];
+      SLOT w[LK][kB];
 #pragma unroll
       for(uint32_t k = 0; k < LK; ++k) load_bucket(hbase + ((hb + ((step + k) << kBucketBits)) & tmask), w[k]);
       uint32_t hitm = 0, empm = 0;
 #pragma unroll
       for(uint32_t k = 0; k < LK; ++k)
 #pragma unroll
-        for(uint32_t i = 0; i < 4; ++i) {
-          hitm |= (uint32_t)((w[k][i] & lmask) == low) << (4 * k + i);
-          empm |= (uint32_t)(w[k][i] == 0) << (4 * k + i);
+        for(uint32_t i = 0; i < kB; ++i) {
+          hitm |= (uint32_t)((w[k][i] & lmask) == low) << (kB * k + i);
+          empm |= (uint32_t)(w[k][i] == 0) << (kB * k + i);
         }
       // candidates in probe order: the first slot that holds the key or nothing.  A compare-and-swap that fails says what
       // the slot holds now -- the key (a lane with the same new key got there first: add to it), or another key: then the
@@ -311,7 +332,7 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
       if((vm >> r) & 1) {
         const uint32_t b = home_of(it[r]) >> kBucketBits;
         const uint32_t rank = (old[r] >> ((b & 1) * 16)) & 0xFFFFu;
-        if(rank < 4) s_tile[(b << kBucketBits) + rank] = inc | occ | (SLOT)((uint64_t)it[r] & (g.occ_bit - 1));
+        if(rank < kB) s_tile[(b << kBucketBits) + rank] = inc | occ | (SLOT)((uint64_t)it[r] & (g.occ_bit - 1));
         else ov = true;
       }
       if constexpr(HEAVY) { if(ov) ovm |= 1u << r; }
@@ -335,13 +356,13 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
     if constexpr(HEAVY) {
       // ---- C0: the items past rank 3, in bulk (it[] is still this round's)
       uint32_t q2 = 0, carry = 0;
-      constexpr int CB = 6;
+      constexpr int CB = kB == 4 ? 6 : 3;                      // (buckets fetched together: at most 24 slot words)
 #pragma unroll
       for(int r0 = 0; r0 < NP; r0 += CB) {
-        SLOT wb[CB][4];
+        SLOT wb[CB][kB];
 #pragma unroll
         for(int k = 0; k < CB; ++k)
-          if(r0 + k < NP && ((ovm >> (r0 + k)) & 1)) load_bucket(home_of(it[r0 + k < NP ? r0 + k : 0]) & ~3u, wb[k]);
+          if(r0 + k < NP && ((ovm >> (r0 + k)) & 1)) load_bucket(home_of(it[r0 + k < NP ? r0 + k : 0]) & ~(kB - 1u), wb[k]);
 #pragma unroll
         for(int k = 0; k < CB; ++k) {
           if(r0 + k >= NP) continue;
@@ -350,10 +371,10 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
           if((ovm >> r) & 1) {
             const ITEM x = it[r];
             const SLOT low = occ | (SLOT)((uint64_t)x & (g.occ_bit - 1));
-            const uint32_t bs = home_of(x) & ~3u;
+            const uint32_t bs = home_of(x) & ~(kB - 1u);
             int hit = -1;
 #pragma unroll
-            for(int i = 3; i >= 0; --i) if((wb[k][i] & lmask) == low) hit = i;
+            for(int i = (int)kB - 1; i >= 0; --i) if((wb[k][i] & lmask) == low) hit = i;
             if(hit >= 0) {
               if(RETURNING) {
                 const SLOT prev = atomicAdd(&s_tile[bs + hit], inc);
@@ -375,12 +396,12 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kerne
         const uint32_t r = (uint32_t)__ffs((int)carry) - 1u; carry &= carry - 1;
         const ITEM x = again[r * BLOCK + threadIdx.x];
         const SLOT low = occ | (SLOT)((uint64_t)x & (g.occ_bit - 1));
-        const uint32_t bs = home_of(x) & ~3u;
-        SLOT w[4];
+        const uint32_t bs = home_of(x) & ~(kB - 1u);
+        SLOT w[kB];
         load_bucket(bs, w);
         uint32_t hit = 0;
 #pragma unroll
-        for(int i = 3; i >= 1; --i) if((w[i] & lmask) == low) hit = (uint32_t)i;      // (the entry is there and does not move)
+        for(int i = (int)kB - 1; i >= 1; --i) if((w[i] & lmask) == low) hit = (uint32_t)i;      // (the entry is there and does not move)
         if((w[0] & lmask) == low) hit = 0;
         ovf_add_call(T.ovf_key, T.ovf_cnt, T.ovf_mask, T.counters, unit_slot0 + bs + hit, 1);
       }

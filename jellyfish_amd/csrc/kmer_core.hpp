@@ -363,7 +363,14 @@ JF_HD uint32_t probe_slot(uint32_t idx0, uint32_t p, uint32_t tile_mask) {
 // start of the home bucket (wrapping inside the tile).  That is what lets the LDS tile kernel place a flush's items by
 // rank instead of by compare-and-swap (kernels_tile.hip.hpp); the global-atomic path, look-ups and growth follow the same
 // sequence with one claim per probe as before.  Keys of two and more words keep the triangular sequence above.
-constexpr uint32_t kBucketBits = 2;
+// (Round 6 measured buckets of EIGHT -- -DJFGPU_BUCKET_BITS=3, the tile kernel is written over the bucket size --: 1.0 % of
+// the items go past their bucket instead of 3.85 %, but looking at every bucket for equal tags compares 28 pairs per
+// eight slots instead of 12 and the wider buckets spill registers: T 24.8 -> 32.2 ms on the metric's job, 30.1 -> 43.3 on
+// distribution G, k = 31 19.5 -> 24.2.  profiles/r06_bucket8.log)
+#ifndef JFGPU_BUCKET_BITS
+#define JFGPU_BUCKET_BITS 2
+#endif
+constexpr uint32_t kBucketBits = JFGPU_BUCKET_BITS;
 JF_HD uint32_t probe_lin(uint32_t idx0, uint32_t p, uint32_t tile_mask) {
   return ((idx0 & ~((1u << kBucketBits) - 1u)) + p) & tile_mask;
 }
