@@ -967,7 +967,11 @@ int query_main(int argc, char* argv[]) {
     const header_matrix hm = header.matrix();
     if(!hm.identity) p.matrix_columns = hm.columns.data();
     jfgpu_table* t = nullptr;
-    if(jfgpu_create(&p, &t) != JFGPU_OK) die(std::string("query: ") + jfgpu_last_error());
+    if(jfgpu_create(&p, &t) != JFGPU_OK) {                   // (no room for the table on the device, ...: the host path answers)
+      if(!getenv("JFGPU_QUIET")) std::cerr << "jellyfish-amd query: device table not created (" << jfgpu_last_error() << "): answering on the host\n";
+      t = nullptr;
+    }
+    if(t) {
     const unsigned kw = (2 * k + 63) / 64, kb = (2 * k + 7) / 8, vb = header.counter_len();
     const size_t rec = kb + vb, n_rec = (map.length() - header.offset()) / rec;
     const unsigned char* body = reinterpret_cast<const unsigned char*>(map.base() + header.offset());
@@ -1015,6 +1019,7 @@ int query_main(int argc, char* argv[]) {
     answer();
     jfgpu_destroy(t);
     sequences.clear();
+    }
   }
   for(const auto& path : sequences) {
     sequence_parser parser(k);
