@@ -355,6 +355,14 @@ def main():
         args.no_extras = True; args.no_cpu_baseline = True
         if "--repeats" not in sys.argv:
             args.repeats = 1
+    # ranks started by an external launcher (torch.distributed.run) on a box with fewer GPUs than ranks: what spawn_ranks
+    # arranges for its own children -- the inter-process test transport, devices shared, a size that fits (the line says so)
+    if args.gpus > 1 and "WORLD_SIZE" in os.environ and os.environ.get("JFGPU_COMM_TRANSPORT") != "ipc":
+        import torch
+        if torch.cuda.device_count() < args.gpus:
+            os.environ["JFGPU_COMM_TRANSPORT"] = "ipc"
+            os.environ["JFGPU_BENCH_SHARED_DEVICES"] = "1"
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     shared = 1                                       # ranks per device (> 1: fewer GPUs than ranks, see spawn_ranks)
     if os.environ.get("JFGPU_BENCH_SHARED_DEVICES") == "1":
         import torch

@@ -1297,6 +1297,13 @@ int comm_piece_rccl(jfgpu_comm* c, jfgpu_comm::Rank& R, const char* d_bases, siz
   R.icap[R.turn] = cap;
   if(cap) { R.sent += routed; rc = c->ipc ? comm_exchange_items_ipc(c) : comm_exchange_items_rccl(c); if(rc) return rc; }
   else {
+#if !defined(JFGPU_EMU)
+    // (the one-box test transport: importing a peer's send buffer of 10 GB never returned -- bench.py --gpus 2 --steps 4 on one
+    //  device, a 1.26 GB step as keys; 5 GB buffers are fine -- so such a step fails here, loudly and on every rank, instead
+    //  of standing in a barrier for ten minutes)
+    if(c->ipc && (uint64_t)n * (t->wide ? 16 : 8) > ((uint64_t)6 << 30))
+      return ipc_fail(c, "a step of this size travels as keys in send buffers of more than 6 GiB, which this runtime does not import: feed smaller steps");
+#endif
     rc = comm_route(c, R, d_bases, n); if(rc) return rc;
     rc = c->ipc ? comm_exchange_ipc(c) : comm_exchange_rccl(c); if(rc) return rc;
   }
