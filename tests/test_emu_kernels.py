@@ -27,6 +27,7 @@ SELECTION = [
     "tests/test_gpu_wide.py::test_dump_of_saturated_count_fields_over_all_ones_tags",
     "tests/test_compat.py::test_hash_counter_check_like_the_reference_unit_test",
     "tests/test_gpu_parity.py::test_ragged_lengths",
+    "tests/test_gpu_parity.py::test_add_key_vals_loads_pairs",
     "tests/test_gpu_parity.py::test_spill_mode_add_keys_and_tiny_pieces",
     "tests/test_gpu_parity.py::test_add_keys_batch_larger_than_the_table_grows_in_order",
     "tests/test_gpu_bloom.py::test_partitioned_insert_equals_direct_and_oracle",

@@ -140,6 +140,35 @@ def test_lookup_and_add_keys(gpu):
         assert vals[100:].tolist() == [5] * len(absent[:50])
 
 
+@pytest.mark.parametrize("k,size", [(21, 1 << 17), (31, 1 << 20), (40, 1 << 16), (21, 1 << 10)])
+def test_add_key_vals_loads_pairs(gpu, k, size):
+    """jfgpu_add_key_vals (round 6): hash_counter::add(key, val) over a batch with a value per key -- what `query -s`
+    loads a sorted file's records with.  Values below, at and far above the in-slot count field (k = 31 at 2^20 slots: 16
+    bits; the rest go to the overflow side table), a key given twice (the values add up), keys of two words (k = 40), a
+    table 64 times too small (size 2^10: it doubles while the batch is taken, in pieces)."""
+    rng = random.Random(5 * k)
+    kw = 2 if k > 32 else 1
+    n = 60000
+    keys = {}
+    while len(keys) < n:
+        keys[rng.getrandbits(2 * k)] = rng.choice([1, 2, 3, 255, 65535, 65536, 70001, 2 ** 33 + 7])
+    ks = list(keys)
+    arr = np.array([[x & (2 ** 64 - 1), x >> 64][:kw] for x in ks], dtype=np.uint64)
+    vals = np.array([keys[x] for x in ks], dtype=np.uint64)
+    with gpu.Table(k, size, canonical=False) as t:
+        t.add_key_vals(arr[: n // 2], vals[: n // 2])
+        t.add_key_vals(arr[n // 2:], vals[n // 2:])
+        t.add_key_vals(arr[:100], np.full(100, 5, dtype=np.uint64))               # again: added to what is there
+        got, found = t.lookup(arr)
+        assert found.all()
+        assert got.tolist() == [keys[x] + (5 if i < 100 else 0) for i, x in enumerate(ks)]
+        st = t.stats()
+        assert st.distinct == n and st.total == int(vals.sum()) + 500
+        absent = np.array([[x & (2 ** 64 - 1), x >> 64][:kw] for x in (rng.getrandbits(2 * k) for _ in range(500)) if x not in keys], dtype=np.uint64)
+        got, found = t.lookup(absent)
+        assert not found.any()
+
+
 def test_count_field_overflow(gpu):
     """k=31 at the minimum table size has a 16-bit in-slot count: larger counts spill to
     the side table (the reference's 'large' entries, tests/small_mers.sh, LargeValue)."""
