@@ -44,7 +44,10 @@ __device__ __attribute__((noinline)) void ovf_add_call(uint64_t* ovf_key, uint64
 #endif
 constexpr int kTileBlock = JFGPU_T_BLOCK;               // threads per workgroup: two workgroups per CU (LDS), 128 registers per lane
 constexpr uint32_t kQueueLook = 2;             // buckets one look of phase C fetches (1: 24.9-25.1 ms, 2: 24.8, 4: 27.3 on the metric's job)
-constexpr uint32_t kTileQueueBytes = 6144;    // LDS queue of phase C (what does not fit stays with the lane)
+#ifndef JFGPU_T_QUEUE
+#define JFGPU_T_QUEUE 6144
+#endif
+constexpr uint32_t kTileQueueBytes = JFGPU_T_QUEUE;    // LDS queue of phase C (what does not fit stays with the lane)
 
 // dynamic LDS of one workgroup: slots | bucket counters (16 bit each) | queue header | queue
 inline size_t tile_rank_lds(size_t slot_bytes, uint32_t tile_bits, int tpb) {
@@ -61,12 +64,13 @@ inline size_t tile_rank_lds(size_t slot_bytes, uint32_t tile_bits, int tpb) {
 // through the plain kernel, which counts how many items went past rank 3: SAMPLE) -- both paths in one kernel cost the
 // common case 3 % (instruction cache).
 template <typename ITEM, bool RETURNING, typename SLOT, int TPB, int BLOCK = kTileBlock, bool HEAVY = false, bool SAMPLE = false>
-__global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void tile_rank_insert_kernel(DevTable T, SegList S, uint64_t tile0, uint32_t n_tiles) {
+__global__ __launch_bounds__(BLOCK, (BLOCK >= 512 ? 2 * BLOCK / 256 : 4)) void tile_rank_insert_kernel(DevTable T, SegList S, uint64_t tile0, uint32_t n_tiles) {
   // S holds ONE item array (the P2 output, or one pending batch of a single-level table: the host launches per batch)
   // register-held items per lane and round: 9216 items per round; 4608 for 8-byte items (k = 31 into a single tile of
   // 8-byte slots: as many items as such a tile takes in one flush at load 0.5, and half the registers -- with 18
   // two-register items those instantiations spilled 100 registers and ran 4 x slower per item)
-  constexpr int NP = (sizeof(ITEM) == 8 ? 4608 : 9216) / BLOCK;
+  // (-DJFGPU_T_BLOCK=256, an experiment of round 6: four workgroups of four waves per CU on single tiles, rounds of 4608 items)
+  constexpr int NP = ((sizeof(ITEM) == 8 || (BLOCK < 512 && TPB == 1)) ? 4608 : 9216) / BLOCK;
   constexpr uint32_t kVec = 16 / sizeof(SLOT);              // slots per 16-byte vector
   constexpr uint32_t kB = 1u << kBucketBits;                // slots per bucket (kmer_core.hpp: the probe rule every path follows)
   constexpr uint32_t kBV = kB / kVec;                       // vectors per bucket
