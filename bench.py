@@ -303,8 +303,8 @@ def plan(args):
         send = (world - 1) / world * 1024 * cap * 4
         per_link = send / (world - 1)
         link = 76.5e9        # one direction of one xGMI link: the guide's ~153 GB/s per link, halved (an assumption until a run measures it)
-        # one GPU's stage times per Gbp of input through the sharded code path (profiles/r05_final_bench_C2_sharded_path_one_gpu.json)
-        per_gbp_ms = {"route_p1": 3.33, "receive_split": 1.37, "p2_partition": 2.01, "tile_insert": 2.57}
+        # one GPU's stage times per Gbp of input through the sharded code path (profiles/r06_final_bench_C2_sharded_path_one_gpu.json)
+        per_gbp_ms = {"route_p1": 2.94, "receive_split": 1.41, "p2_partition": 1.96, "tile_insert": 2.57}
         exchange = {"items_per_step_per_rank": int(items_step), "region_capacity_items": cap, "item_bytes_per_step_per_rank": int(items_step * 4),
                     "send_bytes_per_step_per_rank": int(send), "bytes_per_link_per_step": int(per_link), "link_GB_per_s_assumed": link / 1e9,
                     "exchange_ms_per_step": per_link / link * 1e3,
