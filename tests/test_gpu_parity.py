@@ -1023,6 +1023,61 @@ def test_ring_p2_kernels_at_the_geometries_that_use_them(gpu, monkeypatch, lsize
         t.free(d)
 
 
+@pytest.mark.parametrize("matrix", ["xs", "reference"])
+def test_ring_p1_rounds_with_and_without_the_run_logic(gpu, monkeypatch, matrix):
+    """p1_ring_kernel (round 6) takes its rounds WITHOUT the run logic when no lane of the wave sees an aligned chunk of eight
+    equal bases, and with it otherwise (a run of k + 1 equal bases always covers such a chunk).  Here the metric's kind of
+    reads -- uniform, 150 bp, at the geometry that uses the ring kernels (2^33 4-byte slots) -- are salted with what sits on
+    that boundary: homopolymer runs of 9 .. 60 bases of every base and of N at random offsets (so: shorter and longer than
+    k + 1, straddling lanes' 16-base words and their 8-base chunks, at the start and the end of reads), runs of exactly
+    eight equal bases on an aligned chunk (the wave takes the run logic although no k-mer repeats), and dinucleotide
+    repeats (equal canonical k-mers two positions apart, no homopolymer: the plain rounds emit every occurrence).  The
+    table's content digest must equal the global-atomic path's in a small table; the kernels are asserted from the counters."""
+    if os.environ.get("JFGPU_LIB"):
+        pytest.skip("a table of 32 GB: not under the host emulation")
+    k, L, n_reads = 21, 150, 2_200_000
+    rng = np.random.default_rng(606)
+    with gpu.Table(k, 1 << 29, canonical=True) as ref:
+        d = ref.malloc(n_reads * (L + 1) + 16)
+        ref.gen_reads_dev(d, 0, n_reads, L, 17)
+        buf = ref.d2h(d, n_reads * (L + 1)).reshape(n_reads, L + 1).copy()
+        rows = rng.choice(n_reads, 60000, replace=False)
+        for i, r in enumerate(rows.tolist()):
+            kind = i % 6
+            if kind < 4 or kind == 4:                                              # a run of one base (or of N)
+                n = int(rng.integers(9, 61)); a = int(rng.integers(0, L - 8))
+                buf[r, a:min(L, a + n)] = ord("ACGTN"[kind])
+            else:                                                                  # a dinucleotide repeat
+                n = int(rng.integers(24, 80)); a = int(rng.integers(0, L - 24)); e = min(L, a + n)
+                buf[r, a:e] = np.resize(np.frombuffer(b"ATCGGACT"[2 * (i // 6 % 4): 2 * (i // 6 % 4) + 2], dtype=np.uint8), e - a)
+        for r in rng.choice(n_reads, 5000, replace=False).tolist():                # exactly eight equal bases on an aligned chunk of the buffer
+            a = (-(r * (L + 1)) % 8) + 8 * int(rng.integers(0, 16))
+            if a + 8 <= L:
+                buf[r, a:a + 8] = ord("ACGT"[r % 4])
+                if a > 0 and buf[r, a - 1] == buf[r, a]: buf[r, a - 1] = ord("ACGT"[(r + 1) % 4])
+                if a + 8 < L and buf[r, a + 8] == buf[r, a]: buf[r, a + 8] = ord("ACGT"[(r + 1) % 4])
+        flat = np.ascontiguousarray(buf.reshape(-1))
+        ref.h2d(d, flat)
+        ref.set_mode(1)
+        ref.count_ascii_dev(d, n_reads * (L + 1)); ref.sync()
+        want = ref.digest()
+        ref.free(d)
+    assert want[1] < n_reads * (L - k + 1)                                          # (the N runs took windows away)
+    with gpu.Table(k, 1 << 33, canonical=True, matrix_kind=matrix) as t:
+        assert t.info.slot_bytes == 4 and bool(t.matrix_is_xorshift()) == (matrix == "xs")
+        d = t.malloc(n_reads * (L + 1) + 16)
+        t.h2d(d, flat)
+        t.set_mode(2)
+        t.reserve(n_reads * (L + 1))
+        half = (n_reads // 2) * (L + 1)
+        t.count_ascii_dev(d, half); t.sync()
+        t.count_ascii_dev(d + half, n_reads * (L + 1) - half); t.sync()
+        c = t.counters()
+        assert c["p1_ring"] >= 2 and c["p1_other"] == 0, c
+        assert t.digest() == want
+        t.free(d)
+
+
 def gf2_solve(rows, rhs, n):
     """x (an int of n bits) with parity(rows[i] & x) == rhs[i] for every i, or None: Gaussian elimination on Python ints."""
     piv = {}
