@@ -296,10 +296,10 @@ def plan(args):
     if world > 1:
         # What a step puts on the wires (abi_comm.inl: item path).  A rank routes its step's k-mers into 1024 regions of `cap`
         # 4-byte items -- (owner, the owner's coarse bucket) -- and sends every other owner its 1024 / W regions WHOLE (fixed
-        # capacity: mean x 1.10 for the per-byte estimate x 1.03 head-room + one stranded granule per workgroup and bucket),
+        # capacity: mean x 1.03 for the per-byte estimate x 1.03 head-room + two stranded granules per workgroup and bucket),
         # one message per peer and step over that peer's own xGMI link; its own share does not move.
         items_step = kmers / args.steps
-        cap = int(items_step / 1024 * 1.10 * 1.03 + 2 * 256 * 64)
+        cap = int(items_step / 1024 * 1.03 * 1.03 + 2 * 256 * 64)      # (JFGPU_COMM_SLACK = 0.03 twice: on the k-mers-per-byte estimate and on the mean; round 5: 1.10 x 1.10)
         send = (world - 1) / world * 1024 * cap * 4
         per_link = send / (world - 1)
         link = 76.5e9        # one direction of one xGMI link: the guide's ~153 GB/s per link, halved (an assumption until a run measures it)

@@ -170,11 +170,17 @@ uint32_t items_cap_wanted(const jfgpu_comm* c, const jfgpu_comm::Rank& R, size_t
   const jfgpu_table* t = R.t;
   if(!items_geometry_ok(c, t) || t->operation != 0) return 0;              // (the PRIME / UPDATE passes of count --if travel as keys)
   const ItemLayout L = item_layout(c, t, 64);
-  const double ipb = R.ipb > 0 ? std::min(1.0, R.ipb * 1.10 + 0.005) : 1.0;
+  // Head-room (round 6: JFGPU_COMM_SLACK, 3 % on the k-mers-per-byte figure the rank measured on its earlier steps and 3 % on
+  // the mean; it was 10 % + 10 %).  Regions travel whole, so head-room is wire bytes: 1.21 x + strand was 24 % over the mean
+  // at the metric's step, this is 9 %.  A bucket of ~10^6 items deviates from the mean by 0.1 % (sigma); what the slack has
+  // to absorb is the input changing its k-mers per byte between steps -- and what does not fit a region goes on the
+  // stragglers' list, a step that overflows the list is redone with keys: slower, never wrong.
+  const double slack = c->tun.comm_slack;
+  const double ipb = R.ipb > 0 ? std::min(1.0, R.ipb * (1.0 + slack) + 0.002) : 1.0;
   const uint64_t items = (uint64_t)((double)n * ipb) + 4096;
   const uint64_t strand = (uint64_t)(2 * t->n_cu) * kGran, mean = (items + L.nbg - 1) / L.nbg;
   if(mean < 4 * strand && c->items_mode < 2) return 0;                      // regions would be mostly holes (2: forced, for tests)
-  const uint64_t cap = ((uint64_t)((double)mean * 1.10) + strand + kGran - 1) / kGran * kGran;
+  const uint64_t cap = ((uint64_t)((double)mean * (1.0 + slack)) + strand + kGran - 1) / kGran * kGran;
   if(cap > 0x7FFF0000ull) return 0;
 #if !defined(JFGPU_EMU)
   // (inter-process test transport, observed and not understood: with item-path send buffers of 2.6 GB and more the first

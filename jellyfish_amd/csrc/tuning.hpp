@@ -46,6 +46,7 @@ struct Tuning {
   int comm_self_rccl = -1;       // JFGPU_COMM_SELF_RCCL   world 1: send the rank's own share through RCCL too (-1: default)
   int comm_items = -1;           // JFGPU_COMM_ITEMS       item path: -1 default, 0 off, 1 on, 2 forced
   int comm_strag = -1;           // JFGPU_COMM_STRAG       straggler list capacity (tests; -1: default)
+  double comm_slack = 0.03;      // JFGPU_COMM_SLACK       item path: head-room of a routed region over the mean, applied to the k-mers-per-byte estimate and to the mean (round 6: 0.03; 0.10 before)
   int comm_gbits = 10;           // JFGPU_COMM_GBITS       bits of (owner, coarse bucket) the sender routes by (tests: fewer, so that small shards get the wide receive split of full-size ones)
   uint32_t comm_split_cap = 0;   // JFGPU_COMM_SPLIT_CAP   items per region of the receive split (tests: forces region overflow there)
   int comm_split = 1;            // JFGPU_COMM_SPLIT=0     the receive split by round 4's sort-based kernel instead of the wave-per-stream one (A/B)
@@ -83,6 +84,7 @@ struct Tuning {
     if(const char* e = str("JFGPU_COMM_STRAG")) u.comm_strag = std::max(1, atoi(e));
     if(const char* e = str("JFGPU_COMM_SPLIT")) u.comm_split = atoi(e);
     if(const char* e = str("JFGPU_COMM_SPLIT_CAP")) u.comm_split_cap = (uint32_t)std::max(64, atoi(e));
+    if(const char* e = str("JFGPU_COMM_SLACK")) u.comm_slack = std::min(1.0, std::max(0.0, atof(e)));
     if(const char* e = str("JFGPU_COMM_GBITS")) u.comm_gbits = std::min(10, std::max(1, atoi(e)));
     return u;
   }
