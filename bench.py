@@ -513,7 +513,10 @@ def main():
             t.attach_bloom(None)
             bloom.clear()
 
-    job(warmup)
+    # N ranks: the exchange alternates between two sets of buffers (turns); a warm-up of one step would leave the second set's
+    # first use -- allocations, the peers' mappings or registrations of them -- inside the timed region.  The warm-up is W
+    # steps as asked, and at least two when the path is sharded (untimed either way).
+    job(max(warmup, 2) if sharded else warmup)
     reset()
     t.profile_enable(True); t.profile_reset()
     if bloom is not None:
