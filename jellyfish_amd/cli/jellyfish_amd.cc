@@ -463,8 +463,8 @@ int count_main(int argc, char* argv[]) {
   if(gpus_given) {
     if(gpus < 1 || (gpus & (gpus - 1)) || gpus > 256) die("--gpus must be a power of two");
     if(mer_len > 64) die("--gpus: sharded tables for mer length > 64 are not built yet");
-    if(bf_size_given || disk || text || host_parse || !generator.empty())
-      die("--gpus cannot be combined with --bf-size, --disk, --text, --host-parse or -g yet");
+    if(bf_size_given || disk || host_parse || !generator.empty())
+      die("--gpus cannot be combined with --bf-size, --disk, --host-parse or -g yet");
     // (--if and --bc over shards: keys of one and two words -- every rank loads the whole counter and asks it before routing;
     //  mer length > 64 has no shards at all: refused above)
     renv = read_rank_env();

@@ -221,15 +221,43 @@ public:
   void dump(hash_counter* ary) override {
     ary->flush();
     const std::string path = next_path();
-    std::ofstream out(path, std::ios::binary | std::ios::trunc);
-    if(!out.good()) throw ErrorWriting("Can't open file '" + path + "'");
-    if(header_) {
-      ary->update_header(*header_);
-      header_->format(format);
-      header_->write(out);
+    // One shard of a multi-GPU table (hash_counter::attach_comm): the shards' sorted lines concatenated in rank order are the
+    // globally (pos, key)-sorted body, but a text record has no fixed width -- every rank writes its lines to a part file
+    // beside the output, rank 0 (which wrote the header and its own lines into the output itself) appends the parts in rank
+    // order once everybody is through, and removes them.
+    jfgpu_comm* comm = ary->comm();
+    int world = 1, rank = 0;
+    if(comm) jf_check(jfgpu_comm_world(comm, &world, &rank));
+    auto part_name = [&](int r) { return path + ".rank" + std::to_string(r); };
+    {
+      std::ofstream out(rank == 0 ? path : part_name(rank), std::ios::binary | std::ios::trunc);
+      if(!out.good()) throw ErrorWriting("Can't open file '" + (rank == 0 ? path : part_name(rank)) + "'");
+      if(header_ && rank == 0) {
+        ary->update_header(*header_);
+        header_->format(format);
+        header_->write(out);
+      }
+      write_text_records(ary, min_, max_, out);
+      out.flush();
+      if(!out.good()) throw ErrorWriting("Error while writing '" + path + "'");
     }
-    write_text_records(ary, min_, max_, out);
-    if(!out.good()) throw ErrorWriting("Error while writing '" + path + "'");
+    if(comm && world > 1) {
+      std::vector<uint64_t> done(world);
+      if(jfgpu_comm_allgather_u64(comm, 1, done.data())) throw std::runtime_error(jfgpu_last_error());      // (everybody's part is on disk)
+      if(rank == 0) {
+        std::ofstream out(path, std::ios::binary | std::ios::app);
+        for(int r = 1; r < world; ++r) {
+          std::ifstream in(part_name(r), std::ios::binary);
+          if(!in.good()) throw ErrorWriting("Can't read the part '" + part_name(r) + "'");
+          if(in.peek() != std::ifstream::traits_type::eof()) out << in.rdbuf();
+          in.close();
+          ::unlink(part_name(r).c_str());
+        }
+        out.flush();
+        if(!out.good()) throw ErrorWriting("Error while writing '" + path + "'");
+      }
+      if(jfgpu_comm_allgather_u64(comm, 1, done.data())) throw std::runtime_error(jfgpu_last_error());      // (the file is whole when any rank returns)
+    }
   }
 };
 

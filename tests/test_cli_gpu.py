@@ -897,6 +897,27 @@ def test_count_gpus_n_with_if_files(cli, tmp_path, k):
     assert subprocess.check_output([cli, "stats", out]) == subprocess.check_output([cli, "stats", ref])
 
 
+@pytest.mark.parametrize("world,k", [(2, 21), (4, 21), (2, 40)])
+def test_count_gpus_n_text_output(cli, tmp_path, world, k):
+    """`count --text --gpus N` (text_dumper.hpp:18-20 over hash-prefix shards; round 6): a text record has no fixed width, so
+    every rank writes its lines to a part beside the output and rank 0 appends them in rank order -- the body is, line for
+    line and in the same order, the single-process `--text` file's, and no part file is left behind."""
+    import glob
+    import random
+    rng = random.Random(31 + world + k)
+    fa = tmp_path / "reads.fa"
+    with open(fa, "wb") as f:
+        for r in range(3000):
+            f.write((">r%d\n%s\n" % (r, "".join(rng.choice("ACGT") for _ in range(150)))).encode())
+    ref, out = str(tmp_path / "ref.txt"), str(tmp_path / "gN.txt")
+    subprocess.check_call([cli, "count", "-m", str(k), "-C", "-s", "4M", "--text", "-o", ref, str(fa)])
+    env = dict(os.environ, JFGPU_COMM_TRANSPORT="ipc", JFGPU_PARSE_CHUNK="100000", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    subprocess.check_call([cli, "count", "-m", str(k), "-C", "-s", "4M", "--text", "-o", out, "--gpus", str(world), str(fa)], env=env, timeout=900)
+    assert _body(out) == _body(ref) and len(_body(ref)) > 1_000_000
+    assert not glob.glob(out + ".rank*")
+    assert subprocess.check_output([cli, "histo", out]) == subprocess.check_output([cli, "histo", ref])
+
+
 def test_a_failing_rank_ends_the_others(cli, tmp_path):
     """One rank of `count --gpus 2` cannot read its input (the file disappears for rank 1 only: JFGPU_TEST_FAIL_RANK): the
     command must come back with an error instead of leaving the other rank waiting in a collective."""
