@@ -227,15 +227,20 @@ int merge_main(int argc, char* argv[]) {
 // -g / -S: every line of the file is a shell command whose standard output is a fasta / fastq stream
 // (lib/generator_manager.cc runs them through named pipes; here each is read through a pipe in turn).  Blank
 // lines and # comments are skipped (:223-226); a command that fails is an error.
-static void feed_generators(const std::string& generator, std::string shell, unsigned mer_len, const sequence_parser::sink_type& sink) {
+// rank / world (count --gpus N): command j of the file is run by rank j mod N -- the commands are a partition of the input as
+// good as any, every stream is read whole by one rank.
+static void feed_generators(const std::string& generator, std::string shell, unsigned mer_len, const sequence_parser::sink_type& sink,
+                            unsigned rank = 0, unsigned world = 1) {
   std::ifstream gf(generator);
   if(!gf.good()) die("Can't open generator file '" + generator + "'");
   if(shell.empty()) { const char* e = getenv("SHELL"); shell = e && *e ? e : "/bin/sh"; }
   sequence_parser parser(mer_len);
   std::string cmd;
+  unsigned n_cmd = 0;
   while(std::getline(gf, cmd)) {
     const size_t first = cmd.find_first_not_of(" \t\n\v\f\r");
     if(first == std::string::npos || cmd[first] == '#') continue;
+    if(n_cmd++ % world != rank) continue;
     int fds[2];
     if(pipe(fds) != 0) die("pipe() failed");
     const pid_t pid = fork();
@@ -463,8 +468,8 @@ int count_main(int argc, char* argv[]) {
   if(gpus_given) {
     if(gpus < 1 || (gpus & (gpus - 1)) || gpus > 256) die("--gpus must be a power of two");
     if(mer_len > 64) die("--gpus: sharded tables for mer length > 64 are not built yet");
-    if(bf_size_given || disk || host_parse || !generator.empty())
-      die("--gpus cannot be combined with --bf-size, --disk, --host-parse or -g yet");
+    if(bf_size_given || disk)
+      die("--gpus cannot be combined with --bf-size (a one-pass filter cannot be sharded by input) or --disk yet");
     // (--if and --bc over shards: keys of one and two words -- every rank loads the whole counter and asks it before routing;
     //  mer length > 64 has no shards at all: refused above)
     renv = read_rank_env();
@@ -560,8 +565,10 @@ int count_main(int argc, char* argv[]) {
     if(host_parse) {
       sequence_parser parser(mer_len);
       parser.min_quality(min_qual);
-      for(const auto& f : paths)
-        parser.parse_file(f.c_str(), [&](const char* buf, size_t n) { ary->count_sequence(buf, n); });
+      // (--gpus N: file i is read by rank i mod N -- whole files are a partition of the input too; a single file is one rank's)
+      for(size_t i = 0; i < paths.size(); ++i)
+        if(!gpus_given || i % gpus == (size_t)renv.rank)
+          parser.parse_file(paths[i].c_str(), [&](const char* buf, size_t n) { ary->count_sequence(buf, n); });
     } else {
       device_sequence_parser& parser = *dev_parser;
       const double ms0 = parser.device_ms(); const size_t fb0 = parser.host_fallback_bytes();
@@ -584,7 +591,8 @@ int count_main(int argc, char* argv[]) {
     }
     feed(files);
     if(!generator.empty()) {
-      feed_generators(generator, shell, mer_len, [&](const char* buf, size_t n) { ary->count_sequence(buf, n); });
+      feed_generators(generator, shell, mer_len, [&](const char* buf, size_t n) { ary->count_sequence(buf, n); },
+                      gpus_given ? (unsigned)renv.rank : 0u, gpus_given ? gpus : 1u);
       ary->done();
     }
   } catch(std::exception& e) { die(e.what()); }

@@ -918,6 +918,42 @@ def test_count_gpus_n_text_output(cli, tmp_path, world, k):
     assert subprocess.check_output([cli, "histo", out]) == subprocess.check_output([cli, "histo", ref])
 
 
+@pytest.mark.parametrize("how", ["generators", "host-parse", "generators+files"])
+def test_count_gpus_n_with_generators_and_the_host_reader(cli, tmp_path, how):
+    """`count --gpus 2 -g cmds` and `--host-parse` (round 6): input that no rank can cut into parts -- streams of generator
+    commands (lib/generator_manager.cc), files read by the host reader -- is dealt out whole: command j to rank j mod N,
+    file i to rank i mod N.  Ranks end up with different numbers of steps (the facade keeps stepping with nothing until
+    nobody has input); the file equals the single-process one.  Three commands / files for two ranks: an uneven deal."""
+    import gzip
+    import random
+    rng = random.Random(len(how))
+    fas = []
+    for i in range(3):
+        fa = tmp_path / ("part%d.fa" % i)
+        with open(fa, "wb") as f:
+            for r in range(800 + 700 * i):
+                f.write((">r%d_%d\n%s\n" % (i, r, "".join(rng.choice("ACGT") for _ in range(150)))).encode())
+        fas.append(str(fa))
+    gz = str(tmp_path / "part0.fa.gz")
+    with open(fas[0], "rb") as f, gzip.open(gz, "wb") as g:
+        g.write(f.read())
+    gen = tmp_path / "generators"
+    gen.write_text("gzip -dc %s\n# a comment\ncat %s\n\ncat %s\n" % (gz, fas[1], fas[2]))
+    ref, out = str(tmp_path / "ref.jf"), str(tmp_path / "g2.jf")
+    subprocess.check_call([cli, "count", "-m", "21", "-C", "-s", "4M", "-o", ref] + fas)
+    env = dict(os.environ, JFGPU_COMM_TRANSPORT="ipc", JFGPU_PARSE_CHUNK="100000", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    if how == "generators":
+        args = ["-g", str(gen)]
+    elif how == "host-parse":
+        args = ["--host-parse"] + fas
+    else:
+        gen.write_text("gzip -dc %s\ncat %s\n" % (gz, fas[1]))
+        args = ["-g", str(gen), fas[2]]
+    subprocess.check_call([cli, "count", "-m", "21", "-C", "-s", "4M", "-o", out, "--gpus", "2"] + args, env=env, timeout=900)
+    want = subprocess.check_output([cli, "dump", "-c", ref])
+    assert subprocess.check_output([cli, "dump", "-c", out]) == want and len(want) > 1_000_000
+
+
 def test_a_failing_rank_ends_the_others(cli, tmp_path):
     """One rank of `count --gpus 2` cannot read its input (the file disappears for rank 1 only: JFGPU_TEST_FAIL_RANK): the
     command must come back with an error instead of leaving the other rank waiting in a collective."""
