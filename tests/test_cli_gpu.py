@@ -790,7 +790,7 @@ def test_count_gpus_1_goes_through_the_ranks_machinery(cli, tmp_path, self_rccl)
     assert _body(out) == _body(ref)
     assert subprocess.check_output([cli, "stats", out]) == subprocess.check_output([cli, "stats", ref])
     assert open(tmp_path / "t").read().split()[0::2] == ["Init", "Counting", "Writing"]
-    for bad in (["--gpus", "3"], ["--gpus", "2", "--text"]):
+    for bad in (["--gpus", "3"], ["--gpus", "2", "--disk"], ["--gpus", "2", "--bf-size", "1M"]):      # (round 6: --text, -g and --host-parse are taken with --gpus)
         r = subprocess.run([cli, "count", "-m", "21", "-s", "1M", "-o", out] + bad + [inp], capture_output=True)
         assert r.returncode != 0 and b"--gpus" in r.stderr
 
